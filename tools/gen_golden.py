@@ -1,0 +1,248 @@
+"""Generate tests/golden/*.npz by EXECUTING THE REFERENCE's own functions in this container.
+
+Run from the repo root:  python tools/gen_golden.py
+Needs /root/reference (read-only).  The fixtures hold seeds/small inputs and the reference's
+outputs; they are data, not source.  The same script cross-checks the oracle restatement
+(oracle/attnshift_oracle.py) against every fixture as it writes it and prints the max errors.
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+import ref_import  # noqa: E402
+import attnshift_oracle as O  # noqa: E402
+from attentionshift_amd import synthetic  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+torch.set_grad_enabled(False)
+
+
+def npy(t):
+    return t.detach().cpu().numpy() if torch.is_tensor(t) else np.asarray(t)
+
+
+def report(name, ref, mine, exact=False):
+    ref, mine = npy(ref), npy(mine)
+    if ref.shape != mine.shape:
+        print(f"   !! {name}: shape {ref.shape} vs {mine.shape}")
+        return
+    if exact or ref.dtype.kind in "iub":
+        bad = int((ref != mine).sum())
+        print(f"   {name}: exact mismatches {bad}/{ref.size}")
+    else:
+        d = np.abs(ref.astype(np.float64) - mine.astype(np.float64)).max() if ref.size else 0.0
+        s = np.abs(ref).max() if ref.size else 0.0
+        print(f"   {name}: max|d|={d:.3e} (max|ref|={s:.3e})")
+
+
+# ----------------------------------------------------------------------------------------------
+def backbone_case(tag, cfg, img_hw, store_attn_layers, cam_layer):
+    vt, det = ref_import.load_backbone()
+    model = det.VisionTransformerDet(
+        img_size=cfg["img_size"], patch_size=16, embed_dim=cfg["embed_dim"], depth=cfg["depth"],
+        num_heads=cfg["num_heads"], mlp_ratio=4., qkv_bias=True, drop_path_rate=0.,
+        out_indices=cfg["out_indices"], last_feat=True, point_tokens_num=cfg["point_tokens_num"],
+        num_classes=cfg["num_classes"], return_attention=True)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sd = synthetic.det_state_dict(shapes)
+    model.load_state_dict(sd)
+    model.eval()
+    img = synthetic.images(cfg["batch"], img_hw[0], img_hw[1], seed=cfg["seed"])
+    t0 = time.time()
+    out = model(img)
+    t_ref = time.time() - t0
+    T = cfg["point_tokens_num"]
+    ns = ref_import.load_roi_functions()
+    roll = ns["attns_project_to_feature"](out["attns"][-cam_layer:])       # [B,Lc,N,N]
+    roll_rows = roll[:, :, -T:, :]
+
+    mine = O.backbone_forward(img, sd, patch_size=16, depth=cfg["depth"], num_heads=cfg["num_heads"],
+                              out_indices=cfg["out_indices"], point_tokens_num=T)
+    print(f"[{tag}] reference forward {t_ref:.2f}s")
+    for k in ("last_feat", "point_tokens", "outputs_class", "outputs_coord", "org_feats"):
+        report(k, out[k], mine[k])
+    for i in range(len(out["feature"])):
+        report(f"feature[{i}]", out["feature"][i], mine["feature"][i])
+    for l in store_attn_layers:
+        report(f"attn[{l}]", out["attns"][l], mine["attns"][l])
+    report("rollout_rows", roll_rows, O.rollout_rows(mine["attns"][-cam_layer:], T))
+    report("rollout_full", roll, O.rollout_full(mine["attns"][-cam_layer:]))
+
+    save = dict(cfg_embed_dim=cfg["embed_dim"], cfg_depth=cfg["depth"], cfg_num_heads=cfg["num_heads"],
+                cfg_img_size=cfg["img_size"], cfg_point_tokens_num=T, cfg_num_classes=cfg["num_classes"],
+                cfg_out_indices=np.array(cfg["out_indices"]), cfg_batch=cfg["batch"], cfg_seed=cfg["seed"],
+                cfg_cam_layer=cam_layer, img_hw=np.array(img_hw), ref_seconds=t_ref,
+                param_names=np.array(list(shapes.keys())),
+                param_shapes=np.array([",".join(map(str, s)) for s in shapes.values()]),
+                last_feat=npy(out["last_feat"]), point_tokens=npy(out["point_tokens"]),
+                outputs_class=npy(out["outputs_class"]), outputs_coord=npy(out["outputs_coord"]),
+                rollout_rows=npy(roll_rows))
+    for i in range(len(out["feature"])):
+        f = out["feature"][i]                      # big FPN maps: keep a strided subsample
+        st = max(1, f.shape[-1] // 14)
+        save[f"feature{i}"] = npy(f[:, :, ::st, ::st])
+        save[f"feature{i}_stride"] = st
+    for l in store_attn_layers:
+        save[f"attn{l}"] = npy(out["attns"][l])
+    np.savez_compressed(os.path.join(OUT, f"backbone_{tag}.npz"), **save)
+
+
+# ----------------------------------------------------------------------------------------------
+class _Dummy:
+    pass
+
+
+def shift_case(tag, seed, hp, wp, C, G, Lc, n_shift, pos_thr=0.35, neg_thr=0.8, obj_tau=0.9,
+               num_gt=10, corr_size=21, num_semantic_points=5, cam_thr=0.2, area_ratio=0.5):
+    ns = ref_import.load_roi_functions()
+    inp = synthetic.shift_inputs(seed, hp, wp, C, G, Lc)
+    H, W = hp * 16, wp * 16
+    feat, cams_lr, points = inp["vit_feat"], inp["cams"], inp["points"]
+    save = dict(seed=seed, hp=hp, wp=wp, C=C, G=G, Lc=Lc, n_shift=n_shift, pos_thr=pos_thr,
+                neg_thr=neg_thr, obj_tau=obj_tau, num_gt=num_gt, corr_size=corr_size,
+                num_semantic_points=num_semantic_points, cam_thr=cam_thr, area_ratio=area_ratio)
+    print(f"[{tag}] Hp={hp} Wp={wp} C={C} G={G} Lc={Lc} S={n_shift}")
+
+    # ---- B1: upsample + CAM boxes (stdroi:2272-2294) -----------------------------------------
+    cams = F.interpolate(cams_lr.reshape(-1, 1, hp, wp), (H, W), mode="bilinear").reshape(Lc, G, H, W)
+    t0 = time.time()
+    boxes = torch.zeros(G, Lc, 4)
+    kept_area = np.zeros((G, Lc), dtype=np.int64)
+    for l in range(Lc):
+        for g in range(G):
+            b, kept = ns["get_bbox_from_cam_fast"](cams[l, g].clone(), points[g].clone(), cam_thr=cam_thr,
+                                                   area_ratio=area_ratio, img_size=(H, W))
+            boxes[g, l] = b[0]
+            kept_area[g, l] = int(kept.sum())
+    save.update(ref_boxes=npy(boxes), ref_kept_area=kept_area, t_boxes=time.time() - t0)
+    my_boxes, my_cams = O.cam_boxes_from_rollout(cams_lr, points, cam_thr, area_ratio)
+    report("B1 upsampled cams", cams, my_cams, exact=True)
+    report("B1 boxes", boxes, my_boxes, exact=True)
+
+    # the MIL head (out of scope) would choose one layer per object: fixed choice for the fixture
+    best = torch.tensor([(g * 2 + 1) % Lc for g in range(G)])
+    rois = boxes[torch.arange(G), best]
+    save.update(best_idx=npy(best), rois=npy(rois))
+
+    # ---- B2 + B2': refinement maps + mask points (stdroi:1966-1993) --------------------------
+    dummy = _Dummy()
+    torch.manual_seed(seed + 1)
+    t0 = time.time()
+    (coords, labels, map_fg, map_bg, pts_a, pts_b, f_fg, f_bg) = ns[
+        "get_mask_sample_points_roi_best_attn_feat_refine"](
+        dummy, cams, rois, best, vit_feat=feat.clone(), pos_thr=pos_thr, neg_thr=neg_thr,
+        num_gt=num_gt, obj_tau=obj_tau, gt_points=points)
+    save["t_refine"] = time.time() - t0
+    # reference return order: (..., points_fg(cat supp) , points_bg, ...) under swapped names
+    points_fg, points_bg = pts_a, pts_b
+    sub = 4
+    save.update(points_fg=npy(points_fg), points_bg=npy(points_bg), mask_coords=npy(coords),
+                mask_labels=npy(labels), map_fg_last=npy(map_fg[-1]), map_bg_last=npy(map_bg[-1]),
+                map_fg_sub=npy(map_fg[:, :, ::sub, ::sub]), map_bg_sub=npy(map_bg[:, :, ::sub, ::sub]),
+                fg_feat=npy(f_fg).reshape(f_fg.shape[0], -1), bg_feat=npy(f_bg).reshape(f_bg.shape[0], -1))
+
+    torch.manual_seed(seed + 1)
+    attn_sel = cams[best, torch.arange(G)]
+    my_fg_pts, my_bg_pts = O.sample_refine_inputs(attn_sel, points)
+    report("B2 sampled fg points", points_fg, my_fg_pts, exact=True)
+    report("B2 sampled bg points", points_bg, my_bg_pts, exact=True)
+    m_fg, m_bg, m_ffg, m_fbg = O.cosine_refined_maps(attn_sel, feat, rois, my_fg_pts, my_bg_pts, 2, obj_tau)
+    report("B2 map_fg", map_fg, m_fg)
+    report("B2 map_bg", map_bg, m_bg)
+    report("B2 fg_feat", f_fg.flatten(1), m_ffg)
+    report("B2 bg_feat", f_bg.flatten(1), m_fbg)
+    # stage-wise pinning: every later oracle stage is fed the REFERENCE's output of the stage before
+    torch.manual_seed(seed + 1)
+    O.sample_refine_inputs(attn_sel, points)            # consume the same draws as the reference did
+    my_coords, my_labels = O.mask_sample_points(map_fg[-1], map_bg[-1], rois, pos_thr, neg_thr, num_gt, corr_size)
+    report("B2' mask coords", coords, my_coords, exact=True)
+    report("B2' mask labels", labels, my_labels, exact=True)
+
+    # ---- B3..B5: semantic centres (stdroi:1995-2031) ------------------------------------------
+    trace = []
+    orig_ud = ns["update_density_batch"]
+
+    def spy(prot, feats, mask_weight):
+        tau = orig_ud(prot, feats, mask_weight)
+        trace.append((mask_weight.argmax(1).clone(), mask_weight.sum(-1).clone(), tau[..., 0].clone(), prot.clone()))
+        return tau
+
+    ns["update_density_batch"] = spy
+    gt_labels = inp["labels"]
+    t0 = time.time()
+    fg_inter_ref = None
+    res = ns["get_semantic_centers"](dummy_with(ns), map_fg[-1].clone(), map_bg[-1].clone(), rois, feat.clone(),
+                                     pos_thr=pos_thr, refine_times=n_shift, gt_labels=gt_labels,
+                                     num_semantic_points=num_semantic_points)
+    save["t_semantic"] = time.time() - t0
+    (centers, centers_split, sim_parts, feat_split, feats_all, num_parts, coords_org, labels_org, corres) = res
+    ref_trace = list(trace)
+    # the prototypes / sim maps before filtering are internal: re-run that stage alone
+    trace.clear()
+    fg_inter, bg_inter, fg_bin = O.semantic_prestage(map_fg[-1], map_bg[-1], (hp, wp), pos_thr)
+    prot_ref, sim_ref = ns["mean_shift_grid_prototype"](dummy_with(ns), fg_bin, feat, rois, tau=0.1, temp=0.1, n_shift=n_shift)
+    ns["update_density_batch"] = orig_ud
+    save.update(ref_prot=npy(prot_ref), ref_sim=npy(sim_ref),
+                ref_assign=np.stack([npy(t[0]) for t in ref_trace]).astype(np.int32),
+                ref_count=np.stack([npy(t[1]) for t in ref_trace]),
+                ref_tau=np.stack([npy(t[2]) for t in ref_trace]),
+                ref_prot_iters=np.stack([npy(t[3]) for t in ref_trace]),
+                centers=npy(centers[0]), centers_labels=npy(centers[1]), num_parts=np.array(num_parts),
+                coords_org=npy(coords_org), labels_org=npy(labels_org), corres_gt=npy(corres),
+                feats_all=npy(feats_all) if torch.is_tensor(feats_all) else np.zeros((0, C), np.float32),
+                n_sim_parts=np.array([int(s.shape[0]) for s in sim_parts]))
+    for g, s in enumerate(sim_parts):
+        save[f"sim_parts{g}"] = npy(s)
+
+    my_trace = []
+    mine = O.semantic_centers(map_fg[-1], map_bg[-1], rois, feat, pos_thr, n_shift, gt_labels,
+                              num_semantic_points=num_semantic_points, trace=my_trace)
+    report("B3 fg_inter (vs own prestage on ref maps)", fg_inter, mine["fg_inter"])
+    report("B4 prototypes", prot_ref, mine["prot"])
+    report("B4 sim", sim_ref, mine["sim"])
+    for it, (a, tau) in enumerate(my_trace):
+        report(f"B4 assign it{it}", ref_trace[it][0], a, exact=True)
+        report(f"B4 tau it{it}", ref_trace[it][2], tau)
+    report("B5 num_parts", np.array(num_parts), np.array(mine["num_parts"]), exact=True)
+    report("B5 coords_org", coords_org, mine["coords_org"])
+    report("B5 corres_gt", corres, mine["corres_gt"], exact=True)
+    if torch.is_tensor(feats_all):
+        report("B5 feats", feats_all, mine["feats"])
+    for g, s in enumerate(sim_parts):
+        report(f"B5 sim_parts[{g}]", s, mine["sim_parts"][g])
+    report("B6 pseudo masks", (map_fg[-1] > map_fg[-1].flatten(1).max(1)[0][:, None, None] * pos_thr).to(torch.uint8),
+           O.pseudo_masks(m_fg[-1], pos_thr), exact=True)
+    np.savez_compressed(os.path.join(OUT, f"shift_{tag}.npz"), **save)
+
+
+def dummy_with(ns):
+    d = _Dummy()
+    import types
+    d.mean_shift_grid_prototype = types.MethodType(ns["mean_shift_grid_prototype"], d)
+    return d
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    assert ref_import.reference_available(), "needs /root/reference"
+    backbone_case("small", dict(img_size=64, embed_dim=128, depth=4, num_heads=2, out_indices=(0, 1, 2, 3),
+                                point_tokens_num=10, num_classes=5, batch=2, seed=3), (96, 80), (0, 3), 3)
+    backbone_case("tiny224", dict(img_size=224, embed_dim=192, depth=12, num_heads=3, out_indices=(3, 5, 7, 11),
+                                  point_tokens_num=100, num_classes=20, batch=1, seed=0), (224, 224), (11,), 7)
+    shift_case("tiny224", seed=1234, hp=14, wp=14, C=192, G=3, Lc=7, n_shift=3)
+    shift_case("mid320", seed=77, hp=20, wp=20, C=96, G=3, Lc=3, n_shift=5)
+    tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
+    print(f"fixtures total {tot / 1e6:.2f} MB")
+
+
+if __name__ == "__main__":
+    main()
