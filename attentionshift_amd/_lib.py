@@ -1,0 +1,67 @@
+"""ctypes binding of libattnshift_hip.so (the C ABI declared in include/attnshift.h).
+
+There is NO fallback: if the library is missing or a call fails the product path raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libattnshift_hip.so")
+
+AS_F32, AS_BF16 = 0, 1
+
+_c_void_p, _c_int, _c_float, _c_size_t = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
+
+# name -> (restype, argtypes); every symbol include/attnshift.h declares
+SIGNATURES = {
+    "as_version": (_c_int, []),
+    "as_last_error": (ctypes.c_char_p, []),
+    "as_npad": (_c_int, [_c_int]),
+    "as_linear_fwd": (_c_int, [_c_void_p] * 4 + [_c_int] * 5 + [_c_void_p]),
+    "as_qkv_fwd": (_c_int, [_c_void_p] * 6 + [_c_int] * 5 + [_c_void_p]),
+    "as_sdpa_fwd": (_c_int, [_c_void_p] * 5 + [_c_int] * 4 + [_c_void_p]),
+    "as_attn_fwd": (_c_int, [_c_void_p] * 11 + [_c_int] * 5 + [_c_void_p]),
+    "as_attn_mean_rows": (_c_int, [_c_void_p] * 4 + [_c_int] * 6 + [_c_void_p]),
+    "as_rollout_top": (_c_int, [_c_void_p] * 4 + [_c_int] * 5 + [_c_void_p]),
+    "as_rollout_step": (_c_int, [_c_void_p] * 5 + [_c_int] * 5 + [_c_void_p]),
+    "as_ccl_2d": (_c_int, [_c_void_p] * 2 + [_c_int] * 3 + [_c_void_p]),
+    "as_cam_boxes_workspace_bytes": (_c_size_t, [_c_int] * 4),
+    "as_cam_boxes": (_c_int, [_c_void_p] * 2 + [_c_float] * 2 + [_c_int] * 4 + [_c_void_p] * 4 + [_c_size_t, _c_void_p]),
+    "as_cosine_shift_workspace_bytes": (_c_size_t, [_c_int] * 6),
+    "as_cosine_shift": (_c_int, [_c_void_p] * 4 + [_c_float] * 2 + [_c_int] + [_c_void_p] * 4 + [_c_size_t]
+                        + [_c_int] * 6 + [_c_void_p]),
+    "as_refine_similarity_workspace_bytes": (_c_size_t, [_c_int] * 3),
+    "as_refine_similarity": (_c_int, [_c_void_p] * 3 + [_c_int] * 3 + [_c_float, _c_int] + [_c_void_p] * 3
+                             + [_c_size_t] + [_c_int] * 3 + [_c_void_p]),
+    "as_instance_maps_workspace_bytes": (_c_size_t, [_c_int] * 2),
+    "as_instance_maps": (_c_int, [_c_void_p] * 2 + [_c_int] * 6 + [_c_void_p] * 3 + [_c_size_t, _c_void_p]),
+}
+
+_lib = None
+
+
+class AttnShiftError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library once; raise loudly if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise AttnShiftError(
+            f"{LIB_PATH} is missing: build it with `python -m attentionshift_amd.csrc.build` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the hot path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().as_last_error()
+        raise AttnShiftError(f"{what} failed (rc={rc}): {msg.decode() if msg else ''}")

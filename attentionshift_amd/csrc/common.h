@@ -1,0 +1,101 @@
+// Shared device/host helpers for libattnshift_hip.so (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/attnshift.h"
+
+// ---------------------------------------------------------------------------------------------
+// error plumbing: never throw / exit across the C boundary
+// ---------------------------------------------------------------------------------------------
+void as_set_error(const char* fmt, ...);
+
+#define AS_REQUIRE(cond, code, ...)            \
+  do {                                         \
+    if (!(cond)) {                             \
+      as_set_error(__VA_ARGS__);               \
+      return (code);                           \
+    }                                          \
+  } while (0)
+
+#define AS_CHECK_LAUNCH(what)                                                        \
+  do {                                                                               \
+    hipError_t e_ = hipGetLastError();                                               \
+    if (e_ != hipSuccess) {                                                          \
+      as_set_error("%s: launch failed: %s", (what), hipGetErrorString(e_));          \
+      return AS_E_LAUNCH;                                                            \
+    }                                                                                \
+  } while (0)
+
+static inline int as_ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline int as_round_up(int a, int b) { return as_ceil_div(a, b) * b; }
+
+// ---------------------------------------------------------------------------------------------
+// MFMA fragments.  One "k16 step" of a 32x32 tile: lane l = (i = l & 31, half = l >> 5) holds the 8
+// consecutive k elements k0 + 8*half .. +7 of row i (A) / column i (B).  C/D: col = l & 31,
+// row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5) for accumulator register r (guide section 3).
+//   bf16 : one v_mfma_f32_32x32x16_bf16
+//   f32  : eight v_mfma_f32_32x32x2_f32 (exact fp32 FMA chains, k-ordered), MFMA t contracts the
+//          k pair {element t of half 0, element t of half 1}
+// ---------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+
+#ifdef __HIPCC__
+template <typename T> struct Frag;
+
+template <> struct Frag<__bf16> {
+  bf16x8 v;
+  __device__ __forceinline__ void load16B(const __bf16* p) { v = *reinterpret_cast<const bf16x8*>(p); }
+  __device__ __forceinline__ void zero() {
+    for (int t = 0; t < 8; ++t) v[t] = (__bf16)0.0f;
+  }
+  __device__ __forceinline__ void set(int t, float x) { v[t] = (__bf16)x; }
+};
+template <> struct Frag<float> {
+  float v[8];
+  __device__ __forceinline__ void load16B(const float* p) {   // 32 bytes actually: 8 floats
+    const float4 a = *reinterpret_cast<const float4*>(p);
+    const float4 b = *reinterpret_cast<const float4*>(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  }
+  __device__ __forceinline__ void zero() {
+    for (int t = 0; t < 8; ++t) v[t] = 0.0f;
+  }
+  __device__ __forceinline__ void set(int t, float x) { v[t] = x; }
+};
+
+__device__ __forceinline__ f32x16 mma32(const Frag<__bf16>& a, const Frag<__bf16>& b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mma32(const Frag<float>& a, const Frag<float>& b, f32x16 c) {
+#pragma unroll
+  for (int t = 0; t < 8; ++t) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[t], b.v[t], c, 0, 0, 0);
+  return c;
+}
+
+// accumulator register r of a lane in half `half` -> row inside the 32x32 tile
+__device__ __forceinline__ int acc_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+
+template <typename T> __device__ __forceinline__ float to_f32(T x);
+template <> __device__ __forceinline__ float to_f32<float>(float x) { return x; }
+template <> __device__ __forceinline__ float to_f32<__bf16>(__bf16 x) { return (float)x; }
+template <typename T> __device__ __forceinline__ T from_f32(float x);
+template <> __device__ __forceinline__ float from_f32<float>(float x) { return x; }
+template <> __device__ __forceinline__ __bf16 from_f32<__bf16>(float x) { return (__bf16)x; }
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+#endif

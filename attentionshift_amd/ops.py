@@ -1,0 +1,232 @@
+"""Torch-tensor wrappers over the C ABI (include/attnshift.h).
+
+PyTorch is plumbing here: device memory, the current HIP stream, autograd bookkeeping.  Every
+function validates device/dtype/contiguity, passes raw pointers and raises on any non-zero return.
+"""
+import torch
+
+from . import _lib
+from ._lib import AS_BF16, AS_F32, AttnShiftError
+
+HEAD_DIM = 64
+
+
+def _dt(t):
+    if t.dtype == torch.float32:
+        return AS_F32
+    if t.dtype == torch.bfloat16:
+        return AS_BF16
+    raise AttnShiftError(f"unsupported dtype {t.dtype} (float32 or bfloat16)")
+
+
+def _chk(*tensors, dtype=None):
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise AttnShiftError("hot-path ops need device (HBM) tensors; there is no CPU fallback")
+        if not t.is_contiguous():
+            raise AttnShiftError("hot-path ops need contiguous row-major tensors")
+        if dtype is not None and t.dtype != dtype:
+            raise AttnShiftError(f"expected {dtype}, got {t.dtype}")
+
+
+def _p(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def npad(n):
+    return _lib.load().as_npad(int(n))
+
+
+# ------------------------------------------------------------------------------------------------
+# Part A
+# ------------------------------------------------------------------------------------------------
+def linear(x, weight, bias=None, act="none"):
+    """act(x @ weight.T + bias); x [..., K] in fp32/bf16, bias fp32."""
+    lib = _lib.load()
+    K = x.shape[-1]
+    x2 = x.reshape(-1, K)
+    _chk(x2, weight)
+    if bias is not None:
+        _chk(bias, dtype=torch.float32)
+    if weight.dtype != x.dtype or weight.shape[1] != K:
+        raise AttnShiftError("linear: weight must be [Nout, K] in the dtype of x")
+    out = torch.empty(x2.shape[0], weight.shape[0], device=x.device, dtype=x.dtype)
+    _lib.check(lib.as_linear_fwd(_p(x2), _p(weight), _p(bias), _p(out), x2.shape[0], weight.shape[0], K, _dt(x),
+                                 1 if act == "gelu" else 0, _stream()), "as_linear_fwd")
+    return out.reshape(*x.shape[:-1], weight.shape[0])
+
+
+class AttnLayerState:
+    """What a layer must keep so its attention rows can be recomputed (q, k, lse)."""
+
+    __slots__ = ("q", "k", "vt", "lse", "B", "N", "h", "dtype")
+
+    def __init__(self, q, k, vt, lse, B, N, h, dtype):
+        self.q, self.k, self.vt, self.lse, self.B, self.N, self.h, self.dtype = q, k, vt, lse, B, N, h, dtype
+
+
+def attention_fwd(x, w_qkv, b_qkv, w_proj, b_proj, num_heads, keep_state=True):
+    """Attention.forward (reference models/vision_transformer.py:74-86) -> (out [B,N,D], AttnLayerState)."""
+    lib = _lib.load()
+    B, N, D = x.shape
+    _chk(x, w_qkv, w_proj)
+    if D != num_heads * HEAD_DIM:
+        raise AttnShiftError(f"head dim must be {HEAD_DIM} (D={D}, heads={num_heads})")
+    Np_ = npad(N)
+    dev, dt = x.device, x.dtype
+    q = torch.empty(B, num_heads, Np_, HEAD_DIM, device=dev, dtype=dt)
+    k = torch.empty_like(q)
+    vt = torch.empty(B, num_heads, HEAD_DIM, Np_, device=dev, dtype=dt)
+    o = torch.empty(B, N, D, device=dev, dtype=dt)
+    out = torch.empty(B, N, D, device=dev, dtype=dt)
+    lse = torch.empty(B, num_heads, N, device=dev, dtype=torch.float32)
+    _lib.check(lib.as_attn_fwd(_p(x), _p(w_qkv), _p(b_qkv), _p(w_proj), _p(b_proj), _p(out), _p(lse), _p(q), _p(k),
+                               _p(vt), _p(o), B, N, D, num_heads, _dt(x), _stream()), "as_attn_fwd")
+    return out, (AttnLayerState(q, k, vt, lse, B, N, num_heads, dt) if keep_state else None)
+
+
+def qkv_fwd(x, w_qkv, b_qkv, num_heads):
+    lib = _lib.load()
+    B, N, D = x.shape
+    _chk(x, w_qkv)
+    Np_ = npad(N)
+    q = torch.empty(B, num_heads, Np_, HEAD_DIM, device=x.device, dtype=x.dtype)
+    k = torch.empty_like(q)
+    vt = torch.empty(B, num_heads, HEAD_DIM, Np_, device=x.device, dtype=x.dtype)
+    _lib.check(lib.as_qkv_fwd(_p(x), _p(w_qkv), _p(b_qkv), _p(q), _p(k), _p(vt), B, N, D, num_heads, _dt(x), _stream()),
+               "as_qkv_fwd")
+    return q, k, vt
+
+
+def sdpa_fwd(q, k, vt, N):
+    lib = _lib.load()
+    B, h = q.shape[0], q.shape[1]
+    _chk(q, k, vt)
+    o = torch.empty(B, N, h * HEAD_DIM, device=q.device, dtype=q.dtype)
+    lse = torch.empty(B, h, N, device=q.device, dtype=torch.float32)
+    _lib.check(lib.as_sdpa_fwd(_p(q), _p(k), _p(vt), _p(o), _p(lse), B, N, h, _dt(q), _stream()), "as_sdpa_fwd")
+    return o, lse
+
+
+def attn_mean_rows(state, row0, nrows):
+    """Head-mean softmax rows [B,nrows,N] fp32 recomputed from (q,k,lse)."""
+    lib = _lib.load()
+    out = torch.empty(state.B, nrows, state.N, device=state.q.device, dtype=torch.float32)
+    _lib.check(lib.as_attn_mean_rows(_p(state.q), _p(state.k), _p(state.lse), _p(out), state.B, state.N, state.h,
+                                     int(row0), int(nrows), _dt(state.q), _stream()), "as_attn_mean_rows")
+    return out
+
+
+def rollout_rows(states, num_point_tokens):
+    """Row-sliced attention roll-out over `states` (ordered bottom -> top, as the reference's
+    attns[-cam_layer:]).  Returns [B, Lc, T, N] fp32; index k = product of the top k+1 layers
+    (reference stdroi:1257-1272 + the row slice of :2272)."""
+    lib = _lib.load()
+    top = states[-1]
+    T = int(num_point_tokens)
+    outs = []
+    R = torch.empty(top.B, T, top.N, device=top.q.device, dtype=torch.float32)
+    _lib.check(lib.as_rollout_top(_p(top.q), _p(top.k), _p(top.lse), _p(R), top.B, top.N, top.h, T, _dt(top.q), _stream()),
+               "as_rollout_top")
+    outs.append(R)
+    for st in reversed(states[:-1]):
+        Rn = torch.empty_like(R)
+        _lib.check(lib.as_rollout_step(_p(st.q), _p(st.k), _p(st.lse), _p(R), _p(Rn), st.B, st.N, st.h, T, _dt(st.q),
+                                       _stream()), "as_rollout_step")
+        outs.append(Rn)
+        R = Rn
+    return torch.stack(outs, dim=1)
+
+
+# ------------------------------------------------------------------------------------------------
+# Part B
+# ------------------------------------------------------------------------------------------------
+def ccl_2d(binary):
+    """binary uint8 [M,H,W] (or [H,W]) -> int32 labels, 8-connectivity, label = 1 + min raster index."""
+    lib = _lib.load()
+    squeeze = binary.dim() == 2
+    img = binary[None] if squeeze else binary
+    _chk(img, dtype=torch.uint8)
+    M, H, W = img.shape
+    labels = torch.empty(M, H, W, device=img.device, dtype=torch.int32)
+    _lib.check(lib.as_ccl_2d(_p(img), _p(labels), M, H, W, _stream()), "as_ccl_2d")
+    return labels[0] if squeeze else labels
+
+
+def cam_boxes(cams, points, cam_thr, area_ratio, up=16, return_upsampled=False):
+    """cams [M,Hp,Wp] fp32, points [M,2] -> boxes [M,4], kept-pixel counts [M] (int32), optional [M,H,W]."""
+    lib = _lib.load()
+    _chk(cams, points, dtype=torch.float32)
+    M, Hp, Wp = cams.shape
+    boxes = torch.empty(M, 4, device=cams.device, dtype=torch.float32)
+    status = torch.empty(M, device=cams.device, dtype=torch.int32)
+    cams_up = torch.empty(M, Hp * up, Wp * up, device=cams.device, dtype=torch.float32) if return_upsampled else None
+    nbytes = lib.as_cam_boxes_workspace_bytes(M, Hp, Wp, up)
+    ws = torch.empty(nbytes, device=cams.device, dtype=torch.uint8)
+    _lib.check(lib.as_cam_boxes(_p(cams), _p(points), float(cam_thr), float(area_ratio), M, Hp, Wp, up, _p(boxes),
+                                _p(status), _p(cams_up), _p(ws), nbytes, _stream()), "as_cam_boxes")
+    return (boxes, status, cams_up) if return_upsampled else (boxes, status)
+
+
+def cosine_shift(feat, box_patch, obj_img, prot, n_shift, hp, wp, tau0=0.1, temp=0.1, return_trace=False):
+    """feat [B,Np,C] fp32 token-major; box_patch [G,4] int32; obj_img [G] int32; prot [G,P,C] (seeds).
+    Returns (prot_out [G,P,C], sim [G,P,Np]) and, with return_trace, (assign [S,G,Np], tau [S,G,P])."""
+    lib = _lib.load()
+    _chk(feat, prot, dtype=torch.float32)
+    _chk(box_patch, obj_img, dtype=torch.int32)
+    B, Np_, C = feat.shape
+    G, P, _ = prot.shape
+    if Np_ != hp * wp:
+        raise AttnShiftError("cosine_shift: Np != hp*wp")
+    prot = prot.clone()
+    sim = torch.empty(G, P, Np_, device=feat.device, dtype=torch.float32)
+    assign = torch.empty(max(n_shift, 1), G, Np_, device=feat.device, dtype=torch.int32) if return_trace else None
+    tau = torch.empty(max(n_shift, 1), G, P, device=feat.device, dtype=torch.float32) if return_trace else None
+    nbytes = lib.as_cosine_shift_workspace_bytes(B, C, hp, wp, G, P)
+    ws = torch.empty(nbytes, device=feat.device, dtype=torch.uint8)
+    _lib.check(lib.as_cosine_shift(_p(feat), _p(box_patch), _p(obj_img), _p(prot), float(tau0), float(temp), int(n_shift),
+                                   _p(sim), _p(assign), _p(tau), _p(ws), nbytes, B, C, hp, wp, G, P, _stream()),
+               "as_cosine_shift")
+    if return_trace:
+        return prot, sim, assign[:n_shift], tau[:n_shift]
+    return prot, sim
+
+
+def refine_similarity(feat, seeds, boxes_patch, num_obj, refine_times, tau, is_select, hp, wp):
+    """feat [Np,C], seeds [Gp,C], boxes_patch [G,4] int32 -> (maps [R+1,Gp,Np], seeds_out [Gp,C])."""
+    lib = _lib.load()
+    _chk(feat, seeds, dtype=torch.float32)
+    if boxes_patch is not None:
+        _chk(boxes_patch, dtype=torch.int32)
+    Np_, C = feat.shape
+    Gp = seeds.shape[0]
+    maps = torch.empty(refine_times + 1, Gp, Np_, device=feat.device, dtype=torch.float32)
+    seeds_out = torch.empty(Gp, C, device=feat.device, dtype=torch.float32)
+    nbytes = lib.as_refine_similarity_workspace_bytes(C, Np_, Gp)
+    ws = torch.empty(nbytes, device=feat.device, dtype=torch.uint8)
+    _lib.check(lib.as_refine_similarity(_p(feat), _p(seeds), _p(boxes_patch), int(num_obj), Gp, int(refine_times),
+                                        float(tau), 1 if is_select else 0, _p(maps), _p(seeds_out), _p(ws), nbytes, C,
+                                        hp, wp, _stream()), "as_refine_similarity")
+    return maps, seeds_out
+
+
+def instance_maps(sim_fg, sim_bg, num_obj, hp, wp, up=16):
+    """sim_fg [L,Gp,Np], sim_bg [L,G,Np] -> map_fg, map_bg [L,G,H,W] (stdroi:1010-1019)."""
+    lib = _lib.load()
+    _chk(sim_fg, sim_bg, dtype=torch.float32)
+    L, Gp, _ = sim_fg.shape
+    G = int(num_obj)
+    H, W = hp * up, wp * up
+    map_fg = torch.empty(L, G, H, W, device=sim_fg.device, dtype=torch.float32)
+    map_bg = torch.empty(L, G, H, W, device=sim_fg.device, dtype=torch.float32)
+    nbytes = lib.as_instance_maps_workspace_bytes(L, G)
+    ws = torch.empty(nbytes, device=sim_fg.device, dtype=torch.uint8)
+    _lib.check(lib.as_instance_maps(_p(sim_fg), _p(sim_bg), L, G, Gp, hp, wp, up, _p(map_fg), _p(map_bg), _p(ws), nbytes,
+                                    _stream()), "as_instance_maps")
+    return map_fg, map_bg

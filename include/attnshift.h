@@ -1,0 +1,144 @@
+/* libattnshift_hip.so -- C ABI of the MI355X (gfx950) hot path of AttentionShift.
+ *
+ * The reference is Python on PyTorch; its only native boundary on this path is
+ *   cc_torch.connected_components_labeling(uint8 [H,W]) -> int32 [H,W]
+ *   (mmdet/models/roi_heads/stdroi_point_deform_attn_reppoints.py:23,68  -- source absent upstream)
+ * Every other entry point below replaces a run of ATen calls inside one reference function
+ * (cited per function, paths relative to the reference root, `stdroi` = the file above).
+ *
+ * Conventions
+ *   - return 0 (AS_OK) on success, a negative AS_E_* otherwise; as_last_error() gives the message
+ *     (thread-local).  Never throws, never exits.
+ *   - all pointers are DEVICE pointers (HBM) unless stated; contiguous row-major layouts only.
+ *   - no ownership transfer: inputs, outputs and workspaces are caller-allocated
+ *     (sizes through as_*_workspace_bytes); workspaces need no initialisation.
+ *   - asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream); re-entrant;
+ *     no global mutable state.
+ *   - dtype: AS_F32 = exact fp32 MFMA path (parity), AS_BF16 = bf16 operands with fp32 accumulate.
+ *     Biases, log-sum-exp, roll-out matrices and all of Part B are always fp32; indices int32.
+ */
+#ifndef ATTNSHIFT_H
+#define ATTNSHIFT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AS_VERSION 100
+#define AS_OK 0
+#define AS_E_BADARG (-1)
+#define AS_E_UNSUPPORTED (-2)
+#define AS_E_LAUNCH (-3)
+#define AS_E_WORKSPACE (-4)
+
+#define AS_F32 0
+#define AS_BF16 1
+
+#define AS_HEAD_DIM 64 /* every ViT in the reference has D/h = 64 (models/vision_transformer.py:266-288) */
+
+typedef void* as_stream_t;
+
+int as_version(void);
+const char* as_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Part A -- backbone attention (models/vision_transformer.py:62-124)
+ * ------------------------------------------------------------------------------------------- */
+
+/* padded token count used by the q/k/v workspaces: N rounded up to a multiple of 64 */
+int as_npad(int N);
+
+/* out[M,Nout] = act(x[M,K] . W[Nout,K]^T + bias[Nout])           nn.Linear (vision_transformer.py:47-59,
+ * 84).  x,W,out in `dtype`; bias fp32 or NULL; act 0 = none, 1 = exact (erf) GELU.  K % 32 == 0. */
+int as_linear_fwd(const void* x, const void* W, const float* bias, void* out, int M, int Nout, int K,
+                  int dtype, int act, as_stream_t stream);
+
+/* QKV projection with the head split fused into the epilogue (vision_transformer.py:75-77):
+ *   q,k : [B,h,Npad,64]   vt : [B,h,64,Npad]  (V transposed so the P.V MFMA reads keys contiguously)
+ * rows/cols >= N of the padded layouts are never read unmasked, so they need no initialisation. */
+int as_qkv_fwd(const void* x /*[B,N,D]*/, const void* Wqkv /*[3D,D]*/, const float* bqkv /*[3D] or NULL*/,
+               void* q, void* k, void* vt, int B, int N, int D, int h, int dtype, as_stream_t stream);
+
+/* softmax(q k^T / sqrt(64)) v without materialising [h,N,N] (vision_transformer.py:79-83).
+ *   o   : [B,N,h*64] (heads concatenated, ready for proj)        lse : [B,h,N] fp32, natural log */
+int as_sdpa_fwd(const void* q, const void* k, const void* vt, void* o, float* lse, int B, int N, int h,
+                int dtype, as_stream_t stream);
+
+/* Attention.forward = qkv + sdpa + proj (vision_transformer.py:74-86).  q/k/vt/o are workspaces the
+ * caller keeps alive when the roll-out (below) needs this layer; `o` is [B,N,D]. */
+int as_attn_fwd(const void* x, const void* Wqkv, const float* bqkv, const void* Wproj, const float* bproj,
+                void* out /*[B,N,D]*/, float* lse, void* q, void* k, void* vt, void* o, int B, int N, int D,
+                int h, int dtype, as_stream_t stream);
+
+/* Head-mean attention rows, recomputed from q,k,lse (visual_transformer_det.py:236,242 keeps
+ * attn.mean(1) of every layer; only row slices are ever consumed, stdroi:2272):
+ *   out[b,i,:] = (1/h) sum_h softmax_row(row0 + i)          out : [B,nrows,N] fp32 */
+int as_attn_mean_rows(const void* q, const void* k, const float* lse, float* out, int B, int N, int h,
+                      int row0, int nrows, int dtype, as_stream_t stream);
+
+/* One step of the row-sliced attention roll-out (stdroi:1257-1272 attns_project_to_feature):
+ *   A_hat = (mean_h P + I) / rowsum ,  R_out = R_in . A_hat         R : [B,T,N] fp32
+ * with P recomputed tile by tile from q,k,lse of that layer.  The top layer's R is
+ * (as_attn_mean_rows(row0 = N-T) + I_rows) / 2 (as_rollout_top). */
+int as_rollout_top(const void* q, const void* k, const float* lse, float* R_out, int B, int N, int h, int T,
+                   int dtype, as_stream_t stream);
+int as_rollout_step(const void* q, const void* k, const float* lse, const float* R_in, float* R_out, int B,
+                    int N, int h, int T, int dtype, as_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Part B -- attention-shift pseudo-label generator (stdroi:2209-2415), fp32 + int32
+ * ------------------------------------------------------------------------------------------- */
+
+/* 8-connectivity connected components of M binary images; label = 1 + min raster index of the
+ * component, background 0.  Replaces cc_torch.connected_components_labeling (stdroi:68). */
+int as_ccl_2d(const uint8_t* img /*[M,H,W]*/, int32_t* labels /*[M,H,W]*/, int M, int H, int W,
+              as_stream_t stream);
+
+/* CAM -> box (stdroi:2272-2294 + get_bbox_from_cam_fast :60-116), batched over M = Lc*G maps:
+ * bilinear x`up` upsample (align_corners=False), min-max normalise (clamp 1e-6), binarise at
+ * cam_thr, CCL, keep components with area >= area_ratio * max area, tight box, 'expand' about the
+ * point, clip to the image.  boxes [M,4] fp32 (x0,y0,x1,y1); status[m] = number of kept pixels
+ * (0 = the reference would have raised).  cams_up, if not NULL, receives the upsampled maps
+ * [M,H,W] fp32 (the reference keeps them as attn_maps_dealed, stdroi:2282). */
+size_t as_cam_boxes_workspace_bytes(int M, int Hp, int Wp, int up);
+int as_cam_boxes(const float* cams /*[M,Hp,Wp]*/, const float* points /*[M,2] (x,y)*/, float cam_thr,
+                 float area_ratio, int M, int Hp, int Wp, int up, float* boxes, int32_t* status,
+                 float* cams_up, void* ws, size_t ws_bytes, as_stream_t stream);
+
+/* Mean-shift token clustering (stdroi:830-854 cosine_shift_batch + :882-908 update_density_batch,
+ * with the box masking of :1819-1824 folded in):
+ *   feat      [B,Np,C]  token-major ViT features (Np = Hp*Wp)
+ *   box_patch [G,4]     inclusive patch-grid box (x0,y0,x1,y1) of each object = rois // 16
+ *   obj_img   [G]       image index of each object
+ *   prot      [G,P,C]   in: seed prototypes; out: shifted prototypes (unnormalised, as the reference)
+ *   sim_out   [G,P,Np]  cos(prot, UNMASKED feat) (not clamped)
+ *   assign_out[S,G,Np]  (optional) argmax prototype per patch per iteration, ties -> lowest index
+ *   tau_out   [S,G,P]   (optional) per-prototype density after each iteration */
+size_t as_cosine_shift_workspace_bytes(int B, int C, int Hp, int Wp, int G, int P);
+int as_cosine_shift(const float* feat, const int32_t* box_patch, const int32_t* obj_img, float* prot,
+                    float tau0, float temp, int n_shift, float* sim_out, int32_t* assign_out, float* tau_out,
+                    void* ws, size_t ws_bytes, int B, int C, int Hp, int Wp, int G, int P, as_stream_t stream);
+
+/* Cosine-affinity refinement on the patch grid (stdroi:668-707 get_refined_similarity):
+ *   feat   [Np,C] one image, seeds [Gp,C] (mean feature of the sampled points, :335-338)
+ *   boxes  [G,4] inclusive patch boxes of the first G maps (is_select path)
+ *   maps   [R+1,Gp,Np] ;  seeds_out [Gp,C] = refined seed features of the last round */
+size_t as_refine_similarity_workspace_bytes(int C, int Np, int Gp);
+int as_refine_similarity(const float* feat, const float* seeds, const int32_t* boxes, int G, int Gp,
+                         int refine_times, float tau, int is_select, float* maps, float* seeds_out, void* ws,
+                         size_t ws_bytes, int C, int Hp, int Wp, as_stream_t stream);
+
+/* Full-resolution instance maps from the patch-grid refinement (stdroi:1010-1019):
+ * bilinear x`up` of fg/bg levels, (1-bg)*fg, per-map max normalisation, decouple_instance.
+ *   sim_fg [L,Gp,Np] (first G maps used), sim_bg [L,G,Np] -> map_fg, map_bg [L,G,H,W] */
+size_t as_instance_maps_workspace_bytes(int L, int G);
+int as_instance_maps(const float* sim_fg, const float* sim_bg, int L, int G, int Gp, int Hp, int Wp, int up,
+                     float* map_fg, float* map_bg, void* ws, size_t ws_bytes, as_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ATTNSHIFT_H */

@@ -1,0 +1,49 @@
+"""The C-ABI library loads and exports every symbol include/attnshift.h declares (no compute calls:
+this runs without a GPU).  Also checks the argument validation paths that return before any launch."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "attnshift.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(as_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_builds_and_exports_every_declared_symbol():
+    from attentionshift_amd.csrc import build
+    lib_path = build.build(verbose=False)
+    lib = ctypes.CDLL(lib_path)
+    names = declared_symbols()
+    assert len(names) >= 15
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in attnshift.h but not exported"
+    from attentionshift_amd import _lib
+    assert sorted(_lib.SIGNATURES) == names, "ctypes signature table and header disagree"
+    loaded = _lib.load()
+    assert loaded.as_version() == 100
+
+
+def test_bad_arguments_return_error_codes_without_launching():
+    from attentionshift_amd import _lib
+    lib = _lib.load()
+    assert lib.as_npad(4197) == 4224 and lib.as_npad(64) == 64
+    assert lib.as_linear_fwd(None, None, None, None, 1, 1, 32, 0, 0, None) == -1          # AS_E_BADARG
+    assert b"null" in lib.as_last_error()
+    assert lib.as_cosine_shift_workspace_bytes(2, 768, 64, 64, 6, 20) > 0
+    assert lib.as_cosine_shift_workspace_bytes(0, 768, 64, 64, 6, 20) == 0
+    assert lib.as_cam_boxes_workspace_bytes(21, 64, 64, 16) >= 21 * 1024 * 1024 * 8
+    with pytest.raises(_lib.AttnShiftError):
+        _lib.check(-2, "unit test")
+
+
+def test_product_path_refuses_cpu_tensors():
+    import torch
+    from attentionshift_amd import ops
+    with pytest.raises(ops.AttnShiftError):
+        ops.linear(torch.zeros(4, 32), torch.zeros(8, 32))
