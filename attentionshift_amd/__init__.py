@@ -1,0 +1,13 @@
+"""attentionshift_amd -- MI355X (gfx950) native hot path of AttentionShift.
+
+Exposes the reference's plugin surface (mmdet-style registries, same class names / kwargs):
+    BACKBONES: VisionTransformerDet
+    HEADS:     AttnShiftRoIHead (also registered as StandardRoIHeadMaskPointSampleDeformAttnReppoints)
+Compute goes through libattnshift_hip.so (include/attnshift.h); there is no CPU fallback.
+"""
+from .registry import BACKBONES, HEADS, Registry, build_backbone, build_from_cfg, build_head, register_into_mmdet  # noqa: F401
+from .config import Config, ConfigDict  # noqa: F401
+from .backbone import VisionTransformerDet  # noqa: F401
+from .roi_head import AttnShiftRoIHead  # noqa: F401
+
+__version__ = "0.1.0"

@@ -1,0 +1,273 @@
+"""VisionTransformerDet -- MI355X-native MAE-ViT backbone with point tokens.
+
+Mirror of the reference plugin (same registry name, constructor kwargs, state-dict keys and output
+dict) so configs/mae/*.py build it unchanged:
+    reference mmdet/models/backbones/visual_transformer_det.py:60-275 (VisionTransformerDet)
+    reference models/vision_transformer.py:62-124 (Attention, Block), :187-207 (pos-embed resize)
+
+What is different underneath:
+  * Attention runs through the C ABI (QKV GEMM with fused head split -> flash SDPA with wave64 online
+    softmax -> proj GEMM, attentionshift_amd/csrc/{gemm,sdpa}.hip).  The [B,h,N,N] softmax the reference
+    returns from every block is never materialised; `attns` is a list of AttnLayerState handles
+    (q, k, log-sum-exp) from which any head-mean attention row is recomputed on demand
+    (ops.attn_mean_rows / ops.rollout_rows) -- the only consumer reads 100 rows of a product of 7 of them.
+  * bf16 operands / fp32 accumulate by default (`compute_dtype`), fp32 master parameters; the reference
+    runs apex O1 fp16.  `compute_dtype=torch.float32` is the exact-fp32 parity path.
+  * LayerNorm / GELU-MLP / patch embedding go through the same GEMM kernel (ops.linear) or torch
+    elementwise ops; the FPN taps use torch (MIOpen) -- they are outside the hot path.
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .registry import BACKBONES
+
+
+def trunc_normal_(tensor, std=0.02):
+    # reference utils.py:572 (timm-style truncated normal, +-2 std)
+    return nn.init.trunc_normal_(tensor, std=std, a=-2 * std, b=2 * std)
+
+
+class Mlp(nn.Module):
+    def __init__(self, dim, hidden):
+        super().__init__()
+        self.fc1 = nn.Linear(dim, hidden)
+        self.fc2 = nn.Linear(hidden, dim)
+
+
+class Attention(nn.Module):
+    def __init__(self, dim, num_heads, qkv_bias):
+        super().__init__()
+        self.num_heads = num_heads
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.proj = nn.Linear(dim, dim)
+
+
+class Block(nn.Module):
+    """Parameter container with the reference's key names (norm1, attn.qkv, attn.proj, norm2, mlp.fc1/fc2)."""
+
+    def __init__(self, dim, num_heads, mlp_ratio, qkv_bias, eps):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim, eps=eps)
+        self.attn = Attention(dim, num_heads, qkv_bias)
+        self.norm2 = nn.LayerNorm(dim, eps=eps)
+        self.mlp = Mlp(dim, int(dim * mlp_ratio))
+
+
+class PatchEmbed(nn.Module):
+    def __init__(self, img_size, patch_size, in_chans, embed_dim):
+        super().__init__()
+        if isinstance(img_size, int):
+            img_size = [img_size, img_size]
+        self.num_patches = (img_size[0] // patch_size) * (img_size[1] // patch_size)
+        self.patch_size = patch_size
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size)
+
+
+class MLP(nn.Module):
+    """3-layer FFN of the point head (visual_transformer_det.py:26-38)."""
+
+    def __init__(self, input_dim, hidden_dim, output_dim, num_layers):
+        super().__init__()
+        self.num_layers = num_layers
+        h = [hidden_dim] * (num_layers - 1)
+        self.layers = nn.ModuleList(nn.Linear(n, k) for n, k in zip([input_dim] + h, h + [output_dim]))
+
+    def forward(self, x):
+        for i, layer in enumerate(self.layers):
+            x = F.relu(layer(x)) if i < self.num_layers - 1 else layer(x)
+        return x
+
+
+@BACKBONES.register_module()
+class VisionTransformerDet(nn.Module):
+    def __init__(self, img_size, patch_size, embed_dim, in_chans=3, with_fpn=True, frozen_stages=-1,
+                 out_indices=(3, 5, 7, 11), use_checkpoint=False, learnable_pos_embed=True, last_feat=False,
+                 recompute_last_feat=False, point_tokens_num=100, num_classes=20, return_attention=False,
+                 with_point_head=True, depth=12, num_heads=12, mlp_ratio=4., qkv_bias=False, qk_scale=None,
+                 drop_rate=0., attn_drop_rate=0., drop_path_rate=0., norm_eps=1e-6, init_values=0,
+                 compute_dtype=torch.bfloat16, **unused):
+        super().__init__()
+        assert not with_fpn or patch_size in (8, 16)
+        assert not recompute_last_feat or last_feat
+        if qk_scale is not None or attn_drop_rate or drop_rate or init_values:
+            raise NotImplementedError("qk_scale / dropout / layer-scale are unused by every reference config")
+        if embed_dim != num_heads * ops.HEAD_DIM:
+            raise NotImplementedError(f"head dim must be {ops.HEAD_DIM}")
+        self.embed_dim = self.num_features = embed_dim
+        self.patch_size, self.depth, self.num_heads = patch_size, depth, num_heads
+        self.last_feat, self.recompute_last_feat = last_feat, recompute_last_feat
+        self.with_fpn, self.frozen_stages = with_fpn, frozen_stages
+        self.out_indices = tuple(out_indices)
+        self.use_checkpoint = use_checkpoint            # accepted; activations here are already O(N)
+        self.drop_path_rate = drop_path_rate
+        self.return_attention = return_attention
+        self.point_tokens_num = point_tokens_num
+        self.with_point_head = with_point_head
+        self.compute_dtype = compute_dtype
+
+        self.patch_embed = PatchEmbed(img_size, patch_size, in_chans, embed_dim)
+        n_patches = self.patch_embed.num_patches
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
+        self.pos_embed = nn.Parameter(torch.zeros(1, n_patches + 1, embed_dim), requires_grad=learnable_pos_embed)
+        self.blocks = nn.ModuleList(Block(embed_dim, num_heads, mlp_ratio, qkv_bias, norm_eps) for _ in range(depth))
+        if with_fpn and patch_size == 16:
+            self.fpn1 = nn.Sequential(nn.ConvTranspose2d(embed_dim, embed_dim, 2, 2), nn.BatchNorm2d(embed_dim), nn.GELU(),
+                                      nn.ConvTranspose2d(embed_dim, embed_dim, 2, 2))
+            self.fpn2 = nn.Sequential(nn.ConvTranspose2d(embed_dim, embed_dim, 2, 2))
+            self.fpn3 = nn.Identity()
+            self.fpn4 = nn.MaxPool2d(2, 2)
+        elif with_fpn and patch_size == 8:
+            self.fpn1 = nn.Sequential(nn.ConvTranspose2d(embed_dim, embed_dim, 2, 2))
+            self.fpn2 = nn.Identity()
+            self.fpn3 = nn.Sequential(nn.MaxPool2d(2, 2))
+            self.fpn4 = nn.Sequential(nn.MaxPool2d(4, 4))
+        self.point_token = nn.Parameter(torch.zeros(1, point_tokens_num, embed_dim))
+        self.point_pos_embed = nn.Parameter(torch.zeros(1, point_tokens_num, embed_dim))
+        if with_point_head:
+            self.class_embed = MLP(embed_dim, embed_dim, num_classes, 3)
+            self.bbox_embed = MLP(embed_dim, embed_dim, 2, 3)
+        trunc_normal_(self.pos_embed)
+        trunc_normal_(self.cls_token)
+        trunc_normal_(self.point_token)
+        trunc_normal_(self.point_pos_embed)
+        self.apply(self._init_weights)
+        self._wcache = {}
+
+    # ---- reference API ---------------------------------------------------------------------------
+    @staticmethod
+    def _init_weights(m):
+        if isinstance(m, nn.Linear):
+            trunc_normal_(m.weight)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.constant_(m.bias, 0)
+            nn.init.constant_(m.weight, 1.0)
+
+    def init_weights(self, pretrained=None):
+        """visual_transformer_det.py:179-190: re-init, then (if a file) non-strict load."""
+        if pretrained is not None and not isinstance(pretrained, str):
+            raise TypeError("pretrained must be a str or None")
+        self.apply(self._init_weights)
+        if isinstance(pretrained, str):
+            import os
+            if os.path.isfile(pretrained):
+                ckpt = torch.load(pretrained, map_location="cpu")
+                sd = ckpt.get("state_dict", ckpt.get("model", ckpt))
+                sd = {k[len("backbone."):] if k.startswith("backbone.") else k: v for k, v in sd.items()}
+                self.load_state_dict(sd, strict=False)
+        self.invalidate_cache()
+
+    def train(self, mode=True):
+        # the reference's override forgets to return self (visual_transformer_det.py:153-156); nn.Module
+        # semantics are kept here so `.eval()` chains.
+        super().train(mode)
+        self._freeze_stages()
+        return self
+
+    def _freeze_stages(self):
+        if self.frozen_stages >= 0:
+            self.patch_embed.eval()
+            for p in self.patch_embed.parameters():
+                p.requires_grad = False
+            self.cls_token.requires_grad = False
+            self.pos_embed.requires_grad = False
+        for i in range(1, self.frozen_stages + 1):
+            m = self.blocks[i - 1]
+            m.eval()
+            for p in m.parameters():
+                p.requires_grad = False
+
+    def invalidate_cache(self):
+        self._wcache = {}
+
+    # ---- helpers -----------------------------------------------------------------------------------
+    def _w(self, p):
+        """compute-dtype copy of a weight matrix, cached while parameters are frozen (eval / no-grad)."""
+        if p.dtype == self.compute_dtype:
+            return p
+        if torch.is_grad_enabled() and p.requires_grad:
+            return p.to(self.compute_dtype)
+        key = id(p)
+        hit = self._wcache.get(key)
+        if hit is None or hit[0] != p._version or hit[1].device != p.device:
+            hit = (p._version, p.detach().to(self.compute_dtype).contiguous())
+            self._wcache[key] = hit
+        return hit[1]
+
+    def interpolate_pos_encoding(self, n_patch_tokens, w, h):
+        """models/vision_transformer.py:187-207 (bicubic, scale_factor with the +0.1 trick)."""
+        n0 = self.pos_embed.shape[1] - 1
+        if n_patch_tokens == n0 and w == h:
+            return self.pos_embed
+        dim = self.pos_embed.shape[-1]
+        w0, h0 = w // self.patch_size + 0.1, h // self.patch_size + 0.1
+        s = int(math.sqrt(n0))
+        grid = self.pos_embed[:, 1:].reshape(1, s, s, dim).permute(0, 3, 1, 2)
+        grid = F.interpolate(grid, scale_factor=(w0 / math.sqrt(n0), h0 / math.sqrt(n0)), mode="bicubic")
+        assert int(w0) == grid.shape[-2] and int(h0) == grid.shape[-1]
+        return torch.cat((self.pos_embed[:, :1], grid.permute(0, 2, 3, 1).reshape(1, -1, dim)), dim=1)
+
+    def prepare_tokens(self, img):
+        """visual_transformer_det.py:192-214.  The 16x16/16 conv is a [B*Np, 3*16*16] x [D, 768]^T GEMM."""
+        B, C, w, h = img.shape
+        ps = self.patch_size
+        hp, wp = w // ps, h // ps
+        patches = img.reshape(B, C, hp, ps, wp, ps).permute(0, 2, 4, 1, 3, 5).reshape(B, hp * wp, C * ps * ps)
+        wmat = self.patch_embed.proj.weight.reshape(self.embed_dim, -1)
+        x = ops.linear(patches.to(self.compute_dtype).contiguous(), self._w(wmat).contiguous(),
+                       self.patch_embed.proj.bias.float()).float()
+        x = torch.cat((self.cls_token.expand(B, -1, -1), x), dim=1)
+        x = x + self.interpolate_pos_encoding(x.shape[1] - 1, w, h)
+        pt = (self.point_token + self.point_pos_embed).expand(B, -1, -1)
+        return torch.cat((x, pt), dim=1)
+
+    def _block(self, blk, x, keep_state):
+        """models/vision_transformer.py:109-124 with the residual stream kept in fp32."""
+        cd = self.compute_dtype
+        D = x.shape[-1]
+        y = F.layer_norm(x, (D,), blk.norm1.weight, blk.norm1.bias, blk.norm1.eps).to(cd)
+        a, st = ops.attention_fwd(y.contiguous(), self._w(blk.attn.qkv.weight),
+                                  None if blk.attn.qkv.bias is None else blk.attn.qkv.bias.float(),
+                                  self._w(blk.attn.proj.weight), blk.attn.proj.bias.float(), self.num_heads,
+                                  keep_state=keep_state)
+        x = x + a.float()
+        z = F.layer_norm(x, (D,), blk.norm2.weight, blk.norm2.bias, blk.norm2.eps).to(cd)
+        z = ops.linear(z.contiguous(), self._w(blk.mlp.fc1.weight), blk.mlp.fc1.bias.float(), act="gelu")
+        z = ops.linear(z, self._w(blk.mlp.fc2.weight), blk.mlp.fc2.bias.float())
+        return x + z.float(), st
+
+    def forward(self, x):
+        """visual_transformer_det.py:221-275 (inference / no-grad semantics: drop-path inactive)."""
+        B, _, H, W = x.shape
+        hp, wp = H // self.patch_size, W // self.patch_size
+        T = self.point_tokens_num
+        x = self.prepare_tokens(x)
+        if self.recompute_last_feat:
+            last_feat = x
+        features, attns = [], []
+        for i, blk in enumerate(self.blocks):
+            x, st = self._block(blk, x, self.return_attention)
+            if self.return_attention:
+                attns.append(st)
+            if i in self.out_indices:
+                features.append(x[:, 1:, :][:, :-T].permute(0, 2, 1).reshape(B, -1, hp, wp).contiguous())
+            if self.last_feat and not self.recompute_last_feat and i == len(self.blocks) - 1:
+                last_feat = x[:, :-T]
+        org_features = torch.stack(features, dim=1)
+        if self.with_fpn:
+            fpn = [self.fpn1, self.fpn2, self.fpn3, self.fpn4]
+            features = [fpn[i](f) for i, f in enumerate(features)]
+        point_tokens = x[:, -T:]
+        out = dict(org_feats=org_features, feature=tuple(features), point_tokens=point_tokens)
+        if self.with_point_head:
+            out.update(outputs_class=self.class_embed(point_tokens), outputs_coord=self.bbox_embed(point_tokens).sigmoid())
+        if self.return_attention and self.last_feat:
+            out.update(attns=attns)
+        if self.last_feat:
+            out.update(last_feat=last_feat)
+        return out

@@ -8,11 +8,17 @@
 //                get_bbox_from_cam_fast (:60-116): min-max normalise, threshold, CCL, area filter,
 //                tight box, 'expand' about the point.
 //
-// Union-find with atomicMin linking larger roots under smaller ones: the root of a set is always its
-// minimum raster index, so the result is independent of scheduling (bit-exact labels).  Integer-only
-// atomics everywhere (areas, extents) => deterministic.
-// This file is compiled with -ffp-contract=off: the bilinear weights must round exactly like ATen's
-// (src = scale*(dst+0.5)-0.5 as separate mul/sub) and the two interpolation FMAs are explicit.
+// Run-based union-find (the CAM foreground is a few huge blobs; per-pixel unions would serialise on the
+// root's atomics):
+//   rowscan   one workgroup per image row: prefix-max scan of the last background column, so every
+//             foreground pixel points at the first pixel of its horizontal run (no atomics)
+//   merge     one union per (run, upper run) contact: a pixel links to the row above only where its own
+//             run or the upper run starts (plus the two diagonal contacts)
+//   compress  run starts find their root; then every pixel takes root = L[L[p]]
+// Links always go from the larger raster index to the smaller (atomicMin), so a set's root is its minimum
+// index whatever the scheduling: labels are bit-exact and deterministic.  Areas and extents are
+// accumulated per run / per row with integer arithmetic only.
+// Compiled with -ffp-contract=off (bilinear.h).
 #include "bilinear.h"
 
 namespace {
@@ -47,16 +53,63 @@ __device__ __forceinline__ void uf_union(int32_t* L, int a, int b) {
   }
 }
 
-// parent init from a binary image
-__global__ __launch_bounds__(CC_NT) void ccl_init_kernel(const uint8_t* __restrict__ img, int32_t* __restrict__ L,
-                                                         size_t total, int HW) {
-  const size_t i = (size_t)blockIdx.x * CC_NT + threadIdx.x;
-  if (i >= total) return;
-  const int p = (int)(i % HW);
-  L[i] = img[i] ? p : -1;
+// ---- foreground predicates ------------------------------------------------------------------------
+struct FgImage {            // plain binary image
+  const uint8_t* img;
+  __device__ __forceinline__ bool operator()(int m, int y, int x, int H, int W) const {
+    return img[((size_t)m * H + y) * W + x] != 0;
+  }
+};
+struct CamMeta {            // per map, in workspace
+  unsigned mn, mx;          // ordered-uint encoded min / max of the upsampled map
+  int max_area;
+  int pad;
+};
+struct FgCam {              // upsample + min-max normalise + threshold, recomputed on the fly
+  const float* cams;
+  const CamMeta* meta;
+  float thr;
+  int Hp, Wp;
+  __device__ __forceinline__ bool operator()(int m, int y, int x, int H, int W) const {
+    const float* src = cams + (size_t)m * Hp * Wp;
+    const float sy = (float)Hp / (float)H, sx = (float)Wp / (float)W;
+    const float v = bilerp(src, Wp, lerp_axis(y, Hp, sy), lerp_axis(x, Wp, sx));
+    const float mn = ord2f(meta[m].mn), mx = ord2f(meta[m].mx);
+    return (v - mn) / fmaxf(mx - mn, 1e-6f) >= thr;       // stdroi:63-66
+  }
+};
+
+// ---- rowscan: grid (H, M).  L[p] = first pixel of p's run, or -1 -----------------------------------
+template <typename Fg>
+__global__ __launch_bounds__(CC_NT) void ccl_rowscan_kernel(Fg fg, int32_t* __restrict__ Lall, int H, int W) {
+  __shared__ int wave_max[4];
+  __shared__ int carry_s;
+  const int y = blockIdx.x, m = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int32_t* Lrow = Lall + ((size_t)m * H + y) * W;
+  if (tid == 0) carry_s = -1;                     // column of the last background pixel so far
+  __syncthreads();
+  for (int x0 = 0; x0 < W; x0 += CC_NT) {
+    const int x = x0 + tid;
+    const bool isfg = x < W && fg(m, y, x, H, W);
+    int v = (x < W && !isfg) ? x : -1;            // inclusive prefix max of background columns
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int u = __shfl_up(v, o);
+      if (lane >= o) v = max(v, u);
+    }
+    if (lane == 63) wave_max[wave] = v;
+    __syncthreads();
+    int before = carry_s;
+    for (int w = 0; w < wave; ++w) before = max(before, wave_max[w]);
+    const int lastbg = max(v, before);
+    if (x < W) Lrow[x] = isfg ? (y * W + lastbg + 1) : -1;
+    __syncthreads();
+    if (tid == CC_NT - 1) carry_s = lastbg;
+    __syncthreads();
+  }
 }
 
-// link every foreground pixel with its already-visited 8-neighbours (W, NW, N, NE)
+// ---- merge: one thread per pixel; unions only at run contacts ---------------------------------------
 __global__ __launch_bounds__(CC_NT) void ccl_merge_kernel(int32_t* __restrict__ Lall, int M, int H, int W) {
   const size_t i = (size_t)blockIdx.x * CC_NT + threadIdx.x;
   const int HW = H * W;
@@ -65,65 +118,82 @@ __global__ __launch_bounds__(CC_NT) void ccl_merge_kernel(int32_t* __restrict__ 
   int32_t* L = Lall + (size_t)m * HW;
   if (L[p] < 0) return;
   const int y = p / W, x = p - y * W;
-  const bool up = y > 0;
-  const bool n_fg = up && L[p - W] >= 0;
-  if (n_fg) {
-    uf_union(L, p, p - W);               // N connects NW and NE transitively
-  } else if (up) {
-    if (x > 0 && L[p - W - 1] >= 0) uf_union(L, p, p - W - 1);
-    if (x + 1 < W && L[p - W + 1] >= 0) uf_union(L, p, p - W + 1);
+  if (y == 0) return;
+  const int up = p - W;
+  const bool n = L[up] >= 0;
+  const bool w_fg = x > 0 && L[p - 1] >= 0;
+  const bool nw = x > 0 && L[up - 1] >= 0;
+  if (n) {
+    if (!w_fg || !nw) uf_union(L, p, up);        // my run or the upper run starts at this column
+  } else {
+    const bool ne = x + 1 < W && L[up + 1] >= 0;
+    const bool e_fg = x + 1 < W && L[p + 1] >= 0;
+    if (nw && !w_fg) uf_union(L, p, up - 1);     // diagonal contact with a run ending at x-1
+    if (ne && !e_fg) uf_union(L, p, up + 1);     // diagonal contact with a run starting at x+1
   }
-  if (x > 0 && L[p - 1] >= 0) uf_union(L, p, p - 1);
 }
 
-// path compression in place: every foreground pixel points straight at its root.  Safe while other
-// threads still traverse: a parent entry only ever changes from one ancestor to a closer-to-root one.
-__global__ __launch_bounds__(CC_NT) void ccl_compress_kernel(int32_t* __restrict__ Lall, int M, int HW) {
+// ---- compress: run starts -> root ---------------------------------------------------------------------
+__global__ __launch_bounds__(CC_NT) void ccl_compress_runs_kernel(int32_t* __restrict__ Lall, int M, int H, int W) {
   const size_t i = (size_t)blockIdx.x * CC_NT + threadIdx.x;
+  const int HW = H * W;
   if (i >= (size_t)M * HW) return;
   const int m = (int)(i / HW), p = (int)(i % HW);
   int32_t* L = Lall + (size_t)m * HW;
   if (L[p] < 0) return;
+  const int x = p % W;
+  if (x > 0 && L[p - 1] >= 0) return;             // not a run start
   const int root = uf_find(L, p);
   __hip_atomic_store(&L[p], root, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// after compression: parent (= root) -> label root + 1, background 0
+
+// every pixel: root = L[L[p]] (start pixels already hold their root and L[root] == root).
+// PLUS1: write the final label root+1 / 0.  area != null: add each run's length at its root.
+template <bool PLUS1>
+__global__ __launch_bounds__(CC_NT) void ccl_finalize_kernel(int32_t* __restrict__ Lall, int32_t* __restrict__ area,
+                                                             int M, int H, int W) {
+  const size_t i = (size_t)blockIdx.x * CC_NT + threadIdx.x;
+  const int HW = H * W;
+  if (i >= (size_t)M * HW) return;
+  const int m = (int)(i / HW), p = (int)(i % HW);
+  int32_t* L = Lall + (size_t)m * HW;
+  const int s = L[p];
+  const int x = p % W;
+  // everything this thread needs from its neighbours is read BEFORE anything is written
+  const bool w_fg = x > 0 && L[p - 1] >= 0;
+  const bool e_fg = x + 1 < W && L[p + 1] >= 0;
+  if (s < 0) return;
+  const bool is_start = !w_fg;
+  // a start pixel already holds its root; any other pixel holds its run start, whose entry is the root.
+  // (A start entry is only ever rewritten with the same value, so concurrent in-place writes are benign.)
+  const int root = is_start ? s : __hip_atomic_load(&L[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (area != nullptr && !e_fg) {
+    const int xs = is_start ? x : (s % W);
+    atomicAdd(&area[(size_t)m * HW + root], x - xs + 1);
+  }
+  if (!is_start) __hip_atomic_store(&L[p], root, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// parent array -> labels: root + 1 for foreground, 0 for background
 __global__ __launch_bounds__(CC_NT) void ccl_plus1_kernel(int32_t* __restrict__ L, size_t total) {
   const size_t i = (size_t)blockIdx.x * CC_NT + threadIdx.x;
-  if (i >= total) return;
-  L[i] = L[i] + 1;
-}
-__global__ __launch_bounds__(CC_NT) void ccl_area_kernel(const int32_t* __restrict__ L, int32_t* __restrict__ area,
-                                                         int M, int HW) {
-  const size_t i = (size_t)blockIdx.x * CC_NT + threadIdx.x;
-  if (i >= (size_t)M * HW) return;
-  const int m = (int)(i / HW);
-  const int root = L[i];
-  if (root >= 0) atomicAdd(&area[(size_t)m * HW + root], 1);
+  if (i < total) L[i] = L[i] + 1;
 }
 
 // ------------------------------------------------------------------------------------------------
-// bilinear upsample, align_corners = False, ATen-exact (see oracle upsample_bilinear_explicit)
+// CAM stage
 // ------------------------------------------------------------------------------------------------
-struct CamMeta {      // per map, in workspace
-  unsigned mn, mx;    // ordered-uint encoded min / max of the upsampled map
-  int max_area;
-  int x0, y0, x1, y1; // extent of the kept pixels
-  int kept;
-};
-
 __global__ void cam_meta_init_kernel(CamMeta* meta, int M) {
   const int m = blockIdx.x * blockDim.x + threadIdx.x;
   if (m >= M) return;
   CamMeta c;
-  c.mn = 0xffffffffu; c.mx = 0u; c.max_area = 0;
-  c.x0 = 0x7fffffff; c.y0 = 0x7fffffff; c.x1 = -1; c.y1 = -1; c.kept = 0;
+  c.mn = 0xffffffffu; c.mx = 0u; c.max_area = 0; c.pad = 0;
   meta[m] = c;
 }
 
-// pass 1: min / max of the upsampled map; grid (blocks, M)
+// min / max of the upsampled map (and optionally the map itself); zeroes the area array; grid (blocks, M)
 __global__ __launch_bounds__(CC_NT) void cam_minmax_kernel(const float* __restrict__ cams, CamMeta* __restrict__ meta,
-                                                           float* __restrict__ cams_up, int Hp, int Wp, int up) {
+                                                           float* __restrict__ cams_up, int32_t* __restrict__ area,
+                                                           int Hp, int Wp, int up) {
   __shared__ float smn[CC_NT], smx[CC_NT];
   const int m = blockIdx.y, H = Hp * up, W = Wp * up;
   const float* src = cams + (size_t)m * Hp * Wp;
@@ -133,6 +203,7 @@ __global__ __launch_bounds__(CC_NT) void cam_minmax_kernel(const float* __restri
     const int y = i / W, x = i - y * W;
     const float v = bilerp(src, Wp, lerp_axis(y, Hp, sy), lerp_axis(x, Wp, sx));
     if (cams_up != nullptr) cams_up[(size_t)m * H * W + i] = v;
+    area[(size_t)m * H * W + i] = 0;
     mn = fminf(mn, v);
     mx = fmaxf(mx, v);
   }
@@ -151,25 +222,6 @@ __global__ __launch_bounds__(CC_NT) void cam_minmax_kernel(const float* __restri
   }
 }
 
-// pass 2: normalise, threshold, parent init
-__global__ __launch_bounds__(CC_NT) void cam_binarise_kernel(const float* __restrict__ cams,
-                                                             const CamMeta* __restrict__ meta,
-                                                             int32_t* __restrict__ L, int32_t* __restrict__ area,
-                                                             float cam_thr, int Hp, int Wp, int up) {
-  const int m = blockIdx.y, H = Hp * up, W = Wp * up;
-  const float* src = cams + (size_t)m * Hp * Wp;
-  const float sy = (float)Hp / (float)H, sx = (float)Wp / (float)W;
-  const float mn = ord2f(meta[m].mn), mx = ord2f(meta[m].mx);
-  const float den = fmaxf(mx - mn, 1e-6f);
-  for (int i = blockIdx.x * CC_NT + threadIdx.x; i < H * W; i += gridDim.x * CC_NT) {
-    const int y = i / W, x = i - y * W;
-    const float v = bilerp(src, Wp, lerp_axis(y, Hp, sy), lerp_axis(x, Wp, sx));
-    const float nv = (v - mn) / den;
-    L[(size_t)m * H * W + i] = (nv >= cam_thr) ? i : -1;
-    area[(size_t)m * H * W + i] = 0;
-  }
-}
-
 __global__ __launch_bounds__(CC_NT) void cam_maxarea_kernel(const int32_t* __restrict__ L,
                                                             const int32_t* __restrict__ area,
                                                             CamMeta* __restrict__ meta, int M, int HW) {
@@ -179,36 +231,58 @@ __global__ __launch_bounds__(CC_NT) void cam_maxarea_kernel(const int32_t* __res
   if (L[i] == p) atomicMax(&meta[m].max_area, area[i]);      // roots only
 }
 
-__global__ __launch_bounds__(CC_NT) void cam_extent_kernel(const int32_t* __restrict__ Lall,
-                                                           const int32_t* __restrict__ area,
-                                                           CamMeta* __restrict__ meta, float area_ratio, int M, int H,
-                                                           int W) {
-  const size_t i = (size_t)blockIdx.x * CC_NT + threadIdx.x;
-  const int HW = H * W;
-  if (i >= (size_t)M * HW) return;
-  const int m = (int)(i / HW), p = (int)(i % HW);
-  const int root = Lall[i];                           // compressed: parent == root
-  if (root < 0) return;
-  // reference: areas >= area_ratio * max_area  (int64 tensor vs fp32 scalar tensor -> fp32 compare)
-  if ((float)area[(size_t)m * HW + root] >= area_ratio * (float)meta[m].max_area) {
-    const int y = p / W, x = p - y * W;
-    atomicMin(&meta[m].x0, x); atomicMax(&meta[m].x1, x);
-    atomicMin(&meta[m].y0, y); atomicMax(&meta[m].y1, y);
-    atomicAdd(&meta[m].kept, 1);
+// per row: extent and count of the pixels whose component passes the area filter; grid (H, M)
+struct RowMeta { int x0, x1, cnt, pad; };
+__global__ __launch_bounds__(CC_NT) void cam_row_extent_kernel(const int32_t* __restrict__ Lall,
+                                                               const int32_t* __restrict__ area,
+                                                               const CamMeta* __restrict__ meta,
+                                                               RowMeta* __restrict__ rows, float area_ratio, int H, int W) {
+  __shared__ int s0[CC_NT], s1[CC_NT], sc[CC_NT];
+  const int y = blockIdx.x, m = blockIdx.y, tid = threadIdx.x;
+  const size_t base = ((size_t)m * H + y) * W;
+  const float need = area_ratio * (float)meta[m].max_area;   // stdroi:84: fp32 compare of an int area
+  int x0 = 0x7fffffff, x1 = -1, cnt = 0;
+  for (int x = tid; x < W; x += CC_NT) {
+    const int root = Lall[base + x];
+    if (root >= 0 && (float)area[(size_t)m * H * W + root] >= need) {
+      x0 = min(x0, x); x1 = max(x1, x); ++cnt;
+    }
   }
+  s0[tid] = x0; s1[tid] = x1; sc[tid] = cnt;
+  __syncthreads();
+  for (int o = CC_NT / 2; o > 0; o >>= 1) {
+    if (tid < o) { s0[tid] = min(s0[tid], s0[tid + o]); s1[tid] = max(s1[tid], s1[tid + o]); sc[tid] += sc[tid + o]; }
+    __syncthreads();
+  }
+  if (tid == 0) { RowMeta r; r.x0 = s0[0]; r.x1 = s1[0]; r.cnt = sc[0]; r.pad = 0; rows[(size_t)m * H + y] = r; }
 }
 
-// stdroi:97-115, box_method == 'expand'
-__global__ void cam_box_kernel(const CamMeta* __restrict__ meta, const float* __restrict__ points,
-                               float* __restrict__ boxes, int32_t* __restrict__ status, int M, int H, int W) {
-  const int m = blockIdx.x * blockDim.x + threadIdx.x;
-  if (m >= M) return;
-  const CamMeta c = meta[m];
-  if (status != nullptr) status[m] = c.kept;
+// per map: reduce the rows, then the 'expand' box of stdroi:97-115; grid (M)
+__global__ __launch_bounds__(CC_NT) void cam_box_kernel(const RowMeta* __restrict__ rows,
+                                                        const float* __restrict__ points, float* __restrict__ boxes,
+                                                        int32_t* __restrict__ status, int H, int W) {
+  __shared__ int s0[CC_NT], s1[CC_NT], sy0[CC_NT], sy1[CC_NT], sc[CC_NT];
+  const int m = blockIdx.x, tid = threadIdx.x;
+  int x0 = 0x7fffffff, x1 = -1, y0 = 0x7fffffff, y1 = -1, cnt = 0;
+  for (int y = tid; y < H; y += CC_NT) {
+    const RowMeta r = rows[(size_t)m * H + y];
+    if (r.cnt > 0) { x0 = min(x0, r.x0); x1 = max(x1, r.x1); y0 = min(y0, y); y1 = max(y1, y); cnt += r.cnt; }
+  }
+  s0[tid] = x0; s1[tid] = x1; sy0[tid] = y0; sy1[tid] = y1; sc[tid] = cnt;
+  __syncthreads();
+  for (int o = CC_NT / 2; o > 0; o >>= 1) {
+    if (tid < o) {
+      s0[tid] = min(s0[tid], s0[tid + o]); s1[tid] = max(s1[tid], s1[tid + o]);
+      sy0[tid] = min(sy0[tid], sy0[tid + o]); sy1[tid] = max(sy1[tid], sy1[tid + o]); sc[tid] += sc[tid + o];
+    }
+    __syncthreads();
+  }
+  if (tid != 0) return;
+  if (status != nullptr) status[m] = sc[0];
   float* bx = boxes + (size_t)m * 4;
-  if (c.kept == 0) { bx[0] = 0.f; bx[1] = 0.f; bx[2] = 1.f; bx[3] = 1.f; return; }
+  if (sc[0] == 0) { bx[0] = 0.f; bx[1] = 0.f; bx[2] = 1.f; bx[3] = 1.f; return; }
   const float xc = points[m * 2 + 0], yc = points[m * 2 + 1];
-  const float xmin = (float)c.x0, xmax = (float)c.x1, ymin = (float)c.y0, ymax = (float)c.y1;
+  const float xmin = (float)s0[0], xmax = (float)s1[0], ymin = (float)sy0[0], ymax = (float)sy1[0];
   float gx0, gx1, gy0, gy1;
   if (fabsf(xc - xmin) > fabsf(xc - xmax)) {
     gx0 = xmin; gx1 = xc * 2.0f - gx0; gx1 = gx1 < (float)W ? gx1 : (float)W;
@@ -224,6 +298,7 @@ __global__ void cam_box_kernel(const CamMeta* __restrict__ meta, const float* __
 }
 
 inline int blocks_for(size_t total) { return (int)((total + CC_NT - 1) / CC_NT); }
+inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 }  // namespace
 
@@ -232,10 +307,13 @@ extern "C" int as_ccl_2d(const uint8_t* img, int32_t* labels, int M, int H, int 
   AS_REQUIRE(M > 0 && H > 0 && W > 0 && (size_t)H * W < 0x7fffffffu, AS_E_BADARG, "as_ccl_2d: bad sizes");
   hipStream_t s = (hipStream_t)stream;
   const size_t total = (size_t)M * H * W;
-  // `labels` doubles as the parent array: init -> merge -> compress to roots (in place) -> +1
-  hipLaunchKernelGGL(ccl_init_kernel, dim3(blocks_for(total)), dim3(CC_NT), 0, s, img, labels, total, H * W);
+  FgImage fg{img};
+  // `labels` doubles as the parent array
+  hipLaunchKernelGGL((ccl_rowscan_kernel<FgImage>), dim3(H, M), dim3(CC_NT), 0, s, fg, labels, H, W);
   hipLaunchKernelGGL(ccl_merge_kernel, dim3(blocks_for(total)), dim3(CC_NT), 0, s, labels, M, H, W);
-  hipLaunchKernelGGL(ccl_compress_kernel, dim3(blocks_for(total)), dim3(CC_NT), 0, s, labels, M, H * W);
+  hipLaunchKernelGGL(ccl_compress_runs_kernel, dim3(blocks_for(total)), dim3(CC_NT), 0, s, labels, M, H, W);
+  hipLaunchKernelGGL((ccl_finalize_kernel<true>), dim3(blocks_for(total)), dim3(CC_NT), 0, s, labels,
+                     (int32_t*)nullptr, M, H, W);
   hipLaunchKernelGGL(ccl_plus1_kernel, dim3(blocks_for(total)), dim3(CC_NT), 0, s, labels, total);
   AS_CHECK_LAUNCH("ccl_2d");
   return AS_OK;
@@ -244,7 +322,8 @@ extern "C" int as_ccl_2d(const uint8_t* img, int32_t* labels, int M, int H, int 
 extern "C" size_t as_cam_boxes_workspace_bytes(int M, int Hp, int Wp, int up) {
   if (M <= 0 || Hp <= 0 || Wp <= 0 || up <= 0) return 0;
   const size_t hw = (size_t)Hp * up * Wp * up;
-  return 2 * (size_t)M * hw * sizeof(int32_t) + (((size_t)M * sizeof(CamMeta)) + 255) / 256 * 256;
+  return 2 * al256((size_t)M * hw * sizeof(int32_t)) + al256((size_t)M * sizeof(CamMeta)) +
+         al256((size_t)M * Hp * up * sizeof(RowMeta));
 }
 
 extern "C" int as_cam_boxes(const float* cams, const float* points, float cam_thr, float area_ratio, int M, int Hp,
@@ -257,19 +336,22 @@ extern "C" int as_cam_boxes(const float* cams, const float* points, float cam_th
   hipStream_t s = (hipStream_t)stream;
   const int H = Hp * up, W = Wp * up;
   const size_t hw = (size_t)H * W, total = (size_t)M * hw;
-  int32_t* L = (int32_t*)ws;
-  int32_t* area = L + total;
-  CamMeta* meta = (CamMeta*)(area + total);
-  const int bx = (int)((hw + CC_NT * 4 - 1) / (CC_NT * 4));
+  char* w = (char*)ws;
+  int32_t* L = (int32_t*)w;
+  int32_t* area = (int32_t*)(w + al256(total * 4));
+  CamMeta* meta = (CamMeta*)(w + 2 * al256(total * 4));
+  RowMeta* rows = (RowMeta*)(w + 2 * al256(total * 4) + al256((size_t)M * sizeof(CamMeta)));
+  const int bx = (int)((hw + CC_NT * 16 - 1) / (CC_NT * 16));
   hipLaunchKernelGGL(cam_meta_init_kernel, dim3(as_ceil_div(M, 64)), dim3(64), 0, s, meta, M);
-  hipLaunchKernelGGL(cam_minmax_kernel, dim3(bx, M), dim3(CC_NT), 0, s, cams, meta, cams_up, Hp, Wp, up);
-  hipLaunchKernelGGL(cam_binarise_kernel, dim3(bx, M), dim3(CC_NT), 0, s, cams, meta, L, area, cam_thr, Hp, Wp, up);
+  hipLaunchKernelGGL(cam_minmax_kernel, dim3(bx, M), dim3(CC_NT), 0, s, cams, meta, cams_up, area, Hp, Wp, up);
+  FgCam fg{cams, meta, cam_thr, Hp, Wp};
+  hipLaunchKernelGGL((ccl_rowscan_kernel<FgCam>), dim3(H, M), dim3(CC_NT), 0, s, fg, L, H, W);
   hipLaunchKernelGGL(ccl_merge_kernel, dim3(blocks_for(total)), dim3(CC_NT), 0, s, L, M, H, W);
-  hipLaunchKernelGGL(ccl_compress_kernel, dim3(blocks_for(total)), dim3(CC_NT), 0, s, L, M, (int)hw);
-  hipLaunchKernelGGL(ccl_area_kernel, dim3(blocks_for(total)), dim3(CC_NT), 0, s, L, area, M, (int)hw);
+  hipLaunchKernelGGL(ccl_compress_runs_kernel, dim3(blocks_for(total)), dim3(CC_NT), 0, s, L, M, H, W);
+  hipLaunchKernelGGL((ccl_finalize_kernel<false>), dim3(blocks_for(total)), dim3(CC_NT), 0, s, L, area, M, H, W);
   hipLaunchKernelGGL(cam_maxarea_kernel, dim3(blocks_for(total)), dim3(CC_NT), 0, s, L, area, meta, M, (int)hw);
-  hipLaunchKernelGGL(cam_extent_kernel, dim3(blocks_for(total)), dim3(CC_NT), 0, s, L, area, meta, area_ratio, M, H, W);
-  hipLaunchKernelGGL(cam_box_kernel, dim3(as_ceil_div(M, 64)), dim3(64), 0, s, meta, points, boxes, status, M, H, W);
+  hipLaunchKernelGGL(cam_row_extent_kernel, dim3(H, M), dim3(CC_NT), 0, s, L, area, meta, rows, area_ratio, H, W);
+  hipLaunchKernelGGL(cam_box_kernel, dim3(M), dim3(CC_NT), 0, s, rows, points, boxes, status, H, W);
   AS_CHECK_LAUNCH("cam_boxes");
   return AS_OK;
 }

@@ -39,6 +39,48 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+# ------------------------------------------------------------------------------------------------
+# optional per-kernel timing with HIP events on the launch stream (bench.py's roofline leg)
+# ------------------------------------------------------------------------------------------------
+_TIMED = None      # None = off; else {name: [(start_event, stop_event), ...]}
+
+
+def enable_timing(names):
+    global _TIMED
+    _TIMED = {n: [] for n in names}
+
+
+def disable_timing():
+    global _TIMED
+    _TIMED = None
+
+
+def collect_timing():
+    """-> {name: (launches, mean_ms)}; call after a device synchronize."""
+    out = {}
+    for n, evs in (_TIMED or {}).items():
+        if evs:
+            ms = [a.elapsed_time(b) for a, b in evs]
+            out[n] = (len(ms), sum(ms) / len(ms))
+    return out
+
+
+class _timed:
+    def __init__(self, name):
+        self.on = _TIMED is not None and name in _TIMED
+        self.name = name
+
+    def __enter__(self):
+        if self.on:
+            self.a, self.b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self.a.record(torch.cuda.current_stream())
+
+    def __exit__(self, *exc):
+        if self.on:
+            self.b.record(torch.cuda.current_stream())
+            _TIMED[self.name].append((self.a, self.b))
+
+
 def npad(n):
     return _lib.load().as_npad(int(n))
 
@@ -86,8 +128,19 @@ def attention_fwd(x, w_qkv, b_qkv, w_proj, b_proj, num_heads, keep_state=True):
     o = torch.empty(B, N, D, device=dev, dtype=dt)
     out = torch.empty(B, N, D, device=dev, dtype=dt)
     lse = torch.empty(B, num_heads, N, device=dev, dtype=torch.float32)
-    _lib.check(lib.as_attn_fwd(_p(x), _p(w_qkv), _p(b_qkv), _p(w_proj), _p(b_proj), _p(out), _p(lse), _p(q), _p(k),
-                               _p(vt), _p(o), B, N, D, num_heads, _dt(x), _stream()), "as_attn_fwd")
+    if _TIMED is None:
+        _lib.check(lib.as_attn_fwd(_p(x), _p(w_qkv), _p(b_qkv), _p(w_proj), _p(b_proj), _p(out), _p(lse), _p(q), _p(k),
+                                   _p(vt), _p(o), B, N, D, num_heads, _dt(x), _stream()), "as_attn_fwd")
+    else:       # same three launches as as_attn_fwd, with event pairs around each
+        with _timed("qkv_gemm"):
+            _lib.check(lib.as_qkv_fwd(_p(x), _p(w_qkv), _p(b_qkv), _p(q), _p(k), _p(vt), B, N, D, num_heads, _dt(x),
+                                      _stream()), "as_qkv_fwd")
+        with _timed("sdpa_fwd"):
+            _lib.check(lib.as_sdpa_fwd(_p(q), _p(k), _p(vt), _p(o), _p(lse), B, N, num_heads, _dt(x), _stream()),
+                       "as_sdpa_fwd")
+        with _timed("proj_gemm"):
+            _lib.check(lib.as_linear_fwd(_p(o), _p(w_proj), _p(b_proj), _p(out), B * N, D, D, _dt(x), 0, _stream()),
+                       "as_linear_fwd")
     return out, (AttnLayerState(q, k, vt, lse, B, N, num_heads, dt) if keep_state else None)
 
 
@@ -190,9 +243,10 @@ def cosine_shift(feat, box_patch, obj_img, prot, n_shift, hp, wp, tau0=0.1, temp
     tau = torch.empty(max(n_shift, 1), G, P, device=feat.device, dtype=torch.float32) if return_trace else None
     nbytes = lib.as_cosine_shift_workspace_bytes(B, C, hp, wp, G, P)
     ws = torch.empty(nbytes, device=feat.device, dtype=torch.uint8)
-    _lib.check(lib.as_cosine_shift(_p(feat), _p(box_patch), _p(obj_img), _p(prot), float(tau0), float(temp), int(n_shift),
-                                   _p(sim), _p(assign), _p(tau), _p(ws), nbytes, B, C, hp, wp, G, P, _stream()),
-               "as_cosine_shift")
+    with _timed("cosine_shift"):
+        _lib.check(lib.as_cosine_shift(_p(feat), _p(box_patch), _p(obj_img), _p(prot), float(tau0), float(temp),
+                                       int(n_shift), _p(sim), _p(assign), _p(tau), _p(ws), nbytes, B, C, hp, wp, G, P,
+                                       _stream()), "as_cosine_shift")
     if return_trace:
         return prot, sim, assign[:n_shift], tau[:n_shift]
     return prot, sim

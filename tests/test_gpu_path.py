@@ -1,0 +1,105 @@
+"""End-to-end parity of the plugin classes on the GPU against the reference fixtures.
+
+  * VisionTransformerDet.forward (fp32 MFMA path: 1e-3 relative as north_star asks; bf16 path: 3e-2 of
+    the output range) incl. the roll-out rows recomputed from (q,k,lse)
+  * AttnShiftRoIHead.seed_pseudo_gt: whole chain B1..B6 from CAM rows to masks / part centres
+"""
+import numpy as np
+import pytest
+import torch
+
+import attnshift_oracle as O
+from helpers import assert_close, assert_equal, backbone_cfg, backbone_state_dict, shift_case_inputs, t
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+
+
+def build_backbone(g, dtype):
+    import attentionshift_amd as A
+    from attentionshift_amd import synthetic
+    cfg = backbone_cfg(g)
+    bb = A.build_backbone(dict(type="VisionTransformerDet", img_size=cfg["img_size"], patch_size=16,
+                               embed_dim=cfg["embed_dim"], depth=cfg["depth"], num_heads=cfg["num_heads"], mlp_ratio=4.,
+                               qkv_bias=True, drop_path_rate=0., out_indices=cfg["out_indices"], last_feat=True,
+                               point_tokens_num=cfg["point_tokens_num"], num_classes=cfg["num_classes"],
+                               return_attention=True, compute_dtype=dtype))
+    bb.load_state_dict(backbone_state_dict(g))
+    bb = bb.cuda().eval()
+    img = synthetic.images(cfg["batch"], *cfg["img_hw"], seed=cfg["seed"]).cuda()
+    return bb, img, cfg
+
+
+def rel(ref, got):
+    ref, got = ref.double().cpu(), got.double().cpu()
+    return ((ref - got).abs().max() / (ref.abs().max() + 1e-30)).item()
+
+
+@pytest.mark.parametrize("tag", ["small", "tiny224"])
+def test_backbone_fp32_matches_reference(golden, tag):
+    from attentionshift_amd import ops
+    g = golden(f"backbone_{tag}")
+    bb, img, cfg = build_backbone(g, torch.float32)
+    out = bb(img)
+    for k in ("last_feat", "point_tokens", "outputs_class", "outputs_coord"):
+        assert rel(t(g[k]), out[k]) < 1e-3, (k, rel(t(g[k]), out[k]))
+    for i, f in enumerate(out["feature"]):
+        st = int(g[f"feature{i}_stride"])
+        assert rel(t(g[f"feature{i}"]), f[:, :, ::st, ::st]) < 1e-3, f"feature{i}"
+    T, Lc = cfg["point_tokens_num"], cfg["cam_layer"]
+    rows = ops.rollout_rows(out["attns"][-Lc:], T)
+    assert_close(t(g["rollout_rows"]), rows, 1e-3, 1e-6, "roll-out rows (A3)")
+    for key in g.files:
+        if key.startswith("attn") and key[4:].isdigit():
+            st = out["attns"][int(key[4:])]
+            dense = ops.attn_mean_rows(st, 0, st.N)
+            assert_close(t(g[key]), dense, 1e-3, 1e-7, f"head-mean attention layer {key[4:]}")
+
+
+@pytest.mark.parametrize("tag", ["small", "tiny224"])
+def test_backbone_bf16_close_to_reference(golden, tag):
+    from attentionshift_amd import ops
+    g = golden(f"backbone_{tag}")
+    bb, img, cfg = build_backbone(g, torch.bfloat16)
+    out = bb(img)
+    assert rel(t(g["last_feat"]), out["last_feat"]) < 3e-2
+    assert rel(t(g["outputs_coord"]), out["outputs_coord"]) < 3e-2
+    rows = ops.rollout_rows(out["attns"][-cfg["cam_layer"]:], cfg["point_tokens_num"])
+    assert rel(t(g["rollout_rows"]), rows) < 3e-2
+
+
+@pytest.mark.parametrize("tag", ["tiny224", "mid320"])
+def test_seed_pseudo_gt_chain_matches_reference(golden, tag, monkeypatch):
+    import attentionshift_amd as A
+    g = golden(f"shift_{tag}")
+    inp = shift_case_inputs(g)
+    hp, wp, G, Lc, C = int(g["hp"]), int(g["wp"]), int(g["G"]), int(g["Lc"]), int(g["C"])
+    T, N = 10, 1 + hp * wp + 10
+    head = A.build_head(dict(type="AttnShiftRoIHead", num_semantic_points=int(g["num_semantic_points"]),
+                             mean_shift_times_local=int(g["n_shift"]),
+                             bbox_head=dict(type="MAEBoxHeadRec", seed_thr=float(g["cam_thr"]),
+                                            seed_multiple=float(g["area_ratio"]), cam_layer=Lc, num_classes=20)))
+    rows = torch.zeros(1, Lc, T, N)
+    rows[0, :, :G, 1:-T] = inp["cams"].flatten(2)
+    monkeypatch.setattr(head, "rollout_cams", lambda attns, n: rows.cuda())
+    best = t(g["best_idx"]).cuda()
+    head.layer_selector = lambda boxes, labels, fmap: [best]
+    torch.manual_seed(int(g["seed"]) + 1)
+    out = head.seed_pseudo_gt(None, [dict(img_shape=(hp * 16, wp * 16, 3))], None, None, None,
+                              vit_feat=inp["vit_feat"][None].cuda(), point_cls=torch.zeros(1, T, 20).cuda(),
+                              point_reg=torch.zeros(1, T, 2).cuda(), attns=None, gt_points=[inp["points"].cuda()],
+                              gt_points_labels=[inp["labels"].cuda()], return_mask=True,
+                              pos_mask_thr=float(g["pos_thr"]), neg_mask_thr=float(g["neg_thr"]),
+                              num_mask_point_gt=int(g["num_gt"]), corr_size=int(g["corr_size"]), obj_tau=float(g["obj_tau"]),
+                              pos_inds=[torch.arange(G).cuda()], matched_gt=[torch.arange(G).cuda()])
+    assert_equal(t(g["rois"]), out["pseudo_gt_bboxes"][0], "pseudo boxes (B1)")
+    assert_close(t(g["map_fg_last"]), out["map_cos_fg"][0], 1e-3, 1e-5, "map_cos_fg (B2)")
+    assert_equal(t(g["mask_coords"]), out["mask_points_coords"][0], "mask point coords (B2')")
+    assert_equal(t(g["mask_labels"]), out["mask_points_labels"][0], "mask point labels (B2')")
+    assert_equal(g["num_parts"], np.array(out["num_parts"][0]), "num_parts (B5)")
+    assert_close(t(g["coords_org"]), out["semantic_centers_org"][0][0], 0, 0, "part centres (B5)")
+    assert_equal(g["corres_gt"], out["corres_gts"][0], "corres_gts")
+    ref_masks = O.pseudo_masks(t(g["map_fg_last"]), float(g["pos_thr"]))
+    diff = int((ref_masks != out["pseudo_gt_masks"][0]).sum())
+    assert diff <= ref_masks.size * 1e-5, f"pseudo masks differ in {diff} pixels"      # threshold-edge pixels only
+    assert_close(t(g["fg_feat"]), out["inst_fg_feat"][0].flatten(1), 1e-3, 1e-4, "inst_fg_feat")

@@ -1,0 +1,126 @@
+"""Host-side logic of the plugin (registry, config schema, matching, sampling, part selection) on CPU.
+
+The HIP ops are replaced IN THE TEST by oracle-backed stand-ins (monkeypatch) so the torch glue around
+them is pinned to the reference fixtures without a GPU.  The product itself never imports the oracle.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import attnshift_oracle as O
+from helpers import assert_close, assert_equal, shift_case_inputs, t
+
+import attentionshift_amd as A
+from attentionshift_amd import roi_head as RH
+
+torch.set_grad_enabled(False)
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_registry_surface_and_both_head_names():
+    assert "VisionTransformerDet" in A.BACKBONES
+    assert A.HEADS.get("AttnShiftRoIHead") is A.HEADS.get("StandardRoIHeadMaskPointSampleDeformAttnReppoints")
+    head = A.build_head(dict(type="AttnShiftRoIHead", num_semantic_points=5, mean_shift_times_local=10,
+                             bbox_head=dict(type="MAEBoxHeadRec", seed_thr=0.2, seed_multiple=0.5, cam_layer=7),
+                             mil_head=dict(type="MAEBoxHeadMIL", num_layers_query=7)))
+    assert head.bbox_head.cam_layer == 7 and head.num_semantic_points == 5 and head.with_mil
+    with pytest.raises(KeyError):
+        A.build_head(dict(type="NoSuchHead"))
+    with pytest.raises(KeyError):
+        A.HEADS.register_module(name="AttnShiftRoIHead", module=A.AttnShiftRoIHead)
+
+
+def test_config_schema_roundtrip(tmp_path):
+    base = tmp_path / "base.py"
+    base.write_text("model = dict(type='FasterRCNNPointSupAlign', backbone=dict(type='VisionTransformerDet', img_size=224, "
+                    "patch_size=16, embed_dim=192, depth=12, num_heads=3), roi_head=dict(type='AttnShiftRoIHead', "
+                    "mean_shift_times_local=10, bbox_head=dict(cam_layer=7)))\noptimizer = dict(type='AdamW', lr=1e-4)\n")
+    child = tmp_path / "child.py"
+    child.write_text("_base_ = ['base.py']\nmodel = dict(backbone=dict(embed_dim=768, num_heads=12), "
+                     "roi_head=dict(bbox_head=dict(_delete_=True, cam_layer=5)))\n")
+    cfg = A.Config.fromfile(str(child))
+    assert cfg.model.backbone.embed_dim == 768 and cfg.model.backbone.depth == 12
+    assert cfg.model.roi_head.bbox_head == dict(cam_layer=5)
+    cfg.merge_from_dict({"model.roi_head.mean_shift_times_local": 5})
+    assert cfg.model.roi_head.mean_shift_times_local == 5
+    bb = A.build_backbone(dict(cfg.model.backbone, mlp_ratio=4., qkv_bias=True, last_feat=True, return_attention=True,
+                               compute_dtype=torch.float32))
+    assert bb.embed_dim == 768 and len(bb.blocks) == 12
+
+
+def test_backbone_state_dict_keys_match_reference(golden):
+    g = golden("backbone_small")
+    names = g["param_names"].tolist()
+    bb = A.VisionTransformerDet(img_size=64, patch_size=16, embed_dim=128, depth=4, num_heads=2, mlp_ratio=4.,
+                                qkv_bias=True, out_indices=(0, 1, 2, 3), last_feat=True, point_tokens_num=10,
+                                num_classes=5, return_attention=True)
+    assert sorted(bb.state_dict().keys()) == sorted(names)
+    for n, s in zip(names, g["param_shapes"].tolist()):
+        want = tuple(int(v) for v in s.split(",")) if s else ()
+        assert tuple(bb.state_dict()[n].shape) == want, n
+
+
+def test_hungarian_matching_orders_objects_by_token_index():
+    gen = torch.Generator().manual_seed(0)
+    T, ncls = 12, 5
+    gt_points = torch.tensor([[30., 40.], [200., 120.], [90., 210.]])
+    gt_labels = torch.tensor([1, 3, 0])
+    pred = torch.rand(T, 2, generator=gen)
+    pred[7] = gt_points[0] / 224
+    pred[2] = gt_points[1] / 224
+    pred[9] = gt_points[2] / 224
+    cls = torch.randn(T, ncls, generator=gen) * 0.01
+    pos, gt = RH.hungarian_point_match(pred, cls, gt_points, gt_labels, (224, 224, 3), reg_weight=10.0)
+    assert pos.tolist() == [2, 7, 9] and gt.tolist() == [1, 0, 2]
+
+
+@pytest.mark.parametrize("tag", ["tiny224", "mid320"])
+def test_sampling_and_mask_points_share_the_reference_rng_stream(golden, tag):
+    g = golden(f"shift_{tag}")
+    inp = shift_case_inputs(g)
+    hp, wp, G = int(g["hp"]), int(g["wp"]), int(g["G"])
+    cams = O.upsample_bilinear(inp["cams"], hp * 16, wp * 16)
+    attn_sel = cams[t(g["best_idx"]), torch.arange(G)]
+    torch.manual_seed(int(g["seed"]) + 1)
+    nm = RH._minmax_maps(attn_sel)
+    bg = RH.sample_point_grid(nm, 20, 0.1, False)
+    fg = RH.sample_point_grid(nm, 20, 0.2, True, inp["points"])
+    supp = RH.sample_point_grid(nm.mean(0, keepdim=True), 20, 0.1, False)
+    assert_equal(t(g["points_bg"]), bg, "bg points")
+    assert_equal(t(g["points_fg"]), torch.cat((fg, supp)), "fg points")
+    rois = t(g["rois"])
+    for gi in range(G):
+        x0, y0, x1, y1 = rois[gi].int().tolist()
+        c, l = RH.mask_points_fg_bg(t(g["map_fg_last"])[gi][y0:y1, x0:x1], t(g["map_bg_last"])[gi][y0:y1, x0:x1],
+                                    float(g["pos_thr"]), float(g["neg_thr"]), int(g["num_gt"]), int(g["corr_size"]))
+        c = c.clone(); c[:, 0] += y0; c[:, 1] += x0
+        assert_equal(t(g["mask_coords"])[gi], c.flip(1).float(), f"mask coords obj {gi}")
+        assert_equal(t(g["mask_labels"])[gi], l, f"mask labels obj {gi}")
+
+
+@pytest.mark.parametrize("tag", ["tiny224", "mid320"])
+def test_semantic_center_host_logic_with_oracle_backed_shift(golden, tag, monkeypatch):
+    g = golden(f"shift_{tag}")
+    inp = shift_case_inputs(g)
+    hp, wp, G = int(g["hp"]), int(g["wp"]), int(g["G"])
+
+    def fake_cosine_shift(feat, box_patch, obj_img, prot, n_shift, hp_, wp_, tau0=0.1, temp=0.1, return_trace=False):
+        inbox = O.box_mask(box_patch.float(), (hp_, wp_)).flatten(1)
+        p, s = O.cosine_shift(prot.clone(), feat[0][None] * inbox[..., None], feat[0], tau0, temp, n_shift)
+        return p.reshape(prot.shape), s.reshape(prot.shape[0], prot.shape[1], -1)
+
+    monkeypatch.setattr(RH.ops, "cosine_shift", fake_cosine_shift)
+    head = A.AttnShiftRoIHead(num_semantic_points=int(g["num_semantic_points"]), mean_shift_times_local=int(g["n_shift"]))
+    res = head.get_semantic_centers(t(g["map_fg_last"]), t(g["map_bg_last"]), t(g["rois"]), inp["vit_feat"],
+                                    pos_thr=float(g["pos_thr"]), refine_times=int(g["n_shift"]), gt_labels=inp["labels"],
+                                    num_semantic_points=int(g["num_semantic_points"]))
+    centers, split, sim_parts, feat_split, feats, num_parts, coords_org, labels_org, corres = res
+    assert_equal(g["num_parts"], np.array(num_parts), "num_parts")
+    assert_close(t(g["coords_org"]), coords_org, 0, 0, "centre coords")
+    assert_equal(g["corres_gt"], corres, "corres_gt")
+    assert_equal(g["labels_org"], labels_org, "labels")
+    for i, n in enumerate(g["n_sim_parts"].tolist()):
+        if n:
+            assert_close(t(g[f"sim_parts{i}"]), sim_parts[i], 1e-4, 1e-5, f"sim_parts{i}")

@@ -1,0 +1,126 @@
+"""Per-kernel timing at BASELINE config-2 shapes (ViT-B, 1024^2, B=2) on the GPU box.
+
+    python tools/kernel_bench.py [--reps 20]
+Prints one JSON line per kernel: ms, achieved TFLOP/s or GB/s, fraction of the gfx950 roof.
+Timing = HIP events on the current stream around `reps` back-to-back launches (after warm-up).
+"""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from attentionshift_amd import ops, synthetic  # noqa: E402
+
+PEAK_BF16, PEAK_F32, PEAK_HBM = 2.5e15, 157.3e12, 8.0e12
+
+
+def timeit(fn, reps, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--B", type=int, default=2)
+    ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    B, N, D, h, T = a.B, 4197, 768, 12, 100
+    dev = "cuda"
+    g = torch.Generator().manual_seed(0)
+    out = []
+
+    def emit(name, ms, flops=None, bytes_=None, peak=None, **kw):
+        rec = dict(kernel=name, ms=round(ms, 4))
+        if flops:
+            rec.update(tflops=round(flops / ms / 1e9, 1), frac=round(flops / (ms * 1e-3) / peak, 4))
+        if bytes_:
+            rec.update(gbps=round(bytes_ / ms / 1e6, 1), frac_hbm=round(bytes_ / (ms * 1e-3) / PEAK_HBM, 4))
+        rec.update(kw)
+        print(json.dumps(rec), flush=True)
+        out.append(rec)
+
+    want = lambda k: (not a.only) or (a.only in k)
+    x = torch.randn(B, N, D, generator=g).to(dev)
+    wqkv = (torch.randn(3 * D, D, generator=g) * 0.06).to(dev)
+    bqkv = torch.zeros(3 * D, device=dev)
+    wproj = (torch.randn(D, D, generator=g) * 0.03).to(dev)
+    bproj = torch.zeros(D, device=dev)
+    xb, wqb, wpb = x.bfloat16(), wqkv.bfloat16(), wproj.bfloat16()
+
+    if want("qkv"):
+        ms = timeit(lambda: ops.qkv_fwd(xb, wqb, bqkv, h), a.reps)
+        emit("qkv_gemm_bf16", ms, 2.0 * B * N * D * 3 * D, peak=PEAK_BF16)
+    q, k, vt = ops.qkv_fwd(xb, wqb, bqkv, h)
+    if want("sdpa"):
+        ms = timeit(lambda: ops.sdpa_fwd(q, k, vt, N), a.reps)
+        emit("sdpa_fwd_bf16", ms, 4.0 * B * h * N * N * 64, peak=PEAK_BF16)
+    if want("linear"):
+        o, _ = ops.sdpa_fwd(q, k, vt, N)
+        ms = timeit(lambda: ops.linear(o, wpb, bproj), a.reps)
+        emit("proj_gemm_bf16", ms, 2.0 * B * N * D * D, peak=PEAK_BF16)
+        w1 = (torch.randn(4 * D, D, generator=g) * 0.03).to(dev).bfloat16()
+        b1 = torch.zeros(4 * D, device=dev)
+        ms = timeit(lambda: ops.linear(xb, w1, b1, act="gelu"), a.reps)
+        emit("fc1_gelu_gemm_bf16", ms, 2.0 * B * N * D * 4 * D, peak=PEAK_BF16)
+        ms = timeit(lambda: torch.nn.functional.linear(xb, w1), a.reps)
+        emit("torch_hipblaslt_fc1_bf16", ms, 2.0 * B * N * D * 4 * D, peak=PEAK_BF16)
+    if want("attn"):
+        ms = timeit(lambda: ops.attention_fwd(xb, wqb, bqkv, wpb, bproj, h), a.reps)
+        emit("attention_fwd_bf16(qkv+sdpa+proj)", ms, B * (2.0 * N * D * 3 * D + 4.0 * N * N * D + 2.0 * N * D * D), peak=PEAK_BF16)
+    if want("rollout"):
+        states = [ops.attention_fwd(xb, wqb, bqkv, wpb, bproj, h)[1] for _ in range(7)]
+        ms = timeit(lambda: ops.rollout_rows(states, T), max(a.reps // 4, 2))
+        emit("rollout_rows_7layers_bf16", ms, B * 6 * (2.0 * N * N * 64 * h + 2.0 * 128 * N * N), peak=PEAK_BF16)
+    if want("shift"):
+        hp = wp = 64
+        feats, boxes, prots, obj = [], [], [], []
+        for b in range(B):
+            inp = synthetic.shift_inputs(100 + b, hp, wp, D, 3, 1)
+            f = inp["vit_feat"].flatten(1).t().contiguous()
+            feats.append(f)
+            pb = inp["patch_boxes"].int()
+            boxes.append(pb)
+            for gi in range(3):
+                x0, y0, x1, y1 = pb[gi].tolist()
+                ys = torch.linspace(y0, y1, 5).long()
+                xs = torch.linspace(x0, x1, 4).long()
+                prots.append(f[(ys[:, None] * wp + xs[None, :]).flatten()])
+                obj.append(b)
+        feat = torch.stack(feats).to(dev)
+        box_patch = torch.cat(boxes).to(dev)
+        prot = torch.stack(prots).to(dev)
+        obj_img = torch.tensor(obj, dtype=torch.int32, device=dev)
+        S, G, P = 5, len(obj), 20
+        ms = timeit(lambda: ops.cosine_shift(feat, box_patch, obj_img, prot, S, hp, wp), a.reps)
+        alg = (2 * S + 1) * B * hp * wp * D * 4 + G * P * hp * wp * 4
+        emit("cosine_shift_S5", ms, bytes_=alg, note="algorithmic bytes per SURVEY 8d")
+        full = torch.tensor([[0, 0, wp - 1, hp - 1]] * G, dtype=torch.int32, device=dev)
+        ms = timeit(lambda: ops.cosine_shift(feat, full, obj_img, prot, S, hp, wp), a.reps)
+        emit("cosine_shift_S5_fullboxes", ms, bytes_=alg, note="worst case: every box covers the image")
+    if want("cam"):
+        hp = wp = 64
+        M = 21 * B
+        cams = torch.rand(M, hp, wp, generator=g)
+        for m in range(M):
+            cams[m, 10 + m % 7:40, 12:44 + m % 5] += 1.0
+        cams = cams.to(dev)
+        pts = torch.full((M, 2), 500.0, device=dev)
+        ms = timeit(lambda: ops.cam_boxes(cams, pts, 0.2, 0.5), max(a.reps // 4, 2))
+        emit("cam_boxes_21maps_per_img", ms, bytes_=M * 1024 * 1024 * 13, note="13 B/pixel/map (SURVEY 8d)")
+    return out
+
+
+if __name__ == "__main__":
+    main()
