@@ -26,7 +26,7 @@ SIGNATURES = {
     "as_rollout_step": (_c_int, [_c_void_p] * 5 + [_c_int] * 5 + [_c_void_p]),
     "as_ccl_2d": (_c_int, [_c_void_p] * 2 + [_c_int] * 3 + [_c_void_p]),
     "as_cam_boxes_workspace_bytes": (_c_size_t, [_c_int] * 4),
-    "as_cam_boxes": (_c_int, [_c_void_p] * 2 + [_c_float] * 2 + [_c_int] * 4 + [_c_void_p] * 4 + [_c_size_t, _c_void_p]),
+    "as_cam_boxes": (_c_int, [_c_void_p] * 2 + [_c_float] * 2 + [_c_int] * 4 + [_c_void_p] * 5 + [_c_size_t, _c_void_p]),
     "as_cosine_shift_workspace_bytes": (_c_size_t, [_c_int] * 6),
     "as_cosine_shift": (_c_int, [_c_void_p] * 4 + [_c_float] * 2 + [_c_int] + [_c_void_p] * 4 + [_c_size_t]
                         + [_c_int] * 6 + [_c_void_p]),
@@ -34,6 +34,9 @@ SIGNATURES = {
     "as_refine_similarity": (_c_int, [_c_void_p] * 3 + [_c_int] * 3 + [_c_float, _c_int] + [_c_void_p] * 3
                              + [_c_size_t] + [_c_int] * 3 + [_c_void_p]),
     "as_instance_maps_workspace_bytes": (_c_size_t, [_c_int] * 2),
+    "as_crop_threshold_erode_workspace_bytes": (_c_size_t, [_c_int] * 3),
+    "as_crop_threshold_erode": (_c_int, [_c_void_p] * 2 + [_c_float, _c_int, _c_int] + [_c_void_p] * 3 + [_c_size_t]
+                                + [_c_int] * 3 + [_c_void_p]),
     "as_instance_maps": (_c_int, [_c_void_p] * 2 + [_c_int] * 6 + [_c_void_p] * 3 + [_c_size_t, _c_void_p]),
 }
 

@@ -258,9 +258,10 @@ __global__ __launch_bounds__(CC_NT) void cam_row_extent_kernel(const int32_t* __
 }
 
 // per map: reduce the rows, then the 'expand' box of stdroi:97-115; grid (M)
-__global__ __launch_bounds__(CC_NT) void cam_box_kernel(const RowMeta* __restrict__ rows,
+__global__ __launch_bounds__(CC_NT) void cam_box_kernel(const RowMeta* __restrict__ rows, const CamMeta* __restrict__ meta,
                                                         const float* __restrict__ points, float* __restrict__ boxes,
-                                                        int32_t* __restrict__ status, int H, int W) {
+                                                        int32_t* __restrict__ status, float* __restrict__ minmax, int H,
+                                                        int W) {
   __shared__ int s0[CC_NT], s1[CC_NT], sy0[CC_NT], sy1[CC_NT], sc[CC_NT];
   const int m = blockIdx.x, tid = threadIdx.x;
   int x0 = 0x7fffffff, x1 = -1, y0 = 0x7fffffff, y1 = -1, cnt = 0;
@@ -279,6 +280,7 @@ __global__ __launch_bounds__(CC_NT) void cam_box_kernel(const RowMeta* __restric
   }
   if (tid != 0) return;
   if (status != nullptr) status[m] = sc[0];
+  if (minmax != nullptr) { minmax[m * 2 + 0] = ord2f(meta[m].mn); minmax[m * 2 + 1] = ord2f(meta[m].mx); }
   float* bx = boxes + (size_t)m * 4;
   if (sc[0] == 0) { bx[0] = 0.f; bx[1] = 0.f; bx[2] = 1.f; bx[3] = 1.f; return; }
   const float xc = points[m * 2 + 0], yc = points[m * 2 + 1];
@@ -327,8 +329,8 @@ extern "C" size_t as_cam_boxes_workspace_bytes(int M, int Hp, int Wp, int up) {
 }
 
 extern "C" int as_cam_boxes(const float* cams, const float* points, float cam_thr, float area_ratio, int M, int Hp,
-                            int Wp, int up, float* boxes, int32_t* status, float* cams_up, void* ws, size_t ws_bytes,
-                            as_stream_t stream) {
+                            int Wp, int up, float* boxes, int32_t* status, float* cams_up, float* minmax, void* ws,
+                            size_t ws_bytes, as_stream_t stream) {
   AS_REQUIRE(cams && points && boxes && ws, AS_E_BADARG, "as_cam_boxes: null pointer");
   AS_REQUIRE(M > 0 && Hp > 0 && Wp > 0 && up > 0, AS_E_BADARG, "as_cam_boxes: bad sizes");
   AS_REQUIRE(ws_bytes >= as_cam_boxes_workspace_bytes(M, Hp, Wp, up), AS_E_WORKSPACE,
@@ -351,7 +353,7 @@ extern "C" int as_cam_boxes(const float* cams, const float* points, float cam_th
   hipLaunchKernelGGL((ccl_finalize_kernel<false>), dim3(blocks_for(total)), dim3(CC_NT), 0, s, L, area, M, H, W);
   hipLaunchKernelGGL(cam_maxarea_kernel, dim3(blocks_for(total)), dim3(CC_NT), 0, s, L, area, meta, M, (int)hw);
   hipLaunchKernelGGL(cam_row_extent_kernel, dim3(H, M), dim3(CC_NT), 0, s, L, area, meta, rows, area_ratio, H, W);
-  hipLaunchKernelGGL(cam_box_kernel, dim3(M), dim3(CC_NT), 0, s, rows, points, boxes, status, H, W);
+  hipLaunchKernelGGL(cam_box_kernel, dim3(M), dim3(CC_NT), 0, s, rows, meta, points, boxes, status, minmax, H, W);
   AS_CHECK_LAUNCH("cam_boxes");
   return AS_OK;
 }

@@ -470,72 +470,82 @@ __global__ __launch_bounds__(CS_NT) void refine_select_kernel(float* __restrict_
   }
 }
 
-// one workgroup per seed: threshold at tau * rowmax, similarity-weighted mean feature (:687-691)
-template <int CPT>
-__global__ __launch_bounds__(CS_NT) void refine_aggregate_kernel(const float* __restrict__ feat,
-                                                                 const float* __restrict__ work, float tau,
-                                                                 float* __restrict__ seeds_out, int C, int Np) {
-  extern __shared__ __attribute__((aligned(16))) char smem_r[];
-  int* list_n = reinterpret_cast<int*>(smem_r);
-  float* list_w = reinterpret_cast<float*>(smem_r) + Np;
-  __shared__ float sh[CS_NT];
-  __shared__ int wave_cnt[4];
-  __shared__ int base_s;
-  const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const float* wrow = work + (size_t)g * Np;
+// threshold at tau * rowmax, similarity-weighted mean feature (:687-691), in three deterministic steps:
+//   rowmax   grid (Gp)          peak[g] = max_n work[g][n]
+//   partial  grid (tiles, Gp)   partial[g][tile][:] = sum over the tile's surviving patches of w * feat[n][:]
+//   finish   grid (Gp)          seeds_out[g] = sum_tiles partial / clamp(sum w, 1e-8)
+constexpr int RF_TILE = 128;
 
+__global__ __launch_bounds__(CS_NT) void refine_rowmax_kernel(const float* __restrict__ work, float* __restrict__ peak,
+                                                              int Np) {
+  __shared__ float sh[CS_NT];
+  const int g = blockIdx.x, tid = threadIdx.x;
   float mx = -INFINITY;
-  for (int n = tid; n < Np; n += CS_NT) mx = fmaxf(mx, wrow[n]);
+  for (int n = tid; n < Np; n += CS_NT) mx = fmaxf(mx, work[(size_t)g * Np + n]);
   sh[tid] = mx;
   __syncthreads();
   for (int o = CS_NT / 2; o > 0; o >>= 1) {
     if (tid < o) sh[tid] = fmaxf(sh[tid], sh[tid + o]);
     __syncthreads();
   }
-  const float thr = sh[0] * tau;
-  if (tid == 0) base_s = 0;
-  __syncthreads();
+  if (tid == 0) peak[g] = sh[0];
+}
 
-  // ordered compaction of the patches that survive the threshold (deterministic summation order)
-  for (int n0 = 0; n0 < Np; n0 += CS_NT) {
-    const int n = n0 + tid;
+template <int CPT>
+__global__ __launch_bounds__(CS_NT) void refine_partial_kernel(const float* __restrict__ feat,
+                                                               const float* __restrict__ work,
+                                                               const float* __restrict__ peak, float tau,
+                                                               float* __restrict__ partial, float* __restrict__ partial_w,
+                                                               int C, int Np, int ntile) {
+  __shared__ float w_s[RF_TILE];
+  const int tile = blockIdx.x, g = blockIdx.y, tid = threadIdx.x;
+  const int n0 = tile * RF_TILE;
+  const int count = min(RF_TILE, Np - n0);
+  const float thr = peak[g] * tau;
+  if (tid < RF_TILE) {
     float w = 0.0f;
-    if (n < Np) { w = wrow[n]; if (w < thr) w = 0.0f; }
-    const bool act = w != 0.0f;
-    const unsigned long long bal = __ballot(act);
-    const int pre = __popcll(bal & ((1ull << lane) - 1ull));
-    if (lane == 0) wave_cnt[wave] = __popcll(bal);
-    __syncthreads();
-    int off = base_s;
-    for (int w2 = 0; w2 < wave; ++w2) off += wave_cnt[w2];
-    if (act) { list_n[off + pre] = n; list_w[off + pre] = w; }
-    __syncthreads();
-    if (tid == 0) base_s += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
-    __syncthreads();
+    if (tid < count) { w = work[(size_t)g * Np + n0 + tid]; if (w < thr) w = 0.0f; }   // cos_map1[cos_map1 < thr] *= 0
+    w_s[tid] = w;
   }
-  const int cnt = base_s;
+  __syncthreads();
   float acc[CPT], wsum = 0.0f;
 #pragma unroll
   for (int i = 0; i < CPT; ++i) acc[i] = 0.0f;
-  for (int j = 0; j < cnt; ++j) {
-    const float w = list_w[j];
-    const float* frow = feat + (size_t)list_n[j] * C;
+  for (int j = 0; j < count; ++j) {
+    const float w = w_s[j];
+    if (w == 0.0f) continue;                      // workgroup-uniform
     wsum += w;
+    const float* frow = feat + (size_t)(n0 + j) * C;
 #pragma unroll
     for (int i = 0; i < CPT; ++i) {
       const int c = tid + i * CS_NT;
       if (c < C) acc[i] = fmaf(w, frow[c], acc[i]);
     }
   }
-  const float den = fmaxf(wsum, 1e-8f);
+  float* pp = partial + ((size_t)g * ntile + tile) * C;
 #pragma unroll
   for (int i = 0; i < CPT; ++i) {
     const int c = tid + i * CS_NT;
-    if (c < C) seeds_out[(size_t)g * C + c] = acc[i] / den;
+    if (c < C) pp[c] = acc[i];
+  }
+  if (tid == 0) partial_w[g * ntile + tile] = wsum;
+}
+
+__global__ __launch_bounds__(CS_NT) void refine_finish_kernel(const float* __restrict__ partial,
+                                                              const float* __restrict__ partial_w,
+                                                              float* __restrict__ seeds_out, int C, int ntile) {
+  const int g = blockIdx.x, tid = threadIdx.x;
+  float wsum = 0.0f;
+  for (int t = 0; t < ntile; ++t) wsum += partial_w[g * ntile + t];
+  const float den = fmaxf(wsum, 1e-8f);
+  for (int c = tid; c < C; c += CS_NT) {
+    float v = 0.0f;
+    for (int t = 0; t < ntile; ++t) v += partial[((size_t)g * ntile + t) * C + c];
+    seeds_out[(size_t)g * C + c] = v / den;
   }
 }
 
-struct RefineWs { size_t invn, invnp, ints, part_stats, work, total; int nt1; };
+struct RefineWs { size_t invn, invnp, ints, part_stats, work, peak, partial, partial_w, total; int nt1, ntile; };
 RefineWs refine_ws(int C, int Np, int Gp) {
   RefineWs w;
   auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
@@ -546,6 +556,10 @@ RefineWs refine_ws(int C, int Np, int Gp) {
   w.ints = o; o = al(o + 64);
   w.part_stats = o; o = al(o + (size_t)w.nt1 * PMAX * 8);
   w.work = o; o = al(o + (size_t)Gp * Np * 4);
+  w.ntile = as_ceil_div(Np, RF_TILE);
+  w.peak = o; o = al(o + (size_t)PMAX * 4);
+  w.partial = o; o = al(o + (size_t)Gp * w.ntile * C * 4);
+  w.partial_w = o; o = al(o + (size_t)Gp * w.ntile * 4);
   w.total = o;
   return w;
 }
@@ -567,7 +581,6 @@ extern "C" int as_refine_similarity(const float* feat, const float* seeds, const
   const int Np = Hp * Wp;
   const RefineWs L = refine_ws(C, Np, Gp);
   AS_REQUIRE(ws_bytes >= L.total, AS_E_WORKSPACE, "as_refine_similarity: workspace %zu < %zu bytes", ws_bytes, L.total);
-  AS_REQUIRE((size_t)Np * 8 <= 150 * 1024, AS_E_UNSUPPORTED, "as_refine_similarity: Np=%d too large for the LDS list", Np);
   hipStream_t s = (hipStream_t)stream;
   char* w = (char*)ws;
   float* invn = (float*)(w + L.invn);
@@ -575,26 +588,27 @@ extern "C" int as_refine_similarity(const float* feat, const float* seeds, const
   int32_t* ints = (int32_t*)(w + L.ints);
   float* part_stats = (float*)(w + L.part_stats);
   float* work = (float*)(w + L.work);
+  float* peak = (float*)(w + L.peak);
+  float* partial = (float*)(w + L.partial);
+  float* partial_w = (float*)(w + L.partial_w);
   const int cpt = as_ceil_div(C, CS_NT);
-  const size_t lds = (size_t)Np * 8;
 
   hipLaunchKernelGGL(refine_setup_kernel, dim3(1), dim3(64), 0, s, ints, Hp, Wp);
   hipLaunchKernelGGL(row_invnorm_kernel, dim3(as_ceil_div(Np, 4)), dim3(CS_NT), 0, s, feat, invn, Np, C);
   const float* cur = seeds;
   for (int lvl = 0; lvl <= refine_times; ++lvl) {
     if (lvl > 0) {
-#define AS_AGG(CPT)                                                                                               \
-  do {                                                                                                            \
-    (void)hipFuncSetAttribute((const void*)refine_aggregate_kernel<CPT>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                              (int)lds);                                                                          \
-    hipLaunchKernelGGL((refine_aggregate_kernel<CPT>), dim3(Gp), dim3(CS_NT), lds, s, feat, work, tau, seeds_out, C, Np); \
-  } while (0)
+#define AS_AGG(CPT)                                                                                          \
+  hipLaunchKernelGGL((refine_partial_kernel<CPT>), dim3(L.ntile, Gp), dim3(CS_NT), 0, s, feat, work, peak, tau, \
+                     partial, partial_w, C, Np, L.ntile)
+      hipLaunchKernelGGL(refine_rowmax_kernel, dim3(Gp), dim3(CS_NT), 0, s, work, peak, Np);
       switch (cpt) {
         case 1: AS_AGG(1); break;
         case 2: AS_AGG(2); break;
         case 3: AS_AGG(3); break;
         default: AS_AGG(4); break;
       }
+      hipLaunchKernelGGL(refine_finish_kernel, dim3(Gp), dim3(CS_NT), 0, s, partial, partial_w, seeds_out, C, L.ntile);
 #undef AS_AGG
       cur = seeds_out;
     }

@@ -112,3 +112,124 @@ extern "C" int as_instance_maps(const float* sim_fg, const float* sim_bg, int L,
   AS_CHECK_LAUNCH("instance_maps");
   return AS_OK;
 }
+
+// =====================================================================================================
+// Thresholded + eroded candidate masks inside per-map crops.
+//   fg candidates of get_mask_points_single_box_cos_map_fg_bg (stdroi:442: erode(map > max*thr, 21) on the box
+//   crop), its bg candidates (:443, no erosion) and the full-map erosion of get_semantic_centers (:2011).
+// Erosion = min over the k x k window restricted to the crop (max_pool2d's implicit padding never wins),
+// done as two 1-D passes on a byte mask.
+// =====================================================================================================
+namespace {
+
+struct Crop { int x0, y0, x1, y1; };
+__device__ __forceinline__ Crop load_crop(const int32_t* crops, int m, int H, int W) {
+  Crop c;
+  if (crops == nullptr) { c.x0 = 0; c.y0 = 0; c.x1 = W; c.y1 = H; return c; }
+  c.x0 = min(max(crops[m * 4 + 0], 0), W); c.y0 = min(max(crops[m * 4 + 1], 0), H);
+  c.x1 = min(max(crops[m * 4 + 2], 0), W); c.y1 = min(max(crops[m * 4 + 3], 0), H);
+  return c;
+}
+
+__global__ void crop_meta_init_kernel(unsigned* mx, int32_t* counts, int M) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m < M) { mx[m] = 0u; counts[m] = 0; }
+}
+
+__global__ __launch_bounds__(RF_NT) void crop_max_kernel(const float* __restrict__ maps, const int32_t* __restrict__ crops,
+                                                         unsigned* __restrict__ mx, int H, int W) {
+  __shared__ float sh[RF_NT];
+  const int m = blockIdx.y;
+  const Crop c = load_crop(crops, m, H, W);
+  const int cw = max(c.x1 - c.x0, 0), ch = max(c.y1 - c.y0, 0);
+  float v = -INFINITY;
+  for (int i = blockIdx.x * RF_NT + threadIdx.x; i < cw * ch; i += gridDim.x * RF_NT) {
+    const int y = c.y0 + i / cw, x = c.x0 + i % cw;
+    v = fmaxf(v, maps[((size_t)m * H + y) * W + x]);
+  }
+  const float r = block_max(v, sh);
+  if (threadIdx.x == 0 && cw * ch > 0) atomicMax(&mx[m], f2ord(r));
+}
+
+// MODE 0: bin = in_crop && map > thr          (counts if FINAL)
+// MODE 1: out = AND of in[y][x-r..x+r] within the crop
+// MODE 2: out = AND of in[y-r..y+r][x] within the crop (counts)
+template <int MODE, bool FINAL>
+__global__ __launch_bounds__(RF_NT) void crop_mask_kernel(const float* __restrict__ maps, const uint8_t* __restrict__ in,
+                                                          const int32_t* __restrict__ crops,
+                                                          const unsigned* __restrict__ mx, float thr, int relative,
+                                                          int r, uint8_t* __restrict__ out, int32_t* __restrict__ counts,
+                                                          int H, int W) {
+  __shared__ int shc[RF_NT];
+  const int m = blockIdx.y;
+  const Crop c = load_crop(crops, m, H, W);
+  const size_t base = (size_t)m * H * W;
+  float t = thr;
+  if (MODE == 0 && relative) t = ord2f(mx[m]) * thr;        // map.max() * thr, fp32
+  int cnt = 0;
+  for (int i = blockIdx.x * RF_NT + threadIdx.x; i < H * W; i += gridDim.x * RF_NT) {
+    const int y = i / W, x = i - y * W;
+    const bool inside = x >= c.x0 && x < c.x1 && y >= c.y0 && y < c.y1;
+    bool v = false;
+    if (inside) {
+      if (MODE == 0) {
+        v = maps[base + i] > t;
+      } else if (MODE == 1) {
+        v = true;
+        for (int xx = max(x - r, c.x0); xx <= min(x + r, c.x1 - 1); ++xx) v = v && (in[base + (size_t)y * W + xx] != 0);
+      } else {
+        v = true;
+        for (int yy = max(y - r, c.y0); yy <= min(y + r, c.y1 - 1); ++yy) v = v && (in[base + (size_t)yy * W + x] != 0);
+      }
+    }
+    out[base + i] = v ? 1 : 0;
+    cnt += v ? 1 : 0;
+  }
+  if (FINAL) {
+    shc[threadIdx.x] = cnt;
+    __syncthreads();
+    for (int o = RF_NT / 2; o > 0; o >>= 1) {
+      if (threadIdx.x < o) shc[threadIdx.x] += shc[threadIdx.x + o];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0 && shc[0] > 0) atomicAdd(&counts[m], shc[0]);
+  }
+}
+
+}  // namespace
+
+extern "C" size_t as_crop_threshold_erode_workspace_bytes(int M, int H, int W) {
+  if (M <= 0 || H <= 0 || W <= 0) return 0;
+  return 2 * (((size_t)M * H * W + 255) / 256 * 256) + ((size_t)M * 4 + 255) / 256 * 256;
+}
+
+extern "C" int as_crop_threshold_erode(const float* maps, const int32_t* crops, float thr, int relative, int k,
+                                       uint8_t* mask, int32_t* counts, void* ws, size_t ws_bytes, int M, int H, int W,
+                                       as_stream_t stream) {
+  AS_REQUIRE(maps && mask && counts && ws, AS_E_BADARG, "as_crop_threshold_erode: null pointer");
+  AS_REQUIRE(M > 0 && H > 0 && W > 0 && k >= 1 && (k & 1) == 1, AS_E_BADARG, "as_crop_threshold_erode: bad sizes (k odd)");
+  AS_REQUIRE(ws_bytes >= as_crop_threshold_erode_workspace_bytes(M, H, W), AS_E_WORKSPACE,
+             "as_crop_threshold_erode: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  const size_t plane = ((size_t)M * H * W + 255) / 256 * 256;
+  uint8_t* t0 = (uint8_t*)ws;
+  uint8_t* t1 = t0 + plane;
+  unsigned* mx = (unsigned*)(t1 + plane);
+  const int bx = (int)(((size_t)H * W + RF_NT * 4 - 1) / (RF_NT * 4));
+  const int r = k / 2;
+  hipLaunchKernelGGL(crop_meta_init_kernel, dim3(as_ceil_div(M, 64)), dim3(64), 0, s, mx, counts, M);
+  if (relative) hipLaunchKernelGGL(crop_max_kernel, dim3(bx, M), dim3(RF_NT), 0, s, maps, crops, mx, H, W);
+  if (k == 1) {
+    hipLaunchKernelGGL((crop_mask_kernel<0, true>), dim3(bx, M), dim3(RF_NT), 0, s, maps, (const uint8_t*)nullptr, crops,
+                       mx, thr, relative, 0, mask, counts, H, W);
+  } else {
+    hipLaunchKernelGGL((crop_mask_kernel<0, false>), dim3(bx, M), dim3(RF_NT), 0, s, maps, (const uint8_t*)nullptr, crops,
+                       mx, thr, relative, 0, t0, counts, H, W);
+    hipLaunchKernelGGL((crop_mask_kernel<1, false>), dim3(bx, M), dim3(RF_NT), 0, s, maps, t0, crops, mx, thr, relative, r,
+                       t1, counts, H, W);
+    hipLaunchKernelGGL((crop_mask_kernel<2, true>), dim3(bx, M), dim3(RF_NT), 0, s, maps, t1, crops, mx, thr, relative, r,
+                       mask, counts, H, W);
+  }
+  AS_CHECK_LAUNCH("crop_threshold_erode");
+  return AS_OK;
+}

@@ -213,18 +213,20 @@ def ccl_2d(binary):
 
 
 def cam_boxes(cams, points, cam_thr, area_ratio, up=16, return_upsampled=False):
-    """cams [M,Hp,Wp] fp32, points [M,2] -> boxes [M,4], kept-pixel counts [M] (int32), optional [M,H,W]."""
+    """cams [M,Hp,Wp] fp32, points [M,2] -> boxes [M,4], kept-pixel counts [M] (int32); with
+    return_upsampled also the upsampled maps [M,H,W] and their per-map (min, max) [M,2]."""
     lib = _lib.load()
     _chk(cams, points, dtype=torch.float32)
     M, Hp, Wp = cams.shape
     boxes = torch.empty(M, 4, device=cams.device, dtype=torch.float32)
     status = torch.empty(M, device=cams.device, dtype=torch.int32)
     cams_up = torch.empty(M, Hp * up, Wp * up, device=cams.device, dtype=torch.float32) if return_upsampled else None
+    minmax = torch.empty(M, 2, device=cams.device, dtype=torch.float32) if return_upsampled else None
     nbytes = lib.as_cam_boxes_workspace_bytes(M, Hp, Wp, up)
     ws = torch.empty(nbytes, device=cams.device, dtype=torch.uint8)
     _lib.check(lib.as_cam_boxes(_p(cams), _p(points), float(cam_thr), float(area_ratio), M, Hp, Wp, up, _p(boxes),
-                                _p(status), _p(cams_up), _p(ws), nbytes, _stream()), "as_cam_boxes")
-    return (boxes, status, cams_up) if return_upsampled else (boxes, status)
+                                _p(status), _p(cams_up), _p(minmax), _p(ws), nbytes, _stream()), "as_cam_boxes")
+    return (boxes, status, cams_up, minmax) if return_upsampled else (boxes, status)
 
 
 def cosine_shift(feat, box_patch, obj_img, prot, n_shift, hp, wp, tau0=0.1, temp=0.1, return_trace=False):
@@ -284,3 +286,20 @@ def instance_maps(sim_fg, sim_bg, num_obj, hp, wp, up=16):
     _lib.check(lib.as_instance_maps(_p(sim_fg), _p(sim_bg), L, G, Gp, hp, wp, up, _p(map_fg), _p(map_bg), _p(ws), nbytes,
                                     _stream()), "as_instance_maps")
     return map_fg, map_bg
+
+
+def crop_threshold_erode(maps, crops, thr, relative, k):
+    """maps [M,H,W] fp32, crops [M,4] int32 (x0,y0,x1,y1 half-open) or None -> (mask uint8 [M,H,W], counts int32 [M]).
+    mask = erode_k(map > (thr * cropmax if relative else thr)) restricted to the crop (stdroi:442-443, :2011)."""
+    lib = _lib.load()
+    _chk(maps, dtype=torch.float32)
+    if crops is not None:
+        _chk(crops, dtype=torch.int32)
+    M, H, W = maps.shape
+    mask = torch.empty(M, H, W, device=maps.device, dtype=torch.uint8)
+    counts = torch.empty(M, device=maps.device, dtype=torch.int32)
+    nbytes = lib.as_crop_threshold_erode_workspace_bytes(M, H, W)
+    ws = torch.empty(nbytes, device=maps.device, dtype=torch.uint8)
+    _lib.check(lib.as_crop_threshold_erode(_p(maps), _p(crops), float(thr), 1 if relative else 0, int(k), _p(mask),
+                                           _p(counts), _p(ws), nbytes, M, H, W, _stream()), "as_crop_threshold_erode")
+    return mask, counts

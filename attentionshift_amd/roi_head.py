@@ -72,6 +72,21 @@ def _erode(x, k):
     return (-F.max_pool2d(-x.reshape(1, -1, shp[-2], shp[-1]), k, 1, k // 2)).reshape(shp)
 
 
+def _centre4(x, dy, dx):
+    return x[..., dy::STRIDE, dx::STRIDE]
+
+
+def _down16(x, presampled=False):
+    """F.interpolate(x, size/16, mode='bilinear') for an exact factor 16: source coordinate 16*i + 7.5, i.e. the
+    mean of pixels (16i+7, 16i+8) along each axis with weights 0.5/0.5 (products exact, one rounding per add,
+    identical to ATen's two fma steps).  presampled: x = [4, ...] stacked (7,7),(7,8),(8,7),(8,8) samples."""
+    if presampled:
+        a, b, c, d = x[0], x[1], x[2], x[3]
+    else:
+        a, b, c, d = _centre4(x, 7, 7), _centre4(x, 7, 8), _centre4(x, 8, 7), _centre4(x, 8, 8)
+    return 0.5 * (0.5 * a + 0.5 * b) + 0.5 * (0.5 * c + 0.5 * d)
+
+
 def _minmax_maps(a):
     """stdroi:329-333 norm_attns."""
     flat = a.flatten(1)
@@ -79,8 +94,32 @@ def _minmax_maps(a):
     return (a - lo) / (hi - lo)
 
 
+def rank_select(mask_flat, ranks):
+    """k-th set pixel of each row of a [G, H*W] 0/1 mask, in raster order (= the order of .nonzero()):
+    ranks [G,K] long (0-based) -> flat indices [G,K].  No host sync: prefix sum + binary search on the device."""
+    cum = mask_flat.to(torch.int32).cumsum(1, dtype=torch.int32)
+    return torch.searchsorted(cum, (ranks + 1).to(torch.int32), right=False)
+
+
 def sample_point_grid(maps, num_points, thr, is_pos, gt_points=None):
-    """stdroi:343-371.  Random draws come from torch's global CPU generator exactly like the reference."""
+    """stdroi:343-371.  Random draws come from torch's global CPU generator exactly like the reference
+    (`torch.randint(n, shape)` per object, in object order); candidate counts cost ONE host sync for all
+    objects and the drawn ranks are resolved on the device by rank_select (no .nonzero())."""
+    G, H, W = maps.shape
+    mask = (maps >= thr) if is_pos else (maps < thr)
+    counts = mask.flatten(1).sum(1).tolist()
+    if min(counts) < num_points:
+        return _sample_point_grid_slow(maps, num_points, thr, is_pos, gt_points)
+    ranks = []
+    for n in counts:
+        n_draw = len(range(0, n, n // num_points))
+        ranks.append((torch.randint(n, (n_draw,)) % n)[:num_points])
+    flat = rank_select(mask.flatten(1), torch.stack(ranks).to(maps.device))
+    return torch.stack((flat % W, flat // W), dim=-1)          # (x, y) = coords.flip(-1)
+
+
+def _sample_point_grid_slow(maps, num_points, thr, is_pos, gt_points=None):
+    """The rare branches of stdroi:354-364 (fewer candidates than points), one object at a time."""
     out = []
     for g, m in enumerate(maps):
         factor = 1.0
@@ -108,19 +147,49 @@ def seed_features(point_xy, feat_chw):
     return feat_chw.permute(1, 2, 0)[py, px].mean(dim=1)
 
 
-def mask_points_fg_bg(map_fg, map_bg, pos_thr, neg_thr, num_gt, corr_size):
-    """stdroi:433-461 on one crop."""
+def candidate_masks(map_fg, map_bg, crops, pos_thr, neg_thr, corr_size):
+    """Candidate pixels of stdroi:442-443 for every object at once, as full-size byte masks that are zero
+    outside each object's crop: fg = erode(map_fg > cropmax*pos_thr, corr_size), bg = map_bg > cropmax*neg_thr."""
+    pos, cp = ops.crop_threshold_erode(map_fg, crops, pos_thr, True, corr_size)
+    neg, cn = ops.crop_threshold_erode(map_bg, crops, neg_thr, True, 1)
+    return pos, neg, cp, cn
+
+
+def mask_sample_points(map_fg, map_bg, rois, pos_thr, neg_thr, num_gt, corr_size):
+    """stdroi:1980-1993 + 433-461 for all objects: coords [G,num_gt,2] (x,y) float, labels [G,num_gt] bool.
+    One host sync (candidate counts); `torch.randperm(n)` per object from the global CPU generator in object
+    order like the reference; the drawn ranks index the concatenation [fg candidates, bg candidates] in raster
+    order inside the crop, resolved on the device by rank_select."""
+    G, H, W = map_fg.shape
     dev = map_fg.device
-    pos = _erode((map_fg > map_fg.max() * pos_thr).float(), corr_size).nonzero()
-    neg = (map_bg > map_bg.max() * neg_thr).nonzero()
-    both = torch.cat((pos, neg), dim=0)
-    lab = torch.cat((torch.ones(pos.shape[0], dtype=torch.bool, device=dev), torch.zeros(neg.shape[0], dtype=torch.bool, device=dev)))
-    pick = torch.randperm(both.shape[0])[:num_gt].to(dev)
-    if pick.shape[0] < num_gt:
-        if pick.shape[0] == 0:
-            return -torch.ones(num_gt, 2, dtype=torch.float, device=dev), torch.zeros(num_gt, dtype=torch.bool, device=dev)
-        pick = _fill_in(pick, num_gt)       # NB: the reference's 1-D repeat bug (2-D index) is not reproduced
-    return both[pick], lab[pick]
+    crops = rois.int().contiguous()                      # stdroi:1981: rois[i].int().tolist()
+    pos, neg, cp, cn = candidate_masks(map_fg.contiguous(), map_bg.contiguous(), crops, pos_thr, neg_thr, corr_size)
+    counts = torch.stack((cp, cn), dim=1).tolist()
+    ranks, empty = [], []
+    for g in range(G):
+        n = counts[g][0] + counts[g][1]
+        pick = torch.randperm(n)[:num_gt]
+        if pick.shape[0] < num_gt:
+            if pick.shape[0] == 0:
+                empty.append(g)
+                pick = torch.zeros(num_gt, dtype=torch.long)
+            else:
+                pick = _fill_in(pick, num_gt)     # NB: the reference's 1-D repeat bug (2-D index) is not reproduced
+        ranks.append(pick)
+    ranks = torch.stack(ranks).to(dev)
+    n_pos = cp.long()[:, None]
+    is_pos = ranks < n_pos
+    idx_pos = rank_select(pos.flatten(1), torch.where(is_pos, ranks, torch.zeros_like(ranks)))
+    idx_neg = rank_select(neg.flatten(1), torch.where(is_pos, torch.zeros_like(ranks), ranks - n_pos))
+    flat = torch.where(is_pos, idx_pos, idx_neg).clamp(max=H * W - 1)
+    coords = torch.stack((flat % W, flat // W), dim=-1).float()
+    labels = is_pos
+    for g in empty:                                       # stdroi:451-455: -1 points, later ignored
+        x0, y0 = crops[g, 0].float(), crops[g, 1].float()
+        coords[g, :, 0] = -1 + x0
+        coords[g, :, 1] = -1 + y0
+        labels[g] = False
+    return coords, labels
 
 
 def grid_seed_coords(maps, rois, thr=0.35, n_points=20):
@@ -150,68 +219,106 @@ def filter_parts(sim, fg_inter, pos_thr=0.85):
     return score >= pos_thr
 
 
-def merge_parts(prot_list, thr):
-    """stdroi:278-294 merge_maps."""
-    out = []
-    for prot in prot_list:
-        if prot.shape[0] == 0:
-            out.append([])
-            continue
-        u = _unit(prot)
-        link = (torch.triu(u @ u.t(), diagonal=0) >= thr).to(prot.dtype)
-        merged = []
-        for i in range(link.shape[0]):
-            wgt = link[i].clone()
-            if wgt.sum() > 0:
-                merged.append((wgt @ prot) / (wgt.sum() + 1e-8))
-            link[wgt > 0] *= 0
-        out.append(torch.stack(merged))
+def merge_plan(keep, link):
+    """Greedy upper-triangular grouping of stdroi:278-294 on the host (numpy, a few hundred bytes).
+    keep [P] bool, link [P,P] bool (cos >= thr) -> list of member-index lists over the ORIGINAL prototype ids."""
+    idx = np.flatnonzero(keep)
+    sub = np.triu(link[np.ix_(idx, idx)]).astype(bool)
+    groups = []
+    for i in range(len(idx)):
+        row = sub[i].copy()
+        if row.any():
+            groups.append(idx[row].tolist())
+        sub[row] = False                                   # sim_triu[weight > 0] *= 0
+    return groups
+
+
+def merge_parts(prot, keep, thr):
+    """stdroi:278-294 merge_maps for all objects: prot [G,P,C], keep [G,P] ->
+    (list over objects of merged prototypes [m_g, C] or []).  One host sync for the whole image."""
+    G, P, C = prot.shape
+    u = _unit(prot)
+    link = (u @ u.transpose(1, 2)) >= thr
+    host = torch.cat((keep[:, None, :], link), dim=1).cpu().numpy()          # [G, 1+P, P]
+    plans = [merge_plan(host[g, 0], host[g, 1:]) for g in range(G)]
+    m_max = max((len(p) for p in plans), default=0)
+    if m_max == 0:
+        return [[] for _ in range(G)]
+    wgt = np.zeros((G, m_max, P), dtype=np.float32)
+    for g, plan in enumerate(plans):
+        for i, members in enumerate(plan):
+            wgt[g, i, members] = 1.0
+    wgt = torch.from_numpy(wgt).to(prot.device)
+    merged = torch.bmm(wgt, prot) / (wgt.sum(-1, keepdim=True) + 1e-8)        # matmul(weight, prot) / (sum + 1e-8)
+    return [merged[g, :len(plans[g])] if plans[g] else [] for g in range(G)]
+
+
+def part_similarity(prot_list, feat_chw):
+    """stdroi:297-301 cal_similarity for every object with ONE normalisation of the feature map."""
+    C, hp, wp = feat_chw.shape
+    sizes = [0 if isinstance(p, list) else p.shape[0] for p in prot_list]
+    if sum(sizes) == 0:
+        return [torch.zeros(0, 0) for _ in prot_list]
+    allp = torch.cat([p for p in prot_list if not isinstance(p, list)])
+    sim = (_unit(allp) @ _unit(feat_chw.flatten(1).t()).t()).reshape(-1, hp, wp)
+    out, off = [], 0
+    for n in sizes:
+        out.append(sim[off:off + n] if n else torch.zeros(0, 0))
+        off += n
     return out
 
 
-def part_similarity(prot, feat_chw):
-    """stdroi:297-301 cal_similarity."""
-    if isinstance(prot, list):
-        return torch.zeros(0, 0)
-    C, hp, wp = feat_chw.shape
-    return (_unit(prot) @ _unit(feat_chw.flatten(1).t()).t()).reshape(-1, hp, wp)
-
-
 def part_centers(maps, rois, obj_label, feat_chw, num_max_keep=50, num_max_obj=3):
-    """stdroi:222-262 get_center_coord_with_feat (same eight outputs, same order)."""
-    coords, labels, feats, owner = [], [], [], []
+    """stdroi:222-262 get_center_coord_with_feat (same eight outputs, same order).  The per-part statistics
+    (peak centroid, >0.9 area, inside-box test) are computed for all parts at once on the device and read
+    back in one transfer; the visiting order / cap logic then runs on those few numbers."""
+    dev = rois[0].device if len(rois) else feat_chw.device
     split = [0 for _ in range(len(maps))]
-    for g, m in enumerate(maps):
-        if m.shape[0] == 0:
+    sizes = [int(m.shape[0]) for m in maps]
+    empty = ([torch.zeros(0, 2, dtype=rois[0].dtype, device=dev), torch.zeros(0, dtype=obj_label[0].dtype, device=dev)],
+             [], [], [], split, torch.zeros(0, 2, dtype=rois[0].dtype, device=dev),
+             torch.zeros(0, dtype=obj_label[0].dtype, device=dev), torch.zeros(0, dtype=torch.long, device=dev))
+    if sum(sizes) == 0:
+        return empty
+    allm = torch.cat([m for m in maps if m.shape[0] > 0])                     # [M, hp, wp]
+    owner = torch.cat([torch.full((n,), g, dtype=torch.long) for g, n in enumerate(sizes)]).to(dev)
+    hp, wp = allm.shape[-2:]
+    peak = allm.flatten(1).max(1)[0][:, None, None]
+    at_peak = (allm >= peak).float()
+    cnt = at_peak.sum(dim=[-2, -1])
+    ys = torch.arange(hp, device=dev, dtype=torch.float32)[None, :, None]
+    xs = torch.arange(wp, device=dev, dtype=torch.float32)[None, None, :]
+    cy = (at_peak * ys).sum(dim=[-2, -1]) / cnt                                # mean of nonzero().float() rows
+    cx = (at_peak * xs).sum(dim=[-2, -1]) / cnt
+    area = (allm > 0.9).sum(dim=[-2, -1])
+    c = (torch.stack((cx, cy), dim=1) + 0.5) * STRIDE
+    box = rois[owner]
+    inside = (c[:, 0] >= box[:, 0]) & (c[:, 0] <= box[:, 2]) & (c[:, 1] >= box[:, 1]) & (c[:, 1] <= box[:, 3])
+    host = torch.stack((area.float(), inside.float()), dim=1).cpu().numpy()    # the one sync
+    chosen, off = [], 0
+    for g, n in enumerate(sizes):
+        if n == 0:
             continue
-        peak = m.flatten(1).topk(dim=1, k=1)[0][:, -1, None, None]
-        at_peak = (m >= peak).nonzero().float()
-        x0, y0, x1, y1 = rois[g]
-        order = (m > 0.9).sum(dim=[-2, -1]).argsort(descending=True, dim=0, stable=True)
-        for i in range(m.shape[0]):
+        order = np.argsort(-host[off:off + n, 0], kind="stable")               # argsort(descending, stable)
+        for i in range(n):
             if i > num_max_obj:
                 break
-            xy = at_peak[at_peak[:, 0] == order[i]].mean(dim=0)[1:].flip(0)
-            c = (xy + 0.5) * STRIDE
-            if (c[0] >= x0) & (c[0] <= x1) & (c[1] >= y0) & (c[1] <= y1):
-                coords.append(c)
-                labels.append(obj_label[g])
-                owner.append(g)
-                feats.append(feat_chw[:, xy[1].long(), xy[0].long()])
+            j = off + int(order[i])
+            if host[j, 1] > 0:
+                chosen.append(j)
                 split[g] += 1
-    dev = rois[0].device
-    if len(coords) == 0:
-        z2 = torch.zeros(0, 2, dtype=rois[0].dtype, device=dev)
-        zl = torch.zeros(0, dtype=obj_label[0].dtype, device=dev)
-        return [z2, zl], [], [], [], split, z2.clone(), zl.clone(), torch.zeros(0, dtype=torch.long, device=dev)
-    coords, labels, feats = torch.stack(coords), torch.stack(labels), torch.stack(feats)
+        off += n
+    if not chosen:
+        return empty
+    sel = torch.as_tensor(chosen, device=dev, dtype=torch.long)
+    coords, labels = c[sel], obj_label[owner[sel]]
+    feats = feat_chw[:, cy[sel].long(), cx[sel].long()].t()
     coords_org, labels_org = coords.clone(), labels.clone()
     coord_split, feats_split = list(coords.split(split, dim=0)), list(feats.split(split, dim=0))
     if coords.shape[0] > num_max_keep:
         pick = torch.randperm(coords.shape[0], device=coords.device)[:num_max_keep]
         coords, labels = coords[pick], labels[pick]
-    return ([coords, labels], coord_split, feats_split, feats, split, coords_org, labels_org,
-            torch.tensor(owner, device=dev, dtype=torch.long))
+    return ([coords, labels], coord_split, feats_split, feats, split, coords_org, labels_org, owner[sel])
 
 
 def median_area_selector(boxes_per_img, labels_per_img=None, roi_feature_map=None):
@@ -271,12 +378,17 @@ class AttnShiftRoIHead(nn.Module):
                             "(dense [B,N,N] attention maps are never materialised on this path)")
         return ops.rollout_rows(states, num_proposals)
 
-    def refine_maps(self, attn_sel, feat_chw, rois, gt_points, refine_times, obj_tau):
-        """B2 (stdroi:1000-1019).  attn_sel [G,H,W], feat [C,hp,wp].  Returns map_fg, map_bg [R+1,G,H,W],
-        points_fg, points_bg, fg_feat, bg_feat."""
+    def refine_maps(self, attn_sel, feat_chw, rois, gt_points, refine_times, obj_tau, minmax=None):
+        """B2 (stdroi:1000-1019).  attn_sel [G,H,W], feat [C,hp,wp]; minmax [G,2] = per-map (min,max) if the
+        caller already has them (as_cam_boxes does).  Returns map_fg, map_bg [R+1,G,H,W], points_fg, points_bg,
+        fg_feat, bg_feat."""
         G = attn_sel.shape[0]
         C, hp, wp = feat_chw.shape
-        nm = _minmax_maps(attn_sel)
+        if minmax is None:
+            nm = _minmax_maps(attn_sel)
+        else:                                                   # norm_attns (:329-333) with known extrema
+            lo, hi = minmax[:, 0][:, None, None], minmax[:, 1][:, None, None]
+            nm = (attn_sel - lo) / (hi - lo)
         pts_bg = sample_point_grid(nm, 20, 0.1, False)
         pts_fg = sample_point_grid(nm, 20, 0.2, True, gt_points)
         pts_supp = sample_point_grid(nm.mean(0, keepdim=True), 20, 0.1, False)
@@ -292,21 +404,16 @@ class AttnShiftRoIHead(nn.Module):
 
     def get_mask_sample_points_roi_best_attn_feat_refine(self, attn, rois, attn_idx, vit_feat, pos_thr=0.6, neg_thr=0.6,
                                                          num_gt=20, corr_size=21, refine_times=2, obj_tau=0.85,
-                                                         gt_points=None):
+                                                         gt_points=None, minmax=None):
         """stdroi:1966-1993 (same argument meaning and return order)."""
         G = attn.shape[1]
-        attn_sel = attn[attn_idx, torch.arange(G, device=attn.device)].contiguous()
-        map_fg, map_bg, pts_a, pts_b, f_fg, f_bg = self.refine_maps(attn_sel, vit_feat, rois, gt_points, refine_times, obj_tau)
-        cs, ls = [], []
-        for g in range(G):
-            x0, y0, x1, y1 = rois[g].int().tolist()
-            c, l = mask_points_fg_bg(map_fg[-1][g][y0:y1, x0:x1], map_bg[-1][g][y0:y1, x0:x1], pos_thr, neg_thr, num_gt, corr_size)
-            c = c.clone()
-            c[:, 0] += y0
-            c[:, 1] += x0
-            cs.append(c.flip(1))
-            ls.append(l)
-        return torch.stack(cs).float(), torch.stack(ls), map_fg, map_bg, pts_a, pts_b, f_fg, f_bg
+        ar = torch.arange(G, device=attn.device)
+        attn_sel = attn[attn_idx, ar].contiguous()
+        mm = None if minmax is None else minmax[attn_idx, ar]
+        map_fg, map_bg, pts_a, pts_b, f_fg, f_bg = self.refine_maps(attn_sel, vit_feat, rois, gt_points, refine_times,
+                                                                    obj_tau, mm)
+        coords, labels = mask_sample_points(map_fg[-1], map_bg[-1], rois, pos_thr, neg_thr, num_gt, corr_size)
+        return coords, labels, map_fg, map_bg, pts_a, pts_b, f_fg, f_bg
 
     def mean_shift_grid_prototype(self, maps, vit_feat, rois=None, thr=0.35, n_shift=5, output_size=(4, 4), tau=0.1,
                                   temp=0.1, n_points=20):
@@ -326,16 +433,19 @@ class AttnShiftRoIHead(nn.Module):
                              merge_thr=0.85, num_semantic_points=3):
         """stdroi:1995-2031 (same nine outputs)."""
         hp, wp = vit_feat.shape[-2:]
-        core = _erode((map_cos_fg > pos_thr).float()[None], 11)[0]
-        fg_inter = F.interpolate(core.unsqueeze(0), (hp, wp), mode="bilinear")[0]
-        bg_inter = F.interpolate(map_cos_bg.unsqueeze(0).max(dim=1, keepdim=True)[0], (hp, wp), mode="bilinear")[0]
+        G, H, W = map_cos_fg.shape
+        # :2011-2013.  erode_11(map > thr) at full resolution, then the bilinear /16 down-sampling, which for an
+        # exact factor of 16 reads only the 2x2 centre pixels of each patch with weights 1/2 (bit-identical)
+        core, _ = ops.crop_threshold_erode(map_cos_fg.contiguous(), None, pos_thr, False, 11)
+        fg_inter = _down16(core.float())
+        bg_inter = _down16(torch.stack([_centre4(map_cos_bg, dy, dx) for dy in (7, 8) for dx in (7, 8)]).amax(dim=1, keepdim=False),
+                           presampled=True)[None]
         map_fg = (fg_inter > pos_thr).to(fg_inter.dtype)
         prot, sim = self.mean_shift_grid_prototype(map_fg, vit_feat, rois, tau=0.1, temp=0.1, n_shift=refine_times)
-        G = map_cos_fg.shape[0]
-        keep = filter_parts(sim.unflatten(0, (G, sim.shape[0] // G)), fg_inter)
-        counts = keep.sum(dim=-1).tolist()
-        merged = merge_parts(prot[keep.flatten()].split(counts, dim=0), thr=merge_thr)
-        sim_parts = [part_similarity(p, vit_feat) for p in merged]
+        P = sim.shape[0] // G
+        keep = filter_parts(sim.unflatten(0, (G, P)), fg_inter)
+        merged = merge_parts(prot.unflatten(0, (G, P)), keep, merge_thr)
+        sim_parts = part_similarity(merged, vit_feat)
         (centers, split, feat_split, feats, num_parts, coords_org, labels_org, corres) = part_centers(
             sim_parts, rois, gt_labels, vit_feat, num_max_obj=num_semantic_points)
         return centers, split, sim_parts, feat_split, feats, num_parts, coords_org, labels_org, corres
@@ -375,16 +485,17 @@ class AttnShiftRoIHead(nn.Module):
         pts = torch.cat([point_targets[i].float().repeat(Lc, 1) for i in range(num_imgs)]).contiguous()
         if cams_lr.shape[0] == 0:
             raise RuntimeError("seed_pseudo_gt: no matched point tokens in the batch")
-        boxes, status, cams_up = ops.cam_boxes(cams_lr, pts, self.bbox_head.seed_thr, self.bbox_head.seed_multiple,
-                                               STRIDE, True)
+        boxes, status, cams_up, cam_minmax = ops.cam_boxes(cams_lr, pts, self.bbox_head.seed_thr,
+                                                           self.bbox_head.seed_multiple, STRIDE, True)
         if bool((status == 0).any()):
             # the reference raises here too (torch.stack of an empty list, stdroi:80)
             raise RuntimeError("seed_pseudo_gt: a CAM has no foreground component (constant attention map)")
-        gt_scale_bboxes, attn_maps_dealed, off = [], [], 0
+        gt_scale_bboxes, attn_maps_dealed, attn_minmax, off = [], [], [], 0
         for i in range(num_imgs):
             n = Lc * counts[i]
             gt_scale_bboxes.append(boxes[off:off + n].reshape(Lc, counts[i], 4).permute(1, 0, 2).contiguous())
             attn_maps_dealed.append(cams_up[off:off + n].reshape(Lc, counts[i], H, W))
+            attn_minmax.append(cam_minmax[off:off + n].reshape(Lc, counts[i], 2))
             off += n
 
         gt_box_index = self.layer_selector(gt_scale_bboxes, gt_labels, roi_feature_map)
@@ -406,9 +517,9 @@ class AttnShiftRoIHead(nn.Module):
                 self.get_mask_sample_points_roi_best_attn_feat_refine(
                     attn_maps_dealed[i], pseudo_boxes[i], gt_box_index[i], vit_feat=feat, pos_thr=pos_mask_thr,
                     neg_thr=neg_mask_thr, num_gt=num_mask_point_gt, corr_size=corr_size, obj_tau=obj_tau,
-                    gt_points=gt_points[i])
+                    gt_points=gt_points[i], minmax=attn_minmax[i])
             (centers, centers_split, sim_fg, feat_split, feat_centers, num_parts_obj, c_org, l_org, corres) = \
-                self.get_semantic_centers(map_fg[-1].clone(), map_bg[-1].clone(), pseudo_boxes[i], feat,
+                self.get_semantic_centers(map_fg[-1], map_bg[-1], pseudo_boxes[i], feat,
                                           pos_thr=pos_mask_thr, refine_times=self.mean_shift_times_local,
                                           gt_labels=gt_labels[i], num_semantic_points=self.num_semantic_points)
             out["semantic_centers_feat_split"].append(feat_split)
@@ -424,8 +535,9 @@ class AttnShiftRoIHead(nn.Module):
             coords_sc_org.append(c_org)
             labels_sc_org.append(l_org)
             out["corres_gts"].append(corres)
-            peak = map_fg[-1].flatten(1).max(1)[0][:, None, None]
-            out["pseudo_gt_masks"].append((map_fg[-1] > peak * pos_mask_thr).to(torch.uint8).cpu().numpy())   # stdroi:2356
+            # stdroi:2356-2358: (map > rowmax * thr) as uint8 on the host
+            mask_u8, _ = ops.crop_threshold_erode(map_fg[-1].contiguous(), None, pos_mask_thr, True, 1)
+            out["pseudo_gt_masks"].append(mask_u8.cpu().numpy())
             out["inst_fg_feat"].append(feats_fg)
             out["inst_bg_feat"].append(feats_bg)
         out["semantic_centers_org"] = (coords_sc_org, labels_sc_org)

@@ -90,7 +90,8 @@ def cpu_baseline():
     import attnshift_oracle as O
     from attentionshift_amd import synthetic
 
-    torch.set_num_threads(os.cpu_count() or 1)
+    # many-core hosts thrash on the small ops of this path: cap the pool and report what was used
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
     cores = torch.get_num_threads()
     D, h, T = CFG["embed_dim"], CFG["heads"], CFG["point_tokens"]
     hp = wp = CFG["img"] // CFG["patch"]

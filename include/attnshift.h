@@ -102,11 +102,12 @@ int as_ccl_2d(const uint8_t* img /*[M,H,W]*/, int32_t* labels /*[M,H,W]*/, int M
  * cam_thr, CCL, keep components with area >= area_ratio * max area, tight box, 'expand' about the
  * point, clip to the image.  boxes [M,4] fp32 (x0,y0,x1,y1); status[m] = number of kept pixels
  * (0 = the reference would have raised).  cams_up, if not NULL, receives the upsampled maps
- * [M,H,W] fp32 (the reference keeps them as attn_maps_dealed, stdroi:2282). */
+ * [M,H,W] fp32 (the reference keeps them as attn_maps_dealed, stdroi:2282); minmax, if not NULL,
+ * their per-map (min, max) [M,2] (reused by norm_attns, stdroi:329). */
 size_t as_cam_boxes_workspace_bytes(int M, int Hp, int Wp, int up);
 int as_cam_boxes(const float* cams /*[M,Hp,Wp]*/, const float* points /*[M,2] (x,y)*/, float cam_thr,
                  float area_ratio, int M, int Hp, int Wp, int up, float* boxes, int32_t* status,
-                 float* cams_up, void* ws, size_t ws_bytes, as_stream_t stream);
+                 float* cams_up, float* minmax, void* ws, size_t ws_bytes, as_stream_t stream);
 
 /* Mean-shift token clustering (stdroi:830-854 cosine_shift_batch + :882-908 update_density_batch,
  * with the box masking of :1819-1824 folded in):
@@ -137,6 +138,17 @@ int as_refine_similarity(const float* feat, const float* seeds, const int32_t* b
 size_t as_instance_maps_workspace_bytes(int L, int G);
 int as_instance_maps(const float* sim_fg, const float* sim_bg, int L, int G, int Gp, int Hp, int Wp, int up,
                      float* map_fg, float* map_bg, void* ws, size_t ws_bytes, as_stream_t stream);
+
+/* Thresholded + eroded candidate masks inside per-map crops: the fg candidates of
+ * get_mask_points_single_box_cos_map_fg_bg (stdroi:442, erode(map > max*thr, 21) on the box crop), its bg
+ * candidates (:443, k = 1) and the full-map erosion of get_semantic_centers (:2011, crops = NULL, absolute thr):
+ *   mask[m][y][x] = 1 iff (y,x) in crop_m and min over the k x k window (restricted to the crop) of [map > t_m]
+ *   t_m = relative ? thr * max(map over crop_m) : thr;  crops [M,4] int32 (x0,y0,x1,y1), half-open like the
+ *   reference's slicing [y0:y1, x0:x1];  counts[m] = number of set pixels. */
+size_t as_crop_threshold_erode_workspace_bytes(int M, int H, int W);
+int as_crop_threshold_erode(const float* maps /*[M,H,W]*/, const int32_t* crops, float thr, int relative, int k,
+                            uint8_t* mask /*[M,H,W]*/, int32_t* counts /*[M]*/, void* ws, size_t ws_bytes, int M, int H,
+                            int W, as_stream_t stream);
 
 #ifdef __cplusplus
 }

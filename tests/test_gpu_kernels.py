@@ -190,7 +190,8 @@ def test_cam_boxes_match_golden(ops, golden, tag):
     Lc, G, hp, wp = inp["cams"].shape
     cams = inp["cams"].reshape(Lc * G, hp, wp)
     pts = inp["points"].repeat(Lc, 1)
-    boxes, status, up = ops.cam_boxes(dev(cams), dev(pts), float(g["cam_thr"]), float(g["area_ratio"]), 16, True)
+    boxes, status, up, mm = ops.cam_boxes(dev(cams), dev(pts), float(g["cam_thr"]), float(g["area_ratio"]), 16, True)
+    assert_equal(torch.stack((up.flatten(1).min(1)[0], up.flatten(1).max(1)[0]), dim=1), mm, "per-map min/max")
     assert_equal(O.upsample_bilinear(inp["cams"], hp * 16, wp * 16).reshape(Lc * G, hp * 16, wp * 16), up, "upsampled CAMs")
     got = boxes.reshape(Lc, G, 4).permute(1, 0, 2)
     assert_equal(t(g["ref_boxes"]), got, "CAM boxes vs reference")
@@ -326,3 +327,27 @@ def test_refine_and_instance_maps_match_golden(ops, golden, tag):
     up_bg = O.upsample_bilinear(o_bg, H, W)
     ret = (1 - up_bg) * up_fg
     assert_equal(ret / ret.flatten(-2).max(-1)[0][..., None, None].clamp(1e-8), m_fg, "instance map arithmetic (bitwise)")
+
+
+def test_crop_threshold_erode_matches_torch(ops):
+    """B2'/B3 candidate masks vs erode((crop > cropmax*thr)) built from torch max_pool2d (stdroi:442, :2011)."""
+    g = torch.Generator().manual_seed(12)
+    M, H, W = 4, 160, 200
+    low = torch.rand(M, 1, 10, 13, generator=g)
+    maps = torch.nn.functional.interpolate(low, (H, W), mode="bilinear")[:, 0].contiguous()
+    crops = torch.tensor([[10, 20, 150, 120], [0, 0, 200, 160], [50, 60, 51, 61], [190, 150, 260, 300]], dtype=torch.int32)
+    for rel, thr, k in ((True, 0.6, 21), (True, 0.8, 1), (False, 0.5, 11)):
+        for use_crops in (True, False):
+            mask, cnt = ops.crop_threshold_erode(dev(maps), dev(crops) if use_crops else None, thr, rel, k)
+            ref = torch.zeros(M, H, W, dtype=torch.uint8)
+            for m in range(M):
+                x0, y0, x1, y1 = crops[m].tolist() if use_crops else (0, 0, W, H)
+                sub = maps[m][y0:y1, x0:x1]
+                if sub.numel() == 0:
+                    continue
+                b = (sub > (sub.max() * thr if rel else thr)).float()
+                if k > 1:
+                    b = O.erode(b, k)
+                ref[m][y0:y1, x0:x1] = b.to(torch.uint8)
+            assert_equal(ref, mask, f"mask rel={rel} k={k} crops={use_crops}")
+            assert_equal(ref.flatten(1).sum(1).int(), cnt, "counts")

@@ -76,11 +76,30 @@ def test_hungarian_matching_orders_objects_by_token_index():
     assert pos.tolist() == [2, 7, 9] and gt.tolist() == [1, 0, 2]
 
 
+def fake_crop_threshold_erode(maps, crops, thr, relative, k):
+    """Test-side torch stand-in for ops.crop_threshold_erode (the HIP op needs a GPU)."""
+    M, H, W = maps.shape
+    out = torch.zeros(M, H, W, dtype=torch.uint8)
+    counts = torch.zeros(M, dtype=torch.int32)
+    for m in range(M):
+        x0, y0, x1, y1 = (0, 0, W, H) if crops is None else [int(v) for v in crops[m]]
+        sub = maps[m][y0:y1, x0:x1]
+        if sub.numel() == 0:
+            continue
+        b = (sub > (sub.max() * thr if relative else thr)).float()
+        if k > 1:
+            b = O.erode(b, k)
+        out[m][y0:y1, x0:x1] = b.to(torch.uint8)
+        counts[m] = int(b.sum())
+    return out, counts
+
+
 @pytest.mark.parametrize("tag", ["tiny224", "mid320"])
-def test_sampling_and_mask_points_share_the_reference_rng_stream(golden, tag):
+def test_sampling_and_mask_points_share_the_reference_rng_stream(golden, tag, monkeypatch):
     g = golden(f"shift_{tag}")
     inp = shift_case_inputs(g)
     hp, wp, G = int(g["hp"]), int(g["wp"]), int(g["G"])
+    monkeypatch.setattr(RH.ops, "crop_threshold_erode", fake_crop_threshold_erode)
     cams = O.upsample_bilinear(inp["cams"], hp * 16, wp * 16)
     attn_sel = cams[t(g["best_idx"]), torch.arange(G)]
     torch.manual_seed(int(g["seed"]) + 1)
@@ -90,14 +109,39 @@ def test_sampling_and_mask_points_share_the_reference_rng_stream(golden, tag):
     supp = RH.sample_point_grid(nm.mean(0, keepdim=True), 20, 0.1, False)
     assert_equal(t(g["points_bg"]), bg, "bg points")
     assert_equal(t(g["points_fg"]), torch.cat((fg, supp)), "fg points")
-    rois = t(g["rois"])
-    for gi in range(G):
-        x0, y0, x1, y1 = rois[gi].int().tolist()
-        c, l = RH.mask_points_fg_bg(t(g["map_fg_last"])[gi][y0:y1, x0:x1], t(g["map_bg_last"])[gi][y0:y1, x0:x1],
-                                    float(g["pos_thr"]), float(g["neg_thr"]), int(g["num_gt"]), int(g["corr_size"]))
-        c = c.clone(); c[:, 0] += y0; c[:, 1] += x0
-        assert_equal(t(g["mask_coords"])[gi], c.flip(1).float(), f"mask coords obj {gi}")
-        assert_equal(t(g["mask_labels"])[gi], l, f"mask labels obj {gi}")
+    # the slow per-object path (rare branches) draws the same stream
+    torch.manual_seed(int(g["seed"]) + 1)
+    assert_equal(bg, RH._sample_point_grid_slow(nm, 20, 0.1, False), "slow path == fast path")
+    torch.manual_seed(int(g["seed"]) + 1)
+    for _ in range(3):                                   # consume the three sampling draws, then the mask points
+        pass
+    RH.sample_point_grid(nm, 20, 0.1, False); RH.sample_point_grid(nm, 20, 0.2, True, inp["points"])
+    RH.sample_point_grid(nm.mean(0, keepdim=True), 20, 0.1, False)
+    coords, labels = RH.mask_sample_points(t(g["map_fg_last"]), t(g["map_bg_last"]), t(g["rois"]), float(g["pos_thr"]),
+                                           float(g["neg_thr"]), int(g["num_gt"]), int(g["corr_size"]))
+    assert_equal(t(g["mask_coords"]), coords, "mask point coords")
+    assert_equal(t(g["mask_labels"]), labels, "mask point labels")
+
+
+def test_down16_is_bit_identical_to_interpolate():
+    gen = torch.Generator().manual_seed(4)
+    x = torch.rand(3, 224, 224, generator=gen)
+    ref = torch.nn.functional.interpolate(x[None], (14, 14), mode="bilinear")[0]
+    assert_close(ref, RH._down16(x), 1e-6, 1e-7, "bilinear /16 (general floats: last-bit rounding order only)")
+    b = (x > 0.5).float()        # the path only thresholds the down-sampled BINARY erosion map: exact
+    assert_equal(torch.nn.functional.interpolate(b[None], (14, 14), mode="bilinear")[0], RH._down16(b), "binary /16")
+
+
+def test_merge_plan_matches_reference_greedy_loop():
+    gen = torch.Generator().manual_seed(8)
+    base = torch.randn(4, 16, generator=gen)
+    prot = torch.cat([base[i:i + 1] + 0.05 * torch.randn(3, 16, generator=gen) for i in range(4)])   # 4 groups of 3
+    prot = prot[torch.randperm(12, generator=gen)]
+    keep = torch.ones(12, dtype=torch.bool)
+    keep[5] = False
+    ref = O.merge_parts([prot[keep]], 0.85)[0]
+    got = RH.merge_parts(prot[None], keep[None], 0.85)[0]
+    assert_close(ref, got, 1e-6, 1e-6, "merged prototypes")
 
 
 @pytest.mark.parametrize("tag", ["tiny224", "mid320"])
@@ -112,6 +156,7 @@ def test_semantic_center_host_logic_with_oracle_backed_shift(golden, tag, monkey
         return p.reshape(prot.shape), s.reshape(prot.shape[0], prot.shape[1], -1)
 
     monkeypatch.setattr(RH.ops, "cosine_shift", fake_cosine_shift)
+    monkeypatch.setattr(RH.ops, "crop_threshold_erode", fake_crop_threshold_erode)
     head = A.AttnShiftRoIHead(num_semantic_points=int(g["num_semantic_points"]), mean_shift_times_local=int(g["n_shift"]))
     res = head.get_semantic_centers(t(g["map_fg_last"]), t(g["map_bg_last"]), t(g["rois"]), inp["vit_feat"],
                                     pos_thr=float(g["pos_thr"]), refine_times=int(g["n_shift"]), gt_labels=inp["labels"],
@@ -121,6 +166,8 @@ def test_semantic_center_host_logic_with_oracle_backed_shift(golden, tag, monkey
     assert_close(t(g["coords_org"]), coords_org, 0, 0, "centre coords")
     assert_equal(g["corres_gt"], corres, "corres_gt")
     assert_equal(g["labels_org"], labels_org, "labels")
+    if g["feats_all"].shape[0]:
+        assert_close(t(g["feats_all"]), feats, 0, 0, "centre features")
     for i, n in enumerate(g["n_sim_parts"].tolist()):
         if n:
             assert_close(t(g[f"sim_parts{i}"]), sim_parts[i], 1e-4, 1e-5, f"sim_parts{i}")

@@ -1,0 +1,27 @@
+"""Summarise a rocprofv3 results .db (kernel trace) into a markdown table under profiles/.
+
+    python tools/rocprof_summary.py gpurun_out/prof1/r1_results.db profiles/r01_bench_kernel_stats.md "title"
+"""
+import sqlite3
+import sys
+
+
+def main(db, out, title):
+    c = sqlite3.connect(db)
+    rows = c.execute("select name, count(*), sum(duration), avg(duration), min(duration), max(duration), "
+                     "max(vgpr_count), max(lds_size) from kernels group by name order by sum(duration) desc").fetchall()
+    total = sum(r[2] for r in rows) or 1
+    lines = [f"# {title}", "", f"source: `{db}` (rocprofv3 --kernel-trace --stats); durations in microseconds", "",
+             "| kernel | calls | total us | avg us | min us | max us | % | VGPR | LDS B |", "|---|---|---|---|---|---|---|---|---|"]
+    for name, n, tot, avg, mn, mx, vg, lds in rows[:60]:
+        short = name if len(name) < 110 else name[:107] + "..."
+        lines.append(f"| `{short}` | {n} | {tot / 1e3:.1f} | {avg / 1e3:.2f} | {mn / 1e3:.2f} | {mx / 1e3:.2f} | "
+                     f"{100.0 * tot / total:.1f} | {vg} | {lds} |")
+    lines.append("")
+    lines.append(f"total kernel time {total / 1e6:.3f} ms over {sum(r[1] for r in rows)} dispatches")
+    open(out, "w").write("\n".join(lines) + "\n")
+    print("\n".join(lines[:40]))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else "rocprofv3 kernel stats")
