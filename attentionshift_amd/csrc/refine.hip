@@ -233,3 +233,119 @@ extern "C" int as_crop_threshold_erode(const float* maps, const int32_t* crops, 
   AS_CHECK_LAUNCH("crop_threshold_erode");
   return AS_OK;
 }
+
+// =====================================================================================================
+// Rank select: the k-th set pixel (raster order, = the order of torch's .nonzero()) of byte masks, used to turn the
+// reference's `coords[random_index]` (stdroi:368-369, :456) into a lookup that needs no compaction pass.
+//   counts   grid (chunks, M): set bytes per 4096-byte chunk
+//   select   grid (K, M), one wave per rank: prefix over the chunk counts, then inside the chunk
+// =====================================================================================================
+namespace {
+
+constexpr int RS_CHUNK = 4096;
+
+__device__ __forceinline__ int bytesum16(const uint8_t* p) {          // p 16-byte aligned, bytes are 0/1
+  const uint4 v = *reinterpret_cast<const uint4*>(p);
+  return (int)(((v.x * 0x01010101u) >> 24) + ((v.y * 0x01010101u) >> 24) + ((v.z * 0x01010101u) >> 24) +
+               ((v.w * 0x01010101u) >> 24));
+}
+
+__global__ __launch_bounds__(RF_NT) void rank_counts_kernel(const uint8_t* __restrict__ mask, int32_t* __restrict__ cc,
+                                                            int HW, int nchunk) {
+  __shared__ int sh[RF_NT];
+  const int c = blockIdx.x, m = blockIdx.y, tid = threadIdx.x;
+  const size_t base = (size_t)m * HW + (size_t)c * RS_CHUNK;
+  const int off = tid * 16;
+  int v = 0;
+  if (c * RS_CHUNK + off + 16 <= HW) {
+    v = bytesum16(mask + base + off);
+  } else {
+    for (int i = 0; i < 16; ++i)
+      if (c * RS_CHUNK + off + i < HW) v += mask[base + off + i] != 0;
+  }
+  sh[tid] = v;
+  __syncthreads();
+  for (int o = RF_NT / 2; o > 0; o >>= 1) {
+    if (tid < o) sh[tid] += sh[tid + o];
+    __syncthreads();
+  }
+  if (tid == 0) cc[(size_t)m * nchunk + c] = sh[0];
+}
+
+__device__ __forceinline__ int wave_excl_scan(int v, int lane) {
+  int inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int u = __shfl_up(inc, o);
+    if (lane >= o) inc += u;
+  }
+  return inc - v;
+}
+
+__global__ __launch_bounds__(64) void rank_select_kernel(const uint8_t* __restrict__ mask, const int32_t* __restrict__ cc,
+                                                         const int32_t* __restrict__ ranks, int32_t* __restrict__ out,
+                                                         int HW, int nchunk, int K) {
+  const int k = blockIdx.x, m = blockIdx.y, lane = threadIdx.x;
+  int r = ranks[(size_t)m * K + k];
+  const int32_t* c = cc + (size_t)m * nchunk;
+  // level 1: which chunk
+  const int cpl = (nchunk + 63) / 64;
+  int mine = 0;
+  for (int i = lane * cpl; i < min((lane + 1) * cpl, nchunk); ++i) mine += c[i];
+  const int before = wave_excl_scan(mine, lane);
+  const unsigned long long hit = __ballot(r >= before && r < before + mine);
+  if (hit == 0ull || r < 0) {                    // rank beyond the population
+    if (lane == 0) out[(size_t)m * K + k] = -1;
+    return;
+  }
+  const int owner = __ffsll((long long)hit) - 1;
+  int chunk = -1, rem = 0;
+  if (lane == owner) {
+    int acc = before;
+    for (int i = lane * cpl; i < min((lane + 1) * cpl, nchunk); ++i) {
+      if (r < acc + c[i]) { chunk = i; rem = r - acc; break; }
+      acc += c[i];
+    }
+  }
+  chunk = __shfl(chunk, owner);
+  rem = __shfl(rem, owner);
+  // level 2: inside the chunk, 64 bytes per lane
+  const size_t base = (size_t)m * HW + (size_t)chunk * RS_CHUNK;
+  const int off = lane * 64;
+  int cnt = 0;
+  for (int i = 0; i < 64; ++i)
+    if (chunk * RS_CHUNK + off + i < HW) cnt += mask[base + off + i] != 0;
+  const int b2 = wave_excl_scan(cnt, lane);
+  const unsigned long long hit2 = __ballot(rem >= b2 && rem < b2 + cnt);
+  const int owner2 = __ffsll((long long)hit2) - 1;
+  if (lane == owner2) {
+    int left = rem - b2;
+    for (int i = 0; i < 64; ++i) {
+      if (mask[base + off + i] != 0) {
+        if (left == 0) { out[(size_t)m * K + k] = chunk * RS_CHUNK + off + i; break; }
+        --left;
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" size_t as_rank_select_workspace_bytes(int M, int HW) {
+  if (M <= 0 || HW <= 0) return 0;
+  return ((size_t)M * as_ceil_div(HW, RS_CHUNK) * 4 + 255) / 256 * 256;
+}
+
+extern "C" int as_rank_select(const uint8_t* mask, const int32_t* ranks, int32_t* out, void* ws, size_t ws_bytes, int M,
+                              int HW, int K, as_stream_t stream) {
+  AS_REQUIRE(mask && ranks && out && ws, AS_E_BADARG, "as_rank_select: null pointer");
+  AS_REQUIRE(M > 0 && HW > 0 && K > 0 && HW % 16 == 0, AS_E_BADARG, "as_rank_select: bad sizes (HW %% 16 == 0)");
+  AS_REQUIRE(ws_bytes >= as_rank_select_workspace_bytes(M, HW), AS_E_WORKSPACE, "as_rank_select: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  const int nchunk = as_ceil_div(HW, RS_CHUNK);
+  int32_t* cc = (int32_t*)ws;
+  hipLaunchKernelGGL(rank_counts_kernel, dim3(nchunk, M), dim3(RF_NT), 0, s, mask, cc, HW, nchunk);
+  hipLaunchKernelGGL(rank_select_kernel, dim3(K, M), dim3(64), 0, s, mask, cc, ranks, out, HW, nchunk, K);
+  AS_CHECK_LAUNCH("rank_select");
+  return AS_OK;
+}

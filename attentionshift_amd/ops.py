@@ -303,3 +303,19 @@ def crop_threshold_erode(maps, crops, thr, relative, k):
     _lib.check(lib.as_crop_threshold_erode(_p(maps), _p(crops), float(thr), 1 if relative else 0, int(k), _p(mask),
                                            _p(counts), _p(ws), nbytes, M, H, W, _stream()), "as_crop_threshold_erode")
     return mask, counts
+
+
+def rank_select(mask, ranks):
+    """mask uint8 [M,HW] (0/1), ranks int [M,K] -> int64 [M,K] flat index of the ranks[m,k]-th set byte of row m in
+    raster order (= mask[m].nonzero()[rank]), -1 if out of range."""
+    lib = _lib.load()
+    _chk(mask, dtype=torch.uint8)
+    r32 = ranks.to(torch.int32).contiguous()
+    _chk(r32)
+    M, HW = mask.shape
+    K = r32.shape[1]
+    out = torch.empty(M, K, device=mask.device, dtype=torch.int32)
+    nbytes = lib.as_rank_select_workspace_bytes(M, HW)
+    ws = torch.empty(nbytes, device=mask.device, dtype=torch.uint8)
+    _lib.check(lib.as_rank_select(_p(mask), _p(r32), _p(out), _p(ws), nbytes, M, HW, K, _stream()), "as_rank_select")
+    return out.long()

@@ -96,9 +96,9 @@ def _minmax_maps(a):
 
 def rank_select(mask_flat, ranks):
     """k-th set pixel of each row of a [G, H*W] 0/1 mask, in raster order (= the order of .nonzero()):
-    ranks [G,K] long (0-based) -> flat indices [G,K].  No host sync: prefix sum + binary search on the device."""
-    cum = mask_flat.to(torch.int32).cumsum(1, dtype=torch.int32)
-    return torch.searchsorted(cum, (ranks + 1).to(torch.int32), right=False)
+    ranks [G,K] long (0-based) -> flat indices [G,K].  No host sync and no compaction pass (ops.rank_select)."""
+    m = mask_flat if mask_flat.dtype == torch.uint8 else mask_flat.to(torch.uint8)
+    return ops.rank_select(m.contiguous(), ranks)
 
 
 def sample_point_grid(maps, num_points, thr, is_pos, gt_points=None):

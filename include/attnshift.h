@@ -150,6 +150,13 @@ int as_crop_threshold_erode(const float* maps /*[M,H,W]*/, const int32_t* crops,
                             uint8_t* mask /*[M,H,W]*/, int32_t* counts /*[M]*/, void* ws, size_t ws_bytes, int M, int H,
                             int W, as_stream_t stream);
 
+/* Rank select: out[m][k] = flat index of the ranks[m][k]-th (0-based) set byte of mask[m] in raster order, i.e.
+ * `mask[m].nonzero()[ranks[m][k]]` without the compaction (the reference indexes a .nonzero() list with random
+ * indices, stdroi:368-369 and :456); -1 when the rank is outside the population.  HW % 16 == 0. */
+size_t as_rank_select_workspace_bytes(int M, int HW);
+int as_rank_select(const uint8_t* mask /*[M,HW] 0/1*/, const int32_t* ranks /*[M,K]*/, int32_t* out /*[M,K]*/, void* ws,
+                   size_t ws_bytes, int M, int HW, int K, as_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -351,3 +351,20 @@ def test_crop_threshold_erode_matches_torch(ops):
                 ref[m][y0:y1, x0:x1] = b.to(torch.uint8)
             assert_equal(ref, mask, f"mask rel={rel} k={k} crops={use_crops}")
             assert_equal(ref.flatten(1).sum(1).int(), cnt, "counts")
+
+
+def test_rank_select_matches_nonzero(ops):
+    g = torch.Generator().manual_seed(13)
+    for M, HW, dens in ((3, 1024 * 1024, 0.3), (2, 4096 * 3 + 48, 0.01), (1, 160, 0.5), (2, 50176, 0.9)):
+        mask = (torch.rand(M, HW, generator=g) < dens).to(torch.uint8)
+        mask[0, :5] = 1
+        mask[-1, -3:] = 1
+        cnt = mask.sum(1)
+        ranks = torch.stack([torch.randint(int(cnt[m]), (20,), generator=g) for m in range(M)])
+        ranks[:, 0] = 0
+        ranks[:, 1] = cnt - 1
+        ref = torch.stack([mask[m].nonzero()[:, 0][ranks[m]] for m in range(M)])
+        got = ops.rank_select(dev(mask), dev(ranks))
+        assert_equal(ref, got, f"rank select M={M} HW={HW}")
+        beyond = ops.rank_select(dev(mask), dev(cnt[:, None] + torch.zeros(M, 1, dtype=torch.long)))
+        assert (beyond.cpu() == -1).all()

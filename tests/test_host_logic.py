@@ -94,12 +94,23 @@ def fake_crop_threshold_erode(maps, crops, thr, relative, k):
     return out, counts
 
 
+def fake_rank_select(mask, ranks):
+    """Test-side stand-in for ops.rank_select: literally mask[m].nonzero()[rank]."""
+    out = torch.full(ranks.shape, -1, dtype=torch.long)
+    for m in range(mask.shape[0]):
+        nz = mask[m].nonzero()[:, 0]
+        ok = ranks[m] < nz.numel()
+        out[m][ok] = nz[ranks[m][ok].long()]
+    return out
+
+
 @pytest.mark.parametrize("tag", ["tiny224", "mid320"])
 def test_sampling_and_mask_points_share_the_reference_rng_stream(golden, tag, monkeypatch):
     g = golden(f"shift_{tag}")
     inp = shift_case_inputs(g)
     hp, wp, G = int(g["hp"]), int(g["wp"]), int(g["G"])
     monkeypatch.setattr(RH.ops, "crop_threshold_erode", fake_crop_threshold_erode)
+    monkeypatch.setattr(RH.ops, "rank_select", fake_rank_select)
     cams = O.upsample_bilinear(inp["cams"], hp * 16, wp * 16)
     attn_sel = cams[t(g["best_idx"]), torch.arange(G)]
     torch.manual_seed(int(g["seed"]) + 1)

@@ -36,10 +36,11 @@ def main():
     ap.add_argument("--reps", type=int, default=3)
     a = ap.parse_args()
     torch.cuda.set_device(0)
-    for n in ("attention_fwd", "linear", "rollout_rows", "cam_boxes", "refine_similarity", "instance_maps", "cosine_shift"):
+    for n in ("attention_fwd", "linear", "rollout_rows", "cam_boxes", "refine_similarity", "instance_maps", "cosine_shift",
+              "crop_threshold_erode"):
         wrap(ops, n, "op:" + n)
-    for n in ("sample_point_grid", "seed_features", "mask_points_fg_bg", "grid_seed_coords", "filter_parts", "merge_parts",
-              "part_similarity", "part_centers", "_erode"):
+    for n in ("sample_point_grid", "seed_features", "mask_sample_points", "grid_seed_coords", "filter_parts", "merge_parts",
+              "part_similarity", "part_centers", "rank_select", "_down16", "_minmax_maps"):
         wrap(RH, n, "host:" + n)
     step = bench.build(torch.device("cuda", 0))
     with torch.no_grad():
