@@ -32,6 +32,37 @@ from .registry import HEADS
 STRIDE = 16
 
 
+class _StageClock:
+    """Optional wall-clock log of the stages of seed_pseudo_gt (AS_STAGE_LOG=1): a device sync at every mark, so
+    only for diagnosis."""
+
+    def __init__(self):
+        import os
+        self.on = os.environ.get("AS_STAGE_LOG", "0") == "1"
+        self.acc = {}
+        self.t = None
+
+    def start(self):
+        if self.on:
+            torch.cuda.synchronize()
+            import time
+            self.t = time.perf_counter()
+
+    def mark(self, name):
+        if self.on:
+            import time
+            torch.cuda.synchronize()
+            now = time.perf_counter()
+            self.acc[name] = self.acc.get(name, 0.0) + (now - self.t)
+            self.t = now
+
+    def report(self, steps=1):
+        return {k: round(v / steps * 1e3, 3) for k, v in self.acc.items()}
+
+
+CLOCK = _StageClock()
+
+
 # --------------------------------------------------------------------------------------------------
 # host-side matching (stdroi:2237-2257; HungarianPointAssigner mmdet/core/bbox/assigners/
 # hungarian_point_assigner.py:54-113, FocalLossCost / PointL1Cost match_cost.py:52-104)
@@ -155,7 +186,25 @@ def candidate_masks(map_fg, map_bg, crops, pos_thr, neg_thr, corr_size):
     return pos, neg, cp, cn
 
 
-def mask_sample_points(map_fg, map_bg, rois, pos_thr, neg_thr, num_gt, corr_size):
+def first_of_randperm(n, k, mode="reference"):
+    """The first k entries of a uniformly random permutation of range(n), from torch's global CPU generator.
+    "reference": literally torch.randperm(n)[:k] (stdroi:447) -- the same stream as the reference, but O(n) host
+    work (tens of ms for the 1e5..1e6 candidate pixels of a 1024^2 crop).
+    "fast": the same distribution (k distinct indices in uniformly random order) by rejection from O(k) draws."""
+    if mode == "reference" or n <= 4 * k:
+        return torch.randperm(n)[:k]
+    seen, out = set(), []
+    while len(out) < k:
+        for v in torch.randint(n, (2 * k,)).tolist():
+            if v not in seen:
+                seen.add(v)
+                out.append(v)
+                if len(out) == k:
+                    break
+    return torch.tensor(out, dtype=torch.long)
+
+
+def mask_sample_points(map_fg, map_bg, rois, pos_thr, neg_thr, num_gt, corr_size, rng_mode="reference"):
     """stdroi:1980-1993 + 433-461 for all objects: coords [G,num_gt,2] (x,y) float, labels [G,num_gt] bool.
     One host sync (candidate counts); `torch.randperm(n)` per object from the global CPU generator in object
     order like the reference; the drawn ranks index the concatenation [fg candidates, bg candidates] in raster
@@ -168,7 +217,7 @@ def mask_sample_points(map_fg, map_bg, rois, pos_thr, neg_thr, num_gt, corr_size
     ranks, empty = [], []
     for g in range(G):
         n = counts[g][0] + counts[g][1]
-        pick = torch.randperm(n)[:num_gt]
+        pick = first_of_randperm(n, num_gt, rng_mode)
         if pick.shape[0] < num_gt:
             if pick.shape[0] == 0:
                 empty.append(g)
@@ -339,7 +388,7 @@ class AttnShiftRoIHead(nn.Module):
                  mask_head=None, shared_head=None, mae_head=None, bbox_rec_head=None, train_cfg=None, test_cfg=None,
                  visualize=False, epoch=0, epoch_semantic_centers=0, num_semantic_points=3, semantic_to_token=False,
                  pca_dim=128, mean_shift_times_local=10, reppoints_head=None, num_reppoints_head=1,
-                 layer_selector=None):
+                 layer_selector=None, rng_mode="reference"):
         super().__init__()
         self.train_cfg = _ns(train_cfg)
         self.test_cfg = _ns(test_cfg)
@@ -355,6 +404,8 @@ class AttnShiftRoIHead(nn.Module):
         self.with_mask = mask_head is not None
         self.with_bbox = bbox_head is not None
         self.layer_selector = layer_selector or median_area_selector
+        assert rng_mode in ("reference", "fast")
+        self.rng_mode = rng_mode          # "reference": the reference's exact torch RNG stream; "fast": O(k) draws
         self.visualize = visualize
         self.epoch, self.epoch_semantic_centers = epoch, epoch_semantic_centers
         self.num_semantic_points = num_semantic_points
@@ -393,13 +444,16 @@ class AttnShiftRoIHead(nn.Module):
         pts_fg = sample_point_grid(nm, 20, 0.2, True, gt_points)
         pts_supp = sample_point_grid(nm.mean(0, keepdim=True), 20, 0.1, False)
         pts_fg = torch.cat((pts_fg, pts_supp), dim=0)
+        CLOCK.mark("  sampling")
         feat_tok = feat_chw.flatten(1).t().contiguous()
         box_patch = (rois // STRIDE).to(torch.int32).contiguous()
         sim_fg, fg_feat = ops.refine_similarity(feat_tok, seed_features(pts_fg, feat_chw).contiguous(), box_patch, G,
                                                 refine_times, obj_tau, True, hp, wp)
         sim_bg, bg_feat = ops.refine_similarity(feat_tok, seed_features(pts_bg, feat_chw).contiguous(), box_patch, G,
                                                 refine_times, obj_tau, False, hp, wp)
+        CLOCK.mark("  refine_similarity")
         map_fg, map_bg = ops.instance_maps(sim_fg, sim_bg, G, hp, wp, STRIDE)
+        CLOCK.mark("  instance_maps")
         return map_fg, map_bg, pts_fg, pts_bg, fg_feat[:, :, None, None], bg_feat[:, :, None, None]
 
     def get_mask_sample_points_roi_best_attn_feat_refine(self, attn, rois, attn_idx, vit_feat, pos_thr=0.6, neg_thr=0.6,
@@ -412,7 +466,8 @@ class AttnShiftRoIHead(nn.Module):
         mm = None if minmax is None else minmax[attn_idx, ar]
         map_fg, map_bg, pts_a, pts_b, f_fg, f_bg = self.refine_maps(attn_sel, vit_feat, rois, gt_points, refine_times,
                                                                     obj_tau, mm)
-        coords, labels = mask_sample_points(map_fg[-1], map_bg[-1], rois, pos_thr, neg_thr, num_gt, corr_size)
+        coords, labels = mask_sample_points(map_fg[-1], map_bg[-1], rois, pos_thr, neg_thr, num_gt, corr_size,
+                                            self.rng_mode)
         return coords, labels, map_fg, map_bg, pts_a, pts_b, f_fg, f_bg
 
     def mean_shift_grid_prototype(self, maps, vit_feat, rois=None, thr=0.35, n_shift=5, output_size=(4, 4), tau=0.1,
@@ -437,15 +492,20 @@ class AttnShiftRoIHead(nn.Module):
         # :2011-2013.  erode_11(map > thr) at full resolution, then the bilinear /16 down-sampling, which for an
         # exact factor of 16 reads only the 2x2 centre pixels of each patch with weights 1/2 (bit-identical)
         core, _ = ops.crop_threshold_erode(map_cos_fg.contiguous(), None, pos_thr, False, 11)
+        CLOCK.mark("  sc:erode")
         fg_inter = _down16(core.float())
         bg_inter = _down16(torch.stack([_centre4(map_cos_bg, dy, dx) for dy in (7, 8) for dx in (7, 8)]).amax(dim=1, keepdim=False),
                            presampled=True)[None]
         map_fg = (fg_inter > pos_thr).to(fg_inter.dtype)
+        CLOCK.mark("  sc:down16")
         prot, sim = self.mean_shift_grid_prototype(map_fg, vit_feat, rois, tau=0.1, temp=0.1, n_shift=refine_times)
+        CLOCK.mark("  sc:mean_shift")
         P = sim.shape[0] // G
         keep = filter_parts(sim.unflatten(0, (G, P)), fg_inter)
         merged = merge_parts(prot.unflatten(0, (G, P)), keep, merge_thr)
+        CLOCK.mark("  sc:filter+merge")
         sim_parts = part_similarity(merged, vit_feat)
+        CLOCK.mark("  sc:part_similarity")
         (centers, split, feat_split, feats, num_parts, coords_org, labels_org, corres) = part_centers(
             sim_parts, rois, gt_labels, vit_feat, num_max_obj=num_semantic_points)
         return centers, split, sim_parts, feat_split, feats, num_parts, coords_org, labels_org, corres
@@ -477,7 +537,9 @@ class AttnShiftRoIHead(nn.Module):
         patch_h, patch_w = vit_feat.shape[-2:]
         H, W = patch_h * STRIDE, patch_w * STRIDE
         Lc = self.bbox_head.cam_layer
+        CLOCK.start()
         rows = self.rollout_cams(attns, num_proposals)                       # [B, Lc, T, N]
+        CLOCK.mark("rollout")
         counts = [int(p.numel()) for p in pos_inds]
         # B1, batched over every (image, layer, object): one launch sequence for the whole batch
         cams_lr = torch.cat([rows[i][:, pos_inds[i], 1:-num_proposals].reshape(-1, patch_h, patch_w)
@@ -487,6 +549,7 @@ class AttnShiftRoIHead(nn.Module):
             raise RuntimeError("seed_pseudo_gt: no matched point tokens in the batch")
         boxes, status, cams_up, cam_minmax = ops.cam_boxes(cams_lr, pts, self.bbox_head.seed_thr,
                                                            self.bbox_head.seed_multiple, STRIDE, True)
+        CLOCK.mark("cam_boxes")
         if bool((status == 0).any()):
             # the reference raises here too (torch.stack of an empty list, stdroi:80)
             raise RuntimeError("seed_pseudo_gt: a CAM has no foreground component (constant attention map)")
@@ -498,6 +561,7 @@ class AttnShiftRoIHead(nn.Module):
             attn_minmax.append(cam_minmax[off:off + n].reshape(Lc, counts[i], 2))
             off += n
 
+        CLOCK.mark("box_split")
         gt_box_index = self.layer_selector(gt_scale_bboxes, gt_labels, roi_feature_map)
         pseudo_boxes = [gt_scale_bboxes[i][torch.arange(counts[i], device=boxes.device), gt_box_index[i]]
                         for i in range(num_imgs)]
@@ -509,6 +573,7 @@ class AttnShiftRoIHead(nn.Module):
                    semantic_centers_feat=[], num_parts=[], pseudo_gt_masks=[], corres_gts=[], inst_fg_feat=[],
                    inst_bg_feat=[])
         coords_sc_org, labels_sc_org, map_cos_bg_ret, sim_fg_ret = [], [], [], []
+        CLOCK.mark("select")
         for i in range(num_imgs):
             feat = vit_feat[i].float()
             if not feat.is_contiguous():
@@ -518,10 +583,12 @@ class AttnShiftRoIHead(nn.Module):
                     attn_maps_dealed[i], pseudo_boxes[i], gt_box_index[i], vit_feat=feat, pos_thr=pos_mask_thr,
                     neg_thr=neg_mask_thr, num_gt=num_mask_point_gt, corr_size=corr_size, obj_tau=obj_tau,
                     gt_points=gt_points[i], minmax=attn_minmax[i])
+            CLOCK.mark("refine+mask_points")
             (centers, centers_split, sim_fg, feat_split, feat_centers, num_parts_obj, c_org, l_org, corres) = \
                 self.get_semantic_centers(map_fg[-1], map_bg[-1], pseudo_boxes[i], feat,
                                           pos_thr=pos_mask_thr, refine_times=self.mean_shift_times_local,
                                           gt_labels=gt_labels[i], num_semantic_points=self.num_semantic_points)
+            CLOCK.mark("semantic_centers")
             out["semantic_centers_feat_split"].append(feat_split)
             out["mask_points_coords"].append(coord_point)
             out["mask_points_labels"].append(labels_point)
@@ -538,6 +605,7 @@ class AttnShiftRoIHead(nn.Module):
             # stdroi:2356-2358: (map > rowmax * thr) as uint8 on the host
             mask_u8, _ = ops.crop_threshold_erode(map_fg[-1].contiguous(), None, pos_mask_thr, True, 1)
             out["pseudo_gt_masks"].append(mask_u8.cpu().numpy())
+            CLOCK.mark("pseudo_masks")
             out["inst_fg_feat"].append(feats_fg)
             out["inst_bg_feat"].append(feats_bg)
         out["semantic_centers_org"] = (coords_sc_org, labels_sc_org)

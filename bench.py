@@ -63,7 +63,7 @@ def build(device):
             rows[:, :, :G, 1:-num_proposals] = cams                              # seeded, non-degenerate CAMs
             return rows
 
-    head = BenchHead(num_semantic_points=5, mean_shift_times_local=CFG["n_shift"],
+    head = BenchHead(num_semantic_points=5, mean_shift_times_local=CFG["n_shift"], rng_mode=os.environ.get("AS_RNG_MODE", "fast"),
                      bbox_head=dict(type="MAEBoxHeadRec", seed_thr=0.2, seed_multiple=0.5, cam_layer=Lc,
                                     num_classes=CFG["num_classes"]),
                      mil_head=dict(type="MAEBoxHeadMIL", num_layers_query=Lc))
@@ -153,6 +153,8 @@ def main():
         dist.init_process_group(backend="nccl", device_id=device)
 
     from attentionshift_amd import ops
+    # the host side of this path is a single Python thread; a 256-thread intra-op pool only adds spin-wait noise
+    torch.set_num_threads(int(os.environ.get("AS_HOST_THREADS", "8")))
     step = build(device)
     with torch.no_grad():
         for _ in range(a.warmup):

@@ -9,6 +9,7 @@ from collections import defaultdict
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ["AS_STAGE_LOG"] = "1"
 import bench  # noqa: E402
 import attentionshift_amd as A  # noqa: E402
 from attentionshift_amd import ops, roi_head as RH  # noqa: E402
@@ -36,6 +37,7 @@ def main():
     ap.add_argument("--reps", type=int, default=3)
     a = ap.parse_args()
     torch.cuda.set_device(0)
+    torch.set_num_threads(int(os.environ.get("AS_HOST_THREADS", "8")))
     for n in ("attention_fwd", "linear", "rollout_rows", "cam_boxes", "refine_similarity", "instance_maps", "cosine_shift",
               "crop_threshold_erode"):
         wrap(ops, n, "op:" + n)
@@ -46,6 +48,7 @@ def main():
     with torch.no_grad():
         step(); step()
         T.clear()
+        RH.CLOCK.acc.clear()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(a.reps):
@@ -58,6 +61,9 @@ def main():
         print(f"  {k:28s} {v / a.reps * 1e3:9.3f} ms")
         acc += v
     print(f"  {'(unattributed)':28s} {(total - acc) / a.reps * 1e3:9.3f} ms")
+    print("seed_pseudo_gt stage clock (ms/step):")
+    for k, v in RH.CLOCK.report(a.reps).items():
+        print(f"  {k:28s} {v:9.3f}")
 
 
 if __name__ == "__main__":
