@@ -13,8 +13,8 @@ What is different underneath:
     (ops.attn_mean_rows / ops.rollout_rows) -- the only consumer reads 100 rows of a product of 7 of them.
   * bf16 operands / fp32 accumulate by default (`compute_dtype`), fp32 master parameters; the reference
     runs apex O1 fp16.  `compute_dtype=torch.float32` is the exact-fp32 parity path.
-  * LayerNorm / GELU-MLP / patch embedding go through the same GEMM kernel (ops.linear) or torch
-    elementwise ops; the FPN taps use torch (MIOpen) -- they are outside the hot path.
+  * LayerNorm / residuals are torch elementwise ops; the GELU-MLP, the patch embedding and the 2x2/2 FPN
+    deconvolutions (one GEMM over tokens each) go through the same GEMM kernel (ops.linear).
 """
 import math
 
@@ -199,6 +199,42 @@ class VisionTransformerDet(nn.Module):
             self._wcache[key] = hit
         return hit[1]
 
+    def _derived(self, p, tag, fn):
+        """cached compute-dtype matrix derived from parameter p (re-derived when p changes or needs grad)."""
+        if torch.is_grad_enabled() and p.requires_grad:
+            return fn(p).to(self.compute_dtype).contiguous()
+        key = (id(p), tag)
+        hit = self._wcache.get(key)
+        if hit is None or hit[0] != p._version or hit[1].device != p.device:
+            hit = (p._version, fn(p.detach()).to(self.compute_dtype).contiguous())
+            self._wcache[key] = hit
+        return hit[1]
+
+    def _deconv2x2(self, x_nhwc, conv):
+        """nn.ConvTranspose2d(k=2, s=2) on a channels-last map as ONE GEMM over its pixels:
+        y[b, 2i+di, 2j+dj, co] = sum_ci x[b,i,j,ci] W[ci,co,di,dj] + bias[co]  (visual_transformer_det.py:107-117)."""
+        B, h, w, cin = x_nhwc.shape
+        cout = conv.weight.shape[1]
+        wmat = self._derived(conv.weight, "deconv", lambda t: t.permute(2, 3, 1, 0).reshape(4 * cout, cin))
+        bias = None if conv.bias is None else conv.bias.float().repeat(4)
+        y = ops.linear(x_nhwc.reshape(B * h * w, cin), wmat, bias)
+        return y.reshape(B, h, w, 2, 2, cout).permute(0, 1, 3, 2, 4, 5).reshape(B, 2 * h, 2 * w, cout)
+
+    def _fpn(self, i, feat_nchw, tok):
+        """FPN tap i (visual_transformer_det.py:246-256).  feat_nchw: the fp32 [B,D,hp,wp] tap; tok: the same tokens
+        as a token-major view [B,Np,D].  Deconvolved taps come back NCHW-shaped with channels-last strides in the
+        compute dtype (no layout copy); identity / max-pool taps stay fp32 NCHW."""
+        B, D, hp, wp = feat_nchw.shape
+        ops_ = [self.fpn1, self.fpn2, self.fpn3, self.fpn4]
+        op = ops_[i]
+        if isinstance(op, nn.Sequential) and isinstance(op[0], nn.ConvTranspose2d):
+            y = self._deconv2x2(tok.to(self.compute_dtype).reshape(B, hp, wp, D), op[0]).permute(0, 3, 1, 2)
+            if len(op) == 4:                                             # ConvT -> BN -> GELU -> ConvT (fpn1, patch 16)
+                y = op[2](op[1](y.float())).to(self.compute_dtype)
+                y = self._deconv2x2(y.permute(0, 2, 3, 1), op[3]).permute(0, 3, 1, 2)
+            return y
+        return op(feat_nchw)
+
     def interpolate_pos_encoding(self, n_patch_tokens, w, h):
         """models/vision_transformer.py:187-207 (bicubic, scale_factor with the +0.1 trick)."""
         n0 = self.pos_embed.shape[1] - 1
@@ -249,19 +285,20 @@ class VisionTransformerDet(nn.Module):
         x = self.prepare_tokens(x)
         if self.recompute_last_feat:
             last_feat = x
-        features, attns = [], []
+        features, taps, attns = [], [], []
         for i, blk in enumerate(self.blocks):
             x, st = self._block(blk, x, self.return_attention)
             if self.return_attention:
                 attns.append(st)
             if i in self.out_indices:
+                taps.append(x[:, 1:-T])                                  # token-major view [B, Np, D]
                 features.append(x[:, 1:, :][:, :-T].permute(0, 2, 1).reshape(B, -1, hp, wp).contiguous())
             if self.last_feat and not self.recompute_last_feat and i == len(self.blocks) - 1:
                 last_feat = x[:, :-T]
         org_features = torch.stack(features, dim=1)
         if self.with_fpn:
-            fpn = [self.fpn1, self.fpn2, self.fpn3, self.fpn4]
-            features = [fpn[i](f) for i, f in enumerate(features)]
+            # the taps are token-major already: run the 2x2/2 deconvolutions as GEMMs over tokens (channels-last)
+            features = [self._fpn(i, features[i], taps[i]) for i in range(len(features))]
         point_tokens = x[:, -T:]
         out = dict(org_feats=org_features, feature=tuple(features), point_tokens=point_tokens)
         if self.with_point_head:

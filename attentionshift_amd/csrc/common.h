@@ -78,6 +78,17 @@ __device__ __forceinline__ f32x16 mma32(const Frag<float>& a, const Frag<float>&
   return c;
 }
 
+// Q is stored FRAGMENT-MAJOR so that the row-per-lane 16-byte operand loads of the MFMAs are fully coalesced:
+// inside every 32-row x 64-d tile, element (r, d) lives at ((d/16)*64 + r + 32*((d%16)/8))*8 + d%8, i.e. the 8
+// elements lane (r, half) needs for k16-step ks are contiguous and the 64 lanes of a wave read 1 KiB contiguous.
+// (q workspace of as_qkv_fwd; consumers: sdpa.hip, rollout.hip.)
+__device__ __forceinline__ size_t qf_frag(size_t bh, int Npad, int row, int ks, int half) {     // element index
+  return ((((bh * (size_t)(Npad >> 5) + (size_t)(row >> 5)) * 4 + ks) * 64) + (row & 31) + 32 * half) * 8;
+}
+__device__ __forceinline__ size_t qf_elem(size_t bh, int Npad, int row, int d) {
+  return qf_frag(bh, Npad, row, d >> 4, (d >> 3) & 1) + (d & 7);
+}
+
 // accumulator register r of a lane in half `half` -> row inside the 32x32 tile
 __device__ __forceinline__ int acc_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 

@@ -19,6 +19,18 @@ constexpr float LOG2E = 1.44269504088896340736f;
 
 template <typename T> struct KjCfg { static constexpr int PITCH = HD * (int)sizeof(T) + 16; };
 
+// Fragment-major copy of a roll-out matrix R[b][i][k] (rows i < 128, contraction index k): the 8 values lane
+// (i%32, half) needs as the A operand of k16 sub-step s2 of block (kb = k/32, ib = i/32) are contiguous and a wave
+// reads 1 KiB contiguous: [b][kb][ib][s2][lane][8].  Element (i, k) -> its slot:
+__device__ __forceinline__ size_t rf_slot(int b, int nkb, int i, int k) {
+  const int rem = k & 31, s2 = rem >> 4, r16 = rem & 15;
+  const int lane = (i & 31) + 32 * ((r16 & 7) >> 2), t = (r16 >> 3) * 4 + (r16 & 3);
+  return ((((((size_t)b * nkb + (k >> 5)) * 4 + (i >> 5)) * 2 + s2) * 64) + lane) * 8 + t;
+}
+__device__ __forceinline__ size_t rf_frag(int b, int nkb, int kb, int ib, int s2, int lane) {
+  return ((((((size_t)b * nkb + kb) * 4 + ib) * 2 + s2) * 64) + lane) * 8;
+}
+
 // mean over heads of the softmax tile rows [i0, i0+32) x cols [j0, j0+32) for image b.
 // kj_lds: this workgroup's K rows j0..j0+31 of every head, [h][32][PITCH]  (or nullptr: read global)
 template <typename T>
@@ -33,14 +45,13 @@ __device__ __forceinline__ f32x16 pbar_tile(const T* __restrict__ q, const T* __
   const float c2 = 0.125f * LOG2E;
   for (int hh = 0; hh < h; ++hh) {
     const size_t bh = (size_t)b * h + hh;
-    const T* qrow = q + (bh * Npad + irow) * HD + half * 8;
     f32x16 s;
 #pragma unroll
     for (int r = 0; r < 16; ++r) s[r] = 0.0f;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       Frag<T> fa, fb;
-      fa.load16B(qrow + ks * 16);
+      fa.load16B(q + qf_frag(bh, Npad, irow, ks, half));
       if (kj_lds != nullptr)
         fb.load16B(reinterpret_cast<const T*>(kj_lds + ((size_t)hh * 32 + li) * KjCfg<T>::PITCH) + ks * 16 + half * 8);
       else
@@ -64,8 +75,8 @@ __device__ __forceinline__ f32x16 pbar_tile(const T* __restrict__ q, const T* __
 template <typename T, bool TOP>
 __global__ __launch_bounds__(RO_NT) void attn_mean_rows_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                                const float* __restrict__ lse,
-                                                               float* __restrict__ out, int B, int N, int Npad,
-                                                               int h, int row0, int nrows) {
+                                                               float* __restrict__ out, T* __restrict__ rf_out, int B,
+                                                               int N, int Npad, int h, int row0, int nrows) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 31, half = lane >> 5;
   const int jb = blockIdx.x * 4 + wave, ib = blockIdx.y, b = blockIdx.z;
@@ -73,48 +84,51 @@ __global__ __launch_bounds__(RO_NT) void attn_mean_rows_kernel(const T* __restri
   if (j0 >= N) return;
   const f32x16 p = pbar_tile<T>(q, k, lse, nullptr, b, h, N, Npad, row0 + i0, j0, li, half);
   const int j = j0 + li;
-  if (j < N) {
+  const int nkb = (N + 31) / 32;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int i = i0 + acc_row(r, half);
-      if (i < nrows) {
-        float v = p[r];
-        if (TOP) v = 0.5f * (v + ((row0 + i) == j ? 1.0f : 0.0f));
-        out[((size_t)b * nrows + i) * N + j] = v;
-      }
-    }
+  for (int r = 0; r < 16; ++r) {
+    const int i = i0 + acc_row(r, half);
+    float v = p[r];
+    if (TOP) v = 0.5f * (v + ((row0 + i) == j ? 1.0f : 0.0f));
+    const bool live = i < nrows && j < N;
+    if (live) out[((size_t)b * nrows + i) * N + j] = v;
+    if (rf_out != nullptr && i < 128) rf_out[rf_slot(b, nkb, i, j)] = from_f32<T>(live ? v : 0.0f);
   }
 }
 
-__device__ __forceinline__ void load_r_frag(Frag<__bf16>& f, const float* p, bool v0, bool v1) {
-#pragma unroll
-  for (int t = 0; t < 4; ++t) f.v[t] = (__bf16)(v0 ? p[t] : 0.0f);
-#pragma unroll
-  for (int t = 0; t < 4; ++t) f.v[4 + t] = (__bf16)(v1 ? p[8 + t] : 0.0f);
-}
-__device__ __forceinline__ void load_r_frag(Frag<float>& f, const float* p, bool v0, bool v1) {
-#pragma unroll
-  for (int t = 0; t < 4; ++t) f.v[t] = v0 ? p[t] : 0.0f;
-#pragma unroll
-  for (int t = 0; t < 4; ++t) f.v[4 + t] = v1 ? p[8 + t] : 0.0f;
-}
+// ---------------------------------------------------------------------------------------------------------
+// rollout_step2: latency-tolerant version.  All four waves of a workgroup work on the SAME 32-row contraction
+// block at a time, each on its own heads (wave w: heads w, w+4, ...):
+//   * the per-row -lse term is injected with ONE exact-fp32 MFMA per head (A = -8*lse[row] in the k=0 slot,
+//     B = 1), which lands it directly in the accumulator layout -- no per-register lse loads;
+//   * Q fragments of the next block are prefetched into registers while the current block is computed (bf16);
+//   * the four partial head sums are exchanged through a double-buffered 16 KiB LDS slab (one barrier per
+//     block) and every wave then owns ONE 32-row block of R for the second MFMA, so no final reduction.
+// ---------------------------------------------------------------------------------------------------------
+template <typename T> struct Kj2 {           // bf16: unpadded 128-B rows, XOR-swizzled 16-B chunks; f32: padded
+  static constexpr int PITCH = sizeof(T) == 2 ? 128 : (HD * 4 + 16);
+  __device__ static __forceinline__ int off(int row, int elem) {      // elem multiple of 8
+    if (sizeof(T) == 2) return row * 128 + ((((elem >> 3) ^ (row & 7))) << 4);
+    return row * PITCH + elem * 4;
+  }
+};
 
-// R_out[b] = 0.5 * (R_in[b] . mean_h P + R_in[b]);  one workgroup = 32 output columns of one image,
-// its 4 waves split the contraction (k) range and are reduced through LDS at the end.
-template <typename T, int IB>   // IB = number of 32-row blocks of R (T <= 32*IB)
-__global__ __launch_bounds__(RO_NT) void rollout_step_kernel(const T* __restrict__ q, const T* __restrict__ k,
-                                                             const float* __restrict__ lse,
-                                                             const float* __restrict__ Rin,
-                                                             float* __restrict__ Rout, int B, int N, int Npad,
-                                                             int h, int Trows) {
+template <typename T, int HPW>
+__global__ __launch_bounds__(RO_NT) void rollout_step2_kernel(const T* __restrict__ q, const T* __restrict__ k,
+                                                              const float* __restrict__ lse,
+                                                              const float* __restrict__ Rin, const T* __restrict__ rf_in,
+                                                              float* __restrict__ Rout, T* __restrict__ rf_out, int B,
+                                                              int N, int Npad, int h, int Trows) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr bool PREFETCH = sizeof(T) == 2;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, half = lane >> 5;
   const int j0 = blockIdx.x * 32, b = blockIdx.y;
+  char* kj = smem;
+  float4* xchg = reinterpret_cast<float4*>(smem + (size_t)h * 32 * Kj2<T>::PITCH);    // [2][4 waves][4][64]
 
-  // stage K rows j0..j0+31 of every head: [h][32][PITCH]
-  {
-    constexpr int CPR = HD * (int)sizeof(T) / 16;     // 16-byte chunks per row
+  {  // stage K rows j0..j0+31 of every head
+    constexpr int CPR = HD * (int)sizeof(T) / 16;
     const int total = h * 32 * CPR;
     for (int c = tid; c < total; c += RO_NT) {
       const int hh = c / (32 * CPR), rem = c % (32 * CPR);
@@ -122,121 +136,173 @@ __global__ __launch_bounds__(RO_NT) void rollout_step_kernel(const T* __restrict
       const int jrow = min(j0 + jr, N - 1);
       const uint4 u = *reinterpret_cast<const uint4*>(
           reinterpret_cast<const char*>(k + (((size_t)b * h + hh) * Npad + jrow) * HD) + ch * 16);
-      *reinterpret_cast<uint4*>(smem + ((size_t)hh * 32 + jr) * KjCfg<T>::PITCH + ch * 16) = u;
+      const int elem = ch * (16 / (int)sizeof(T));
+      const int base = Kj2<T>::off(hh * 32 + jr, elem & ~7);
+      *reinterpret_cast<uint4*>(kj + base + (elem & 7) * (int)sizeof(T)) = u;
     }
   }
   __syncthreads();
-
-  f32x16 acc[IB];
-#pragma unroll
-  for (int ib = 0; ib < IB; ++ib)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[ib][r] = 0.0f;
 
   const int nkb = (N + 31) / 32;
-  const float* Rb = Rin + (size_t)b * Trows * N;
-  for (int kb = wave; kb < nkb; kb += 4) {
-    const int k0 = kb * 32;
-    f32x16 p = pbar_tile<T>(q, k, lse, smem, b, h, N, Npad, k0, j0, li, half);
-    // rows (contraction index) beyond N contribute nothing
-    if (k0 + 32 > N) {
+  const float c2 = 0.125f * LOG2E;
+  const float inv_h = 1.0f / (float)h;
+  const bool own_rows = wave * 32 < Trows;              // this wave's 32-row block of R exists
+
+  f32x16 acc;
 #pragma unroll
-      for (int r = 0; r < 16; ++r)
-        if (k0 + acc_row(r, half) >= N) p[r] = 0.0f;
+  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+
+  // everything a block needs from global memory (Q fragments, the lane's lse values, its R values) is fetched one
+  // block AHEAD, in one batch at the top of the iteration: vmcnt completes in order, so a load issued at its point
+  // of use would first have to drain the whole prefetch batch issued before it.
+  struct Fetch {
+    Frag<T> fq[HPW][4];
+    float l8[HPW];
+    Frag<T> fr[2];
+  };
+  auto fetch = [&](int kb, Fetch& f) {
+    const int row = min(kb * 32 + li, N - 1);
+#pragma unroll
+    for (int t = 0; t < HPW; ++t) {
+      const int hh = min(wave + 4 * t, h - 1);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) f.fq[t][ks].load16B(q + qf_frag((size_t)b * h + hh, Npad, row, ks, half));
+      f.l8[t] = -8.0f * lse[((size_t)b * h + hh) * N + row];
     }
-    Frag<T> fp[2];
+    if (own_rows) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) fp[r >> 3].set(r & 7, p[r]);
+      for (int s2 = 0; s2 < 2; ++s2) f.fr[s2].load16B(rf_in + rf_frag(b, nkb, kb, wave, s2, lane));
+    }
+  };
+  Fetch cur, nxt;
+  if (PREFETCH) fetch(0, nxt);
+
+  for (int kb = 0; kb < nkb; ++kb) {
+    const int k0 = kb * 32;
+    if (PREFETCH) {
+      cur = nxt;
+      if (kb + 1 < nkb) fetch(kb + 1, nxt);
+    } else {
+      fetch(kb, cur);
+    }
+
+    f32x16 pbar;
 #pragma unroll
-    for (int ib = 0; ib < IB; ++ib) {
-      const int i = ib * 32 + li;
-      const bool iv = i < Trows;
-      const float* rrow = Rb + (size_t)min(i, Trows - 1) * N;
+    for (int r = 0; r < 16; ++r) pbar[r] = 0.0f;
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        const int kk = k0 + 16 * s + 4 * half;          // runs kk..kk+3 and kk+8..kk+11
-        Frag<T> fr;
-        if (k0 + 32 <= N) {
-          load_r_frag(fr, rrow + kk, iv, iv);
-        } else {                                        // ragged tail: element-wise guard
+    for (int t = 0; t < HPW; ++t) {
+      const int hh = wave + 4 * t;
+      if (hh < h) {                                      // wave-uniform
+        const float l8 = cur.l8[t];
+        f32x16 sc;
 #pragma unroll
-          for (int t = 0; t < 8; ++t) {
-            const int kx = kk + 8 * (t >> 2) + (t & 3);
-            fr.set(t, (iv && kx < N) ? rrow[kx] : 0.0f);
-          }
+        for (int r = 0; r < 16; ++r) sc[r] = 0.0f;
+        // sc[i][j] = -8 * lse[k0 + i]: exact fp32 row broadcast in accumulator layout
+        sc = __builtin_amdgcn_mfma_f32_32x32x2f32(half == 0 ? l8 : 0.0f, 1.0f, sc, 0, 0, 0);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          Frag<T> fk;
+          fk.load16B(reinterpret_cast<const T*>(kj + Kj2<T>::off(hh * 32 + li, ks * 16 + half * 8)));
+          sc = mma32(cur.fq[t][ks], fk, sc);
         }
-        acc[ib] = mma32(fr, fp[s], acc[ib]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pbar[r] += __builtin_amdgcn_exp2f(sc[r] * c2);
       }
+    }
+    // publish this wave's partial head sum
+    float4* slab = xchg + (size_t)(kb & 1) * 4 * 4 * 64;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      slab[(wave * 4 + g) * 64 + lane] = make_float4(pbar[4 * g], pbar[4 * g + 1], pbar[4 * g + 2], pbar[4 * g + 3]);
+    __syncthreads();
+    if (own_rows) {
+      Frag<T> fp[2];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float4 v = slab[(0 * 4 + g) * 64 + lane];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+          const float4 u = slab[(w * 4 + g) * 64 + lane];
+          v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+        }
+        const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+          const int r = 4 * g + x;
+          const bool live = k0 + acc_row(r, half) < N;   // contraction rows beyond N contribute nothing
+          fp[r >> 3].set(r & 7, live ? e[x] * inv_h : 0.0f);
+        }
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) acc = mma32(cur.fr[s2], fp[s2], acc);
     }
   }
 
-  // cross-wave reduction through LDS (aliases the K staging area)
-  __syncthreads();
-  float* red = reinterpret_cast<float*>(smem);          // [4 waves][IB*32 rows][32 cols]
+  if (own_rows) {
+    const int j = j0 + li;
 #pragma unroll
-  for (int ib = 0; ib < IB; ++ib)
-#pragma unroll
-    for (int r = 0; r < 16; ++r)
-      red[((size_t)wave * IB * 32 + ib * 32 + acc_row(r, half)) * 32 + li] = acc[ib][r];
-  __syncthreads();
-  for (int e = tid; e < IB * 32 * 32; e += RO_NT) {
-    const int i = e / 32, jj = e % 32;
-    const int j = j0 + jj;
-    if (i < Trows && j < N) {
+    for (int r = 0; r < 16; ++r) {
+      const int i = wave * 32 + acc_row(r, half);
+      const bool live = i < Trows && j < N;
       float v = 0.0f;
-#pragma unroll
-      for (int w = 0; w < 4; ++w) v += red[((size_t)w * IB * 32 + i) * 32 + jj];
-      const size_t idx = ((size_t)b * Trows + i) * N + j;
-      Rout[idx] = 0.5f * (v + Rin[idx]);
+      if (live) {
+        const size_t idx = ((size_t)b * Trows + i) * N + j;
+        v = 0.5f * (acc[r] + Rin[idx]);
+        Rout[idx] = v;
+      }
+      if (rf_out != nullptr) rf_out[rf_slot(b, nkb, i, j)] = from_f32<T>(v);
     }
   }
 }
 
 template <typename T>
-int launch_mean_rows(const void* q, const void* k, const float* lse, float* out, int B, int N, int h, int row0,
-                     int nrows, bool top, hipStream_t s) {
+int launch_rollout_step2(const void* q, const void* k, const float* lse, const float* Rin, const void* rf_in, float* Rout,
+                         void* rf_out, int B, int N, int h, int Trows, hipStream_t s) {
+  const int Npad = as_round_up(N, 64);
+  const int hpw = as_ceil_div(h, 4);
+  dim3 grid(as_ceil_div(N, 32), B);
+  const size_t lds = (size_t)h * 32 * Kj2<T>::PITCH + 2 * 4 * 4 * 64 * sizeof(float4);
+  AS_REQUIRE(lds <= 160 * 1024, AS_E_UNSUPPORTED, "rollout_step: LDS %zu B exceeds 160 KiB (h=%d)", lds, h);
+#define AS_RO2(HPW)                                                                                            \
+  do {                                                                                                         \
+    (void)hipFuncSetAttribute((const void*)rollout_step2_kernel<T, HPW>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                              (int)lds);                                                                       \
+    hipLaunchKernelGGL((rollout_step2_kernel<T, HPW>), grid, dim3(RO_NT), lds, s, (const T*)q, (const T*)k, lse, Rin, \
+                       (const T*)rf_in, Rout, (T*)rf_out, B, N, Npad, h, Trows);                               \
+  } while (0)
+  switch (hpw) {
+    case 1: AS_RO2(1); break;
+    case 2: AS_RO2(2); break;
+    case 3: AS_RO2(3); break;
+    case 4: AS_RO2(4); break;
+    default: AS_REQUIRE(false, AS_E_UNSUPPORTED, "rollout_step: h=%d heads (max 16)", h);
+  }
+#undef AS_RO2
+  AS_CHECK_LAUNCH("rollout_step2");
+  return AS_OK;
+}
+
+template <typename T>
+int launch_mean_rows(const void* q, const void* k, const float* lse, float* out, void* rf_out, int B, int N, int h,
+                     int row0, int nrows, bool top, hipStream_t s) {
   const int Npad = as_round_up(N, 64);
   dim3 grid(as_ceil_div(as_ceil_div(N, 32), 4), as_ceil_div(nrows, 32), B);
   if (top)
     hipLaunchKernelGGL((attn_mean_rows_kernel<T, true>), grid, dim3(RO_NT), 0, s, (const T*)q, (const T*)k, lse,
-                       out, B, N, Npad, h, row0, nrows);
+                       out, (T*)rf_out, B, N, Npad, h, row0, nrows);
   else
     hipLaunchKernelGGL((attn_mean_rows_kernel<T, false>), grid, dim3(RO_NT), 0, s, (const T*)q, (const T*)k, lse,
-                       out, B, N, Npad, h, row0, nrows);
+                       out, (T*)rf_out, B, N, Npad, h, row0, nrows);
   AS_CHECK_LAUNCH("attn_mean_rows");
   return AS_OK;
 }
 
-template <typename T>
-int launch_rollout_step(const void* q, const void* k, const float* lse, const float* Rin, float* Rout, int B,
-                        int N, int h, int Trows, hipStream_t s) {
-  const int Npad = as_round_up(N, 64);
-  const int IB = as_ceil_div(Trows, 32);
-  dim3 grid(as_ceil_div(N, 32), B);
-  size_t lds_k = (size_t)h * 32 * KjCfg<T>::PITCH;
-  size_t lds_r = (size_t)4 * IB * 32 * 32 * sizeof(float);
-  size_t lds = lds_k > lds_r ? lds_k : lds_r;
-  AS_REQUIRE(lds <= 160 * 1024, AS_E_UNSUPPORTED, "rollout_step: LDS %zu B exceeds 160 KiB (h=%d T=%d)", lds, h, Trows);
-#define AS_RO_LAUNCH(IBV)                                                                                      \
-  do {                                                                                                         \
-    (void)hipFuncSetAttribute((const void*)rollout_step_kernel<T, IBV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                        (int)lds);                                                                             \
-    hipLaunchKernelGGL((rollout_step_kernel<T, IBV>), grid, dim3(RO_NT), lds, s, (const T*)q, (const T*)k, lse, \
-                       Rin, Rout, B, N, Npad, h, Trows);                                                       \
-  } while (0)
-  switch (IB) {
-    case 1: AS_RO_LAUNCH(1); break;
-    case 2: AS_RO_LAUNCH(2); break;
-    case 3: AS_RO_LAUNCH(3); break;
-    case 4: AS_RO_LAUNCH(4); break;
-    default: AS_REQUIRE(false, AS_E_UNSUPPORTED, "rollout_step: T=%d > 128 point tokens unsupported", Trows);
-  }
-#undef AS_RO_LAUNCH
-  AS_CHECK_LAUNCH("rollout_step");
-  return AS_OK;
-}
-
 }  // namespace
+
+extern "C" size_t as_rollout_rfrag_bytes(int B, int N, int dtype) {
+  if (B <= 0 || N <= 0) return 0;
+  return (size_t)B * as_ceil_div(N, 32) * 4 * 2 * 64 * 8 * (dtype == AS_BF16 ? 2 : 4);
+}
 
 extern "C" int as_attn_mean_rows(const void* q, const void* k, const float* lse, float* out, int B, int N, int h,
                                  int row0, int nrows, int dtype, as_stream_t stream) {
@@ -244,27 +310,29 @@ extern "C" int as_attn_mean_rows(const void* q, const void* k, const float* lse,
   AS_REQUIRE(B > 0 && N > 0 && h > 0 && row0 >= 0 && nrows > 0 && row0 + nrows <= N, AS_E_BADARG,
              "as_attn_mean_rows: bad row range %d+%d of %d", row0, nrows, N);
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == AS_BF16) return launch_mean_rows<__bf16>(q, k, lse, out, B, N, h, row0, nrows, false, s);
-  if (dtype == AS_F32) return launch_mean_rows<float>(q, k, lse, out, B, N, h, row0, nrows, false, s);
+  if (dtype == AS_BF16) return launch_mean_rows<__bf16>(q, k, lse, out, nullptr, B, N, h, row0, nrows, false, s);
+  if (dtype == AS_F32) return launch_mean_rows<float>(q, k, lse, out, nullptr, B, N, h, row0, nrows, false, s);
   AS_REQUIRE(false, AS_E_UNSUPPORTED, "as_attn_mean_rows: dtype %d", dtype);
 }
 
-extern "C" int as_rollout_top(const void* q, const void* k, const float* lse, float* R_out, int B, int N, int h,
-                              int T, int dtype, as_stream_t stream) {
+extern "C" int as_rollout_top(const void* q, const void* k, const float* lse, float* R_out, void* rf_out, int B, int N,
+                              int h, int T, int dtype, as_stream_t stream) {
   AS_REQUIRE(q && k && lse && R_out, AS_E_BADARG, "as_rollout_top: null pointer");
-  AS_REQUIRE(B > 0 && h > 0 && T > 0 && T <= N, AS_E_BADARG, "as_rollout_top: bad sizes N=%d T=%d", N, T);
+  AS_REQUIRE(B > 0 && h > 0 && T > 0 && T <= N && T <= 128, AS_E_BADARG, "as_rollout_top: bad sizes N=%d T=%d", N, T);
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == AS_BF16) return launch_mean_rows<__bf16>(q, k, lse, R_out, B, N, h, N - T, T, true, s);
-  if (dtype == AS_F32) return launch_mean_rows<float>(q, k, lse, R_out, B, N, h, N - T, T, true, s);
+  if (dtype == AS_BF16) return launch_mean_rows<__bf16>(q, k, lse, R_out, rf_out, B, N, h, N - T, T, true, s);
+  if (dtype == AS_F32) return launch_mean_rows<float>(q, k, lse, R_out, rf_out, B, N, h, N - T, T, true, s);
   AS_REQUIRE(false, AS_E_UNSUPPORTED, "as_rollout_top: dtype %d", dtype);
 }
 
-extern "C" int as_rollout_step(const void* q, const void* k, const float* lse, const float* R_in, float* R_out,
-                               int B, int N, int h, int T, int dtype, as_stream_t stream) {
-  AS_REQUIRE(q && k && lse && R_in && R_out && R_in != R_out, AS_E_BADARG, "as_rollout_step: null/aliased pointer");
-  AS_REQUIRE(B > 0 && h > 0 && T > 0 && T <= N, AS_E_BADARG, "as_rollout_step: bad sizes N=%d T=%d", N, T);
+extern "C" int as_rollout_step(const void* q, const void* k, const float* lse, const float* R_in, const void* rf_in,
+                               float* R_out, void* rf_out, int B, int N, int h, int T, int dtype, as_stream_t stream) {
+  AS_REQUIRE(q && k && lse && R_in && rf_in && R_out && R_in != R_out && rf_in != rf_out, AS_E_BADARG,
+             "as_rollout_step: null/aliased pointer");
+  AS_REQUIRE(B > 0 && h > 0 && h <= 16 && T > 0 && T <= N && T <= 128, AS_E_BADARG,
+             "as_rollout_step: bad sizes N=%d T=%d h=%d", N, T, h);
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == AS_BF16) return launch_rollout_step<__bf16>(q, k, lse, R_in, R_out, B, N, h, T, s);
-  if (dtype == AS_F32) return launch_rollout_step<float>(q, k, lse, R_in, R_out, B, N, h, T, s);
+  if (dtype == AS_BF16) return launch_rollout_step2<__bf16>(q, k, lse, R_in, rf_in, R_out, rf_out, B, N, h, T, s);
+  if (dtype == AS_F32) return launch_rollout_step2<float>(q, k, lse, R_in, rf_in, R_out, rf_out, B, N, h, T, s);
   AS_REQUIRE(false, AS_E_UNSUPPORTED, "as_rollout_step: dtype %d", dtype);
 }

@@ -71,13 +71,12 @@ __global__ __launch_bounds__(SD_NT) void sdpa_fwd_kernel(const T* __restrict__ q
   const int query = qt * SD_QB + wave * 32 + li;
   const int qclamped = min(query, N - 1);
 
-  const T* qb = q + (size_t)bh * Npad * HD;
   const T* kb_ = k + (size_t)bh * Npad * HD;
   const T* vb = vt + (size_t)bh * HD * Npad;
 
   Frag<T> fq[4];
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks) fq[ks].load16B(qb + (size_t)qclamped * HD + ks * 16 + half * 8);
+  for (int ks = 0; ks < 4; ++ks) fq[ks].load16B(q + qf_frag((size_t)bh, Npad, qclamped, ks, half));
 
   uint4 rk[K_CHUNKS], rv[V_CHUNKS];
   const int nkt = Npad / SD_KB;

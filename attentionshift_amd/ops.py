@@ -144,6 +144,19 @@ def attention_fwd(x, w_qkv, b_qkv, w_proj, b_proj, num_heads, keep_state=True):
     return out, (AttnLayerState(q, k, vt, lse, B, N, num_heads, dt) if keep_state else None)
 
 
+def q_to_fragment_major(q_rows):
+    """[B,h,Npad,64] row-major -> the fragment-major tile layout as_qkv_fwd writes (include/attnshift.h)."""
+    B, h, Np_, d = q_rows.shape
+    t = q_rows.reshape(B, h, Np_ // 32, 32, 4, 2, 8)            # [.., tile, r, ks, half, e]
+    return t.permute(0, 1, 2, 4, 5, 3, 6).contiguous().reshape(B, h, Np_, d)
+
+
+def q_from_fragment_major(q_frag):
+    B, h, Np_, d = q_frag.shape
+    t = q_frag.reshape(B, h, Np_ // 32, 4, 2, 32, 8)            # [.., tile, ks, half, r, e]
+    return t.permute(0, 1, 2, 5, 3, 4, 6).contiguous().reshape(B, h, Np_, d)
+
+
 def qkv_fwd(x, w_qkv, b_qkv, num_heads):
     lib = _lib.load()
     B, N, D = x.shape
@@ -183,17 +196,22 @@ def rollout_rows(states, num_point_tokens):
     lib = _lib.load()
     top = states[-1]
     T = int(num_point_tokens)
+    dev, dt = top.q.device, _dt(top.q)
+    nbytes = lib.as_rollout_rfrag_bytes(top.B, top.N, dt)
     outs = []
-    R = torch.empty(top.B, T, top.N, device=top.q.device, dtype=torch.float32)
-    _lib.check(lib.as_rollout_top(_p(top.q), _p(top.k), _p(top.lse), _p(R), top.B, top.N, top.h, T, _dt(top.q), _stream()),
+    R = torch.empty(top.B, T, top.N, device=dev, dtype=torch.float32)
+    rf = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+    _lib.check(lib.as_rollout_top(_p(top.q), _p(top.k), _p(top.lse), _p(R), _p(rf), top.B, top.N, top.h, T, dt, _stream()),
                "as_rollout_top")
     outs.append(R)
-    for st in reversed(states[:-1]):
+    lower = list(reversed(states[:-1]))
+    for n, st in enumerate(lower):
         Rn = torch.empty_like(R)
-        _lib.check(lib.as_rollout_step(_p(st.q), _p(st.k), _p(st.lse), _p(R), _p(Rn), st.B, st.N, st.h, T, _dt(st.q),
-                                       _stream()), "as_rollout_step")
+        rfn = torch.empty_like(rf) if n + 1 < len(lower) else None
+        _lib.check(lib.as_rollout_step(_p(st.q), _p(st.k), _p(st.lse), _p(R), _p(rf), _p(Rn), _p(rfn), st.B, st.N, st.h, T,
+                                       dt, _stream()), "as_rollout_step")
         outs.append(Rn)
-        R = Rn
+        R, rf = Rn, rfn
     return torch.stack(outs, dim=1)
 
 

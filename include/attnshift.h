@@ -57,7 +57,9 @@ int as_linear_fwd(const void* x, const void* W, const float* bias, void* out, in
                   int dtype, int act, as_stream_t stream);
 
 /* QKV projection with the head split fused into the epilogue (vision_transformer.py:75-77):
- *   q,k : [B,h,Npad,64]   vt : [B,h,64,Npad]  (V transposed so the P.V MFMA reads keys contiguously)
+ *   k : [B,h,Npad,64]   vt : [B,h,64,Npad]  (V transposed so the P.V MFMA reads keys contiguously)
+ *   q : [B,h,Npad,64] elements, FRAGMENT-MAJOR inside every 32-row x 64-d tile: element (r, d) of a tile sits at
+ *       ((d/16)*64 + r + 32*((d%16)/8))*8 + d%8, so the MFMA operand loads of sdpa / roll-out are coalesced
  * rows/cols >= N of the padded layouts are never read unmasked, so they need no initialisation. */
 int as_qkv_fwd(const void* x /*[B,N,D]*/, const void* Wqkv /*[3D,D]*/, const float* bqkv /*[3D] or NULL*/,
                void* q, void* k, void* vt, int B, int N, int D, int h, int dtype, as_stream_t stream);
@@ -79,14 +81,17 @@ int as_attn_fwd(const void* x, const void* Wqkv, const float* bqkv, const void* 
 int as_attn_mean_rows(const void* q, const void* k, const float* lse, float* out, int B, int N, int h,
                       int row0, int nrows, int dtype, as_stream_t stream);
 
-/* One step of the row-sliced attention roll-out (stdroi:1257-1272 attns_project_to_feature):
- *   A_hat = (mean_h P + I) / rowsum ,  R_out = R_in . A_hat         R : [B,T,N] fp32
- * with P recomputed tile by tile from q,k,lse of that layer.  The top layer's R is
- * (as_attn_mean_rows(row0 = N-T) + I_rows) / 2 (as_rollout_top). */
-int as_rollout_top(const void* q, const void* k, const float* lse, float* R_out, int B, int N, int h, int T,
-                   int dtype, as_stream_t stream);
-int as_rollout_step(const void* q, const void* k, const float* lse, const float* R_in, float* R_out, int B,
-                    int N, int h, int T, int dtype, as_stream_t stream);
+/* Row-sliced attention roll-out (stdroi:1257-1272 attns_project_to_feature, rows [-T:] only, T <= 128):
+ *   A_hat = (mean_h P + I) / rowsum (rowsum == 2),   R_out = R_in . A_hat        R : [B,T,N] fp32
+ * with the tiles of mean_h P recomputed from q,k,lse of that layer.  as_rollout_top gives the top layer's
+ * R = rows [N-T, N) of A_hat.  Next to the fp32 row-major R every call also emits a FRAGMENT-MAJOR copy `rf`
+ * (as_rollout_rfrag_bytes; element dtype = `dtype`) that the next step reads as its MFMA A operand with fully
+ * coalesced loads; rf_out may be NULL on the last step. */
+size_t as_rollout_rfrag_bytes(int B, int N, int dtype);
+int as_rollout_top(const void* q, const void* k, const float* lse, float* R_out, void* rf_out, int B, int N, int h,
+                   int T, int dtype, as_stream_t stream);
+int as_rollout_step(const void* q, const void* k, const float* lse, const float* R_in, const void* rf_in,
+                    float* R_out, void* rf_out, int B, int N, int h, int T, int dtype, as_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Part B -- attention-shift pseudo-label generator (stdroi:2209-2415), fp32 + int32

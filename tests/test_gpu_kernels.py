@@ -70,7 +70,7 @@ def test_qkv_layout(ops, dtype):
     ref = torch.nn.functional.linear(x.float(), w.float(), b).reshape(B, N, 3, h, 64).permute(2, 0, 3, 1, 4)
     q, k, vt = ops.qkv_fwd(dev(x), dev(w), dev(b), h)
     tol = 1e-4 if dtype == torch.float32 else 2e-2
-    assert_close(ref[0], q[:, :, :N].float(), tol, tol, "q")
+    assert_close(ref[0], ops.q_from_fragment_major(q)[:, :, :N].float(), tol, tol, "q (fragment-major workspace)")
     assert_close(ref[1], k[:, :, :N].float(), tol, tol, "k")
     assert_close(ref[2].transpose(-1, -2), vt[:, :, :, :N].float(), tol, tol, "v^T")
 
@@ -124,7 +124,7 @@ def test_sdpa_spike_row_forces_rescale(ops):
     Np_ = ops.npad(N)
     qp = torch.zeros(B, h, Np_, 64); kp = torch.zeros(B, h, Np_, 64); vtp = torch.zeros(B, h, 64, Np_)
     qp[:, :, :N], kp[:, :, :N], vtp[:, :, :, :N] = q, k, v.transpose(-1, -2)
-    o, lse = ops.sdpa_fwd(dev(qp), dev(kp), dev(vtp), N)
+    o, lse = ops.sdpa_fwd(ops.q_to_fragment_major(dev(qp)), dev(kp), dev(vtp), N)
     p = ((q @ k.transpose(-1, -2)) * 0.125).softmax(-1)
     ref = (p @ v).transpose(1, 2).reshape(B, N, 64)
     mx, _ = rel_to_range(ref, o)

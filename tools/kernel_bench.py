@@ -76,6 +76,12 @@ def main():
         emit("fc1_gelu_gemm_bf16", ms, 2.0 * B * N * D * 4 * D, peak=PEAK_BF16)
         ms = timeit(lambda: torch.nn.functional.linear(xb, w1), a.reps)
         emit("torch_hipblaslt_fc1_bf16", ms, 2.0 * B * N * D * 4 * D, peak=PEAK_BF16)
+        h1 = ops.linear(xb, w1, b1, act="gelu")
+        w2 = (torch.randn(D, 4 * D, generator=g) * 0.03).to(dev).bfloat16()
+        ms = timeit(lambda: ops.linear(h1, w2, bproj), a.reps)
+        emit("fc2_gemm_bf16", ms, 2.0 * B * N * D * 4 * D, peak=PEAK_BF16)
+        ms = timeit(lambda: torch.nn.functional.linear(h1, w2), a.reps)
+        emit("torch_hipblaslt_fc2_bf16", ms, 2.0 * B * N * D * 4 * D, peak=PEAK_BF16)
     if want("attn"):
         ms = timeit(lambda: ops.attention_fwd(xb, wqb, bqkv, wpb, bproj, h), a.reps)
         emit("attention_fwd_bf16(qkv+sdpa+proj)", ms, B * (2.0 * N * D * 3 * D + 4.0 * N * N * D + 2.0 * N * D * D), peak=PEAK_BF16)
