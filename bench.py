@@ -51,7 +51,8 @@ def build(device):
 
     hp = wp = CFG["img"] // CFG["patch"]
     G, Lc, T, B = CFG["objects"], CFG["cam_layer"], CFG["point_tokens"], CFG["batch"]
-    shift = [synthetic.shift_inputs(1234 + b, hp, wp, CFG["embed_dim"], G, Lc) for b in range(B)]
+    rank = int(os.environ.get("RANK", "0"))                # every rank works on its own images (weak scaling)
+    shift = [synthetic.shift_inputs(1234 + rank * B + b, hp, wp, CFG["embed_dim"], G, Lc) for b in range(B)]
     cams = torch.stack([s["cams"].flatten(2) for s in shift]).to(device)          # [B, Lc, G, Np]
     vit_feat = torch.stack([s["vit_feat"] for s in shift]).to(device)             # [B, C, hp, wp]
     gt_points = [s["points"].to(device) for s in shift]
@@ -63,11 +64,11 @@ def build(device):
             rows[:, :, :G, 1:-num_proposals] = cams                              # seeded, non-degenerate CAMs
             return rows
 
-    head = BenchHead(num_semantic_points=5, mean_shift_times_local=CFG["n_shift"], rng_mode=os.environ.get("AS_RNG_MODE", "fast"),
+    head = BenchHead(num_semantic_points=5, mean_shift_times_local=CFG["n_shift"], rng_mode=os.environ.get("AS_RNG_MODE", "reference"),
                      bbox_head=dict(type="MAEBoxHeadRec", seed_thr=0.2, seed_multiple=0.5, cam_layer=Lc,
                                     num_classes=CFG["num_classes"]),
                      mil_head=dict(type="MAEBoxHeadMIL", num_layers_query=Lc))
-    img = synthetic.images(B, CFG["img"], CFG["img"], seed=0).to(device)
+    img = synthetic.images(B, CFG["img"], CFG["img"], seed=rank).to(device)
     metas = [dict(img_shape=(CFG["img"], CFG["img"], 3)) for _ in range(B)]
     pos_inds = [torch.arange(G, device=device) for _ in range(B)]
 
@@ -142,15 +143,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=device)
+    from attentionshift_amd.dist import Ranks
+    ranks = Ranks(backend="nccl", device=device)          # "nccl" is RCCL on ROCm
+    world, rank = ranks.world, ranks.rank
 
     from attentionshift_amd import ops
     # the host side of this path is a single Python thread; a 256-thread intra-op pool only adds spin-wait noise
@@ -160,22 +158,17 @@ def main():
         for _ in range(a.warmup):
             step()
         ops.enable_timing(["sdpa_fwd", "cosine_shift"])
-        if dist is not None:
-            dist.barrier()
+        ranks.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(a.steps):
             step()
         torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
+        ranks.barrier()
         elapsed = time.perf_counter() - t0
     timing = ops.collect_timing()
     ops.disable_timing()
-    if dist is not None:
-        tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    elapsed = ranks.max_over_ranks(elapsed)
 
     if rank == 0:
         B, N, h = CFG["batch"], 1 + (CFG["img"] // CFG["patch"]) ** 2 + CFG["point_tokens"], CFG["heads"]
@@ -206,8 +199,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline()
         print(json.dumps(rec), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
+    ranks.close()
 
 
 if __name__ == "__main__":
