@@ -59,8 +59,7 @@ __global__ __launch_bounds__(SD_NT) void sdpa_fwd_kernel(const T* __restrict__ q
   constexpr int K_CHUNKS = SD_KB * HD / EPC / SD_NT;         // per thread
   constexpr int V_CHUNKS = HD * SD_KB / EPC / SD_NT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* Ks = smem;
-  char* Vs = smem + SD_KB * Cfg::K_PITCH;
+  constexpr int BUF_BYTES = SD_KB * Cfg::K_PITCH + HD * Cfg::V_PITCH;     // one K tile + one V^T tile
 
   const int BH = B * h;
   const int bid = blockIdx.x;
@@ -101,7 +100,9 @@ __global__ __launch_bounds__(SD_NT) void sdpa_fwd_kernel(const T* __restrict__ q
       rv[i] = u;
     }
   };
-  auto lstore = [&]() {
+  auto lstore = [&](int buf) {
+    char* Ks = smem + buf * BUF_BYTES;
+    char* Vs = Ks + SD_KB * Cfg::K_PITCH;
 #pragma unroll
     for (int i = 0; i < K_CHUNKS; ++i) {
       const int c = tid + i * SD_NT;
@@ -129,10 +130,12 @@ __global__ __launch_bounds__(SD_NT) void sdpa_fwd_kernel(const T* __restrict__ q
   const float c2 = 0.125f * 1.44269504088896340736f;   // d^-0.5 * log2(e)
 
   gload(0);
-  lstore();
+  lstore(0);
   __syncthreads();
   for (int kt = 0; kt < nkt; ++kt) {
     if (kt + 1 < nkt) gload(kt + 1);
+    const char* Ks = smem + (kt & 1) * BUF_BYTES;
+    const char* Vs = Ks + SD_KB * Cfg::K_PITCH;
 
     // ---- S^T = K . Q^T : two 32-key blocks ----
     f32x16 sacc[2];
@@ -177,8 +180,10 @@ __global__ __launch_bounds__(SD_NT) void sdpa_fwd_kernel(const T* __restrict__ q
         fp[kb][r >> 3].set(r & 7, p);
       }
     l_part = l_part * alpha + psum;
+    if (!__all(alpha == 1.0f)) {          // the running max moved for some query of this wave: rescale O
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { oacc[0][r] *= alpha; oacc[1][r] *= alpha; }
+      for (int r = 0; r < 16; ++r) { oacc[0][r] *= alpha; oacc[1][r] *= alpha; }
+    }
 
     // ---- O^T += V^T . P^T ----
 #pragma unroll
@@ -193,11 +198,9 @@ __global__ __launch_bounds__(SD_NT) void sdpa_fwd_kernel(const T* __restrict__ q
           oacc[db] = mma32(fv, fp[kb][s], oacc[db]);
         }
     }
+    // the other buffer was last read in iteration kt-1, and every wave has passed the barrier that ended it
+    if (kt + 1 < nkt) lstore((kt + 1) & 1);
     __syncthreads();
-    if (kt + 1 < nkt) {
-      lstore();
-      __syncthreads();
-    }
   }
 
   // ---- epilogue: normalise, store O (heads concatenated) and lse ----
@@ -217,12 +220,250 @@ __global__ __launch_bounds__(SD_NT) void sdpa_fwd_kernel(const T* __restrict__ q
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// bf16 fast path.  Same dataflow as sdpa_fwd_kernel, but the K and V^T tiles go global -> LDS with
+// global_load_lds_dwordx4 (no staging VGPRs) into a 3-deep LDS ring: tile kt+2 is in flight while tile kt is
+// consumed, with counted `s_waitcnt vmcnt(N)` + raw s_barrier so the LDS-DMA spans the barriers.  The LDS images are
+// lane-linear, so the bank swizzle sits on the source address: K row r keeps global 16-B chunk c at c ^ (r & 7);
+// V^T row d keeps chunk c at c ^ ((d >> 1) & 7) (2-way on the 8-byte fragment reads, the optimum for same-half
+// reads).  Padded keys of the last tile are zeroed in LDS (P is exactly 0 there, but 0 * garbage must stay 0).
+// ---------------------------------------------------------------------------------------------------------
+// LDS reads the compiler must NOT see: after an LDS-DMA hipcc drains vmcnt(0) before any ds_read it can see (it cannot
+// prove the read does not alias the DMA destination), which would collapse the 3-deep ring to depth 0.  The reads are
+// issued in inline asm and completed by lds_wait<>, which names every destination as read-write so nothing is
+// consumed early (cdna_hip_programming.md section 5.7, form ii), followed by a sched_barrier (rule 18).
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+  return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;
+}
+__device__ __forceinline__ void lds_read128(u32x4& dst, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr));
+}
+__device__ __forceinline__ void lds_read64(u32x2& dst, unsigned addr) {
+  asm volatile("ds_read_b64 %0, %1" : "=v"(dst) : "v"(addr));
+}
+__device__ __forceinline__ void lds_wait4(u32x4& a, u32x4& b, u32x4& c, u32x4& d) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+  __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ void lds_wait8(u32x2 (&v)[8]) {
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+constexpr int GL_TILE = SD_KB * HD * 2;          // 8 KiB per K (or V^T) tile
+constexpr int GL_NBUF = 3;                       // LDS ring: tiles kt, kt+1, kt+2 (48 KiB per workgroup)
+
+__global__ __launch_bounds__(SD_NT, 3) void sdpa_fwd_glds_kernel(const __bf16* __restrict__ q, const __bf16* __restrict__ k,
+                                                                 const __bf16* __restrict__ vt, __bf16* __restrict__ o,
+                                                                 float* __restrict__ lse, int B, int N, int Npad, int h) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];     // [2][K tile | V^T tile]
+  const int BH = B * h;
+  const int bid = blockIdx.x;
+  const int bh = bid % BH, qt = bid / BH;
+  const int b = bh / h, head = bh % h;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, half = lane >> 5;
+  const int query = qt * SD_QB + wave * 32 + li;
+  const int qclamped = min(query, N - 1);
+
+  Frag<__bf16> fq[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) fq[ks].load16B(q + qf_frag((size_t)bh, Npad, qclamped, ks, half));
+  // consume Q here so hipcc waits for these ordinary loads BEFORE the ring starts; otherwise it re-waits vmcnt(0) at
+  // their first use inside the loop on every iteration and drains the LDS-DMA ring
+  asm volatile("; Q fragments landed" : "+v"(fq[0].v), "+v"(fq[1].v), "+v"(fq[2].v), "+v"(fq[3].v));
+
+  // loader: per tile each wave moves 2 one-KiB pieces of K and 2 of V^T (8 rows x 128 B each)
+  const int lr = lane >> 3, lc = lane & 7;
+  const char* srcK[2];
+  const char* srcV[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int r = (wave * 2 + j) * 8 + lr;                         // key row of the K tile / d row of the V^T tile
+    srcK[j] = reinterpret_cast<const char*>(k + ((size_t)bh * Npad + r) * HD) + ((lc ^ (r & 7)) << 4);
+    srcV[j] = reinterpret_cast<const char*>(vt + ((size_t)bh * HD + r) * Npad) + ((lc ^ ((r >> 1) & 7)) << 4);
+  }
+  auto stage = [&](int kt, int buf) {
+    char* base = smem + buf * (2 * GL_TILE);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int piece = (wave * 2 + j) * 1024;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcK[j] + (size_t)kt * SD_KB * HD * 2),
+                                       (__attribute__((address_space(3))) void*)(base + piece), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcV[j] + (size_t)kt * SD_KB * 2),
+                                       (__attribute__((address_space(3))) void*)(base + GL_TILE + piece), 16, 0, 0);
+    }
+  };
+
+  f32x16 oacc[2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { oacc[0][r] = 0.0f; oacc[1][r] = 0.0f; }
+  float m_run = -INFINITY, l_part = 0.0f;
+  const float c2 = 0.125f * 1.44269504088896340736f;
+  const int nkt = Npad / SD_KB;
+
+  // Ring protocol: at the top of iteration kt tiles kt and kt+1 are in flight or landed; tile kt+2 is issued into
+  // the buffer last read in iteration kt-1 (every wave passed the barrier that ended it).  Each wave issues 4 LDS-DMA
+  // pieces per tile, so `vmcnt(8)` = "everything except the two newest tiles has landed" = tile kt is in LDS; the
+  // barrier then publishes all waves' pieces.  Raw s_barrier: __syncthreads() would drain vmcnt(0).
+  stage(0, 0);
+  if (GL_NBUF > 2 && nkt > 1) stage(1, 1);
+  for (int kt = 0; kt < nkt; ++kt) {
+    if (GL_NBUF > 2) {
+      if (kt + 2 < nkt) {
+        stage(kt + 2, (kt + 2) % GL_NBUF);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      } else if (kt + 1 < nkt) {
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+    } else {                                   // two buffers: tile kt+1 is issued while tile kt is consumed
+      if (kt + 1 < nkt) {
+        stage(kt + 1, (kt + 1) % GL_NBUF);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+    }
+    __builtin_amdgcn_s_barrier();
+    char* Ks = smem + (kt % GL_NBUF) * (2 * GL_TILE);
+    char* Vs = Ks + GL_TILE;
+    const bool ragged = (kt == nkt - 1) && (N % SD_KB) != 0;
+    if (ragged) {                                   // zero V^T columns of the padded keys (workgroup-uniform branch)
+      for (int e = tid; e < HD * SD_KB; e += SD_NT) {
+        const int d = e >> 6, key = e & 63;
+        if (kt * SD_KB + key >= N)
+          *reinterpret_cast<__bf16*>(Vs + d * 128 + ((((key >> 3) ^ ((d >> 1) & 7))) << 4) + (key & 7) * 2) = (__bf16)0.0f;
+      }
+      __syncthreads();
+    }
+
+    f32x16 sacc[2];
+    const unsigned ks_base = lds_addr(Ks);
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.0f;
+      const int row = kb * 32 + li;
+      u32x4 kf[4];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) lds_read128(kf[ks], ks_base + row * 128 + ((((ks << 1) | half) ^ (row & 7)) << 4));
+      lds_wait4(kf[0], kf[1], kf[2], kf[3]);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        Frag<__bf16> fk;
+        fk.v = *reinterpret_cast<bf16x8*>(&kf[ks]);
+        sacc[kb] = mma32(fk, fq[ks], sacc[kb]);
+      }
+    }
+    if (ragged) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (kt * SD_KB + kb * 32 + acc_row(r, half) >= N) sacc[kb][r] = -INFINITY;
+    }
+
+    float mloc = sacc[0][0];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, sacc[kb][r]);
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+    const float m_new = fmaxf(m_run, mloc);
+    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c2);
+    const float mc = m_new * c2;
+    m_run = m_new;
+    float psum = 0.0f;
+    Frag<__bf16> fp[2][2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = __builtin_amdgcn_exp2f(fmaf(sacc[kb][r], c2, -mc));
+        psum += p;
+        fp[kb][r >> 3].set(r & 7, p);
+      }
+    l_part = l_part * alpha + psum;
+    if (!__all(alpha == 1.0f)) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { oacc[0][r] *= alpha; oacc[1][r] *= alpha; }
+    }
+
+    const unsigned vs_base = lds_addr(Vs);
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+      const int d = db * 32 + li;
+      const unsigned vrow = vs_base + d * 128;
+      const int sw = (d >> 1) & 7;
+      u32x2 vf[8];
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          // keys key0..key0+3 and key0+8..key0+11, key0 = kb*32 + s2*16 + half*4  (8-byte units u and u+2)
+          const int u = kb * 8 + s2 * 4 + half;
+          lds_read64(vf[(kb * 2 + s2) * 2 + 0], vrow + (((u >> 1) ^ sw) << 4) + (u & 1) * 8);
+          lds_read64(vf[(kb * 2 + s2) * 2 + 1], vrow + ((((u + 2) >> 1) ^ sw) << 4) + (u & 1) * 8);
+        }
+      lds_wait8(vf);
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const u32x2 a = vf[(kb * 2 + s2) * 2 + 0], c = vf[(kb * 2 + s2) * 2 + 1];
+          uint4 w4 = make_uint4(a[0], a[1], c[0], c[1]);
+          Frag<__bf16> fv;
+          fv.v = *reinterpret_cast<bf16x8*>(&w4);
+          oacc[db] = mma32(fv, fp[kb][s2], oacc[db]);
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my LDS reads of this tile are done ...
+    __builtin_amdgcn_s_barrier();                         // ... and so are everybody else's: the buffer may be refilled
+  }
+
+  const float l = l_part + __shfl_xor(l_part, 32);
+  const float inv = 1.0f / l;
+  if (query < N) {
+    __bf16* orow = o + ((size_t)b * N + query) * ((size_t)h * HD) + head * HD;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d = db * 32 + 8 * g + 4 * half;
+        store4(orow + d, oacc[db][4 * g] * inv, oacc[db][4 * g + 1] * inv, oacc[db][4 * g + 2] * inv,
+               oacc[db][4 * g + 3] * inv);
+      }
+    if (half == 0) lse[(size_t)bh * N + query] = m_run * 0.125f + logf(l);
+  }
+}
+
+int launch_sdpa_glds(const void* q, const void* k, const void* vt, void* o, float* lse, int B, int N, int h,
+                     hipStream_t s) {
+  const int Npad = as_round_up(N, 64);
+  const int grid = as_ceil_div(N, SD_QB) * B * h;
+  const size_t lds = (size_t)GL_NBUF * 2 * GL_TILE;        // 48 KiB
+  hipLaunchKernelGGL(sdpa_fwd_glds_kernel, dim3(grid), dim3(SD_NT), lds, s, (const __bf16*)q, (const __bf16*)k,
+                     (const __bf16*)vt, (__bf16*)o, lse, B, N, Npad, h);
+  AS_CHECK_LAUNCH("sdpa_fwd_glds");
+  return AS_OK;
+}
+
 template <typename T>
 int launch_sdpa(const void* q, const void* k, const void* vt, void* o, float* lse, int B, int N, int h,
                 hipStream_t s) {
   const int Npad = as_round_up(N, 64);
   const int grid = as_ceil_div(N, SD_QB) * B * h;
-  const size_t lds = (size_t)SD_KB * SdpaCfg<T>::K_PITCH + (size_t)HD * SdpaCfg<T>::V_PITCH;
+  const size_t lds = 2 * ((size_t)SD_KB * SdpaCfg<T>::K_PITCH + (size_t)HD * SdpaCfg<T>::V_PITCH);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)sdpa_fwd_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
   hipLaunchKernelGGL((sdpa_fwd_kernel<T>), dim3(grid), dim3(SD_NT), lds, s, (const T*)q, (const T*)k,
                      (const T*)vt, (T*)o, lse, B, N, Npad, h);
   AS_CHECK_LAUNCH("sdpa_fwd");
@@ -236,7 +477,7 @@ extern "C" int as_sdpa_fwd(const void* q, const void* k, const void* vt, void* o
   AS_REQUIRE(q && k && vt && o && lse, AS_E_BADARG, "as_sdpa_fwd: null pointer");
   AS_REQUIRE(B > 0 && N > 0 && h > 0, AS_E_BADARG, "as_sdpa_fwd: bad sizes B=%d N=%d h=%d", B, N, h);
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == AS_BF16) return launch_sdpa<__bf16>(q, k, vt, o, lse, B, N, h, s);
+  if (dtype == AS_BF16) return launch_sdpa_glds(q, k, vt, o, lse, B, N, h, s);
   if (dtype == AS_F32) return launch_sdpa<float>(q, k, vt, o, lse, B, N, h, s);
   AS_REQUIRE(false, AS_E_UNSUPPORTED, "as_sdpa_fwd: dtype %d", dtype);
 }
