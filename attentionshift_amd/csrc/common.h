@@ -52,6 +52,7 @@ template <> struct Frag<__bf16> {
   bf16x8 v;
   __device__ __forceinline__ void load16B(const __bf16* p) { v = *reinterpret_cast<const bf16x8*>(p); }
   __device__ __forceinline__ void zero() {
+#pragma unroll
     for (int t = 0; t < 8; ++t) v[t] = (__bf16)0.0f;
   }
   __device__ __forceinline__ void set(int t, float x) { v[t] = (__bf16)x; }
@@ -64,6 +65,7 @@ template <> struct Frag<float> {
     v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
   }
   __device__ __forceinline__ void zero() {
+#pragma unroll
     for (int t = 0; t < 8; ++t) v[t] = 0.0f;
   }
   __device__ __forceinline__ void set(int t, float x) { v[t] = x; }

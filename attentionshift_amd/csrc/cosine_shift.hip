@@ -22,7 +22,7 @@ namespace {
 
 constexpr int CS_NT = 256;
 constexpr int CS_TILE1 = 32;     // patches per sim tile
-constexpr int CS_TILE3 = 128;    // patches per aggregation tile
+constexpr int CS_TILE3 = 32;     // patches per aggregation tile
 constexpr int PMAX = 32;
 constexpr float COS_EPS = 1e-8f;
 
@@ -94,16 +94,27 @@ __global__ __launch_bounds__(CS_NT) void sim_kernel(const float* __restrict__ fe
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
   const int nsteps = (C + 15) / 16;
-  for (int s = wave; s < nsteps; s += 4) {
-    const int k0 = s * 16 + half * 8;
-    Frag<float> fa, fb;
-    if (k0 + 8 <= C) {
-      fb.load16B(frow + k0);
-      if (pvalid) fa.load16B(prow + k0); else fa.zero();
-    } else {
-      fa.zero(); fb.zero();
+  // SU k16 steps of this wave per trip, all 2*SU operand loads issued before the first MFMA (a step past the end
+  // or a row past P reads a valid address and is multiplied by 0)
+  constexpr int SU = 6;
+  for (int s = wave; s < nsteps; s += 4 * SU) {
+    Frag<float> fa[SU], fb[SU];
+    float keep[SU];
+#pragma unroll
+    for (int u = 0; u < SU; ++u) {
+      const int su = s + 4 * u;
+      const bool ok = su < nsteps && su * 16 + half * 8 + 8 <= C;
+      const int k0 = ok ? su * 16 + half * 8 : 0;
+      fb[u].load16B(frow + k0);
+      fa[u].load16B(prow + k0);
+      keep[u] = (ok && pvalid) ? 1.0f : 0.0f;
     }
-    acc = mma32(fa, fb, acc);          // D[p][n]
+#pragma unroll
+    for (int u = 0; u < SU; ++u) {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) fa[u].v[t] *= keep[u];
+      acc = mma32(fa[u], fb[u], acc);          // D[p][n]
+    }
   }
 #pragma unroll
   for (int r = 0; r < 16; ++r) red[wave][acc_row(r, half)][li] = acc[r];
@@ -260,29 +271,38 @@ __global__ __launch_bounds__(CS_NT) void assign_kernel(const float* __restrict__
 #pragma unroll
     for (int p = 0; p < PMAX; ++p) acc[i][p] = 0.0f;
   const float* fb = feat + (size_t)b * Np * C;
-  for (int j = 0; j < count; ++j) {
-    const int a = __builtin_amdgcn_readfirstlane(a_s[j]);
-    const float wa = w_s[j];
-    const float* frow = fb + (size_t)n_s[j] * C;
-    float f[CPT];
+  constexpr int UNR = 8;                 // feature rows of UNR patches are in flight before the first one is used
+  for (int j0 = 0; j0 < count; j0 += UNR) {
+    float f[UNR][CPT];
 #pragma unroll
-    for (int i = 0; i < CPT; ++i) {
-      const int c = tid + i * CS_NT;
-      f[i] = c < C ? frow[c] : 0.0f;
+    for (int u = 0; u < UNR; ++u) {
+      const float* frow = fb + (size_t)n_s[min(j0 + u, count - 1)] * C;
+#pragma unroll
+      for (int i = 0; i < CPT; ++i) {
+        const int c = tid + i * CS_NT;
+        f[u][i] = c < C ? frow[c] : 0.0f;
+      }
     }
-    // wave-uniform selection of the accumulator: compiles to a scalar branch tree, registers stay static
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      if (j0 + u < count) {                // workgroup-uniform
+        const int a = __builtin_amdgcn_readfirstlane(a_s[j0 + u]);
+        const float wa = w_s[j0 + u];
+        // wave-uniform selection of the accumulator: compiles to a scalar branch tree, registers stay static
 #define AS_CASE(PP)                                                            \
   case PP:                                                                     \
-    _Pragma("unroll") for (int i = 0; i < CPT; ++i) acc[i][PP] = fmaf(wa, f[i], acc[i][PP]); \
+    _Pragma("unroll") for (int i = 0; i < CPT; ++i) acc[i][PP] = fmaf(wa, f[u][i], acc[i][PP]); \
     break;
-    switch (a) {
-      AS_CASE(0) AS_CASE(1) AS_CASE(2) AS_CASE(3) AS_CASE(4) AS_CASE(5) AS_CASE(6) AS_CASE(7)
-      AS_CASE(8) AS_CASE(9) AS_CASE(10) AS_CASE(11) AS_CASE(12) AS_CASE(13) AS_CASE(14) AS_CASE(15)
-      AS_CASE(16) AS_CASE(17) AS_CASE(18) AS_CASE(19) AS_CASE(20) AS_CASE(21) AS_CASE(22) AS_CASE(23)
-      AS_CASE(24) AS_CASE(25) AS_CASE(26) AS_CASE(27) AS_CASE(28) AS_CASE(29) AS_CASE(30) AS_CASE(31)
-      default: break;
-    }
+        switch (a) {
+          AS_CASE(0) AS_CASE(1) AS_CASE(2) AS_CASE(3) AS_CASE(4) AS_CASE(5) AS_CASE(6) AS_CASE(7)
+          AS_CASE(8) AS_CASE(9) AS_CASE(10) AS_CASE(11) AS_CASE(12) AS_CASE(13) AS_CASE(14) AS_CASE(15)
+          AS_CASE(16) AS_CASE(17) AS_CASE(18) AS_CASE(19) AS_CASE(20) AS_CASE(21) AS_CASE(22) AS_CASE(23)
+          AS_CASE(24) AS_CASE(25) AS_CASE(26) AS_CASE(27) AS_CASE(28) AS_CASE(29) AS_CASE(30) AS_CASE(31)
+          default: break;
+        }
 #undef AS_CASE
+      }
+    }
   }
   float* pp = part_prot + ((size_t)g * nt3 + tile) * P * C;
 #pragma unroll
@@ -314,8 +334,19 @@ __global__ __launch_bounds__(CS_NT) void finalize_kernel(const float* __restrict
   const int ntiles = (nb + CS_TILE3 - 1) / CS_TILE3;
   float sq = 0.0f;
   for (int c = tid; c < C; c += CS_NT) {
-    float v = 0.0f;
-    for (int t = 0; t < ntiles; ++t) v += part_prot[(((size_t)g * nt3 + t) * P + p) * C + c];
+    // four interleaved partial sums (independent loads in flight), combined in a fixed order: deterministic
+    float v0 = 0.0f, v1 = 0.0f, v2 = 0.0f, v3 = 0.0f;
+    const float* base = part_prot + (((size_t)g * nt3) * P + p) * C + c;
+    const size_t step = (size_t)P * C;
+    int t = 0;
+    for (; t + 4 <= ntiles; t += 4) {
+      v0 += base[(size_t)t * step];
+      v1 += base[(size_t)(t + 1) * step];
+      v2 += base[(size_t)(t + 2) * step];
+      v3 += base[(size_t)(t + 3) * step];
+    }
+    for (; t < ntiles; ++t) v0 += base[(size_t)t * step];
+    const float v = (v0 + v1) + (v2 + v3);
     prot[((size_t)g * P + p) * C + c] = v;
     sq = fmaf(v, v, sq);
   }
