@@ -309,27 +309,21 @@ __global__ __launch_bounds__(SD_NT, 3) void sdpa_fwd_glds_kernel(const __bf16* _
   // the buffer last read in iteration kt-1 (every wave passed the barrier that ended it).  Each wave issues 4 LDS-DMA
   // pieces per tile, so `vmcnt(8)` = "everything except the two newest tiles has landed" = tile kt is in LDS; the
   // barrier then publishes all waves' pieces.  Raw s_barrier: __syncthreads() would drain vmcnt(0).
+  // Ring protocol (GL_NBUF = 3, ONE barrier per tile): entering iteration kt, tile kt has landed and been published
+  // and tile kt+1 is in flight; tile kt+2 is issued into the buffer last read in iteration kt-1 (every wave passed the
+  // barrier that ended it).  Each wave issues 4 LDS-DMA pieces per tile, so at the end of the iteration `vmcnt(4)`
+  // = "everything but the newest tile has landed" = tile kt+1 is in LDS; the barrier publishes it and at the same
+  // time certifies that tile kt is fully consumed.  Raw s_barrier: __syncthreads() would drain vmcnt(0).
   stage(0, 0);
-  if (GL_NBUF > 2 && nkt > 1) stage(1, 1);
+  if (nkt > 1) {
+    stage(1, 1);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
   for (int kt = 0; kt < nkt; ++kt) {
-    if (GL_NBUF > 2) {
-      if (kt + 2 < nkt) {
-        stage(kt + 2, (kt + 2) % GL_NBUF);
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      } else if (kt + 1 < nkt) {
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-    } else {                                   // two buffers: tile kt+1 is issued while tile kt is consumed
-      if (kt + 1 < nkt) {
-        stage(kt + 1, (kt + 1) % GL_NBUF);
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-    }
-    __builtin_amdgcn_s_barrier();
+    if (kt + 2 < nkt) stage(kt + 2, (kt + 2) % GL_NBUF);
     char* Ks = smem + (kt % GL_NBUF) * (2 * GL_TILE);
     char* Vs = Ks + GL_TILE;
     const bool ragged = (kt == nkt - 1) && (N % SD_KB) != 0;
@@ -374,10 +368,19 @@ __global__ __launch_bounds__(SD_NT, 3) void sdpa_fwd_glds_kernel(const __bf16* _
 #pragma unroll
       for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, sacc[kb][r]);
     mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
-    const float m_new = fmaxf(m_run, mloc);
-    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c2);
-    const float mc = m_new * c2;
-    m_run = m_new;
+    // deferred running max (guide T13): keep the stale max while no query of this wave saw its max grow by more than
+    // 2^8; P is then bounded by 2^8 instead of 1, O / l stay consistent, and the O rescale + its exp are skipped.
+    // (the first tile always takes the branch: m_run = -inf)
+    const float m_cand = fmaxf(m_run, mloc);
+    float mc = m_run * c2;
+    if (__any((m_cand - m_run) * c2 > 8.0f)) {
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_cand) * c2);
+      m_run = m_cand;
+      mc = m_cand * c2;
+      l_part *= alpha;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { oacc[0][r] *= alpha; oacc[1][r] *= alpha; }
+    }
     float psum = 0.0f;
     Frag<__bf16> fp[2][2];
 #pragma unroll
@@ -388,11 +391,7 @@ __global__ __launch_bounds__(SD_NT, 3) void sdpa_fwd_glds_kernel(const __bf16* _
         psum += p;
         fp[kb][r >> 3].set(r & 7, p);
       }
-    l_part = l_part * alpha + psum;
-    if (!__all(alpha == 1.0f)) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { oacc[0][r] *= alpha; oacc[1][r] *= alpha; }
-    }
+    l_part += psum;
 
     const unsigned vs_base = lds_addr(Vs);
 #pragma unroll
@@ -422,8 +421,13 @@ __global__ __launch_bounds__(SD_NT, 3) void sdpa_fwd_glds_kernel(const __bf16* _
           oacc[db] = mma32(fv, fp[kb][s2], oacc[db]);
         }
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my LDS reads of this tile are done ...
-    __builtin_amdgcn_s_barrier();                         // ... and so are everybody else's: the buffer may be refilled
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my LDS reads of this tile are done
+    if (kt + 2 < nkt) {
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // my pieces of tile kt+1 have landed (kt+2 may still fly)
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
   }
 
   const float l = l_part + __shfl_xor(l_part, 32);

@@ -131,6 +131,31 @@ def test_sdpa_spike_row_forces_rescale(ops):
     assert mx < 1e-4, mx
 
 
+def test_sdpa_bf16_deferred_max_and_spikes(ops):
+    """bf16 LDS-DMA kernel: the deferred-max branch (threshold 2^8) must be taken for spiked rows and skipped for the
+    rest, with results matching the fp32 oracle on the same bf16-rounded operands (max error <= 2e-2 of the range).
+    Spikes at several tiles, one of them in the ragged last tile."""
+    B, N, h = 1, 1000, 2
+    g = torch.Generator().manual_seed(31)
+    q, k, v = (torch.randn(B, h, N, 64, generator=g) for _ in range(3))
+    for (qi, ki, s) in ((5, 650, 6.0), (77, 130, 9.0), (400, 999, 12.0), (401, 3, 5.0)):
+        k[0, 0, ki] = q[0, 0, qi] * s / 8.0
+        k[0, 1, ki] = q[0, 1, qi] * s / 8.0
+    qb, kb, vb = q.bfloat16(), k.bfloat16(), v.bfloat16()
+    Np_ = ops.npad(N)
+    qp = torch.zeros(B, h, Np_, 64, dtype=torch.bfloat16); kp = torch.zeros_like(qp)
+    vtp = torch.full((B, h, 64, Np_), float("nan"), dtype=torch.bfloat16)        # padded keys hold garbage on purpose
+    qp[:, :, :N], kp[:, :, :N], vtp[:, :, :, :N] = qb, kb, vb.transpose(-1, -2)
+    kp[:, :, N:] = float("nan")
+    o, lse = ops.sdpa_fwd(ops.q_to_fragment_major(dev(qp)), dev(kp), dev(vtp), N)
+    s_ = (qb.float() @ kb.float().transpose(-1, -2)) * 0.125
+    ref = (s_.softmax(-1) @ vb.float()).transpose(1, 2).reshape(B, N, h * 64)
+    mx, mean = rel_to_range(ref, o.float())
+    assert mx < 2e-2 and mean < 3e-3, (mx, mean)
+    assert_close(torch.logsumexp(s_, dim=-1), lse, 1e-4, 1e-3, "lse (bf16 path)")
+    assert torch.isfinite(o.float()).all()
+
+
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, 3e-2)])
 def test_rollout_rows_match_oracle(ops, dtype, tol):
     """A3: row-sliced roll-out from recomputed attention tiles vs attns_project_to_feature rows."""
