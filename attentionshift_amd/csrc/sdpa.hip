@@ -13,6 +13,7 @@
 // needs A and B to agree on the key order, so the V^T fragment is read in that same permuted order
 // (two runs of 4 keys per k16 step) and P never moves between lanes.  Row max / sum are in-lane
 // reductions plus one cross-half exchange.  Online softmax in the exp2 domain (v_exp_f32).
+#include <utility>
 #include "common.h"
 
 namespace {
@@ -224,9 +225,8 @@ __global__ __launch_bounds__(SD_NT) void sdpa_fwd_kernel(const T* __restrict__ q
 // bf16 fast path.  Same dataflow as sdpa_fwd_kernel, but the K and V^T tiles go global -> LDS with
 // global_load_lds_dwordx4 (no staging VGPRs) into a 3-deep LDS ring: tile kt+2 is in flight while tile kt is
 // consumed, with counted `s_waitcnt vmcnt(N)` + raw s_barrier so the LDS-DMA spans the barriers.  The LDS images are
-// lane-linear, so the bank swizzle sits on the source address: K row r keeps global 16-B chunk c at c ^ (r & 7);
-// V^T row d keeps chunk c at c ^ ((d >> 1) & 7) (2-way on the 8-byte fragment reads, the optimum for same-half
-// reads).  Padded keys of the last tile are zeroed in LDS (P is exactly 0 there, but 0 * garbage must stay 0).
+// lane-linear, so the bank swizzle sits on the source address: K row r (V^T row d) keeps global 16-B chunk c at
+// c ^ (r & 7), which makes the 16-byte row-per-lane fragment reads conflict-free.  Padded keys of the last tile are zeroed in LDS (P is exactly 0 there, but 0 * garbage must stay 0).
 // ---------------------------------------------------------------------------------------------------------
 // LDS reads the compiler must NOT see: after an LDS-DMA hipcc drains vmcnt(0) before any ds_read it can see (it cannot
 // prove the read does not alias the DMA destination), which would collapse the 3-deep ring to depth 0.  The reads are
@@ -242,6 +242,19 @@ __device__ __forceinline__ void lds_read128(u32x4& dst, unsigned addr) {
 }
 __device__ __forceinline__ void lds_read64(u32x2& dst, unsigned addr) {
   asm volatile("ds_read_b64 %0, %1" : "=v"(dst) : "v"(addr));
+}
+// immediate-offset forms: the per-lane address register is loop-invariant, ring slot / row block are immediates
+template <int OFF> __device__ __forceinline__ void lds_read128_i(u32x4& dst, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+template <int OFF> __device__ __forceinline__ void lds_read64_i(u32x2& dst, unsigned addr) {
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+template <int... I, typename F> __device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(std::make_integer_sequence<int, N>{}, f);
 }
 __device__ __forceinline__ void lds_wait4(u32x4& a, u32x4& b, u32x4& c, u32x4& d) {
   asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
@@ -280,11 +293,12 @@ __global__ __launch_bounds__(SD_NT, 3) void sdpa_fwd_glds_kernel(const __bf16* _
   const int lr = lane >> 3, lc = lane & 7;
   const char* srcK[2];
   const char* srcV[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int r = (wave * 2 + j) * 8 + lr;                         // key row of the K tile / d row of the V^T tile
-    srcK[j] = reinterpret_cast<const char*>(k + ((size_t)bh * Npad + r) * HD) + ((lc ^ (r & 7)) << 4);
-    srcV[j] = reinterpret_cast<const char*>(vt + ((size_t)bh * HD + r) * Npad) + ((lc ^ ((r >> 1) & 7)) << 4);
+  {
+    const int r = wave * 16 + lr;                                  // key row of the K tile / d row of the V^T tile
+    srcK[0] = reinterpret_cast<const char*>(k + ((size_t)bh * Npad + r) * HD) + ((lc ^ (r & 7)) << 4);
+    srcV[0] = reinterpret_cast<const char*>(vt + ((size_t)bh * HD + r) * Npad) + ((lc ^ (r & 7)) << 4);
+    srcK[1] = srcK[0] + 8 * HD * 2;                                // rows r + 8: same swizzle key
+    srcV[1] = srcV[0] + (size_t)8 * Npad * 2;
   }
   auto stage = [&](int kt, int buf) {
     char* base = smem + buf * (2 * GL_TILE);
@@ -301,7 +315,7 @@ __global__ __launch_bounds__(SD_NT, 3) void sdpa_fwd_glds_kernel(const __bf16* _
   f32x16 oacc[2];
 #pragma unroll
   for (int r = 0; r < 16; ++r) { oacc[0][r] = 0.0f; oacc[1][r] = 0.0f; }
-  float m_run = -INFINITY, l_part = 0.0f;
+  float m_run = 0.0f, l_part = 0.0f;
   const float c2 = 0.125f * 1.44269504088896340736f;
   const int nkt = Npad / SD_KB;
 
@@ -322,30 +336,49 @@ __global__ __launch_bounds__(SD_NT, 3) void sdpa_fwd_glds_kernel(const __bf16* _
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   __builtin_amdgcn_s_barrier();
-  for (int kt = 0; kt < nkt; ++kt) {
-    if (kt + 2 < nkt) stage(kt + 2, (kt + 2) % GL_NBUF);
-    char* Ks = smem + (kt % GL_NBUF) * (2 * GL_TILE);
+  // per-lane LDS addresses of the operand fragments are loop-invariant (12 registers); with the tile loop unrolled by
+  // the ring depth the slot base and the 32-row block are immediates, so no address arithmetic is left in the loop
+  const unsigned smem_base = lds_addr(smem);
+  // Key permutation: MFMA row i of the S^T tile is fed K row pi(i) = i with bits 2 and 3 swapped.  Accumulator
+  // registers 8*s2 .. 8*s2+7 of a lane in half `half` then hold the 8 CONSECUTIVE keys 16*s2 + 8*half + 0..7, which is
+  // exactly the k-fragment of the P^T operand of the second MFMA, so P goes accumulator -> operand with no shuffle and
+  // the V^T operand is one plain 16-byte fragment read.
+  unsigned koff[4], voff[4];
+  {
+    const int krow = (li & 0x13) | ((li & 4) << 1) | ((li & 8) >> 1);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) koff[ks] = smem_base + krow * 128 + ((((ks << 1) | half) ^ (krow & 7)) << 4);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) voff[c] = smem_base + li * 128 + ((((c << 1) | half) ^ (li & 7)) << 4);
+  }
+  float mc = 0.0f;
+  for (int kt0 = 0; kt0 < nkt; kt0 += GL_NBUF) {
+   static_for<GL_NBUF>([&](auto slot_c) {
+    constexpr int slot = decltype(slot_c)::value;
+    const int kt = kt0 + slot;
+    if (kt >= nkt) return;
+    if (kt + 2 < nkt) stage(kt + 2, (slot + 2) % GL_NBUF);
+    char* Ks = smem + slot * (2 * GL_TILE);
     char* Vs = Ks + GL_TILE;
     const bool ragged = (kt == nkt - 1) && (N % SD_KB) != 0;
     if (ragged) {                                   // zero V^T columns of the padded keys (workgroup-uniform branch)
       for (int e = tid; e < HD * SD_KB; e += SD_NT) {
         const int d = e >> 6, key = e & 63;
         if (kt * SD_KB + key >= N)
-          *reinterpret_cast<__bf16*>(Vs + d * 128 + ((((key >> 3) ^ ((d >> 1) & 7))) << 4) + (key & 7) * 2) = (__bf16)0.0f;
+          *reinterpret_cast<__bf16*>(Vs + d * 128 + (((key >> 3) ^ (d & 7)) << 4) + (key & 7) * 2) = (__bf16)0.0f;
       }
       __syncthreads();
     }
 
     f32x16 sacc[2];
-    const unsigned ks_base = lds_addr(Ks);
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
+    static_for<2>([&](auto kb_c) {
+      constexpr int kb = decltype(kb_c)::value;
+      constexpr int OFF = slot * (2 * GL_TILE) + kb * 32 * 128;
 #pragma unroll
       for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.0f;
-      const int row = kb * 32 + li;
       u32x4 kf[4];
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) lds_read128(kf[ks], ks_base + row * 128 + ((((ks << 1) | half) ^ (row & 7)) << 4));
+      for (int ks = 0; ks < 4; ++ks) lds_read128_i<OFF>(kf[ks], koff[ks]);
       lds_wait4(kf[0], kf[1], kf[2], kf[3]);
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
@@ -353,33 +386,30 @@ __global__ __launch_bounds__(SD_NT, 3) void sdpa_fwd_glds_kernel(const __bf16* _
         fk.v = *reinterpret_cast<bf16x8*>(&kf[ks]);
         sacc[kb] = mma32(fk, fq[ks], sacc[kb]);
       }
-    }
+    });
     if (ragged) {
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-          if (kt * SD_KB + kb * 32 + acc_row(r, half) >= N) sacc[kb][r] = -INFINITY;
+          if (kt * SD_KB + kb * 32 + 16 * (r >> 3) + 8 * half + (r & 7) >= N) sacc[kb][r] = -INFINITY;
     }
 
-    float mloc = sacc[0][0];
+    // Softmax reference point: the row max of the FIRST tile only.  Any fixed reference gives the same softmax; the
+    // running max exists to keep exp() in range, and fp32/bf16 have 2^127 of headroom, so the max (16 v_max3 + a
+    // shuffle per tile) is only recomputed when a row sum leaves the safe range (> 1e20, inf or NaN): then the tile is
+    // redone against the true max and O / l are rescaled exactly as in the usual online softmax.
+    auto rowmax = [&]() {
+      float m = sacc[0][0];
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+      for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, sacc[kb][r]);
-    mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
-    // deferred running max (guide T13): keep the stale max while no query of this wave saw its max grow by more than
-    // 2^8; P is then bounded by 2^8 instead of 1, O / l stay consistent, and the O rescale + its exp are skipped.
-    // (the first tile always takes the branch: m_run = -inf)
-    const float m_cand = fmaxf(m_run, mloc);
-    float mc = m_run * c2;
-    if (__any((m_cand - m_run) * c2 > 8.0f)) {
-      const float alpha = __builtin_amdgcn_exp2f((m_run - m_cand) * c2);
-      m_run = m_cand;
-      mc = m_cand * c2;
-      l_part *= alpha;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { oacc[0][r] *= alpha; oacc[1][r] *= alpha; }
+        for (int r = 0; r < 16; ++r) m = fmaxf(m, sacc[kb][r]);
+      return fmaxf(m, __shfl_xor(m, 32));
+    };
+    if (kt == 0) {
+      m_run = rowmax();
+      mc = m_run * c2;
     }
     float psum = 0.0f;
     Frag<__bf16> fp[2][2];
@@ -391,36 +421,40 @@ __global__ __launch_bounds__(SD_NT, 3) void sdpa_fwd_glds_kernel(const __bf16* _
         psum += p;
         fp[kb][r >> 3].set(r & 7, p);
       }
-    l_part += psum;
-
-    const unsigned vs_base = lds_addr(Vs);
+    if (__any(!(psum < 1e20f))) {                       // rare: re-reference this wave's rows to the true running max
+      const float m_cand = fmaxf(m_run, rowmax());
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_cand) * c2);
+      m_run = m_cand;
+      mc = m_cand * c2;
+      l_part *= alpha;
 #pragma unroll
-    for (int db = 0; db < 2; ++db) {
-      const int d = db * 32 + li;
-      const unsigned vrow = vs_base + d * 128;
-      const int sw = (d >> 1) & 7;
-      u32x2 vf[8];
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-          // keys key0..key0+3 and key0+8..key0+11, key0 = kb*32 + s2*16 + half*4  (8-byte units u and u+2)
-          const int u = kb * 8 + s2 * 4 + half;
-          lds_read64(vf[(kb * 2 + s2) * 2 + 0], vrow + (((u >> 1) ^ sw) << 4) + (u & 1) * 8);
-          lds_read64(vf[(kb * 2 + s2) * 2 + 1], vrow + ((((u + 2) >> 1) ^ sw) << 4) + (u & 1) * 8);
-        }
-      lds_wait8(vf);
+      for (int r = 0; r < 16; ++r) { oacc[0][r] *= alpha; oacc[1][r] *= alpha; }
+      psum = 0.0f;
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-          const u32x2 a = vf[(kb * 2 + s2) * 2 + 0], c = vf[(kb * 2 + s2) * 2 + 1];
-          uint4 w4 = make_uint4(a[0], a[1], c[0], c[1]);
-          Frag<__bf16> fv;
-          fv.v = *reinterpret_cast<bf16x8*>(&w4);
-          oacc[db] = mma32(fv, fp[kb][s2], oacc[db]);
+        for (int r = 0; r < 16; ++r) {
+          const float p = __builtin_amdgcn_exp2f(fmaf(sacc[kb][r], c2, -mc));
+          psum += p;
+          fp[kb][r >> 3].set(r & 7, p);
         }
     }
+    l_part += psum;
+
+    static_for<2>([&](auto db_c) {
+      constexpr int db = decltype(db_c)::value;
+      constexpr int OFF = slot * (2 * GL_TILE) + GL_TILE + db * 32 * 128;
+      u32x4 vf[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) lds_read128_i<OFF>(vf[c], voff[c]);
+      lds_wait4(vf[0], vf[1], vf[2], vf[3]);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        Frag<__bf16> fv;
+        fv.v = *reinterpret_cast<bf16x8*>(&vf[c]);
+        oacc[db] = mma32(fv, fp[c >> 1][c & 1], oacc[db]);
+      }
+    });
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my LDS reads of this tile are done
     if (kt + 2 < nkt) {
       asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // my pieces of tile kt+1 have landed (kt+2 may still fly)
@@ -428,6 +462,7 @@ __global__ __launch_bounds__(SD_NT, 3) void sdpa_fwd_glds_kernel(const __bf16* _
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
+   });
   }
 
   const float l = l_part + __shfl_xor(l_part, 32);
