@@ -206,7 +206,7 @@ def main():
             "config": {"workload": "BASELINE configs[1]: MAE-ViT-Base 1024x1024, batch 2/GPU, 3 objects/img, "
                                    "7 roll-out layers, 5 shift iters, forward + no-grad attention shift",
                        "global_batch": world * B, "parallelism": f"dp{world} (image sharding, no data-path collective)"},
-            "roofline": {"kernel": "sdpa_fwd_kernel<bf16>", "bound": "mfma", "achieved": round(ach, 2),
+            "roofline": {"kernel": "sdpa_fwd_glds_kernel (bf16)", "bound": "mfma", "achieved": round(ach, 2),
                          "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
                          "traffic": None, "launches_timed": n_sdpa, "ms_per_launch": round(ms_sdpa, 4),
                          "flops_per_launch": flops_sdpa},
