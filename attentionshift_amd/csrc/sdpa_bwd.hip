@@ -1,0 +1,481 @@
+// Backward of the fused scaled-dot-product attention (head dim 64) for gfx950: dQ, dK, dV from dO, recomputing the
+// softmax tiles from q, k and the saved row log-sum-exp instead of reading a stored [h,N,N] matrix.
+//
+// Replaces the autograd backward of   attn = softmax(q k^T * d^-0.5); x = attn @ v
+// (reference models/vision_transformer.py:79-83; under `use_checkpoint` the reference recomputes the forward of every
+// block in backward, visual_transformer_det.py:232-236 -- the recompute here is per tile and stays on chip).
+//
+//   P  = exp(S * scale - lse)            S = Q K^T
+//   dV = P^T dO
+//   dP = dO V^T          delta_i = sum_d dO[i,d] O[i,d]
+//   dS = P o (dP - delta) * scale
+//   dQ = dS K            dK = dS^T Q
+//
+// Three kernels, no atomics, fixed summation order (bit-reproducible run to run):
+//   bwd_prep      : delta, a fragment-major copy of dO, and the transposed copies (q^T, k^T, dO^T) / row-major v that
+//                   the MFMAs below need as k-contiguous A operands.
+//   bwd_dq        : one workgroup = 128 queries (a lane owns ONE query), loops over 64-key tiles.
+//   bwd_dkv       : one workgroup = 128 keys    (a lane owns ONE key),   loops over 64-query tiles.
+// As in the forward every MFMA is "swapped" so the lane that owns a query (key) keeps its column through the whole
+// chain, and the row operand of the first MFMA is fed in the order pi(i) = i with bits 2,3 swapped, which makes the
+// accumulator registers 8*s .. 8*s+7 of a lane hold 8 CONSECUTIVE rows: P / dS go accumulator -> B operand of the
+// next MFMA without leaving the lane, and that MFMA's A operand is a plain contiguous fragment of the transposed tile.
+// Templated on the element type: bf16 (v_mfma_f32_32x32x16_bf16) and fp32 (exact v_mfma_f32_32x32x2_f32 chains; the
+// parity path).
+#include "common.h"
+
+namespace {
+
+constexpr int BW_NT = 256, BW_HD = 64, BW_TILE = 64;
+typedef __attribute__((ext_vector_type(4))) unsigned bw_u32x4;   // plain vector type: staging arrays stay in VGPRs
+
+__device__ __forceinline__ int pi_row(int i) { return (i & 0x13) | ((i & 4) << 1) | ((i & 8) >> 1); }
+// accumulator register r of a lane in half `half` <-> row inside a 32-row block when the rows were fed through pi
+__device__ __forceinline__ int pi_acc_row(int r, int half) { return 16 * (r >> 3) + 8 * half + (r & 7); }
+
+__device__ __forceinline__ void st4(__bf16* p, float a, float b, float c, float d) {
+  bf16x4 v = {(__bf16)a, (__bf16)b, (__bf16)c, (__bf16)d};
+  *reinterpret_cast<bf16x4*>(p) = v;
+}
+__device__ __forceinline__ void st4(float* p, float a, float b, float c, float d) {
+  *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
+}
+
+// One 64-row x 64-element tile staged global -> registers -> LDS in 16-byte chunks by 256 threads.
+template <typename T> struct TileStage {
+  static constexpr int ROWB = BW_HD * (int)sizeof(T);       // bytes per tile row
+  static constexpr int CPR = ROWB / 16;                     // chunks per row
+  static constexpr int CH = BW_TILE * CPR / BW_NT;          // chunks per thread
+};
+template <typename T>
+__device__ __forceinline__ void tile_load(bw_u32x4 (&r)[TileStage<T>::CH], const char* src, size_t src_row_stride, int tid) {
+  constexpr int CPR = TileStage<T>::CPR;
+#pragma unroll
+  for (int i = 0; i < TileStage<T>::CH; ++i) {
+    const int c = tid + i * BW_NT;
+    r[i] = *reinterpret_cast<const bw_u32x4*>(src + (size_t)(c / CPR) * src_row_stride + (c % CPR) * 16);
+  }
+}
+template <typename T>
+__device__ __forceinline__ void tile_store(const bw_u32x4 (&r)[TileStage<T>::CH], char* dst, int pitch, int tid) {
+  constexpr int CPR = TileStage<T>::CPR;
+#pragma unroll
+  for (int i = 0; i < TileStage<T>::CH; ++i) {
+    const int c = tid + i * BW_NT;
+    *reinterpret_cast<bw_u32x4*>(dst + (c / CPR) * pitch + (c % CPR) * 16) = r[i];
+  }
+}
+
+template <typename T> __device__ __forceinline__ void lds_frag(Frag<T>& f, const char* p) {
+  f.load16B(reinterpret_cast<const T*>(p));
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// prep: one workgroup per (image*head, 64-row tile)
+// ---------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(BW_NT) void bwd_prep_kernel(const T* __restrict__ q, const T* __restrict__ k,
+                                                         const T* __restrict__ vt, const T* __restrict__ o,
+                                                         const T* __restrict__ d_o, T* __restrict__ dof,
+                                                         T* __restrict__ dot, T* __restrict__ qt, T* __restrict__ kt,
+                                                         T* __restrict__ vrow, float* __restrict__ delta, int B, int N,
+                                                         int Npad, int h) {
+  __shared__ float tile[64][65];
+  const int BH = B * h;
+  const int bh = blockIdx.x % BH, t = blockIdx.x / BH;
+  const int b = bh / h, head = bh % h;
+  const int tid = threadIdx.x;
+  const int D = h * BW_HD;
+  const int row0 = t * 64;
+
+  // dO tile: rows -> dof (fragment-major), delta; transposed -> dot
+  for (int e = tid; e < 64 * 64; e += BW_NT) {
+    const int r = e >> 6, d = e & 63, n = row0 + r;
+    float g = 0.0f, ov = 0.0f;
+    if (n < N) {
+      g = to_f32<T>(d_o[((size_t)b * N + n) * D + head * BW_HD + d]);
+      ov = to_f32<T>(o[((size_t)b * N + n) * D + head * BW_HD + d]);
+    }
+    dof[qf_elem((size_t)bh, Npad, n, d)] = from_f32<T>(g);
+    tile[r][d] = g;
+    // row reduction of g * o inside the 64-lane wave that owns row r (e>>6 is wave-uniform: 64 consecutive e)
+    const float s = wave_sum(g * ov);
+    if (d == 0) delta[(size_t)bh * Npad + n] = s;
+  }
+  __syncthreads();
+  for (int e = tid; e < 64 * 64; e += BW_NT) {
+    const int d = e >> 6, r = e & 63;
+    dot[((size_t)bh * BW_HD + d) * Npad + row0 + r] = from_f32<T>(tile[r][d]);
+  }
+  __syncthreads();
+  // q (fragment-major) -> qt
+  for (int e = tid; e < 64 * 64; e += BW_NT) {
+    const int r = e >> 6, d = e & 63, n = row0 + r;
+    tile[r][d] = n < N ? to_f32<T>(q[qf_elem((size_t)bh, Npad, n, d)]) : 0.0f;
+  }
+  __syncthreads();
+  for (int e = tid; e < 64 * 64; e += BW_NT) {
+    const int d = e >> 6, r = e & 63;
+    qt[((size_t)bh * BW_HD + d) * Npad + row0 + r] = from_f32<T>(tile[r][d]);
+  }
+  __syncthreads();
+  // k (row-major) -> kt
+  for (int e = tid; e < 64 * 64; e += BW_NT) {
+    const int r = e >> 6, d = e & 63, n = row0 + r;
+    tile[r][d] = n < N ? to_f32<T>(k[((size_t)bh * Npad + n) * BW_HD + d]) : 0.0f;
+  }
+  __syncthreads();
+  for (int e = tid; e < 64 * 64; e += BW_NT) {
+    const int d = e >> 6, r = e & 63;
+    kt[((size_t)bh * BW_HD + d) * Npad + row0 + r] = from_f32<T>(tile[r][d]);
+  }
+  __syncthreads();
+  // vt (transposed) -> v row-major, zero padded
+  for (int e = tid; e < 64 * 64; e += BW_NT) {
+    const int d = e >> 6, r = e & 63, n = row0 + r;
+    tile[r][d] = n < N ? to_f32<T>(vt[((size_t)bh * BW_HD + d) * Npad + n]) : 0.0f;
+  }
+  __syncthreads();
+  for (int e = tid; e < 64 * 64; e += BW_NT) {
+    const int r = e >> 6, d = e & 63;
+    vrow[((size_t)bh * Npad + row0 + r) * BW_HD + d] = from_f32<T>(tile[r][d]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// dQ: workgroup = 128 queries of one (image, head); key tiles of 64
+//   S^T  = K . Q^T        A = K rows (pi order)     B = Q^T  (registers)
+//   dP^T = V . dO^T       A = V rows (pi order)     B = dO^T (registers)
+//   dQ^T += K^T . dS^T    A = K^T rows d            B = dS^T (from the accumulators)
+// ---------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(BW_NT) void sdpa_bwd_dq_kernel(const T* __restrict__ q, const T* __restrict__ dof,
+                                                            const T* __restrict__ k, const T* __restrict__ vrow,
+                                                            const T* __restrict__ kt, const float* __restrict__ lse,
+                                                            const float* __restrict__ delta, T* __restrict__ dqkv,
+                                                            int B, int N, int Npad, int h) {
+  using TS = TileStage<T>;
+  constexpr int ES = (int)sizeof(T);
+  constexpr int PITCH = TS::ROWB + 16;
+  constexpr int TILE_B = BW_TILE * PITCH;
+  constexpr int BUF_B = 3 * TILE_B;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int BH = B * h;
+  const int bh = blockIdx.x % BH, qtile = blockIdx.x / BH;
+  const int b = bh / h, head = bh % h;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, half = lane >> 5;
+  const int query = qtile * 128 + wave * 32 + li;
+  const int qc = min(query, N - 1);
+
+  Frag<T> fq[4], fdo[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    fq[ks].load16B(q + qf_frag((size_t)bh, Npad, qc, ks, half));
+    fdo[ks].load16B(dof + qf_frag((size_t)bh, Npad, qc, ks, half));
+  }
+  const float lse2 = lse[(size_t)bh * N + qc] * 1.44269504088896340736f;
+  const float dl = delta[(size_t)bh * Npad + qc];
+  const float c2 = 0.125f * 1.44269504088896340736f;
+
+  const char* ksrc = reinterpret_cast<const char*>(k + (size_t)bh * Npad * BW_HD);
+  const char* vsrc = reinterpret_cast<const char*>(vrow + (size_t)bh * Npad * BW_HD);
+  const char* ktsrc = reinterpret_cast<const char*>(kt + (size_t)bh * BW_HD * Npad);
+  bw_u32x4 sk[TS::CH], sv[TS::CH], skt[TS::CH];
+#define GLOAD(t)                                                                         \
+  do {                                                                                   \
+    tile_load<T>(sk, ksrc + (size_t)(t) * BW_TILE * TS::ROWB, TS::ROWB, tid);            \
+    tile_load<T>(sv, vsrc + (size_t)(t) * BW_TILE * TS::ROWB, TS::ROWB, tid);            \
+    tile_load<T>(skt, ktsrc + (size_t)(t) * BW_TILE * ES, (size_t)Npad * ES, tid);       \
+  } while (0)
+#define LSTORE(buf)                                                                      \
+  do {                                                                                   \
+    char* base_ = smem + (buf) * BUF_B;                                                  \
+    tile_store<T>(sk, base_, PITCH, tid);                                                \
+    tile_store<T>(sv, base_ + TILE_B, PITCH, tid);                                       \
+    tile_store<T>(skt, base_ + 2 * TILE_B, PITCH, tid);                                  \
+  } while (0)
+
+  f32x16 dqacc[2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { dqacc[0][r] = 0.0f; dqacc[1][r] = 0.0f; }
+
+  const int nkt = Npad / BW_TILE;
+  const int prow = pi_row(li);
+  GLOAD(0);
+  LSTORE(0);
+  __syncthreads();
+  for (int t = 0; t < nkt; ++t) {
+    if (t + 1 < nkt) GLOAD(t + 1);
+    const char* Ks = smem + (t & 1) * BUF_B;
+    const char* Vs = Ks + TILE_B;
+    const char* Kts = Ks + 2 * TILE_B;
+    Frag<T> fds[2][2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      f32x16 sacc, pacc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { sacc[r] = 0.0f; pacc[r] = 0.0f; }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        Frag<T> fa;
+        lds_frag(fa, Ks + (kb * 32 + prow) * PITCH + (ks * 16 + half * 8) * ES);
+        sacc = mma32(fa, fq[ks], sacc);
+      }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        Frag<T> fa;
+        lds_frag(fa, Vs + (kb * 32 + prow) * PITCH + (ks * 16 + half * 8) * ES);
+        pacc = mma32(fa, fdo[ks], pacc);
+      }
+      const bool ragged = (t + 1) * BW_TILE > N;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = __builtin_amdgcn_exp2f(fmaf(sacc[r], c2, -lse2));
+        float ds = p * (pacc[r] - dl) * 0.125f;
+        if (ragged && t * BW_TILE + kb * 32 + pi_acc_row(r, half) >= N) ds = 0.0f;   // padded key rows hold garbage
+        fds[kb][r >> 3].set(r & 7, ds);
+      }
+    }
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          Frag<T> fa;
+          lds_frag(fa, Kts + (db * 32 + li) * PITCH + (kb * 32 + s2 * 16 + half * 8) * ES);
+          dqacc[db] = mma32(fa, fds[kb][s2], dqacc[db]);
+        }
+    if (t + 1 < nkt) LSTORE((t + 1) & 1);
+    __syncthreads();
+  }
+#undef GLOAD
+#undef LSTORE
+
+  if (query < N) {
+    T* row = dqkv + ((size_t)b * N + query) * (size_t)(3 * h * BW_HD) + head * BW_HD;       // q slot of [3,h,64]
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        st4(row + db * 32 + 8 * g + 4 * half, dqacc[db][4 * g], dqacc[db][4 * g + 1], dqacc[db][4 * g + 2],
+            dqacc[db][4 * g + 3]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// dK, dV: workgroup = 128 keys of one (image, head); query tiles of 64
+//   S    = Q . K^T        A = Q rows (pi order; the fragment-major q tile is already in operand order)
+//   dP   = dO . V^T       A = dO rows (pi order, fragment-major copy)        B = K, V fragments (registers)
+//   dV^T += dO^T . P      A = dO^T rows d      B = P  (from the accumulators)
+//   dK^T += Q^T . dS      A = Q^T rows d       B = dS (from the accumulators)
+// ---------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(BW_NT) void sdpa_bwd_dkv_kernel(const T* __restrict__ q, const T* __restrict__ dof,
+                                                             const T* __restrict__ qt, const T* __restrict__ dot,
+                                                             const T* __restrict__ k, const T* __restrict__ vrow,
+                                                             const float* __restrict__ lse,
+                                                             const float* __restrict__ delta, T* __restrict__ dqkv,
+                                                             int B, int N, int Npad, int h) {
+  using TS = TileStage<T>;
+  constexpr int ES = (int)sizeof(T);
+  constexpr int PITCH = TS::ROWB + 16;
+  constexpr int FRAG_B = BW_TILE * TS::ROWB;          // fragment-major tiles are copied linearly (no padding)
+  constexpr int TR_B = BW_TILE * PITCH;
+  constexpr int BUF_B = 2 * FRAG_B + 2 * TR_B + 2 * BW_TILE * 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int BH = B * h;
+  const int bh = blockIdx.x % BH, ktile = blockIdx.x / BH;
+  const int b = bh / h, head = bh % h;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, half = lane >> 5;
+  const int key = ktile * 128 + wave * 32 + li;
+  const int kc = min(key, Npad - 1);
+
+  Frag<T> fk[4], fv[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    fk[ks].load16B(k + ((size_t)bh * Npad + kc) * BW_HD + ks * 16 + half * 8);
+    fv[ks].load16B(vrow + ((size_t)bh * Npad + kc) * BW_HD + ks * 16 + half * 8);
+  }
+  const float c2 = 0.125f * 1.44269504088896340736f;
+
+  const char* qsrc = reinterpret_cast<const char*>(q + (size_t)bh * Npad * BW_HD);
+  const char* dosrc = reinterpret_cast<const char*>(dof + (size_t)bh * Npad * BW_HD);
+  const char* qtsrc = reinterpret_cast<const char*>(qt + (size_t)bh * BW_HD * Npad);
+  const char* dotsrc = reinterpret_cast<const char*>(dot + (size_t)bh * BW_HD * Npad);
+  bw_u32x4 sq[TS::CH], sdo[TS::CH], sqt[TS::CH], sdot[TS::CH];
+  float stat = 0.0f;                                 // threads 0..63: lse*log2e, 64..127: delta
+#define GLOAD(t)                                                                                                   \
+  do {                                                                                                             \
+    tile_load<T>(sq, qsrc + (size_t)(t) * FRAG_B, TS::ROWB, tid);                                                  \
+    tile_load<T>(sdo, dosrc + (size_t)(t) * FRAG_B, TS::ROWB, tid);                                                \
+    tile_load<T>(sqt, qtsrc + (size_t)(t) * BW_TILE * ES, (size_t)Npad * ES, tid);                                 \
+    tile_load<T>(sdot, dotsrc + (size_t)(t) * BW_TILE * ES, (size_t)Npad * ES, tid);                               \
+    if (tid < 64) {                                                                                                \
+      const int n_ = (t) * BW_TILE + tid; /* padded query: P = exp2(-inf) = 0 */                                   \
+      stat = n_ < N ? lse[(size_t)bh * N + n_] * 1.44269504088896340736f : INFINITY;                               \
+    } else if (tid < 128) {                                                                                        \
+      const int n_ = (t) * BW_TILE + tid - 64;                                                                     \
+      stat = n_ < N ? delta[(size_t)bh * Npad + n_] : 0.0f;                                                        \
+    }                                                                                                              \
+  } while (0)
+#define LSTORE(buf)                                                                                                \
+  do {                                                                                                             \
+    char* base_ = smem + (buf) * BUF_B;                                                                            \
+    tile_store<T>(sq, base_, TS::ROWB, tid);                                                                       \
+    tile_store<T>(sdo, base_ + FRAG_B, TS::ROWB, tid);                                                             \
+    tile_store<T>(sqt, base_ + 2 * FRAG_B, PITCH, tid);                                                            \
+    tile_store<T>(sdot, base_ + 2 * FRAG_B + TR_B, PITCH, tid);                                                    \
+    if (tid < 128) reinterpret_cast<float*>(base_ + 2 * FRAG_B + 2 * TR_B)[tid] = stat;                            \
+  } while (0)
+
+  f32x16 dkacc[2], dvacc[2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { dkacc[0][r] = 0.0f; dkacc[1][r] = 0.0f; dvacc[0][r] = 0.0f; dvacc[1][r] = 0.0f; }
+
+  const int nqt = Npad / BW_TILE;
+  const int prow = pi_row(li);
+  GLOAD(0);
+  LSTORE(0);
+  __syncthreads();
+  for (int t = 0; t < nqt; ++t) {
+    if (t + 1 < nqt) GLOAD(t + 1);
+    const char* Qs = smem + (t & 1) * BUF_B;
+    const char* dOs = Qs + FRAG_B;
+    const char* Qts = Qs + 2 * FRAG_B;
+    const char* dOts = Qts + TR_B;
+    const float* st = reinterpret_cast<const float*>(dOts + TR_B);
+    const bool ragged = (t + 1) * BW_TILE > N;
+
+    Frag<T> fp[2][2], fds[2][2];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      f32x16 sacc, pacc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { sacc[r] = 0.0f; pacc[r] = 0.0f; }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        Frag<T> fa;
+        lds_frag(fa, Qs + (size_t)(((qb * 4 + ks) * 64) + prow + 32 * half) * 8 * ES);
+        sacc = mma32(fa, fk[ks], sacc);
+      }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        Frag<T> fa;
+        lds_frag(fa, dOs + (size_t)(((qb * 4 + ks) * 64) + prow + 32 * half) * 8 * ES);
+        pacc = mma32(fa, fv[ks], pacc);
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const int q0 = qb * 32 + 16 * s2 + 8 * half;            // 8 consecutive queries of this lane's registers
+        const float4 l0 = *reinterpret_cast<const float4*>(st + q0), l1 = *reinterpret_cast<const float4*>(st + q0 + 4);
+        const float4 d0 = *reinterpret_cast<const float4*>(st + 64 + q0),
+                     d1 = *reinterpret_cast<const float4*>(st + 64 + q0 + 4);
+        const float lv[8] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
+        const float dv[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+#pragma unroll
+        for (int t8 = 0; t8 < 8; ++t8) {
+          const int r = s2 * 8 + t8;
+          float p = __builtin_amdgcn_exp2f(fmaf(sacc[r], c2, -lv[t8]));
+          float ds = p * (pacc[r] - dv[t8]) * 0.125f;
+          if (ragged && t * BW_TILE + q0 + t8 >= N) { p = 0.0f; ds = 0.0f; }   // padded query rows hold garbage
+          fp[qb][s2].set(t8, p);
+          fds[qb][s2].set(t8, ds);
+        }
+      }
+    }
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          Frag<T> fa;
+          lds_frag(fa, dOts + (db * 32 + li) * PITCH + (qb * 32 + s2 * 16 + half * 8) * ES);
+          dvacc[db] = mma32(fa, fp[qb][s2], dvacc[db]);
+          lds_frag(fa, Qts + (db * 32 + li) * PITCH + (qb * 32 + s2 * 16 + half * 8) * ES);
+          dkacc[db] = mma32(fa, fds[qb][s2], dkacc[db]);
+        }
+    if (t + 1 < nqt) LSTORE((t + 1) & 1);
+    __syncthreads();
+  }
+#undef GLOAD
+#undef LSTORE
+
+  if (key < N) {
+    const int D = h * BW_HD;
+    T* row = dqkv + ((size_t)b * N + key) * (size_t)(3 * D) + head * BW_HD;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d = db * 32 + 8 * g + 4 * half;
+        st4(row + D + d, dkacc[db][4 * g], dkacc[db][4 * g + 1], dkacc[db][4 * g + 2], dkacc[db][4 * g + 3]);
+        st4(row + 2 * D + d, dvacc[db][4 * g], dvacc[db][4 * g + 1], dvacc[db][4 * g + 2], dvacc[db][4 * g + 3]);
+      }
+  }
+}
+
+template <typename T> size_t bwd_ws_bytes(int B, int N, int h) {
+  const size_t Npad = as_round_up(N, 64);
+  return (size_t)B * h * Npad * (5 * BW_HD * sizeof(T) + sizeof(float));
+}
+
+template <typename T>
+int launch_bwd(const void* q, const void* k, const void* vt, const void* o, const void* d_o, const float* lse,
+               void* dqkv, void* ws, int B, int N, int h, hipStream_t s) {
+  using TS = TileStage<T>;
+  const int Npad = as_round_up(N, 64);
+  const size_t per = (size_t)B * h * Npad * BW_HD;
+  T* dof = (T*)ws;
+  T* dot = dof + per;
+  T* qt = dot + per;
+  T* kt = qt + per;
+  T* vrow = kt + per;
+  float* delta = (float*)(vrow + per);
+  const int BH = B * h;
+  hipLaunchKernelGGL((bwd_prep_kernel<T>), dim3(BH * (Npad / 64)), dim3(BW_NT), 0, s, (const T*)q, (const T*)k,
+                     (const T*)vt, (const T*)o, (const T*)d_o, dof, dot, qt, kt, vrow, delta, B, N, Npad, h);
+  AS_CHECK_LAUNCH("sdpa_bwd_prep");
+  constexpr int PITCH = TS::ROWB + 16;
+  const size_t lds_dq = 2 * (size_t)(3 * BW_TILE * PITCH);
+  const size_t lds_dkv = 2 * (size_t)(2 * BW_TILE * TS::ROWB + 2 * BW_TILE * PITCH + 2 * BW_TILE * 4);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)sdpa_bwd_dq_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dq);
+    (void)hipFuncSetAttribute((const void*)sdpa_bwd_dkv_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dkv);
+    attr_set = true;
+  }
+  const int tiles = as_ceil_div(N, 128);
+  hipLaunchKernelGGL((sdpa_bwd_dkv_kernel<T>), dim3(BH * tiles), dim3(BW_NT), lds_dkv, s, (const T*)q, dof, qt, dot,
+                     (const T*)k, vrow, lse, delta, (T*)dqkv, B, N, Npad, h);
+  AS_CHECK_LAUNCH("sdpa_bwd_dkv");
+  hipLaunchKernelGGL((sdpa_bwd_dq_kernel<T>), dim3(BH * tiles), dim3(BW_NT), lds_dq, s, (const T*)q, dof,
+                     (const T*)k, vrow, kt, lse, delta, (T*)dqkv, B, N, Npad, h);
+  AS_CHECK_LAUNCH("sdpa_bwd_dq");
+  return AS_OK;
+}
+
+}  // namespace
+
+extern "C" size_t as_sdpa_bwd_workspace_bytes(int B, int N, int h, int dtype) {
+  if (B <= 0 || N <= 0 || h <= 0) return 0;
+  return dtype == AS_F32 ? bwd_ws_bytes<float>(B, N, h) : bwd_ws_bytes<__bf16>(B, N, h);
+}
+
+extern "C" int as_sdpa_bwd(const void* q, const void* k, const void* vt, const void* o, const void* d_o,
+                           const float* lse, void* dqkv, void* workspace, size_t workspace_bytes, int B, int N, int h,
+                           int dtype, as_stream_t stream) {
+  AS_REQUIRE(q && k && vt && o && d_o && lse && dqkv && workspace, AS_E_BADARG, "as_sdpa_bwd: null pointer");
+  AS_REQUIRE(B > 0 && N > 0 && h > 0, AS_E_BADARG, "as_sdpa_bwd: bad sizes B=%d N=%d h=%d", B, N, h);
+  AS_REQUIRE(dtype == AS_F32 || dtype == AS_BF16, AS_E_UNSUPPORTED, "as_sdpa_bwd: dtype %d", dtype);
+  AS_REQUIRE(workspace_bytes >= as_sdpa_bwd_workspace_bytes(B, N, h, dtype), AS_E_BADARG,
+             "as_sdpa_bwd: workspace too small (%zu < %zu)", workspace_bytes, as_sdpa_bwd_workspace_bytes(B, N, h, dtype));
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == AS_BF16) return launch_bwd<__bf16>(q, k, vt, o, d_o, lse, dqkv, workspace, B, N, h, s);
+  return launch_bwd<float>(q, k, vt, o, d_o, lse, dqkv, workspace, B, N, h, s);
+}

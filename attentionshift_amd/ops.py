@@ -180,6 +180,20 @@ def sdpa_fwd(q, k, vt, N):
     return o, lse
 
 
+def sdpa_bwd(q, k, vt, o, d_o, lse, N):
+    """Gradient of sdpa_fwd w.r.t. the QKV projection output: returns dqkv [B,N,3*h*64] in the reference's
+    reshape(B,N,3,h,d) order (models/vision_transformer.py:76)."""
+    lib = _lib.load()
+    B, h = q.shape[0], q.shape[1]
+    _chk(q, k, vt, o, d_o, lse)
+    dqkv = torch.empty(B, N, 3 * h * HEAD_DIM, device=q.device, dtype=q.dtype)
+    nbytes = lib.as_sdpa_bwd_workspace_bytes(B, N, h, _dt(q))
+    ws = torch.empty(nbytes, device=q.device, dtype=torch.uint8)
+    _lib.check(lib.as_sdpa_bwd(_p(q), _p(k), _p(vt), _p(o), _p(d_o), _p(lse), _p(dqkv), _p(ws), nbytes, B, N, h,
+                               _dt(q), _stream()), "as_sdpa_bwd")
+    return dqkv
+
+
 def attn_mean_rows(state, row0, nrows):
     """Head-mean softmax rows [B,nrows,N] fp32 recomputed from (q,k,lse)."""
     lib = _lib.load()

@@ -69,6 +69,17 @@ int as_qkv_fwd(const void* x /*[B,N,D]*/, const void* Wqkv /*[3D,D]*/, const flo
 int as_sdpa_fwd(const void* q, const void* k, const void* vt, void* o, float* lse, int B, int N, int h,
                 int dtype, as_stream_t stream);
 
+/* Backward of as_sdpa_fwd (autograd of vision_transformer.py:79-83; the reference trains the backbone, and with
+ * use_checkpoint recomputes each block's forward in backward, visual_transformer_det.py:232-236).  Softmax tiles are
+ * recomputed from q, k and lse; no [h,N,N] buffer, no atomics, fixed summation order.
+ *   q,k,vt,lse : as written by as_qkv_fwd / as_sdpa_fwd           o, d_o : [B,N,h*64] (forward output, its gradient)
+ *   dqkv       : [B,N,3,h,64] = gradient of the QKV projection output in the reference's reshape order (:76)
+ *   workspace  : as_sdpa_bwd_workspace_bytes(B,N,h,dtype) bytes, caller-owned */
+size_t as_sdpa_bwd_workspace_bytes(int B, int N, int h, int dtype);
+int as_sdpa_bwd(const void* q, const void* k, const void* vt, const void* o, const void* d_o, const float* lse,
+                void* dqkv, void* workspace, size_t workspace_bytes, int B, int N, int h, int dtype,
+                as_stream_t stream);
+
 /* Attention.forward = qkv + sdpa + proj (vision_transformer.py:74-86).  q/k/vt/o are workspaces the
  * caller keeps alive when the roll-out (below) needs this layer; `o` is [B,N,D]. */
 int as_attn_fwd(const void* x, const void* Wqkv, const float* bqkv, const void* Wproj, const float* bproj,

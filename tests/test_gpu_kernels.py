@@ -156,6 +156,40 @@ def test_sdpa_bf16_deferred_max_and_spikes(ops):
     assert torch.isfinite(o.float()).all()
 
 
+@pytest.mark.parametrize("B,N,h", [(1, 297, 3), (2, 200, 2), (1, 1000, 2), (1, 64, 1)])
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-4), (torch.bfloat16, 3e-2)])
+def test_sdpa_bwd_matches_autograd(ops, dtype, tol, B, N, h):
+    """Backward of A2 (autograd of vision_transformer.py:79-83): dq, dk, dv from the tile-recomputing HIP kernels vs
+    torch autograd (fp64) of softmax(q k^T / 8) v on the same (dtype-rounded) operands.  Padded rows of the q/k/v^T
+    workspaces hold NaN on purpose: nothing outside [0, N) may leak into a gradient.
+    Tolerance: max error relative to the gradient's range; 1e-4 fp32 (north_star asks 1e-3), 3e-2 bf16."""
+    g = torch.Generator().manual_seed(77 + N)
+    q, k, v = (torch.randn(B, h, N, 64, generator=g) for _ in range(3))
+    q = q * 1.5
+    d_o = torch.randn(B, N, h * 64, generator=g)
+    qd, kd, vd, dod = q.to(dtype), k.to(dtype), v.to(dtype), d_o.to(dtype)
+    # fp64 autograd reference on the rounded operands
+    with torch.enable_grad():
+        q64, k64, v64 = (t.double().requires_grad_(True) for t in (qd, kd, vd))
+        o64 = (torch.softmax(q64 @ k64.transpose(-1, -2) * 0.125, -1) @ v64).transpose(1, 2).reshape(B, N, h * 64)
+        o64.backward(dod.double())
+    ref = torch.stack([q64.grad, k64.grad, v64.grad], 0).permute(1, 3, 0, 2, 4).reshape(B, N, 3 * h * 64).float()
+    Np_ = ops.npad(N)
+    nan = float("nan")
+    qp = torch.full((B, h, Np_, 64), nan, dtype=dtype); kp = torch.full_like(qp, nan)
+    vtp = torch.full((B, h, 64, Np_), nan, dtype=dtype)
+    qp[:, :, :N], kp[:, :, :N], vtp[:, :, :, :N] = qd, kd, vd.transpose(-1, -2)
+    qf, kdev, vtdev = ops.q_to_fragment_major(dev(qp)), dev(kp), dev(vtp)
+    o, lse = ops.sdpa_fwd(qf, kdev, vtdev, N)
+    dqkv = ops.sdpa_bwd(qf, kdev, vtdev, o, dev(dod), lse, N)
+    assert torch.isfinite(dqkv.float()).all()
+    got = dqkv.float().cpu().reshape(B, N, 3, h * 64)
+    refr = ref.reshape(B, N, 3, h * 64)
+    for i, name in enumerate(("dq", "dk", "dv")):
+        mx, mean = rel_to_range(refr[:, :, i], got[:, :, i])
+        assert mx < tol, (name, mx, mean)
+
+
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, 3e-2)])
 def test_rollout_rows_match_oracle(ops, dtype, tol):
     """A3: row-sliced roll-out from recomputed attention tiles vs attns_project_to_feature rows."""

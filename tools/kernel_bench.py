@@ -35,8 +35,9 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--B", type=int, default=2)
     ap.add_argument("--only", default="")
+    ap.add_argument("--N", type=int, default=4197)
     a = ap.parse_args()
-    B, N, D, h, T = a.B, 4197, 768, 12, 100
+    B, N, D, h, T = a.B, a.N, 768, 12, 100
     dev = "cuda"
     g = torch.Generator().manual_seed(0)
     out = []
