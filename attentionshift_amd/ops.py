@@ -107,13 +107,14 @@ def linear(x, weight, bias=None, act="none"):
 class AttnLayerState:
     """What a layer must keep so its attention rows can be recomputed (q, k, lse)."""
 
-    __slots__ = ("q", "k", "vt", "lse", "B", "N", "h", "dtype")
+    __slots__ = ("q", "k", "vt", "lse", "B", "N", "h", "dtype", "o")
 
-    def __init__(self, q, k, vt, lse, B, N, h, dtype):
+    def __init__(self, q, k, vt, lse, B, N, h, dtype, o=None):
         self.q, self.k, self.vt, self.lse, self.B, self.N, self.h, self.dtype = q, k, vt, lse, B, N, h, dtype
+        self.o = o                                  # pre-projection attention output, kept only for the backward
 
 
-def attention_fwd(x, w_qkv, b_qkv, w_proj, b_proj, num_heads, keep_state=True):
+def attention_fwd(x, w_qkv, b_qkv, w_proj, b_proj, num_heads, keep_state=True, keep_o=False):
     """Attention.forward (reference models/vision_transformer.py:74-86) -> (out [B,N,D], AttnLayerState)."""
     lib = _lib.load()
     B, N, D = x.shape
@@ -141,7 +142,28 @@ def attention_fwd(x, w_qkv, b_qkv, w_proj, b_proj, num_heads, keep_state=True):
         with _timed("proj_gemm"):
             _lib.check(lib.as_linear_fwd(_p(o), _p(w_proj), _p(b_proj), _p(out), B * N, D, D, _dt(x), 0, _stream()),
                        "as_linear_fwd")
-    return out, (AttnLayerState(q, k, vt, lse, B, N, num_heads, dt) if keep_state else None)
+    return out, (AttnLayerState(q, k, vt, lse, B, N, num_heads, dt, o if keep_o else None) if keep_state else None)
+
+
+def attention_bwd(x, w_qkv, w_proj, dout, state, want_bias=(True, True)):
+    """Backward of attention_fwd: (dx, dWqkv, dbqkv, dWproj, dbproj); bias gradients fp32 (None if not wanted)."""
+    lib = _lib.load()
+    B, N, D = x.shape
+    if state.o is None:
+        raise AttnShiftError("attention_bwd needs the forward's pre-projection output: call attention_fwd(keep_o=True)")
+    _chk(x, w_qkv, w_proj, dout, state.q, state.k, state.vt, state.o, state.lse)
+    dev, dt = x.device, x.dtype
+    dx = torch.empty_like(x)
+    dwqkv = torch.empty_like(w_qkv)
+    dwproj = torch.empty_like(w_proj)
+    dbqkv = torch.empty(3 * D, device=dev, dtype=torch.float32) if want_bias[0] else None
+    dbproj = torch.empty(D, device=dev, dtype=torch.float32) if want_bias[1] else None
+    nbytes = lib.as_attn_bwd_workspace_bytes(B, N, D, state.h, _dt(x))
+    ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+    _lib.check(lib.as_attn_bwd(_p(x), _p(w_qkv), _p(w_proj), _p(dout), _p(state.q), _p(state.k), _p(state.vt),
+                               _p(state.o), _p(state.lse), _p(dx), _p(dwqkv), _p(dbqkv), _p(dwproj), _p(dbproj), _p(ws),
+                               nbytes, B, N, D, state.h, _dt(x), _stream()), "as_attn_bwd")
+    return dx, dwqkv, dbqkv, dwproj, dbproj
 
 
 def q_to_fragment_major(q_rows):

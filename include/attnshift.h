@@ -86,6 +86,16 @@ int as_attn_fwd(const void* x, const void* Wqkv, const float* bqkv, const void* 
                 void* out /*[B,N,D]*/, float* lse, void* q, void* k, void* vt, void* o, int B, int N, int D,
                 int h, int dtype, as_stream_t stream);
 
+/* Backward of as_attn_fwd (autograd of Attention.forward, vision_transformer.py:74-86): given dout = dL/d out and the
+ * tensors as_attn_fwd saved (q,k,vt,o,lse) returns dL/dx and the parameter gradients.
+ *   x, dout, dx : [B,N,D]     dWqkv : [3D,D]   dWproj : [D,D] (element dtype = `dtype`)   dbqkv [3D], dbproj [D] fp32 or NULL
+ *   workspace   : as_attn_bwd_workspace_bytes(B,N,D,h,dtype) bytes, caller-owned */
+size_t as_attn_bwd_workspace_bytes(int B, int N, int D, int h, int dtype);
+int as_attn_bwd(const void* x, const void* Wqkv, const void* Wproj, const void* dout, const void* q, const void* k,
+                const void* vt, const void* o, const float* lse, void* dx, void* dWqkv, float* dbqkv, void* dWproj,
+                float* dbproj, void* workspace, size_t workspace_bytes, int B, int N, int D, int h, int dtype,
+                as_stream_t stream);
+
 /* Head-mean attention rows, recomputed from q,k,lse (visual_transformer_det.py:236,242 keeps
  * attn.mean(1) of every layer; only row slices are ever consumed, stdroi:2272):
  *   out[b,i,:] = (1/h) sum_h softmax_row(row0 + i)          out : [B,nrows,N] fp32 */

@@ -190,6 +190,31 @@ def test_sdpa_bwd_matches_autograd(ops, dtype, tol, B, N, h):
         assert mx < tol, (name, mx, mean)
 
 
+@pytest.mark.parametrize("B,N,h", [(2, 297, 3), (1, 130, 2)])
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-4), (torch.bfloat16, 4e-2)])
+def test_attention_module_bwd_matches_autograd(ops, dtype, tol, B, N, h):
+    """as_attn_bwd through the torch.autograd bridge (attentionshift_amd.autograd.AttentionFn) vs autograd of the
+    oracle's Attention.forward (fp64) on the same rounded operands: dx, dWqkv, dbqkv, dWproj, dbproj."""
+    from attentionshift_amd import autograd as AG
+    x, wqkv, bqkv, wproj, bproj = _attn_inputs(B, N, h, 91, scale=2.0)
+    g = torch.Generator().manual_seed(5)
+    dout = torch.randn(B, N, 64 * h, generator=g)
+    xd, wq, wp, dod = x.to(dtype), wqkv.to(dtype), wproj.to(dtype), dout.to(dtype)
+    with torch.enable_grad():
+        ref_in = [t.double().requires_grad_(True) for t in (xd, wq, bqkv, wp, bproj)]
+        out_ref, _ = O.attention(ref_in[0], ref_in[1], ref_in[2], ref_in[3], ref_in[4], h)
+        out_ref.backward(dod.double())
+        got_in = [dev(t).requires_grad_(True) for t in (xd, wq, bqkv, wp, bproj)]
+        out = AG.attention(got_in[0], got_in[1], got_in[2], got_in[3], got_in[4], h)
+        out.backward(dev(dod))
+    mx, _ = rel_to_range(out_ref.detach().float(), out.detach().float())
+    assert mx < tol, ("out", mx)
+    for name, r, gt in zip(("dx", "dWqkv", "dbqkv", "dWproj", "dbproj"), ref_in, got_in):
+        assert gt.grad is not None, name
+        mx, mean = rel_to_range(r.grad.float(), gt.grad.float())
+        assert mx < tol, (name, mx, mean)
+
+
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, 3e-2)])
 def test_rollout_rows_match_oracle(ops, dtype, tol):
     """A3: row-sliced roll-out from recomputed attention tiles vs attns_project_to_feature rows."""
