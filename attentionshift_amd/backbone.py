@@ -277,17 +277,65 @@ class VisionTransformerDet(nn.Module):
         z = ops.linear(z, self._w(blk.mlp.fc2.weight), blk.mlp.fc2.bias.float())
         return x + z.float(), st
 
+    # ---- trainable path (autograd): HIP attention forward + backward, library GEMMs for the MLP -------------------
+    def _grad_path(self):
+        return torch.is_grad_enabled() and self.training and any(p.requires_grad for p in self.blocks.parameters())
+
+    def _drop_path(self, x, i):
+        """Stochastic depth per sample, rate rising linearly with depth (models/vision_transformer.py:24-36, :165)."""
+        rate = self.drop_path_rate * i / max(self.depth - 1, 1)
+        if rate == 0.0 or not self.training:
+            return x
+        keep = 1.0 - rate
+        mask = torch.rand(x.shape[0], 1, 1, device=x.device, dtype=x.dtype).add_(keep).floor_()
+        return x / keep * mask
+
+    def _prepare_tokens_train(self, img):
+        B, C, w, h = img.shape
+        ps = self.patch_size
+        hp, wp = w // ps, h // ps
+        cd = self.compute_dtype
+        patches = img.reshape(B, C, hp, ps, wp, ps).permute(0, 2, 4, 1, 3, 5).reshape(B, hp * wp, C * ps * ps)
+        x = F.linear(patches.to(cd), self.patch_embed.proj.weight.reshape(self.embed_dim, -1).to(cd),
+                     self.patch_embed.proj.bias.to(cd)).float()
+        x = torch.cat((self.cls_token.expand(B, -1, -1), x), dim=1)
+        x = x + self.interpolate_pos_encoding(x.shape[1] - 1, w, h)
+        pt = (self.point_token + self.point_pos_embed).expand(B, -1, -1)
+        return torch.cat((x, pt), dim=1)
+
+    def _block_train(self, blk, x, i, sink):
+        """Block.forward under autograd.  Attention = autograd.AttentionFn (as_attn_fwd / as_attn_bwd); LayerNorm,
+        MLP GEMMs + GELU and the residual adds are torch ops (library GEMMs acceptable)."""
+        from . import autograd as AG
+        cd = self.compute_dtype
+        D = x.shape[-1]
+        y = F.layer_norm(x, (D,), blk.norm1.weight, blk.norm1.bias, blk.norm1.eps).to(cd)
+        a = AG.attention(y, blk.attn.qkv.weight.to(cd), None if blk.attn.qkv.bias is None else blk.attn.qkv.bias.float(),
+                         blk.attn.proj.weight.to(cd), blk.attn.proj.bias.float(), self.num_heads, sink)
+        x = x + self._drop_path(a.float(), i)
+        z = F.layer_norm(x, (D,), blk.norm2.weight, blk.norm2.bias, blk.norm2.eps).to(cd)
+        z = F.gelu(F.linear(z, blk.mlp.fc1.weight.to(cd), blk.mlp.fc1.bias.to(cd)))
+        z = F.linear(z, blk.mlp.fc2.weight.to(cd), blk.mlp.fc2.bias.to(cd))
+        return x + self._drop_path(z.float(), i)
+
     def forward(self, x):
-        """visual_transformer_det.py:221-275 (inference / no-grad semantics: drop-path inactive)."""
+        """visual_transformer_det.py:221-275.  Under no-grad / eval every GEMM and the attention run on the HIP
+        inference kernels; with grad enabled in train() mode the blocks run the autograd path above."""
         B, _, H, W = x.shape
         hp, wp = H // self.patch_size, W // self.patch_size
         T = self.point_tokens_num
-        x = self.prepare_tokens(x)
+        grad_path = self._grad_path()
+        x = self._prepare_tokens_train(x) if grad_path else self.prepare_tokens(x)
         if self.recompute_last_feat:
             last_feat = x
         features, taps, attns = [], [], []
         for i, blk in enumerate(self.blocks):
-            x, st = self._block(blk, x, self.return_attention)
+            if grad_path:
+                sink = [] if self.return_attention else None
+                x = self._block_train(blk, x, i, sink)
+                st = sink[0] if sink else None
+            else:
+                x, st = self._block(blk, x, self.return_attention)
             if self.return_attention:
                 attns.append(st)
             if i in self.out_indices:
@@ -296,7 +344,10 @@ class VisionTransformerDet(nn.Module):
             if self.last_feat and not self.recompute_last_feat and i == len(self.blocks) - 1:
                 last_feat = x[:, :-T]
         org_features = torch.stack(features, dim=1)
-        if self.with_fpn:
+        if self.with_fpn and grad_path:
+            fpn = [self.fpn1, self.fpn2, self.fpn3, self.fpn4]
+            features = [fpn[i](features[i]) for i in range(len(features))]
+        elif self.with_fpn:
             # the taps are token-major already: run the 2x2/2 deconvolutions as GEMMs over tokens (channels-last)
             features = [self._fpn(i, features[i], taps[i]) for i in range(len(features))]
         point_tokens = x[:, -T:]

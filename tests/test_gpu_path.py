@@ -103,3 +103,41 @@ def test_seed_pseudo_gt_chain_matches_reference(golden, tag, monkeypatch):
     diff = int((ref_masks != out["pseudo_gt_masks"][0]).sum())
     assert diff <= ref_masks.size * 1e-5, f"pseudo masks differ in {diff} pixels"      # threshold-edge pixels only
     assert_close(t(g["fg_feat"]), out["inst_fg_feat"][0].flatten(1), 1e-3, 1e-4, "inst_fg_feat")
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-3), (torch.bfloat16, 8e-2)])
+def test_backbone_train_step_grads_match_oracle_autograd(golden, dtype, tol):
+    """Trainable path (train() + grad enabled): forward through autograd.AttentionFn (as_attn_fwd / as_attn_bwd) and
+    backward to the parameters, vs torch autograd (fp64) through the oracle's restatement of the same forward.
+    Loss = fixed random projection of last_feat, point_tokens, outputs_coord and the un-FPN'd taps."""
+    g = golden("backbone_small")
+    bb, img, cfg = build_backbone(g, dtype)
+    bb.train()
+    sd = {k: v.double() for k, v in backbone_state_dict(g).items()}
+    names = ["blocks.0.attn.qkv.weight", "blocks.0.attn.qkv.bias", "blocks.0.attn.proj.weight", "blocks.0.norm1.weight",
+             "blocks.1.mlp.fc1.weight", f"blocks.{cfg['depth'] - 1}.attn.proj.bias", "pos_embed", "point_token",
+             "patch_embed.proj.weight", "bbox_embed.layers.0.weight"]
+    gen = torch.Generator().manual_seed(3)
+
+    def loss_of(out, like):
+        tot = 0.0
+        gen.manual_seed(3)
+        for k in ("last_feat", "point_tokens", "outputs_coord", "org_feats"):
+            w = torch.randn(out[k].shape, generator=gen).to(like)
+            tot = tot + (out[k].to(like.dtype) * w).sum()
+        return tot
+
+    with torch.enable_grad():
+        for n in names:
+            sd[n].requires_grad_(True)
+        ref = O.backbone_forward(img.double().cpu(), sd, patch_size=16, depth=cfg["depth"], num_heads=cfg["num_heads"],
+                                 out_indices=cfg["out_indices"], point_tokens_num=cfg["point_tokens_num"])
+        loss_of(ref, torch.zeros((), dtype=torch.float64)).backward()
+        out = bb(img)
+        assert out["attns"][0].o is not None                      # the autograd path ran (state keeps o for backward)
+        loss_of(out, torch.zeros((), dtype=torch.float32, device="cuda")).backward()
+    params = dict(bb.named_parameters())
+    for n in names:
+        assert params[n].grad is not None, n
+        r = rel(sd[n].grad.float(), params[n].grad.float())
+        assert r < tol, (n, r)
