@@ -30,17 +30,30 @@ __global__ __launch_bounds__(256) void transpose_pad_kernel(const T* __restrict_
   }
 }
 
-// fp32 column sums of in [R, C]; fixed order: one workgroup per 64 columns, 4 row-strided partials combined in order
+// fp32 column sums of in [R, C] in two fixed-order stages: CS_SLICES row slices -> partials [CS_SLICES, C] (in the
+// workspace), then one pass over the partials.  No atomics: bit-reproducible.
+constexpr int CS_SLICES = 64;
 template <typename T>
-__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ in, float* __restrict__ out, int R, int C) {
-  __shared__ float part[4][64];
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ in, float* __restrict__ part, int R,
+                                                             int C) {
+  __shared__ float sm[4][64];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), ty = threadIdx.x >> 6;
+  const int rows = as_ceil_div_dev(R, CS_SLICES);
+  const int r0 = blockIdx.y * rows, r1 = min(R, r0 + rows);
   float s = 0.0f;
   if (c < C)
-    for (int r = ty; r < R; r += 4) s += to_f32<T>(in[(size_t)r * C + c]);
-  part[ty][threadIdx.x & 63] = s;
+    for (int r = r0 + ty; r < r1; r += 4) s += to_f32<T>(in[(size_t)r * C + c]);
+  sm[ty][threadIdx.x & 63] = s;
   __syncthreads();
-  if (ty == 0 && c < C) out[c] = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+  if (ty == 0 && c < C)
+    part[(size_t)blockIdx.y * C + c] = (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]);
+}
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, float* __restrict__ out, int C) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.0f;
+  for (int i = 0; i < CS_SLICES; ++i) s += part[(size_t)i * C + c];
+  out[c] = s;
 }
 
 template <typename T> int transpose_pad(const void* in, void* out, int R, int C, int Rpad, hipStream_t s) {
@@ -49,15 +62,18 @@ template <typename T> int transpose_pad(const void* in, void* out, int R, int C,
   AS_CHECK_LAUNCH("transpose_pad");
   return AS_OK;
 }
-template <typename T> int colsum(const void* in, float* out, int R, int C, hipStream_t s) {
-  hipLaunchKernelGGL((colsum_kernel<T>), dim3(as_ceil_div(C, 64)), dim3(256), 0, s, (const T*)in, out, R, C);
-  AS_CHECK_LAUNCH("colsum");
+template <typename T> int colsum(const void* in, float* out, float* part, int R, int C, hipStream_t s) {
+  hipLaunchKernelGGL((colsum_partial_kernel<T>), dim3(as_ceil_div(C, 64), CS_SLICES), dim3(256), 0, s, (const T*)in, part,
+                     R, C);
+  AS_CHECK_LAUNCH("colsum_partial");
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(as_ceil_div(C, 256)), dim3(256), 0, s, (const float*)part, out, C);
+  AS_CHECK_LAUNCH("colsum_final");
   return AS_OK;
 }
 
 struct BwdLayout {
   size_t es, M, Mpad, D;
-  size_t off_sdpa, off_do, off_dqkv, off_doutT, off_oT, off_dqkvT, off_xT, off_WprojT, off_WqkvT, total;
+  size_t off_sdpa, off_do, off_dqkv, off_doutT, off_oT, off_dqkvT, off_xT, off_WprojT, off_WqkvT, off_part, total;
 };
 BwdLayout bwd_layout(int B, int N, int D, int h, int dtype) {
   BwdLayout L{};
@@ -76,6 +92,7 @@ BwdLayout bwd_layout(int B, int N, int D, int h, int dtype) {
   L.off_xT = take((size_t)D * L.Mpad * L.es);
   L.off_WprojT = take((size_t)D * D * L.es);
   L.off_WqkvT = take((size_t)3 * D * D * L.es);
+  L.off_part = take((size_t)CS_SLICES * 3 * D * sizeof(float));
   L.total = off;
   return L;
 }
@@ -99,7 +116,7 @@ int attn_bwd(const void* x, const void* Wqkv, const void* Wproj, const void* dou
   STEP(transpose_pad<T>(dout, ws + L.off_doutT, M, D, Mpad, s));
   STEP(transpose_pad<T>(o, ws + L.off_oT, M, D, Mpad, s));
   STEP(as_linear_fwd(ws + L.off_doutT, ws + L.off_oT, nullptr, dWproj, D, D, Mpad, dtype, 0, s));   // dout^T . o
-  if (dbproj) STEP(colsum<T>(dout, dbproj, M, D, s));
+  if (dbproj) STEP(colsum<T>(dout, dbproj, (float*)(ws + L.off_part), M, D, s));
   // attention core
   STEP(as_sdpa_bwd(q, k, vt, o, d_o, lse, dqkv, ws + L.off_sdpa, as_sdpa_bwd_workspace_bytes(B, N, h, dtype), B, N, h,
                    dtype, s));
@@ -109,7 +126,7 @@ int attn_bwd(const void* x, const void* Wqkv, const void* Wproj, const void* dou
   STEP(transpose_pad<T>(dqkv, ws + L.off_dqkvT, M, 3 * D, Mpad, s));
   STEP(transpose_pad<T>(x, ws + L.off_xT, M, D, Mpad, s));
   STEP(as_linear_fwd(ws + L.off_dqkvT, ws + L.off_xT, nullptr, dWqkv, 3 * D, D, Mpad, dtype, 0, s)); // dqkv^T . x
-  if (dbqkv) STEP(colsum<T>(dqkv, dbqkv, M, 3 * D, s));
+  if (dbqkv) STEP(colsum<T>(dqkv, dbqkv, (float*)(ws + L.off_part), M, 3 * D, s));
 #undef STEP
   return AS_OK;
 }

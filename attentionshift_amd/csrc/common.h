@@ -31,6 +31,9 @@ void as_set_error(const char* fmt, ...);
 
 static inline int as_ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline int as_round_up(int a, int b) { return as_ceil_div(a, b) * b; }
+#ifdef __HIPCC__
+__device__ __forceinline__ int as_ceil_div_dev(int a, int b) { return (a + b - 1) / b; }
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // MFMA fragments.  One "k16 step" of a 32x32 tile: lane l = (i = l & 31, half = l >> 5) holds the 8

@@ -160,9 +160,10 @@ def attention_bwd(x, w_qkv, w_proj, dout, state, want_bias=(True, True)):
     dbproj = torch.empty(D, device=dev, dtype=torch.float32) if want_bias[1] else None
     nbytes = lib.as_attn_bwd_workspace_bytes(B, N, D, state.h, _dt(x))
     ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
-    _lib.check(lib.as_attn_bwd(_p(x), _p(w_qkv), _p(w_proj), _p(dout), _p(state.q), _p(state.k), _p(state.vt),
-                               _p(state.o), _p(state.lse), _p(dx), _p(dwqkv), _p(dbqkv), _p(dwproj), _p(dbproj), _p(ws),
-                               nbytes, B, N, D, state.h, _dt(x), _stream()), "as_attn_bwd")
+    with _timed("attn_bwd"):
+        _lib.check(lib.as_attn_bwd(_p(x), _p(w_qkv), _p(w_proj), _p(dout), _p(state.q), _p(state.k), _p(state.vt),
+                                   _p(state.o), _p(state.lse), _p(dx), _p(dwqkv), _p(dbqkv), _p(dwproj), _p(dbproj),
+                                   _p(ws), nbytes, B, N, D, state.h, _dt(x), _stream()), "as_attn_bwd")
     return dx, dwqkv, dbqkv, dwproj, dbproj
 
 
