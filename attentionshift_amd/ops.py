@@ -217,6 +217,22 @@ def sdpa_bwd(q, k, vt, o, d_o, lse, N):
     return dqkv
 
 
+def window_attention_fwd(qkv, b_qkv, table, num_heads, ws, shift, return_attn=False):
+    """Fused Swin (shifted-)window attention on the un-partitioned grid: qkv [B,H,W,3C] (no bias) -> out [B,H,W,C]
+    (+ softmax [B*nW,h,ws^2,ws^2] fp32 if asked).  See include/attnshift.h / csrc/window_attn.hip."""
+    lib = _lib.load()
+    B, H, W, C3 = qkv.shape
+    C = C3 // 3
+    _chk(qkv)
+    _chk(b_qkv, table, dtype=torch.float32)
+    out = torch.empty(B, H, W, C, device=qkv.device, dtype=qkv.dtype)
+    nW = -(-H // ws) * -(-W // ws)
+    attn = torch.empty(B * nW, num_heads, ws * ws, ws * ws, device=qkv.device, dtype=torch.float32) if return_attn else None
+    _lib.check(lib.as_window_attn_fwd(_p(qkv), _p(b_qkv), _p(table), _p(out), _p(attn), B, H, W, C, num_heads, int(ws),
+                                      int(shift), _dt(qkv), _stream()), "as_window_attn_fwd")
+    return out, attn
+
+
 def attn_mean_rows(state, row0, nrows):
     """Head-mean softmax rows [B,nrows,N] fp32 recomputed from (q,k,lse)."""
     lib = _lib.load()

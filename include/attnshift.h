@@ -96,6 +96,18 @@ int as_attn_bwd(const void* x, const void* Wqkv, const void* Wproj, const void* 
                 float* dbproj, void* workspace, size_t workspace_bytes, int B, int N, int D, int h, int dtype,
                 as_stream_t stream);
 
+/* Swin window attention for one SwinTransformerBlock (models/swin_transformer.py): fuses the pad (:271-276), cyclic
+ * shift (:279-280), window_partition (:292-293), the WindowAttention core (:131-153 incl. the relative-position-bias
+ * gather :141-144 and the shift mask :233-256), window_reverse (:299-300), reverse shift (:303-304) and un-pad (:308).
+ *   qkv      : [B,H,W,3C] = x_normed . Wqkv^T WITHOUT bias, on the original token grid, channel order (3,h,32)
+ *   bqkv     : fp32 [3C] or NULL (added here; padded tokens are exactly the bias, as in the reference)
+ *   table    : fp32 [(2*ws-1)^2, h] relative_position_bias_table
+ *   out      : [B,H,W,C] attention output at the original token positions (input of the proj Linear)
+ *   attn_out : fp32 [B*nW, h, ws*ws, ws*ws] softmax (the reference returns it) or NULL
+ * ws must be 7 and C == 32*h (all Swin variants of the reference, swin_transformer.py:844-870). */
+int as_window_attn_fwd(const void* qkv, const float* bqkv, const float* table, void* out, float* attn_out, int B, int H,
+                       int W, int C, int h, int ws, int shift, int dtype, as_stream_t stream);
+
 /* Head-mean attention rows, recomputed from q,k,lse (visual_transformer_det.py:236,242 keeps
  * attn.mean(1) of every layer; only row slices are ever consumed, stdroi:2272):
  *   out[b,i,:] = (1/h) sum_h softmax_row(row0 + i)          out : [B,nrows,N] fp32 */

@@ -598,3 +598,87 @@ def pseudo_masks(map_fg_last, pos_thr):
     """stdroi:2356-2358: (map > rowmax * thr) as uint8 numpy."""
     peak = map_fg_last.flatten(1).max(1)[0][:, None, None]
     return (map_fg_last > peak * pos_thr).to(torch.uint8).numpy()
+
+
+# ---------------------------------------------------------------------------------------------------------
+# A6 (BASELINE config 5): Swin window attention.  Restates models/swin_transformer.py
+# ---------------------------------------------------------------------------------------------------------
+def swin_window_partition(x, ws):
+    """models/swin_transformer.py:45-57: [B,H,W,C] -> [nW*B, ws, ws, C]."""
+    B, H, W, C = x.shape
+    return x.view(B, H // ws, ws, W // ws, ws, C).permute(0, 1, 3, 2, 4, 5).contiguous().view(-1, ws, ws, C)
+
+
+def swin_window_reverse(windows, ws, H, W):
+    """models/swin_transformer.py:60-74."""
+    B = int(windows.shape[0] / (H * W / ws / ws))
+    return windows.view(B, H // ws, W // ws, ws, ws, -1).permute(0, 1, 3, 2, 4, 5).contiguous().view(B, H, W, -1)
+
+
+def swin_relative_position_index(ws):
+    """models/swin_transformer.py:120-130."""
+    coords = torch.stack(torch.meshgrid([torch.arange(ws), torch.arange(ws)], indexing="ij")).flatten(1)
+    rel = (coords[:, :, None] - coords[:, None, :]).permute(1, 2, 0).contiguous()
+    rel[:, :, 0] += ws - 1
+    rel[:, :, 1] += ws - 1
+    rel[:, :, 0] *= 2 * ws - 1
+    return rel.sum(-1)
+
+
+def swin_attn_mask(H, W, ws, shift):
+    """SwinTransformerBlock.create_attn_mask, models/swin_transformer.py:233-256: [nW, ws*ws, ws*ws] of 0 / -100."""
+    Hp, Wp = -(-H // ws) * ws, -(-W // ws) * ws
+    img = torch.zeros(1, Hp, Wp, 1)
+    cnt = 0
+    for hs in (slice(0, -ws), slice(-ws, -shift), slice(-shift, None)):
+        for wsl in (slice(0, -ws), slice(-ws, -shift), slice(-shift, None)):
+            img[:, hs, wsl, :] = cnt
+            cnt += 1
+    mw = swin_window_partition(img, ws).view(-1, ws * ws)
+    m = mw.unsqueeze(1) - mw.unsqueeze(2)
+    return m.masked_fill(m != 0, -100.0).masked_fill(m == 0, 0.0)
+
+
+def swin_window_attention(xw, p, num_heads, ws, mask=None):
+    """WindowAttention.forward, models/swin_transformer.py:125-157 -> (out [B_,N,C], attn [B_,h,N,N]).
+    p: dict with qkv.weight/bias, proj.weight/bias, relative_position_bias_table."""
+    B_, N, C = xw.shape
+    d = C // num_heads
+    qkv = F.linear(xw, p["qkv.weight"], p.get("qkv.bias")).reshape(B_, N, 3, num_heads, d).permute(2, 0, 3, 1, 4)
+    q, k, v = qkv[0] * d ** -0.5, qkv[1], qkv[2]
+    attn = q @ k.transpose(-2, -1)
+    bias = p["relative_position_bias_table"][swin_relative_position_index(ws).view(-1)].view(N, N, -1).permute(2, 0, 1)
+    attn = attn + bias.unsqueeze(0)
+    if mask is not None:
+        nW = mask.shape[0]
+        attn = (attn.view(B_ // nW, nW, num_heads, N, N) + mask.unsqueeze(1).unsqueeze(0)).view(-1, num_heads, N, N)
+    attn = attn.softmax(dim=-1)
+    out = (attn @ v).transpose(1, 2).reshape(B_, N, C)
+    return F.linear(out, p["proj.weight"], p["proj.bias"]), attn
+
+
+def swin_block(x, p, num_heads, ws, shift, ln_eps=1e-5):
+    """SwinTransformerBlock.forward, models/swin_transformer.py:259-314 (drop_path identity) -> (x [B,L,C], attn).
+    p: norm1.*, attn.qkv.*, attn.proj.*, attn.relative_position_bias_table, norm2.*, mlp.fc1.*, mlp.fc2.*"""
+    B, L, C = x.shape
+    H = W = int(math.sqrt(L))
+    shortcut = x
+    y = F.layer_norm(x, (C,), p["norm1.weight"], p["norm1.bias"], ln_eps).view(B, H, W, C)
+    pad_r, pad_b = (ws - W % ws) % ws, (ws - H % ws) % ws
+    y = F.pad(y, (0, 0, 0, pad_r, 0, pad_b))
+    Hp, Wp = y.shape[1], y.shape[2]
+    mask = None
+    if shift > 0:
+        y = torch.roll(y, shifts=(-shift, -shift), dims=(1, 2))
+        mask = swin_attn_mask(H, W, ws, shift)
+    xw = swin_window_partition(y, ws).view(-1, ws * ws, C)
+    ap = {k[len("attn."):]: v for k, v in p.items() if k.startswith("attn.")}
+    aw, attn = swin_window_attention(xw, ap, num_heads, ws, mask)
+    y = swin_window_reverse(aw.view(-1, ws, ws, C), ws, Hp, Wp)
+    if shift > 0:
+        y = torch.roll(y, shifts=(shift, shift), dims=(1, 2))
+    y = y[:, :H, :W, :].contiguous().view(B, H * W, C)
+    x = shortcut + y
+    z = F.layer_norm(x, (C,), p["norm2.weight"], p["norm2.bias"], ln_eps)
+    z = F.linear(F.gelu(F.linear(z, p["mlp.fc1.weight"], p["mlp.fc1.bias"])), p["mlp.fc2.weight"], p["mlp.fc2.bias"])
+    return x + z, attn

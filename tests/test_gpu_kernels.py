@@ -452,3 +452,26 @@ def test_rank_select_matches_nonzero(ops):
         assert_equal(ref, got, f"rank select M={M} HW={HW}")
         beyond = ops.rank_select(dev(mask), dev(cnt[:, None] + torch.zeros(M, 1, dtype=torch.long)))
         assert (beyond.cpu() == -1).all()
+
+
+# ------------------------------------------------------------------------------------------------
+# A6: Swin window attention (BASELINE config 5)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag", ["w14_s0", "w14_s3", "w16_s3_pad", "w9_s0_pad"])
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-4), (torch.bfloat16, 3e-2)])
+def test_swin_block_matches_reference(ops, golden, tag, dtype, tol):
+    """SwinTransformerBlock on the fused as_window_attn_fwd kernel vs the reference block's own outputs (fixture):
+    shifted and unshifted windows, grids that need padding (16 -> 21, 9 -> 14)."""
+    from attentionshift_amd.swin import SwinTransformerBlock
+    g = golden(f"swin_{tag}")
+    hw, ws, heads, C = int(g["hw"]), int(g["ws"]), int(g["heads"]), int(g["C"])
+    blk = SwinTransformerBlock(C, (hw, hw), heads, window_size=ws, shift_size=int(g["shift"]), compute_dtype=dtype)
+    sd = {k[2:]: t(g[k]) for k in g.files if k.startswith("p.")}
+    missing = blk.load_state_dict(sd, strict=False)
+    assert missing.unexpected_keys == [] and missing.missing_keys == ["attn.relative_position_index"]
+    blk = blk.cuda().eval()
+    y, attn = blk(dev(t(g["x"])))
+    mx, _ = rel_to_range(t(g["y"]), y)
+    assert mx < tol, ("block output", mx)
+    mx, _ = rel_to_range(t(g["attn"]), attn)
+    assert mx < tol, ("attention probabilities", mx)

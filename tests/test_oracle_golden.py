@@ -132,3 +132,17 @@ def test_cosine_shift_duplicate_seed_ties_resolve_to_lowest_index():
     assign = trace[0][0][0]
     assert set(assign.tolist()) <= {0, 2}
     assert trace[0][1][0, 1] == 1.0 and trace[0][1][0, 3] == 1.0      # empty cluster -> tau = 1
+
+
+@pytest.mark.parametrize("tag", ["w14_s0", "w14_s3", "w16_s3_pad", "w9_s0_pad"])
+def test_swin_block_oracle_matches_reference(golden, tag):
+    """A6: the oracle's restatement of SwinTransformerBlock.forward (pad / shift / partition / WindowAttention with
+    relative-position bias and shift mask / reverse) vs outputs of the reference block itself."""
+    g = golden(f"swin_{tag}")
+    p = {k[2:]: t(g[k]) for k in g.files if k.startswith("p.")}
+    hw, ws, shift, heads = int(g["hw"]), int(g["ws"]), int(g["shift"]), int(g["heads"])
+    y, attn = O.swin_block(t(g["x"]), p, heads, ws, shift)
+    assert_close(t(g["y"]), y, 1e-5, 1e-6, "swin block output")
+    assert_close(t(g["attn"]), attn, 1e-5, 1e-7, "window attention probabilities")
+    if shift > 0:
+        assert_equal(t(g["attn_mask"]), O.swin_attn_mask(hw, hw, ws, shift), "shift mask")

@@ -231,15 +231,55 @@ def dummy_with(ns):
     return d
 
 
+def swin_case(tag, seed, C, heads, hw, shift, B=2, ws=7):
+    """One reference SwinTransformerBlock (models/swin_transformer.py:182-314) on a seeded token grid: stores the
+    parameters, the input and the block's outputs (x, attn) -- A6 of SURVEY section 8."""
+    print(f"[swin {tag}] C={C} heads={heads} grid={hw}x{hw} ws={ws} shift={shift}")
+    sw = ref_import.load_swin()
+    torch.manual_seed(seed)
+    blk = sw.SwinTransformerBlock(C, (hw, hw), heads, window_size=ws, shift_size=shift, mlp_ratio=4., qkv_bias=True)
+    blk.eval()
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        for n, prm in blk.named_parameters():        # non-trivial values everywhere (default init leaves biases 0)
+            prm.copy_(torch.randn(prm.shape, generator=g) * (0.5 if n.endswith("bias_table") else 0.08)
+                      + (1.0 if n.endswith("norm1.weight") or n.endswith("norm2.weight") else 0.0))
+    x = torch.randn(B, hw * hw, C, generator=g)
+    y, attn = blk(x)
+    save = dict(x=npy(x), y=npy(y), attn=npy(attn), C=C, heads=heads, hw=hw, ws=ws, shift=blk.shift_size, B=B)
+    p = {}
+    for n, prm in blk.named_parameters():
+        save["p." + n] = npy(prm)
+        p[n] = prm.detach()
+    if blk.shift_size > 0:
+        save["attn_mask"] = npy(blk.create_attn_mask(hw, hw))
+        report("attn_mask", save["attn_mask"], O.swin_attn_mask(hw, hw, ws, blk.shift_size))
+    report("rel_index", blk.attn.relative_position_index, O.swin_relative_position_index(ws), exact=True)
+    yo, ao = O.swin_block(x, p, heads, ws, blk.shift_size)
+    report("block out", y, yo)
+    report("attn", attn, ao)
+    np.savez_compressed(os.path.join(OUT, f"swin_{tag}.npz"), **save)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     assert ref_import.reference_available(), "needs /root/reference"
+    if "--swin-only" in sys.argv:
+        swin_case("w14_s0", 11, 64, 2, 14, 0)
+        swin_case("w14_s3", 12, 64, 2, 14, 3)
+        swin_case("w16_s3_pad", 13, 96, 3, 16, 3)
+        swin_case("w9_s0_pad", 14, 64, 2, 9, 0, B=1)
+        return
     backbone_case("small", dict(img_size=64, embed_dim=128, depth=4, num_heads=2, out_indices=(0, 1, 2, 3),
                                 point_tokens_num=10, num_classes=5, batch=2, seed=3), (96, 80), (0, 3), 3)
     backbone_case("tiny224", dict(img_size=224, embed_dim=192, depth=12, num_heads=3, out_indices=(3, 5, 7, 11),
                                   point_tokens_num=100, num_classes=20, batch=1, seed=0), (224, 224), (11,), 7)
     shift_case("tiny224", seed=1234, hp=14, wp=14, C=192, G=3, Lc=7, n_shift=3)
     shift_case("mid320", seed=77, hp=20, wp=20, C=96, G=3, Lc=3, n_shift=5)
+    swin_case("w14_s0", 11, 64, 2, 14, 0)
+    swin_case("w14_s3", 12, 64, 2, 14, 3)
+    swin_case("w16_s3_pad", 13, 96, 3, 16, 3)
+    swin_case("w9_s0_pad", 14, 64, 2, 9, 0, B=1)
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print(f"fixtures total {tot / 1e6:.2f} MB")
 

@@ -102,3 +102,23 @@ def load_backbone():
     _stub("mmdet.models"); _stub("mmdet.models.builder", BACKBONES=_FakeRegistry())
     det = _load_by_path("ref_vtd", os.path.join(REF, "mmdet/models/backbones/visual_transformer_det.py"))
     return vt, det
+
+
+def load_swin():
+    """models/swin_transformer.py with `timm` stubbed (DropPath at rate 0 is the identity; to_2tuple; trunc_normal_)."""
+    import torch.nn as nn
+
+    class DropPath(nn.Module):
+        def __init__(self, p=0.0):
+            super().__init__()
+            self.p = p
+
+        def forward(self, x):
+            assert self.p == 0.0 or not self.training
+            return x
+
+    _stub("timm"); _stub("timm.models")
+    _stub("timm.models.registry", register_model=lambda f: f)
+    _stub("timm.models.layers", DropPath=DropPath, to_2tuple=lambda v: (v, v) if not isinstance(v, tuple) else v,
+          trunc_normal_=lambda t, std=0.02: nn.init.trunc_normal_(t, std=std, a=-2 * std, b=2 * std))
+    return _load_by_path("ref_swin", os.path.join(REF, "models/swin_transformer.py"))
