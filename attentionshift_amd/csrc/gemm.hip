@@ -7,6 +7,7 @@
 // The QKV epilogue writes k as [B,h,Npad,64], q in the fragment-major tile layout of common.h (qf_elem) and V
 // TRANSPOSED as [B,h,64,Npad]; V tiles are computed with swapped MFMA operands so lanes run along tokens and
 // the transposed store stays coalesced.
+#include <utility>
 #include "common.h"
 
 namespace {
@@ -178,41 +179,72 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const T* __restrict__ A, const
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// bf16 fast path: 128x128x64 tiles, operands streamed global -> LDS with global_load_lds_dwordx4 (no VGPR
-// round trip), two LDS buffers (64 KiB), one barrier per K step.  The LDS image of a tile is lane-linear
-// ([row][8 x 16-B chunks], 1 KiB per wave instruction), so the bank-conflict swizzle is applied on the SOURCE
-// address: LDS chunk c of row r holds global chunk c ^ (r & 7); fragment reads apply the same XOR (guide rule 21).
+// bf16 fast path: 128x128 output tile, K step 32, operands streamed global -> LDS with global_load_lds_dwordx4 (no
+// VGPR round trip) into a 4-deep LDS ring (4 x 16 KiB): three K steps are in flight while one is consumed, with
+// counted `s_waitcnt vmcnt(N)` + raw s_barrier so the LDS-DMA spans barriers (ONE barrier per K step; __syncthreads
+// would drain vmcnt(0) and expose a full L2/HBM latency per step -- the short-K GEMMs of this path, K = 768, have only
+// 24 steps to hide it in).  The LDS image of a tile is lane-linear ([row][4 x 16-B chunks], 1 KiB per wave
+// instruction), so the bank-conflict swizzle is applied on the SOURCE address: LDS chunk c of row r holds global chunk
+// c ^ ((r >> 2) & 3) -- four 64-B rows share one 256-B bank row, and with that key the 16-lane groups ds_read_b128 is
+// serviced in ({0-3,12-15,20-27}, ...) hit 16 distinct slots.  Fragment reads are issued in inline asm (hipcc would
+// otherwise wait vmcnt(0) before any LDS read that follows an LDS-DMA).
+// All MFMAs are issued as D[n][m] = W . A^T, so a lane owns ONE output row (token) m and its accumulator registers run
+// along the output columns n in groups of 4: the tile is staged through LDS (reusing the ring) with 8-byte writes and
+// leaves as 16-byte fully coalesced global stores (row-major out, k, fragment-major q); V^T tiles are stored straight
+// from the accumulators (lanes run along tokens: 128 contiguous bytes per store instruction).
 // ---------------------------------------------------------------------------------------------------------
-constexpr int GK = 64;                       // K step (elements)
-constexpr int G_TILE_BYTES = BM * GK * 2;    // 16 KiB per operand tile
+constexpr int GK = 32;                       // K step (elements)
+constexpr int G_TILE_BYTES = BM * GK * 2;    // 8 KiB per operand tile
+constexpr int G_STAGE = 2 * G_TILE_BYTES;    // A tile | W tile
+constexpr int G_NSTAGE = 4;
+constexpr int G_EPI_PITCH = BN * 2 + 16;     // bytes per staged output row
+
+typedef __attribute__((ext_vector_type(4))) unsigned g_u32x4;
+__device__ __forceinline__ unsigned g_lds_addr(const void* p) {
+  return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;
+}
+template <int OFF> __device__ __forceinline__ void g_lds_read128(g_u32x4& dst, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+__device__ __forceinline__ void g_lds_wait8(g_u32x4 (&a)[8]) {
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]));
+  __builtin_amdgcn_sched_barrier(0);
+}
+template <int... I, typename F> __device__ __forceinline__ void g_static_for_impl(std::integer_sequence<int, I...>, F&& f) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F> __device__ __forceinline__ void g_static_for(F&& f) {
+  g_static_for_impl(std::make_integer_sequence<int, N>{}, f);
+}
 
 template <int MODE>
-__global__ __launch_bounds__(NT) void gemm_glds_kernel(const __bf16* __restrict__ A, const __bf16* __restrict__ W,
-                                                       const float* __restrict__ bias, __bf16* __restrict__ out, int M,
-                                                       int Nout, int K, int act, QkvEpi epi) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];     // [2 buffers][A tile | W tile]
+__global__ __launch_bounds__(NT, 2) void gemm_glds_kernel(const __bf16* __restrict__ A, const __bf16* __restrict__ W,
+                                                          const float* __restrict__ bias, __bf16* __restrict__ out,
+                                                          int M, int Nout, int K, int act, QkvEpi epi) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];     // [4 stages][A tile | W tile]; reused by the epilogue
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int li = lane & 31, half = lane >> 5;
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
 
-  // loader: wave w issues 4 + 4 one-KiB pieces per K step; piece j covers tile rows (w*4+j)*8 .. +7
-  const int lr = lane >> 3, lc = lane & 7;
-  const char* srcA[4];
-  const char* srcW[4];
+  // loader: per K step wave w moves 2 one-KiB pieces of A and 2 of W; piece p covers tile rows 16p .. 16p+15
+  const int lr = lane >> 2, lc = lane & 3;
+  const char* srcA[2];
+  const char* srcW[2];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int r = (wave * 4 + j) * 8 + lr;
-    const int cs = lc ^ (r & 7);
+  for (int j = 0; j < 2; ++j) {
+    const int r = (wave * 2 + j) * 16 + lr;
+    const int cs = lc ^ ((r >> 2) & 3);
     srcA[j] = reinterpret_cast<const char*>(A + (size_t)min(m0 + r, M - 1) * K) + cs * 16;
     srcW[j] = reinterpret_cast<const char*>(W + (size_t)min(n0 + r, Nout - 1) * K) + cs * 16;
   }
   auto stage = [&](int kt, int buf) {
-    char* base = smem + buf * (2 * G_TILE_BYTES);
+    char* base = smem + buf * G_STAGE;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int piece = (wave * 4 + j) * 1024;
+    for (int j = 0; j < 2; ++j) {
+      const int piece = (wave * 2 + j) * 1024;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[j] + (size_t)kt * GK * 2),
                                        (__attribute__((address_space(3))) void*)(base + piece), 16, 0, 0);
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcW[j] + (size_t)kt * GK * 2),
@@ -220,55 +252,147 @@ __global__ __launch_bounds__(NT) void gemm_glds_kernel(const __bf16* __restrict_
     }
   };
 
-  f32x16 acc[2][2];
+  f32x16 acc[2][2];                                  // [i: 32-row block of m][j: 32-col block of n], D[n][m] orientation
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-  bool swapped[2] = {false, false};
-  if (MODE == 1) {
+
+  // per-lane fragment addresses (loop-invariant): [ks] for the A rows of block i = 0 and the W rows of block j = 0;
+  // the second block (+32 rows = +2048 B) and the ring stage are immediates
+  const unsigned smem_base = g_lds_addr(smem);
+  unsigned offA[2], offW[2];
+  {
+    const int ra = wm * 64 + li, rb = wn * 64 + li;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) swapped[j] = (n0 + wn * 64 + j * 32) >= 2 * epi.D;
+    for (int ks = 0; ks < 2; ++ks) {
+      const int g = ks * 2 + half;
+      offA[ks] = smem_base + ra * 64 + ((g ^ ((ra >> 2) & 3)) << 4);
+      offW[ks] = smem_base + G_TILE_BYTES + rb * 64 + ((g ^ ((rb >> 2) & 3)) << 4);
+    }
   }
 
   const int nk = K / GK;
   stage(0, 0);
-  __syncthreads();                                   // drains the LDS-DMA (vmcnt(0)) and publishes the tile
-  for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
-    const char* As = smem + (kt & 1) * (2 * G_TILE_BYTES);
-    const char* Bs = As + G_TILE_BYTES;
+  if (nk > 1) stage(1, 1);
+  if (nk > 2) stage(2, 2);
+  for (int kt0 = 0; kt0 < nk; kt0 += G_NSTAGE) {
+    g_static_for<G_NSTAGE>([&](auto slot_c) {
+      constexpr int slot = decltype(slot_c)::value;
+      const int kt = kt0 + slot;
+      if (kt >= nk) return;
+      // my pieces of stage kt have landed when at most the (up to two) newer stages are still in flight
+      const int newer = min(2, nk - 1 - kt);
+      if (newer == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if (newer == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                  // publishes stage kt; everyone is done reading stage kt-1
+      if (kt + 3 < nk) stage(kt + 3, (slot + 3) % G_NSTAGE);
+      g_u32x4 f[8];                                  // [ks][A0, A1, W0, W1]
+      g_static_for<2>([&](auto ks_c) {
+        constexpr int ks = decltype(ks_c)::value;
+        g_lds_read128<slot * G_STAGE>(f[ks * 4 + 0], offA[ks]);
+        g_lds_read128<slot * G_STAGE + 2048>(f[ks * 4 + 1], offA[ks]);
+        g_lds_read128<slot * G_STAGE>(f[ks * 4 + 2], offW[ks]);
+        g_lds_read128<slot * G_STAGE + 2048>(f[ks * 4 + 3], offW[ks]);
+      });
+      g_lds_wait8(f);
 #pragma unroll
-    for (int ks = 0; ks < GK / 16; ++ks) {
-      Frag<__bf16> fa[2], fb[2];
-      const int g = ks * 2 + half;                   // 16-byte chunk of the 128-byte row
+      for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int ra = wm * 64 + i * 32 + li;
-        fa[i].load16B(reinterpret_cast<const __bf16*>(As + ra * 128 + ((g ^ (ra & 7)) << 4)));
-        const int rb = wn * 64 + i * 32 + li;
-        fb[i].load16B(reinterpret_cast<const __bf16*>(Bs + rb * 128 + ((g ^ (rb & 7)) << 4)));
-      }
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+          for (int j = 0; j < 2; ++j) {
+            Frag<__bf16> fa, fb;
+            fa.v = *reinterpret_cast<bf16x8*>(&f[ks * 4 + i]);
+            fb.v = *reinterpret_cast<bf16x8*>(&f[ks * 4 + 2 + j]);
+            acc[i][j] = mma32(fb, fa, acc[i][j]);    // D[n][m]
+          }
+    });
+  }
+
+  // ---------------- epilogue ----------------
+  // lane -> token row m = m0 + wm*64 + i*32 + li; register r of block (i,j) -> column n0 + wn*64 + j*32 + acc_row(r,half)
+  const bool vtile = MODE == 1 && n0 >= 2 * epi.D;   // block-uniform: the whole 128-column tile is V
+  if (vtile) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = m0 + wm * 64 + i * 32 + li;
+      if (row < M) {
+        const int b = row / epi.N, n = row - b * epi.N;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          if (MODE == 1 && swapped[j]) acc[i][j] = mma32(fb[j], fa[i], acc[i][j]);
-          else acc[i][j] = mma32(fa[i], fb[j], acc[i][j]);
+          const int cbase = n0 + wn * 64 + j * 32;
+          const int head = (cbase % epi.D) / 64, dd0 = cbase % 64;
+          __bf16* dst = reinterpret_cast<__bf16*>(epi.vt) + ((size_t)(b * epi.h + head) * 64 + dd0) * epi.Npad + n;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int f_ = acc_row(r, half);
+            if (cbase + f_ < Nout) {
+              const float bv = bias != nullptr ? bias[cbase + f_] : 0.0f;
+              dst[(size_t)f_ * epi.Npad] = (__bf16)(acc[i][j][r] + bv);
+            }
+          }
         }
+      }
     }
-    __syncthreads();                                 // next tile landed, everyone finished reading this one
+    return;
   }
-  gemm_epilogue<__bf16, MODE>(acc, swapped, bias, out, M, Nout, act, epi, m0, n0, wm, wn, li, half);
+  __syncthreads();                                   // every wave is done with the ring: reuse it as the staging tile
+  float* bias_s = reinterpret_cast<float*>(smem + BM * G_EPI_PITCH);
+  if (tid < BN) bias_s[tid] = (bias != nullptr && n0 + tid < Nout) ? bias[n0 + tid] : 0.0f;
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    char* srow = smem + (wm * 64 + i * 32 + li) * G_EPI_PITCH;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int c0 = wn * 64 + j * 32 + 8 * g + 4 * half;     // 4 consecutive columns: registers 4g .. 4g+3
+        const float4 bv = *reinterpret_cast<const float4*>(bias_s + c0);
+        float v0 = acc[i][j][4 * g] + bv.x, v1 = acc[i][j][4 * g + 1] + bv.y, v2 = acc[i][j][4 * g + 2] + bv.z,
+              v3 = acc[i][j][4 * g + 3] + bv.w;
+        if (act == 1) { v0 = gelu_exact(v0); v1 = gelu_exact(v1); v2 = gelu_exact(v2); v3 = gelu_exact(v3); }
+        bf16x4 pk = {(__bf16)v0, (__bf16)v1, (__bf16)v2, (__bf16)v3};
+        *reinterpret_cast<bf16x4*>(srow + c0 * 2) = pk;
+      }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < BM * (BN / 8) / NT; ++t) {
+    const int c = tid + t * NT;
+    const int rr = c >> 4, ch = c & 15;               // 16 chunks of 8 columns per row
+    const int row = m0 + rr, col = n0 + ch * 8;
+    if (row >= M || col >= Nout) continue;
+    const uint4 v = *reinterpret_cast<const uint4*>(smem + rr * G_EPI_PITCH + ch * 16);
+    if (MODE == 0) {
+      if (col + 8 <= Nout) {
+        *reinterpret_cast<uint4*>(out + (size_t)row * Nout + col) = v;
+      } else {
+        const __bf16* e = reinterpret_cast<const __bf16*>(smem + rr * G_EPI_PITCH + ch * 16);
+        for (int x = 0; x < Nout - col; ++x) out[(size_t)row * Nout + col + x] = e[x];
+      }
+    } else {
+      const int which = col / epi.D;                   // 0 q, 1 k
+      const int head = (col % epi.D) / 64, d0 = col % 64;
+      const int b = row / epi.N, n = row - b * epi.N;
+      const size_t bh = (size_t)(b * epi.h + head);
+      if (which == 0)
+        *reinterpret_cast<uint4*>(reinterpret_cast<__bf16*>(epi.q) + qf_frag(bh, epi.Npad, n, d0 >> 4, (d0 >> 3) & 1)) = v;
+      else
+        *reinterpret_cast<uint4*>(reinterpret_cast<__bf16*>(epi.k) + (bh * epi.Npad + n) * 64 + d0) = v;
+    }
+  }
 }
 
 template <int MODE>
 int launch_gemm_glds(const void* A, const void* W, const float* bias, void* out, int M, int Nout, int K, int act,
                      QkvEpi epi, hipStream_t s) {
   dim3 grid(as_ceil_div(M, BM), as_ceil_div(Nout, BN));
-  const size_t lds = 4 * (size_t)G_TILE_BYTES;      // 64 KiB
+  const size_t lds = (size_t)G_NSTAGE * G_STAGE;     // 64 KiB (epilogue staging: 128 x 272 B + 512 B bias)
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)gemm_glds_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

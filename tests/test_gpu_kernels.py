@@ -131,14 +131,18 @@ def test_sdpa_spike_row_forces_rescale(ops):
     assert mx < 1e-4, mx
 
 
-def test_sdpa_bf16_deferred_max_and_spikes(ops):
-    """bf16 LDS-DMA kernel: the deferred-max branch (threshold 2^8) must be taken for spiked rows and skipped for the
+@pytest.mark.parametrize("tail,N", [("0", 1000), ("1", 1000), ("1", 100), ("1", 1153)])
+def test_sdpa_bf16_deferred_max_and_spikes(ops, monkeypatch, tail, N):
+    """bf16 LDS-DMA kernel: the re-referencing branch of the softmax must be taken for spiked rows and skipped for the
     rest, with results matching the fp32 oracle on the same bf16-rounded operands (max error <= 2e-2 of the range).
-    Spikes at several tiles, one of them in the ragged last tile."""
-    B, N, h = 1, 1000, 2
+    Spikes at several tiles, one of them in the ragged last tile.  tail=1 forces the last q-tile of every (image, head)
+    through the key-split tail kernel (N=100: every row; N=1153: a single row in the tail)."""
+    monkeypatch.setenv("AS_SDPA_TAIL", tail)
+    B, h = 1, 2
     g = torch.Generator().manual_seed(31)
     q, k, v = (torch.randn(B, h, N, 64, generator=g) for _ in range(3))
-    for (qi, ki, s) in ((5, 650, 6.0), (77, 130, 9.0), (400, 999, 12.0), (401, 3, 5.0)):
+    for (qi, ki, s) in ((5, 650, 6.0), (77, 130, 9.0), (400, 999, 12.0), (401, 3, 5.0), (N - 3, N - 1, 9.0), (N - 2, 1, 7.0)):
+        qi, ki = qi % N, ki % N
         k[0, 0, ki] = q[0, 0, qi] * s / 8.0
         k[0, 1, ki] = q[0, 1, qi] * s / 8.0
     qb, kb, vb = q.bfloat16(), k.bfloat16(), v.bfloat16()
