@@ -29,6 +29,18 @@ struct QkvEpi {
 };
 
 __device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// erf-GELU for a bf16 result: erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far below bf16's 2^-9), ~15
+// instructions instead of the ~50 of erff -- at 64 outputs per lane erff alone cost twice the MFMA time of a K=768 tile.
+__device__ __forceinline__ float gelu_bf16(float x) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float e = 1.0f - p * t * __builtin_amdgcn_exp2f(-z * z * 1.44269504088896340736f);   // erf(|x| / sqrt 2)
+  return 0.5f * x + 0.5f * fabsf(x) * e;
+}
 
 // accumulators -> memory.  MODE 0: row-major out (+bias, +GELU).  MODE 1: q,k [B,h,Npad,64] and V^T [B,h,64,Npad].
 template <typename T, int MODE>
@@ -180,7 +192,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const T* __restrict__ A, const
 
 // ---------------------------------------------------------------------------------------------------------
 // bf16 fast path: 128x128 output tile, K step 32, operands streamed global -> LDS with global_load_lds_dwordx4 (no
-// VGPR round trip) into a 4-deep LDS ring (4 x 16 KiB): three K steps are in flight while one is consumed, with
+// VGPR round trip) into a 3-deep LDS ring (3 x 16 KiB, three workgroups per CU): two K steps are in flight while one is consumed, with
 // counted `s_waitcnt vmcnt(N)` + raw s_barrier so the LDS-DMA spans barriers (ONE barrier per K step; __syncthreads
 // would drain vmcnt(0) and expose a full L2/HBM latency per step -- the short-K GEMMs of this path, K = 768, have only
 // 24 steps to hide it in).  The LDS image of a tile is lane-linear ([row][4 x 16-B chunks], 1 KiB per wave
@@ -196,7 +208,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const T* __restrict__ A, const
 constexpr int GK = 32;                       // K step (elements)
 constexpr int G_TILE_BYTES = BM * GK * 2;    // 8 KiB per operand tile
 constexpr int G_STAGE = 2 * G_TILE_BYTES;    // A tile | W tile
-constexpr int G_NSTAGE = 4;
+constexpr int G_NSTAGE = 3;              // ring depth: 2 K steps in flight + 1 consumed; 48 KiB -> 3 workgroups per CU
 constexpr int G_EPI_PITCH = BN * 2 + 16;     // bytes per staged output row
 
 typedef __attribute__((ext_vector_type(4))) unsigned g_u32x4;
@@ -206,9 +218,8 @@ __device__ __forceinline__ unsigned g_lds_addr(const void* p) {
 template <int OFF> __device__ __forceinline__ void g_lds_read128(g_u32x4& dst, unsigned addr) {
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
 }
-__device__ __forceinline__ void g_lds_wait8(g_u32x4 (&a)[8]) {
-  asm volatile("s_waitcnt lgkmcnt(0)"
-               : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]));
+template <int LEFT> __device__ __forceinline__ void g_lds_wait4(g_u32x4& a, g_u32x4& b, g_u32x4& c, g_u32x4& d) {
+  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(LEFT));   // LDS returns in order
   __builtin_amdgcn_sched_barrier(0);
 }
 template <int... I, typename F> __device__ __forceinline__ void g_static_for_impl(std::integer_sequence<int, I...>, F&& f) {
@@ -219,7 +230,7 @@ template <int N, typename F> __device__ __forceinline__ void g_static_for(F&& f)
 }
 
 template <int MODE>
-__global__ __launch_bounds__(NT, 2) void gemm_glds_kernel(const __bf16* __restrict__ A, const __bf16* __restrict__ W,
+__global__ __launch_bounds__(NT, 3) void gemm_glds_kernel(const __bf16* __restrict__ A, const __bf16* __restrict__ W,
                                                           const float* __restrict__ bias, __bf16* __restrict__ out,
                                                           int M, int Nout, int K, int act, QkvEpi epi) {
   extern __shared__ __attribute__((aligned(16))) char smem[];     // [4 stages][A tile | W tile]; reused by the epilogue
@@ -227,7 +238,15 @@ __global__ __launch_bounds__(NT, 2) void gemm_glds_kernel(const __bf16* __restri
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int li = lane & 31, half = lane >> 5;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  // XCD-aware tile order.  Workgroup ids are dealt round-robin over the 8 XCDs (each with its own 4 MiB L2), so id
+  // -> (xcd = id % 8, slot = id / 8) and XCD x walks the CONTIGUOUS range [x * per, (x+1) * per) of tiles, n fastest:
+  // an A tile (128 tokens x K) is fetched into one L2 once and reused by all Nout/128 column tiles, instead of being
+  // pulled through the fabric by every XCD (measured: 192 MB fetched per QKV launch for 16 MB of operands).
+  const int nt_n = (Nout + BN - 1) / BN, tiles = ((M + BM - 1) / BM) * nt_n;
+  const int per = (tiles + 7) >> 3;
+  const int tile = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if (tile >= tiles) return;
+  const int m0 = (tile / nt_n) * BM, n0 = (tile % nt_n) * BN;
 
   // loader: per K step wave w moves 2 one-KiB pieces of A and 2 of W; piece p covers tile rows 16p .. 16p+15
   const int lr = lane >> 2, lc = lane & 3;
@@ -276,20 +295,21 @@ __global__ __launch_bounds__(NT, 2) void gemm_glds_kernel(const __bf16* __restri
 
   const int nk = K / GK;
   stage(0, 0);
-  if (nk > 1) stage(1, 1);
-  if (nk > 2) stage(2, 2);
+#pragma unroll
+  for (int p_ = 1; p_ < G_NSTAGE - 1; ++p_)
+    if (nk > p_) stage(p_, p_);
   for (int kt0 = 0; kt0 < nk; kt0 += G_NSTAGE) {
     g_static_for<G_NSTAGE>([&](auto slot_c) {
       constexpr int slot = decltype(slot_c)::value;
       const int kt = kt0 + slot;
       if (kt >= nk) return;
-      // my pieces of stage kt have landed when at most the (up to two) newer stages are still in flight
-      const int newer = min(2, nk - 1 - kt);
-      if (newer == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      // my pieces of stage kt have landed when at most the (up to G_NSTAGE-2) newer stages are still in flight
+      const int newer = min(G_NSTAGE - 2, nk - 1 - kt);
+      if (newer >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       else if (newer == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();                  // publishes stage kt; everyone is done reading stage kt-1
-      if (kt + 3 < nk) stage(kt + 3, (slot + 3) % G_NSTAGE);
+      if (kt + G_NSTAGE - 1 < nk) stage(kt + G_NSTAGE - 1, (slot + G_NSTAGE - 1) % G_NSTAGE);
       g_u32x4 f[8];                                  // [ks][A0, A1, W0, W1]
       g_static_for<2>([&](auto ks_c) {
         constexpr int ks = decltype(ks_c)::value;
@@ -298,9 +318,11 @@ __global__ __launch_bounds__(NT, 2) void gemm_glds_kernel(const __bf16* __restri
         g_lds_read128<slot * G_STAGE>(f[ks * 4 + 2], offW[ks]);
         g_lds_read128<slot * G_STAGE + 2048>(f[ks * 4 + 3], offW[ks]);
       });
-      g_lds_wait8(f);
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
+      // the first half's MFMAs start as soon as ITS four fragments are back; the second half's reads finish under them
+      g_static_for<2>([&](auto ks_c) {
+        constexpr int ks = decltype(ks_c)::value;
+        if (ks == 0) g_lds_wait4<4>(f[0], f[1], f[2], f[3]);
+        else g_lds_wait4<0>(f[4], f[5], f[6], f[7]);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -310,6 +332,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_glds_kernel(const __bf16* __restri
             fb.v = *reinterpret_cast<bf16x8*>(&f[ks * 4 + 2 + j]);
             acc[i][j] = mma32(fb, fa, acc[i][j]);    // D[n][m]
           }
+      });
     });
   }
 
@@ -355,7 +378,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_glds_kernel(const __bf16* __restri
         const float4 bv = *reinterpret_cast<const float4*>(bias_s + c0);
         float v0 = acc[i][j][4 * g] + bv.x, v1 = acc[i][j][4 * g + 1] + bv.y, v2 = acc[i][j][4 * g + 2] + bv.z,
               v3 = acc[i][j][4 * g + 3] + bv.w;
-        if (act == 1) { v0 = gelu_exact(v0); v1 = gelu_exact(v1); v2 = gelu_exact(v2); v3 = gelu_exact(v3); }
+        if (act == 1) { v0 = gelu_bf16(v0); v1 = gelu_bf16(v1); v2 = gelu_bf16(v2); v3 = gelu_bf16(v3); }
         bf16x4 pk = {(__bf16)v0, (__bf16)v1, (__bf16)v2, (__bf16)v3};
         *reinterpret_cast<bf16x4*>(srow + c0 * 2) = pk;
       }
@@ -391,8 +414,9 @@ __global__ __launch_bounds__(NT, 2) void gemm_glds_kernel(const __bf16* __restri
 template <int MODE>
 int launch_gemm_glds(const void* A, const void* W, const float* bias, void* out, int M, int Nout, int K, int act,
                      QkvEpi epi, hipStream_t s) {
-  dim3 grid(as_ceil_div(M, BM), as_ceil_div(Nout, BN));
-  const size_t lds = (size_t)G_NSTAGE * G_STAGE;     // 64 KiB (epilogue staging: 128 x 272 B + 512 B bias)
+  const int tiles = as_ceil_div(M, BM) * as_ceil_div(Nout, BN);
+  dim3 grid(8 * as_ceil_div(tiles, 8));              // 1-D, padded to a multiple of the 8 XCDs (see the tile order)
+  const size_t lds = (size_t)G_NSTAGE * G_STAGE;     // 48 KiB (epilogue staging: 128 x 272 B + 512 B bias = 35 KiB)
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)gemm_glds_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
