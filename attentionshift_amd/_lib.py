@@ -29,7 +29,8 @@ SIGNATURES = {
     "as_attn_mean_rows": (_c_int, [_c_void_p] * 4 + [_c_int] * 6 + [_c_void_p]),
     "as_rollout_rfrag_bytes": (_c_size_t, [_c_int] * 3),
     "as_rollout_top": (_c_int, [_c_void_p] * 5 + [_c_int] * 5 + [_c_void_p]),
-    "as_rollout_step": (_c_int, [_c_void_p] * 7 + [_c_int] * 5 + [_c_void_p]),
+    "as_rollout_step_workspace_bytes": (_c_size_t, [_c_int] * 3),
+    "as_rollout_step": (_c_int, [_c_void_p] * 8 + [_c_size_t] + [_c_int] * 5 + [_c_void_p]),
     "as_ccl_2d": (_c_int, [_c_void_p] * 2 + [_c_int] * 3 + [_c_void_p]),
     "as_cam_boxes_workspace_bytes": (_c_size_t, [_c_int] * 4),
     "as_cam_boxes": (_c_int, [_c_void_p] * 2 + [_c_float] * 2 + [_c_int] * 4 + [_c_void_p] * 5 + [_c_size_t, _c_void_p]),

@@ -117,13 +117,14 @@ template <typename T, int HPW>
 __global__ __launch_bounds__(RO_NT) void rollout_step2_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                               const float* __restrict__ lse,
                                                               const float* __restrict__ Rin, const T* __restrict__ rf_in,
-                                                              float* __restrict__ Rout, T* __restrict__ rf_out, int B,
-                                                              int N, int Npad, int h, int Trows) {
+                                                              float* __restrict__ Rout, T* __restrict__ rf_out,
+                                                              float* __restrict__ part, int B, int N, int Npad, int h,
+                                                              int Trows, int nsplit) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr bool PREFETCH = sizeof(T) == 2;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, half = lane >> 5;
-  const int j0 = blockIdx.x * 32, b = blockIdx.y;
+  const int j0 = blockIdx.x * 32, b = blockIdx.y, split = blockIdx.z;
   char* kj = smem;
   float4* xchg = reinterpret_cast<float4*>(smem + (size_t)h * 32 * Kj2<T>::PITCH);    // [2][4 waves][4][64]
 
@@ -174,14 +175,17 @@ __global__ __launch_bounds__(RO_NT) void rollout_step2_kernel(const T* __restric
       for (int s2 = 0; s2 < 2; ++s2) f.fr[s2].load16B(rf_in + rf_frag(b, nkb, kb, wave, s2, lane));
     }
   };
+  // contraction-range split: workgroup `split` of `nsplit` takes blocks [kb0, kb1) and leaves a raw partial sum; the
+  // grid is then (N/32) x B x nsplit workgroups instead of 264 for 256 CUs (which ran as two rounds of one per CU)
+  const int kb0 = (int)((long long)nkb * split / nsplit), kb1 = (int)((long long)nkb * (split + 1) / nsplit);
   Fetch cur, nxt;
-  if (PREFETCH) fetch(0, nxt);
+  if (PREFETCH && kb0 < kb1) fetch(kb0, nxt);
 
-  for (int kb = 0; kb < nkb; ++kb) {
+  for (int kb = kb0; kb < kb1; ++kb) {
     const int k0 = kb * 32;
     if (PREFETCH) {
       cur = nxt;
-      if (kb + 1 < nkb) fetch(kb + 1, nxt);
+      if (kb + 1 < kb1) fetch(kb + 1, nxt);
     } else {
       fetch(kb, cur);
     }
@@ -210,7 +214,7 @@ __global__ __launch_bounds__(RO_NT) void rollout_step2_kernel(const T* __restric
       }
     }
     // publish this wave's partial head sum
-    float4* slab = xchg + (size_t)(kb & 1) * 4 * 4 * 64;
+    float4* slab = xchg + (size_t)((kb - kb0) & 1) * 4 * 4 * 64;
 #pragma unroll
     for (int g = 0; g < 4; ++g)
       slab[(wave * 4 + g) * 64 + lane] = make_float4(pbar[4 * g], pbar[4 * g + 1], pbar[4 * g + 2], pbar[4 * g + 3]);
@@ -244,6 +248,10 @@ __global__ __launch_bounds__(RO_NT) void rollout_step2_kernel(const T* __restric
     for (int r = 0; r < 16; ++r) {
       const int i = wave * 32 + acc_row(r, half);
       const bool live = i < Trows && j < N;
+      if (nsplit > 1) {
+        if (live) part[(((size_t)split * B + b) * Trows + i) * N + j] = acc[r];
+        continue;
+      }
       float v = 0.0f;
       if (live) {
         const size_t idx = ((size_t)b * Trows + i) * N + j;
@@ -255,12 +263,32 @@ __global__ __launch_bounds__(RO_NT) void rollout_step2_kernel(const T* __restric
   }
 }
 
+// R_out = 0.5 (sum of the contraction-split partials, in split order + R_in), plus the fragment-major copy (all 128 x
+// nkb*32 slots, zeros outside [Trows) x [N)).  grid (nkb*32/64, 128, B), 64 threads along j.
+template <typename T>
+__global__ __launch_bounds__(64) void rollout_finish_kernel(const float* __restrict__ part, const float* __restrict__ Rin,
+                                                            float* __restrict__ Rout, T* __restrict__ rf_out, int B, int N,
+                                                            int Trows, int nsplit) {
+  const int nkb = (N + 31) / 32;
+  const int j = blockIdx.x * 64 + threadIdx.x, i = blockIdx.y, b = blockIdx.z;
+  if (j >= nkb * 32) return;
+  float v = 0.0f;
+  if (i < Trows && j < N) {
+    const size_t idx = ((size_t)b * Trows + i) * N + j;
+    float a = 0.0f;
+    for (int sp = 0; sp < nsplit; ++sp) a += part[(size_t)sp * B * Trows * N + idx];
+    v = 0.5f * (a + Rin[idx]);
+    Rout[idx] = v;
+  }
+  if (rf_out != nullptr) rf_out[rf_slot(b, nkb, i, j)] = from_f32<T>(v);
+}
+
 template <typename T>
 int launch_rollout_step2(const void* q, const void* k, const float* lse, const float* Rin, const void* rf_in, float* Rout,
-                         void* rf_out, int B, int N, int h, int Trows, hipStream_t s) {
+                         void* rf_out, float* part, int nsplit, int B, int N, int h, int Trows, hipStream_t s) {
   const int Npad = as_round_up(N, 64);
   const int hpw = as_ceil_div(h, 4);
-  dim3 grid(as_ceil_div(N, 32), B);
+  dim3 grid(as_ceil_div(N, 32), B, nsplit);
   const size_t lds = (size_t)h * 32 * Kj2<T>::PITCH + 2 * 4 * 4 * 64 * sizeof(float4);
   AS_REQUIRE(lds <= 160 * 1024, AS_E_UNSUPPORTED, "rollout_step: LDS %zu B exceeds 160 KiB (h=%d)", lds, h);
 #define AS_RO2(HPW)                                                                                            \
@@ -268,7 +296,7 @@ int launch_rollout_step2(const void* q, const void* k, const float* lse, const f
     (void)hipFuncSetAttribute((const void*)rollout_step2_kernel<T, HPW>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                               (int)lds);                                                                       \
     hipLaunchKernelGGL((rollout_step2_kernel<T, HPW>), grid, dim3(RO_NT), lds, s, (const T*)q, (const T*)k, lse, Rin, \
-                       (const T*)rf_in, Rout, (T*)rf_out, B, N, Npad, h, Trows);                               \
+                       (const T*)rf_in, Rout, (T*)rf_out, part, B, N, Npad, h, Trows, nsplit);                 \
   } while (0)
   switch (hpw) {
     case 1: AS_RO2(1); break;
@@ -279,7 +307,21 @@ int launch_rollout_step2(const void* q, const void* k, const float* lse, const f
   }
 #undef AS_RO2
   AS_CHECK_LAUNCH("rollout_step2");
+  if (nsplit > 1) {
+    dim3 fg(as_ceil_div(as_ceil_div(N, 32) * 32, 64), 128, B);
+    hipLaunchKernelGGL((rollout_finish_kernel<T>), fg, dim3(64), 0, s, (const float*)part, Rin, Rout, (T*)rf_out, B, N,
+                       Trows, nsplit);
+    AS_CHECK_LAUNCH("rollout_finish");
+  }
   return AS_OK;
+}
+
+// contraction split of a roll-out step: enough workgroups for >= 8 per CU-round granularity, bounded partial buffers
+int rollout_nsplit(int B, int N) {
+  const int wgs = as_ceil_div(N, 32) * B;
+  int ns = 1;
+  while (ns < 16 && wgs * ns < 2048) ns *= 2;
+  return wgs >= 2048 ? 1 : ns;
 }
 
 template <typename T>
@@ -325,14 +367,26 @@ extern "C" int as_rollout_top(const void* q, const void* k, const float* lse, fl
   AS_REQUIRE(false, AS_E_UNSUPPORTED, "as_rollout_top: dtype %d", dtype);
 }
 
+extern "C" size_t as_rollout_step_workspace_bytes(int B, int N, int T) {
+  if (B <= 0 || N <= 0 || T <= 0) return 0;
+  const int ns = rollout_nsplit(B, N);
+  return ns > 1 ? (size_t)ns * B * T * N * sizeof(float) : 0;
+}
+
 extern "C" int as_rollout_step(const void* q, const void* k, const float* lse, const float* R_in, const void* rf_in,
-                               float* R_out, void* rf_out, int B, int N, int h, int T, int dtype, as_stream_t stream) {
+                               float* R_out, void* rf_out, void* workspace, size_t workspace_bytes, int B, int N, int h,
+                               int T, int dtype, as_stream_t stream) {
   AS_REQUIRE(q && k && lse && R_in && rf_in && R_out && R_in != R_out && rf_in != rf_out, AS_E_BADARG,
              "as_rollout_step: null/aliased pointer");
   AS_REQUIRE(B > 0 && h > 0 && h <= 16 && T > 0 && T <= N && T <= 128, AS_E_BADARG,
              "as_rollout_step: bad sizes N=%d T=%d h=%d", N, T, h);
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == AS_BF16) return launch_rollout_step2<__bf16>(q, k, lse, R_in, rf_in, R_out, rf_out, B, N, h, T, s);
-  if (dtype == AS_F32) return launch_rollout_step2<float>(q, k, lse, R_in, rf_in, R_out, rf_out, B, N, h, T, s);
+  // without a workspace the step runs unsplit (one workgroup per 32-column block and image)
+  const size_t need = as_rollout_step_workspace_bytes(B, N, T);
+  const int ns = (workspace != nullptr && workspace_bytes >= need && need > 0) ? rollout_nsplit(B, N) : 1;
+  float* part = ns > 1 ? (float*)workspace : nullptr;
+  if (dtype == AS_BF16)
+    return launch_rollout_step2<__bf16>(q, k, lse, R_in, rf_in, R_out, rf_out, part, ns, B, N, h, T, s);
+  if (dtype == AS_F32) return launch_rollout_step2<float>(q, k, lse, R_in, rf_in, R_out, rf_out, part, ns, B, N, h, T, s);
   AS_REQUIRE(false, AS_E_UNSUPPORTED, "as_rollout_step: dtype %d", dtype);
 }

@@ -258,11 +258,13 @@ def rollout_rows(states, num_point_tokens):
                "as_rollout_top")
     outs.append(R)
     lower = list(reversed(states[:-1]))
+    wbytes = lib.as_rollout_step_workspace_bytes(top.B, top.N, T) if lower else 0
+    ws = torch.empty(wbytes, device=dev, dtype=torch.uint8) if wbytes else None     # contraction-split partials
     for n, st in enumerate(lower):
         Rn = torch.empty_like(R)
         rfn = torch.empty_like(rf) if n + 1 < len(lower) else None
-        _lib.check(lib.as_rollout_step(_p(st.q), _p(st.k), _p(st.lse), _p(R), _p(rf), _p(Rn), _p(rfn), st.B, st.N, st.h, T,
-                                       dt, _stream()), "as_rollout_step")
+        _lib.check(lib.as_rollout_step(_p(st.q), _p(st.k), _p(st.lse), _p(R), _p(rf), _p(Rn), _p(rfn), _p(ws), wbytes,
+                                       st.B, st.N, st.h, T, dt, _stream()), "as_rollout_step")
         outs.append(Rn)
         R, rf = Rn, rfn
     return torch.stack(outs, dim=1)
