@@ -10,6 +10,7 @@
 // pbar_tile(): one wave, one 32x32 tile of mean_h P via h x 4 MFMAs + exp2, accumulators laid out
 // rows = contraction index (registers), cols = output column (lanes) so they feed the second MFMA
 // as its B operand without any data movement (same trick as sdpa.hip).
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -263,6 +264,149 @@ __global__ __launch_bounds__(RO_NT) void rollout_step2_kernel(const T* __restric
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// rollout_step3: barrier-free inner loop.  Each WAVE takes whole 32-row contraction blocks (all heads) of the
+// workgroup's range, so the head-mean tile never leaves its registers: no per-block LDS exchange, no per-block
+// barrier, LDS holds only the K_j tile (48 KiB at h = 12).  Per block a wave runs, per head, one exact-fp32 MFMA that
+// injects -8*lse in accumulator layout + 4 MFMAs q.k^T and 16 exp2, then 8 MFMAs R . Pbar for all four 32-row blocks
+// of R.  Q fragments are prefetched one head ahead, R fragments at the top of the block.  The four waves'
+// accumulators are summed once at the end (two passes through LDS, fixed order).
+// ---------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(RO_NT, 2) void rollout_step3_kernel(const T* __restrict__ q, const T* __restrict__ k,
+                                                                 const float* __restrict__ lse,
+                                                                 const float* __restrict__ Rin, const T* __restrict__ rf_in,
+                                                                 float* __restrict__ Rout, T* __restrict__ rf_out,
+                                                                 float* __restrict__ part, int B, int N, int Npad, int h,
+                                                                 int Trows, int nsplit) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, half = lane >> 5;
+  const int j0 = blockIdx.x * 32, b = blockIdx.y, split = blockIdx.z;
+  char* kj = smem;
+  {  // stage K rows j0..j0+31 of every head
+    constexpr int CPR = HD * (int)sizeof(T) / 16;
+    const int total = h * 32 * CPR;
+    for (int c = tid; c < total; c += RO_NT) {
+      const int hh = c / (32 * CPR), rem = c % (32 * CPR);
+      const int jr = rem / CPR, ch = rem % CPR;
+      const int jrow = min(j0 + jr, N - 1);
+      const uint4 u = *reinterpret_cast<const uint4*>(
+          reinterpret_cast<const char*>(k + (((size_t)b * h + hh) * Npad + jrow) * HD) + ch * 16);
+      const int elem = ch * (16 / (int)sizeof(T));
+      const int base = Kj2<T>::off(hh * 32 + jr, elem & ~7);
+      *reinterpret_cast<uint4*>(kj + base + (elem & 7) * (int)sizeof(T)) = u;
+    }
+  }
+  __syncthreads();
+
+  const int nkb = (N + 31) / 32;
+  const int nib = (Trows + 31) / 32;                      // 32-row blocks of R that exist (<= 4)
+  const float c2 = 0.125f * LOG2E;
+  const float inv_h = 1.0f / (float)h;
+  const int kb0 = (int)((long long)nkb * split / nsplit), kb1 = (int)((long long)nkb * (split + 1) / nsplit);
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[ib][r] = 0.0f;
+
+  for (int kb = kb0 + wave; kb < kb1; kb += 4) {
+    const int k0 = kb * 32;
+    const int row = min(k0 + li, N - 1);
+    Frag<T> fr[4][2];
+#pragma unroll
+    for (int ib = 0; ib < 4; ++ib) {
+      const int ibc = min(ib, nib - 1);                  // a missing block re-reads a valid one; its MFMA is skipped
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) fr[ib][s2].load16B(rf_in + rf_frag(b, nkb, kb, ibc, s2, lane));
+    }
+    Frag<T> fq[4], fn[4];
+    float l8, l8n = 0.0f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) fq[ks].load16B(q + qf_frag((size_t)b * h, Npad, row, ks, half));
+    l8 = -8.0f * lse[((size_t)b * h) * N + row];
+    f32x16 pbar;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) pbar[r] = 0.0f;
+    for (int hh = 0; hh < h; ++hh) {
+      const int hn = min(hh + 1, h - 1);                  // last head re-fetches itself (harmless)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) fn[ks].load16B(q + qf_frag((size_t)b * h + hn, Npad, row, ks, half));
+      l8n = -8.0f * lse[((size_t)b * h + hn) * N + row];
+      f32x16 sc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sc[r] = 0.0f;
+      sc = __builtin_amdgcn_mfma_f32_32x32x2f32(half == 0 ? l8 : 0.0f, 1.0f, sc, 0, 0, 0);   // -8*lse[row i], exact
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        Frag<T> fk;
+        fk.load16B(reinterpret_cast<const T*>(kj + Kj2<T>::off(hh * 32 + li, ks * 16 + half * 8)));
+        sc = mma32(fq[ks], fk, sc);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) pbar[r] += __builtin_amdgcn_exp2f(sc[r] * c2);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) fq[ks] = fn[ks];
+      l8 = l8n;
+    }
+    Frag<T> fp[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const bool live = k0 + acc_row(r, half) < N;         // contraction rows beyond N contribute nothing
+      fp[r >> 3].set(r & 7, live ? pbar[r] * inv_h : 0.0f);
+    }
+#pragma unroll
+    for (int ib = 0; ib < 4; ++ib)
+      if (ib < nib) {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) acc[ib] = mma32(fr[ib][s2], fp[s2], acc[ib]);
+      }
+  }
+
+  // sum the four waves' accumulators: two passes of two R blocks through LDS (32 KiB), wave w finishes block w
+  float* red = reinterpret_cast<float*>(smem);
+  f32x16 mine;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) mine[r] = 0.0f;
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    __syncthreads();                                      // K tile / previous pass no longer needed
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[((wave * 2 + x) * 16 + r) * 64 + lane] = acc[pass * 2 + x][r];
+    __syncthreads();
+    if ((wave >> 1) == pass) {
+      const int x = wave & 1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        mine[r] = ((red[((0 * 2 + x) * 16 + r) * 64 + lane] + red[((1 * 2 + x) * 16 + r) * 64 + lane]) +
+                   red[((2 * 2 + x) * 16 + r) * 64 + lane]) + red[((3 * 2 + x) * 16 + r) * 64 + lane];
+    }
+  }
+  if (wave * 32 < Trows) {
+    const int j = j0 + li;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = wave * 32 + acc_row(r, half);
+      const bool live = i < Trows && j < N;
+      if (nsplit > 1) {
+        if (live) part[(((size_t)split * B + b) * Trows + i) * N + j] = mine[r];
+        continue;
+      }
+      float v = 0.0f;
+      if (live) {
+        const size_t idx = ((size_t)b * Trows + i) * N + j;
+        v = 0.5f * (mine[r] + Rin[idx]);
+        Rout[idx] = v;
+      }
+      if (rf_out != nullptr) rf_out[rf_slot(b, nkb, i, j)] = from_f32<T>(v);
+    }
+  }
+}
+
 // R_out = 0.5 (sum of the contraction-split partials, in split order + R_in), plus the fragment-major copy (all 128 x
 // nkb*32 slots, zeros outside [Trows) x [N)).  grid (nkb*32/64, 128, B), 64 threads along j.
 template <typename T>
@@ -298,12 +442,20 @@ int launch_rollout_step2(const void* q, const void* k, const float* lse, const f
     hipLaunchKernelGGL((rollout_step2_kernel<T, HPW>), grid, dim3(RO_NT), lds, s, (const T*)q, (const T*)k, lse, Rin, \
                        (const T*)rf_in, Rout, (T*)rf_out, part, B, N, Npad, h, Trows, nsplit);                 \
   } while (0)
+  if (sizeof(T) == 2 && h >= 8 && (getenv("AS_ROLLOUT_V2") == nullptr)) {
+    // bf16, 8..16 heads (K tile 32..64 KiB): barrier-free kernel, LDS = K tile only
+    const size_t lds3 = (size_t)h * 32 * Kj2<T>::PITCH;
+    (void)hipFuncSetAttribute((const void*)rollout_step3_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+    hipLaunchKernelGGL((rollout_step3_kernel<T>), grid, dim3(RO_NT), lds3, s, (const T*)q, (const T*)k, lse, Rin,
+                       (const T*)rf_in, Rout, (T*)rf_out, part, B, N, Npad, h, Trows, nsplit);
+  } else {
   switch (hpw) {
     case 1: AS_RO2(1); break;
     case 2: AS_RO2(2); break;
     case 3: AS_RO2(3); break;
     case 4: AS_RO2(4); break;
     default: AS_REQUIRE(false, AS_E_UNSUPPORTED, "rollout_step: h=%d heads (max 16)", h);
+  }
   }
 #undef AS_RO2
   AS_CHECK_LAUNCH("rollout_step2");
