@@ -273,7 +273,7 @@ __global__ __launch_bounds__(RO_NT) void rollout_step2_kernel(const T* __restric
 // accumulators are summed once at the end (two passes through LDS, fixed order).
 // ---------------------------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(RO_NT, 2) void rollout_step3_kernel(const T* __restrict__ q, const T* __restrict__ k,
+__global__ __launch_bounds__(RO_NT, 3) void rollout_step3_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                                  const float* __restrict__ lse,
                                                                  const float* __restrict__ Rin, const T* __restrict__ rf_in,
                                                                  float* __restrict__ Rout, T* __restrict__ rf_out,
@@ -315,26 +315,15 @@ __global__ __launch_bounds__(RO_NT, 2) void rollout_step3_kernel(const T* __rest
   for (int kb = kb0 + wave; kb < kb1; kb += 4) {
     const int k0 = kb * 32;
     const int row = min(k0 + li, N - 1);
-    Frag<T> fr[4][2];
-#pragma unroll
-    for (int ib = 0; ib < 4; ++ib) {
-      const int ibc = min(ib, nib - 1);                  // a missing block re-reads a valid one; its MFMA is skipped
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) fr[ib][s2].load16B(rf_in + rf_frag(b, nkb, kb, ibc, s2, lane));
-    }
-    Frag<T> fq[4], fn[4];
-    float l8, l8n = 0.0f;
+    Frag<T> fq[4];
+    float l8;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) fq[ks].load16B(q + qf_frag((size_t)b * h, Npad, row, ks, half));
     l8 = -8.0f * lse[((size_t)b * h) * N + row];
     f32x16 pbar;
 #pragma unroll
     for (int r = 0; r < 16; ++r) pbar[r] = 0.0f;
-    for (int hh = 0; hh < h; ++hh) {
-      const int hn = min(hh + 1, h - 1);                  // last head re-fetches itself (harmless)
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) fn[ks].load16B(q + qf_frag((size_t)b * h + hn, Npad, row, ks, half));
-      l8n = -8.0f * lse[((size_t)b * h + hn) * N + row];
+    auto head = [&](int hh) {
       f32x16 sc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) sc[r] = 0.0f;
@@ -347,10 +336,25 @@ __global__ __launch_bounds__(RO_NT, 2) void rollout_step3_kernel(const T* __rest
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) pbar[r] += __builtin_amdgcn_exp2f(sc[r] * c2);
+    };
+    for (int hh = 0; hh + 1 < h; ++hh) {                  // heads 0 .. h-2: next head's Q fragments in flight
+      Frag<T> fn[4];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) fn[ks].load16B(q + qf_frag((size_t)b * h + hh + 1, Npad, row, ks, half));
+      const float l8n = -8.0f * lse[((size_t)b * h + hh + 1) * N + row];
+      head(hh);
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) fq[ks] = fn[ks];
       l8 = l8n;
     }
+    Frag<T> fr[4][2];                                      // last head: the R fragments take the prefetch slot
+#pragma unroll
+    for (int ib = 0; ib < 4; ++ib) {
+      const int ibc = min(ib, nib - 1);                    // a missing block re-reads a valid one; its MFMA is skipped
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) fr[ib][s2].load16B(rf_in + rf_frag(b, nkb, kb, ibc, s2, lane));
+    }
+    head(h - 1);
     Frag<T> fp[2];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
