@@ -19,13 +19,14 @@ SIGNATURES = {
     "as_npad": (_c_int, [_c_int]),
     "as_linear_fwd": (_c_int, [_c_void_p] * 4 + [_c_int] * 5 + [_c_void_p]),
     "as_qkv_fwd": (_c_int, [_c_void_p] * 6 + [_c_int] * 5 + [_c_void_p]),
-    "as_sdpa_fwd": (_c_int, [_c_void_p] * 5 + [_c_int] * 4 + [_c_void_p]),
+    "as_sdpa_fwd_workspace_bytes": (_c_size_t, [_c_int] * 4),
+    "as_sdpa_fwd": (_c_int, [_c_void_p] * 6 + [_c_size_t] + [_c_int] * 4 + [_c_void_p]),
     "as_sdpa_bwd_workspace_bytes": (_c_size_t, [_c_int] * 4),
     "as_sdpa_bwd": (_c_int, [_c_void_p] * 8 + [_c_size_t] + [_c_int] * 4 + [_c_void_p]),
     "as_attn_bwd_workspace_bytes": (_c_size_t, [_c_int] * 5),
     "as_attn_bwd": (_c_int, [_c_void_p] * 15 + [_c_size_t] + [_c_int] * 5 + [_c_void_p]),
     "as_window_attn_fwd": (_c_int, [_c_void_p] * 5 + [_c_int] * 8 + [_c_void_p]),
-    "as_attn_fwd": (_c_int, [_c_void_p] * 11 + [_c_int] * 5 + [_c_void_p]),
+    "as_attn_fwd": (_c_int, [_c_void_p] * 12 + [_c_size_t] + [_c_int] * 5 + [_c_void_p]),
     "as_attn_mean_rows": (_c_int, [_c_void_p] * 4 + [_c_int] * 6 + [_c_void_p]),
     "as_rollout_rfrag_bytes": (_c_size_t, [_c_int] * 3),
     "as_rollout_top": (_c_int, [_c_void_p] * 5 + [_c_int] * 5 + [_c_void_p]),

@@ -20,6 +20,7 @@
 namespace {
 
 constexpr int SD_NT = 256, SD_QB = 128, SD_KB = 64, HD = 64;
+constexpr int SD_REC = 68;                       // floats per row of a key-split partial record
 
 template <typename T> struct SdpaCfg;
 template <> struct SdpaCfg<__bf16> {
@@ -271,18 +272,28 @@ __device__ __forceinline__ void lds_wait8(u32x2 (&v)[8]) {
 constexpr int GL_TILE = SD_KB * HD * 2;          // 8 KiB per K (or V^T) tile
 constexpr int GL_NBUF = 3;                       // LDS ring: tiles kt, kt+1, kt+2 (48 KiB per workgroup)
 
+// SPLIT = false: one workgroup per (q-tile, image*head), whole key range, writes o and lse.
+// SPLIT = true : q-tile `qt_fixed` only; workgroup (image*head, slice) takes key tiles [slice*per, (slice+1)*per) and
+//                leaves its unnormalised partial (O^T fp32, reference max, row sum) in `part` for sdpa_combine_kernel.
+template <bool SPLIT>
 __global__ __launch_bounds__(SD_NT, 3) void sdpa_fwd_glds_kernel(const __bf16* __restrict__ q, const __bf16* __restrict__ k,
                                                                  const __bf16* __restrict__ vt, __bf16* __restrict__ o,
-                                                                 float* __restrict__ lse, int B, int N, int Npad, int h) {
+                                                                 float* __restrict__ lse, int B, int N, int Npad, int h,
+                                                                 int qt_fixed, int nslices, float* __restrict__ part) {
   extern __shared__ __attribute__((aligned(16))) char smem[];     // [2][K tile | V^T tile]
   const int BH = B * h;
   const int bid = blockIdx.x;
-  const int bh = bid % BH, qt = bid / BH;
+  const int bh = bid % BH, qt = SPLIT ? qt_fixed : bid / BH;
+  const int slice = SPLIT ? bid / BH : 0;
   const int b = bh / h, head = bh % h;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, half = lane >> 5;
   const int query = qt * SD_QB + wave * 32 + li;
   const int qclamped = min(query, N - 1);
+  const int nkt_all = Npad / SD_KB;
+  const int per = SPLIT ? (nkt_all + nslices - 1) / nslices : nkt_all;
+  const int kt_off = slice * per;                                   // first key tile of this workgroup
+  const int nkt = min(nkt_all, kt_off + per) - kt_off;              // key tiles of this workgroup (>= 1 by construction)
 
   Frag<__bf16> fq[4];
 #pragma unroll
@@ -308,9 +319,9 @@ __global__ __launch_bounds__(SD_NT, 3) void sdpa_fwd_glds_kernel(const __bf16* _
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int piece = (wave + 4 * j) * 1024;                     // rows 8*wave.. and 32 + 8*wave..
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcK[j] + (size_t)kt * SD_KB * HD * 2),
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcK[j] + (size_t)(kt_off + kt) * SD_KB * HD * 2),
                                        (__attribute__((address_space(3))) void*)(base + piece), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcV[j] + (size_t)kt * SD_KB * 2),
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcV[j] + (size_t)(kt_off + kt) * SD_KB * 2),
                                        (__attribute__((address_space(3))) void*)(base + GL_TILE + piece), 16, 0, 0);
     }
   };
@@ -320,7 +331,6 @@ __global__ __launch_bounds__(SD_NT, 3) void sdpa_fwd_glds_kernel(const __bf16* _
   for (int r = 0; r < 16; ++r) { oacc[0][r] = 0.0f; oacc[1][r] = 0.0f; }
   float m_run = 0.0f, l_part = 0.0f;
   const float c2 = 0.125f * 1.44269504088896340736f;
-  const int nkt = Npad / SD_KB;
 
   // Ring protocol: at the top of iteration kt tiles kt and kt+1 are in flight or landed; tile kt+2 is issued into
   // the buffer last read in iteration kt-1 (every wave passed the barrier that ended it).  Each wave issues 4 LDS-DMA
@@ -363,11 +373,12 @@ __global__ __launch_bounds__(SD_NT, 3) void sdpa_fwd_glds_kernel(const __bf16* _
     if (kt + 2 < nkt) stage(kt + 2, (slot + 2) % GL_NBUF);
     char* Ks = smem + slot * (2 * GL_TILE);
     char* Vs = Ks + GL_TILE;
-    const bool ragged = (kt == nkt - 1) && (N % SD_KB) != 0;
+    const int ktg = kt_off + kt;                    // absolute key tile
+    const bool ragged = (ktg == nkt_all - 1) && (N % SD_KB) != 0;
     if (ragged) {                                   // zero V^T columns of the padded keys (workgroup-uniform branch)
       for (int e = tid; e < HD * SD_KB; e += SD_NT) {
         const int d = e >> 6, key = e & 63;
-        if (kt * SD_KB + key >= N)
+        if (ktg * SD_KB + key >= N)
           *reinterpret_cast<__bf16*>(Vs + d * 128 + (((key >> 3) ^ ((d >> 1) & 7)) << 4) + (key & 7) * 2) = (__bf16)0.0f;
       }
       __syncthreads();
@@ -395,7 +406,7 @@ __global__ __launch_bounds__(SD_NT, 3) void sdpa_fwd_glds_kernel(const __bf16* _
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-          if (kt * SD_KB + kb * 32 + 16 * (r >> 3) + 8 * half + (r & 7) >= N) sacc[kb][r] = -INFINITY;
+          if (ktg * SD_KB + kb * 32 + 16 * (r >> 3) + 8 * half + (r & 7) >= N) sacc[kb][r] = -INFINITY;
     }
 
     // Softmax reference point: the row max of the FIRST tile only.  Any fixed reference gives the same softmax; the
@@ -469,6 +480,19 @@ __global__ __launch_bounds__(SD_NT, 3) void sdpa_fwd_glds_kernel(const __bf16* _
   }
 
   const float l = l_part + __shfl_xor(l_part, 32);
+  if (SPLIT) {
+    // partial record of row (wave*32 + li): [64 x O^T unnormalised | m | l | pad], SD_REC floats (16-B aligned rows);
+    // rows past N are never combined
+    float* rec = part + (((size_t)bh * nslices + slice) * SD_QB + wave * 32 + li) * SD_REC;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<float4*>(rec + db * 32 + 8 * g + 4 * half) =
+            make_float4(oacc[db][4 * g], oacc[db][4 * g + 1], oacc[db][4 * g + 2], oacc[db][4 * g + 3]);
+    if (half == 0) { rec[64] = m_run; rec[65] = l; }
+    return;
+  }
   const float inv = 1.0f / l;
   if (query < N) {
     __bf16* orow = o + ((size_t)b * N + query) * ((size_t)h * HD) + head * HD;
@@ -484,181 +508,40 @@ __global__ __launch_bounds__(SD_NT, 3) void sdpa_fwd_glds_kernel(const __bf16* _
   }
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// Tail kernel.  At ViT-B / 1024^2 / B=2 the grid above is 33 q-tiles x 24 (image, head) = 792 workgroups for 768
-// resident slots (3 per CU): the 24 left-over workgroups run alone afterwards and cost ~20% of the launch (measured:
-// 146 us at N=4096, 179 us at N=4197).  When dropping the LAST q-tile of every (image, head) makes the main grid an
-// exact multiple of the slots, those rows are computed here instead: one workgroup per 32-row tile, its 8 waves
-// SPLIT THE KEYS (flash-decoding style), operands straight from global/L2 (no LDS staging: the kernel is short), and
-// the 8 partial (max, sum, O) triples are merged through LDS.  Same arithmetic per tile as the main kernel.
-// ---------------------------------------------------------------------------------------------------------
-constexpr int TL_SLICES = 8, TL_NT = TL_SLICES * 64;
-
-__global__ __launch_bounds__(TL_NT) void sdpa_fwd_tail_kernel(const __bf16* __restrict__ q, const __bf16* __restrict__ k,
-                                                              const __bf16* __restrict__ vt, __bf16* __restrict__ o,
-                                                              float* __restrict__ lse, int B, int N, int Npad, int h,
-                                                              int row0) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* Osm = reinterpret_cast<float*>(smem);                      // [slice][d 64][row 32]
-  float* msm = Osm + TL_SLICES * HD * 32;                           // [slice][row]
-  float* lsm = msm + TL_SLICES * 32;
-  const int BH = B * h;
-  const int bh = blockIdx.x % BH, rt = blockIdx.x / BH;
-  const int b = bh / h, head = bh % h;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int li = lane & 31, half = lane >> 5;
-  const int query = row0 + rt * 32 + li;
-  const int qclamped = min(query, N - 1);
-
-  Frag<__bf16> fq[4];
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) fq[ks].load16B(q + qf_frag((size_t)bh, Npad, qclamped, ks, half));
-
-  const int nkt = Npad / SD_KB;
-  const int per = as_ceil_div_dev(nkt, TL_SLICES);
-  const int kt0 = wave * per, kt1 = min(nkt, kt0 + per);
-  const int krow = (li & 0x13) | ((li & 4) << 1) | ((li & 8) >> 1);       // pi(li), as in the main kernel
-  const __bf16* kbase = k + (size_t)bh * Npad * HD;
-  const __bf16* vbase = vt + (size_t)bh * HD * Npad;
-
-  f32x16 oacc[2];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) { oacc[0][r] = 0.0f; oacc[1][r] = 0.0f; }
-  float m_run = -INFINITY, l_part = 0.0f, mc = 0.0f;
+// merges the key-slice partials of the split q-tile: thread = (row, 4 consecutive d); grid (8, B*h), 256 threads
+__global__ __launch_bounds__(256) void sdpa_combine_kernel(const float* __restrict__ part, __bf16* __restrict__ o,
+                                                           float* __restrict__ lse, int B, int N, int h, int qt,
+                                                           int nslices) {
+  const int bh = blockIdx.y, b = bh / h, head = bh % h;
+  const int row = blockIdx.x * 16 + (threadIdx.x >> 4), dg = threadIdx.x & 15;
+  const int query = qt * SD_QB + row;
+  if (query >= N) return;
   const float c2 = 0.125f * 1.44269504088896340736f;
-  // operand fragments of tile kt+1 are fetched (registers) while tile kt is computed: no LDS, one L2 latency hidden
-  bf16x8 kf[2][4], vf[2][4], kn[2][4], vn[2][4];
-  auto fetch = [&](int kt, bf16x8 (&kd)[2][4], bf16x8 (&vd)[2][4]) {
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-      const __bf16* krow_p = kbase + (size_t)(kt * SD_KB + kb * 32 + krow) * HD + half * 8;
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) kd[kb][ks] = *reinterpret_cast<const bf16x8*>(krow_p + ks * 16);
-    }
-#pragma unroll
-    for (int db = 0; db < 2; ++db) {
-      const __bf16* vrow_p = vbase + (size_t)(db * 32 + li) * Npad + kt * SD_KB + half * 8;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) vd[db][c] = *reinterpret_cast<const bf16x8*>(vrow_p + c * 16);
-    }
-  };
-  if (kt0 < kt1) fetch(kt0, kn, vn);
-  for (int kt = kt0; kt < kt1; ++kt) {
-    const bool ragged = (kt == nkt - 1) && (N % SD_KB) != 0;
-#pragma unroll
-    for (int x = 0; x < 2; ++x)
-#pragma unroll
-      for (int y = 0; y < 4; ++y) { kf[x][y] = kn[x][y]; vf[x][y] = vn[x][y]; }
-    if (kt + 1 < kt1) fetch(kt + 1, kn, vn);
-    f32x16 sacc[2];
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.0f;
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        Frag<__bf16> fk;
-        fk.v = kf[kb][ks];
-        sacc[kb] = mma32(fk, fq[ks], sacc[kb]);
-      }
-    }
-    if (ragged) {
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          if (kt * SD_KB + kb * 32 + 16 * (r >> 3) + 8 * half + (r & 7) >= N) sacc[kb][r] = -INFINITY;
-    }
-    auto rowmax = [&]() {
-      float m = sacc[0][0];
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) m = fmaxf(m, sacc[kb][r]);
-      return fmaxf(m, __shfl_xor(m, 32));
-    };
-    if (kt == kt0) {
-      m_run = rowmax();
-      mc = m_run * c2;
-    }
-    float psum = 0.0f;
-    Frag<__bf16> fp[2][2];
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float p = __builtin_amdgcn_exp2f(fmaf(sacc[kb][r], c2, -mc));
-        psum += p;
-        fp[kb][r >> 3].set(r & 7, p);
-      }
-    if (__any(!(psum < 1e20f))) {
-      const float m_cand = fmaxf(m_run, rowmax());
-      const float alpha = __builtin_amdgcn_exp2f((m_run - m_cand) * c2);
-      m_run = m_cand;
-      mc = m_cand * c2;
-      l_part *= alpha;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { oacc[0][r] *= alpha; oacc[1][r] *= alpha; }
-      psum = 0.0f;
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float p = __builtin_amdgcn_exp2f(fmaf(sacc[kb][r], c2, -mc));
-          psum += p;
-          fp[kb][r >> 3].set(r & 7, p);
-        }
-    }
-    l_part += psum;
-#pragma unroll
-    for (int db = 0; db < 2; ++db) {
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        Frag<__bf16> fv;
-        fv.v = vf[db][c];
-        if (ragged) {                                 // padded keys: P is exactly 0 there, 0 * garbage must stay 0
-#pragma unroll
-          for (int t = 0; t < 8; ++t)
-            if (kt * SD_KB + c * 16 + half * 8 + t >= N) fv.v[t] = (__bf16)0.0f;
-        }
-        oacc[db] = mma32(fv, fp[c >> 1][c & 1], oacc[db]);
-      }
-    }
-  }
-  // publish this slice's partial result
-  const float l_row = l_part + __shfl_xor(l_part, 32);
-  if (half == 0) {
-    msm[wave * 32 + li] = (kt0 < kt1) ? m_run : -INFINITY;
-    lsm[wave * 32 + li] = (kt0 < kt1) ? l_row : 0.0f;
-  }
-#pragma unroll
-  for (int db = 0; db < 2; ++db)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) Osm[(wave * HD + db * 32 + acc_row(r, half)) * 32 + li] = oacc[db][r];
-  __syncthreads();
-  // merge: thread = (row, group of 4 d)
-  const int row = tid & 31, dg = tid >> 5;                          // 16 groups x 4 d = 64
-  const int qrow = row0 + rt * 32 + row;
+  const float* base = part + ((size_t)bh * nslices * SD_QB + row) * SD_REC;
+  const size_t step = (size_t)SD_QB * SD_REC;
   float m = -INFINITY;
-#pragma unroll
-  for (int w = 0; w < TL_SLICES; ++w) m = fmaxf(m, msm[w * 32 + row]);
-  float l = 0.0f, acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-  for (int w = 0; w < TL_SLICES; ++w) {
-    const float mw = msm[w * 32 + row];
-    const float sc = (mw == -INFINITY) ? 0.0f : __builtin_amdgcn_exp2f((mw - m) * c2);
-    l += lsm[w * 32 + row] * sc;
-#pragma unroll
-    for (int x = 0; x < 4; ++x) acc[x] += Osm[(w * HD + dg * 4 + x) * 32 + row] * sc;
+  for (int s = 0; s < nslices; ++s) m = fmaxf(m, base[s * step + 64]);
+  float l = 0.0f, a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+  for (int s = 0; s < nslices; ++s) {
+    const float* r = base + s * step;
+    const float sc = __builtin_amdgcn_exp2f((r[64] - m) * c2);
+    const float4 v = *reinterpret_cast<const float4*>(r + dg * 4);
+    l += r[65] * sc;
+    a0 += v.x * sc; a1 += v.y * sc; a2 += v.z * sc; a3 += v.w * sc;
   }
-  if (qrow < N) {
-    const float inv = 1.0f / l;
-    store4(o + ((size_t)b * N + qrow) * ((size_t)h * HD) + head * HD + dg * 4, acc[0] * inv, acc[1] * inv, acc[2] * inv,
-           acc[3] * inv);
-    if (dg == 0) lse[(size_t)bh * N + qrow] = m * 0.125f + logf(l);
-  }
+  const float inv = 1.0f / l;
+  store4(o + ((size_t)b * N + query) * ((size_t)h * HD) + head * HD + dg * 4, a0 * inv, a1 * inv, a2 * inv, a3 * inv);
+  if (dg == 0) lse[(size_t)bh * N + query] = m * 0.125f + logf(l);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The 792-vs-768 tail.  At ViT-B / 1024^2 / B=2 the plain grid is 33 q-tiles x 24 (image, head) = 792 workgroups for
+// 768 resident slots (3 per CU): the 24 left-over workgroups run alone afterwards and cost ~20% of the launch
+// (measured: 138 us for the first 768, 172 us in total).  When dropping the LAST q-tile of every (image, head) makes
+// the main grid an exact multiple of the slots and the caller supplied a workspace, that q-tile is computed by the
+// same kernel in SPLIT mode -- (image*head) x 11 key slices = 264 short workgroups that still share K/V tiles through
+// the LDS ring -- followed by a tiny merge of the 11 partial (max, sum, O) records per row (fixed order).
+// ---------------------------------------------------------------------------------------------------------
 int sdpa_slots() {                                    // resident workgroups of sdpa_fwd_glds_kernel: 3 per CU
   static int slots = 0;                               // read-only device-properties cache
   if (slots == 0) {
@@ -669,35 +552,39 @@ int sdpa_slots() {                                    // resident workgroups of 
   return slots;
 }
 
-int launch_sdpa_glds(const void* q, const void* k, const void* vt, void* o, float* lse, int B, int N, int h,
-                     hipStream_t s) {
+int sdpa_split_slices(int B, int N, int h) {           // 0 = no split for this shape
+  const int BH = B * h, qtiles = as_ceil_div(N, SD_QB), slots = sdpa_slots();
+  bool tail = qtiles * BH > slots && ((qtiles - 1) * BH) % slots == 0;
+  if (const char* e = getenv("AS_SDPA_TAIL")) tail = e[0] == '1' ? true : (e[0] == '0' ? false : tail);
+  if (!tail) return 0;
+  const int nkt = as_round_up(N, 64) / SD_KB;
+  int ns = as_ceil_div(slots / 3, BH);                 // about one workgroup per CU
+  ns = ns < 2 ? 2 : (ns > nkt ? nkt : ns);
+  const int per = as_ceil_div(nkt, ns);
+  return as_ceil_div(nkt, per);                         // no empty slice
+}
+
+int launch_sdpa_glds(const void* q, const void* k, const void* vt, void* o, float* lse, void* ws, size_t ws_bytes, int B,
+                     int N, int h, hipStream_t s) {
   const int Npad = as_round_up(N, 64);
   const int BH = B * h;
   int qtiles = as_ceil_div(N, SD_QB);
-  // move the last q-tile of every (image, head) to the key-split tail kernel when that makes the main grid an exact
-  // number of full waves of resident workgroups (AS_SDPA_TAIL=1 forces it, =0 disables it: test / measurement hook)
-  const int slots = sdpa_slots();
-  bool tail = qtiles * BH > slots && ((qtiles - 1) * BH) % slots == 0;
-  if (const char* e = getenv("AS_SDPA_TAIL")) tail = e[0] == '1' ? true : (e[0] == '0' ? false : tail);
-  if (tail) --qtiles;
+  int ns = sdpa_split_slices(B, N, h);
+  if (ns > 0 && (ws == nullptr || ws_bytes < (size_t)BH * ns * SD_QB * SD_REC * sizeof(float))) ns = 0;
+  if (ns > 0) --qtiles;
   const size_t lds = (size_t)GL_NBUF * 2 * GL_TILE;        // 48 KiB
   if (qtiles > 0) {
-    hipLaunchKernelGGL(sdpa_fwd_glds_kernel, dim3(qtiles * BH), dim3(SD_NT), lds, s, (const __bf16*)q, (const __bf16*)k,
-                       (const __bf16*)vt, (__bf16*)o, lse, B, N, Npad, h);
+    hipLaunchKernelGGL(sdpa_fwd_glds_kernel<false>, dim3(qtiles * BH), dim3(SD_NT), lds, s, (const __bf16*)q,
+                       (const __bf16*)k, (const __bf16*)vt, (__bf16*)o, lse, B, N, Npad, h, 0, 1, (float*)nullptr);
     AS_CHECK_LAUNCH("sdpa_fwd_glds");
   }
-  if (tail) {
-    const int row0 = qtiles * SD_QB;
-    const int rts = as_ceil_div(N - row0, 32);
-    const size_t tl_lds = (size_t)(TL_SLICES * HD * 32 + 2 * TL_SLICES * 32) * sizeof(float);     // 66 KiB
-    static bool attr_set = false;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute((const void*)sdpa_fwd_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tl_lds);
-      attr_set = true;
-    }
-    hipLaunchKernelGGL(sdpa_fwd_tail_kernel, dim3(rts * BH), dim3(TL_NT), tl_lds, s, (const __bf16*)q, (const __bf16*)k,
-                       (const __bf16*)vt, (__bf16*)o, lse, B, N, Npad, h, row0);
-    AS_CHECK_LAUNCH("sdpa_fwd_tail");
+  if (ns > 0) {
+    hipLaunchKernelGGL(sdpa_fwd_glds_kernel<true>, dim3(ns * BH), dim3(SD_NT), lds, s, (const __bf16*)q, (const __bf16*)k,
+                       (const __bf16*)vt, (__bf16*)o, lse, B, N, Npad, h, qtiles, ns, (float*)ws);
+    AS_CHECK_LAUNCH("sdpa_fwd_glds<split>");
+    hipLaunchKernelGGL(sdpa_combine_kernel, dim3(SD_QB / 16, BH), dim3(256), 0, s, (const float*)ws, (__bf16*)o, lse, B, N,
+                       h, qtiles, ns);
+    AS_CHECK_LAUNCH("sdpa_combine");
   }
   return AS_OK;
 }
@@ -721,22 +608,29 @@ int launch_sdpa(const void* q, const void* k, const void* vt, void* o, float* ls
 
 }  // namespace
 
-extern "C" int as_sdpa_fwd(const void* q, const void* k, const void* vt, void* o, float* lse, int B, int N, int h,
-                           int dtype, as_stream_t stream) {
+extern "C" size_t as_sdpa_fwd_workspace_bytes(int B, int N, int h, int dtype) {
+  if (B <= 0 || N <= 0 || h <= 0 || dtype != AS_BF16) return 0;
+  const int ns = sdpa_split_slices(B, N, h);
+  return (size_t)B * h * ns * SD_QB * SD_REC * sizeof(float);
+}
+
+extern "C" int as_sdpa_fwd(const void* q, const void* k, const void* vt, void* o, float* lse, void* workspace,
+                           size_t workspace_bytes, int B, int N, int h, int dtype, as_stream_t stream) {
   AS_REQUIRE(q && k && vt && o && lse, AS_E_BADARG, "as_sdpa_fwd: null pointer");
   AS_REQUIRE(B > 0 && N > 0 && h > 0, AS_E_BADARG, "as_sdpa_fwd: bad sizes B=%d N=%d h=%d", B, N, h);
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == AS_BF16) return launch_sdpa_glds(q, k, vt, o, lse, B, N, h, s);
+  if (dtype == AS_BF16) return launch_sdpa_glds(q, k, vt, o, lse, workspace, workspace_bytes, B, N, h, s);
   if (dtype == AS_F32) return launch_sdpa<float>(q, k, vt, o, lse, B, N, h, s);
   AS_REQUIRE(false, AS_E_UNSUPPORTED, "as_sdpa_fwd: dtype %d", dtype);
 }
 
 extern "C" int as_attn_fwd(const void* x, const void* Wqkv, const float* bqkv, const void* Wproj,
-                           const float* bproj, void* out, float* lse, void* q, void* k, void* vt, void* o, int B,
-                           int N, int D, int h, int dtype, as_stream_t stream) {
+                           const float* bproj, void* out, float* lse, void* q, void* k, void* vt, void* o,
+                           void* workspace, size_t workspace_bytes, int B, int N, int D, int h, int dtype,
+                           as_stream_t stream) {
   int rc = as_qkv_fwd(x, Wqkv, bqkv, q, k, vt, B, N, D, h, dtype, stream);
   if (rc != AS_OK) return rc;
-  rc = as_sdpa_fwd(q, k, vt, o, lse, B, N, h, dtype, stream);
+  rc = as_sdpa_fwd(q, k, vt, o, lse, workspace, workspace_bytes, B, N, h, dtype, stream);
   if (rc != AS_OK) return rc;
   return as_linear_fwd(o, Wproj, bproj, out, B * N, D, D, dtype, 0, stream);
 }

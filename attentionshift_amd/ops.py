@@ -114,6 +114,12 @@ class AttnLayerState:
         self.o = o                                  # pre-projection attention output, kept only for the backward
 
 
+def _sdpa_ws(lib, B, N, h, like):
+    """optional key-split workspace of as_sdpa_fwd (non-zero only for shapes whose grid leaves a short last round)"""
+    n = lib.as_sdpa_fwd_workspace_bytes(B, N, h, _dt(like))
+    return (torch.empty(n, device=like.device, dtype=torch.uint8), n) if n else (None, 0)
+
+
 def attention_fwd(x, w_qkv, b_qkv, w_proj, b_proj, num_heads, keep_state=True, keep_o=False):
     """Attention.forward (reference models/vision_transformer.py:74-86) -> (out [B,N,D], AttnLayerState)."""
     lib = _lib.load()
@@ -129,16 +135,17 @@ def attention_fwd(x, w_qkv, b_qkv, w_proj, b_proj, num_heads, keep_state=True, k
     o = torch.empty(B, N, D, device=dev, dtype=dt)
     out = torch.empty(B, N, D, device=dev, dtype=dt)
     lse = torch.empty(B, num_heads, N, device=dev, dtype=torch.float32)
+    ws, wbytes = _sdpa_ws(lib, B, N, num_heads, x)
     if _TIMED is None:
         _lib.check(lib.as_attn_fwd(_p(x), _p(w_qkv), _p(b_qkv), _p(w_proj), _p(b_proj), _p(out), _p(lse), _p(q), _p(k),
-                                   _p(vt), _p(o), B, N, D, num_heads, _dt(x), _stream()), "as_attn_fwd")
+                                   _p(vt), _p(o), _p(ws), wbytes, B, N, D, num_heads, _dt(x), _stream()), "as_attn_fwd")
     else:       # same three launches as as_attn_fwd, with event pairs around each
         with _timed("qkv_gemm"):
             _lib.check(lib.as_qkv_fwd(_p(x), _p(w_qkv), _p(b_qkv), _p(q), _p(k), _p(vt), B, N, D, num_heads, _dt(x),
                                       _stream()), "as_qkv_fwd")
         with _timed("sdpa_fwd"):
-            _lib.check(lib.as_sdpa_fwd(_p(q), _p(k), _p(vt), _p(o), _p(lse), B, N, num_heads, _dt(x), _stream()),
-                       "as_sdpa_fwd")
+            _lib.check(lib.as_sdpa_fwd(_p(q), _p(k), _p(vt), _p(o), _p(lse), _p(ws), wbytes, B, N, num_heads, _dt(x),
+                                       _stream()), "as_sdpa_fwd")
         with _timed("proj_gemm"):
             _lib.check(lib.as_linear_fwd(_p(o), _p(w_proj), _p(b_proj), _p(out), B * N, D, D, _dt(x), 0, _stream()),
                        "as_linear_fwd")
@@ -199,7 +206,9 @@ def sdpa_fwd(q, k, vt, N):
     _chk(q, k, vt)
     o = torch.empty(B, N, h * HEAD_DIM, device=q.device, dtype=q.dtype)
     lse = torch.empty(B, h, N, device=q.device, dtype=torch.float32)
-    _lib.check(lib.as_sdpa_fwd(_p(q), _p(k), _p(vt), _p(o), _p(lse), B, N, h, _dt(q), _stream()), "as_sdpa_fwd")
+    ws, wbytes = _sdpa_ws(lib, B, N, h, q)
+    _lib.check(lib.as_sdpa_fwd(_p(q), _p(k), _p(vt), _p(o), _p(lse), _p(ws), wbytes, B, N, h, _dt(q), _stream()),
+               "as_sdpa_fwd")
     return o, lse
 
 

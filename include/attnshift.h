@@ -65,9 +65,13 @@ int as_qkv_fwd(const void* x /*[B,N,D]*/, const void* Wqkv /*[3D,D]*/, const flo
                void* q, void* k, void* vt, int B, int N, int D, int h, int dtype, as_stream_t stream);
 
 /* softmax(q k^T / sqrt(64)) v without materialising [h,N,N] (vision_transformer.py:79-83).
- *   o   : [B,N,h*64] (heads concatenated, ready for proj)        lse : [B,h,N] fp32, natural log */
-int as_sdpa_fwd(const void* q, const void* k, const void* vt, void* o, float* lse, int B, int N, int h,
-                int dtype, as_stream_t stream);
+ *   o   : [B,N,h*64] (heads concatenated, ready for proj)        lse : [B,h,N] fp32, natural log
+ *   workspace : optional, as_sdpa_fwd_workspace_bytes(...) bytes (0 for most shapes): lets the launch split the keys
+ *               of the last q-tile over extra workgroups when the plain grid would leave a short second round
+ *               (ViT-B/1024^2/B=2: 792 workgroups for 768 resident slots); NULL = plain grid.  Same results. */
+size_t as_sdpa_fwd_workspace_bytes(int B, int N, int h, int dtype);
+int as_sdpa_fwd(const void* q, const void* k, const void* vt, void* o, float* lse, void* workspace,
+                size_t workspace_bytes, int B, int N, int h, int dtype, as_stream_t stream);
 
 /* Backward of as_sdpa_fwd (autograd of vision_transformer.py:79-83; the reference trains the backbone, and with
  * use_checkpoint recomputes each block's forward in backward, visual_transformer_det.py:232-236).  Softmax tiles are
@@ -83,8 +87,9 @@ int as_sdpa_bwd(const void* q, const void* k, const void* vt, const void* o, con
 /* Attention.forward = qkv + sdpa + proj (vision_transformer.py:74-86).  q/k/vt/o are workspaces the
  * caller keeps alive when the roll-out (below) needs this layer; `o` is [B,N,D]. */
 int as_attn_fwd(const void* x, const void* Wqkv, const float* bqkv, const void* Wproj, const float* bproj,
-                void* out /*[B,N,D]*/, float* lse, void* q, void* k, void* vt, void* o, int B, int N, int D,
-                int h, int dtype, as_stream_t stream);
+                void* out /*[B,N,D]*/, float* lse, void* q, void* k, void* vt, void* o, void* workspace,
+                size_t workspace_bytes /* as_sdpa_fwd_workspace_bytes, may be NULL/0 */, int B, int N, int D, int h,
+                int dtype, as_stream_t stream);
 
 /* Backward of as_attn_fwd (autograd of Attention.forward, vision_transformer.py:74-86): given dout = dL/d out and the
  * tensors as_attn_fwd saved (q,k,vt,o,lse) returns dL/dx and the parameter gradients.
