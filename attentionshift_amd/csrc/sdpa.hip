@@ -314,15 +314,20 @@ __global__ __launch_bounds__(SD_NT, 3) void sdpa_fwd_glds_kernel(const __bf16* _
     srcK[1] = srcK[0] + 32 * HD * 2;                               // rows r + 32: same swizzle key
     srcV[1] = srcV[0] + (size_t)32 * Npad * 2;
   }
-  auto stage = [&](int kt, int buf) {
+  // running source pointers: tiles are staged strictly in order, so each call just advances them by one tile
+  const char* pK[2] = {srcK[0] + (size_t)kt_off * SD_KB * HD * 2, srcK[1] + (size_t)kt_off * SD_KB * HD * 2};
+  const char* pV[2] = {srcV[0] + (size_t)kt_off * SD_KB * 2, srcV[1] + (size_t)kt_off * SD_KB * 2};
+  auto stage = [&](int /*kt*/, int buf) {
     char* base = smem + buf * (2 * GL_TILE);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int piece = (wave + 4 * j) * 1024;                     // rows 8*wave.. and 32 + 8*wave..
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcK[j] + (size_t)(kt_off + kt) * SD_KB * HD * 2),
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pK[j],
                                        (__attribute__((address_space(3))) void*)(base + piece), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcV[j] + (size_t)(kt_off + kt) * SD_KB * 2),
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pV[j],
                                        (__attribute__((address_space(3))) void*)(base + GL_TILE + piece), 16, 0, 0);
+      pK[j] += SD_KB * HD * 2;
+      pV[j] += SD_KB * 2;
     }
   };
 
