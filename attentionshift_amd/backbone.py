@@ -220,6 +220,28 @@ class VisionTransformerDet(nn.Module):
         y = ops.linear(x_nhwc.reshape(B * h * w, cin), wmat, bias)
         return y.reshape(B, h, w, 2, 2, cout).permute(0, 1, 3, 2, 4, 5).reshape(B, 2 * h, 2 * w, cout)
 
+    def _deconv2x2_train(self, x_nhwc, conv):
+        """_deconv2x2 under autograd: the same token GEMM through F.linear (library GEMM, differentiable) instead of
+        MIOpen's fp32 transposed convolution (whose backward dominated the training step: 17 ms of 55)."""
+        B, h, w, cin = x_nhwc.shape
+        cout = conv.weight.shape[1]
+        cd = self.compute_dtype
+        wmat = conv.weight.permute(2, 3, 1, 0).reshape(4 * cout, cin).to(cd)
+        bias = None if conv.bias is None else conv.bias.repeat(4).to(cd)
+        y = F.linear(x_nhwc.reshape(B * h * w, cin), wmat, bias)
+        return y.reshape(B, h, w, 2, 2, cout).permute(0, 1, 3, 2, 4, 5).reshape(B, 2 * h, 2 * w, cout)
+
+    def _fpn_train(self, i, feat_nchw, tok):
+        B, D, hp, wp = feat_nchw.shape
+        op = [self.fpn1, self.fpn2, self.fpn3, self.fpn4][i]
+        if isinstance(op, nn.Sequential) and isinstance(op[0], nn.ConvTranspose2d):
+            y = self._deconv2x2_train(tok.to(self.compute_dtype).reshape(B, hp, wp, D), op[0]).permute(0, 3, 1, 2)
+            if len(op) == 4:
+                y = op[2](op[1](y.float())).to(self.compute_dtype)
+                y = self._deconv2x2_train(y.permute(0, 2, 3, 1), op[3]).permute(0, 3, 1, 2)
+            return y
+        return op(feat_nchw)
+
     def _fpn(self, i, feat_nchw, tok):
         """FPN tap i (visual_transformer_det.py:246-256).  feat_nchw: the fp32 [B,D,hp,wp] tap; tok: the same tokens
         as a token-major view [B,Np,D].  Deconvolved taps come back NCHW-shaped with channels-last strides in the
@@ -345,8 +367,7 @@ class VisionTransformerDet(nn.Module):
                 last_feat = x[:, :-T]
         org_features = torch.stack(features, dim=1)
         if self.with_fpn and grad_path:
-            fpn = [self.fpn1, self.fpn2, self.fpn3, self.fpn4]
-            features = [fpn[i](features[i]) for i in range(len(features))]
+            features = [self._fpn_train(i, features[i], taps[i]) for i in range(len(features))]
         elif self.with_fpn:
             # the taps are token-major already: run the 2x2/2 deconvolutions as GEMMs over tokens (channels-last)
             features = [self._fpn(i, features[i], taps[i]) for i in range(len(features))]
