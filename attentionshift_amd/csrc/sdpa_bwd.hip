@@ -233,7 +233,7 @@ __global__ __launch_bounds__(BW_NT) void sdpa_bwd_dq_kernel(const T* __restrict_
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float p = __builtin_amdgcn_exp2f(fmaf(sacc[r], c2, -lse2));
-        float ds = p * (pacc[r] - dl) * 0.125f;
+        float ds = p * (pacc[r] - dl);                  // the softmax scale 1/8 is applied once, to the accumulators
         if (ragged && t * BW_TILE + kb * 32 + pi_acc_row(r, half) >= N) ds = 0.0f;   // padded key rows hold garbage
         fds[kb][r >> 3].set(r & 7, ds);
       }
@@ -260,8 +260,8 @@ __global__ __launch_bounds__(BW_NT) void sdpa_bwd_dq_kernel(const T* __restrict_
     for (int db = 0; db < 2; ++db)
 #pragma unroll
       for (int g = 0; g < 4; ++g)
-        st4(row + db * 32 + 8 * g + 4 * half, dqacc[db][4 * g], dqacc[db][4 * g + 1], dqacc[db][4 * g + 2],
-            dqacc[db][4 * g + 3]);
+        st4(row + db * 32 + 8 * g + 4 * half, dqacc[db][4 * g] * 0.125f, dqacc[db][4 * g + 1] * 0.125f,
+            dqacc[db][4 * g + 2] * 0.125f, dqacc[db][4 * g + 3] * 0.125f);
   }
 }
 
@@ -381,7 +381,7 @@ __global__ __launch_bounds__(BW_NT) void sdpa_bwd_dkv_kernel(const T* __restrict
         for (int t8 = 0; t8 < 8; ++t8) {
           const int r = s2 * 8 + t8;
           float p = __builtin_amdgcn_exp2f(fmaf(sacc[r], c2, -lv[t8]));
-          float ds = p * (pacc[r] - dv[t8]) * 0.125f;
+          float ds = p * (pacc[r] - dv[t8]);            // scale 1/8 applied once to the dK accumulators
           if (ragged && t * BW_TILE + q0 + t8 >= N) { p = 0.0f; ds = 0.0f; }   // padded query rows hold garbage
           fp[qb][s2].set(t8, p);
           fds[qb][s2].set(t8, ds);
@@ -414,7 +414,8 @@ __global__ __launch_bounds__(BW_NT) void sdpa_bwd_dkv_kernel(const T* __restrict
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int d = db * 32 + 8 * g + 4 * half;
-        st4(row + D + d, dkacc[db][4 * g], dkacc[db][4 * g + 1], dkacc[db][4 * g + 2], dkacc[db][4 * g + 3]);
+        st4(row + D + d, dkacc[db][4 * g] * 0.125f, dkacc[db][4 * g + 1] * 0.125f, dkacc[db][4 * g + 2] * 0.125f,
+            dkacc[db][4 * g + 3] * 0.125f);
         st4(row + 2 * D + d, dvacc[db][4 * g], dvacc[db][4 * g + 1], dvacc[db][4 * g + 2], dvacc[db][4 * g + 3]);
       }
   }
