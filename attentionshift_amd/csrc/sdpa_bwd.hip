@@ -149,7 +149,7 @@ __global__ __launch_bounds__(BW_NT) void bwd_prep_kernel(const T* __restrict__ q
 //   dQ^T += K^T . dS^T    A = K^T rows d            B = dS^T (from the accumulators)
 // ---------------------------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(BW_NT) void sdpa_bwd_dq_kernel(const T* __restrict__ q, const T* __restrict__ dof,
+__global__ __launch_bounds__(BW_NT, sizeof(T) == 2 ? 2 : 1) void sdpa_bwd_dq_kernel(const T* __restrict__ q, const T* __restrict__ dof,
                                                             const T* __restrict__ k, const T* __restrict__ vrow,
                                                             const T* __restrict__ kt, const float* __restrict__ lse,
                                                             const float* __restrict__ delta, T* __restrict__ dqkv,
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(BW_NT) void sdpa_bwd_dq_kernel(const T* __restrict_
 //   dK^T += Q^T . dS      A = Q^T rows d       B = dS (from the accumulators)
 // ---------------------------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(BW_NT) void sdpa_bwd_dkv_kernel(const T* __restrict__ q, const T* __restrict__ dof,
+__global__ __launch_bounds__(BW_NT, sizeof(T) == 2 ? 2 : 1) void sdpa_bwd_dkv_kernel(const T* __restrict__ q, const T* __restrict__ dof,
                                                              const T* __restrict__ qt, const T* __restrict__ dot,
                                                              const T* __restrict__ k, const T* __restrict__ vrow,
                                                              const float* __restrict__ lse,
