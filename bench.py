@@ -114,6 +114,16 @@ def build(device, rng_mode="fast", train=False, ranks=None):
     return train_step
 
 
+def sdpa_traffic():
+    """HBM bytes per as_sdpa_fwd call at this shape from the PMC passes kept under profiles/ (FETCH_SIZE + WRITE_SIZE,
+    separate rocprofv3 --pmc runs, gfx950 correction applied there); None if the summary is absent."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_sdpa_traffic.json")) as f:
+            return float(json.load(f)["per_as_sdpa_fwd_call_bytes"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline():
     """The CPU oracle (a port of the reference's PyTorch path) on this box's host cores, bounded sample:
     ONE image; 2 of the 12 ViT-B blocks at N=4197 incl. the dense head-mean attention the reference keeps
@@ -267,7 +277,7 @@ def main():
                        "global_batch": world * B, "parallelism": f"dp{world} (image sharding, no data-path collective)"},
             "roofline": {"kernel": "sdpa_fwd_glds_kernel (bf16)", "bound": "mfma", "achieved": round(ach, 2),
                          "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
-                         "traffic": None, "launches_timed": n_sdpa, "ms_per_launch": round(ms_sdpa, 4),
+                         "traffic": sdpa_traffic(), "launches_timed": n_sdpa, "ms_per_launch": round(ms_sdpa, 4),
                          "flops_per_launch": flops_sdpa},
             "roofline_affinity": {"kernel": "as_cosine_shift (sim/stats/assign/finalize x S + final sim)", "bound": "hbm",
                                   "achieved": round(gbps, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
