@@ -152,6 +152,8 @@ def rank_select(mask_flat, ranks):
     """k-th set pixel of each row of a [G, H*W] 0/1 mask, in raster order (= the order of .nonzero()):
     ranks [G,K] long (0-based) -> flat indices [G,K].  No host sync and no compaction pass (ops.rank_select)."""
     m = mask_flat if mask_flat.dtype == torch.uint8 else mask_flat.to(torch.uint8)
+    if m.shape[1] % 16:                                    # the kernel reads 16-byte groups: zero-pad the tail
+        m = F.pad(m, (0, 16 - m.shape[1] % 16))
     return ops.rank_select(m.contiguous(), ranks)
 
 
@@ -170,6 +172,28 @@ def sample_point_grid(maps, num_points, thr, is_pos, gt_points=None):
         ranks.append((torch.randint(n, (n_draw,), generator=_gen()) % n)[:num_points])
     flat = rank_select(mask.flatten(1), torch.stack(ranks).to(maps.device))
     return torch.stack((flat % W, flat // W), dim=-1)          # (x, y) = coords.flip(-1)
+
+
+def sample_point_grid_multi(specs, num_points):
+    """Several sample_point_grid calls with ONE host sync: specs = [(maps, thr, is_pos, gt_points), ...].  The draws
+    are made spec by spec, object by object -- the same stream order as consecutive sample_point_grid calls."""
+    masks = [((m >= thr) if pos else (m < thr)) for (m, thr, pos, _) in specs]
+    counts = torch.cat([mk.flatten(1).sum(1) for mk in masks]).tolist()
+    out, off = [], 0
+    for (maps, thr, pos, gtp), mask in zip(specs, masks):
+        G, H, W = maps.shape
+        cs = counts[off:off + G]
+        off += G
+        if min(cs) < num_points:
+            out.append(_sample_point_grid_slow(maps, num_points, thr, pos, gtp))
+            continue
+        ranks = []
+        for n in cs:
+            n_draw = len(range(0, n, n // num_points))
+            ranks.append((torch.randint(n, (n_draw,), generator=_gen()) % n)[:num_points])
+        flat = rank_select(mask.flatten(1), torch.stack(ranks).to(maps.device))
+        out.append(torch.stack((flat % W, flat // W), dim=-1))
+    return out
 
 
 def _sample_point_grid_slow(maps, num_points, thr, is_pos, gt_points=None):
@@ -266,18 +290,24 @@ def mask_sample_points(map_fg, map_bg, rois, pos_thr, neg_thr, num_gt, corr_size
 
 def grid_seed_coords(maps, rois, thr=0.35, n_points=20):
     """stdroi:1784-1810: (y,x) patch coords of n_points grid-strided positives per object."""
-    out = []
-    for g, m in enumerate(maps):
-        pos = (m >= thr).nonzero()
-        n = pos.shape[0]
+    G, hp, wp = maps.shape
+    mask = maps >= thr
+    counts = mask.flatten(1).sum(1).tolist()                 # the one host sync (was one .nonzero() per object)
+    ranks = []
+    for n in counts:                                         # which of the n positives (raster order) are taken
         if n >= n_points:
-            c = pos[torch.arange(0, n, step=n // n_points, device=pos.device)[:n_points]]
+            r = torch.arange(0, n, step=n // n_points)[:n_points]
         elif n > 0:
-            c = _fill_in(pos, n_points)
+            r = _fill_in(torch.arange(n), n_points)
         else:
-            c = ((rois[g][:2] + rois[g][2:]) // (2 * STRIDE)).long().view(1, 2).flip(1).repeat(n_points, 1)
-        out.append(c)
-    return torch.stack(out)
+            r = torch.zeros(n_points, dtype=torch.long)      # placeholder, replaced by the box centre below
+        ranks.append(r)
+    flat = rank_select(mask.flatten(1), torch.stack(ranks).to(maps.device))
+    coords = torch.stack((flat // wp, flat % wp), dim=-1)    # (y, x), as .nonzero() rows
+    for g, n in enumerate(counts):
+        if n == 0:
+            coords[g] = ((rois[g][:2] + rois[g][2:]) // (2 * STRIDE)).long().view(1, 2).flip(1).repeat(n_points, 1)
+    return coords
 
 
 def _unit(x):
@@ -465,9 +495,8 @@ class AttnShiftRoIHead(nn.Module):
         else:                                                   # norm_attns (:329-333) with known extrema
             lo, hi = minmax[:, 0][:, None, None], minmax[:, 1][:, None, None]
             nm = (attn_sel - lo) / (hi - lo)
-        pts_bg = sample_point_grid(nm, 20, 0.1, False)
-        pts_fg = sample_point_grid(nm, 20, 0.2, True, gt_points)
-        pts_supp = sample_point_grid(nm.mean(0, keepdim=True), 20, 0.1, False)
+        pts_bg, pts_fg, pts_supp = sample_point_grid_multi(
+            [(nm, 0.1, False, None), (nm, 0.2, True, gt_points), (nm.mean(0, keepdim=True), 0.1, False, None)], 20)
         pts_fg = torch.cat((pts_fg, pts_supp), dim=0)
         CLOCK.mark("  sampling")
         feat_tok = feat_chw.flatten(1).t().contiguous()

@@ -168,6 +168,7 @@ def test_semantic_center_host_logic_with_oracle_backed_shift(golden, tag, monkey
 
     monkeypatch.setattr(RH.ops, "cosine_shift", fake_cosine_shift)
     monkeypatch.setattr(RH.ops, "crop_threshold_erode", fake_crop_threshold_erode)
+    monkeypatch.setattr(RH.ops, "rank_select", fake_rank_select)
     head = A.AttnShiftRoIHead(num_semantic_points=int(g["num_semantic_points"]), mean_shift_times_local=int(g["n_shift"]))
     res = head.get_semantic_centers(t(g["map_fg_last"]), t(g["map_bg_last"]), t(g["rois"]), inp["vit_feat"],
                                     pos_thr=float(g["pos_thr"]), refine_times=int(g["n_shift"]), gt_labels=inp["labels"],
