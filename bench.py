@@ -182,7 +182,10 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--train-steps", type=int, default=5, help="steps of the extra DDP training leg (0 = skip)")
+    ap.add_argument("--train-steps", type=int, default=5, help="steps of the extra training-step leg (0 = skip)")
+    ap.add_argument("--train-multi", action="store_true",
+                    help="also run the training leg when N > 1 (RCCL gradient all-reduce); off by default so that an "
+                         "untested-fabric problem in the extra leg can never take the headline scaling run down")
     a = ap.parse_args()
 
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -232,7 +235,7 @@ def main():
 
     # extra leg: the DDP training step (forward + attention shift + backward + gradient all-reduce + AdamW)
     train_rec = None
-    if a.train_steps > 0:
+    if a.train_steps > 0 and (world == 1 or a.train_multi):
         del step
         torch.cuda.empty_cache()
         tstep = build(device, rng_mode, train=True, ranks=ranks)

@@ -86,7 +86,7 @@ def _attn_inputs(B, N, h, seed, scale=1.0):
     return x, wqkv, bqkv, wproj, bproj
 
 
-@pytest.mark.parametrize("B,N,h", [(2, 297, 3), (1, 64, 1), (1, 1000, 2), (1, 4197, 2)])
+@pytest.mark.parametrize("B,N,h", [(2, 297, 3), (1, 64, 1), (1, 1000, 2), (1, 4197, 2), (1, 6501, 1)])
 def test_attention_f32_matches_oracle(ops, B, N, h):
     """fp32 MFMA path vs Attention.forward restated in the oracle; tolerance 1e-4 of the range
     (north_star asks 1e-3)."""
@@ -158,6 +158,21 @@ def test_sdpa_bf16_deferred_max_and_spikes(ops, monkeypatch, tail, N):
     assert mx < 2e-2 and mean < 3e-3, (mx, mean)
     assert_close(torch.logsumexp(s_, dim=-1), lse, 1e-4, 1e-3, "lse (bf16 path)")
     assert torch.isfinite(o.float()).all()
+
+
+def test_attention_bf16_vit_large_token_count(ops):
+    """BASELINE config 4 token count (ViT-L at 1280^2: N = 1 + 80*80 + 100 = 6501, 51 q-tiles, ragged last key tile)
+    through the bf16 path, 4 of its 16 heads' worth of width, vs the oracle's Attention.forward."""
+    B, N, h = 1, 6501, 4
+    x, wqkv, bqkv, wproj, bproj = _attn_inputs(B, N, h, 17, scale=2.0)
+    xd, wq, wp = x.bfloat16(), wqkv.bfloat16(), wproj.bfloat16()
+    ref, p = O.attention(xd.float(), wq.float(), bqkv, wp.float(), bproj, h)
+    out, st = ops.attention_fwd(dev(xd), dev(wq), dev(bqkv), dev(wp), dev(bproj), h)
+    mx, mean = rel_to_range(ref, out.float())
+    assert mx < 3e-2 and mean < 3e-3, (mx, mean)
+    rows = ops.attn_mean_rows(st, N - 100, 100)
+    mx, _ = rel_to_range(p.mean(1)[:, N - 100:], rows)
+    assert mx < 3e-2, mx
 
 
 @pytest.mark.parametrize("B,N,h", [(1, 297, 3), (2, 200, 2), (1, 1000, 2), (1, 64, 1)])
