@@ -284,20 +284,24 @@ class VisionTransformerDet(nn.Module):
         pt = (self.point_token + self.point_pos_embed).expand(B, -1, -1)
         return torch.cat((x, pt), dim=1)
 
-    def _block(self, blk, x, keep_state):
-        """models/vision_transformer.py:109-124 with the residual stream kept in fp32."""
+    def _block(self, blk, x, delta, keep_state, need_x):
+        """models/vision_transformer.py:109-124 with the residual stream kept in fp32 and every residual add fused into
+        the LayerNorm that follows it (ops.add_layernorm).  `delta` is the previous block's MLP output that has not
+        been added to `x` yet (None for the first block); returns (x, pending MLP output, attention state); with
+        `need_x` the block's own MLP output is added before returning (feature taps, last block)."""
         cd = self.compute_dtype
-        D = x.shape[-1]
-        y = F.layer_norm(x, (D,), blk.norm1.weight, blk.norm1.bias, blk.norm1.eps).to(cd)
-        a, st = ops.attention_fwd(y.contiguous(), self._w(blk.attn.qkv.weight),
+        x, y = ops.add_layernorm(x, delta, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps, cd)
+        a, st = ops.attention_fwd(y, self._w(blk.attn.qkv.weight),
                                   None if blk.attn.qkv.bias is None else blk.attn.qkv.bias.float(),
                                   self._w(blk.attn.proj.weight), blk.attn.proj.bias.float(), self.num_heads,
                                   keep_state=keep_state)
-        x = x + a.float()
-        z = F.layer_norm(x, (D,), blk.norm2.weight, blk.norm2.bias, blk.norm2.eps).to(cd)
-        z = ops.linear(z.contiguous(), self._w(blk.mlp.fc1.weight), blk.mlp.fc1.bias.float(), act="gelu")
+        x, z = ops.add_layernorm(x, a, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps, cd)
+        z = ops.linear(z, self._w(blk.mlp.fc1.weight), blk.mlp.fc1.bias.float(), act="gelu")
         z = ops.linear(z, self._w(blk.mlp.fc2.weight), blk.mlp.fc2.bias.float())
-        return x + z.float(), st
+        if need_x:
+            x, _ = ops.add_layernorm(x, z, None, None, 0.0, cd, want_y=False)
+            z = None
+        return x, z, st
 
     # ---- trainable path (autograd): HIP attention forward + backward, library GEMMs for the MLP -------------------
     def _grad_path(self):
@@ -351,13 +355,17 @@ class VisionTransformerDet(nn.Module):
         if self.recompute_last_feat:
             last_feat = x
         features, taps, attns = [], [], []
+        delta = None                                       # inference path: MLP output not yet added to x
+        if not grad_path:
+            x = x.contiguous()
         for i, blk in enumerate(self.blocks):
             if grad_path:
                 sink = [] if self.return_attention else None
                 x = self._block_train(blk, x, i, sink)
                 st = sink[0] if sink else None
             else:
-                x, st = self._block(blk, x, self.return_attention)
+                need_x = i in self.out_indices or i == len(self.blocks) - 1
+                x, delta, st = self._block(blk, x, delta, self.return_attention, need_x)
             if self.return_attention:
                 attns.append(st)
             if i in self.out_indices:

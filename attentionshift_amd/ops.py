@@ -104,6 +104,26 @@ def linear(x, weight, bias=None, act="none"):
     return out.reshape(*x.shape[:-1], weight.shape[0])
 
 
+def add_layernorm(x, delta, gamma, beta, eps, out_dtype, want_x=True, want_y=True):
+    """x_new = x + delta (fp32; delta may be None), y = LayerNorm(x_new) in `out_dtype` -- one pass (csrc/layernorm.hip).
+    Returns (x_new | None, y | None)."""
+    lib = _lib.load()
+    D = x.shape[-1]
+    x2 = x.reshape(-1, D)
+    _chk(x2, dtype=torch.float32)
+    _chk(delta)
+    _chk(gamma, beta, dtype=torch.float32)       # (None is allowed when only the add is wanted)
+    if delta is not None and delta.dtype != out_dtype:
+        raise AttnShiftError("add_layernorm: delta must have the output dtype")
+    x_out = torch.empty_like(x2) if (want_x and delta is not None) else None
+    y = torch.empty(x2.shape, device=x.device, dtype=out_dtype) if want_y else None
+    dt = AS_BF16 if out_dtype == torch.bfloat16 else AS_F32
+    _lib.check(lib.as_add_layernorm(_p(x2), _p(delta), _p(gamma), _p(beta), float(eps), _p(x_out), _p(y), x2.shape[0], D,
+                                    dt, _stream()), "as_add_layernorm")
+    xo = x if (delta is None or not want_x) else x_out.reshape(x.shape)
+    return (xo if want_x else None), (None if y is None else y.reshape(x.shape))
+
+
 class AttnLayerState:
     """What a layer must keep so its attention rows can be recomputed (q, k, lse)."""
 

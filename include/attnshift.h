@@ -113,6 +113,12 @@ int as_attn_bwd(const void* x, const void* Wqkv, const void* Wproj, const void* 
 int as_window_attn_fwd(const void* qkv, const float* bqkv, const float* table, void* out, float* attn_out, int B, int H,
                        int W, int C, int h, int ws, int shift, int dtype, as_stream_t stream);
 
+/* Fused residual add + LayerNorm of the pre-LN block (vision_transformer.py:109-124: x = x + sublayer(norm(x))):
+ *   x_out = x_in + delta (fp32 residual stream; delta [M,D] in `dtype`, or NULL),  y_out = LN(x_out)*gamma + beta (`dtype`)
+ * x_out may alias x_in; either output may be NULL (x_out NULL: LN only; y_out NULL: add only).  D % 4 == 0, D <= 1536. */
+int as_add_layernorm(const float* x_in, const void* delta, const float* gamma, const float* beta, float eps,
+                     float* x_out, void* y_out, int M, int D, int dtype, as_stream_t stream);
+
 /* Head-mean attention rows, recomputed from q,k,lse (visual_transformer_det.py:236,242 keeps
  * attn.mean(1) of every layer; only row slices are ever consumed, stdroi:2272):
  *   out[b,i,:] = (1/h) sum_h softmax_row(row0 + i)          out : [B,nrows,N] fp32 */

@@ -160,6 +160,29 @@ def test_sdpa_bf16_deferred_max_and_spikes(ops, monkeypatch, tail, N):
     assert torch.isfinite(o.float()).all()
 
 
+@pytest.mark.parametrize("M,D", [(297, 192), (1000, 768), (77, 1024), (5, 128)])
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-6), (torch.bfloat16, 1e-2)])
+def test_add_layernorm_matches_torch(ops, dtype, tol, M, D):
+    """Fused residual add + LayerNorm (Block.forward's `x = x + f(norm(x))` chain, vision_transformer.py:109-124) vs
+    torch: x_new exact in fp32 (one add), y within rounding of F.layer_norm on the same x_new."""
+    g = torch.Generator().manual_seed(M + D)
+    x = torch.randn(2, M, D, generator=g) * 3 + 0.5
+    delta = (torch.randn(2, M, D, generator=g)).to(dtype)
+    gamma, beta = torch.randn(D, generator=g) * 0.2 + 1.0, torch.randn(D, generator=g) * 0.1
+    x_ref = x + delta.float()
+    y_ref = torch.nn.functional.layer_norm(x_ref, (D,), gamma, beta, 1e-6)
+    x_new, y = ops.add_layernorm(dev(x), dev(delta), dev(gamma), dev(beta), 1e-6, dtype)
+    assert_equal(x_ref, x_new, "x + delta")
+    mx, _ = rel_to_range(y_ref, y.float())
+    assert mx < tol, mx
+    _, y0 = ops.add_layernorm(dev(x), None, dev(gamma), dev(beta), 1e-6, dtype)          # LN only
+    mx, _ = rel_to_range(torch.nn.functional.layer_norm(x, (D,), gamma, beta, 1e-6), y0.float())
+    assert mx < tol, mx
+    x_only, none = ops.add_layernorm(dev(x), dev(delta), None, None, 0.0, dtype, want_y=False)   # add only
+    assert none is None
+    assert_equal(x_ref, x_only, "add only")
+
+
 def test_attention_bf16_vit_large_token_count(ops):
     """BASELINE config 4 token count (ViT-L at 1280^2: N = 1 + 80*80 + 100 = 6501, 51 q-tiles, ragged last key tile)
     through the bf16 path, 4 of its 16 heads' worth of width, vs the oracle's Attention.forward."""
