@@ -232,6 +232,39 @@ def test_sdpa_bwd_matches_autograd(ops, dtype, tol, B, N, h):
         assert mx < tol, (name, mx, mean)
 
 
+def test_sdpa_bwd_full_size_properties(ops):
+    """BASELINE config 2 shape (B=2, h=12, N=4197, bf16), where an fp64 autograd reference is too big to run in seconds:
+    size-independent properties of the backward.
+      * determinism: two runs are bitwise equal (no atomics, fixed summation order);
+      * linearity in dO: scaling dO by 2 (exact in bf16) scales dq, dk, dv by exactly 2;
+      * dO = 1: dV[key, d] = sum_q P[q, key], so summing dV over keys gives N per (image, head, d) (rows of P sum to 1);
+      * <q, dq> = <k, dk> per (image, head) (both are scale * sum_ij dS_ij S_ij)."""
+    B, N, h = 2, 4197, 12
+    g = torch.Generator().manual_seed(9)
+    x, wqkv, bqkv, _, _ = _attn_inputs(B, N, h, 123, scale=2.0)
+    q, k, vt = ops.qkv_fwd(dev(x.bfloat16()), dev(wqkv.bfloat16()), dev(bqkv), h)
+    o, lse = ops.sdpa_fwd(q, k, vt, N)
+    d_o = dev(torch.randn(B, N, 64 * h, generator=g).bfloat16())
+    g1 = ops.sdpa_bwd(q, k, vt, o, d_o, lse, N)
+    g2 = ops.sdpa_bwd(q, k, vt, o, d_o, lse, N)
+    assert torch.equal(g1, g2)
+    assert torch.isfinite(g1.float()).all()
+    g3 = ops.sdpa_bwd(q, k, vt, o, d_o * 2, lse, N)
+    assert torch.equal(g3.float(), g1.float() * 2)
+    ones = torch.ones_like(d_o)
+    gi = ops.sdpa_bwd(q, k, vt, o, ones, lse, N).float().reshape(B, N, 3, h, 64)
+    colsum = gi[:, :, 2].sum(dim=1)                                   # [B, h, 64]
+    assert (colsum - N).abs().max().item() < 0.02 * N, (colsum.min().item(), colsum.max().item())
+    # <q, dq> = <k, dk> per (image, head): both equal scale * sum_ij dS_ij S_ij (random dO run)
+    gq = g1.float().reshape(B, N, 3, h, 64)
+    qr = ops.q_from_fragment_major(q)[:, :, :N].float()               # [B, h, N, 64]
+    kr = k[:, :, :N].float()
+    lhs = (qr * gq[:, :, 0].permute(0, 2, 1, 3)).sum(dim=(2, 3))
+    rhs = (kr * gq[:, :, 1].permute(0, 2, 1, 3)).sum(dim=(2, 3))
+    scale = torch.maximum(lhs.abs(), rhs.abs()).max().item() + 1e-6
+    assert ((lhs - rhs).abs().max().item() / scale) < 3e-2, (lhs, rhs)
+
+
 @pytest.mark.parametrize("B,N,h", [(2, 297, 3), (1, 130, 2)])
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-4), (torch.bfloat16, 4e-2)])
 def test_attention_module_bwd_matches_autograd(ops, dtype, tol, B, N, h):
