@@ -460,6 +460,7 @@ class AttnShiftRoIHead(nn.Module):
         assert rng_mode in ("reference", "fast")
         self.rng_mode = rng_mode          # "reference": the reference's exact torch RNG stream; "fast": O(k) draws
         self.parallel_images = parallel_images    # one host thread + HIP stream per image (only with rng_mode "fast")
+        self.batch_mean_shift = True              # one as_cosine_shift call for all images of a batch
         self._pool, self._streams = None, []
         self.visualize = visualize
         self.epoch, self.epoch_semantic_centers = epoch, epoch_semantic_centers
@@ -538,6 +539,28 @@ class AttnShiftRoIHead(nn.Module):
         pout, sim = ops.cosine_shift(feat_tok[None], box_patch, obj_img, prot, n_shift, hp, wp, tau, temp)
         return pout.flatten(0, 1), sim.reshape(-1, hp, wp).clamp(0)
 
+    def mean_shift_batch(self, coords_list, feats_list, rois_list, n_shift, tau=0.1, temp=0.1):
+        """mean_shift_grid_prototype for every image of the batch in ONE as_cosine_shift call (coords_list[i] =
+        grid_seed_coords of image i; the objects carry their
+        image index; the kernels are batched over objects, and a call's latency does not depend on how many objects it
+        holds).  Returns per-image (prototypes [G_i*P,C], sim [G_i*P,hp,wp] clamped at 0) exactly as the per-image
+        method does (batched == per-image bitwise, tests/test_gpu_kernels.py)."""
+        C, hp, wp = feats_list[0].shape
+        prots, boxes, owners = [], [], []
+        for i, (coords, feat, rois) in enumerate(zip(coords_list, feats_list, rois_list)):
+            prots.append(feat.permute(1, 2, 0)[coords[..., 0], coords[..., 1]])
+            boxes.append((rois // STRIDE).to(torch.int32))
+            owners.append(torch.full((coords.shape[0],), i, dtype=torch.int32, device=feat.device))
+        feat_tok = torch.stack([f.flatten(1).t() for f in feats_list]).contiguous()
+        pout, sim = ops.cosine_shift(feat_tok, torch.cat(boxes).contiguous(), torch.cat(owners), torch.cat(prots).contiguous(),
+                                     n_shift, hp, wp, tau, temp)
+        out, off = [], 0
+        for coords in coords_list:
+            g = coords.shape[0]
+            out.append((pout[off:off + g].flatten(0, 1), sim[off:off + g].reshape(-1, hp, wp).clamp(0)))
+            off += g
+        return out
+
     def get_semantic_centers(self, map_cos_fg, map_cos_bg, rois, vit_feat, pos_thr=0.35, refine_times=5, gt_labels=None,
                              merge_thr=0.85, num_semantic_points=3):
         """stdroi:1995-2031 (same nine outputs)."""
@@ -545,6 +568,13 @@ class AttnShiftRoIHead(nn.Module):
         G, H, W = map_cos_fg.shape
         # :2011-2013.  erode_11(map > thr) at full resolution, then the bilinear /16 down-sampling, which for an
         # exact factor of 16 reads only the 2x2 centre pixels of each patch with weights 1/2 (bit-identical)
+        fg_inter, map_fg = self._semantic_pre(map_cos_fg, map_cos_bg, pos_thr)
+        prot, sim = self.mean_shift_grid_prototype(map_fg, vit_feat, rois, tau=0.1, temp=0.1, n_shift=refine_times)
+        CLOCK.mark("  sc:mean_shift")
+        return self._semantic_post(prot, sim, fg_inter, rois, vit_feat, gt_labels, merge_thr, num_semantic_points)
+
+    def _semantic_pre(self, map_cos_fg, map_cos_bg, pos_thr):
+        """First part of get_semantic_centers (stdroi:2011-2020): the patch-grid foreground maps."""
         core, _ = ops.crop_threshold_erode(map_cos_fg.contiguous(), None, pos_thr, False, 11)
         CLOCK.mark("  sc:erode")
         fg_inter = _down16(core.float())
@@ -552,8 +582,11 @@ class AttnShiftRoIHead(nn.Module):
                            presampled=True)[None]
         map_fg = (fg_inter > pos_thr).to(fg_inter.dtype)
         CLOCK.mark("  sc:down16")
-        prot, sim = self.mean_shift_grid_prototype(map_fg, vit_feat, rois, tau=0.1, temp=0.1, n_shift=refine_times)
-        CLOCK.mark("  sc:mean_shift")
+        return fg_inter, map_fg
+
+    def _semantic_post(self, prot, sim, fg_inter, rois, vit_feat, gt_labels, merge_thr, num_semantic_points):
+        """Last part of get_semantic_centers (stdroi:2022-2031): filter / merge the shifted prototypes, part centres."""
+        G = fg_inter.shape[0]
         P = sim.shape[0] // G
         keep = filter_parts(sim.unflatten(0, (G, P)), fg_inter)
         merged = merge_parts(prot.unflatten(0, (G, P)), keep, merge_thr)
@@ -663,25 +696,50 @@ class AttnShiftRoIHead(nn.Module):
                    inst_bg_feat=[])
         coords_sc_org, labels_sc_org, map_cos_bg_ret, sim_fg_ret = [], [], [], []
         CLOCK.mark("select")
-        def image_chain(i):
-            feat = vit_feat[i].float()
-            if not feat.is_contiguous():
-                feat = feat.contiguous()
+        feats = [vit_feat[i].float().contiguous() for i in range(num_imgs)]
+
+        def chain_refine(i):
             (coord_point, labels_point, map_fg, map_bg, _pb, _pf, feats_fg, feats_bg) = \
                 self.get_mask_sample_points_roi_best_attn_feat_refine(
-                    attn_maps_dealed[i], pseudo_boxes[i], gt_box_index[i], vit_feat=feat, pos_thr=pos_mask_thr,
+                    attn_maps_dealed[i], pseudo_boxes[i], gt_box_index[i], vit_feat=feats[i], pos_thr=pos_mask_thr,
                     neg_thr=neg_mask_thr, num_gt=num_mask_point_gt, corr_size=corr_size, obj_tau=obj_tau,
                     gt_points=gt_points[i], minmax=attn_minmax[i])
             CLOCK.mark("refine+mask_points")
-            sc = self.get_semantic_centers(map_fg[-1], map_bg[-1], pseudo_boxes[i], feat, pos_thr=pos_mask_thr,
-                                           refine_times=self.mean_shift_times_local, gt_labels=gt_labels[i],
-                                           num_semantic_points=self.num_semantic_points)
-            CLOCK.mark("semantic_centers")
+            return coord_point, labels_point, map_fg, map_bg, feats_fg, feats_bg
+
+        def chain_masks(i, map_fg):
             # stdroi:2356-2358: (map > rowmax * thr) as uint8 on the host
             mask_u8, _ = ops.crop_threshold_erode(map_fg[-1].contiguous(), None, pos_mask_thr, True, 1)
             mask_np = _to_host_numpy(mask_u8)
             CLOCK.mark("pseudo_masks")
-            return coord_point, labels_point, map_fg, map_bg, feats_fg, feats_bg, sc, mask_np
+            return mask_np
+
+        if num_imgs > 1 and self.batch_mean_shift:
+            # three phases: per-image refinement (threads) -> ONE mean-shift call for all images -> per-image tail
+            def phase_a(i):
+                r = chain_refine(i)
+                fg_inter, map_fg_patch = self._semantic_pre(r[2][-1], r[3][-1], pos_mask_thr)
+                return r + ((fg_inter, grid_seed_coords(map_fg_patch, pseudo_boxes[i], 0.35, 20)),)
+
+            ra = self._run_images(phase_a, num_imgs)
+            shifted = self.mean_shift_batch([r[6][1] for r in ra], feats, pseudo_boxes, self.mean_shift_times_local)
+            CLOCK.mark("semantic_centers")
+
+            def phase_b(i):
+                prot, sim = shifted[i]
+                sc = self._semantic_post(prot, sim, ra[i][6][0], pseudo_boxes[i], feats[i], gt_labels[i], 0.85,
+                                         self.num_semantic_points)
+                return ra[i][:6] + (sc, chain_masks(i, ra[i][2]))
+
+            image_chain = phase_b
+        else:
+            def image_chain(i):
+                r = chain_refine(i)
+                sc = self.get_semantic_centers(r[2][-1], r[3][-1], pseudo_boxes[i], feats[i], pos_thr=pos_mask_thr,
+                                               refine_times=self.mean_shift_times_local, gt_labels=gt_labels[i],
+                                               num_semantic_points=self.num_semantic_points)
+                CLOCK.mark("semantic_centers")
+                return r + (sc, chain_masks(i, r[2]))
 
         for res in self._run_images(image_chain, num_imgs):
             coord_point, labels_point, map_fg, map_bg, feats_fg, feats_bg, sc, mask_np = res

@@ -267,7 +267,8 @@ def main():
         ach = flops_sdpa / (ms_sdpa * 1e-3) / 1e12
         n_cs, ms_cs = timing.get("cosine_shift", (0, float("nan")))
         Np, C, S, G, P = (CFG["img"] // CFG["patch"]) ** 2, CFG["embed_dim"], CFG["n_shift"], CFG["objects"], 20
-        bytes_cs = (2 * S + 1) * 1 * Np * C * 4 + 1 * G * P * Np * 4    # per call = one image
+        imgs_per_call = max(1, round(B * a.steps / max(n_cs, 1)))         # the head batches a step's images into one call
+        bytes_cs = imgs_per_call * ((2 * S + 1) * Np * C * 4 + G * P * Np * 4)   # SURVEY 8d, per call
         gbps = bytes_cs / (ms_cs * 1e-3) / 1e9
         rec = {
             "metric": "images/sec (1024^2, ViT-B) hot path: backbone attention fwd + attention-shift pseudo-labels",
@@ -284,7 +285,7 @@ def main():
                          "flops_per_launch": flops_sdpa},
             "roofline_affinity": {"kernel": "as_cosine_shift (sim/stats/assign/finalize x S + final sim)", "bound": "hbm",
                                   "achieved": round(gbps, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
-                                  "frac": round(gbps / PEAK_HBM_GBPS, 4), "traffic": None, "calls_timed": n_cs,
+                                  "frac": round(gbps / PEAK_HBM_GBPS, 4), "traffic": None, "calls_timed": n_cs, "images_per_call": imgs_per_call,
                                   "ms_per_call": round(ms_cs, 4), "algorithmic_bytes_per_call": bytes_cs},
         }
         if train_rec is not None:

@@ -141,3 +141,46 @@ def test_backbone_train_step_grads_match_oracle_autograd(golden, dtype, tol):
         assert params[n].grad is not None, n
         r = rel(sd[n].grad.float(), params[n].grad.float())
         assert r < tol, (n, r)
+
+
+def test_seed_pseudo_gt_two_images_equals_per_image(golden, monkeypatch):
+    """A batch of two images (the second = the first) through the batched path (per-image threads off so that both use
+    the global RNG stream deterministically; ONE mean-shift call for both images) must reproduce, for image 0, what the
+    single-image call gives -- integer outputs bitwise, maps to fp32 rounding."""
+    import attentionshift_amd as A
+    g = golden("shift_tiny224")
+    inp = shift_case_inputs(g)
+    hp, wp, G, Lc = int(g["hp"]), int(g["wp"]), int(g["G"]), int(g["Lc"])
+    T, N = 10, 1 + hp * wp + 10
+
+    def run(nimg):
+        head = A.build_head(dict(type="AttnShiftRoIHead", num_semantic_points=int(g["num_semantic_points"]),
+                                 mean_shift_times_local=int(g["n_shift"]),
+                                 bbox_head=dict(type="MAEBoxHeadRec", seed_thr=float(g["cam_thr"]),
+                                                seed_multiple=float(g["area_ratio"]), cam_layer=Lc, num_classes=20)))
+        rows = torch.zeros(nimg, Lc, T, N)
+        rows[:, :, :G, 1:-T] = inp["cams"].flatten(2)
+        monkeypatch.setattr(head, "rollout_cams", lambda attns, n: rows.cuda())
+        best = t(g["best_idx"]).cuda()
+        head.layer_selector = lambda boxes, labels, fmap: [best] * nimg
+        torch.manual_seed(int(g["seed"]) + 1)
+        return head.seed_pseudo_gt(None, [dict(img_shape=(hp * 16, wp * 16, 3))] * nimg, None, None, None,
+                                   vit_feat=inp["vit_feat"][None].repeat(nimg, 1, 1, 1).cuda(),
+                                   point_cls=torch.zeros(nimg, T, 20).cuda(), point_reg=torch.zeros(nimg, T, 2).cuda(),
+                                   attns=None, gt_points=[inp["points"].cuda()] * nimg,
+                                   gt_points_labels=[inp["labels"].cuda()] * nimg, return_mask=True,
+                                   pos_mask_thr=float(g["pos_thr"]), neg_mask_thr=float(g["neg_thr"]),
+                                   num_mask_point_gt=int(g["num_gt"]), corr_size=int(g["corr_size"]),
+                                   obj_tau=float(g["obj_tau"]),
+                                   pos_inds=[torch.arange(G).cuda()] * nimg, matched_gt=[torch.arange(G).cuda()] * nimg)
+
+    one, two = run(1), run(2)
+    assert_equal(one["pseudo_gt_bboxes"][0], two["pseudo_gt_bboxes"][0], "boxes")
+    assert_equal(one["mask_points_coords"][0], two["mask_points_coords"][0], "mask points (same RNG prefix)")
+    assert (one["pseudo_gt_masks"][0] == two["pseudo_gt_masks"][0]).all()
+    assert one["num_parts"][0] == two["num_parts"][0]
+    assert_equal(one["semantic_centers_org"][0][0], two["semantic_centers_org"][0][0], "part centres")
+    assert_close(one["map_cos_fg"][0], two["map_cos_fg"][0], 1e-6, 1e-6, "instance maps")
+    # image 1 is the same scene with its own random seed points: same boxes, same number of objects
+    assert_equal(two["pseudo_gt_bboxes"][0], two["pseudo_gt_bboxes"][1], "boxes of the duplicated image")
+    assert two["pseudo_gt_masks"][1].shape == two["pseudo_gt_masks"][0].shape
