@@ -345,7 +345,9 @@ extern "C" int as_cam_boxes(const float* cams, const float* points, float cam_th
   RowMeta* rows = (RowMeta*)(w + 2 * al256(total * 4) + al256((size_t)M * sizeof(CamMeta)));
   const int bx = (int)((hw + CC_NT * 16 - 1) / (CC_NT * 16));
   hipLaunchKernelGGL(cam_meta_init_kernel, dim3(as_ceil_div(M, 64)), dim3(64), 0, s, meta, M);
-  hipLaunchKernelGGL(cam_minmax_kernel, dim3(bx, M), dim3(CC_NT), 0, s, cams, meta, cams_up, area, Hp, Wp, up);
+  // two atomics per workgroup on meta[m]: grid-stride over at most 32 workgroups per map (same-address atomics
+  // serialise at ~10 ns each; 256 workgroups x 42 maps made this pass atomic-bound)
+  hipLaunchKernelGGL(cam_minmax_kernel, dim3(bx < 32 ? bx : 32, M), dim3(CC_NT), 0, s, cams, meta, cams_up, area, Hp, Wp, up);
   FgCam fg{cams, meta, cam_thr, Hp, Wp};
   hipLaunchKernelGGL((ccl_rowscan_kernel<FgCam>), dim3(H, M), dim3(CC_NT), 0, s, fg, L, H, W);
   hipLaunchKernelGGL(ccl_merge_kernel, dim3(blocks_for(total)), dim3(CC_NT), 0, s, L, M, H, W);

@@ -102,10 +102,13 @@ extern "C" int as_instance_maps(const float* sim_fg, const float* sim_bg, int L,
   const int n = L * G;
   const size_t hw = (size_t)Hp * up * Wp * up;
   const int bx = (int)((hw + RF_NT * 4 - 1) / (RF_NT * 4));
+  // the reduction passes end in ONE atomic per workgroup on a per-map word: same-address atomics serialise at ~10 ns,
+  // so 1024 workgroups per map made those passes atomic-bound (160 / 92 us); grid-stride over fewer, fatter workgroups
+  const int bxr = bx < 96 ? bx : 96;
   hipLaunchKernelGGL(meta_init_kernel, dim3(as_ceil_div(n, 64)), dim3(64), 0, s, meta, n);
-  hipLaunchKernelGGL((instance_maps_kernel<1>), dim3(bx, n), dim3(RF_NT), 0, s, sim_fg, sim_bg, meta, map_fg, map_bg, G,
+  hipLaunchKernelGGL((instance_maps_kernel<1>), dim3(bxr, n), dim3(RF_NT), 0, s, sim_fg, sim_bg, meta, map_fg, map_bg, G,
                      Gp, Hp, Wp, up);
-  hipLaunchKernelGGL((instance_maps_kernel<2>), dim3(bx, n), dim3(RF_NT), 0, s, sim_fg, sim_bg, meta, map_fg, map_bg, G,
+  hipLaunchKernelGGL((instance_maps_kernel<2>), dim3(bxr, n), dim3(RF_NT), 0, s, sim_fg, sim_bg, meta, map_fg, map_bg, G,
                      Gp, Hp, Wp, up);
   hipLaunchKernelGGL((instance_maps_kernel<3>), dim3(bx, n), dim3(RF_NT), 0, s, sim_fg, sim_bg, meta, map_fg, map_bg, G,
                      Gp, Hp, Wp, up);
@@ -218,7 +221,8 @@ extern "C" int as_crop_threshold_erode(const float* maps, const int32_t* crops, 
   const int bx = (int)(((size_t)H * W + RF_NT * 4 - 1) / (RF_NT * 4));
   const int r = k / 2;
   hipLaunchKernelGGL(crop_meta_init_kernel, dim3(as_ceil_div(M, 64)), dim3(64), 0, s, mx, counts, M);
-  if (relative) hipLaunchKernelGGL(crop_max_kernel, dim3(bx, M), dim3(RF_NT), 0, s, maps, crops, mx, H, W);
+  // one atomicMax per workgroup on mx[m]: keep the workgroup count per map small (same-address atomics serialise)
+  if (relative) hipLaunchKernelGGL(crop_max_kernel, dim3(bx < 64 ? bx : 64, M), dim3(RF_NT), 0, s, maps, crops, mx, H, W);
   if (k == 1) {
     hipLaunchKernelGGL((crop_mask_kernel<0, true>), dim3(bx, M), dim3(RF_NT), 0, s, maps, (const uint8_t*)nullptr, crops,
                        mx, thr, relative, 0, mask, counts, H, W);
@@ -270,6 +274,26 @@ __global__ __launch_bounds__(RF_NT) void rank_counts_kernel(const uint8_t* __res
     __syncthreads();
   }
   if (tid == 0) cc[(size_t)m * nchunk + c] = sh[0];
+}
+
+// number of set bytes of each row of a [M, HW] 0/1 byte mask (torch's bool -> int64 row sum takes 70-220 us here)
+__global__ __launch_bounds__(RF_NT) void mask_count_kernel(const uint8_t* __restrict__ mask, int32_t* __restrict__ counts,
+                                                           int HW) {
+  __shared__ int sh[RF_NT];
+  const int m = blockIdx.y, tid = threadIdx.x;
+  const uint8_t* row = mask + (size_t)m * HW;
+  int v = 0;
+  const int n16 = HW / 16;
+  for (int i = blockIdx.x * RF_NT + tid; i < n16; i += gridDim.x * RF_NT) v += bytesum16(row + (size_t)i * 16);
+  if (blockIdx.x == 0)
+    for (int i = n16 * 16 + tid; i < HW; i += RF_NT) v += row[i] != 0;
+  sh[tid] = v;
+  __syncthreads();
+  for (int o = RF_NT / 2; o > 0; o >>= 1) {
+    if (tid < o) sh[tid] += sh[tid + o];
+    __syncthreads();
+  }
+  if (tid == 0 && sh[0] != 0) atomicAdd(&counts[m], sh[0]);
 }
 
 __device__ __forceinline__ int wave_excl_scan(int v, int lane) {
@@ -347,5 +371,17 @@ extern "C" int as_rank_select(const uint8_t* mask, const int32_t* ranks, int32_t
   hipLaunchKernelGGL(rank_counts_kernel, dim3(nchunk, M), dim3(RF_NT), 0, s, mask, cc, HW, nchunk);
   hipLaunchKernelGGL(rank_select_kernel, dim3(K, M), dim3(64), 0, s, mask, cc, ranks, out, HW, nchunk, K);
   AS_CHECK_LAUNCH("rank_select");
+  return AS_OK;
+}
+
+extern "C" int as_mask_count(const uint8_t* mask, int32_t* counts, int M, int HW, as_stream_t stream) {
+  AS_REQUIRE(mask && counts, AS_E_BADARG, "as_mask_count: null pointer");
+  AS_REQUIRE(M > 0 && HW > 0 && ((size_t)mask % 16) == 0 && (HW % 16 == 0 || M == 1), AS_E_BADARG,
+             "as_mask_count: rows must be 16-byte aligned (HW %% 16 == 0)");
+  hipStream_t s = (hipStream_t)stream;
+  (void)hipMemsetAsync(counts, 0, (size_t)M * sizeof(int32_t), s);
+  const int bx = as_ceil_div(HW / 16 + 1, RF_NT);
+  hipLaunchKernelGGL(mask_count_kernel, dim3(bx < 32 ? bx : 32, M), dim3(RF_NT), 0, s, mask, counts, HW);
+  AS_CHECK_LAUNCH("mask_count");
   return AS_OK;
 }

@@ -407,6 +407,17 @@ def crop_threshold_erode(maps, crops, thr, relative, k):
     return mask, counts
 
 
+def mask_count(mask):
+    """mask bool/uint8 [M,HW] (HW % 16 == 0) -> int32 [M] number of set elements per row."""
+    lib = _lib.load()
+    m = mask.view(torch.uint8) if mask.dtype == torch.bool else mask
+    _chk(m, dtype=torch.uint8)
+    M, HW = m.shape
+    out = torch.empty(M, device=m.device, dtype=torch.int32)
+    _lib.check(lib.as_mask_count(_p(m), _p(out), M, HW, _stream()), "as_mask_count")
+    return out
+
+
 def rank_select(mask, ranks):
     """mask uint8 [M,HW] (0/1), ranks int [M,K] -> int64 [M,K] flat index of the ranks[m,k]-th set byte of row m in
     raster order (= mask[m].nonzero()[rank]), -1 if out of range."""

@@ -178,7 +178,10 @@ def sample_point_grid_multi(specs, num_points):
     """Several sample_point_grid calls with ONE host sync: specs = [(maps, thr, is_pos, gt_points), ...].  The draws
     are made spec by spec, object by object -- the same stream order as consecutive sample_point_grid calls."""
     masks = [((m >= thr) if pos else (m < thr)) for (m, thr, pos, _) in specs]
-    counts = torch.cat([mk.flatten(1).sum(1) for mk in masks]).tolist()
+    if all(mk[0].numel() % 16 == 0 for mk in masks):
+        counts = ops.mask_count(torch.cat([mk.flatten(1) for mk in masks])).tolist()      # one launch, one sync
+    else:
+        counts = torch.cat([mk.flatten(1).sum(1) for mk in masks]).tolist()
     out, off = [], 0
     for (maps, thr, pos, gtp), mask in zip(specs, masks):
         G, H, W = maps.shape
@@ -441,7 +444,7 @@ class AttnShiftRoIHead(nn.Module):
                  mask_head=None, shared_head=None, mae_head=None, bbox_rec_head=None, train_cfg=None, test_cfg=None,
                  visualize=False, epoch=0, epoch_semantic_centers=0, num_semantic_points=3, semantic_to_token=False,
                  pca_dim=128, mean_shift_times_local=10, reppoints_head=None, num_reppoints_head=1,
-                 layer_selector=None, rng_mode="reference", parallel_images=True):
+                 layer_selector=None, rng_mode="reference", parallel_images=False):
         super().__init__()
         self.train_cfg = _ns(train_cfg)
         self.test_cfg = _ns(test_cfg)
@@ -459,7 +462,10 @@ class AttnShiftRoIHead(nn.Module):
         self.layer_selector = layer_selector or median_area_selector
         assert rng_mode in ("reference", "fast")
         self.rng_mode = rng_mode          # "reference": the reference's exact torch RNG stream; "fast": O(k) draws
-        self.parallel_images = parallel_images    # one host thread + HIP stream per image (only with rng_mode "fast")
+        # optional: one host thread + HIP stream per image (only with rng_mode "fast").  Off by default: after the host
+        # syncs of a chain were merged the chains are interpreter-bound, and two GIL-sharing threads measure within
+        # +-10 % of the sequential loop depending on the host (tools/phase_times.py)
+        self.parallel_images = parallel_images
         self.batch_mean_shift = True              # one as_cosine_shift call for all images of a batch
         self._pool, self._streams = None, []
         self.visualize = visualize
@@ -628,8 +634,16 @@ class AttnShiftRoIHead(nn.Module):
             finally:
                 _TLS.gen = None
 
-        futs = [self._pool.submit(job, i) for i in range(num_imgs)]
-        res = [f.result() for f in futs]
+        # the chains are short (a few ms) and alternate between Python and blocking device waits: with the interpreter's
+        # default 5 ms switch interval one thread can hold the GIL for a whole chain while the other's device queue runs dry
+        import sys
+        old_iv = sys.getswitchinterval()
+        sys.setswitchinterval(1e-4)
+        try:
+            futs = [self._pool.submit(job, i) for i in range(num_imgs)]
+            res = [f.result() for f in futs]
+        finally:
+            sys.setswitchinterval(old_iv)
         for st in self._streams[:num_imgs]:
             main.wait_stream(st)                                            # results are consumed on the caller's stream
         return res

@@ -206,6 +206,10 @@ int as_crop_threshold_erode(const float* maps /*[M,H,W]*/, const int32_t* crops,
 /* Rank select: out[m][k] = flat index of the ranks[m][k]-th (0-based) set byte of mask[m] in raster order, i.e.
  * `mask[m].nonzero()[ranks[m][k]]` without the compaction (the reference indexes a .nonzero() list with random
  * indices, stdroi:368-369 and :456); -1 when the rank is outside the population.  HW % 16 == 0. */
+/* counts[m] = number of non-zero bytes of row m of a [M,HW] byte mask (the candidate counts of stdroi:346-366 that the
+ * reference gets from .nonzero().shape); HW % 16 == 0. */
+int as_mask_count(const uint8_t* mask, int32_t* counts, int M, int HW, as_stream_t stream);
+
 size_t as_rank_select_workspace_bytes(int M, int HW);
 int as_rank_select(const uint8_t* mask /*[M,HW] 0/1*/, const int32_t* ranks /*[M,K]*/, int32_t* out /*[M,K]*/, void* ws,
                    size_t ws_bytes, int M, int HW, int K, as_stream_t stream);

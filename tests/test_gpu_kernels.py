@@ -550,3 +550,12 @@ def test_swin_block_matches_reference(ops, golden, tag, dtype, tol):
     assert mx < tol, ("block output", mx)
     mx, _ = rel_to_range(t(g["attn"]), attn)
     assert mx < tol, ("attention probabilities", mx)
+
+
+def test_mask_count_matches_torch(ops):
+    g = torch.Generator().manual_seed(4)
+    for (M, HW) in ((3, 1024 * 1024), (7, 4096), (1, 16), (5, 208)):
+        mask = torch.rand(M, HW, generator=g) < 0.3
+        mask[0] = False
+        got = ops.mask_count(dev(mask))
+        assert_equal(mask.sum(1).to(torch.int32), got, f"mask_count {M}x{HW}")

@@ -33,8 +33,8 @@ def main():
         print("backbone only   %.2f ms" % loop(lambda: bb(img)))
         print("roi head only   %.2f ms" % loop(lambda: pl(out)))
         print("full step       %.2f ms" % loop(step))
-        step.head.parallel_images = False
-        print("roi head only (sequential images) %.2f ms" % loop(lambda: pl(out)))
+        step.head.parallel_images = True
+        print("roi head only (one thread + stream per image) %.2f ms" % loop(lambda: pl(out)))
 
 
 if __name__ == "__main__":
