@@ -559,3 +559,26 @@ def test_mask_count_matches_torch(ops):
         mask[0] = False
         got = ops.mask_count(dev(mask))
         assert_equal(mask.sum(1).to(torch.int32), got, f"mask_count {M}x{HW}")
+
+
+@pytest.mark.parametrize("shift", [0, 3])
+def test_swin_block_config5_stage1_full_size(ops, shift):
+    """BASELINE config 5 stage-1 shape (Swin-B at 1024^2: 256x256 tokens, C=128, 4 heads, window 7 -> padded to 259,
+    37x37 windows per image), B=1, fp32 path, against the oracle's SwinTransformerBlock restatement (which the
+    swin_*.npz fixtures pin bit-exactly to the reference)."""
+    from attentionshift_amd.swin import SwinTransformerBlock
+    C, heads, hw = 128, 4, 256
+    g = torch.Generator().manual_seed(50 + shift)
+    blk = SwinTransformerBlock(C, (hw, hw), heads, window_size=7, shift_size=shift, compute_dtype=torch.float32,
+                               return_attention=False)
+    with torch.no_grad():
+        for n, prm in blk.named_parameters():
+            prm.copy_(torch.randn(prm.shape, generator=g) * (0.5 if n.endswith("bias_table") else 0.08)
+                      + (1.0 if n.endswith("norm1.weight") or n.endswith("norm2.weight") else 0.0))
+    x = torch.randn(1, hw * hw, C, generator=g)
+    p = {n: prm.detach() for n, prm in blk.named_parameters()}
+    ref, _ = O.swin_block(x, p, heads, 7, shift)
+    y, attn = blk.cuda().eval()(dev(x))
+    assert attn is None
+    mx, mean = rel_to_range(ref, y)
+    assert mx < 1e-4, (mx, mean)
