@@ -40,6 +40,19 @@ def test_bad_arguments_return_error_codes_without_launching():
     assert lib.as_cam_boxes_workspace_bytes(21, 64, 64, 16) >= 21 * 1024 * 1024 * 8
     with pytest.raises(_lib.AttnShiftError):
         _lib.check(-2, "unit test")
+    # every entry point validates before it launches (no GPU needed to get the error code)
+    assert lib.as_sdpa_fwd(None, None, None, None, None, None, 0, 1, 64, 1, 1, None) == -1
+    assert lib.as_sdpa_bwd(None, None, None, None, None, None, None, None, 0, 1, 64, 1, 1, None) == -1
+    assert lib.as_attn_bwd(*([None] * 15), 0, 1, 64, 64, 1, 1, None) == -1
+    assert lib.as_window_attn_fwd(None, None, None, None, None, 1, 14, 14, 64, 2, 7, 0, 1, None) == -1
+    assert lib.as_add_layernorm(None, None, None, None, 1e-6, None, None, 4, 64, 1, None) == -1
+    assert lib.as_mask_count(None, None, 1, 16, None) == -1
+    assert lib.as_rollout_step(*([None] * 8), 0, 1, 64, 1, 8, 1, None) == -1
+    # workspace size queries are pure host functions
+    assert lib.as_sdpa_bwd_workspace_bytes(2, 4197, 12, 1) == 2 * 12 * 4224 * (5 * 64 * 2 + 4)
+    assert lib.as_attn_bwd_workspace_bytes(2, 4197, 768, 12, 1) > lib.as_sdpa_bwd_workspace_bytes(2, 4197, 12, 1)
+    assert lib.as_rollout_step_workspace_bytes(2, 4197, 100) == 8 * 2 * 100 * 4197 * 4
+    assert lib.as_sdpa_bwd_workspace_bytes(0, 4197, 12, 1) == 0
 
 
 def test_product_path_refuses_cpu_tensors():
