@@ -73,6 +73,21 @@ def _gen():
     return getattr(_TLS, "gen", None)
 
 
+def _to_host_issue(t):
+    """Start the device -> pinned-host copy of `t` on the current stream; returns (pinned tensor, event)."""
+    host = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+    host.copy_(t, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream())
+    return host, ev
+
+
+def _to_host_finish(pending):
+    host, ev = pending
+    ev.synchronize()
+    return host.numpy()
+
+
 def _to_host_numpy(t):
     """Device tensor -> numpy through a PINNED staging tensor (torch's caching host allocator recycles it): a 3 MB
     pseudo-mask stack goes over PCIe at DMA speed instead of the ~2 GB/s of a pageable `.cpu()` (1.7 ms -> ~0.1 ms).
@@ -259,11 +274,22 @@ def mask_sample_points(map_fg, map_bg, rois, pos_thr, neg_thr, num_gt, corr_size
     One host sync (candidate counts); `torch.randperm(n)` per object from the global CPU generator in object
     order like the reference; the drawn ranks index the concatenation [fg candidates, bg candidates] in raster
     order inside the crop, resolved on the device by rank_select."""
-    G, H, W = map_fg.shape
-    dev = map_fg.device
+    return mask_points_finish(mask_points_issue(map_fg, map_bg, rois, pos_thr, neg_thr, corr_size), num_gt, rng_mode)
+
+
+def mask_points_issue(map_fg, map_bg, rois, pos_thr, neg_thr, corr_size):
+    """Device half of mask_sample_points: candidate masks and their counts are queued, nothing is read back."""
     crops = rois.int().contiguous()                      # stdroi:1981: rois[i].int().tolist()
     pos, neg, cp, cn = candidate_masks(map_fg.contiguous(), map_bg.contiguous(), crops, pos_thr, neg_thr, corr_size)
-    counts = torch.stack((cp, cn), dim=1).tolist()
+    return dict(pos=pos, neg=neg, cp=cp, crops=crops, counts=torch.stack((cp, cn), dim=1), shape=tuple(map_fg.shape))
+
+
+def mask_points_finish(pend, num_gt, rng_mode="reference"):
+    """Host half of mask_sample_points: ONE sync (the counts), the draws, and the rank lookups."""
+    pos, neg, cp, crops = pend["pos"], pend["neg"], pend["cp"], pend["crops"]
+    G, H, W = pend["shape"]
+    dev = pos.device
+    counts = pend["counts"].tolist()
     ranks, empty = [], []
     for g in range(G):
         n = counts[g][0] + counts[g][1]
@@ -293,9 +319,17 @@ def mask_sample_points(map_fg, map_bg, rois, pos_thr, neg_thr, num_gt, corr_size
 
 def grid_seed_coords(maps, rois, thr=0.35, n_points=20):
     """stdroi:1784-1810: (y,x) patch coords of n_points grid-strided positives per object."""
-    G, hp, wp = maps.shape
+    return grid_seed_finish(*grid_seed_issue(maps, thr), rois, n_points)
+
+
+def grid_seed_issue(maps, thr=0.35):
     mask = maps >= thr
-    counts = mask.flatten(1).sum(1).tolist()                 # the one host sync (was one .nonzero() per object)
+    return mask, mask.flatten(1).sum(1)
+
+
+def grid_seed_finish(mask, count_dev, rois, n_points=20):
+    G, hp, wp = mask.shape
+    counts = count_dev.tolist()                              # the one host sync (was one .nonzero() per object)
     ranks = []
     for n in counts:                                         # which of the n positives (raster order) are taken
         if n >= n_points:
@@ -305,7 +339,7 @@ def grid_seed_coords(maps, rois, thr=0.35, n_points=20):
         else:
             r = torch.zeros(n_points, dtype=torch.long)      # placeholder, replaced by the box centre below
         ranks.append(r)
-    flat = rank_select(mask.flatten(1), torch.stack(ranks).to(maps.device))
+    flat = rank_select(mask.flatten(1), torch.stack(ranks).to(mask.device))
     coords = torch.stack((flat // wp, flat % wp), dim=-1)    # (y, x), as .nonzero() rows
     for g, n in enumerate(counts):
         if n == 0:
@@ -712,48 +746,53 @@ class AttnShiftRoIHead(nn.Module):
         CLOCK.mark("select")
         feats = [vit_feat[i].float().contiguous() for i in range(num_imgs)]
 
-        def chain_refine(i):
-            (coord_point, labels_point, map_fg, map_bg, _pb, _pf, feats_fg, feats_bg) = \
-                self.get_mask_sample_points_roi_best_attn_feat_refine(
-                    attn_maps_dealed[i], pseudo_boxes[i], gt_box_index[i], vit_feat=feats[i], pos_thr=pos_mask_thr,
-                    neg_thr=neg_mask_thr, num_gt=num_mask_point_gt, corr_size=corr_size, obj_tau=obj_tau,
-                    gt_points=gt_points[i], minmax=attn_minmax[i])
+        def phase_a(i):
+            """Refinement (B2), then EVERYTHING that depends only on the refined maps is queued on the device -- the
+            candidate masks of the mask points (B2'), the patch-grid foreground maps and seed counts (B3), the pseudo
+            mask and its device->host copy (B6) -- before the first host sync of the chain, so that the device keeps
+            working while the host waits for counts and draws.  (stdroi:1966-1993, 2011-2020, 2356-2358.)"""
+            G_i = attn_maps_dealed[i].shape[1]
+            ar = torch.arange(G_i, device=attn_maps_dealed[i].device)
+            attn_sel = attn_maps_dealed[i][gt_box_index[i], ar].contiguous()
+            mm = attn_minmax[i][gt_box_index[i], ar]
+            map_fg, map_bg, _pa, _pb, feats_fg, feats_bg = self.refine_maps(attn_sel, feats[i], pseudo_boxes[i],
+                                                                            gt_points[i], 2, obj_tau, mm)
+            mp = mask_points_issue(map_fg[-1], map_bg[-1], pseudo_boxes[i], pos_mask_thr, neg_mask_thr, corr_size)
+            fg_inter, map_fg_patch = self._semantic_pre(map_fg[-1], map_bg[-1], pos_mask_thr)
+            gs = grid_seed_issue(map_fg_patch, 0.35)
+            mask_u8, _ = ops.crop_threshold_erode(map_fg[-1].contiguous(), None, pos_mask_thr, True, 1)   # stdroi:2356
+            pm = _to_host_issue(mask_u8)
+            return mp, gs, map_fg, map_bg, feats_fg, feats_bg, fg_inter, pm
+
+        def phase_a_finish(i, r):
+            mp, gs, map_fg, map_bg, feats_fg, feats_bg, fg_inter, pm = r
+            coord_point, labels_point = mask_points_finish(mp, num_mask_point_gt, self.rng_mode)
             CLOCK.mark("refine+mask_points")
-            return coord_point, labels_point, map_fg, map_bg, feats_fg, feats_bg
+            seeds = grid_seed_finish(gs[0], gs[1], pseudo_boxes[i], 20)
+            return coord_point, labels_point, map_fg, map_bg, feats_fg, feats_bg, (fg_inter, seeds), pm
 
-        def chain_masks(i, map_fg):
-            # stdroi:2356-2358: (map > rowmax * thr) as uint8 on the host
-            mask_u8, _ = ops.crop_threshold_erode(map_fg[-1].contiguous(), None, pos_mask_thr, True, 1)
-            mask_np = _to_host_numpy(mask_u8)
-            CLOCK.mark("pseudo_masks")
-            return mask_np
-
-        if num_imgs > 1 and self.batch_mean_shift:
-            # three phases: per-image refinement (threads) -> ONE mean-shift call for all images -> per-image tail
-            def phase_a(i):
-                r = chain_refine(i)
-                fg_inter, map_fg_patch = self._semantic_pre(r[2][-1], r[3][-1], pos_mask_thr)
-                return r + ((fg_inter, grid_seed_coords(map_fg_patch, pseudo_boxes[i], 0.35, 20)),)
-
-            ra = self._run_images(phase_a, num_imgs)
-            shifted = self.mean_shift_batch([r[6][1] for r in ra], feats, pseudo_boxes, self.mean_shift_times_local)
-            CLOCK.mark("semantic_centers")
-
-            def phase_b(i):
-                prot, sim = shifted[i]
-                sc = self._semantic_post(prot, sim, ra[i][6][0], pseudo_boxes[i], feats[i], gt_labels[i], 0.85,
-                                         self.num_semantic_points)
-                return ra[i][:6] + (sc, chain_masks(i, ra[i][2]))
-
-            image_chain = phase_b
+        if self.rng_mode == "fast" and num_imgs > 1 and not self.parallel_images:
+            # queue every image's device work first, then read the counts back: image i+1's refinement runs on the
+            # device while the host draws and resolves image i's points (the draw ORDER across images changes, which
+            # only the literal reference stream forbids)
+            issued = [phase_a(i) for i in range(num_imgs)]
+            ra = [phase_a_finish(i, issued[i]) for i in range(num_imgs)]
         else:
-            def image_chain(i):
-                r = chain_refine(i)
-                sc = self.get_semantic_centers(r[2][-1], r[3][-1], pseudo_boxes[i], feats[i], pos_thr=pos_mask_thr,
-                                               refine_times=self.mean_shift_times_local, gt_labels=gt_labels[i],
-                                               num_semantic_points=self.num_semantic_points)
-                CLOCK.mark("semantic_centers")
-                return r + (sc, chain_masks(i, r[2]))
+            ra = self._run_images(lambda i: phase_a_finish(i, phase_a(i)), num_imgs)
+        if self.batch_mean_shift or num_imgs == 1:           # ONE mean-shift call for the whole batch
+            shifted = self.mean_shift_batch([r[6][1] for r in ra], feats, pseudo_boxes, self.mean_shift_times_local)
+        else:
+            shifted = [self.mean_shift_batch([ra[i][6][1]], [feats[i]], [pseudo_boxes[i]], self.mean_shift_times_local)[0]
+                       for i in range(num_imgs)]
+        CLOCK.mark("semantic_centers")
+
+        def image_chain(i):
+            prot, sim = shifted[i]
+            sc = self._semantic_post(prot, sim, ra[i][6][0], pseudo_boxes[i], feats[i], gt_labels[i], 0.85,
+                                     self.num_semantic_points)
+            mask_np = _to_host_finish(ra[i][7])
+            CLOCK.mark("pseudo_masks")
+            return ra[i][:6] + (sc, mask_np)
 
         for res in self._run_images(image_chain, num_imgs):
             coord_point, labels_point, map_fg, map_bg, feats_fg, feats_bg, sc, mask_np = res
