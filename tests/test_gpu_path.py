@@ -184,3 +184,48 @@ def test_seed_pseudo_gt_two_images_equals_per_image(golden, monkeypatch):
     # image 1 is the same scene with its own random seed points: same boxes, same number of objects
     assert_equal(two["pseudo_gt_bboxes"][0], two["pseudo_gt_bboxes"][1], "boxes of the duplicated image")
     assert two["pseudo_gt_masks"][1].shape == two["pseudo_gt_masks"][0].shape
+
+
+def test_seed_pseudo_gt_ragged_batch(golden, monkeypatch):
+    """Ragged batch: image 0 carries all 3 objects of the fixture scene, image 1 only the first 2.  Image 0 of the batch
+    must equal the single-image run bitwise (same RNG prefix); image 1 must have 2 objects everywhere and the boxes /
+    CAM-derived quantities of those 2 objects (no randomness involved) must equal image 0's first two."""
+    import attentionshift_amd as A
+    g = golden("shift_tiny224")
+    inp = shift_case_inputs(g)
+    hp, wp, G, Lc = int(g["hp"]), int(g["wp"]), int(g["G"]), int(g["Lc"])
+    T, N = 10, 1 + hp * wp + 10
+    counts = [G, G - 1]
+
+    def run(ns):
+        nimg = len(ns)
+        head = A.build_head(dict(type="AttnShiftRoIHead", num_semantic_points=int(g["num_semantic_points"]),
+                                 mean_shift_times_local=int(g["n_shift"]),
+                                 bbox_head=dict(type="MAEBoxHeadRec", seed_thr=float(g["cam_thr"]),
+                                                seed_multiple=float(g["area_ratio"]), cam_layer=Lc, num_classes=20)))
+        rows = torch.zeros(nimg, Lc, T, N)
+        rows[:, :, :G, 1:-T] = inp["cams"].flatten(2)
+        monkeypatch.setattr(head, "rollout_cams", lambda attns, n: rows.cuda())
+        best = t(g["best_idx"]).cuda()
+        head.layer_selector = lambda boxes, labels, fmap: [best[:n] for n in ns]
+        torch.manual_seed(int(g["seed"]) + 1)
+        return head.seed_pseudo_gt(None, [dict(img_shape=(hp * 16, wp * 16, 3))] * nimg, None, None, None,
+                                   vit_feat=inp["vit_feat"][None].repeat(nimg, 1, 1, 1).cuda(),
+                                   point_cls=torch.zeros(nimg, T, 20).cuda(), point_reg=torch.zeros(nimg, T, 2).cuda(),
+                                   attns=None, gt_points=[inp["points"][:n].cuda() for n in ns],
+                                   gt_points_labels=[inp["labels"][:n].cuda() for n in ns], return_mask=True,
+                                   pos_mask_thr=float(g["pos_thr"]), neg_mask_thr=float(g["neg_thr"]),
+                                   num_mask_point_gt=int(g["num_gt"]), corr_size=int(g["corr_size"]),
+                                   obj_tau=float(g["obj_tau"]),
+                                   pos_inds=[torch.arange(n).cuda() for n in ns],
+                                   matched_gt=[torch.arange(n).cuda() for n in ns])
+
+    one, two = run([G]), run(counts)
+    assert_equal(one["pseudo_gt_bboxes"][0], two["pseudo_gt_bboxes"][0], "boxes, image 0")
+    assert_equal(one["mask_points_coords"][0], two["mask_points_coords"][0], "mask points, image 0")
+    assert (one["pseudo_gt_masks"][0] == two["pseudo_gt_masks"][0]).all()
+    assert one["num_parts"][0] == two["num_parts"][0]
+    assert_equal(one["semantic_centers_org"][0][0], two["semantic_centers_org"][0][0], "part centres, image 0")
+    assert two["pseudo_gt_bboxes"][1].shape[0] == G - 1 and two["pseudo_gt_masks"][1].shape[0] == G - 1
+    assert len(two["num_parts"][1]) == G - 1 and two["mask_points_coords"][1].shape[0] == G - 1
+    assert_equal(two["pseudo_gt_bboxes"][0][:G - 1], two["pseudo_gt_bboxes"][1], "boxes of the shared objects")
