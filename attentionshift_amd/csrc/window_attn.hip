@@ -140,3 +140,240 @@ extern "C" int as_window_attn_fwd(const void* qkv, const float* bqkv, const floa
   if (dtype == AS_F32) return launch_window_attn<float>(qkv, bqkv, table, out, attn_out, B, H, W, h, shift, s);
   AS_REQUIRE(false, AS_E_UNSUPPORTED, "as_window_attn_fwd: dtype %d", dtype);
 }
+
+// =====================================================================================================
+// Backward of as_window_attn_fwd.  Same decomposition (one wave per (window, head), fp32 arithmetic): the softmax is
+// recomputed, then
+//   dP_ij = dO_i . V_j        delta_i = sum_j P_ij dP_ij        dS_ij = P_ij (dP_ij - delta_i)
+//   dq_i = scale sum_j dS_ij k_j      dk_j = sum_i dS_ij (scale q_i)      dv_j = sum_i P_ij dO_i
+// Row-wise sums run with lane = i, column-wise sums with lane = j over the P / dS tiles kept in LDS (row stride 49:
+// both access directions are bank-conflict free).  Gradients of REAL tokens are scattered to the original token grid
+// (the qkv Linear's backward takes it from there); PADDED tokens' qkv is the bias itself, so their gradient is a bias
+// gradient: it is summed per workgroup in lane order and reduced over windows by a second launch in window order, as
+// is the gradient of the relative-position-bias table (each of the 169 offsets sums its (i, j) pairs in a fixed
+// order).  No atomics anywhere: bit-reproducible.
+// =====================================================================================================
+namespace {
+
+template <typename T, int WS, int HD>
+__global__ __launch_bounds__(64) void window_attn_bwd_kernel(const T* __restrict__ qkv, const float* __restrict__ bqkv,
+                                                             const float* __restrict__ table, const T* __restrict__ d_out,
+                                                             T* __restrict__ dqkv, float* __restrict__ part_tab,
+                                                             float* __restrict__ part_pad, int B, int H, int W, int h,
+                                                             int shift) {
+  constexpr int N = WS * WS, TB = (2 * WS - 1) * (2 * WS - 1);
+  __shared__ __attribute__((aligned(16))) float Ks[N][HD];
+  __shared__ __attribute__((aligned(16))) float Vs[N][HD];
+  __shared__ __attribute__((aligned(16))) float Qs[N][HD];       // scale * q
+  __shared__ __attribute__((aligned(16))) float Gs[N][HD];       // dO
+  __shared__ float Ps[64 * N];                                   // P, row i at i*N
+  __shared__ float Ds[64 * N];                                   // dS
+  __shared__ float tab[TB];
+  __shared__ int rid[64];
+  __shared__ int isreal[64];
+  const int C = h * HD;
+  const int nWh = as_ceil_div_dev(H, WS), nWw = as_ceil_div_dev(W, WS);
+  const int Hp = nWh * WS, Wp = nWw * WS;
+  const int win = blockIdx.x, head = blockIdx.y;
+  const int b = win / (nWh * nWw), wi = (win / nWw) % nWh, wj = win % nWw;
+  const int lane = threadIdx.x;
+  const int li = min(lane, N - 1);
+  const int a = li / WS, c_ = li % WS;
+  const int hs = wi * WS + a, ws_ = wj * WS + c_;
+  const int ho = (hs + shift) % Hp, wo = (ws_ + shift) % Wp;
+  const bool real = ho < H && wo < W;
+  const size_t tokidx = ((size_t)b * H + (real ? ho : 0)) * W + (real ? wo : 0);
+  const T* tok = qkv + tokidx * (size_t)(3 * C) + head * HD;
+  const T* gtok = d_out + tokidx * (size_t)C + head * HD;
+  const float scale = rsqrtf((float)HD);
+
+  float q[HD], g[HD];
+#pragma unroll
+  for (int c = 0; c < HD; ++c) {
+    const float bq = bqkv ? bqkv[head * HD + c] : 0.0f, bk = bqkv ? bqkv[C + head * HD + c] : 0.0f,
+                bv = bqkv ? bqkv[2 * C + head * HD + c] : 0.0f;
+    q[c] = ((real ? to_f32<T>(tok[c]) : 0.0f) + bq) * scale;
+    g[c] = real ? to_f32<T>(gtok[c]) : 0.0f;                      // padded rows produce no output
+    if (lane < N) {
+      Ks[li][c] = (real ? to_f32<T>(tok[C + c]) : 0.0f) + bk;
+      Vs[li][c] = (real ? to_f32<T>(tok[2 * C + c]) : 0.0f) + bv;
+      Qs[li][c] = q[c];
+      Gs[li][c] = g[c];
+    }
+  }
+  for (int t = lane; t < TB; t += 64) tab[t] = table[(size_t)t * h + head];
+  {
+    const int rh = hs < Hp - WS ? 0 : (hs < Hp - shift ? 1 : 2), rw = ws_ < Wp - WS ? 0 : (ws_ < Wp - shift ? 1 : 2);
+    rid[lane] = shift > 0 ? 3 * rh + rw : 0;
+    isreal[lane] = (lane < N && real) ? 1 : 0;
+  }
+  __syncthreads();
+
+  // ---- forward recompute: P row of this lane ----
+  float* prow = &Ps[lane * N];
+  float* drow = &Ds[lane * N];
+  const int myrid = rid[li];
+  float m = -INFINITY;
+  for (int j = 0, aj = 0, cj = 0; j < N; ++j) {
+    float acc = 0.0f;
+#pragma unroll
+    for (int c = 0; c < HD; c += 4) {
+      const float4 kv = *reinterpret_cast<const float4*>(&Ks[j][c]);
+      acc = fmaf(q[c], kv.x, acc); acc = fmaf(q[c + 1], kv.y, acc); acc = fmaf(q[c + 2], kv.z, acc);
+      acc = fmaf(q[c + 3], kv.w, acc);
+    }
+    acc += tab[(a - aj + WS - 1) * (2 * WS - 1) + (c_ - cj + WS - 1)];
+    if (shift > 0 && rid[j] != myrid) acc += -100.0f;
+    prow[j] = acc;
+    m = fmaxf(m, acc);
+    if (++cj == WS) { cj = 0; ++aj; }
+  }
+  float sum = 0.0f;
+  for (int j = 0; j < N; ++j) {
+    const float e = expf(prow[j] - m);
+    prow[j] = e;
+    sum += e;
+  }
+  const float inv = 1.0f / sum;
+  // ---- dP, delta, dS (row-wise) ----
+  float delta = 0.0f;
+  for (int j = 0; j < N; ++j) {
+    const float p = prow[j] * inv;
+    prow[j] = p;
+    float dp = 0.0f;
+#pragma unroll
+    for (int c = 0; c < HD; c += 4) {
+      const float4 vv = *reinterpret_cast<const float4*>(&Vs[j][c]);
+      dp = fmaf(g[c], vv.x, dp); dp = fmaf(g[c + 1], vv.y, dp); dp = fmaf(g[c + 2], vv.z, dp);
+      dp = fmaf(g[c + 3], vv.w, dp);
+    }
+    drow[j] = dp;
+    delta = fmaf(p, dp, delta);
+  }
+  float dq[HD];
+#pragma unroll
+  for (int c = 0; c < HD; ++c) dq[c] = 0.0f;
+  for (int j = 0; j < N; ++j) {
+    const float ds = prow[j] * (drow[j] - delta);
+    drow[j] = ds;
+#pragma unroll
+    for (int c = 0; c < HD; c += 4) {
+      const float4 kv = *reinterpret_cast<const float4*>(&Ks[j][c]);
+      dq[c] = fmaf(ds, kv.x, dq[c]); dq[c + 1] = fmaf(ds, kv.y, dq[c + 1]); dq[c + 2] = fmaf(ds, kv.z, dq[c + 2]);
+      dq[c + 3] = fmaf(ds, kv.w, dq[c + 3]);
+    }
+  }
+  if (lane >= N) {                                               // rows 49..63 do not exist
+    for (int j = 0; j < N; ++j) { prow[j] = 0.0f; drow[j] = 0.0f; }
+  }
+  __syncthreads();
+  // ---- column-wise: this lane is key j = li ----
+  float dk[HD], dv[HD];
+#pragma unroll
+  for (int c = 0; c < HD; ++c) { dk[c] = 0.0f; dv[c] = 0.0f; }
+  for (int i = 0; i < N; ++i) {
+    const float p = Ps[i * N + li], ds = Ds[i * N + li];
+#pragma unroll
+    for (int c = 0; c < HD; c += 4) {
+      const float4 gv = *reinterpret_cast<const float4*>(&Gs[i][c]);
+      const float4 qv = *reinterpret_cast<const float4*>(&Qs[i][c]);
+      dv[c] = fmaf(p, gv.x, dv[c]); dv[c + 1] = fmaf(p, gv.y, dv[c + 1]); dv[c + 2] = fmaf(p, gv.z, dv[c + 2]);
+      dv[c + 3] = fmaf(p, gv.w, dv[c + 3]);
+      dk[c] = fmaf(ds, qv.x, dk[c]); dk[c + 1] = fmaf(ds, qv.y, dk[c + 1]); dk[c + 2] = fmaf(ds, qv.z, dk[c + 2]);
+      dk[c + 3] = fmaf(ds, qv.w, dk[c + 3]);
+    }
+  }
+  // ---- relative-position-bias table gradient of this (window, head): offset r sums its pairs in (i) order ----
+  for (int r = lane; r < TB; r += 64) {
+    const int da = r / (2 * WS - 1) - (WS - 1), db = r % (2 * WS - 1) - (WS - 1);     // a_i - a_j, b_i - b_j
+    float s = 0.0f;
+    for (int i = 0; i < N; ++i) {
+      const int aj = i / WS - da, bj = i % WS - db;
+      if (aj >= 0 && aj < WS && bj >= 0 && bj < WS) s += Ds[i * N + aj * WS + bj];
+    }
+    part_tab[((size_t)win * h + head) * TB + r] = s;
+  }
+  // ---- scatter real tokens; padded tokens feed the bias gradient ----
+  if (lane < N && real) {
+    T* dst = dqkv + tokidx * (size_t)(3 * C) + head * HD;
+#pragma unroll
+    for (int c = 0; c < HD; ++c) {
+      dst[c] = from_f32<T>(dq[c] * scale);
+      dst[C + c] = from_f32<T>(dk[c]);
+      dst[2 * C + c] = from_f32<T>(dv[c]);
+    }
+  }
+  __syncthreads();                                               // Ks / Vs / Qs are free: stage the padded rows there
+  if (lane < N && !real) {
+#pragma unroll
+    for (int c = 0; c < HD; ++c) { Qs[li][c] = dq[c] * scale; Ks[li][c] = dk[c]; Vs[li][c] = dv[c]; }
+  }
+  __syncthreads();
+  for (int x = lane; x < 3 * HD; x += 64) {
+    const int which = x / HD, c = x % HD;
+    float s = 0.0f;
+    for (int i = 0; i < N; ++i)
+      if (!isreal[i]) s += which == 0 ? Qs[i][c] : (which == 1 ? Ks[i][c] : Vs[i][c]);
+    part_pad[((size_t)win * h + head) * (3 * HD) + x] = s;
+  }
+}
+
+// dtable[r][head] = sum over windows (in window order) of part_tab;  dpad[which*C + head*32 + c] likewise
+__global__ void window_attn_bwd_reduce_kernel(const float* __restrict__ part_tab, const float* __restrict__ part_pad,
+                                              float* __restrict__ dtable, float* __restrict__ dpad, int nwin, int h, int TB,
+                                              int HD3) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int C = h * (HD3 / 3);
+  if (t < TB * h) {
+    const int r = t / h, head = t % h;
+    float s = 0.0f;
+    for (int w = 0; w < nwin; ++w) s += part_tab[((size_t)w * h + head) * TB + r];
+    dtable[t] = s;
+  } else if (t < TB * h + h * HD3) {
+    const int u = t - TB * h, head = u / HD3, x = u % HD3, which = x / (HD3 / 3), c = x % (HD3 / 3);
+    float s = 0.0f;
+    for (int w = 0; w < nwin; ++w) s += part_pad[((size_t)w * h + head) * HD3 + x];
+    dpad[which * C + head * (HD3 / 3) + c] = s;
+  }
+}
+
+}  // namespace
+
+extern "C" size_t as_window_attn_bwd_workspace_bytes(int B, int H, int W, int h, int ws) {
+  if (B <= 0 || H <= 0 || W <= 0 || h <= 0 || ws <= 0) return 0;
+  const size_t nwin = (size_t)B * as_ceil_div(H, ws) * as_ceil_div(W, ws);
+  const size_t TB = (size_t)(2 * ws - 1) * (2 * ws - 1);
+  return nwin * h * (TB + 96) * sizeof(float);
+}
+
+extern "C" int as_window_attn_bwd(const void* qkv, const float* bqkv, const float* table, const void* d_out, void* dqkv,
+                                  float* dtable, float* dbqkv_pad, void* workspace, size_t workspace_bytes, int B, int H,
+                                  int W, int C, int h, int ws, int shift, int dtype, as_stream_t stream) {
+  AS_REQUIRE(qkv && table && d_out && dqkv && dtable && dbqkv_pad && workspace, AS_E_BADARG,
+             "as_window_attn_bwd: null pointer");
+  AS_REQUIRE(B > 0 && H > 0 && W > 0 && h > 0, AS_E_BADARG, "as_window_attn_bwd: bad sizes");
+  AS_REQUIRE(ws == 7 && C == h * 32, AS_E_UNSUPPORTED, "as_window_attn_bwd: window 7 and head dim 32 only (ws=%d C=%d h=%d)",
+             ws, C, h);
+  AS_REQUIRE(shift >= 0 && shift < ws, AS_E_BADARG, "as_window_attn_bwd: need 0 <= shift < ws");
+  AS_REQUIRE(workspace_bytes >= as_window_attn_bwd_workspace_bytes(B, H, W, h, ws), AS_E_WORKSPACE,
+             "as_window_attn_bwd: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  const int nwin = B * as_ceil_div(H, 7) * as_ceil_div(W, 7);
+  float* part_tab = (float*)workspace;
+  float* part_pad = part_tab + (size_t)nwin * h * 169;
+  // padded-grid positions have no row in dqkv: rows of real tokens are all written (every real token is in exactly one window)
+  if (dtype == AS_BF16)
+    hipLaunchKernelGGL((window_attn_bwd_kernel<__bf16, 7, 32>), dim3(nwin, h), dim3(64), 0, s, (const __bf16*)qkv, bqkv, table,
+                       (const __bf16*)d_out, (__bf16*)dqkv, part_tab, part_pad, B, H, W, h, shift);
+  else if (dtype == AS_F32)
+    hipLaunchKernelGGL((window_attn_bwd_kernel<float, 7, 32>), dim3(nwin, h), dim3(64), 0, s, (const float*)qkv, bqkv, table,
+                       (const float*)d_out, (float*)dqkv, part_tab, part_pad, B, H, W, h, shift);
+  else
+    AS_REQUIRE(false, AS_E_UNSUPPORTED, "as_window_attn_bwd: dtype %d", dtype);
+  AS_CHECK_LAUNCH("window_attn_bwd");
+  const int total = 169 * h + h * 96;
+  hipLaunchKernelGGL(window_attn_bwd_reduce_kernel, dim3(as_ceil_div(total, 256)), dim3(256), 0, s, (const float*)part_tab,
+                     (const float*)part_pad, dtable, dbqkv_pad, nwin, h, 169, 96);
+  AS_CHECK_LAUNCH("window_attn_bwd_reduce");
+  return AS_OK;
+}

@@ -262,6 +262,24 @@ def window_attention_fwd(qkv, b_qkv, table, num_heads, ws, shift, return_attn=Fa
     return out, attn
 
 
+def window_attention_bwd(qkv, b_qkv, table, d_out, num_heads, ws, shift):
+    """Backward of window_attention_fwd -> (dqkv [B,H,W,3C], dtable [(2ws-1)^2,h] fp32, dbqkv_pad [3C] fp32)."""
+    lib = _lib.load()
+    B, H, W, C3 = qkv.shape
+    C = C3 // 3
+    _chk(qkv, d_out)
+    _chk(b_qkv, table, dtype=torch.float32)
+    dqkv = torch.zeros_like(qkv)
+    dtable = torch.empty_like(table)
+    dpad = torch.empty(C3, device=qkv.device, dtype=torch.float32)
+    nbytes = lib.as_window_attn_bwd_workspace_bytes(B, H, W, num_heads, int(ws))
+    wsbuf = torch.empty(nbytes, device=qkv.device, dtype=torch.uint8)
+    _lib.check(lib.as_window_attn_bwd(_p(qkv), _p(b_qkv), _p(table), _p(d_out), _p(dqkv), _p(dtable), _p(dpad), _p(wsbuf),
+                                      nbytes, B, H, W, C, num_heads, int(ws), int(shift), _dt(qkv), _stream()),
+               "as_window_attn_bwd")
+    return dqkv, dtable, dpad
+
+
 def attn_mean_rows(state, row0, nrows):
     """Head-mean softmax rows [B,nrows,N] fp32 recomputed from (q,k,lse)."""
     lib = _lib.load()

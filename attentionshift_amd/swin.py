@@ -25,6 +25,30 @@ def relative_position_index(ws):
     return rel.sum(-1)
 
 
+class WindowAttnFn(torch.autograd.Function):
+    """Fused (shifted-)window attention core under autograd: as_window_attn_fwd / as_window_attn_bwd.
+    forward(qkv [B,H,W,3C] (bias-free), b_qkv fp32 [3C] | None, table fp32 [(2ws-1)^2,h], num_heads, ws, shift) -> [B,H,W,C]"""
+
+    @staticmethod
+    def forward(ctx, qkv, b_qkv, table, num_heads, ws, shift):
+        qkv = qkv.contiguous()
+        bq = torch.zeros(qkv.shape[-1], device=qkv.device, dtype=torch.float32) if b_qkv is None else b_qkv.contiguous()
+        table = table.contiguous()
+        out, _ = ops.window_attention_fwd(qkv, bq, table, num_heads, ws, shift, return_attn=False)
+        ctx.save_for_backward(qkv, bq, table)
+        ctx.cfg = (num_heads, ws, shift, b_qkv is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        qkv, bq, table = ctx.saved_tensors
+        num_heads, ws, shift, has_bias = ctx.cfg
+        dqkv, dtable, dpad = ops.window_attention_bwd(qkv, bq, table, d_out.contiguous(), num_heads, ws, shift)
+        # the bias is added inside the kernel: its gradient = column sum over real tokens + the padded tokens' share
+        dbias = (dqkv.float().sum(dim=(0, 1, 2)) + dpad) if has_bias else None
+        return dqkv, dbias, dtable, None, None, None
+
+
 class WindowAttention(nn.Module):
     """Parameter container with the reference's names (models/swin_transformer.py:92-123)."""
 
@@ -67,7 +91,27 @@ class SwinTransformerBlock(nn.Module):
         self.compute_dtype = compute_dtype
         self.return_attention = return_attention
 
+    def _forward_train(self, x):
+        """Autograd path (train() + grad enabled): the window attention core runs on the HIP forward / backward kernels
+        (WindowAttnFn); LayerNorm, the Linear layers and GELU are torch ops (library GEMMs)."""
+        B, L, C = x.shape
+        H = W = int(math.sqrt(L))
+        cd = self.compute_dtype
+        y = F.layer_norm(x, (C,), self.norm1.weight, self.norm1.bias, self.norm1.eps).to(cd)
+        qkv = F.linear(y, self.attn.qkv.weight.to(cd)).reshape(B, H, W, 3 * C)
+        bq = None if self.attn.qkv.bias is None else self.attn.qkv.bias.float()
+        o = WindowAttnFn.apply(qkv, bq, self.attn.relative_position_bias_table.float(), self.num_heads, self.window_size,
+                               self.shift_size)
+        y = F.linear(o.reshape(B, L, C), self.attn.proj.weight.to(cd), self.attn.proj.bias.to(cd))
+        x = x + y.float()
+        z = F.layer_norm(x, (C,), self.norm2.weight, self.norm2.bias, self.norm2.eps).to(cd)
+        z = F.linear(F.gelu(F.linear(z, self.mlp.fc1.weight.to(cd), self.mlp.fc1.bias.to(cd))),
+                     self.mlp.fc2.weight.to(cd), self.mlp.fc2.bias.to(cd))
+        return x + z.float(), None
+
     def forward(self, x):
+        if self.training and torch.is_grad_enabled():
+            return self._forward_train(x)
         B, L, C = x.shape
         H = W = int(math.sqrt(L))
         cd = self.compute_dtype

@@ -119,6 +119,17 @@ int as_window_attn_fwd(const void* qkv, const float* bqkv, const float* table, v
 int as_add_layernorm(const float* x_in, const void* delta, const float* gamma, const float* beta, float eps,
                      float* x_out, void* y_out, int M, int D, int dtype, as_stream_t stream);
 
+/* Backward of as_window_attn_fwd (autograd of WindowAttention's core + the index maps around it):
+ *   d_out     : [B,H,W,C] gradient of the attention output        dqkv : [B,H,W,3C] gradient w.r.t. the bias-free qkv
+ *   dtable    : fp32 [(2*ws-1)^2, h] gradient of relative_position_bias_table
+ *   dbqkv_pad : fp32 [3C] bias gradient contributed by PADDED tokens (whose qkv is the bias itself); the full qkv-bias
+ *               gradient is the column sum of dqkv over real tokens plus this vector
+ * No atomics: window partials are reduced in window order by a second launch. */
+size_t as_window_attn_bwd_workspace_bytes(int B, int H, int W, int h, int ws);
+int as_window_attn_bwd(const void* qkv, const float* bqkv, const float* table, const void* d_out, void* dqkv,
+                       float* dtable, float* dbqkv_pad, void* workspace, size_t workspace_bytes, int B, int H, int W,
+                       int C, int h, int ws, int shift, int dtype, as_stream_t stream);
+
 /* Head-mean attention rows, recomputed from q,k,lse (visual_transformer_det.py:236,242 keeps
  * attn.mean(1) of every layer; only row slices are ever consumed, stdroi:2272):
  *   out[b,i,:] = (1/h) sum_h softmax_row(row0 + i)          out : [B,nrows,N] fp32 */

@@ -582,3 +582,42 @@ def test_swin_block_config5_stage1_full_size(ops, shift):
     assert attn is None
     mx, mean = rel_to_range(ref, y)
     assert mx < 1e-4, (mx, mean)
+
+
+@pytest.mark.parametrize("tag", ["w14_s0", "w14_s3", "w16_s3_pad", "w9_s0_pad"])
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-4), (torch.bfloat16, 6e-2)])
+def test_swin_block_backward_matches_autograd(ops, golden, tag, dtype, tol):
+    """Trainable Swin block: forward + backward through WindowAttnFn (as_window_attn_fwd / as_window_attn_bwd) vs torch
+    autograd (fp64) through the oracle's SwinTransformerBlock restatement: gradients of the input, the qkv weight and
+    BIAS (padded tokens feed the bias), the relative-position-bias table, proj and an MLP weight."""
+    from attentionshift_amd.swin import SwinTransformerBlock
+    g = golden(f"swin_{tag}")
+    hw, ws, heads, C, shift = int(g["hw"]), int(g["ws"]), int(g["heads"]), int(g["C"]), int(g["shift"])
+    blk = SwinTransformerBlock(C, (hw, hw), heads, window_size=ws, shift_size=shift, compute_dtype=dtype)
+    sd = {k[2:]: t(g[k]) for k in g.files if k.startswith("p.")}
+    blk.load_state_dict(sd, strict=False)
+    blk = blk.cuda().train()
+    gen = torch.Generator().manual_seed(1)
+    x = t(g["x"])
+    w = torch.randn(x.shape, generator=gen)
+    names = ["attn.qkv.weight", "attn.qkv.bias", "attn.relative_position_bias_table", "attn.proj.weight", "norm1.weight",
+             "mlp.fc1.weight"]
+    with torch.enable_grad():
+        p64 = {k: v.double() for k, v in sd.items()}
+        for n in names:
+            p64[n].requires_grad_(True)
+        x64 = x.double().requires_grad_(True)
+        y64, _ = O.swin_block(x64, p64, heads, ws, shift)
+        (y64 * w.double()).sum().backward()
+        xg = dev(x).requires_grad_(True)
+        y, _ = blk(xg)
+        (y * dev(w)).sum().backward()
+    mx, _ = rel_to_range(y64.detach().float(), y.detach().float())
+    assert mx < tol, ("forward", mx)
+    mx, _ = rel_to_range(x64.grad.float(), xg.grad.float())
+    assert mx < tol, ("dx", mx)
+    params = dict(blk.named_parameters())
+    for n in names:
+        assert params[n].grad is not None, n
+        mx, mean = rel_to_range(p64[n].grad.float(), params[n].grad.float())
+        assert mx < tol, (n, mx, mean)
