@@ -564,6 +564,7 @@ int sdpa_split_slices(int B, int N, int h) {           // 0 = no split for this 
   if (!tail) return 0;
   const int nkt = as_round_up(N, 64) / SD_KB;
   int ns = as_ceil_div(slots / 3, BH);                 // about one workgroup per CU
+  if (const char* e = getenv("AS_SDPA_SLICES")) ns = atoi(e);      // tuning hook
   ns = ns < 2 ? 2 : (ns > nkt ? nkt : ns);
   const int per = as_ceil_div(nkt, ns);
   return as_ceil_div(nkt, per);                         // no empty slice
@@ -578,19 +579,46 @@ int launch_sdpa_glds(const void* q, const void* k, const void* vt, void* o, floa
   if (ns > 0 && (ws == nullptr || ws_bytes < (size_t)BH * ns * SD_QB * SD_REC * sizeof(float))) ns = 0;
   if (ns > 0) --qtiles;
   const size_t lds = (size_t)GL_NBUF * 2 * GL_TILE;        // 48 KiB
+  // The split q-tile runs CONCURRENTLY with the main grid on a helper stream (fork / join with events on the caller's
+  // stream): its 264 short workgroups fill the slots the main grid's workgroups free up as they retire, instead of
+  // running as a separate 13 us phase afterwards.  Helper stream and events are created once per host thread.
+  struct Side {
+    hipStream_t st = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+    bool ok = false;
+    int dev = -1;
+    void init() {                                        // (re)created when this thread first uses a device
+      int d = -1;
+      if (hipGetDevice(&d) != hipSuccess) { ok = false; return; }
+      if (d == dev) return;
+      dev = d;
+      ok = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess &&
+           hipEventCreateWithFlags(&fork, hipEventDisableTiming) == hipSuccess &&
+           hipEventCreateWithFlags(&join, hipEventDisableTiming) == hipSuccess;
+    }
+  };
+  static thread_local Side side;
+  if (ns > 0) side.init();
+  const bool concurrent = ns > 0 && qtiles > 0 && side.ok && getenv("AS_SDPA_SERIAL") == nullptr;
+  hipStream_t s2 = concurrent ? side.st : s;
+  if (concurrent) {
+    if (hipEventRecord(side.fork, s) != hipSuccess || hipStreamWaitEvent(side.st, side.fork, 0) != hipSuccess) s2 = s;
+  }
+  if (ns > 0) {
+    hipLaunchKernelGGL(sdpa_fwd_glds_kernel<true>, dim3(ns * BH), dim3(SD_NT), lds, s2, (const __bf16*)q, (const __bf16*)k,
+                       (const __bf16*)vt, (__bf16*)o, lse, B, N, Npad, h, qtiles, ns, (float*)ws);
+    AS_CHECK_LAUNCH("sdpa_fwd_glds<split>");
+    hipLaunchKernelGGL(sdpa_combine_kernel, dim3(SD_QB / 16, BH), dim3(256), 0, s2, (const float*)ws, (__bf16*)o, lse, B, N,
+                       h, qtiles, ns);
+    AS_CHECK_LAUNCH("sdpa_combine");
+    if (s2 != s) (void)hipEventRecord(side.join, s2);
+  }
   if (qtiles > 0) {
     hipLaunchKernelGGL(sdpa_fwd_glds_kernel<false>, dim3(qtiles * BH), dim3(SD_NT), lds, s, (const __bf16*)q,
                        (const __bf16*)k, (const __bf16*)vt, (__bf16*)o, lse, B, N, Npad, h, 0, 1, (float*)nullptr);
     AS_CHECK_LAUNCH("sdpa_fwd_glds");
   }
-  if (ns > 0) {
-    hipLaunchKernelGGL(sdpa_fwd_glds_kernel<true>, dim3(ns * BH), dim3(SD_NT), lds, s, (const __bf16*)q, (const __bf16*)k,
-                       (const __bf16*)vt, (__bf16*)o, lse, B, N, Npad, h, qtiles, ns, (float*)ws);
-    AS_CHECK_LAUNCH("sdpa_fwd_glds<split>");
-    hipLaunchKernelGGL(sdpa_combine_kernel, dim3(SD_QB / 16, BH), dim3(256), 0, s, (const float*)ws, (__bf16*)o, lse, B, N,
-                       h, qtiles, ns);
-    AS_CHECK_LAUNCH("sdpa_combine");
-  }
+  if (ns > 0 && s2 != s) (void)hipStreamWaitEvent(s, side.join, 0);     // join: later work on `s` sees the split rows
   return AS_OK;
 }
 
