@@ -539,18 +539,41 @@ __global__ __launch_bounds__(CS_NT) void refine_partial_kernel(const float* __re
     w_s[tid] = w;
   }
   __syncthreads();
+  // surviving patches, in patch order (thread 0 compacts: <= RF_TILE entries), then the weighted sum with 8 feature
+  // rows in flight per trip -- the same order of fma's as a plain loop, without one exposed load latency per patch
+  __shared__ int j_s[RF_TILE];
+  __shared__ int nlive_s;
+  if (tid == 0) {
+    int nl = 0;
+    for (int j = 0; j < count; ++j)
+      if (w_s[j] != 0.0f) j_s[nl++] = j;
+    nlive_s = nl;
+  }
+  __syncthreads();
+  const int nlive = nlive_s;
   float acc[CPT], wsum = 0.0f;
 #pragma unroll
   for (int i = 0; i < CPT; ++i) acc[i] = 0.0f;
-  for (int j = 0; j < count; ++j) {
-    const float w = w_s[j];
-    if (w == 0.0f) continue;                      // workgroup-uniform
-    wsum += w;
-    const float* frow = feat + (size_t)(n0 + j) * C;
+  constexpr int UNR = 8;
+  for (int q0 = 0; q0 < nlive; q0 += UNR) {
+    float f[UNR][CPT];
 #pragma unroll
-    for (int i = 0; i < CPT; ++i) {
-      const int c = tid + i * CS_NT;
-      if (c < C) acc[i] = fmaf(w, frow[c], acc[i]);
+    for (int u = 0; u < UNR; ++u) {
+      const float* frow = feat + (size_t)(n0 + j_s[min(q0 + u, nlive - 1)]) * C;
+#pragma unroll
+      for (int i = 0; i < CPT; ++i) {
+        const int c = tid + i * CS_NT;
+        f[u][i] = c < C ? frow[c] : 0.0f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      if (q0 + u < nlive) {                        // workgroup-uniform
+        const float w = w_s[j_s[q0 + u]];
+        wsum += w;
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) acc[i] = fmaf(w, f[u][i], acc[i]);
+      }
     }
   }
   float* pp = partial + ((size_t)g * ntile + tile) * C;
