@@ -35,8 +35,19 @@ def _p(t):
     return 0 if t is None else t.data_ptr()
 
 
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_DEV = [None]
+
+
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    """raw hipStream_t of torch's current stream on the current device.  torch.cuda.current_stream() builds a Stream
+    object through three Python layers (~10 us, ~70 times per step in a host-bound phase); the raw accessor is ~0.3 us."""
+    if _RAW_STREAM is None:
+        return torch.cuda.current_stream().cuda_stream
+    d = _DEV[0]
+    if d is None:
+        d = _DEV[0] = torch.cuda.current_device()      # one process drives one GPU (one rank per GPU)
+    return _RAW_STREAM(d)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -720,9 +720,10 @@ class AttnShiftRoIHead(nn.Module):
         boxes, status, cams_up, cam_minmax = ops.cam_boxes(cams_lr, pts, self.bbox_head.seed_thr,
                                                            self.bbox_head.seed_multiple, STRIDE, True)
         CLOCK.mark("cam_boxes")
-        if bool((status == 0).any()):
-            # the reference raises here too (torch.stack of an empty list, stdroi:80)
-            raise RuntimeError("seed_pseudo_gt: a CAM has no foreground component (constant attention map)")
+        # the reference raises here when a CAM has no foreground component (torch.stack of an empty list, stdroi:80).
+        # The flag stays on the device and is checked at the first host sync the chain needs anyway (the seed counts):
+        # reading it here would stall the host for the whole roll-out + CAM-box phase with nothing queued behind it.
+        bad_cam = (status == 0).any()
         gt_scale_bboxes, attn_maps_dealed, attn_minmax, off = [], [], [], 0
         for i in range(num_imgs):
             n = Lc * counts[i]
@@ -779,6 +780,8 @@ class AttnShiftRoIHead(nn.Module):
             ra = [phase_a_finish(i, issued[i]) for i in range(num_imgs)]
         else:
             ra = self._run_images(lambda i: phase_a_finish(i, phase_a(i)), num_imgs)
+        if bool(bad_cam):
+            raise RuntimeError("seed_pseudo_gt: a CAM has no foreground component (constant attention map)")
         if self.batch_mean_shift or num_imgs == 1:           # ONE mean-shift call for the whole batch
             shifted = self.mean_shift_batch([r[6][1] for r in ra], feats, pseudo_boxes, self.mean_shift_times_local)
         else:
