@@ -22,14 +22,11 @@ namespace {
 constexpr int SD_NT = 256, SD_QB = 128, SD_KB = 64, HD = 64;
 constexpr int SD_REC = 68;                       // floats per row of a key-split partial record
 
-template <typename T> struct SdpaCfg;
-template <> struct SdpaCfg<__bf16> {
-  static constexpr int K_PITCH = HD * 2 + 16;    // bytes
-  static constexpr int V_PITCH = SD_KB * 2 + 8;  // 136: conflict-free ds_read_b64 down the d rows
-};
-template <> struct SdpaCfg<float> {
-  static constexpr int K_PITCH = HD * 4 + 16;
-  static constexpr int V_PITCH = SD_KB * 4 + 16;
+// LDS row pitches of the generic (register-staged) kernel; only its fp32 instantiation is built -- bf16 always takes
+// the LDS-DMA ring kernel below
+template <typename T> struct SdpaCfg {
+  static constexpr int K_PITCH = HD * (int)sizeof(T) + 16;      // bytes
+  static constexpr int V_PITCH = SD_KB * (int)sizeof(T) + 16;
 };
 
 // V^T fragment for (key block kb, sub-step s): element t <-> key kb*32 + 16 s + 8 (t>>2) + 4 half + (t&3)
