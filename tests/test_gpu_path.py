@@ -229,3 +229,39 @@ def test_seed_pseudo_gt_ragged_batch(golden, monkeypatch):
     assert two["pseudo_gt_bboxes"][1].shape[0] == G - 1 and two["pseudo_gt_masks"][1].shape[0] == G - 1
     assert len(two["num_parts"][1]) == G - 1 and two["mask_points_coords"][1].shape[0] == G - 1
     assert_equal(two["pseudo_gt_bboxes"][0][:G - 1], two["pseudo_gt_bboxes"][1], "boxes of the shared objects")
+
+
+def test_full_size_step_properties():
+    """BASELINE config 2 at full size (ViT-B, 1024^2, 2 images, 3 objects, 7 roll-out layers, 5 shift iterations, bf16):
+    the whole bench step, twice from the same RNG seed.  Size-independent properties: the step is deterministic (every
+    integer output bitwise equal, maps bitwise equal), boxes lie inside the image and contain their GT point, pseudo
+    masks are 0/1 with one mask per object, part counts respect the cap, mask points with a positive label lie inside
+    their object's box."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    step = bench.build(torch.device("cuda", 0), "reference")
+    outs = []
+    for _ in range(2):
+        torch.manual_seed(1234)
+        outs.append(step())
+    a, b = outs
+    G, H = bench.CFG["objects"], bench.CFG["img"]
+    for i in range(bench.CFG["batch"]):
+        assert_equal(a["pseudo_gt_bboxes"][i], b["pseudo_gt_bboxes"][i], "boxes")
+        assert_equal(a["mask_points_coords"][i], b["mask_points_coords"][i], "mask points")
+        assert_equal(a["mask_points_labels"][i], b["mask_points_labels"][i], "mask point labels")
+        assert (a["pseudo_gt_masks"][i] == b["pseudo_gt_masks"][i]).all()
+        assert a["num_parts"][i] == b["num_parts"][i]
+        assert_equal(a["map_cos_fg"][i], b["map_cos_fg"][i], "instance maps")
+        box = a["pseudo_gt_bboxes"][i]
+        assert box.shape == (G, 4)
+        assert (box[:, :2] >= 0).all() and (box[:, 2:] <= H).all() and (box[:, 2] > box[:, 0]).all() and (box[:, 3] > box[:, 1]).all()
+        m = a["pseudo_gt_masks"][i]
+        assert m.shape == (G, H, H) and m.dtype == np.uint8 and set(np.unique(m)) <= {0, 1} and m.reshape(G, -1).any(1).all()
+        assert all(0 <= n <= 6 for n in a["num_parts"][i])          # num_semantic_points (5) + 1
+        pts, lab = a["mask_points_coords"][i], a["mask_points_labels"][i]
+        inside = (pts[..., 0] >= box[:, None, 0]) & (pts[..., 0] <= box[:, None, 2]) & \
+                 (pts[..., 1] >= box[:, None, 1]) & (pts[..., 1] <= box[:, None, 3])
+        assert inside[lab].all()
