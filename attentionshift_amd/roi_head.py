@@ -501,6 +501,7 @@ class AttnShiftRoIHead(nn.Module):
         # +-10 % of the sequential loop depending on the host (tools/phase_times.py)
         self.parallel_images = parallel_images
         self.batch_mean_shift = True              # one as_cosine_shift call for all images of a batch
+        self.image_streams = True                 # one HIP stream per image in the single-threaded fast-RNG path
         self._pool, self._streams = None, []
         self.visualize = visualize
         self.epoch, self.epoch_semantic_centers = epoch, epoch_semantic_centers
@@ -772,10 +773,28 @@ class AttnShiftRoIHead(nn.Module):
             seeds = grid_seed_finish(gs[0], gs[1], pseudo_boxes[i], 20)
             return coord_point, labels_point, map_fg, map_bg, feats_fg, feats_bg, (fg_inter, seeds), pm
 
-        if self.rng_mode == "fast" and num_imgs > 1 and not self.parallel_images:
-            # queue every image's device work first, then read the counts back: image i+1's refinement runs on the
-            # device while the host draws and resolves image i's points (the draw ORDER across images changes, which
-            # only the literal reference stream forbids)
+        multi = (self.rng_mode == "fast" and num_imgs > 1 and not self.parallel_images and self.image_streams
+                 and torch.cuda.is_available() and not CLOCK.on)
+        if multi:
+            # One HIP stream per image, one host thread.  Every image's device work is queued first and only then are
+            # the counts read back: a host sync waits for ITS image's stream only, so image i+1's refinement runs on
+            # the device while the host draws and resolves image i's points (the draw ORDER across images changes,
+            # which only the literal reference stream forbids), and the small kernels of different images overlap.
+            if len(self._streams) < num_imgs:
+                self._streams = [torch.cuda.Stream() for _ in range(num_imgs)]
+            main = torch.cuda.current_stream()
+
+            def on_stream(i, fn, *args):
+                with torch.cuda.stream(self._streams[i]):
+                    return fn(i, *args)
+
+            for st in self._streams[:num_imgs]:
+                st.wait_stream(main)                         # CAM maps / boxes were produced on the caller's stream
+            issued = [on_stream(i, phase_a) for i in range(num_imgs)]
+            ra = [on_stream(i, phase_a_finish, issued[i]) for i in range(num_imgs)]
+            for st in self._streams[:num_imgs]:
+                main.wait_stream(st)                         # the batched mean shift below consumes every image's seeds
+        elif self.rng_mode == "fast" and num_imgs > 1 and not self.parallel_images:
             issued = [phase_a(i) for i in range(num_imgs)]
             ra = [phase_a_finish(i, issued[i]) for i in range(num_imgs)]
         else:
@@ -797,7 +816,15 @@ class AttnShiftRoIHead(nn.Module):
             CLOCK.mark("pseudo_masks")
             return ra[i][:6] + (sc, mask_np)
 
-        for res in self._run_images(image_chain, num_imgs):
+        if multi:
+            for st in self._streams[:num_imgs]:
+                st.wait_stream(main)                         # shifted prototypes come from the caller's stream
+            results = [on_stream(i, image_chain) for i in range(num_imgs)]
+            for st in self._streams[:num_imgs]:
+                main.wait_stream(st)
+        else:
+            results = self._run_images(image_chain, num_imgs)
+        for res in results:
             coord_point, labels_point, map_fg, map_bg, feats_fg, feats_bg, sc, mask_np = res
             (centers, centers_split, sim_fg, feat_split, feat_centers, num_parts_obj, c_org, l_org, corres) = sc
             out["semantic_centers_feat_split"].append(feat_split)
