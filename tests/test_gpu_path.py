@@ -231,7 +231,8 @@ def test_seed_pseudo_gt_ragged_batch(golden, monkeypatch):
     assert_equal(two["pseudo_gt_bboxes"][0][:G - 1], two["pseudo_gt_bboxes"][1], "boxes of the shared objects")
 
 
-def test_full_size_step_properties():
+@pytest.mark.parametrize("rng_mode", ["reference", "fast"])
+def test_full_size_step_properties(rng_mode):
     """BASELINE config 2 at full size (ViT-B, 1024^2, 2 images, 3 objects, 7 roll-out layers, 5 shift iterations, bf16):
     the whole bench step, twice from the same RNG seed.  Size-independent properties: the step is deterministic (every
     integer output bitwise equal, maps bitwise equal), boxes lie inside the image and contain their GT point, pseudo
@@ -241,7 +242,7 @@ def test_full_size_step_properties():
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import bench
-    step = bench.build(torch.device("cuda", 0), "reference")
+    step = bench.build(torch.device("cuda", 0), rng_mode)      # "fast": stage-wise issue on one HIP stream per image
     outs = []
     for _ in range(2):
         torch.manual_seed(1234)
