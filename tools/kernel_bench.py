@@ -72,7 +72,7 @@ def main():
         d_o = torch.randn(B, N, D, generator=g).to(dev).bfloat16()
         ms = timeit(lambda: ops.sdpa_bwd(q, k, vt, o, d_o, lse, N), a.reps)
         emit("sdpa_bwd_bf16(prep+dkv+dq)", ms, 2 * 4.0 * B * h * N * N * 64, peak=PEAK_BF16, note="2x-forward flop convention")
-        out, st = ops.attention_fwd(xb, wqb, bqkv, wpb, bproj, h, keep_o=True)
+        _y, st = ops.attention_fwd(xb, wqb, bqkv, wpb, bproj, h, keep_o=True)
         dout = torch.randn(B, N, D, generator=g).to(dev).bfloat16()
         ms = timeit(lambda: ops.attention_bwd(xb, wqb, wpb, dout, st), a.reps)
         emit("attention_bwd_bf16(module)", ms, 2 * B * (2.0 * N * D * 3 * D + 4.0 * N * N * D + 2.0 * N * D * D), peak=PEAK_BF16)
