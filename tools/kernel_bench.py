@@ -17,10 +17,19 @@ from attentionshift_amd import ops, synthetic  # noqa: E402
 PEAK_BF16, PEAK_F32, PEAK_HBM = 2.5e15, 157.3e12, 8.0e12
 
 
-def timeit(fn, reps, warm=3):
+def timeit(fn, reps, warm=3, sync_each=False):
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
+    if sync_each:                       # ops whose caller reads a result back right away (the RoI-head stages)
+        import time
+        tot = 0.0
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            tot += time.perf_counter() - t0
+        return tot / reps * 1e3
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
@@ -119,11 +128,11 @@ def main():
         prot = torch.stack(prots).to(dev)
         obj_img = torch.tensor(obj, dtype=torch.int32, device=dev)
         S, G, P = 5, len(obj), 20
-        ms = timeit(lambda: ops.cosine_shift(feat, box_patch, obj_img, prot, S, hp, wp), a.reps)
+        ms = timeit(lambda: ops.cosine_shift(feat, box_patch, obj_img, prot, S, hp, wp), a.reps, sync_each=True)
         alg = (2 * S + 1) * B * hp * wp * D * 4 + G * P * hp * wp * 4
         emit("cosine_shift_S5", ms, bytes_=alg, note="algorithmic bytes per SURVEY 8d")
         full = torch.tensor([[0, 0, wp - 1, hp - 1]] * G, dtype=torch.int32, device=dev)
-        ms = timeit(lambda: ops.cosine_shift(feat, full, obj_img, prot, S, hp, wp), a.reps)
+        ms = timeit(lambda: ops.cosine_shift(feat, full, obj_img, prot, S, hp, wp), a.reps, sync_each=True)
         emit("cosine_shift_S5_fullboxes", ms, bytes_=alg, note="worst case: every box covers the image")
     if want("cam"):
         hp = wp = 64
@@ -133,7 +142,7 @@ def main():
             cams[m, 10 + m % 7:40, 12:44 + m % 5] += 1.0
         cams = cams.to(dev)
         pts = torch.full((M, 2), 500.0, device=dev)
-        ms = timeit(lambda: ops.cam_boxes(cams, pts, 0.2, 0.5), max(a.reps // 4, 2))
+        ms = timeit(lambda: ops.cam_boxes(cams, pts, 0.2, 0.5), max(a.reps // 4, 2), sync_each=True)
         emit("cam_boxes_21maps_per_img", ms, bytes_=M * 1024 * 1024 * 13, note="13 B/pixel/map (SURVEY 8d)")
     return out
 
