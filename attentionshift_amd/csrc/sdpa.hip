@@ -561,7 +561,6 @@ int sdpa_split_slices(int B, int N, int h) {           // 0 = no split for this 
   if (!tail) return 0;
   const int nkt = as_round_up(N, 64) / SD_KB;
   int ns = as_ceil_div(slots / 3, BH);                 // about one workgroup per CU
-  if (const char* e = getenv("AS_SDPA_SLICES")) ns = atoi(e);      // tuning hook
   ns = ns < 2 ? 2 : (ns > nkt ? nkt : ns);
   const int per = as_ceil_div(nkt, ns);
   return as_ceil_div(nkt, per);                         // no empty slice
