@@ -15,11 +15,12 @@ def loop(fn, n=20):
 torch.cuda.set_device(0); torch.set_num_threads(8)
 step = bench.build(torch.device("cuda", 0), "fast")
 h = step.head
-configs = {"all on": dict(pipeline_images=True, image_streams=True), "no per-image pipeline": dict(pipeline_images=False, image_streams=True),
-           "one stream": dict(pipeline_images=False, image_streams=False)}
+configs = {"stream per image": dict(image_streams=True), "one stream": dict(image_streams=False),
+           "thread + stream per image": dict(image_streams=False, parallel_images=True)}
 with torch.no_grad():
     for rep in range(3):
         for name, cfg in configs.items():
+            h.parallel_images = False
             for k, v in cfg.items():
                 setattr(h, k, v)
             print(f"{name:24s} {loop(step):.2f} ms", flush=True)
