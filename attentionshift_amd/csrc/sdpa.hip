@@ -427,16 +427,18 @@ __global__ __launch_bounds__(SD_NT, 3) void sdpa_fwd_glds_kernel(const __bf16* _
       m_run = rowmax();
       mc = m_run * c2;
     }
-    float psum = 0.0f;
+    // four independent partial sums: one 32-deep chain of dependent v_add would sit on the critical path of the tile
+    float ps4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     Frag<__bf16> fp[2][2];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float p = __builtin_amdgcn_exp2f(fmaf(sacc[kb][r], c2, -mc));
-        psum += p;
+        ps4[r & 3] += p;
         fp[kb][r >> 3].set(r & 7, p);
       }
+    float psum = (ps4[0] + ps4[1]) + (ps4[2] + ps4[3]);
     if (__any(!(psum < 1e20f))) {                       // rare: re-reference this wave's rows to the true running max
       const float m_cand = fmaxf(m_run, rowmax());
       const float alpha = __builtin_amdgcn_exp2f((m_run - m_cand) * c2);
