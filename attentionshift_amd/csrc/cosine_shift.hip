@@ -22,7 +22,6 @@ namespace {
 
 constexpr int CS_NT = 256;
 constexpr int CS_TILE1 = 32;     // patches per sim tile
-constexpr int CS_TILE3 = 32;     // patches per aggregation tile
 constexpr int PMAX = 32;
 constexpr float COS_EPS = 1e-8f;
 
@@ -218,151 +217,465 @@ __device__ __forceinline__ int outside_cluster(const float* st_g, int P) {
   return best;
 }
 
-// ---- assign + aggregate: grid (nt3, G) ---------------------------------------------------------------
-template <int CPT>   // channels per thread = ceil(C / 256)
-__global__ __launch_bounds__(CS_NT) void assign_kernel(const float* __restrict__ feat, const float* __restrict__ sim,
-                                                       const float* __restrict__ stats,
-                                                       const int32_t* __restrict__ box_patch_,
-                                                       const int32_t* __restrict__ obj_img,
-                                                       int32_t* __restrict__ assign, int32_t* __restrict__ assign_out,
-                                                       float* __restrict__ part_prot, int32_t* __restrict__ part_cnt,
-                                                       int C, int Hp, int Wp, int P, int nt3) {
-  __shared__ float st_s[PMAX * 4];
-  __shared__ int a_s[CS_TILE3];
-  __shared__ float w_s[CS_TILE3];
-  __shared__ int n_s[CS_TILE3];
-  __shared__ int cnt_s[PMAX];
+// ---- shift iteration, pass 1: similarity tiles (8 waves split the channel range) ---------------------
+// grid (tiles, G).  FULL=false: tile indexes the object's in-box patches, sim is written COMPACT
+// ([g][p][in-box index]); FULL=true: the whole grid, sim written by patch index.  pn2 holds `npart` partial squared
+// norms per prototype (1 for the caller's prototypes, C/SH_CH after an aggregation pass), summed here in fixed order.
+constexpr int S1_NT = 512;
+constexpr int SH_CH = 32;        // channels per aggregation workgroup
+
+template <bool FULL>
+__global__ __launch_bounds__(S1_NT) void shift_sim_kernel(const float* __restrict__ feat, const float* __restrict__ invn,
+                                                          const float* __restrict__ prot, const float* __restrict__ pn2,
+                                                          int npart, const int32_t* __restrict__ box_patch_,
+                                                          const int32_t* __restrict__ obj_img,
+                                                          const int2* __restrict__ aw_prev,   // [G][Np] compact or null
+                                                          float* __restrict__ sim, float* __restrict__ part_stats,
+                                                          int C, int Hp, int Wp, int P, int nt1) {
+  __shared__ float red[8][32][33];
+  __shared__ float invnp_s[PMAX];
+  const int Np = Hp * Wp;
+  const int g = blockIdx.y, tile = blockIdx.x;
+  const Box ob = load_box(box_patch_, g, Hp, Wp);
+  const int nb = FULL ? Np : box_count(ob);
+  if (tile * CS_TILE1 >= nb) return;
+  const int b = obj_img[g];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, half = lane >> 5;
+
+  if (tid < PMAX) {
+    float s = 0.0f;
+    if (tid < P)
+      for (int k = 0; k < npart; ++k) s += pn2[((size_t)g * npart + k) * PMAX + tid];
+    invnp_s[tid] = tid < P ? 1.0f / fmaxf(sqrtf(s), COS_EPS) : 0.0f;
+  }
+
+  auto patch_of = [&](int local) {
+    const int t = min(tile * CS_TILE1 + local, nb - 1);
+    return FULL ? t : box_patch(ob, t, Wp);
+  };
+  const int n_mine = patch_of(li);
+  const float* frow = feat + ((size_t)b * Np + n_mine) * C;
+  const float* prow = prot + ((size_t)g * P + min(li, P - 1)) * C;
+  const bool pvalid = li < P;
+
+  // epilogue operands requested before the contraction: this thread's (patch nn, prototype rows pq, pq+16)
+  const int nn = tid & 31, pq = tid >> 5;
+  const int t_loc = tile * CS_TILE1 + nn;
+  const bool nvalid = t_loc < nb;
+  const int n = patch_of(nn);
+  const float fin = invn[(size_t)b * Np + n];
+  int a_prev = -1;
+  if (aw_prev != nullptr && nvalid) {
+    if (!FULL) {
+      a_prev = aw_prev[(size_t)g * Np + t_loc].x;
+    } else if (in_box(ob, n, Wp)) {
+      const int y = n / Wp, x = n - y * Wp;
+      a_prev = aw_prev[(size_t)g * Np + (y - ob.y0) * box_w(ob) + (x - ob.x0)].x;
+    }
+  }
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+  const int nsteps = (C + 15) / 16;
+  constexpr int SU = 6;
+  for (int s = wave; s < nsteps; s += 8 * SU) {
+    Frag<float> fa[SU], fb[SU];
+    float keep[SU];
+#pragma unroll
+    for (int u = 0; u < SU; ++u) {
+      const int su = s + 8 * u;
+      const bool ok = su < nsteps && su * 16 + half * 8 + 8 <= C;
+      const int k0 = ok ? su * 16 + half * 8 : 0;
+      fb[u].load16B(frow + k0);
+      fa[u].load16B(prow + k0);
+      keep[u] = (ok && pvalid) ? 1.0f : 0.0f;
+    }
+    // keep all 4*SU operand loads in flight: without the fence the scheduler sinks each load to its MFMA to save
+    // registers and the loop degenerates into SU dependent memory round trips
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < SU; ++u) {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) fa[u].v[t] *= keep[u];
+      acc = mma32(fa[u], fb[u], acc);          // D[p][n]
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[wave][acc_row(r, half)][li] = acc[r];
+  __syncthreads();
+
+#pragma unroll
+  for (int qd = 0; qd < 2; ++qd) {
+    const int p = pq + 16 * qd;
+    float v = (((red[0][p][nn] + red[1][p][nn]) + (red[2][p][nn] + red[3][p][nn])) +
+               ((red[4][p][nn] + red[5][p][nn]) + (red[6][p][nn] + red[7][p][nn])));
+    v = v * invnp_s[p] * fin;
+    if (p < P && nvalid) sim[((size_t)g * P + p) * Np + (FULL ? n : t_loc)] = v;
+    float mx = (nvalid && p < P) ? v : -INFINITY;
+    float ds = (a_prev == p) ? v : 0.0f;
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) {
+      mx = fmaxf(mx, __shfl_xor(mx, o));
+      ds += __shfl_xor(ds, o);
+    }
+    if (nn == 0) {
+      float* ps = part_stats + (((size_t)g * nt1 + tile) * PMAX + p) * 2;
+      ps[0] = mx;
+      ps[1] = ds;
+    }
+  }
+}
+
+// ---- final similarity over the UNMASKED grid: grid (tiles, B) ----------------------------------------------
+// One workgroup per (32-patch tile, image): the tile's feature fragments are loaded ONCE and contracted with the
+// prototypes of every object of that image in turn (the per-object form re-streamed the 12.6 MB map per object).
+// Also reduces the density sums of the last assignment (tau trace) like the per-object pass.
+constexpr int SF_SU = 8;          // k16 steps per wave held in registers: covers C <= 8 * 8 * 16 = 1024
+
+__global__ __launch_bounds__(S1_NT) void shift_sim_full_kernel(const float* __restrict__ feat,
+                                                               const float* __restrict__ invn,
+                                                               const float* __restrict__ prot,
+                                                               const float* __restrict__ pn2, int npart,
+                                                               const int32_t* __restrict__ box_patch_,
+                                                               const int32_t* __restrict__ obj_img,
+                                                               const int2* __restrict__ aw_prev,
+                                                               float* __restrict__ sim, float* __restrict__ part_stats,
+                                                               int C, int Hp, int Wp, int P, int G, int nt1) {
+  __shared__ float red[8][32][33];
+  __shared__ float invnp_s[PMAX];
+  const int Np = Hp * Wp;
+  const int b = blockIdx.y, tile = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, half = lane >> 5;
+  const int n_mine = min(tile * CS_TILE1 + li, Np - 1);
+  const float* frow = feat + ((size_t)b * Np + n_mine) * C;
+  const int nsteps = (C + 15) / 16;
+
+  Frag<float> fb[SF_SU];
+  bool okk[SF_SU];
+#pragma unroll
+  for (int u = 0; u < SF_SU; ++u) {
+    const int su = wave + 8 * u;
+    okk[u] = su < nsteps && su * 16 + half * 8 + 8 <= C;
+    fb[u].load16B(frow + (okk[u] ? su * 16 + half * 8 : 0));
+  }
+  const int nn = tid & 31, pq = tid >> 5;
+  const int n = tile * CS_TILE1 + nn;
+  const bool nvalid = n < Np;
+  const float fin = invn[(size_t)b * Np + min(n, Np - 1)];
+
+  for (int g = 0; g < G; ++g) {
+    if (obj_img[g] != b) continue;                         // workgroup-uniform
+    const float* prow = prot + ((size_t)g * P + min(li, P - 1)) * C;
+    Frag<float> fa[SF_SU];
+#pragma unroll
+    for (int u = 0; u < SF_SU; ++u) fa[u].load16B(prow + (okk[u] ? (wave + 8 * u) * 16 + half * 8 : 0));
+    if (tid < PMAX) {
+      float s2 = 0.0f;
+      if (tid < P)
+        for (int k = 0; k < npart; ++k) s2 += pn2[((size_t)g * npart + k) * PMAX + tid];
+      invnp_s[tid] = tid < P ? 1.0f / fmaxf(sqrtf(s2), COS_EPS) : 0.0f;
+    }
+    const Box ob = load_box(box_patch_, g, Hp, Wp);
+    int a_prev = -1;
+    if (aw_prev != nullptr && nvalid && in_box(ob, n, Wp)) {
+      const int y = n / Wp, x = n - y * Wp;
+      a_prev = aw_prev[(size_t)g * Np + (y - ob.y0) * box_w(ob) + (x - ob.x0)].x;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+    for (int u = 0; u < SF_SU; ++u) {
+      const float keep = (okk[u] && li < P) ? 1.0f : 0.0f;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) fa[u].v[t] *= keep;
+      acc = mma32(fa[u], fb[u], acc);          // D[p][n]
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave][acc_row(r, half)][li] = acc[r];
+    __syncthreads();
+#pragma unroll
+    for (int qd = 0; qd < 2; ++qd) {
+      const int p = pq + 16 * qd;
+      float v = (((red[0][p][nn] + red[1][p][nn]) + (red[2][p][nn] + red[3][p][nn])) +
+                 ((red[4][p][nn] + red[5][p][nn]) + (red[6][p][nn] + red[7][p][nn])));
+      v = v * invnp_s[p] * fin;
+      if (p < P && nvalid) sim[((size_t)g * P + p) * Np + n] = v;
+      if (aw_prev != nullptr) {
+        float ds = (a_prev == p) ? v : 0.0f;
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) ds += __shfl_xor(ds, o);
+        if (nn == 0) {
+          float* ps = part_stats + (((size_t)g * nt1 + tile) * PMAX + p) * 2;
+          ps[0] = 0.0f;
+          ps[1] = ds;
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ---- shift iteration, pass 2: per-prototype softmax statistics + assignment of this tile ------------------
+// grid (tiles, G).  Every tile workgroup of an object recomputes the object's statistics (tau, logit max, Z over
+// the compact similarity rows: a few thousand exps) instead of waiting for a separate statistics launch; it then
+// assigns its 32 patches: w = exp(sim/(temp*tau) - max)/Z, strict-> argmax over prototypes (ties -> lowest).
+__global__ __launch_bounds__(CS_NT) void shift_assign_kernel(const float* __restrict__ sim_c,
+                                                             const float* __restrict__ part_stats,
+                                                             const int32_t* __restrict__ cnt,
+                                                             const int32_t* __restrict__ box_patch_,
+                                                             float* __restrict__ stats, float* __restrict__ tau_out,
+                                                             int2* __restrict__ aw, int32_t* __restrict__ assign_out,
+                                                             float tau0, float temp, int it, int Hp, int Wp, int P,
+                                                             int G, int nt1) {
+  __shared__ float sh_mx[8][32], sh_ds[8][32];
+  __shared__ float st_s[PMAX * 4], zs_s[PMAX * 2];
   const int Np = Hp * Wp;
   const int g = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int t0 = tile * CS_TILE1;
+  // Every dependent global-memory hop of these small kernels costs ~2 us, so ALL operands are requested before
+  // anything is known about the box: addresses are clamped to the array, masks are applied when the box arrives.
+  constexpr int PSU = 8;                       // part_stats tiles per thread per trip (8 slots x PSU = 64 tiles)
+  constexpr int ZQ = PMAX / 4, ZU = 12;        // Z trip: ZQ prototypes x ZU patches per lane (768 patches)
+  const int sp = tid & 31, slot = tid >> 5;
+  float2 ps[PSU];
+#pragma unroll
+  for (int k = 0; k < PSU; ++k)
+    ps[k] = *reinterpret_cast<const float2*>(part_stats + (((size_t)g * nt1 + min(slot + 8 * k, nt1 - 1)) * PMAX + sp) * 2);
+  // (the bulk -- the similarity rows for Z -- is requested blind only by the first 32 tiles of an object, which
+  // cover boxes up to 1024 patches; later tiles, mostly beyond the box, wait for the box first)
+  const bool eager = tile < 32;
+  float v[ZQ][ZU];
+  if (eager) {
+#pragma unroll
+    for (int q = 0; q < ZQ; ++q) {
+      const float* srow = sim_c + ((size_t)g * P + min(wave + 4 * q, P - 1)) * Np;
+#pragma unroll
+      for (int u = 0; u < ZU; ++u) v[q][u] = srow[min(lane + 64 * u, Np - 1)];
+    }
+  }
+  float sv[PMAX / 8];
+#pragma unroll
+  for (int k = 0; k < PMAX / 8; ++k)
+    sv[k] = sim_c[((size_t)g * P + min(slot + 8 * k, P - 1)) * Np + min(t0 + sp, Np - 1)];
+  const float cnt_p = (float)cnt[g * PMAX + sp];
   const Box ob = load_box(box_patch_, g, Hp, Wp);
   const int nb = box_count(ob);
-  const int b = obj_img[g];
-  if (tid < P * 4) st_s[tid] = stats[(size_t)g * PMAX * 4 + tid];
-  if (tid < PMAX) cnt_s[tid] = 0;
+  __builtin_amdgcn_sched_barrier(0);
+  if (t0 >= nb && assign_out == nullptr) return;
+  const int ntiles = (nb + CS_TILE1 - 1) / CS_TILE1;
+
+  {                                             // maximum / previous-assignment density sums over the tiles
+    float mx = -INFINITY, ds = 0.0f;
+#pragma unroll
+    for (int k = 0; k < PSU; ++k)
+      if (slot + 8 * k < ntiles) { mx = fmaxf(mx, ps[k].x); ds += ps[k].y; }
+    for (int t = slot + 8 * PSU; t < ntiles; t += 8) {
+      const float* q = part_stats + (((size_t)g * nt1 + t) * PMAX + sp) * 2;
+      mx = fmaxf(mx, q[0]);
+      ds += q[1];
+    }
+    sh_mx[slot][sp] = mx; sh_ds[slot][sp] = ds;
+  }
   __syncthreads();
+  if (tid < PMAX) {
+    const int p = tid;
+    float maxsim = sh_mx[0][p], dens = sh_ds[0][p];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) { maxsim = fmaxf(maxsim, sh_mx[k][p]); dens += sh_ds[k][p]; }
+    if (nb < Np) maxsim = fmaxf(maxsim, 0.0f);          // out-of-box patches have cosine exactly 0
+    float tau = tau0;
+    if (it > 0) {                                       // update_density_batch (:882-908)
+      const float c = p < P ? cnt_p : 0.0f;
+      const float mean = c >= 1.0f ? dens / c : 0.0f;
+      tau = fmaxf(1.0f - mean, 1e-10f);
+      if (tau_out != nullptr && tile == 0 && p < P) tau_out[((size_t)(it - 1) * G + g) * P + p] = tau;
+    }
+    const float tt = temp * tau;
+    st_s[p * 4 + 0] = tt; st_s[p * 4 + 1] = maxsim / tt; st_s[p * 4 + 3] = tau;
+    zs_s[p * 2 + 0] = maxsim; zs_s[p * 2 + 1] = 1.4426950408889634f / tt;
+  }
+  __syncthreads();
+  // Z_p: wave w owns prototypes w, w+4, ... (<= 8 of them).  Every tile workgroup of the object repeats this sum,
+  // so it uses the hardware exp2 on (sim - max) * log2(e)/(temp*tau): the difference is exact for the terms that
+  // matter (close to the maximum), one rounding + v_exp_f32 instead of an IEEE division and a full expf per term.
+  {
+    float z[ZQ], mxs[ZQ], r2[ZQ];
+#pragma unroll
+    for (int q = 0; q < ZQ; ++q) {
+      const int p = min(wave + 4 * q, P - 1);
+      z[q] = 0.0f; mxs[q] = zs_s[p * 2 + 0]; r2[q] = zs_s[p * 2 + 1];
+    }
+    for (int tb = 0; tb < nb; tb += 64 * ZU) {
+      if (tb > 0 || !eager) {                   // boxes beyond 768 patches: further trips
+#pragma unroll
+        for (int q = 0; q < ZQ; ++q) {
+          const float* srow = sim_c + ((size_t)g * P + min(wave + 4 * q, P - 1)) * Np;
+#pragma unroll
+          for (int u = 0; u < ZU; ++u) v[q][u] = srow[min(tb + lane + 64 * u, nb - 1)];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int q = 0; q < ZQ; ++q) {
+        if (wave + 4 * q < P) {                  // wave-uniform
+#pragma unroll
+          for (int u = 0; u < ZU; ++u) {
+            const float e = __builtin_amdgcn_exp2f((v[q][u] - mxs[q]) * r2[q]);
+            z[q] += (tb + lane + 64 * u < nb) ? e : 0.0f;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < ZQ; ++q) {
+      const int p = wave + 4 * q;
+      const float zz = wave_sum(z[q]);
+      if (lane == 0 && p < P) st_s[p * 4 + 2] = zz + (float)(Np - nb) * __builtin_amdgcn_exp2f((0.0f - mxs[q]) * r2[q]);
+    }
+  }
+  __syncthreads();
+  if (tile == 0 && tid < P * 4) stats[(size_t)g * PMAX * 4 + tid] = st_s[tid];
 
   // user-visible assignment of out-of-box patches (never read back by the iteration itself)
   if (assign_out != nullptr) {
-    const int n = tile * CS_TILE3 + tid;
-    if (tid < CS_TILE3 && n < Np && !in_box(ob, n, Wp)) assign_out[(size_t)g * Np + n] = outside_cluster(st_s, P);
+    const int n = tile * CS_TILE1 + tid;
+    if (tid < CS_TILE1 && n < Np && !in_box(ob, n, Wp)) assign_out[(size_t)g * Np + n] = outside_cluster(st_s, P);
   }
-  const int t0 = tile * CS_TILE3;
-  if (t0 >= nb) return;
-  const int count = min(CS_TILE3, nb - t0);
-
-  if (tid < count) {
-    const int n = box_patch(ob, t0 + tid, Wp);
+  // this tile's 32 patches: thread (patch, slot) scores prototypes slot, slot+8, ..., then the 8 slots are merged
+  // with the sequential scan's rule: highest weight, ties -> lowest prototype index
+  {
+    float bw = -INFINITY;
+    int bp = PMAX;
+#pragma unroll
+    for (int k = 0; k < PMAX / 8; ++k) {
+      const int p = slot + 8 * k;
+      if (p < P) {
+        const float w = expf(sv[k] / st_s[p * 4 + 0] - st_s[p * 4 + 1]) / st_s[p * 4 + 2];
+        if (w > bw) { bw = w; bp = p; }
+      }
+    }
+    __syncthreads();                               // sh_mx / sh_ds are free again
+    sh_mx[slot][sp] = bw;
+    sh_ds[slot][sp] = __int_as_float(bp);
+  }
+  __syncthreads();
+  if (tid < CS_TILE1 && t0 + tid < nb) {
+    const int t = t0 + tid;
     int best = 0;
     float bw = -INFINITY;
-    for (int p = 0; p < P; ++p) {
-      const float w = expf(sim[((size_t)g * P + p) * Np + n] / st_s[p * 4 + 0] - st_s[p * 4 + 1]) / st_s[p * 4 + 2];
-      if (w > bw) { bw = w; best = p; }           // strict: ties keep the lowest prototype index
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float w = sh_mx[k][tid];
+      const int p = __float_as_int(sh_ds[k][tid]);
+      if (w > bw || (w == bw && p < best)) { bw = w; best = p; }
     }
-    a_s[tid] = best; w_s[tid] = bw; n_s[tid] = n;
-    assign[(size_t)g * Np + n] = best;
-    if (assign_out != nullptr) assign_out[(size_t)g * Np + n] = best;
-    atomicAdd(&cnt_s[best], 1);
+    aw[(size_t)g * Np + t] = make_int2(best, __float_as_int(bw));
+    if (assign_out != nullptr) assign_out[(size_t)g * Np + box_patch(ob, t, Wp)] = best;
   }
-  __syncthreads();
-
-  float acc[CPT][PMAX];
-#pragma unroll
-  for (int i = 0; i < CPT; ++i)
-#pragma unroll
-    for (int p = 0; p < PMAX; ++p) acc[i][p] = 0.0f;
-  const float* fb = feat + (size_t)b * Np * C;
-  constexpr int UNR = 8;                 // feature rows of UNR patches are in flight before the first one is used
-  for (int j0 = 0; j0 < count; j0 += UNR) {
-    float f[UNR][CPT];
-#pragma unroll
-    for (int u = 0; u < UNR; ++u) {
-      const float* frow = fb + (size_t)n_s[min(j0 + u, count - 1)] * C;
-#pragma unroll
-      for (int i = 0; i < CPT; ++i) {
-        const int c = tid + i * CS_NT;
-        f[u][i] = c < C ? frow[c] : 0.0f;
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < UNR; ++u) {
-      if (j0 + u < count) {                // workgroup-uniform
-        const int a = __builtin_amdgcn_readfirstlane(a_s[j0 + u]);
-        const float wa = w_s[j0 + u];
-        // wave-uniform selection of the accumulator: compiles to a scalar branch tree, registers stay static
-#define AS_CASE(PP)                                                            \
-  case PP:                                                                     \
-    _Pragma("unroll") for (int i = 0; i < CPT; ++i) acc[i][PP] = fmaf(wa, f[u][i], acc[i][PP]); \
-    break;
-        switch (a) {
-          AS_CASE(0) AS_CASE(1) AS_CASE(2) AS_CASE(3) AS_CASE(4) AS_CASE(5) AS_CASE(6) AS_CASE(7)
-          AS_CASE(8) AS_CASE(9) AS_CASE(10) AS_CASE(11) AS_CASE(12) AS_CASE(13) AS_CASE(14) AS_CASE(15)
-          AS_CASE(16) AS_CASE(17) AS_CASE(18) AS_CASE(19) AS_CASE(20) AS_CASE(21) AS_CASE(22) AS_CASE(23)
-          AS_CASE(24) AS_CASE(25) AS_CASE(26) AS_CASE(27) AS_CASE(28) AS_CASE(29) AS_CASE(30) AS_CASE(31)
-          default: break;
-        }
-#undef AS_CASE
-      }
-    }
-  }
-  float* pp = part_prot + ((size_t)g * nt3 + tile) * P * C;
-#pragma unroll
-  for (int p = 0; p < PMAX; ++p) {
-    if (p < P) {
-#pragma unroll
-      for (int i = 0; i < CPT; ++i) {
-        const int c = tid + i * CS_NT;
-        if (c < C) pp[(size_t)p * C + c] = acc[i][p];
-      }
-    }
-  }
-  if (tid < PMAX) part_cnt[((size_t)g * nt3 + tile) * PMAX + tid] = cnt_s[tid];
 }
 
-// ---- finalize: grid (P, G): sum partial prototypes in tile order, norm, member count -----------------
-__global__ __launch_bounds__(CS_NT) void finalize_kernel(const float* __restrict__ part_prot,
-                                                         const int32_t* __restrict__ part_cnt,
-                                                         const float* __restrict__ stats,
-                                                         const int32_t* __restrict__ box_patch_,
-                                                         float* __restrict__ prot, float* __restrict__ invnp,
-                                                         int32_t* __restrict__ cnt, int C, int Hp, int Wp, int P,
-                                                         int nt3) {
-  __shared__ float sh[CS_NT];
+// ---- shift iteration, pass 3: cluster-wise aggregation, channel-major ---------------------------------------
+// grid (C / 32, G).  A workgroup owns 32 channels of ALL prototypes of its object, so there are no cross-workgroup
+// partials: thread (member slot ms, channel quad cq) walks the in-box patches ms, ms+32, ... in order and adds
+// w * feat into ITS slot of the patch's cluster (LDS, one float4 per thread and prototype); the 32 member slots are
+// then summed in a fixed order.  Also: squared-norm partial of the new prototypes (for the next similarity pass)
+// and, from channel block 0, the member counts (for the density).
+__global__ __launch_bounds__(CS_NT) void shift_aggregate_kernel(const float* __restrict__ feat,
+                                                                const int2* __restrict__ aw,
+                                                                const float* __restrict__ stats,
+                                                                const int32_t* __restrict__ box_patch_,
+                                                                const int32_t* __restrict__ obj_img,
+                                                                float* __restrict__ prot, float* __restrict__ pn2,
+                                                                int32_t* __restrict__ cnt, int C, int Hp, int Wp,
+                                                                int P) {
+  __shared__ float4 acc_s[PMAX * CS_NT];
+  __shared__ int cnt_s[PMAX];
   const int Np = Hp * Wp;
-  const int p = blockIdx.x, g = blockIdx.y, tid = threadIdx.x;
+  const int chunk = blockIdx.x, nchunk = gridDim.x, g = blockIdx.y, tid = threadIdx.x;
   const Box ob = load_box(box_patch_, g, Hp, Wp);
-  const int nb = box_count(ob);
-  const int ntiles = (nb + CS_TILE3 - 1) / CS_TILE3;
-  float sq = 0.0f;
-  for (int c = tid; c < C; c += CS_NT) {
-    // four interleaved partial sums (independent loads in flight), combined in a fixed order: deterministic
-    float v0 = 0.0f, v1 = 0.0f, v2 = 0.0f, v3 = 0.0f;
-    const float* base = part_prot + (((size_t)g * nt3) * P + p) * C + c;
-    const size_t step = (size_t)P * C;
-    int t = 0;
-    for (; t + 4 <= ntiles; t += 4) {
-      v0 += base[(size_t)t * step];
-      v1 += base[(size_t)(t + 1) * step];
-      v2 += base[(size_t)(t + 2) * step];
-      v3 += base[(size_t)(t + 3) * step];
-    }
-    for (; t < ntiles; ++t) v0 += base[(size_t)t * step];
-    const float v = (v0 + v1) + (v2 + v3);
-    prot[((size_t)g * P + p) * C + c] = v;
-    sq = fmaf(v, v, sq);
-  }
-  sh[tid] = sq;
+  const int nb = box_count(ob), bw = max(box_w(ob), 1);
+  const int b = obj_img[g];
+  const int cq = tid & 7, ms = tid >> 3;
+  const bool count_here = chunk == 0 && cq == 0;
+  if (tid < PMAX) cnt_s[tid] = 0;
   __syncthreads();
-  for (int o = CS_NT / 2; o > 0; o >>= 1) {
-    if (tid < o) sh[tid] += sh[tid + o];
-    __syncthreads();
+
+  const float* fb = feat + (size_t)b * Np * C + chunk * SH_CH + cq * 4;
+  const int2* awg = aw + (size_t)g * Np;
+  constexpr int U = 16;
+  bool zeroed = false;
+  for (int j0 = ms; j0 < nb || !zeroed; j0 += 32 * U) {
+    float4 f[U];
+    int2 m[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int j = max(min(j0 + 32 * u, nb - 1), 0);
+      const int ty = j / bw;
+      const int n = min((ob.y0 + ty) * Wp + ob.x0 + (j - ty * bw), Np - 1);
+      f[u] = *reinterpret_cast<const float4*>(fb + (size_t)n * C);
+      m[u] = awg[j];
+    }
+    __builtin_amdgcn_sched_barrier(0);          // all 2*U loads issued before the first use
+    if (!zeroed) {                              // a thread only ever touches its own accumulator slots: no barrier
+      for (int p = 0; p < P; ++p) acc_s[p * CS_NT + tid] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      zeroed = true;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (j0 + 32 * u < nb) {
+        const float w = __int_as_float(m[u].y);
+        float4 cur = acc_s[m[u].x * CS_NT + tid];
+        cur.x = fmaf(w, f[u].x, cur.x); cur.y = fmaf(w, f[u].y, cur.y);
+        cur.z = fmaf(w, f[u].z, cur.z); cur.w = fmaf(w, f[u].w, cur.w);
+        acc_s[m[u].x * CS_NT + tid] = cur;
+        if (count_here) atomicAdd(&cnt_s[m[u].x], 1);
+      }
+    }
   }
-  if (tid == 0) {
-    invnp[g * PMAX + p] = 1.0f / fmaxf(sqrtf(sh[0]), COS_EPS);
-    int c = 0;
-    for (int t = 0; t < ntiles; ++t) c += part_cnt[((size_t)g * nt3 + t) * PMAX + p];
-    if (nb < Np && outside_cluster(stats + (size_t)g * PMAX * 4, P) == p) c += Np - nb;
-    cnt[g * PMAX + p] = c;
+  __syncthreads();
+
+  const float* accf = reinterpret_cast<const float*>(acc_s);
+  for (int o = tid; o < PMAX * SH_CH; o += CS_NT) {       // uniform trip count: the shuffles below need whole waves
+    const int p = o >> 5, c = o & 31;
+    float v = 0.0f;
+    if (p < P) {
+      const float* base = accf + ((size_t)p * CS_NT + (c >> 2)) * 4 + (c & 3);
+      float v0 = 0.0f, v1 = 0.0f, v2 = 0.0f, v3 = 0.0f;
+#pragma unroll
+      for (int k = 0; k < 32; k += 4) {
+        v0 += base[(k + 0) * 32]; v1 += base[(k + 1) * 32];
+        v2 += base[(k + 2) * 32]; v3 += base[(k + 3) * 32];
+      }
+      v = (v0 + v1) + (v2 + v3);
+      prot[((size_t)g * P + p) * C + chunk * SH_CH + c] = v;
+    }
+    float sq = v * v;
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) sq += __shfl_xor(sq, off);
+    if (c == 0 && p < P) pn2[((size_t)g * nchunk + chunk) * PMAX + p] = sq;
   }
+  if (chunk == 0 && tid < P) {
+    int c = cnt_s[tid];
+    if (nb < Np && outside_cluster(stats + (size_t)g * PMAX * 4, P) == tid) c += Np - nb;
+    cnt[g * PMAX + tid] = c;
+  }
+}
+
+// squared norms of the caller's prototypes in the pn2 layout with one partial: [G][1][PMAX]
+__global__ void prot_norm2_kernel(const float* __restrict__ prot, float* __restrict__ pn2, int G, int P, int C) {
+  const int gp = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (gp >= G * P) return;
+  const float* r = prot + (size_t)gp * C;
+  float s = 0.0f;
+  for (int c = lane; c < C; c += 64) s = fmaf(r[c], r[c], s);
+  s = wave_sum(s);
+  if (lane == 0) pn2[(gp / P) * PMAX + gp % P] = s;
 }
 
 __global__ void prot_invnorm_kernel(const float* __restrict__ prot, float* __restrict__ invnp, int G, int P, int C) {
@@ -376,23 +689,22 @@ __global__ void prot_invnorm_kernel(const float* __restrict__ prot, float* __res
 }
 
 struct WsLayout {
-  size_t invn, invnp, cnt, stats, part_stats, assign, part_prot, part_cnt, total;
-  int nt1, nt3;
+  size_t invn, pn2, cnt, stats, part_stats, sim_c, aw, total;
+  int nt1, nchunk;
 };
 WsLayout ws_layout(int B, int C, int Np, int G, int P) {
   WsLayout w;
   auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
   w.nt1 = as_ceil_div(Np, CS_TILE1);
-  w.nt3 = as_ceil_div(Np, CS_TILE3);
+  w.nchunk = as_ceil_div(C, SH_CH);
   size_t o = 0;
   w.invn = o; o = al(o + (size_t)B * Np * 4);
-  w.invnp = o; o = al(o + (size_t)G * PMAX * 4);
+  w.pn2 = o; o = al(o + (size_t)G * w.nchunk * PMAX * 4);
   w.cnt = o; o = al(o + (size_t)G * PMAX * 4);
   w.stats = o; o = al(o + (size_t)G * PMAX * 16);
   w.part_stats = o; o = al(o + (size_t)G * w.nt1 * PMAX * 8);
-  w.assign = o; o = al(o + (size_t)G * Np * 4);
-  w.part_prot = o; o = al(o + (size_t)G * w.nt3 * P * C * 4);
-  w.part_cnt = o; o = al(o + (size_t)G * w.nt3 * PMAX * 4);
+  w.sim_c = o; o = al(o + (size_t)G * P * Np * 4);
+  w.aw = o; o = al(o + (size_t)G * Np * 8);
   w.total = o;
   return w;
 }
@@ -411,46 +723,39 @@ extern "C" int as_cosine_shift(const float* feat, const int32_t* box_patch, cons
   AS_REQUIRE(feat && box_patch && obj_img && prot && sim_out && ws, AS_E_BADARG, "as_cosine_shift: null pointer");
   AS_REQUIRE(B > 0 && Hp > 0 && Wp > 0 && G > 0 && n_shift >= 0, AS_E_BADARG, "as_cosine_shift: bad sizes");
   AS_REQUIRE(P > 0 && P <= PMAX, AS_E_UNSUPPORTED, "as_cosine_shift: P=%d prototypes per object (max %d)", P, PMAX);
-  AS_REQUIRE(C % 8 == 0 && C <= 4 * CS_NT, AS_E_UNSUPPORTED, "as_cosine_shift: C=%d must be a multiple of 8 and <= 1024", C);
+  AS_REQUIRE(C % SH_CH == 0 && C <= 4 * CS_NT, AS_E_UNSUPPORTED,
+             "as_cosine_shift: C=%d must be a multiple of %d and <= 1024", C, SH_CH);
   const int Np = Hp * Wp;
   const WsLayout L = ws_layout(B, C, Np, G, P);
   AS_REQUIRE(ws_bytes >= L.total, AS_E_WORKSPACE, "as_cosine_shift: workspace %zu < %zu bytes", ws_bytes, L.total);
   hipStream_t s = (hipStream_t)stream;
   char* w = (char*)ws;
   float* invn = (float*)(w + L.invn);
-  float* invnp = (float*)(w + L.invnp);
+  float* pn2 = (float*)(w + L.pn2);
   int32_t* cnt = (int32_t*)(w + L.cnt);
   float* stats = (float*)(w + L.stats);
   float* part_stats = (float*)(w + L.part_stats);
-  int32_t* assign = (int32_t*)(w + L.assign);
-  float* part_prot = (float*)(w + L.part_prot);
-  int32_t* part_cnt = (int32_t*)(w + L.part_cnt);
+  float* sim_c = (float*)(w + L.sim_c);
+  int2* aw = (int2*)(w + L.aw);
 
   hipLaunchKernelGGL(row_invnorm_kernel, dim3(as_ceil_div(B * Np, 4)), dim3(CS_NT), 0, s, feat, invn, B * Np, C);
-  hipLaunchKernelGGL(prot_invnorm_kernel, dim3(as_ceil_div(G * P, 4)), dim3(CS_NT), 0, s, prot, invnp, G, P, C);
-  const int cpt = as_ceil_div(C, CS_NT);
+  hipLaunchKernelGGL(prot_norm2_kernel, dim3(as_ceil_div(G * P, 4)), dim3(CS_NT), 0, s, prot, pn2, G, P, C);
+  // three launches per iteration (a dependent launch boundary costs ~1.5 us, a grid barrier more):
+  //   similarity tiles -> statistics + assignment per tile -> channel-major aggregation (no partial prototypes)
   for (int it = 0; it < n_shift; ++it) {
-    hipLaunchKernelGGL((sim_kernel<false>), dim3(L.nt1, G), dim3(CS_NT), 0, s, feat, invn, prot, invnp, box_patch,
-                       obj_img, it > 0 ? assign : nullptr, sim_out, part_stats, C, Hp, Wp, P, L.nt1);
-    hipLaunchKernelGGL(stats_kernel, dim3(P, G), dim3(CS_NT), 0, s, sim_out, part_stats, cnt, box_patch, stats,
-                       tau_out, tau0, temp, it, Hp, Wp, P, G, L.nt1, 0);
+    hipLaunchKernelGGL((shift_sim_kernel<false>), dim3(L.nt1, G), dim3(S1_NT), 0, s, feat, invn, prot, pn2,
+                       it == 0 ? 1 : L.nchunk, box_patch, obj_img, it > 0 ? aw : nullptr, sim_c, part_stats, C, Hp,
+                       Wp, P, L.nt1);
     int32_t* aout = assign_out ? assign_out + (size_t)it * G * Np : nullptr;
-#define AS_ASSIGN(CPT)                                                                                         \
-  hipLaunchKernelGGL((assign_kernel<CPT>), dim3(L.nt3, G), dim3(CS_NT), 0, s, feat, sim_out, stats, box_patch, \
-                     obj_img, assign, aout, part_prot, part_cnt, C, Hp, Wp, P, L.nt3)
-    switch (cpt) {
-      case 1: AS_ASSIGN(1); break;
-      case 2: AS_ASSIGN(2); break;
-      case 3: AS_ASSIGN(3); break;
-      default: AS_ASSIGN(4); break;
-    }
-#undef AS_ASSIGN
-    hipLaunchKernelGGL(finalize_kernel, dim3(P, G), dim3(CS_NT), 0, s, part_prot, part_cnt, stats, box_patch, prot,
-                       invnp, cnt, C, Hp, Wp, P, L.nt3);
+    hipLaunchKernelGGL(shift_assign_kernel, dim3(L.nt1, G), dim3(CS_NT), 0, s, sim_c, part_stats, cnt, box_patch,
+                       stats, tau_out, aw, aout, tau0, temp, it, Hp, Wp, P, G, L.nt1);
+    hipLaunchKernelGGL(shift_aggregate_kernel, dim3(L.nchunk, G), dim3(CS_NT), 0, s, feat, aw, stats, box_patch,
+                       obj_img, prot, pn2, cnt, C, Hp, Wp, P);
   }
   // final similarity on the UNMASKED map (+ the density of the last assignment for tau_out)
-  hipLaunchKernelGGL((sim_kernel<true>), dim3(L.nt1, G), dim3(CS_NT), 0, s, feat, invn, prot, invnp, box_patch,
-                     obj_img, n_shift > 0 ? assign : nullptr, sim_out, part_stats, C, Hp, Wp, P, L.nt1);
+  hipLaunchKernelGGL(shift_sim_full_kernel, dim3(L.nt1, B), dim3(S1_NT), 0, s, feat, invn, prot, pn2,
+                     n_shift > 0 ? L.nchunk : 1, box_patch, obj_img, (n_shift > 0 && tau_out) ? aw : nullptr, sim_out,
+                     part_stats, C, Hp, Wp, P, G, L.nt1);
   if (n_shift > 0 && tau_out != nullptr)
     hipLaunchKernelGGL(stats_kernel, dim3(P, G), dim3(CS_NT), 0, s, sim_out, part_stats, cnt, box_patch, stats,
                        tau_out, tau0, temp, n_shift, Hp, Wp, P, G, L.nt1, 1);
