@@ -7,16 +7,21 @@
 // nothing to the aggregation, and all fall into ONE cluster (the argmax of exp(-max_p)/Z_p).  The loop
 // therefore only touches in-box patches; the final similarity map is over the whole (unmasked) grid.
 //
-// Per iteration (deterministic, no float atomics; every cross-workgroup reduction goes through
-// partials summed in a fixed order):
-//   sim      : cos(prot, feat) tiles, 32 patches x <=32 prototypes, exact-fp32 MFMA (v_mfma_f32_32x32x2),
-//              the 4 waves of a workgroup split the channel range; also per-tile max and the density sums
-//              of the PREVIOUS assignment (update_density_batch needs cos(new prot, feat) = this pass)
-//   stats    : tau, logit max, softmax denominator Z per prototype
-//   assign   : w = exp(sim/(temp*tau) - max)/Z, argmax over prototypes (ties -> lowest), one-hot
-//              weighted aggregation prot_new[a] += w * feat[n] with register accumulators
-//   finalize : sum the per-tile partial prototypes, norms, member counts
+// Per iteration, three launches (deterministic, no float atomics, every sum in a fixed order):
+//   sim       : cos(prot, feat) tiles, 32 in-box patches x <=32 prototypes, exact-fp32 MFMA
+//               (v_mfma_f32_32x32x2), the 8 waves of a workgroup split the channel range; also per-tile max
+//               and the density sums of the PREVIOUS assignment (update_density_batch needs
+//               cos(new prot, feat) = this pass).  Similarities are kept compact ([g][p][in-box index]).
+//   assign    : every tile workgroup rebuilds its object's statistics (tau, logit max, Z) from the tile
+//               partials and the compact rows, then assigns its 32 patches:
+//               w = exp(sim/(temp*tau) - max)/Z, argmax over prototypes (ties -> lowest)
+//   aggregate : prot_new[a] += w * feat[n], owned per 32-channel block of ALL prototypes of an object, so there
+//               are no cross-workgroup partial prototypes; norms and member counts come out of the same pass
+// These kernels are latency-bound (each dependent global-memory hop of a small grid costs ~2 us): operands are
+// requested before the box is known, and every batch of loads is fenced (sched_barrier) against the scheduler
+// sinking the loads to their uses.
 #include "common.h"
+#include "bilinear.h"
 
 namespace {
 
@@ -58,93 +63,6 @@ __global__ __launch_bounds__(CS_NT) void row_invnorm_kernel(const float* __restr
   }
   s = wave_sum(s);
   if (lane == 0) out[row] = 1.0f / fmaxf(sqrtf(s), COS_EPS);
-}
-
-// ---- sim pass ------------------------------------------------------------------------------------
-// grid (tiles, G).  FULL=false: tile indexes the object's in-box patches; FULL=true: the whole grid.
-template <bool FULL>
-__global__ __launch_bounds__(CS_NT) void sim_kernel(const float* __restrict__ feat, const float* __restrict__ invn,
-                                                    const float* __restrict__ prot, const float* __restrict__ invnp,
-                                                    const int32_t* __restrict__ box_patch_,
-                                                    const int32_t* __restrict__ obj_img,
-                                                    const int32_t* __restrict__ assign_prev,   // [G,Np] or null
-                                                    float* __restrict__ sim, float* __restrict__ part_stats,
-                                                    int C, int Hp, int Wp, int P, int nt1) {
-  __shared__ float red[4][32][33];
-  const int Np = Hp * Wp;
-  const int g = blockIdx.y, tile = blockIdx.x;
-  const Box ob = load_box(box_patch_, g, Hp, Wp);
-  const int nb = FULL ? Np : box_count(ob);
-  if (tile * CS_TILE1 >= nb) return;
-  const int b = obj_img[g];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int li = lane & 31, half = lane >> 5;
-
-  auto patch_of = [&](int local) {
-    const int t = min(tile * CS_TILE1 + local, nb - 1);
-    return FULL ? t : box_patch(ob, t, Wp);
-  };
-  const int n_mine = patch_of(li);
-  const float* frow = feat + ((size_t)b * Np + n_mine) * C;
-  const float* prow = prot + ((size_t)g * P + min(li, P - 1)) * C;
-  const bool pvalid = li < P;
-
-  f32x16 acc;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-  const int nsteps = (C + 15) / 16;
-  // SU k16 steps of this wave per trip, all 2*SU operand loads issued before the first MFMA (a step past the end
-  // or a row past P reads a valid address and is multiplied by 0)
-  constexpr int SU = 6;
-  for (int s = wave; s < nsteps; s += 4 * SU) {
-    Frag<float> fa[SU], fb[SU];
-    float keep[SU];
-#pragma unroll
-    for (int u = 0; u < SU; ++u) {
-      const int su = s + 4 * u;
-      const bool ok = su < nsteps && su * 16 + half * 8 + 8 <= C;
-      const int k0 = ok ? su * 16 + half * 8 : 0;
-      fb[u].load16B(frow + k0);
-      fa[u].load16B(prow + k0);
-      keep[u] = (ok && pvalid) ? 1.0f : 0.0f;
-    }
-#pragma unroll
-    for (int u = 0; u < SU; ++u) {
-#pragma unroll
-      for (int t = 0; t < 8; ++t) fa[u].v[t] *= keep[u];
-      acc = mma32(fa[u], fb[u], acc);          // D[p][n]
-    }
-  }
-#pragma unroll
-  for (int r = 0; r < 16; ++r) red[wave][acc_row(r, half)][li] = acc[r];
-  __syncthreads();
-
-  const int nn = tid & 31, pq = tid >> 5;
-  const int t_loc = tile * CS_TILE1 + nn;
-  const bool nvalid = t_loc < nb;
-  const int n = patch_of(nn);
-  const float fin = invn[(size_t)b * Np + n];
-  const bool dens_ok = assign_prev != nullptr && nvalid && (!FULL || in_box(ob, n, Wp));
-  const int a_prev = dens_ok ? assign_prev[(size_t)g * Np + n] : -1;
-#pragma unroll
-  for (int qd = 0; qd < 4; ++qd) {
-    const int p = pq + 8 * qd;
-    float v = ((red[0][p][nn] + red[1][p][nn]) + red[2][p][nn]) + red[3][p][nn];
-    v = v * (p < P ? invnp[g * PMAX + p] : 0.0f) * fin;
-    if (p < P && nvalid) sim[((size_t)g * P + p) * Np + n] = v;
-    float mx = (nvalid && p < P) ? v : -INFINITY;
-    float ds = (a_prev == p) ? v : 0.0f;
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) {
-      mx = fmaxf(mx, __shfl_xor(mx, o));
-      ds += __shfl_xor(ds, o);
-    }
-    if (nn == 0) {
-      float* ps = part_stats + (((size_t)g * nt1 + tile) * PMAX + p) * 2;
-      ps[0] = mx;
-      ps[1] = ds;
-    }
-  }
 }
 
 // ---- stats pass: grid (P, G) ------------------------------------------------------------------------
@@ -678,16 +596,6 @@ __global__ void prot_norm2_kernel(const float* __restrict__ prot, float* __restr
   if (lane == 0) pn2[(gp / P) * PMAX + gp % P] = s;
 }
 
-__global__ void prot_invnorm_kernel(const float* __restrict__ prot, float* __restrict__ invnp, int G, int P, int C) {
-  const int gp = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (gp >= G * P) return;
-  const float* r = prot + (size_t)gp * C;
-  float s = 0.0f;
-  for (int c = lane; c < C; c += 64) s = fmaf(r[c], r[c], s);
-  s = wave_sum(s);
-  if (lane == 0) invnp[(gp / P) * PMAX + gp % P] = 1.0f / fmaxf(sqrtf(s), COS_EPS);
-}
-
 struct WsLayout {
   size_t invn, pn2, cnt, stats, part_stats, sim_c, aw, total;
   int nt1, nchunk;
@@ -765,160 +673,224 @@ extern "C" int as_cosine_shift(const float* feat, const int32_t* box_patch, cons
 
 // =====================================================================================================
 // Cosine-affinity refinement on the patch grid (stdroi:668-707 get_refined_similarity), one image.
-// Reuses the exact-fp32 MFMA similarity pass above with the seeds as the "prototypes" of one object
-// whose box is the whole grid.
+//
+//   level 0      : cos(seed, feat) -> output map (box mask + keep-the-winner when is_select)
+//   level l >= 1 : seeds <- similarity-weighted mean feature over the patches with cos >= tau * max;
+//                  cos again; the map carried to the next level is box-masked (:696), level 0's is not (:672)
+//
+// Two launches per level: an aggregation owned per 32-channel block (no partials) and a similarity pass whose
+// epilogue applies the masking / selection and reduces the row maxima the next level thresholds with.  The norms
+// of both operands are accumulated from the MFMA operand fragments, so there is no separate norm pass.
 // =====================================================================================================
 namespace {
 
-__global__ void refine_setup_kernel(int32_t* ints, int Hp, int Wp) {
-  if (threadIdx.x == 0) { ints[0] = 0; ints[1] = 0; ints[2] = Wp - 1; ints[3] = Hp - 1; ints[4] = 0; }
-}
-
-// level output: optional box masking of the first G maps + keep-the-winner selection (:676-683, :697-703)
-__global__ __launch_bounds__(CS_NT) void refine_select_kernel(float* __restrict__ work, const int32_t* __restrict__ boxes,
-                                                              float* __restrict__ out, int G, int Gp, int Hp, int Wp,
-                                                              int is_select, int write_back) {
+// grid (tiles).  work[g][n] = the map the next level consumes, out[g][n] = this level's output map,
+// peak[g] (ordered-uint, zeroed by the caller) = max_n work[g][n].
+__global__ __launch_bounds__(S1_NT) void refine_sim_kernel(const float* __restrict__ feat, const float* __restrict__ seeds,
+                                                           const int32_t* __restrict__ boxes, float* __restrict__ work,
+                                                           float* __restrict__ out, unsigned* __restrict__ peak, int G,
+                                                           int Gp, int C, int Hp, int Wp, int is_select, int mask_work) {
+  __shared__ float red[8][32][33];
+  __shared__ float nrm[2][16][32];
+  __shared__ float val[32][33];
   const int Np = Hp * Wp;
-  const int n = blockIdx.x * CS_NT + threadIdx.x;
-  if (n >= Np) return;
-  if (!is_select) {
-    for (int g = 0; g < Gp; ++g) out[(size_t)g * Np + n] = work[(size_t)g * Np + n];
-    return;
-  }
-  int best = 0;
-  float bv = -INFINITY;
-  for (int g = 0; g < Gp; ++g) {
-    float v = work[(size_t)g * Np + n];
-    if (g < G) {
-      const Box bx = load_box(boxes, g, Hp, Wp);
-      v = v * (in_box(bx, n, Wp) ? 1.0f : 0.0f);
-      if (write_back) work[(size_t)g * Np + n] = v;
+  const int tile = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, half = lane >> 5;
+  const int n_mine = min(tile * CS_TILE1 + li, Np - 1);
+  const float* frow = feat + (size_t)n_mine * C;
+  const float* prow = seeds + (size_t)min(li, Gp - 1) * C;
+  const float pkeep = li < Gp ? 1.0f : 0.0f;
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+  float qa = 0.0f, qb = 0.0f;                    // squared-norm partials of this lane's operand fragments
+  const int nsteps = (C + 15) / 16;
+  constexpr int SU = 6;
+  for (int s = wave; s < nsteps; s += 8 * SU) {
+    Frag<float> fa[SU], fb[SU];
+    float keep[SU];
+#pragma unroll
+    for (int u = 0; u < SU; ++u) {
+      const int su = s + 8 * u;
+      const bool ok = su < nsteps && su * 16 + half * 8 + 8 <= C;
+      const int k0 = ok ? su * 16 + half * 8 : 0;
+      fb[u].load16B(frow + k0);
+      fa[u].load16B(prow + k0);
+      keep[u] = ok ? 1.0f : 0.0f;
     }
-    if (v > bv) { bv = v; best = g; }
-  }
-  for (int g = 0; g < Gp; ++g) {
-    float v = work[(size_t)g * Np + n];
-    if (g < G && !write_back) {
-      const Box bx = load_box(boxes, g, Hp, Wp);
-      v = v * (in_box(bx, n, Wp) ? 1.0f : 0.0f);
+    __builtin_amdgcn_sched_barrier(0);           // all operand loads in flight before the first MFMA
+#pragma unroll
+    for (int u = 0; u < SU; ++u) {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        fa[u].v[t] *= pkeep * keep[u];
+        fb[u].v[t] *= keep[u];
+        qa = fmaf(fa[u].v[t], fa[u].v[t], qa);
+        qb = fmaf(fb[u].v[t], fb[u].v[t], qb);
+      }
+      acc = mma32(fa[u], fb[u], acc);            // D[g][n]
     }
-    out[(size_t)g * Np + n] = (g == best) ? v : 0.0f;
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[wave][acc_row(r, half)][li] = acc[r];
+  nrm[0][wave * 2 + half][li] = qa;
+  nrm[1][wave * 2 + half][li] = qb;
+  __syncthreads();
+
+  {
+    const int nn = tid & 31, pq = tid >> 5;
+    float fn = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) fn += nrm[1][k][nn];
+    const float fin = 1.0f / fmaxf(sqrtf(fn), COS_EPS);
+#pragma unroll
+    for (int qd = 0; qd < 2; ++qd) {
+      const int p = pq + 16 * qd;
+      float sn = 0.0f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) sn += nrm[0][k][p];
+      const float v = (((red[0][p][nn] + red[1][p][nn]) + (red[2][p][nn] + red[3][p][nn])) +
+                       ((red[4][p][nn] + red[5][p][nn]) + (red[6][p][nn] + red[7][p][nn])));
+      val[p][nn] = v * (1.0f / fmaxf(sqrtf(sn), COS_EPS)) * fin;
+    }
+  }
+  __syncthreads();
+
+  if (tid < 32) {                                // one lane per patch: masking, winner, outputs, row maxima
+    const int n = tile * CS_TILE1 + tid;
+    const bool nvalid = n < Np;
+    const int nc = min(n, Np - 1);
+    auto masked = [&](int g) {
+      float v = val[g][tid];
+      if (is_select && g < G) v = v * (in_box(load_box(boxes, g, Hp, Wp), nc, Wp) ? 1.0f : 0.0f);
+      return v;
+    };
+    int best = 0;
+    float bv = -INFINITY;
+    if (is_select)
+      for (int g = 0; g < Gp; ++g) {
+        const float v = masked(g);
+        if (v > bv) { bv = v; best = g; }        // strict: ties keep the lowest map index
+      }
+    for (int g = 0; g < Gp; ++g) {
+      const float raw = val[g][tid], mv = masked(g);
+      const float o = is_select ? (g == best ? mv : 0.0f) : raw;
+      const float wv = (is_select && mask_work) ? mv : raw;
+      if (nvalid) {
+        out[(size_t)g * Np + n] = o;
+        work[(size_t)g * Np + n] = wv;
+      }
+      float m = nvalid ? wv : -INFINITY;
+#pragma unroll
+      for (int off = 16; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+      if (tid == 0) atomicMax(&peak[g], f2ord(m));
+    }
   }
 }
 
-// threshold at tau * rowmax, similarity-weighted mean feature (:687-691), in three deterministic steps:
-//   rowmax   grid (Gp)          peak[g] = max_n work[g][n]
-//   partial  grid (tiles, Gp)   partial[g][tile][:] = sum over the tile's surviving patches of w * feat[n][:]
-//   finish   grid (Gp)          seeds_out[g] = sum_tiles partial / clamp(sum w, 1e-8)
-constexpr int RF_TILE = 128;
+// grid (C / 32, Gp).  seeds_out[g][c] = sum_n w[n] feat[n][c] / clamp(sum_n w[n], 1e-8) with w = work[g] zeroed
+// below tau * peak[g] (:687-691).  Each wave compacts its quarter of the patch range (ballot + popcount, patch
+// order), then thread (member slot, channel quad) accumulates the surviving patches slot, slot+32, ...
+__global__ __launch_bounds__(CS_NT) void refine_aggregate_kernel(const float* __restrict__ feat,
+                                                                 const float* __restrict__ work,
+                                                                 const unsigned* __restrict__ peak_in,
+                                                                 unsigned* __restrict__ peak_zero, float tau,
+                                                                 float* __restrict__ seeds_out, int C, int Np, int Q) {
+  extern __shared__ unsigned char dyn_s[];
+  int* n_s = reinterpret_cast<int*>(dyn_s);                 // [4][Q]
+  float* w_s = reinterpret_cast<float*>(dyn_s) + 4 * Q;     // [4][Q]
+  __shared__ int cnt_s[4];
+  __shared__ float wpart_s[CS_NT];
+  __shared__ float4 part_s[CS_NT];
+  const int chunk = blockIdx.x, g = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (chunk == 0 && g == 0 && tid < PMAX) peak_zero[tid] = 0u;
+  const float thr = ord2f(peak_in[g]) * tau;
+  const float* wrow = work + (size_t)g * Np;
 
-__global__ __launch_bounds__(CS_NT) void refine_rowmax_kernel(const float* __restrict__ work, float* __restrict__ peak,
-                                                              int Np) {
-  __shared__ float sh[CS_NT];
-  const int g = blockIdx.x, tid = threadIdx.x;
-  float mx = -INFINITY;
-  for (int n = tid; n < Np; n += CS_NT) mx = fmaxf(mx, work[(size_t)g * Np + n]);
-  sh[tid] = mx;
+  {                                              // wave-local compaction of patches [wave*Q, wave*Q + Q)
+    int cnt = 0;
+    constexpr int R = 8;
+    const int lo = wave * Q, hi = min(lo + Q, Np);
+    for (int r0 = lo; r0 < hi; r0 += 64 * R) {
+      float v[R];
+#pragma unroll
+      for (int k = 0; k < R; ++k) v[k] = wrow[min(r0 + 64 * k + lane, Np - 1)];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int k = 0; k < R; ++k) {
+        const int n = r0 + 64 * k + lane;
+        float w = v[k];
+        if (w < thr) w = 0.0f;                   // cos_map1[cos_map1 < thr] *= 0
+        const bool live = n < hi && w != 0.0f;
+        const unsigned long long m = __ballot(live);
+        if (live) {
+          const int pos = cnt + __popcll(m & ((1ull << lane) - 1ull));
+          n_s[wave * Q + pos] = n;
+          w_s[wave * Q + pos] = w;
+        }
+        cnt += __popcll(m);
+      }
+    }
+    if (lane == 0) cnt_s[wave] = cnt;
+  }
   __syncthreads();
-  for (int o = CS_NT / 2; o > 0; o >>= 1) {
-    if (tid < o) sh[tid] = fmaxf(sh[tid], sh[tid + o]);
+  const int c0 = cnt_s[0], c1 = c0 + cnt_s[1], c2 = c1 + cnt_s[2], nlive = c2 + cnt_s[3];
+  auto slot_of = [&](int i) {                     // i-th surviving patch in patch order -> index into n_s / w_s
+    return i < c0 ? i : i < c1 ? Q + (i - c0) : i < c2 ? 2 * Q + (i - c1) : 3 * Q + (i - c2);
+  };
+
+  float wp = 0.0f;
+  for (int i = tid; i < nlive; i += CS_NT) wp += w_s[slot_of(i)];
+  wpart_s[tid] = wp;
+
+  const int cq = tid & 7, ms = tid >> 3;
+  const float* fb = feat + chunk * SH_CH + cq * 4;
+  float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  constexpr int U = 8;
+  for (int i0 = ms; i0 < nlive; i0 += 32 * U) {
+    float4 f[U];
+    float w[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int sl = slot_of(min(i0 + 32 * u, nlive - 1));
+      f[u] = *reinterpret_cast<const float4*>(fb + (size_t)n_s[sl] * C);
+      w[u] = i0 + 32 * u < nlive ? w_s[sl] : 0.0f;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      acc.x = fmaf(w[u], f[u].x, acc.x); acc.y = fmaf(w[u], f[u].y, acc.y);
+      acc.z = fmaf(w[u], f[u].z, acc.z); acc.w = fmaf(w[u], f[u].w, acc.w);
+    }
+  }
+  part_s[tid] = acc;
+  __syncthreads();
+  for (int o = CS_NT / 2; o > 0; o >>= 1) {      // total weight, fixed tree
+    if (tid < o) wpart_s[tid] += wpart_s[tid + o];
     __syncthreads();
   }
-  if (tid == 0) peak[g] = sh[0];
-}
-
-template <int CPT>
-__global__ __launch_bounds__(CS_NT) void refine_partial_kernel(const float* __restrict__ feat,
-                                                               const float* __restrict__ work,
-                                                               const float* __restrict__ peak, float tau,
-                                                               float* __restrict__ partial, float* __restrict__ partial_w,
-                                                               int C, int Np, int ntile) {
-  __shared__ float w_s[RF_TILE];
-  const int tile = blockIdx.x, g = blockIdx.y, tid = threadIdx.x;
-  const int n0 = tile * RF_TILE;
-  const int count = min(RF_TILE, Np - n0);
-  const float thr = peak[g] * tau;
-  if (tid < RF_TILE) {
-    float w = 0.0f;
-    if (tid < count) { w = work[(size_t)g * Np + n0 + tid]; if (w < thr) w = 0.0f; }   // cos_map1[cos_map1 < thr] *= 0
-    w_s[tid] = w;
-  }
-  __syncthreads();
-  // surviving patches, in patch order (thread 0 compacts: <= RF_TILE entries), then the weighted sum with 8 feature
-  // rows in flight per trip -- the same order of fma's as a plain loop, without one exposed load latency per patch
-  __shared__ int j_s[RF_TILE];
-  __shared__ int nlive_s;
-  if (tid == 0) {
-    int nl = 0;
-    for (int j = 0; j < count; ++j)
-      if (w_s[j] != 0.0f) j_s[nl++] = j;
-    nlive_s = nl;
-  }
-  __syncthreads();
-  const int nlive = nlive_s;
-  float acc[CPT], wsum = 0.0f;
+  if (tid < SH_CH) {
+    const float* pf = reinterpret_cast<const float*>(part_s) + (tid >> 2) * 4 + (tid & 3);
+    float v0 = 0.0f, v1 = 0.0f, v2 = 0.0f, v3 = 0.0f;
 #pragma unroll
-  for (int i = 0; i < CPT; ++i) acc[i] = 0.0f;
-  constexpr int UNR = 8;
-  for (int q0 = 0; q0 < nlive; q0 += UNR) {
-    float f[UNR][CPT];
-#pragma unroll
-    for (int u = 0; u < UNR; ++u) {
-      const float* frow = feat + (size_t)(n0 + j_s[min(q0 + u, nlive - 1)]) * C;
-#pragma unroll
-      for (int i = 0; i < CPT; ++i) {
-        const int c = tid + i * CS_NT;
-        f[u][i] = c < C ? frow[c] : 0.0f;
-      }
+    for (int k = 0; k < 32; k += 4) {
+      v0 += pf[(k + 0) * 32]; v1 += pf[(k + 1) * 32]; v2 += pf[(k + 2) * 32]; v3 += pf[(k + 3) * 32];
     }
-#pragma unroll
-    for (int u = 0; u < UNR; ++u) {
-      if (q0 + u < nlive) {                        // workgroup-uniform
-        const float w = w_s[j_s[q0 + u]];
-        wsum += w;
-#pragma unroll
-        for (int i = 0; i < CPT; ++i) acc[i] = fmaf(w, f[u][i], acc[i]);
-      }
-    }
-  }
-  float* pp = partial + ((size_t)g * ntile + tile) * C;
-#pragma unroll
-  for (int i = 0; i < CPT; ++i) {
-    const int c = tid + i * CS_NT;
-    if (c < C) pp[c] = acc[i];
-  }
-  if (tid == 0) partial_w[g * ntile + tile] = wsum;
-}
-
-__global__ __launch_bounds__(CS_NT) void refine_finish_kernel(const float* __restrict__ partial,
-                                                              const float* __restrict__ partial_w,
-                                                              float* __restrict__ seeds_out, int C, int ntile) {
-  const int g = blockIdx.x, tid = threadIdx.x;
-  float wsum = 0.0f;
-  for (int t = 0; t < ntile; ++t) wsum += partial_w[g * ntile + t];
-  const float den = fmaxf(wsum, 1e-8f);
-  for (int c = tid; c < C; c += CS_NT) {
-    float v = 0.0f;
-    for (int t = 0; t < ntile; ++t) v += partial[((size_t)g * ntile + t) * C + c];
-    seeds_out[(size_t)g * C + c] = v / den;
+    seeds_out[(size_t)g * C + chunk * SH_CH + tid] = ((v0 + v1) + (v2 + v3)) / fmaxf(wpart_s[0], 1e-8f);
   }
 }
 
-struct RefineWs { size_t invn, invnp, ints, part_stats, work, peak, partial, partial_w, total; int nt1, ntile; };
+struct RefineWs { size_t work, peak, total; int nt1, Q; };
 RefineWs refine_ws(int C, int Np, int Gp) {
   RefineWs w;
   auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
   w.nt1 = as_ceil_div(Np, CS_TILE1);
+  w.Q = as_round_up(as_ceil_div(Np, 4), 64);
   size_t o = 0;
-  w.invn = o; o = al(o + (size_t)Np * 4);
-  w.invnp = o; o = al(o + (size_t)PMAX * 4);
-  w.ints = o; o = al(o + 64);
-  w.part_stats = o; o = al(o + (size_t)w.nt1 * PMAX * 8);
   w.work = o; o = al(o + (size_t)Gp * Np * 4);
-  w.ntile = as_ceil_div(Np, RF_TILE);
-  w.peak = o; o = al(o + (size_t)PMAX * 4);
-  w.partial = o; o = al(o + (size_t)Gp * w.ntile * C * 4);
-  w.partial_w = o; o = al(o + (size_t)Gp * w.ntile * 4);
+  w.peak = o; o = al(o + (size_t)2 * PMAX * 4);
   w.total = o;
   return w;
 }
@@ -935,47 +907,31 @@ extern "C" int as_refine_similarity(const float* feat, const float* seeds, const
                                     size_t ws_bytes, int C, int Hp, int Wp, as_stream_t stream) {
   AS_REQUIRE(feat && seeds && maps && seeds_out && ws && (boxes || !is_select), AS_E_BADARG, "as_refine_similarity: null pointer");
   AS_REQUIRE(G >= 0 && Gp > 0 && G <= Gp && Gp <= PMAX, AS_E_UNSUPPORTED, "as_refine_similarity: Gp=%d seeds (max %d)", Gp, PMAX);
-  AS_REQUIRE(C % 8 == 0 && C <= 4 * CS_NT && Hp > 0 && Wp > 0 && refine_times >= 0, AS_E_UNSUPPORTED,
-             "as_refine_similarity: C=%d must be a multiple of 8 and <= 1024", C);
+  AS_REQUIRE(C % SH_CH == 0 && C <= 4 * CS_NT && Hp > 0 && Wp > 0 && refine_times >= 0, AS_E_UNSUPPORTED,
+             "as_refine_similarity: C=%d must be a multiple of %d and <= 1024", C, SH_CH);
   const int Np = Hp * Wp;
   const RefineWs L = refine_ws(C, Np, Gp);
   AS_REQUIRE(ws_bytes >= L.total, AS_E_WORKSPACE, "as_refine_similarity: workspace %zu < %zu bytes", ws_bytes, L.total);
+  const size_t lds = (size_t)8 * 4 * L.Q;
+  AS_REQUIRE(lds <= 120 * 1024, AS_E_UNSUPPORTED, "as_refine_similarity: %d patches exceed the aggregation list", Np);
   hipStream_t s = (hipStream_t)stream;
   char* w = (char*)ws;
-  float* invn = (float*)(w + L.invn);
-  float* invnp = (float*)(w + L.invnp);
-  int32_t* ints = (int32_t*)(w + L.ints);
-  float* part_stats = (float*)(w + L.part_stats);
   float* work = (float*)(w + L.work);
-  float* peak = (float*)(w + L.peak);
-  float* partial = (float*)(w + L.partial);
-  float* partial_w = (float*)(w + L.partial_w);
-  const int cpt = as_ceil_div(C, CS_NT);
+  unsigned* peak = (unsigned*)(w + L.peak);
+  if (lds > 48 * 1024)
+    (void)hipFuncSetAttribute((const void*)refine_aggregate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 
-  hipLaunchKernelGGL(refine_setup_kernel, dim3(1), dim3(64), 0, s, ints, Hp, Wp);
-  hipLaunchKernelGGL(row_invnorm_kernel, dim3(as_ceil_div(Np, 4)), dim3(CS_NT), 0, s, feat, invn, Np, C);
+  (void)hipMemsetAsync(peak, 0, (size_t)2 * PMAX * 4, s);
   const float* cur = seeds;
   for (int lvl = 0; lvl <= refine_times; ++lvl) {
     if (lvl > 0) {
-#define AS_AGG(CPT)                                                                                          \
-  hipLaunchKernelGGL((refine_partial_kernel<CPT>), dim3(L.ntile, Gp), dim3(CS_NT), 0, s, feat, work, peak, tau, \
-                     partial, partial_w, C, Np, L.ntile)
-      hipLaunchKernelGGL(refine_rowmax_kernel, dim3(Gp), dim3(CS_NT), 0, s, work, peak, Np);
-      switch (cpt) {
-        case 1: AS_AGG(1); break;
-        case 2: AS_AGG(2); break;
-        case 3: AS_AGG(3); break;
-        default: AS_AGG(4); break;
-      }
-      hipLaunchKernelGGL(refine_finish_kernel, dim3(Gp), dim3(CS_NT), 0, s, partial, partial_w, seeds_out, C, L.ntile);
-#undef AS_AGG
+      hipLaunchKernelGGL(refine_aggregate_kernel, dim3(C / SH_CH, Gp), dim3(CS_NT), lds, s, feat, work,
+                         peak + ((lvl - 1) & 1) * PMAX, peak + (lvl & 1) * PMAX, tau, seeds_out, C, Np, L.Q);
       cur = seeds_out;
     }
-    hipLaunchKernelGGL(prot_invnorm_kernel, dim3(as_ceil_div(Gp, 4)), dim3(CS_NT), 0, s, cur, invnp, 1, Gp, C);
-    hipLaunchKernelGGL((sim_kernel<true>), dim3(L.nt1, 1), dim3(CS_NT), 0, s, feat, invn, cur, invnp, ints, ints + 4,
-                       (const int32_t*)nullptr, work, part_stats, C, Hp, Wp, Gp, L.nt1);
-    hipLaunchKernelGGL(refine_select_kernel, dim3(as_ceil_div(Np, CS_NT)), dim3(CS_NT), 0, s, work, boxes,
-                       maps + (size_t)lvl * Gp * Np, G, Gp, Hp, Wp, is_select, lvl > 0 ? 1 : 0);
+    hipLaunchKernelGGL(refine_sim_kernel, dim3(L.nt1), dim3(S1_NT), 0, s, feat, cur, boxes, work,
+                       maps + (size_t)lvl * Gp * Np, peak + (lvl & 1) * PMAX, G, Gp, C, Hp, Wp, is_select,
+                       lvl > 0 ? 1 : 0);
   }
   if (refine_times == 0)
     (void)hipMemcpyAsync(seeds_out, seeds, (size_t)Gp * C * 4, hipMemcpyDeviceToDevice, s);

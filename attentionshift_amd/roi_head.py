@@ -243,6 +243,20 @@ def seed_features(point_xy, feat_chw):
     return feat_chw.permute(1, 2, 0)[py, px].mean(dim=1)
 
 
+def feature_tokens(vit_feat):
+    """[B,C,hp,wp] (any strides) -> fp32 [B,Np,C] whose per-image slices are contiguous: the layout every kernel of
+    this path reads.  The reference's caller builds vit_feat as a permuted VIEW of the token-major last_feat
+    (two_stage_point_align.py:77); for such an input this is a view too (no copy).  Anything else is transposed once
+    per batch here instead of once per consumer."""
+    B, C = vit_feat.shape[:2]
+    t = vit_feat.flatten(2).transpose(1, 2)
+    if t.dtype != torch.float32:
+        return t.to(torch.float32, memory_format=torch.contiguous_format)
+    if t.stride(2) != 1 or t.stride(1) != C:
+        t = t.contiguous()
+    return t
+
+
 def candidate_masks(map_fg, map_bg, crops, pos_thr, neg_thr, corr_size):
     """Candidate pixels of stdroi:442-443 for every object at once, as full-size byte masks that are zero
     outside each object's crop: fg = erode(map_fg > cropmax*pos_thr, corr_size), bg = map_bg > cropmax*neg_thr."""
@@ -393,13 +407,16 @@ def merge_parts(prot, keep, thr):
 
 
 def part_similarity(prot_list, feat_chw):
-    """stdroi:297-301 cal_similarity for every object with ONE normalisation of the feature map."""
+    """stdroi:297-301 cal_similarity for every object: one similarity pass per <= 32 merged prototypes (norms of both
+    operands inside the kernel; no normalised copy of the feature map)."""
     C, hp, wp = feat_chw.shape
     sizes = [0 if isinstance(p, list) else p.shape[0] for p in prot_list]
     if sum(sizes) == 0:
         return [torch.zeros(0, 0) for _ in prot_list]
-    allp = torch.cat([p for p in prot_list if not isinstance(p, list)])
-    sim = (_unit(allp) @ _unit(feat_chw.flatten(1).t()).t()).reshape(-1, hp, wp)
+    allp = torch.cat([p for p in prot_list if not isinstance(p, list)]).contiguous()
+    feat_tok = feat_chw.flatten(1).t().contiguous()                      # a view when feat_chw views token-major storage
+    sim = torch.cat([ops.refine_similarity(feat_tok, allp[o:o + 32], None, 0, 0, 1.0, False, hp, wp)[0][0]
+                     for o in range(0, allp.shape[0], 32)]).reshape(-1, hp, wp)
     out, off = [], 0
     for n in sizes:
         out.append(sim[off:off + n] if n else torch.zeros(0, 0))
@@ -580,7 +597,7 @@ class AttnShiftRoIHead(nn.Module):
         pout, sim = ops.cosine_shift(feat_tok[None], box_patch, obj_img, prot, n_shift, hp, wp, tau, temp)
         return pout.flatten(0, 1), sim.reshape(-1, hp, wp).clamp(0)
 
-    def mean_shift_batch(self, coords_list, feats_list, rois_list, n_shift, tau=0.1, temp=0.1):
+    def mean_shift_batch(self, coords_list, feats_list, rois_list, n_shift, tau=0.1, temp=0.1, feat_tok=None):
         """mean_shift_grid_prototype for every image of the batch in ONE as_cosine_shift call (coords_list[i] =
         grid_seed_coords of image i; the objects carry their
         image index; the kernels are batched over objects, and a call's latency does not depend on how many objects it
@@ -592,7 +609,8 @@ class AttnShiftRoIHead(nn.Module):
             prots.append(feat.permute(1, 2, 0)[coords[..., 0], coords[..., 1]])
             boxes.append((rois // STRIDE).to(torch.int32))
             owners.append(torch.full((coords.shape[0],), i, dtype=torch.int32, device=feat.device))
-        feat_tok = torch.stack([f.flatten(1).t() for f in feats_list]).contiguous()
+        if feat_tok is None or not feat_tok.is_contiguous():
+            feat_tok = torch.stack([f.flatten(1).t() for f in feats_list]).contiguous()
         pout, sim = ops.cosine_shift(feat_tok, torch.cat(boxes).contiguous(), torch.cat(owners), torch.cat(prots).contiguous(),
                                      n_shift, hp, wp, tau, temp)
         out, off = [], 0
@@ -746,7 +764,8 @@ class AttnShiftRoIHead(nn.Module):
                    inst_bg_feat=[])
         coords_sc_org, labels_sc_org, map_cos_bg_ret, sim_fg_ret = [], [], [], []
         CLOCK.mark("select")
-        feats = [vit_feat[i].float().contiguous() for i in range(num_imgs)]
+        feat_tok = feature_tokens(vit_feat)                                   # [B, Np, C], per-image contiguous
+        feats = [feat_tok[i].t().unflatten(1, (patch_h, patch_w)) for i in range(num_imgs)]   # [C,hp,wp] views
 
         def phase_a(i):
             """Refinement (B2), then EVERYTHING that depends only on the refined maps is queued on the device -- the
@@ -802,7 +821,8 @@ class AttnShiftRoIHead(nn.Module):
         if bool(bad_cam):
             raise RuntimeError("seed_pseudo_gt: a CAM has no foreground component (constant attention map)")
         if self.batch_mean_shift or num_imgs == 1:           # ONE mean-shift call for the whole batch
-            shifted = self.mean_shift_batch([r[6][1] for r in ra], feats, pseudo_boxes, self.mean_shift_times_local)
+            shifted = self.mean_shift_batch([r[6][1] for r in ra], feats, pseudo_boxes, self.mean_shift_times_local,
+                                            feat_tok=feat_tok)
         else:
             shifted = [self.mean_shift_batch([ra[i][6][1]], [feats[i]], [pseudo_boxes[i]], self.mean_shift_times_local)[0]
                        for i in range(num_imgs)]

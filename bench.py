@@ -55,7 +55,13 @@ def build(device, rng_mode="fast", train=False, ranks=None):
     rank = int(os.environ.get("RANK", "0"))                # every rank works on its own images (weak scaling)
     shift = [synthetic.shift_inputs(1234 + rank * B + b, hp, wp, CFG["embed_dim"], G, Lc) for b in range(B)]
     cams = torch.stack([s["cams"].flatten(2) for s in shift]).to(device)          # [B, Lc, G, Np]
-    vit_feat = torch.stack([s["vit_feat"] for s in shift]).to(device)             # [B, C, hp, wp]
+    # vit_feat reaches seed_pseudo_gt the way the reference's caller builds it (two_stage_point_align.py:77): a
+    # permuted VIEW [B, C, hp, wp] of the token-major last_feat [B, 1 + Np, C] with the cls row dropped
+    last = torch.zeros(B, 1 + hp * wp, CFG["embed_dim"])
+    last[:, 1:] = torch.stack([s["vit_feat"].flatten(1).t() for s in shift])
+    vit_feat = last.to(device).permute(0, 2, 1)[..., 1:].unflatten(-1, (hp, wp))
+    if os.environ.get("AS_BENCH_CHW", "0") == "1":          # A/B: channel-major contiguous copy instead of the view
+        vit_feat = vit_feat.contiguous()
     gt_points = [s["points"].to(device) for s in shift]
     gt_labels = [s["labels"].to(device) for s in shift]
 

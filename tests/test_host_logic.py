@@ -166,7 +166,13 @@ def test_semantic_center_host_logic_with_oracle_backed_shift(golden, tag, monkey
         p, s = O.cosine_shift(prot.clone(), feat[0][None] * inbox[..., None], feat[0], tau0, temp, n_shift)
         return p.reshape(prot.shape), s.reshape(prot.shape[0], prot.shape[1], -1)
 
+    def fake_refine_similarity(feat, seeds, boxes_patch, num_obj, refine_times, tau, is_select, hp_, wp_):
+        assert refine_times == 0 and not is_select          # part_similarity only needs the plain cosine map
+        cos = torch.nn.functional.cosine_similarity(seeds[:, None, :], feat[None, :, :], dim=-1)
+        return cos[None], seeds.clone()
+
     monkeypatch.setattr(RH.ops, "cosine_shift", fake_cosine_shift)
+    monkeypatch.setattr(RH.ops, "refine_similarity", fake_refine_similarity)
     monkeypatch.setattr(RH.ops, "crop_threshold_erode", fake_crop_threshold_erode)
     monkeypatch.setattr(RH.ops, "rank_select", fake_rank_select)
     head = A.AttnShiftRoIHead(num_semantic_points=int(g["num_semantic_points"]), mean_shift_times_local=int(g["n_shift"]))

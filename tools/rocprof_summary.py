@@ -14,7 +14,8 @@ def main(db, out, title):
     lines = [f"# {title}", "", f"source: `{db}` (rocprofv3 --kernel-trace --stats); durations in microseconds", "",
              "| kernel | calls | total us | avg us | min us | max us | % | VGPR | LDS B |", "|---|---|---|---|---|---|---|---|---|"]
     for name, n, tot, avg, mn, mx, vg, lds in rows[:60]:
-        short = name if len(name) < 110 else name[:107] + "..."
+        width = int(__import__("os").environ.get("PROF_NAME_WIDTH", "110"))
+        short = name if len(name) < width else name[:width - 3] + "..."
         lines.append(f"| `{short}` | {n} | {tot / 1e3:.1f} | {avg / 1e3:.2f} | {mn / 1e3:.2f} | {mx / 1e3:.2f} | "
                      f"{100.0 * tot / total:.1f} | {vg} | {lds} |")
     lines.append("")
