@@ -190,10 +190,9 @@ __global__ void cam_meta_init_kernel(CamMeta* meta, int M) {
   meta[m] = c;
 }
 
-// min / max of the upsampled map (and optionally the map itself); zeroes the area array; grid (blocks, M)
+// min / max of the upsampled map (and optionally the map itself); grid (blocks, M)
 __global__ __launch_bounds__(CC_NT) void cam_minmax_kernel(const float* __restrict__ cams, CamMeta* __restrict__ meta,
-                                                           float* __restrict__ cams_up, int32_t* __restrict__ area,
-                                                           int Hp, int Wp, int up) {
+                                                           float* __restrict__ cams_up, int Hp, int Wp, int up) {
   __shared__ float smn[CC_NT], smx[CC_NT];
   const int m = blockIdx.y, H = Hp * up, W = Wp * up;
   const float* src = cams + (size_t)m * Hp * Wp;
@@ -203,7 +202,6 @@ __global__ __launch_bounds__(CC_NT) void cam_minmax_kernel(const float* __restri
     const int y = i / W, x = i - y * W;
     const float v = bilerp(src, Wp, lerp_axis(y, Hp, sy), lerp_axis(x, Wp, sx));
     if (cams_up != nullptr) cams_up[(size_t)m * H * W + i] = v;
-    area[(size_t)m * H * W + i] = 0;
     mn = fminf(mn, v);
     mx = fmaxf(mx, v);
   }
@@ -222,69 +220,187 @@ __global__ __launch_bounds__(CC_NT) void cam_minmax_kernel(const float* __restri
   }
 }
 
-__global__ __launch_bounds__(CC_NT) void cam_maxarea_kernel(const int32_t* __restrict__ L,
-                                                            const int32_t* __restrict__ area,
-                                                            CamMeta* __restrict__ meta, int M, int HW) {
-  const size_t i = (size_t)blockIdx.x * CC_NT + threadIdx.x;
-  if (i >= (size_t)M * HW) return;
-  const int m = (int)(i / HW), p = (int)(i % HW);
-  if (L[i] == p) atomicMax(&meta[m].max_area, area[i]);      // roots only
-}
-
-// per row: extent and count of the pixels whose component passes the area filter; grid (H, M)
-struct RowMeta { int x0, x1, cnt, pad; };
-__global__ __launch_bounds__(CC_NT) void cam_row_extent_kernel(const int32_t* __restrict__ Lall,
-                                                               const int32_t* __restrict__ area,
-                                                               const CamMeta* __restrict__ meta,
-                                                               RowMeta* __restrict__ rows, float area_ratio, int H, int W) {
-  __shared__ int s0[CC_NT], s1[CC_NT], sc[CC_NT];
-  const int y = blockIdx.x, m = blockIdx.y, tid = threadIdx.x;
-  const size_t base = ((size_t)m * H + y) * W;
-  const float need = area_ratio * (float)meta[m].max_area;   // stdroi:84: fp32 compare of an int area
-  int x0 = 0x7fffffff, x1 = -1, cnt = 0;
-  for (int x = tid; x < W; x += CC_NT) {
-    const int root = Lall[base + x];
-    if (root >= 0 && (float)area[(size_t)m * H * W + root] >= need) {
-      x0 = min(x0, x); x1 = max(x1, x); ++cnt;
+// ---- run-based CAM -> box path (no per-pixel label array) ---------------------------------------------------
+// The foreground of an upsampled CAM is a handful of blobs: a row holds a few runs.  The box stage only needs the
+// PARTITION of the foreground (areas, kept set, extents; stdroi:69-96), so the components are built over runs:
+//   cam_runs   one wave per image row: foreground bits by ballot, run (x0,x1) pairs written per row
+//   cam_cc     one workgroup per map: union-find over the runs (8-connectivity: runs of adjacent rows whose column
+//              ranges touch or overlap diagonally), areas, area filter, extents, the 'expand' box
+// Links go from the larger run id to the smaller (atomicMin) and areas / extents are integers, so the result does
+// not depend on scheduling; it is the same partition the per-pixel path labels (tested against it).
+__global__ __launch_bounds__(CC_NT) void cam_runs_kernel(FgCam fg, uint32_t* __restrict__ runs,
+                                                         int32_t* __restrict__ nruns, int H, int W, int rmax) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int y = blockIdx.x * 4 + wave, m = blockIdx.y;
+  if (y >= H) return;
+  uint32_t* out = runs + ((size_t)m * H + y) * rmax;
+  int n = 0, open = -1;                                   // wave-uniform: runs so far, start of the open run
+  for (int x0 = 0; x0 < W; x0 += 64) {
+    const int x = x0 + lane;
+    const bool isfg = x < W && fg(m, y, x, H, W);
+    const unsigned long long b = __ballot(isfg);
+    const unsigned long long prev = (b << 1) | (open >= 0 ? 1ull : 0ull);
+    unsigned long long starts = b & ~prev;                // pixel is foreground, its left neighbour is not
+    unsigned long long ends = ~b & prev;                  // pixel is background, its left neighbour was foreground
+    while (starts | ends) {
+      const int is = starts ? __ffsll((long long)starts) - 1 : 64;
+      const int ie = ends ? __ffsll((long long)ends) - 1 : 64;
+      if (ie < is) {
+        if (lane == 0 && n < rmax) out[n] = (uint32_t)open | ((uint32_t)(x0 + ie - 1) << 16);
+        ++n; open = -1; ends &= ends - 1;
+      } else {
+        open = x0 + is; starts &= starts - 1;
+      }
     }
   }
-  s0[tid] = x0; s1[tid] = x1; sc[tid] = cnt;
-  __syncthreads();
-  for (int o = CC_NT / 2; o > 0; o >>= 1) {
-    if (tid < o) { s0[tid] = min(s0[tid], s0[tid + o]); s1[tid] = max(s1[tid], s1[tid + o]); sc[tid] += sc[tid + o]; }
-    __syncthreads();
+  if (open >= 0) {
+    if (lane == 0 && n < rmax) out[n] = (uint32_t)open | ((uint32_t)(W - 1) << 16);
+    ++n;
   }
-  if (tid == 0) { RowMeta r; r.x0 = s0[0]; r.x1 = s1[0]; r.cnt = sc[0]; r.pad = 0; rows[(size_t)m * H + y] = r; }
+  if (lane == 0) nruns[(size_t)m * H + y] = n;            // n > rmax: overflow, reported through status
 }
 
-// per map: reduce the rows, then the 'expand' box of stdroi:97-115; grid (M)
-__global__ __launch_bounds__(CC_NT) void cam_box_kernel(const RowMeta* __restrict__ rows, const CamMeta* __restrict__ meta,
-                                                        const float* __restrict__ points, float* __restrict__ boxes,
-                                                        int32_t* __restrict__ status, float* __restrict__ minmax, int H,
-                                                        int W) {
-  __shared__ int s0[CC_NT], s1[CC_NT], sy0[CC_NT], sy1[CC_NT], sc[CC_NT];
-  const int m = blockIdx.x, tid = threadIdx.x;
+constexpr int CCM_NT = 1024;
+constexpr int CCM_HMAX = 2048;          // rows whose run offsets fit the LDS scan
+constexpr int CCM_RCAP = 18432;         // runs per map whose parents + run words fit LDS (else the workspace arrays)
+
+struct CcShared { int32_t* offs; int *s_max, *s_changed, *s_x0, *s_x1, *s_y0, *s_y1, *s_cnt; };
+
+// Components over the runs of one map: hook-and-shortcut rounds (every adjacency hooks the larger of the two current
+// parents onto the smaller, then every run jumps to its grandparent twice) until nothing changes.  A blob as tall as
+// the image is a chain of hundreds of stacked runs: a find-based union walks such chains one dependent access at a
+// time (55 us measured), the rounds need about log2(chain) passes of a few LDS operations per thread.  Parents only
+// ever decrease and end at the component's smallest run id, whatever the scheduling.  `parent` / `rw` (run words,
+// compact ids) are in LDS or, for maps with more runs than fit, in the workspace.
+__device__ __forceinline__ void cam_cc_body(int32_t* parent, const uint32_t* rw, int32_t* __restrict__ area,
+                                            const CcShared sh, int R, int H, float area_ratio) {
+  const int tid = threadIdx.x;
+  const int32_t* offs = sh.offs;
+  int &s_max = *sh.s_max, &s_changed = *sh.s_changed, &s_x0 = *sh.s_x0, &s_x1 = *sh.s_x1, &s_y0 = *sh.s_y0,
+      &s_y1 = *sh.s_y1, &s_cnt = *sh.s_cnt;
+  for (int i = tid; i < R; i += CCM_NT) { parent[i] = i; area[i] = 0; }
+  __syncthreads();
+  for (;;) {
+    if (tid == 0) s_changed = 0;
+    __syncthreads();
+    bool ch = false;
+    for (int y = 1 + tid; y < H; y += CCM_NT) {            // hooks across the (y-1, y) row boundary
+      const int a0 = offs[y], a1 = offs[y + 1], b0 = offs[y - 1], b1 = a0;
+      int kb = b0;
+      for (int ka = a0; ka < a1; ++ka) {
+        const uint32_t ra = rw[ka];
+        const int ax0 = (int)(ra & 0xffffu), ax1 = (int)(ra >> 16);
+        while (kb < b1 && (int)(rw[kb] >> 16) + 1 < ax0) ++kb;          // upper runs entirely to the left
+        for (int k = kb; k < b1; ++k) {
+          if ((int)(rw[k] & 0xffffu) > ax1 + 1) break;                  // 8-connectivity: ranges touch diagonally
+          const int pu = __hip_atomic_load(&parent[ka], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const int pv = __hip_atomic_load(&parent[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (pu != pv) { atomicMin(&parent[max(pu, pv)], min(pu, pv)); ch = true; }
+        }
+      }
+    }
+    if (ch) s_changed = 1;
+    __syncthreads();
+    const bool again = s_changed != 0;
+    for (int rep = 0; rep < 2; ++rep) {                    // shortcut twice
+      for (int i = tid; i < R; i += CCM_NT) {
+        const int p = __hip_atomic_load(&parent[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int gp = __hip_atomic_load(&parent[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (gp != p) __hip_atomic_store(&parent[i], gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      __syncthreads();
+    }
+    if (!again) break;
+  }
+  // after a round without hooks every run's parent is its root (the last shortcuts flattened what the previous
+  // round hooked); areas per root, largest area, then extents of the runs whose component passes the filter
+  for (int i = tid; i < R; i += CCM_NT) {
+    const uint32_t r = rw[i];
+    atomicAdd(&area[parent[i]], (int)(r >> 16) - (int)(r & 0xffffu) + 1);
+  }
+  __syncthreads();
+  for (int i = tid; i < R; i += CCM_NT)
+    if (parent[i] == i) atomicMax(&s_max, __hip_atomic_load(&area[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  __syncthreads();
+  const float need = area_ratio * (float)s_max;            // stdroi:84: fp32 compare of an int area
   int x0 = 0x7fffffff, x1 = -1, y0 = 0x7fffffff, y1 = -1, cnt = 0;
-  for (int y = tid; y < H; y += CC_NT) {
-    const RowMeta r = rows[(size_t)m * H + y];
-    if (r.cnt > 0) { x0 = min(x0, r.x0); x1 = max(x1, r.x1); y0 = min(y0, y); y1 = max(y1, y); cnt += r.cnt; }
-  }
-  s0[tid] = x0; s1[tid] = x1; sy0[tid] = y0; sy1[tid] = y1; sc[tid] = cnt;
-  __syncthreads();
-  for (int o = CC_NT / 2; o > 0; o >>= 1) {
-    if (tid < o) {
-      s0[tid] = min(s0[tid], s0[tid + o]); s1[tid] = max(s1[tid], s1[tid + o]);
-      sy0[tid] = min(sy0[tid], sy0[tid + o]); sy1[tid] = max(sy1[tid], sy1[tid + o]); sc[tid] += sc[tid + o];
+  for (int y = tid; y < H; y += CCM_NT) {
+    for (int k = offs[y]; k < offs[y + 1]; ++k) {
+      const uint32_t r = rw[k];
+      if ((float)__hip_atomic_load(&area[parent[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need) {
+        const int rx0 = (int)(r & 0xffffu), rx1 = (int)(r >> 16);
+        x0 = min(x0, rx0); x1 = max(x1, rx1); y0 = min(y0, y); y1 = max(y1, y); cnt += rx1 - rx0 + 1;
+      }
     }
+  }
+  if (cnt > 0) {
+    atomicMin(&s_x0, x0); atomicMax(&s_x1, x1); atomicMin(&s_y0, y0); atomicMax(&s_y1, y1); atomicAdd(&s_cnt, cnt);
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(CCM_NT) void cam_cc_kernel(const uint32_t* __restrict__ runs_all,
+                                                        const int32_t* __restrict__ nruns_all,
+                                                        int32_t* __restrict__ parent_all, int32_t* __restrict__ area_all,
+                                                        uint32_t* __restrict__ rw_all,
+                                                        const CamMeta* __restrict__ meta, const float* __restrict__ points,
+                                                        float* __restrict__ boxes, int32_t* __restrict__ status,
+                                                        float* __restrict__ minmax, float area_ratio, int H, int W,
+                                                        int rmax) {
+  __shared__ int32_t offs[CCM_HMAX + 1];
+  __shared__ int32_t lds_parent[CCM_RCAP];
+  __shared__ uint32_t lds_rw[CCM_RCAP];
+  __shared__ int wsum[CCM_NT / 64];
+  __shared__ int s_max, s_over, s_x0, s_x1, s_y0, s_y1, s_cnt, s_changed, s_base;
+  const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t* runs = runs_all + (size_t)m * H * rmax;
+  const int32_t* nruns = nruns_all + (size_t)m * H;
+  if (tid == 0) { s_max = 0; s_over = 0; s_x0 = 0x7fffffff; s_x1 = -1; s_y0 = 0x7fffffff; s_y1 = -1; s_cnt = 0; s_base = 0; }
+  __syncthreads();
+  // exclusive scan of the per-row run counts -> compact run ids offs[y] + k
+  for (int y0 = 0; y0 < H; y0 += CCM_NT) {
+    const int y = y0 + tid;
+    int n = y < H ? nruns[y] : 0;
+    if (n > rmax) { s_over = 1; n = rmax; }
+    int v = n;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int u = __shfl_up(v, o);
+      if (lane >= o) v += u;
+    }
+    if (lane == 63) wsum[wave] = v;
+    __syncthreads();
+    int before = s_base;
+    for (int w = 0; w < wave; ++w) before += wsum[w];
+    if (y < H) offs[y] = before + v - n;
+    __syncthreads();
+    if (tid == CCM_NT - 1) s_base = before + v;
     __syncthreads();
   }
+  const int R = s_base;
+  if (tid == 0) offs[H] = R;
+  __syncthreads();
+  const bool fits = R <= CCM_RCAP;
+  uint32_t* rw_g = rw_all + (size_t)m * H * rmax;
+  for (int y = tid; y < H; y += CCM_NT)                   // compact the run words
+    for (int k = offs[y]; k < offs[y + 1]; ++k) {
+      const uint32_t r = runs[y * rmax + (k - offs[y])];
+      if (fits) lds_rw[k] = r; else rw_g[k] = r;
+    }
+  __syncthreads();
+  // two instantiations of the same body, so that the LDS one compiles to ds_ instructions instead of flat accesses
+  // through a generic pointer; areas are touched once per run and live in the workspace either way
+  int32_t* area = area_all + (size_t)m * H * rmax;
+  CcShared sh{offs, &s_max, &s_changed, &s_x0, &s_x1, &s_y0, &s_y1, &s_cnt};
+  if (fits) cam_cc_body(lds_parent, lds_rw, area, sh, R, H, area_ratio);
+  else cam_cc_body(parent_all + (size_t)m * H * rmax, rw_g, area, sh, R, H, area_ratio);
   if (tid != 0) return;
-  if (status != nullptr) status[m] = sc[0];
+  if (status != nullptr) status[m] = s_over ? -1 : s_cnt;
   if (minmax != nullptr) { minmax[m * 2 + 0] = ord2f(meta[m].mn); minmax[m * 2 + 1] = ord2f(meta[m].mx); }
   float* bx = boxes + (size_t)m * 4;
-  if (sc[0] == 0) { bx[0] = 0.f; bx[1] = 0.f; bx[2] = 1.f; bx[3] = 1.f; return; }
+  if (s_cnt == 0 || s_over) { bx[0] = 0.f; bx[1] = 0.f; bx[2] = 1.f; bx[3] = 1.f; return; }
   const float xc = points[m * 2 + 0], yc = points[m * 2 + 1];
-  const float xmin = (float)s0[0], xmax = (float)s1[0], ymin = (float)sy0[0], ymax = (float)sy1[0];
+  const float xmin = (float)s_x0, xmax = (float)s_x1, ymin = (float)s_y0, ymax = (float)s_y1;
   float gx0, gx1, gy0, gy1;
   if (fabsf(xc - xmin) > fabsf(xc - xmax)) {
     gx0 = xmin; gx1 = xc * 2.0f - gx0; gx1 = gx1 < (float)W ? gx1 : (float)W;
@@ -297,6 +413,62 @@ __global__ __launch_bounds__(CC_NT) void cam_box_kernel(const RowMeta* __restric
     gy1 = ymax; gy0 = yc * 2.0f - gy1; gy0 = gy0 > 0.0f ? gy0 : 0.0f;
   }
   bx[0] = gx0; bx[1] = gy0; bx[2] = gx1; bx[3] = gy1;
+}
+
+// ---- seed-sampling candidate masks straight from the low-resolution CAMs (stdroi:329-333, 343-371, 1003-1007) --
+// For the G selected maps of an image: nm = (up16(cam) - min) / (max - min) recomputed on the fly (same bilinear
+// code as the box stage, so the values are the ones the upsampled map would hold), and in ONE pass the three
+// candidate masks of sample_point_grid -- background nm < thr_bg per map, foreground nm >= thr_fg per map, shared
+// background mean_g(nm) < thr_bg -- with their candidate counts.  masks [2G+1][H*W] uint8, counts [2G+1].
+__global__ __launch_bounds__(CC_NT) void cam_sample_masks_kernel(const float* __restrict__ cams,
+                                                                 const int32_t* __restrict__ map_idx,
+                                                                 const float* __restrict__ minmax, int G, int Hp, int Wp,
+                                                                 int up, float thr_bg, float thr_fg,
+                                                                 uint8_t* __restrict__ masks, int32_t* __restrict__ counts) {
+  __shared__ int cnt_s[2 * 32 + 1];
+  const int H = Hp * up, W = Wp * up, HW = H * W, tid = threadIdx.x;
+  const float sy = (float)Hp / (float)H, sx = (float)Wp / (float)W;
+  for (int k = tid; k < 2 * G + 1; k += CC_NT) cnt_s[k] = 0;
+  __syncthreads();
+  int c_supp = 0;
+  for (int i4 = (blockIdx.x * CC_NT + tid) * 4; i4 < HW; i4 += gridDim.x * CC_NT * 4) {     // W % 4 == 0
+    const int y = i4 / W, x = i4 - y * W;
+    const Lerp ly = lerp_axis(y, Hp, sy);
+    Lerp lx[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) lx[j] = lerp_axis(x + j, Wp, sx);
+    float sum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int g = 0; g < G; ++g) {
+      const int mi = map_idx[g];
+      const float* src = cams + (size_t)mi * Hp * Wp;
+      const float lo = minmax[mi * 2 + 0], hi = minmax[mi * 2 + 1];
+      uchar4 bg, fg;
+      unsigned char* pb = reinterpret_cast<unsigned char*>(&bg);
+      unsigned char* pf = reinterpret_cast<unsigned char*>(&fg);
+      int cb = 0, cf = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float nm = (bilerp(src, Wp, ly, lx[j]) - lo) / (hi - lo);
+        sum[j] += nm;
+        pb[j] = nm < thr_bg ? 1 : 0;
+        pf[j] = nm >= thr_fg ? 1 : 0;
+        cb += pb[j]; cf += pf[j];
+      }
+      *reinterpret_cast<uchar4*>(masks + (size_t)g * HW + i4) = bg;
+      *reinterpret_cast<uchar4*>(masks + (size_t)(G + g) * HW + i4) = fg;
+      if (cb) atomicAdd(&cnt_s[g], cb);
+      if (cf) atomicAdd(&cnt_s[G + g], cf);
+    }
+    uchar4 sp;
+    unsigned char* ps = reinterpret_cast<unsigned char*>(&sp);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { ps[j] = (sum[j] / (float)G) < thr_bg ? 1 : 0; c_supp += ps[j]; }
+    *reinterpret_cast<uchar4*>(masks + (size_t)(2 * G) * HW + i4) = sp;
+  }
+  if (c_supp) atomicAdd(&cnt_s[2 * G], c_supp);
+  __syncthreads();
+  for (int k = tid; k < 2 * G + 1; k += CC_NT)
+    if (cnt_s[k]) atomicAdd(&counts[k], cnt_s[k]);
 }
 
 inline int blocks_for(size_t total) { return (int)((total + CC_NT - 1) / CC_NT); }
@@ -321,11 +493,29 @@ extern "C" int as_ccl_2d(const uint8_t* img, int32_t* labels, int M, int H, int 
   return AS_OK;
 }
 
+namespace {
+struct CamWs { size_t runs, nruns, parent, area, rw, meta, total; int rmax; };
+CamWs cam_ws(int M, int Hp, int Wp, int up) {
+  CamWs w;
+  const size_t H = (size_t)Hp * up;
+  // a row of the upsampled map is piecewise linear between the Wp source columns: at most one threshold crossing
+  // per interval, i.e. <= Wp/2 + 1 runs; Wp + 2 leaves room for rounding wiggles (overflow is reported, not hidden)
+  w.rmax = Wp + 2;
+  size_t o = 0;
+  w.runs = o; o = al256(o + (size_t)M * H * w.rmax * 4);
+  w.nruns = o; o = al256(o + (size_t)M * H * 4);
+  w.parent = o; o = al256(o + (size_t)M * H * w.rmax * 4);
+  w.area = o; o = al256(o + (size_t)M * H * w.rmax * 4);
+  w.rw = o; o = al256(o + (size_t)M * H * w.rmax * 4);
+  w.meta = o; o = al256(o + (size_t)M * sizeof(CamMeta));
+  w.total = o;
+  return w;
+}
+}  // namespace
+
 extern "C" size_t as_cam_boxes_workspace_bytes(int M, int Hp, int Wp, int up) {
   if (M <= 0 || Hp <= 0 || Wp <= 0 || up <= 0) return 0;
-  const size_t hw = (size_t)Hp * up * Wp * up;
-  return 2 * al256((size_t)M * hw * sizeof(int32_t)) + al256((size_t)M * sizeof(CamMeta)) +
-         al256((size_t)M * Hp * up * sizeof(RowMeta));
+  return cam_ws(M, Hp, Wp, up).total;
 }
 
 extern "C" int as_cam_boxes(const float* cams, const float* points, float cam_thr, float area_ratio, int M, int Hp,
@@ -333,29 +523,46 @@ extern "C" int as_cam_boxes(const float* cams, const float* points, float cam_th
                             size_t ws_bytes, as_stream_t stream) {
   AS_REQUIRE(cams && points && boxes && ws, AS_E_BADARG, "as_cam_boxes: null pointer");
   AS_REQUIRE(M > 0 && Hp > 0 && Wp > 0 && up > 0, AS_E_BADARG, "as_cam_boxes: bad sizes");
-  AS_REQUIRE(ws_bytes >= as_cam_boxes_workspace_bytes(M, Hp, Wp, up), AS_E_WORKSPACE,
-             "as_cam_boxes: workspace %zu < %zu bytes", ws_bytes, as_cam_boxes_workspace_bytes(M, Hp, Wp, up));
+  AS_REQUIRE((size_t)Wp * up <= 0xffffu && Hp * up <= CCM_HMAX, AS_E_UNSUPPORTED,
+             "as_cam_boxes: upsampled size %dx%d exceeds %dx65535", Hp * up, Wp * up, CCM_HMAX);
+  const CamWs L = cam_ws(M, Hp, Wp, up);
+  AS_REQUIRE(ws_bytes >= L.total, AS_E_WORKSPACE, "as_cam_boxes: workspace %zu < %zu bytes", ws_bytes, L.total);
   hipStream_t s = (hipStream_t)stream;
   const int H = Hp * up, W = Wp * up;
-  const size_t hw = (size_t)H * W, total = (size_t)M * hw;
+  const size_t hw = (size_t)H * W;
   char* w = (char*)ws;
-  int32_t* L = (int32_t*)w;
-  int32_t* area = (int32_t*)(w + al256(total * 4));
-  CamMeta* meta = (CamMeta*)(w + 2 * al256(total * 4));
-  RowMeta* rows = (RowMeta*)(w + 2 * al256(total * 4) + al256((size_t)M * sizeof(CamMeta)));
+  uint32_t* runs = (uint32_t*)(w + L.runs);
+  int32_t* nruns = (int32_t*)(w + L.nruns);
+  int32_t* parent = (int32_t*)(w + L.parent);
+  int32_t* area = (int32_t*)(w + L.area);
+  uint32_t* rw = (uint32_t*)(w + L.rw);
+  CamMeta* meta = (CamMeta*)(w + L.meta);
   const int bx = (int)((hw + CC_NT * 16 - 1) / (CC_NT * 16));
   hipLaunchKernelGGL(cam_meta_init_kernel, dim3(as_ceil_div(M, 64)), dim3(64), 0, s, meta, M);
   // two atomics per workgroup on meta[m]: grid-stride over at most 32 workgroups per map (same-address atomics
   // serialise at ~10 ns each; 256 workgroups x 42 maps made this pass atomic-bound)
-  hipLaunchKernelGGL(cam_minmax_kernel, dim3(bx < 32 ? bx : 32, M), dim3(CC_NT), 0, s, cams, meta, cams_up, area, Hp, Wp, up);
+  hipLaunchKernelGGL(cam_minmax_kernel, dim3(bx < 32 ? bx : 32, M), dim3(CC_NT), 0, s, cams, meta, cams_up, Hp, Wp, up);
   FgCam fg{cams, meta, cam_thr, Hp, Wp};
-  hipLaunchKernelGGL((ccl_rowscan_kernel<FgCam>), dim3(H, M), dim3(CC_NT), 0, s, fg, L, H, W);
-  hipLaunchKernelGGL(ccl_merge_kernel, dim3(blocks_for(total)), dim3(CC_NT), 0, s, L, M, H, W);
-  hipLaunchKernelGGL(ccl_compress_runs_kernel, dim3(blocks_for(total)), dim3(CC_NT), 0, s, L, M, H, W);
-  hipLaunchKernelGGL((ccl_finalize_kernel<false>), dim3(blocks_for(total)), dim3(CC_NT), 0, s, L, area, M, H, W);
-  hipLaunchKernelGGL(cam_maxarea_kernel, dim3(blocks_for(total)), dim3(CC_NT), 0, s, L, area, meta, M, (int)hw);
-  hipLaunchKernelGGL(cam_row_extent_kernel, dim3(H, M), dim3(CC_NT), 0, s, L, area, meta, rows, area_ratio, H, W);
-  hipLaunchKernelGGL(cam_box_kernel, dim3(M), dim3(CC_NT), 0, s, rows, meta, points, boxes, status, minmax, H, W);
+  hipLaunchKernelGGL(cam_runs_kernel, dim3(as_ceil_div(H, 4), M), dim3(CC_NT), 0, s, fg, runs, nruns, H, W, L.rmax);
+  hipLaunchKernelGGL(cam_cc_kernel, dim3(M), dim3(CCM_NT), 0, s, runs, nruns, parent, area, rw, meta, points, boxes,
+                     status, minmax, area_ratio, H, W, L.rmax);
   AS_CHECK_LAUNCH("cam_boxes");
+  return AS_OK;
+}
+
+extern "C" int as_cam_sample_masks(const float* cams, const int32_t* map_idx, const float* minmax, int G, int Hp, int Wp,
+                                   int up, float thr_bg, float thr_fg, uint8_t* masks, int32_t* counts,
+                                   as_stream_t stream) {
+  AS_REQUIRE(cams && map_idx && minmax && masks && counts, AS_E_BADARG, "as_cam_sample_masks: null pointer");
+  AS_REQUIRE(G > 0 && G <= 32 && Hp > 0 && Wp > 0 && up > 0 && up % 4 == 0, AS_E_UNSUPPORTED,
+             "as_cam_sample_masks: G=%d maps (max 32), scale %d must be a multiple of 4", G, up);
+  hipStream_t s = (hipStream_t)stream;
+  const size_t hw = (size_t)Hp * up * Wp * up;
+  (void)hipMemsetAsync(counts, 0, (size_t)(2 * G + 1) * 4, s);
+  const int blocks = (int)((hw / 4 + CC_NT - 1) / CC_NT);
+  // one atomic per counter per workgroup: grid-stride over at most 256 workgroups
+  hipLaunchKernelGGL(cam_sample_masks_kernel, dim3(blocks < 256 ? blocks : 256), dim3(CC_NT), 0, s, cams, map_idx,
+                     minmax, G, Hp, Wp, up, thr_bg, thr_fg, masks, counts);
+  AS_CHECK_LAUNCH("cam_sample_masks");
   return AS_OK;
 }

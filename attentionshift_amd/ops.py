@@ -343,21 +343,39 @@ def ccl_2d(binary):
     return labels[0] if squeeze else labels
 
 
-def cam_boxes(cams, points, cam_thr, area_ratio, up=16, return_upsampled=False):
+def cam_boxes(cams, points, cam_thr, area_ratio, up=16, return_upsampled=False, return_minmax=False):
     """cams [M,Hp,Wp] fp32, points [M,2] -> boxes [M,4], kept-pixel counts [M] (int32); with
-    return_upsampled also the upsampled maps [M,H,W] and their per-map (min, max) [M,2]."""
+    return_upsampled also the upsampled maps [M,H,W] and their per-map (min, max) [M,2]; with return_minmax
+    (boxes, status, minmax) -- the maps are then never materialised."""
     lib = _lib.load()
     _chk(cams, points, dtype=torch.float32)
     M, Hp, Wp = cams.shape
     boxes = torch.empty(M, 4, device=cams.device, dtype=torch.float32)
     status = torch.empty(M, device=cams.device, dtype=torch.int32)
     cams_up = torch.empty(M, Hp * up, Wp * up, device=cams.device, dtype=torch.float32) if return_upsampled else None
-    minmax = torch.empty(M, 2, device=cams.device, dtype=torch.float32) if return_upsampled else None
+    minmax = torch.empty(M, 2, device=cams.device, dtype=torch.float32) if (return_upsampled or return_minmax) else None
     nbytes = lib.as_cam_boxes_workspace_bytes(M, Hp, Wp, up)
     ws = torch.empty(nbytes, device=cams.device, dtype=torch.uint8)
     _lib.check(lib.as_cam_boxes(_p(cams), _p(points), float(cam_thr), float(area_ratio), M, Hp, Wp, up, _p(boxes),
                                 _p(status), _p(cams_up), _p(minmax), _p(ws), nbytes, _stream()), "as_cam_boxes")
-    return (boxes, status, cams_up, minmax) if return_upsampled else (boxes, status)
+    if return_upsampled:
+        return boxes, status, cams_up, minmax
+    return (boxes, status, minmax) if return_minmax else (boxes, status)
+
+
+def cam_sample_masks(cams, map_idx, minmax, thr_bg, thr_fg, up=16):
+    """cams [M,Hp,Wp] fp32, map_idx [G] int32, minmax [M,2] -> (masks [2G+1, H, W] uint8, counts [2G+1] int32):
+    the background / foreground / shared-background candidate masks of the seed sampling (stdroi:1003-1007)."""
+    lib = _lib.load()
+    _chk(cams, minmax, dtype=torch.float32)
+    _chk(map_idx, dtype=torch.int32)
+    M, Hp, Wp = cams.shape
+    G = map_idx.shape[0]
+    masks = torch.empty(2 * G + 1, Hp * up, Wp * up, device=cams.device, dtype=torch.uint8)
+    counts = torch.empty(2 * G + 1, device=cams.device, dtype=torch.int32)
+    _lib.check(lib.as_cam_sample_masks(_p(cams), _p(map_idx), _p(minmax), G, Hp, Wp, up, float(thr_bg), float(thr_fg),
+                                       _p(masks), _p(counts), _stream()), "as_cam_sample_masks")
+    return masks, counts
 
 
 def cosine_shift(feat, box_patch, obj_img, prot, n_shift, hp, wp, tau0=0.1, temp=0.1, return_trace=False):

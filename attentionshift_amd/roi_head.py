@@ -214,6 +214,44 @@ def sample_point_grid_multi(specs, num_points):
     return out
 
 
+def sample_points_from_cams(cams_lr, map_idx, minmax, gt_points, num_points, thr_bg=0.1, thr_fg=0.2):
+    """The three seed samplings of stdroi:1003-1007 (background / foreground / shared background on norm_attns of
+    the selected CAMs) from the LOW-resolution maps: one fused launch builds the candidate masks and counts
+    (ops.cam_sample_masks; the upsampled maps are never written), one host sync reads the counts, the draws follow
+    the reference's order (spec by spec, object by object) and rank_select resolves them on the device.
+    cams_lr [M,hp,wp], map_idx [G] int32 (rows of cams_lr), minmax [M,2].  Returns (pts_bg, pts_fg, pts_supp)."""
+    G = map_idx.shape[0]
+    masks, counts_dev = ops.cam_sample_masks(cams_lr, map_idx, minmax, thr_bg, thr_fg, STRIDE)
+    counts = counts_dev.tolist()                                                     # the one sync
+    H, W = masks.shape[-2:]
+    nm_cache = []
+
+    def nm():                                               # only the rare short-of-candidates branches need the maps
+        if not nm_cache:
+            idx = map_idx.long()
+            dummy = torch.zeros(G, 2, device=cams_lr.device)
+            up = ops.cam_boxes(cams_lr[idx].contiguous(), dummy, 0.5, 0.5, STRIDE, True)[2]
+            lo, hi = minmax[idx, 0][:, None, None], minmax[idx, 1][:, None, None]
+            nm_cache.append((up - lo) / (hi - lo))
+        return nm_cache[0]
+
+    out = []
+    for (lo_, hi_, thr, pos, gtp, mean) in ((0, G, thr_bg, False, None, False), (G, 2 * G, thr_fg, True, gt_points, False),
+                                           (2 * G, 2 * G + 1, thr_bg, False, None, True)):
+        cs = counts[lo_:hi_]
+        if min(cs) < num_points:
+            maps = nm().mean(0, keepdim=True) if mean else nm()
+            out.append(_sample_point_grid_slow(maps, num_points, thr, pos, gtp))
+            continue
+        ranks = []
+        for n in cs:
+            n_draw = len(range(0, n, n // num_points))
+            ranks.append((torch.randint(n, (n_draw,), generator=_gen()) % n)[:num_points])
+        flat = ops.rank_select(masks[lo_:hi_].flatten(1), torch.stack(ranks).to(masks.device))
+        out.append(torch.stack((flat % W, flat // W), dim=-1))
+    return out
+
+
 def _sample_point_grid_slow(maps, num_points, thr, is_pos, gt_points=None):
     """The rare branches of stdroi:354-364 (fewer candidates than points), one object at a time."""
     out = []
@@ -543,19 +581,24 @@ class AttnShiftRoIHead(nn.Module):
                             "(dense [B,N,N] attention maps are never materialised on this path)")
         return ops.rollout_rows(states, num_proposals)
 
-    def refine_maps(self, attn_sel, feat_chw, rois, gt_points, refine_times, obj_tau, minmax=None):
+    def refine_maps(self, attn_sel, feat_chw, rois, gt_points, refine_times, obj_tau, minmax=None, cam_src=None):
         """B2 (stdroi:1000-1019).  attn_sel [G,H,W], feat [C,hp,wp]; minmax [G,2] = per-map (min,max) if the
-        caller already has them (as_cam_boxes does).  Returns map_fg, map_bg [R+1,G,H,W], points_fg, points_bg,
-        fg_feat, bg_feat."""
-        G = attn_sel.shape[0]
+        caller already has them (as_cam_boxes does).  cam_src = (cams_lr [M,hp,wp], map_idx [G] int32, minmax [M,2])
+        replaces attn_sel: the seed sampling then reads the low-resolution CAMs and the upsampled maps are never
+        materialised.  Returns map_fg, map_bg [R+1,G,H,W], points_fg, points_bg, fg_feat, bg_feat."""
         C, hp, wp = feat_chw.shape
-        if minmax is None:
-            nm = _minmax_maps(attn_sel)
-        else:                                                   # norm_attns (:329-333) with known extrema
-            lo, hi = minmax[:, 0][:, None, None], minmax[:, 1][:, None, None]
-            nm = (attn_sel - lo) / (hi - lo)
-        pts_bg, pts_fg, pts_supp = sample_point_grid_multi(
-            [(nm, 0.1, False, None), (nm, 0.2, True, gt_points), (nm.mean(0, keepdim=True), 0.1, False, None)], 20)
+        if cam_src is not None:
+            G = cam_src[1].shape[0]
+            pts_bg, pts_fg, pts_supp = sample_points_from_cams(cam_src[0], cam_src[1], cam_src[2], gt_points, 20)
+        else:
+            G = attn_sel.shape[0]
+            if minmax is None:
+                nm = _minmax_maps(attn_sel)
+            else:                                               # norm_attns (:329-333) with known extrema
+                lo, hi = minmax[:, 0][:, None, None], minmax[:, 1][:, None, None]
+                nm = (attn_sel - lo) / (hi - lo)
+            pts_bg, pts_fg, pts_supp = sample_point_grid_multi(
+                [(nm, 0.1, False, None), (nm, 0.2, True, gt_points), (nm.mean(0, keepdim=True), 0.1, False, None)], 20)
         pts_fg = torch.cat((pts_fg, pts_supp), dim=0)
         CLOCK.mark("  sampling")
         feat_tok = feat_chw.flatten(1).t().contiguous()
@@ -736,19 +779,25 @@ class AttnShiftRoIHead(nn.Module):
         pts = torch.cat([point_targets[i].float().repeat(Lc, 1) for i in range(num_imgs)]).contiguous()
         if cams_lr.shape[0] == 0:
             raise RuntimeError("seed_pseudo_gt: no matched point tokens in the batch")
-        boxes, status, cams_up, cam_minmax = ops.cam_boxes(cams_lr, pts, self.bbox_head.seed_thr,
-                                                           self.bbox_head.seed_multiple, STRIDE, True)
+        if self.visualize:                                   # the reference keeps attn_maps_dealed only for plots
+            boxes, status, cams_up, cam_minmax = ops.cam_boxes(cams_lr, pts, self.bbox_head.seed_thr,
+                                                               self.bbox_head.seed_multiple, STRIDE, True)
+        else:
+            cams_up = None
+            boxes, status, cam_minmax = ops.cam_boxes(cams_lr, pts, self.bbox_head.seed_thr,
+                                                      self.bbox_head.seed_multiple, STRIDE, return_minmax=True)
         CLOCK.mark("cam_boxes")
         # the reference raises here when a CAM has no foreground component (torch.stack of an empty list, stdroi:80).
         # The flag stays on the device and is checked at the first host sync the chain needs anyway (the seed counts):
         # reading it here would stall the host for the whole roll-out + CAM-box phase with nothing queued behind it.
-        bad_cam = (status == 0).any()
-        gt_scale_bboxes, attn_maps_dealed, attn_minmax, off = [], [], [], 0
+        bad_cam = (status <= 0).any()                        # 0: no component; -1: run table overflow
+        gt_scale_bboxes, attn_maps_dealed, cam_off, off = [], [], [], 0
         for i in range(num_imgs):
             n = Lc * counts[i]
             gt_scale_bboxes.append(boxes[off:off + n].reshape(Lc, counts[i], 4).permute(1, 0, 2).contiguous())
-            attn_maps_dealed.append(cams_up[off:off + n].reshape(Lc, counts[i], H, W))
-            attn_minmax.append(cam_minmax[off:off + n].reshape(Lc, counts[i], 2))
+            if cams_up is not None:
+                attn_maps_dealed.append(cams_up[off:off + n].reshape(Lc, counts[i], H, W))
+            cam_off.append(off)
             off += n
 
         CLOCK.mark("box_split")
@@ -772,12 +821,10 @@ class AttnShiftRoIHead(nn.Module):
             candidate masks of the mask points (B2'), the patch-grid foreground maps and seed counts (B3), the pseudo
             mask and its device->host copy (B6) -- before the first host sync of the chain, so that the device keeps
             working while the host waits for counts and draws.  (stdroi:1966-1993, 2011-2020, 2356-2358.)"""
-            G_i = attn_maps_dealed[i].shape[1]
-            ar = torch.arange(G_i, device=attn_maps_dealed[i].device)
-            attn_sel = attn_maps_dealed[i][gt_box_index[i], ar].contiguous()
-            mm = attn_minmax[i][gt_box_index[i], ar]
-            map_fg, map_bg, _pa, _pb, feats_fg, feats_bg = self.refine_maps(attn_sel, feats[i], pseudo_boxes[i],
-                                                                            gt_points[i], 2, obj_tau, mm)
+            ar = torch.arange(counts[i], device=boxes.device)
+            map_idx = (cam_off[i] + gt_box_index[i] * counts[i] + ar).to(torch.int32)      # rows of cams_lr (layer-major)
+            map_fg, map_bg, _pa, _pb, feats_fg, feats_bg = self.refine_maps(
+                None, feats[i], pseudo_boxes[i], gt_points[i], 2, obj_tau, cam_src=(cams_lr, map_idx, cam_minmax))
             mp = mask_points_issue(map_fg[-1], map_bg[-1], pseudo_boxes[i], pos_mask_thr, neg_mask_thr, corr_size)
             fg_inter, map_fg_patch = self._semantic_pre(map_fg[-1], map_bg[-1], pos_mask_thr)
             gs = grid_seed_issue(map_fg_patch, 0.35)
@@ -865,7 +912,7 @@ class AttnShiftRoIHead(nn.Module):
             out["inst_bg_feat"].append(feats_bg)
         out["semantic_centers_org"] = (coords_sc_org, labels_sc_org)
         if self.visualize:
-            out.update(map_cos_bg=map_cos_bg_ret, sim_fg=sim_fg_ret, attns=attn_maps_dealed[-1])
+            out.update(map_cos_bg=map_cos_bg_ret, sim_fg=sim_fg_ret, attns=attn_maps_dealed[-1])   # cams_up kept above
         return out
 
 

@@ -165,13 +165,25 @@ int as_ccl_2d(const uint8_t* img /*[M,H,W]*/, int32_t* labels /*[M,H,W]*/, int M
  * bilinear x`up` upsample (align_corners=False), min-max normalise (clamp 1e-6), binarise at
  * cam_thr, CCL, keep components with area >= area_ratio * max area, tight box, 'expand' about the
  * point, clip to the image.  boxes [M,4] fp32 (x0,y0,x1,y1); status[m] = number of kept pixels
- * (0 = the reference would have raised).  cams_up, if not NULL, receives the upsampled maps
+ * (0 = the reference would have raised; -1 = a row held more foreground runs than the workspace
+ * provides, result invalid).  cams_up, if not NULL, receives the upsampled maps
  * [M,H,W] fp32 (the reference keeps them as attn_maps_dealed, stdroi:2282); minmax, if not NULL,
  * their per-map (min, max) [M,2] (reused by norm_attns, stdroi:329). */
 size_t as_cam_boxes_workspace_bytes(int M, int Hp, int Wp, int up);
 int as_cam_boxes(const float* cams /*[M,Hp,Wp]*/, const float* points /*[M,2] (x,y)*/, float cam_thr,
                  float area_ratio, int M, int Hp, int Wp, int up, float* boxes, int32_t* status,
                  float* cams_up, float* minmax, void* ws, size_t ws_bytes, as_stream_t stream);
+
+/* Candidate masks of the seed sampling (stdroi:1003-1007 -> sample_point_grid :343-371 on norm_attns
+ * :329-333) for the G selected maps of one image, straight from the low-resolution CAMs:
+ *   nm_g = (up(cams[map_idx[g]]) - min) / (max - min)   with (min, max) = minmax[map_idx[g]] of as_cam_boxes
+ *   masks [2G+1, H*W] uint8: rows 0..G-1  nm_g < thr_bg,  rows G..2G-1  nm_g >= thr_fg,
+ *                            row 2G       mean_g(nm_g) < thr_bg
+ *   counts [2G+1] int32: set pixels per row (written by the call).
+ * The upsampled maps are never materialised (same bilinear arithmetic as as_cam_boxes). */
+int as_cam_sample_masks(const float* cams /*[M,Hp,Wp]*/, const int32_t* map_idx /*[G]*/,
+                        const float* minmax /*[M,2]*/, int G, int Hp, int Wp, int up, float thr_bg, float thr_fg,
+                        uint8_t* masks, int32_t* counts, as_stream_t stream);
 
 /* Mean-shift token clustering (stdroi:830-854 cosine_shift_batch + :882-908 update_density_batch,
  * with the box masking of :1819-1824 folded in):

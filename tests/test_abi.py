@@ -37,7 +37,7 @@ def test_bad_arguments_return_error_codes_without_launching():
     assert b"null" in lib.as_last_error()
     assert lib.as_cosine_shift_workspace_bytes(2, 768, 64, 64, 6, 20) > 0
     assert lib.as_cosine_shift_workspace_bytes(0, 768, 64, 64, 6, 20) == 0
-    assert lib.as_cam_boxes_workspace_bytes(21, 64, 64, 16) >= 21 * 1024 * 1024 * 8
+    assert lib.as_cam_boxes_workspace_bytes(21, 64, 64, 16) >= 21 * 1024 * 66 * 4 * 3        # runs + parents + areas
     with pytest.raises(_lib.AttnShiftError):
         _lib.check(-2, "unit test")
     # every entry point validates before it launches (no GPU needed to get the error code)
@@ -47,6 +47,7 @@ def test_bad_arguments_return_error_codes_without_launching():
     assert lib.as_window_attn_fwd(None, None, None, None, None, 1, 14, 14, 64, 2, 7, 0, 1, None) == -1
     assert lib.as_add_layernorm(None, None, None, None, 1e-6, None, None, 4, 64, 1, None) == -1
     assert lib.as_mask_count(None, None, 1, 16, None) == -1
+    assert lib.as_cam_sample_masks(None, None, None, 3, 64, 64, 16, 0.1, 0.2, None, None, None) == -1
     assert lib.as_rollout_step(*([None] * 8), 0, 1, 64, 1, 8, 1, None) == -1
     # workspace size queries are pure host functions
     assert lib.as_sdpa_bwd_workspace_bytes(2, 4197, 12, 1) == 2 * 12 * 4224 * (5 * 64 * 2 + 4)

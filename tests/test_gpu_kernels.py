@@ -357,6 +357,56 @@ def test_cam_boxes_match_golden(ops, golden, tag):
     assert_equal(t(g["ref_kept_area"]).int(), status.reshape(Lc, G).t().cpu(), "kept-pixel counts")
 
 
+def test_cam_boxes_noise_maps_match_pixel_ccl(ops):
+    """Speckled maps (hundreds of components, dozens of runs per row): the run-based box stage must give what the
+    per-pixel labelling (as_ccl_2d, itself pinned to scipy) gives -- kept area and tight box per map."""
+    gen = torch.Generator().manual_seed(11)
+    M, hp, wp = 6, 20, 24
+    cams = torch.rand(M, hp, wp, generator=gen)
+    cams[0, 5:12, 6:15] += 1.0                               # one dominant blob, the rest pure noise
+    pts = torch.full((M, 2), 100.0)
+    boxes, status, up, mm = ops.cam_boxes(dev(cams), dev(pts), 0.45, 0.5, 16, True)
+    nmap = (up - mm[:, 0, None, None]) / (mm[:, 1, None, None] - mm[:, 0, None, None]).clamp_min(1e-6)
+    fg = (nmap >= 0.45).to(torch.uint8)
+    labels = ops.ccl_2d(fg.contiguous()).cpu()
+    H, W = hp * 16, wp * 16
+    for m in range(M):
+        lab = labels[m]
+        ids, areas = torch.unique(lab[lab > 0], return_counts=True)
+        keep = ids[areas.float() >= 0.5 * areas.max().float()]
+        kept = torch.isin(lab, keep)
+        assert int(status[m]) == int(kept.sum()), m
+        ys, xs = kept.nonzero(as_tuple=True)
+        xmin, xmax, ymin, ymax = float(xs.min()), float(xs.max()), float(ys.min()), float(ys.max())
+        xc = yc = 100.0                                      # 'expand' about the point (stdroi:97-115)
+        if abs(xc - xmin) > abs(xc - xmax):
+            want_x = (xmin, min(2 * xc - xmin, float(W)))
+        else:
+            want_x = (max(2 * xc - xmax, 0.0), xmax)
+        if abs(yc - ymin) > abs(yc - ymax):
+            want_y = (ymin, min(2 * yc - ymin, float(H)))
+        else:
+            want_y = (max(2 * yc - ymax, 0.0), ymax)
+        assert boxes[m].tolist() == [want_x[0], want_y[0], want_x[1], want_y[1]], m
+
+
+@pytest.mark.parametrize("G,hp,wp", [(3, 14, 14), (1, 8, 12), (5, 20, 16)])
+def test_cam_sample_masks_bit_exact(ops, G, hp, wp):
+    """as_cam_sample_masks == thresholding the materialised normalised maps (norm_attns on the upsampled CAMs)."""
+    gen = torch.Generator().manual_seed(5 + G)
+    M = 3 * G
+    cams = torch.rand(M, hp, wp, generator=gen)
+    pts = torch.full((M, 2), 20.0)
+    _, _, up, mm = ops.cam_boxes(dev(cams), dev(pts), 0.2, 0.5, 16, True)
+    idx = torch.randperm(M, generator=gen)[:G].to(torch.int32)
+    masks, counts = ops.cam_sample_masks(dev(cams), dev(idx), mm, 0.1, 0.2, 16)
+    sel = idx.long().to(up.device)
+    nm = (up[sel] - mm[sel, 0, None, None]) / (mm[sel, 1, None, None] - mm[sel, 0, None, None])
+    want = torch.cat((nm < 0.1, nm >= 0.2, (nm.sum(0, keepdim=True) / G) < 0.1)).to(torch.uint8)
+    assert_equal(want, masks, "candidate masks")
+    assert_equal(want.flatten(1).sum(1).int(), counts, "candidate counts")
+
+
 def _shift_inputs_dev(g, inp):
     hp, wp, G = int(g["hp"]), int(g["wp"]), int(g["G"])
     rois = t(g["rois"])
