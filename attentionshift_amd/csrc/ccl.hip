@@ -190,20 +190,56 @@ __global__ void cam_meta_init_kernel(CamMeta* meta, int M) {
   meta[m] = c;
 }
 
-// min / max of the upsampled map (and optionally the map itself); grid (blocks, M)
+// Row-block evaluation of the x`up` bilinear map.  bilerp(y, x) = fma(ly.l0, top, ly.l1 * bot) where
+// top / bot = the horizontal interpolation in source rows ly.i0 / ly.i1 depend on (x, source row) only: a thread
+// keeps the columns it owns, walks the rows of its block and recomputes top / bot only when the source row pair
+// changes (every `up` rows) -- 2 flops per pixel instead of two index computations, four loads and 7 flops, with
+// exactly the same operations and rounding as bilerp().
+struct ColLerp { Lerp lx; float top, bot; };
+__device__ __forceinline__ void col_refresh(ColLerp& c, const float* __restrict__ src, int Wp, const Lerp& ly) {
+  c.top = fmaf(c.lx.l0, src[ly.i0 * Wp + c.lx.i0], c.lx.l1 * src[ly.i0 * Wp + c.lx.i1]);
+  c.bot = fmaf(c.lx.l0, src[ly.i1 * Wp + c.lx.i0], c.lx.l1 * src[ly.i1 * Wp + c.lx.i1]);
+}
+__device__ __forceinline__ float col_value(const ColLerp& c, const Lerp& ly) { return fmaf(ly.l0, c.top, ly.l1 * c.bot); }
+
+// (q / den >= thr) without the division except in a 1e-6-wide relative band around the threshold: outside the band the
+// sign of q - thr*den decides, and the IEEE quotient, being monotone and 6e-8-accurate, rounds to the same side.
+struct ThrBand { float lo, hi, den, thr; };
+__device__ __forceinline__ ThrBand thr_band(float thr, float den) {
+  ThrBand b;
+  const float t = thr * den, mg = fabsf(t) * 1e-6f + 1e-30f;
+  b.lo = t - mg; b.hi = t + mg; b.den = den; b.thr = thr;
+  return b;
+}
+__device__ __forceinline__ bool ge_thr(float q, const ThrBand& b) {
+  if (q >= b.hi) return true;
+  if (!(q > b.lo)) return false;                            // below the band (or NaN: the quotient compares false too)
+  return q / b.den >= b.thr;
+}
+
+constexpr int CAM_RB = 16;        // rows per workgroup (minmax / sampling masks) or per wave (runs)
+
+// min / max of the upsampled map (and optionally the map itself); grid (ceil(H / CAM_RB), M)
 __global__ __launch_bounds__(CC_NT) void cam_minmax_kernel(const float* __restrict__ cams, CamMeta* __restrict__ meta,
                                                            float* __restrict__ cams_up, int Hp, int Wp, int up) {
   __shared__ float smn[CC_NT], smx[CC_NT];
   const int m = blockIdx.y, H = Hp * up, W = Wp * up;
   const float* src = cams + (size_t)m * Hp * Wp;
   const float sy = (float)Hp / (float)H, sx = (float)Wp / (float)W;
+  const int y0 = blockIdx.x * CAM_RB, y1 = min(y0 + CAM_RB, H);
   float mn = INFINITY, mx = -INFINITY;
-  for (int i = blockIdx.x * CC_NT + threadIdx.x; i < H * W; i += gridDim.x * CC_NT) {
-    const int y = i / W, x = i - y * W;
-    const float v = bilerp(src, Wp, lerp_axis(y, Hp, sy), lerp_axis(x, Wp, sx));
-    if (cams_up != nullptr) cams_up[(size_t)m * H * W + i] = v;
-    mn = fminf(mn, v);
-    mx = fmaxf(mx, v);
+  for (int x = threadIdx.x; x < W; x += CC_NT) {
+    ColLerp c;
+    c.lx = lerp_axis(x, Wp, sx);
+    int cur = -1;
+    for (int y = y0; y < y1; ++y) {
+      const Lerp ly = lerp_axis(y, Hp, sy);
+      if (ly.i0 != cur) { col_refresh(c, src, Wp, ly); cur = ly.i0; }
+      const float v = col_value(c, ly);
+      if (cams_up != nullptr) cams_up[((size_t)m * H + y) * W + x] = v;
+      mn = fminf(mn, v);
+      mx = fmaxf(mx, v);
+    }
   }
   smn[threadIdx.x] = mn; smx[threadIdx.x] = mx;
   __syncthreads();
@@ -228,36 +264,70 @@ __global__ __launch_bounds__(CC_NT) void cam_minmax_kernel(const float* __restri
 //              ranges touch or overlap diagonally), areas, area filter, extents, the 'expand' box
 // Links go from the larger run id to the smaller (atomicMin) and areas / extents are integers, so the result does
 // not depend on scheduling; it is the same partition the per-pixel path labels (tested against it).
-__global__ __launch_bounds__(CC_NT) void cam_runs_kernel(FgCam fg, uint32_t* __restrict__ runs,
-                                                         int32_t* __restrict__ nruns, int H, int W, int rmax) {
+// one wave per RUNS_RB consecutive rows; grid (ceil(H / (4 * RUNS_RB)), M).  Lane l owns the columns 64 * s + l.
+constexpr int RUNS_RB = 1;
+constexpr int CAM_XS = 16;        // 64-column words per row held in registers (rows up to 1024 wide; wider: reloaded)
+__global__ __launch_bounds__(CC_NT) void cam_runs_kernel(const float* __restrict__ cams, const CamMeta* __restrict__ meta,
+                                                         float thr, uint32_t* __restrict__ runs,
+                                                         int32_t* __restrict__ nruns, int Hp, int Wp, int up, int rmax) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int y = blockIdx.x * 4 + wave, m = blockIdx.y;
-  if (y >= H) return;
-  uint32_t* out = runs + ((size_t)m * H + y) * rmax;
-  int n = 0, open = -1;                                   // wave-uniform: runs so far, start of the open run
-  for (int x0 = 0; x0 < W; x0 += 64) {
-    const int x = x0 + lane;
-    const bool isfg = x < W && fg(m, y, x, H, W);
-    const unsigned long long b = __ballot(isfg);
-    const unsigned long long prev = (b << 1) | (open >= 0 ? 1ull : 0ull);
-    unsigned long long starts = b & ~prev;                // pixel is foreground, its left neighbour is not
-    unsigned long long ends = ~b & prev;                  // pixel is background, its left neighbour was foreground
-    while (starts | ends) {
-      const int is = starts ? __ffsll((long long)starts) - 1 : 64;
-      const int ie = ends ? __ffsll((long long)ends) - 1 : 64;
-      if (ie < is) {
-        if (lane == 0 && n < rmax) out[n] = (uint32_t)open | ((uint32_t)(x0 + ie - 1) << 16);
-        ++n; open = -1; ends &= ends - 1;
-      } else {
-        open = x0 + is; starts &= starts - 1;
+  const int m = blockIdx.y, H = Hp * up, W = Wp * up;
+  const int yb = (blockIdx.x * 4 + wave) * RUNS_RB;
+  if (yb >= H) return;
+  const float* src = cams + (size_t)m * Hp * Wp;
+  const float sy = (float)Hp / (float)H, sx = (float)Wp / (float)W;
+  const float mn = ord2f(meta[m].mn), den = fmaxf(ord2f(meta[m].mx) - mn, 1e-6f);       // stdroi:63-66
+  const ThrBand band = thr_band(thr, den);                  // (v - mn) / den >= thr
+  const int nwords = (W + 63) / 64;
+  for (int w0 = 0; w0 < nwords; w0 += CAM_XS) {            // one trip for W <= 1024
+    ColLerp c[CAM_XS];
+#pragma unroll
+    for (int s = 0; s < CAM_XS; ++s) c[s].lx = lerp_axis(min((w0 + s) * 64 + lane, W - 1), Wp, sx);
+    int cur = -1;
+    for (int y = yb; y < min(yb + RUNS_RB, H); ++y) {
+      const Lerp ly = lerp_axis(y, Hp, sy);
+      if (ly.i0 != cur) {
+#pragma unroll
+        for (int s = 0; s < CAM_XS; ++s) col_refresh(c[s], src, Wp, ly);
+        cur = ly.i0;
       }
+      uint32_t* out = runs + ((size_t)m * H + y) * rmax;
+      // wave-uniform run state; for rows wider than CAM_XS words it is carried through nruns / the last run word
+      int n = 0, open = -1;
+      if (w0 > 0) {                                          // written by this wave's lane 0 a trip ago: bypass L1
+        n = __hip_atomic_load(&nruns[(size_t)m * H + y], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (n > 0 && n <= rmax) {
+          const uint32_t last = __hip_atomic_load(&out[n - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if ((int)(last >> 16) == w0 * 64 - 1) { open = (int)(last & 0xffffu); --n; }
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < CAM_XS; ++s) {
+        const int x0 = (w0 + s) * 64, x = x0 + lane;
+        const bool isfg = x < W && ge_thr(col_value(c[s], ly) - mn, band);      // words beyond W: all background
+        const unsigned long long b = __ballot(isfg);
+        const unsigned long long prev = (b << 1) | (open >= 0 ? 1ull : 0ull);
+        unsigned long long starts = b & ~prev;              // pixel is foreground, its left neighbour is not
+        unsigned long long ends = ~b & prev;                // pixel is background, its left neighbour was foreground
+        while (starts | ends) {
+          const int is = starts ? __ffsll((long long)starts) - 1 : 64;
+          const int ie = ends ? __ffsll((long long)ends) - 1 : 64;
+          if (ie < is) {
+            if (lane == 0 && n < rmax) out[n] = (uint32_t)open | ((uint32_t)(x0 + ie - 1) << 16);
+            ++n; open = -1; ends &= ends - 1;
+          } else {
+            open = x0 + is; starts &= starts - 1;
+          }
+        }
+      }
+      if (open >= 0) {                                      // closes at the end of this trip's columns
+        const int xe = min((w0 + CAM_XS) * 64, W) - 1;
+        if (lane == 0 && n < rmax) out[n] = (uint32_t)open | ((uint32_t)xe << 16);
+        ++n;
+      }
+      if (lane == 0) nruns[(size_t)m * H + y] = n;          // n > rmax: overflow, reported through status
     }
   }
-  if (open >= 0) {
-    if (lane == 0 && n < rmax) out[n] = (uint32_t)open | ((uint32_t)(W - 1) << 16);
-    ++n;
-  }
-  if (lane == 0) nruns[(size_t)m * H + y] = n;            // n > rmax: overflow, reported through status
 }
 
 constexpr int CCM_NT = 1024;
@@ -420,50 +490,96 @@ __global__ __launch_bounds__(CCM_NT) void cam_cc_kernel(const uint32_t* __restri
 // code as the box stage, so the values are the ones the upsampled map would hold), and in ONE pass the three
 // candidate masks of sample_point_grid -- background nm < thr_bg per map, foreground nm >= thr_fg per map, shared
 // background mean_g(nm) < thr_bg -- with their candidate counts.  masks [2G+1][H*W] uint8, counts [2G+1].
+// grid (ceil(H / CAM_RB)); thread t owns the 4 columns 4t .. 4t+3 (and 4t + 1024 k), see ColLerp above.
+constexpr int CSM_G = 8;          // maps whose column state is kept in registers per pass
 __global__ __launch_bounds__(CC_NT) void cam_sample_masks_kernel(const float* __restrict__ cams,
                                                                  const int32_t* __restrict__ map_idx,
                                                                  const float* __restrict__ minmax, int G, int Hp, int Wp,
                                                                  int up, float thr_bg, float thr_fg,
-                                                                 uint8_t* __restrict__ masks, int32_t* __restrict__ counts) {
+                                                                 uint8_t* __restrict__ masks, int32_t* __restrict__ counts,
+                                                                 float* __restrict__ sum_ws) {
   __shared__ int cnt_s[2 * 32 + 1];
-  const int H = Hp * up, W = Wp * up, HW = H * W, tid = threadIdx.x;
+  const int H = Hp * up, W = Wp * up, tid = threadIdx.x;
+  const size_t HW = (size_t)H * W;
   const float sy = (float)Hp / (float)H, sx = (float)Wp / (float)W;
+  const int y0 = blockIdx.x * CAM_RB, y1 = min(y0 + CAM_RB, H);
   for (int k = tid; k < 2 * G + 1; k += CC_NT) cnt_s[k] = 0;
   __syncthreads();
   int c_supp = 0;
-  for (int i4 = (blockIdx.x * CC_NT + tid) * 4; i4 < HW; i4 += gridDim.x * CC_NT * 4) {     // W % 4 == 0
-    const int y = i4 / W, x = i4 - y * W;
-    const Lerp ly = lerp_axis(y, Hp, sy);
+  for (int xb = tid * 4; xb < W; xb += CC_NT * 4) {          // W % 4 == 0
     Lerp lx[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) lx[j] = lerp_axis(x + j, Wp, sx);
-    float sum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    for (int g = 0; g < G; ++g) {
-      const int mi = map_idx[g];
-      const float* src = cams + (size_t)mi * Hp * Wp;
-      const float lo = minmax[mi * 2 + 0], hi = minmax[mi * 2 + 1];
-      uchar4 bg, fg;
-      unsigned char* pb = reinterpret_cast<unsigned char*>(&bg);
-      unsigned char* pf = reinterpret_cast<unsigned char*>(&fg);
-      int cb = 0, cf = 0;
+    for (int j = 0; j < 4; ++j) lx[j] = lerp_axis(xb + j, Wp, sx);
+    // maps in passes of CSM_G; the running sum over maps (for the shared-background mask) stays in registers when
+    // G <= CSM_G and goes through sum_ws otherwise
+    for (int g0 = 0; g0 < G; g0 += CSM_G) {
+      const int gn = min(CSM_G, G - g0);
+      ColLerp c[CSM_G][4];
+      float lo[CSM_G], den[CSM_G];
+      const float* src[CSM_G];
+      int cb[CSM_G], cf[CSM_G];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float nm = (bilerp(src, Wp, ly, lx[j]) - lo) / (hi - lo);
-        sum[j] += nm;
-        pb[j] = nm < thr_bg ? 1 : 0;
-        pf[j] = nm >= thr_fg ? 1 : 0;
-        cb += pb[j]; cf += pf[j];
+      for (int g = 0; g < CSM_G; ++g) {
+        const int mi = map_idx[g0 + min(g, gn - 1)];
+        src[g] = cams + (size_t)mi * Hp * Wp;
+        lo[g] = minmax[mi * 2 + 0]; den[g] = minmax[mi * 2 + 1] - lo[g];
+        cb[g] = 0; cf[g] = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c[g][j].lx = lx[j];
       }
-      *reinterpret_cast<uchar4*>(masks + (size_t)g * HW + i4) = bg;
-      *reinterpret_cast<uchar4*>(masks + (size_t)(G + g) * HW + i4) = fg;
-      if (cb) atomicAdd(&cnt_s[g], cb);
-      if (cf) atomicAdd(&cnt_s[G + g], cf);
-    }
-    uchar4 sp;
-    unsigned char* ps = reinterpret_cast<unsigned char*>(&sp);
+      int cur = -1;
+      for (int y = y0; y < y1; ++y) {
+        const Lerp ly = lerp_axis(y, Hp, sy);
+        if (ly.i0 != cur) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { ps[j] = (sum[j] / (float)G) < thr_bg ? 1 : 0; c_supp += ps[j]; }
-    *reinterpret_cast<uchar4*>(masks + (size_t)(2 * G) * HW + i4) = sp;
+          for (int g = 0; g < CSM_G; ++g)
+            if (g < gn) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) col_refresh(c[g][j], src[g], Wp, ly);
+            }
+          cur = ly.i0;
+        }
+        const size_t pix = (size_t)y * W + xb;
+        float sum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (g0 > 0) {
+          const float4 sv = *reinterpret_cast<const float4*>(sum_ws + pix);
+          sum[0] = sv.x; sum[1] = sv.y; sum[2] = sv.z; sum[3] = sv.w;
+        }
+#pragma unroll
+        for (int g = 0; g < CSM_G; ++g) {
+          if (g < gn) {
+            uchar4 bg, fg;
+            unsigned char* pb = reinterpret_cast<unsigned char*>(&bg);
+            unsigned char* pf = reinterpret_cast<unsigned char*>(&fg);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const float nm = (col_value(c[g][j], ly) - lo[g]) / den[g];
+              sum[j] += nm;
+              pb[j] = nm < thr_bg ? 1 : 0;
+              pf[j] = nm >= thr_fg ? 1 : 0;
+              cb[g] += pb[j]; cf[g] += pf[j];
+            }
+            *reinterpret_cast<uchar4*>(masks + (size_t)(g0 + g) * HW + pix) = bg;
+            *reinterpret_cast<uchar4*>(masks + (size_t)(G + g0 + g) * HW + pix) = fg;
+          }
+        }
+        if (g0 + gn == G) {
+          uchar4 sp;
+          unsigned char* ps = reinterpret_cast<unsigned char*>(&sp);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { ps[j] = (sum[j] / (float)G) < thr_bg ? 1 : 0; c_supp += ps[j]; }
+          *reinterpret_cast<uchar4*>(masks + (size_t)(2 * G) * HW + pix) = sp;
+        } else {
+          *reinterpret_cast<float4*>(sum_ws + pix) = make_float4(sum[0], sum[1], sum[2], sum[3]);
+        }
+      }
+#pragma unroll
+      for (int g = 0; g < CSM_G; ++g)
+        if (g < gn) {
+          if (cb[g]) atomicAdd(&cnt_s[g0 + g], cb[g]);
+          if (cf[g]) atomicAdd(&cnt_s[G + g0 + g], cf[g]);
+        }
+    }
   }
   if (c_supp) atomicAdd(&cnt_s[2 * G], c_supp);
   __syncthreads();
@@ -529,7 +645,6 @@ extern "C" int as_cam_boxes(const float* cams, const float* points, float cam_th
   AS_REQUIRE(ws_bytes >= L.total, AS_E_WORKSPACE, "as_cam_boxes: workspace %zu < %zu bytes", ws_bytes, L.total);
   hipStream_t s = (hipStream_t)stream;
   const int H = Hp * up, W = Wp * up;
-  const size_t hw = (size_t)H * W;
   char* w = (char*)ws;
   uint32_t* runs = (uint32_t*)(w + L.runs);
   int32_t* nruns = (int32_t*)(w + L.nruns);
@@ -537,32 +652,37 @@ extern "C" int as_cam_boxes(const float* cams, const float* points, float cam_th
   int32_t* area = (int32_t*)(w + L.area);
   uint32_t* rw = (uint32_t*)(w + L.rw);
   CamMeta* meta = (CamMeta*)(w + L.meta);
-  const int bx = (int)((hw + CC_NT * 16 - 1) / (CC_NT * 16));
   hipLaunchKernelGGL(cam_meta_init_kernel, dim3(as_ceil_div(M, 64)), dim3(64), 0, s, meta, M);
-  // two atomics per workgroup on meta[m]: grid-stride over at most 32 workgroups per map (same-address atomics
-  // serialise at ~10 ns each; 256 workgroups x 42 maps made this pass atomic-bound)
-  hipLaunchKernelGGL(cam_minmax_kernel, dim3(bx < 32 ? bx : 32, M), dim3(CC_NT), 0, s, cams, meta, cams_up, Hp, Wp, up);
-  FgCam fg{cams, meta, cam_thr, Hp, Wp};
-  hipLaunchKernelGGL(cam_runs_kernel, dim3(as_ceil_div(H, 4), M), dim3(CC_NT), 0, s, fg, runs, nruns, H, W, L.rmax);
+  // two atomics per workgroup on meta[m] (same-address atomics serialise at ~10 ns each: 64 workgroups per map)
+  hipLaunchKernelGGL(cam_minmax_kernel, dim3(as_ceil_div(H, CAM_RB), M), dim3(CC_NT), 0, s, cams, meta, cams_up, Hp, Wp,
+                     up);
+  hipLaunchKernelGGL(cam_runs_kernel, dim3(as_ceil_div(H, 4 * RUNS_RB), M), dim3(CC_NT), 0, s, cams, meta, cam_thr, runs,
+                     nruns, Hp, Wp, up, L.rmax);
   hipLaunchKernelGGL(cam_cc_kernel, dim3(M), dim3(CCM_NT), 0, s, runs, nruns, parent, area, rw, meta, points, boxes,
                      status, minmax, area_ratio, H, W, L.rmax);
   AS_CHECK_LAUNCH("cam_boxes");
   return AS_OK;
 }
 
+extern "C" size_t as_cam_sample_masks_workspace_bytes(int G, int Hp, int Wp, int up) {
+  if (G <= CSM_G || Hp <= 0 || Wp <= 0 || up <= 0) return 0;
+  return (size_t)Hp * up * Wp * up * sizeof(float);        // running sum over maps between register passes
+}
+
 extern "C" int as_cam_sample_masks(const float* cams, const int32_t* map_idx, const float* minmax, int G, int Hp, int Wp,
-                                   int up, float thr_bg, float thr_fg, uint8_t* masks, int32_t* counts,
-                                   as_stream_t stream) {
+                                   int up, float thr_bg, float thr_fg, uint8_t* masks, int32_t* counts, void* ws,
+                                   size_t ws_bytes, as_stream_t stream) {
   AS_REQUIRE(cams && map_idx && minmax && masks && counts, AS_E_BADARG, "as_cam_sample_masks: null pointer");
   AS_REQUIRE(G > 0 && G <= 32 && Hp > 0 && Wp > 0 && up > 0 && up % 4 == 0, AS_E_UNSUPPORTED,
              "as_cam_sample_masks: G=%d maps (max 32), scale %d must be a multiple of 4", G, up);
+  const size_t need = as_cam_sample_masks_workspace_bytes(G, Hp, Wp, up);
+  AS_REQUIRE(ws_bytes >= need && (ws || !need), AS_E_WORKSPACE, "as_cam_sample_masks: workspace %zu < %zu bytes",
+             ws_bytes, need);
   hipStream_t s = (hipStream_t)stream;
-  const size_t hw = (size_t)Hp * up * Wp * up;
   (void)hipMemsetAsync(counts, 0, (size_t)(2 * G + 1) * 4, s);
-  const int blocks = (int)((hw / 4 + CC_NT - 1) / CC_NT);
-  // one atomic per counter per workgroup: grid-stride over at most 256 workgroups
-  hipLaunchKernelGGL(cam_sample_masks_kernel, dim3(blocks < 256 ? blocks : 256), dim3(CC_NT), 0, s, cams, map_idx,
-                     minmax, G, Hp, Wp, up, thr_bg, thr_fg, masks, counts);
+  // one atomic per counter per workgroup (64 workgroups at 1024 rows)
+  hipLaunchKernelGGL(cam_sample_masks_kernel, dim3(as_ceil_div(Hp * up, CAM_RB)), dim3(CC_NT), 0, s, cams, map_idx,
+                     minmax, G, Hp, Wp, up, thr_bg, thr_fg, masks, counts, (float*)ws);
   AS_CHECK_LAUNCH("cam_sample_masks");
   return AS_OK;
 }

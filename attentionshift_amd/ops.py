@@ -373,8 +373,10 @@ def cam_sample_masks(cams, map_idx, minmax, thr_bg, thr_fg, up=16):
     G = map_idx.shape[0]
     masks = torch.empty(2 * G + 1, Hp * up, Wp * up, device=cams.device, dtype=torch.uint8)
     counts = torch.empty(2 * G + 1, device=cams.device, dtype=torch.int32)
+    nbytes = lib.as_cam_sample_masks_workspace_bytes(G, Hp, Wp, up)
+    ws = torch.empty(nbytes, device=cams.device, dtype=torch.uint8) if nbytes else None
     _lib.check(lib.as_cam_sample_masks(_p(cams), _p(map_idx), _p(minmax), G, Hp, Wp, up, float(thr_bg), float(thr_fg),
-                                       _p(masks), _p(counts), _stream()), "as_cam_sample_masks")
+                                       _p(masks), _p(counts), _p(ws), nbytes, _stream()), "as_cam_sample_masks")
     return masks, counts
 
 

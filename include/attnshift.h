@@ -181,9 +181,10 @@ int as_cam_boxes(const float* cams /*[M,Hp,Wp]*/, const float* points /*[M,2] (x
  *                            row 2G       mean_g(nm_g) < thr_bg
  *   counts [2G+1] int32: set pixels per row (written by the call).
  * The upsampled maps are never materialised (same bilinear arithmetic as as_cam_boxes). */
+size_t as_cam_sample_masks_workspace_bytes(int G, int Hp, int Wp, int up);     /* 0 for G <= 8 */
 int as_cam_sample_masks(const float* cams /*[M,Hp,Wp]*/, const int32_t* map_idx /*[G]*/,
                         const float* minmax /*[M,2]*/, int G, int Hp, int Wp, int up, float thr_bg, float thr_fg,
-                        uint8_t* masks, int32_t* counts, as_stream_t stream);
+                        uint8_t* masks, int32_t* counts, void* ws, size_t ws_bytes, as_stream_t stream);
 
 /* Mean-shift token clustering (stdroi:830-854 cosine_shift_batch + :882-908 update_density_batch,
  * with the box masking of :1819-1824 folded in):

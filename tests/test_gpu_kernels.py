@@ -390,7 +390,7 @@ def test_cam_boxes_noise_maps_match_pixel_ccl(ops):
         assert boxes[m].tolist() == [want_x[0], want_y[0], want_x[1], want_y[1]], m
 
 
-@pytest.mark.parametrize("G,hp,wp", [(3, 14, 14), (1, 8, 12), (5, 20, 16)])
+@pytest.mark.parametrize("G,hp,wp", [(3, 14, 14), (1, 8, 12), (5, 20, 16), (11, 9, 72)])
 def test_cam_sample_masks_bit_exact(ops, G, hp, wp):
     """as_cam_sample_masks == thresholding the materialised normalised maps (norm_attns on the upsampled CAMs)."""
     gen = torch.Generator().manual_seed(5 + G)
@@ -402,7 +402,10 @@ def test_cam_sample_masks_bit_exact(ops, G, hp, wp):
     masks, counts = ops.cam_sample_masks(dev(cams), dev(idx), mm, 0.1, 0.2, 16)
     sel = idx.long().to(up.device)
     nm = (up[sel] - mm[sel, 0, None, None]) / (mm[sel, 1, None, None] - mm[sel, 0, None, None])
-    want = torch.cat((nm < 0.1, nm >= 0.2, (nm.sum(0, keepdim=True) / G) < 0.1)).to(torch.uint8)
+    tot = nm[0].clone()                                   # sequential sum over the maps, then one division
+    for g_ in range(1, G):
+        tot = tot + nm[g_]
+    want = torch.cat((nm < 0.1, nm >= 0.2, ((tot / G) < 0.1)[None])).to(torch.uint8)
     assert_equal(want, masks, "candidate masks")
     assert_equal(want.flatten(1).sum(1).int(), counts, "candidate counts")
 
