@@ -244,6 +244,83 @@ extern "C" int as_crop_threshold_erode(const float* maps, const int32_t* crops, 
 //   counts   grid (chunks, M): set bytes per 4096-byte chunk
 //   select   grid (K, M), one wave per rank: prefix over the chunk counts, then inside the chunk
 // =====================================================================================================
+// =====================================================================================================
+// Patch-grid foreground of get_semantic_centers (stdroi:2011-2012, 2020): erode(map_fg > thr, k) at full resolution,
+// bilinear DOWN to the patch grid.  For an exact integer factor `up` the down-sampled value is the mean of the 2x2
+// pixels (up/2-1, up/2) of the patch with weights 0.5/0.5, so only those four erosions are evaluated: a 16-lane group
+// per patch, lane = one row of the (k+1) x (k+1) block the four windows span, rows combined with AND shuffles.
+// Also the binary patch map (fg_inter > thr) and its per-object count (the grid-seed candidates, :1784).
+// =====================================================================================================
+namespace {
+
+__global__ __launch_bounds__(RF_NT) void semantic_prestage_kernel(const float* __restrict__ map_fg, float thr, int G,
+                                                                  int Hp, int Wp, int up, int k,
+                                                                  float* __restrict__ fg_inter, uint8_t* __restrict__ mask,
+                                                                  int32_t* __restrict__ counts) {
+  const int H = Hp * up, W = Wp * up, Np = Hp * Wp, r0 = k / 2;
+  const int gid = blockIdx.x * RF_NT + threadIdx.x;
+  const int patch = gid >> 4, r = gid & 15;                  // r = row of the block (k + 1 <= 16 rows)
+  const bool live = patch < G * Np;
+  const int pc = live ? patch : 0;
+  const int g = pc / Np, pp = pc - g * Np, py = pp / Wp, px = pp - py * Wp;
+  const int y = up * py + up / 2 - 1 - r0 + r, xb = up * px + up / 2 - 1 - r0;
+  const float* row = map_fg + ((size_t)g * H + min(max(y, 0), H - 1)) * W;
+  const bool yin = y >= 0 && y < H && r <= k;
+  unsigned bits = 0;                                          // bit c: pixel (y, xb + c) passes or lies outside the image
+  for (int c = 0; c <= k; ++c) {
+    const int x = xb + c;
+    const bool in = yin && x >= 0 && x < W;
+    const float v = row[min(max(x, 0), W - 1)];
+    if (!in || v > thr) bits |= 1u << c;
+  }
+  const unsigned full = (1u << k) - 1u;
+  float val = 0.0f;
+#pragma unroll
+  for (int sr = 0; sr < 2; ++sr)
+#pragma unroll
+    for (int sc = 0; sc < 2; ++sc) {
+      // window of sample (sr, sc): rows sr .. sr+k-1, columns sc .. sc+k-1 of the block
+      unsigned ok = (r < sr || r > sr + k - 1) ? 1u : (((bits >> sc) & full) == full ? 1u : 0u);
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) ok &= __shfl_xor(ok, o);
+      const float e = ok ? 1.0f : 0.0f;
+      // 0.5 * (0.5 a + 0.5 b) + 0.5 * (0.5 c + 0.5 d): exact for 0/1 inputs
+      val += 0.25f * e;
+    }
+  const bool m = val > thr;
+  if (live && r == 0) {
+    fg_inter[pc] = val;
+    mask[pc] = m ? 1 : 0;
+  }
+  // objects do not straddle waves unless Np % 4 != 0: count per lane group leader with one atomic per wave and object
+  const unsigned long long b = __ballot(live && r == 0 && m);
+  if (b) {
+    const int lane = threadIdx.x & 63;
+    const int g_first = __shfl(g, 0), g_last = __shfl(g, 48);
+    if (g_first == g_last) {
+      if (lane == 0) atomicAdd(&counts[g_first], __popcll(b));
+    } else if (live && r == 0 && m) {
+      atomicAdd(&counts[g], 1);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int as_semantic_prestage(const float* map_fg, float thr, int k, int G, int Hp, int Wp, int up, float* fg_inter,
+                                    uint8_t* mask, int32_t* counts, as_stream_t stream) {
+  AS_REQUIRE(map_fg && fg_inter && mask && counts, AS_E_BADARG, "as_semantic_prestage: null pointer");
+  AS_REQUIRE(G > 0 && Hp > 0 && Wp > 0 && up >= 2 && up % 2 == 0 && k >= 1 && (k & 1) == 1 && k <= 15, AS_E_UNSUPPORTED,
+             "as_semantic_prestage: even scale >= 2 and odd erosion size <= 15 (got %d, %d)", up, k);
+  hipStream_t s = (hipStream_t)stream;
+  (void)hipMemsetAsync(counts, 0, (size_t)G * 4, s);
+  const size_t threads = (size_t)G * Hp * Wp * 16;
+  hipLaunchKernelGGL(semantic_prestage_kernel, dim3((unsigned)((threads + RF_NT - 1) / RF_NT)), dim3(RF_NT), 0, s, map_fg,
+                     thr, G, Hp, Wp, up, k, fg_inter, mask, counts);
+  AS_CHECK_LAUNCH("semantic_prestage");
+  return AS_OK;
+}
+
 namespace {
 
 constexpr int RS_CHUNK = 4096;

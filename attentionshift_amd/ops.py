@@ -380,6 +380,21 @@ def cam_sample_masks(cams, map_idx, minmax, thr_bg, thr_fg, up=16):
     return masks, counts
 
 
+def semantic_prestage(map_fg, thr, k=11, up=16):
+    """map_fg [G,H,W] fp32 -> (fg_inter [G,H/up,W/up] fp32, mask uint8 same shape, counts [G] int32):
+    bilinear down-sampling of erode_k(map_fg > thr), its > thr binarisation and the per-object counts."""
+    lib = _lib.load()
+    _chk(map_fg, dtype=torch.float32)
+    G, H, W = map_fg.shape
+    hp, wp = H // up, W // up
+    fg_inter = torch.empty(G, hp, wp, device=map_fg.device, dtype=torch.float32)
+    mask = torch.empty(G, hp, wp, device=map_fg.device, dtype=torch.uint8)
+    counts = torch.empty(G, device=map_fg.device, dtype=torch.int32)
+    _lib.check(lib.as_semantic_prestage(_p(map_fg), float(thr), int(k), G, hp, wp, up, _p(fg_inter), _p(mask), _p(counts),
+                                        _stream()), "as_semantic_prestage")
+    return fg_inter, mask, counts
+
+
 def cosine_shift(feat, box_patch, obj_img, prot, n_shift, hp, wp, tau0=0.1, temp=0.1, return_trace=False):
     """feat [B,Np,C] fp32 token-major; box_patch [G,4] int32; obj_img [G] int32; prot [G,P,C] (seeds).
     Returns (prot_out [G,P,C], sim [G,P,Np]) and, with return_trace, (assign [S,G,Np], tau [S,G,P])."""

@@ -670,21 +670,19 @@ class AttnShiftRoIHead(nn.Module):
         G, H, W = map_cos_fg.shape
         # :2011-2013.  erode_11(map > thr) at full resolution, then the bilinear /16 down-sampling, which for an
         # exact factor of 16 reads only the 2x2 centre pixels of each patch with weights 1/2 (bit-identical)
-        fg_inter, map_fg = self._semantic_pre(map_cos_fg, map_cos_bg, pos_thr)
+        fg_inter, map_fg, _seeds = self._semantic_pre(map_cos_fg, map_cos_bg, pos_thr)
         prot, sim = self.mean_shift_grid_prototype(map_fg, vit_feat, rois, tau=0.1, temp=0.1, n_shift=refine_times)
         CLOCK.mark("  sc:mean_shift")
         return self._semantic_post(prot, sim, fg_inter, rois, vit_feat, gt_labels, merge_thr, num_semantic_points)
 
     def _semantic_pre(self, map_cos_fg, map_cos_bg, pos_thr):
-        """First part of get_semantic_centers (stdroi:2011-2020): the patch-grid foreground maps."""
-        core, _ = ops.crop_threshold_erode(map_cos_fg.contiguous(), None, pos_thr, False, 11)
-        CLOCK.mark("  sc:erode")
-        fg_inter = _down16(core.float())
-        bg_inter = _down16(torch.stack([_centre4(map_cos_bg, dy, dx) for dy in (7, 8) for dx in (7, 8)]).amax(dim=1, keepdim=False),
-                           presampled=True)[None]
-        map_fg = (fg_inter > pos_thr).to(fg_inter.dtype)
-        CLOCK.mark("  sc:down16")
-        return fg_inter, map_fg
+        """First part of get_semantic_centers (stdroi:2011-2020): the patch-grid foreground maps, one fused launch
+        (ops.semantic_prestage).  The reference also down-samples max_g(map_cos_bg) here (bg_inter, :2013), but its
+        only consumer is commented out (filter_maps :267), so it is not computed.  Returns fg_inter, the binary
+        patch map (float, as the reference), and (mask uint8, counts) of its positives for the grid seeds."""
+        fg_inter, mask, counts = ops.semantic_prestage(map_cos_fg.contiguous(), pos_thr, 11, STRIDE)
+        CLOCK.mark("  sc:prestage")
+        return fg_inter, mask.to(fg_inter.dtype), (mask, counts)
 
     def _semantic_post(self, prot, sim, fg_inter, rois, vit_feat, gt_labels, merge_thr, num_semantic_points):
         """Last part of get_semantic_centers (stdroi:2022-2031): filter / merge the shifted prototypes, part centres."""
@@ -826,8 +824,7 @@ class AttnShiftRoIHead(nn.Module):
             map_fg, map_bg, _pa, _pb, feats_fg, feats_bg = self.refine_maps(
                 None, feats[i], pseudo_boxes[i], gt_points[i], 2, obj_tau, cam_src=(cams_lr, map_idx, cam_minmax))
             mp = mask_points_issue(map_fg[-1], map_bg[-1], pseudo_boxes[i], pos_mask_thr, neg_mask_thr, corr_size)
-            fg_inter, map_fg_patch = self._semantic_pre(map_fg[-1], map_bg[-1], pos_mask_thr)
-            gs = grid_seed_issue(map_fg_patch, 0.35)
+            fg_inter, _map_fg_patch, gs = self._semantic_pre(map_fg[-1], map_bg[-1], pos_mask_thr)   # gs: >= 0.35 of a 0/1 map
             mask_u8, _ = ops.crop_threshold_erode(map_fg[-1].contiguous(), None, pos_mask_thr, True, 1)   # stdroi:2356
             pm = _to_host_issue(mask_u8)
             return mp, gs, map_fg, map_bg, feats_fg, feats_bg, fg_inter, pm

@@ -186,6 +186,12 @@ int as_cam_sample_masks(const float* cams /*[M,Hp,Wp]*/, const int32_t* map_idx 
                         const float* minmax /*[M,2]*/, int G, int Hp, int Wp, int up, float thr_bg, float thr_fg,
                         uint8_t* masks, int32_t* counts, void* ws, size_t ws_bytes, as_stream_t stream);
 
+/* Patch-grid foreground of get_semantic_centers (stdroi:2011-2012, 2020), one launch:
+ *   fg_inter [G,Hp*Wp] = bilinear x(1/up) of erode_k(map_fg > thr)   (map_fg [G, Hp*up, Wp*up])
+ *   mask     [G,Hp*Wp] uint8 = fg_inter > thr,  counts [G] = set entries per object (the grid-seed candidates, :1784) */
+int as_semantic_prestage(const float* map_fg, float thr, int k, int G, int Hp, int Wp, int up, float* fg_inter,
+                         uint8_t* mask, int32_t* counts, as_stream_t stream);
+
 /* Mean-shift token clustering (stdroi:830-854 cosine_shift_batch + :882-908 update_density_batch,
  * with the box masking of :1819-1824 folded in):
  *   feat      [B,Np,C]  token-major ViT features (Np = Hp*Wp)

@@ -410,6 +410,20 @@ def test_cam_sample_masks_bit_exact(ops, G, hp, wp):
     assert_equal(want.flatten(1).sum(1).int(), counts, "candidate counts")
 
 
+@pytest.mark.parametrize("G,hp,wp,thr", [(3, 14, 14, 0.35), (2, 9, 20, 0.5), (5, 6, 6, 0.35)])
+def test_semantic_prestage_matches_oracle(ops, G, hp, wp, thr):
+    """erode_11(map > thr) -> bilinear /16 -> binarise (stdroi:2011-2020) in one launch vs max-pool + interpolate."""
+    gen = torch.Generator().manual_seed(17 + G)
+    low = torch.rand(G, hp, wp, generator=gen)
+    m = torch.nn.functional.interpolate(low[None], scale_factor=16, mode="bilinear")[0]      # blobs with soft edges
+    m[:, :3] = 1.0                                            # foreground touching the image border (padding rule)
+    fg_inter, _bg, fg_bin = O.semantic_prestage(m, m, (hp, wp), thr)
+    got_inter, got_mask, got_cnt = ops.semantic_prestage(dev(m), thr, 11, 16)
+    assert_equal(fg_inter, got_inter, "fg_inter")
+    assert_equal(fg_bin.to(torch.uint8), got_mask, "binary patch map")
+    assert_equal(fg_bin.flatten(1).sum(1).int(), got_cnt, "counts")
+
+
 def _shift_inputs_dev(g, inp):
     hp, wp, G = int(g["hp"]), int(g["wp"]), int(g["G"])
     rois = t(g["rois"])

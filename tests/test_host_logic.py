@@ -171,7 +171,12 @@ def test_semantic_center_host_logic_with_oracle_backed_shift(golden, tag, monkey
         cos = torch.nn.functional.cosine_similarity(seeds[:, None, :], feat[None, :, :], dim=-1)
         return cos[None], seeds.clone()
 
+    def fake_semantic_prestage(map_fg, thr, k=11, up=16):
+        fg_inter, _bg, fg_bin = O.semantic_prestage(map_fg, map_fg, (map_fg.shape[-2] // up, map_fg.shape[-1] // up), thr)
+        return fg_inter, fg_bin.to(torch.uint8), fg_bin.flatten(1).sum(1).int()
+
     monkeypatch.setattr(RH.ops, "cosine_shift", fake_cosine_shift)
+    monkeypatch.setattr(RH.ops, "semantic_prestage", fake_semantic_prestage)
     monkeypatch.setattr(RH.ops, "refine_similarity", fake_refine_similarity)
     monkeypatch.setattr(RH.ops, "crop_threshold_erode", fake_crop_threshold_erode)
     monkeypatch.setattr(RH.ops, "rank_select", fake_rank_select)
