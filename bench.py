@@ -292,7 +292,7 @@ def main():
                          "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
                          "traffic": sdpa_traffic(), "launches_timed": n_sdpa, "ms_per_launch": round(ms_sdpa, 4),
                          "flops_per_launch": flops_sdpa},
-            "roofline_affinity": {"kernel": "as_cosine_shift (sim/stats/assign/finalize x S + final sim)", "bound": "hbm",
+            "roofline_affinity": {"kernel": "as_cosine_shift (similarity / assign / aggregate x S + final similarity)", "bound": "hbm",
                                   "achieved": round(gbps, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                                   "frac": round(gbps / PEAK_HBM_GBPS, 4), "traffic": None, "calls_timed": n_cs, "images_per_call": imgs_per_call,
                                   "ms_per_call": round(ms_cs, 4), "algorithmic_bytes_per_call": bytes_cs},
