@@ -392,7 +392,15 @@ __global__ __launch_bounds__(64) void rank_select_kernel(const uint8_t* __restri
   // level 1: which chunk
   const int cpl = (nchunk + 63) / 64;
   int mine = 0;
-  for (int i = lane * cpl; i < min((lane + 1) * cpl, nchunk); ++i) mine += c[i];
+  int c4[4] = {0, 0, 0, 0};
+  const bool vec = cpl == 4 && nchunk % 4 == 0 && (lane + 1) * 4 <= nchunk;   // 1024^2 masks: 256 chunks, an int4 per lane
+  if (vec) {
+    const int4 v = *reinterpret_cast<const int4*>(c + lane * 4);
+    c4[0] = v.x; c4[1] = v.y; c4[2] = v.z; c4[3] = v.w;
+    mine = (v.x + v.y) + (v.z + v.w);
+  } else {
+    for (int i = lane * cpl; i < min((lane + 1) * cpl, nchunk); ++i) mine += c[i];
+  }
   const int before = wave_excl_scan(mine, lane);
   const unsigned long long hit = __ballot(r >= before && r < before + mine);
   if (hit == 0ull || r < 0) {                    // rank beyond the population
@@ -403,30 +411,54 @@ __global__ __launch_bounds__(64) void rank_select_kernel(const uint8_t* __restri
   int chunk = -1, rem = 0;
   if (lane == owner) {
     int acc = before;
-    for (int i = lane * cpl; i < min((lane + 1) * cpl, nchunk); ++i) {
-      if (r < acc + c[i]) { chunk = i; rem = r - acc; break; }
-      acc += c[i];
+    if (vec) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (chunk < 0 && r < acc + c4[j]) { chunk = lane * 4 + j; rem = r - acc; }
+        acc += c4[j];
+      }
+    } else {
+      for (int i = lane * cpl; i < min((lane + 1) * cpl, nchunk); ++i) {
+        if (r < acc + c[i]) { chunk = i; rem = r - acc; break; }
+        acc += c[i];
+      }
     }
   }
   chunk = __shfl(chunk, owner);
   rem = __shfl(rem, owner);
-  // level 2: inside the chunk, 64 bytes per lane
+  // level 2: inside the chunk, 64 bytes per lane held in registers as a 64-bit occupancy word
   const size_t base = (size_t)m * HW + (size_t)chunk * RS_CHUNK;
   const int off = lane * 64;
-  int cnt = 0;
-  for (int i = 0; i < 64; ++i)
-    if (chunk * RS_CHUNK + off + i < HW) cnt += mask[base + off + i] != 0;
+  unsigned long long occ = 0ull;
+  if (chunk * RS_CHUNK + off + 64 <= HW) {
+    const uint4* p4 = reinterpret_cast<const uint4*>(mask + base + off);      // rows and chunks are 16-byte aligned
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint4 w = p4[j];
+      const unsigned xs[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        // 4 bytes of 0/1 -> 4 bits (multiplying gathers byte i's bit 0 at bit 24 + i; the partial products do not carry)
+        const unsigned long long nib = ((xs[q] & 0x01010101u) * 0x01020408u) >> 24 & 0xfu;
+        occ |= nib << (16 * j + 4 * q);
+      }
+    }
+  } else {
+    for (int i = 0; i < 64; ++i)
+      if (chunk * RS_CHUNK + off + i < HW && mask[base + off + i] != 0) occ |= 1ull << i;
+  }
+  const int cnt = __popcll(occ);
   const int b2 = wave_excl_scan(cnt, lane);
   const unsigned long long hit2 = __ballot(rem >= b2 && rem < b2 + cnt);
   const int owner2 = __ffsll((long long)hit2) - 1;
   if (lane == owner2) {
-    int left = rem - b2;
-    for (int i = 0; i < 64; ++i) {
-      if (mask[base + off + i] != 0) {
-        if (left == 0) { out[(size_t)m * K + k] = chunk * RS_CHUNK + off + i; break; }
-        --left;
-      }
+    int left = rem - b2, pos = 0;                 // position of the left-th set bit of occ
+#pragma unroll
+    for (int sft = 32; sft > 0; sft >>= 1) {
+      const int c = __popcll(occ & ((1ull << sft) - 1ull));
+      if (left >= c) { occ >>= sft; left -= c; pos += sft; }
     }
+    out[(size_t)m * K + k] = chunk * RS_CHUNK + off + pos;
   }
 }
 
