@@ -41,6 +41,9 @@ SIGNATURES = {
     "as_cam_boxes": (_c_int, [_c_void_p] * 2 + [_c_float] * 2 + [_c_int] * 4 + [_c_void_p] * 5 + [_c_size_t, _c_void_p]),
     "as_cam_sample_masks_workspace_bytes": (_c_size_t, [_c_int] * 4),
     "as_cam_sample_masks": (_c_int, [_c_void_p] * 3 + [_c_int] * 4 + [_c_float] * 2 + [_c_void_p] * 3 + [_c_size_t, _c_void_p]),
+    "as_mask_candidates_workspace_bytes": (_c_size_t, [_c_int] * 3),
+    "as_mask_candidates": (_c_int, [_c_void_p] * 3 + [_c_float] * 3 + [_c_int] + [_c_void_p] * 5 + [_c_size_t]
+                           + [_c_int] * 3 + [_c_void_p]),
     "as_semantic_prestage": (_c_int, [_c_void_p, _c_float] + [_c_int] * 5 + [_c_void_p] * 4),
     "as_cosine_shift_workspace_bytes": (_c_size_t, [_c_int] * 6),
     "as_cosine_shift": (_c_int, [_c_void_p] * 4 + [_c_float] * 2 + [_c_int] + [_c_void_p] * 4 + [_c_size_t]

@@ -239,12 +239,6 @@ extern "C" int as_crop_threshold_erode(const float* maps, const int32_t* crops, 
 }
 
 // =====================================================================================================
-// Rank select: the k-th set pixel (raster order, = the order of torch's .nonzero()) of byte masks, used to turn the
-// reference's `coords[random_index]` (stdroi:368-369, :456) into a lookup that needs no compaction pass.
-//   counts   grid (chunks, M): set bytes per 4096-byte chunk
-//   select   grid (K, M), one wave per rank: prefix over the chunk counts, then inside the chunk
-// =====================================================================================================
-// =====================================================================================================
 // Patch-grid foreground of get_semantic_centers (stdroi:2011-2012, 2020): erode(map_fg > thr, k) at full resolution,
 // bilinear DOWN to the patch grid.  For an exact integer factor `up` the down-sampled value is the mean of the 2x2
 // pixels (up/2-1, up/2) of the patch with weights 0.5/0.5, so only those four erosions are evaluated: a 16-lane group
@@ -321,6 +315,12 @@ extern "C" int as_semantic_prestage(const float* map_fg, float thr, int k, int G
   return AS_OK;
 }
 
+// =====================================================================================================
+// Rank select: the k-th set pixel (raster order, = the order of torch's .nonzero()) of byte masks, used to turn the
+// reference's `coords[random_index]` (stdroi:368-369, :456) into a lookup that needs no compaction pass.
+//   counts   grid (chunks, M): set bytes per 4096-byte chunk
+//   select   grid (K, M), one wave per rank: prefix over the chunk counts, then inside the chunk
+// =====================================================================================================
 namespace {
 
 constexpr int RS_CHUNK = 4096;
@@ -463,6 +463,119 @@ __global__ __launch_bounds__(64) void rank_select_kernel(const uint8_t* __restri
 }
 
 }  // namespace
+
+// =====================================================================================================
+// All three candidate masks of one image's objects in one call (stdroi:433-461 mask points, :2356-2358 pseudo masks):
+//   pos    = erode_k(in_crop && map_fg > max_crop(map_fg) * pos_thr)   (foreground point candidates, :442)
+//   neg    =          in_crop && map_bg > max_crop(map_bg) * neg_thr   (background point candidates, :443)
+//   pseudo =                     map_fg > max(map_fg)      * mask_thr   (the pseudo mask, :2357)
+// The three maxima come from one pass over the maps, the three thresholdings from a second; the separable erosion
+// reuses the crop kernels above.  counts [3, G]: set pixels of pos / neg / pseudo.
+// =====================================================================================================
+namespace {
+
+__global__ __launch_bounds__(RF_NT) void cand_max_kernel(const float* __restrict__ map_fg, const float* __restrict__ map_bg,
+                                                         const int32_t* __restrict__ crops, unsigned* __restrict__ mx,
+                                                         int G, int H, int W) {
+  __shared__ float sh[RF_NT];
+  const int g = blockIdx.y;
+  const Crop c = load_crop(crops, g, H, W);
+  const size_t base = (size_t)g * H * W;
+  float vf = -INFINITY, vb = -INFINITY, va = -INFINITY;
+  for (int i = blockIdx.x * RF_NT + threadIdx.x; i < H * W; i += gridDim.x * RF_NT) {
+    const int y = i / W, x = i - y * W;
+    const float f = map_fg[base + i];
+    va = fmaxf(va, f);
+    if (x >= c.x0 && x < c.x1 && y >= c.y0 && y < c.y1) {
+      vf = fmaxf(vf, f);
+      vb = fmaxf(vb, map_bg[base + i]);
+    }
+  }
+  const float rf = block_max(vf, sh), rb = block_max(vb, sh), ra = block_max(va, sh);
+  if (threadIdx.x == 0) {
+    if (rf > -INFINITY) atomicMax(&mx[g], f2ord(rf));
+    if (rb > -INFINITY) atomicMax(&mx[G + g], f2ord(rb));
+    atomicMax(&mx[2 * G + g], f2ord(ra));
+  }
+}
+
+__global__ __launch_bounds__(RF_NT) void cand_threshold_kernel(const float* __restrict__ map_fg,
+                                                               const float* __restrict__ map_bg,
+                                                               const int32_t* __restrict__ crops,
+                                                               const unsigned* __restrict__ mx, float pos_thr,
+                                                               float neg_thr, float mask_thr, uint8_t* __restrict__ t0,
+                                                               uint8_t* __restrict__ neg, uint8_t* __restrict__ pseudo,
+                                                               int32_t* __restrict__ counts, int G, int H, int W) {
+  __shared__ int shc[RF_NT];
+  const int g = blockIdx.y;
+  const Crop c = load_crop(crops, g, H, W);
+  const size_t base = (size_t)g * H * W;
+  const float tp = ord2f(mx[g]) * pos_thr, tn = ord2f(mx[G + g]) * neg_thr, ta = ord2f(mx[2 * G + g]) * mask_thr;
+  int cn = 0, ca = 0;
+  for (int i = blockIdx.x * RF_NT + threadIdx.x; i < H * W; i += gridDim.x * RF_NT) {
+    const int y = i / W, x = i - y * W;
+    const bool inside = x >= c.x0 && x < c.x1 && y >= c.y0 && y < c.y1;
+    const float f = map_fg[base + i];
+    const bool vp = inside && f > tp;
+    const bool vn = inside && map_bg[base + i] > tn;
+    const bool va = f > ta;
+    t0[base + i] = vp ? 1 : 0;
+    neg[base + i] = vn ? 1 : 0;
+    pseudo[base + i] = va ? 1 : 0;
+    cn += vn ? 1 : 0; ca += va ? 1 : 0;
+  }
+  for (int which = 0; which < 2; ++which) {
+    shc[threadIdx.x] = which == 0 ? cn : ca;
+    __syncthreads();
+    for (int o = RF_NT / 2; o > 0; o >>= 1) {
+      if (threadIdx.x < o) shc[threadIdx.x] += shc[threadIdx.x + o];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0 && shc[0] > 0) atomicAdd(&counts[(1 + which) * G + g], shc[0]);
+    __syncthreads();
+  }
+}
+
+}  // namespace
+
+extern "C" size_t as_mask_candidates_workspace_bytes(int G, int H, int W) {
+  if (G <= 0 || H <= 0 || W <= 0) return 0;
+  return 2 * (((size_t)G * H * W + 255) / 256 * 256) + ((size_t)3 * G * 4 + 255) / 256 * 256;
+}
+
+extern "C" int as_mask_candidates(const float* map_fg, const float* map_bg, const int32_t* crops, float pos_thr,
+                                  float neg_thr, float mask_thr, int k, uint8_t* pos, uint8_t* neg, uint8_t* pseudo,
+                                  int32_t* counts, void* ws, size_t ws_bytes, int G, int H, int W, as_stream_t stream) {
+  AS_REQUIRE(map_fg && map_bg && crops && pos && neg && pseudo && counts && ws, AS_E_BADARG,
+             "as_mask_candidates: null pointer");
+  AS_REQUIRE(G > 0 && H > 0 && W > 0 && k >= 1 && (k & 1) == 1, AS_E_BADARG, "as_mask_candidates: bad sizes (k odd)");
+  AS_REQUIRE(ws_bytes >= as_mask_candidates_workspace_bytes(G, H, W), AS_E_WORKSPACE,
+             "as_mask_candidates: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  const size_t plane = ((size_t)G * H * W + 255) / 256 * 256;
+  uint8_t* t0 = (uint8_t*)ws;
+  uint8_t* t1 = t0 + plane;
+  unsigned* mx = (unsigned*)(t1 + plane);
+  const int bx = (int)(((size_t)H * W + RF_NT * 4 - 1) / (RF_NT * 4));
+  (void)hipMemsetAsync(mx, 0, (size_t)3 * G * 4, s);
+  (void)hipMemsetAsync(counts, 0, (size_t)3 * G * 4, s);
+  // atomics per workgroup on a few words per object: keep the workgroup count per object small
+  hipLaunchKernelGGL(cand_max_kernel, dim3(bx < 64 ? bx : 64, G), dim3(RF_NT), 0, s, map_fg, map_bg, crops, mx, G, H, W);
+  hipLaunchKernelGGL(cand_threshold_kernel, dim3(bx < 96 ? bx : 96, G), dim3(RF_NT), 0, s, map_fg, map_bg, crops, mx,
+                     pos_thr, neg_thr, mask_thr, k == 1 ? pos : t0, neg, pseudo, counts, G, H, W);
+  if (k == 1) {
+    // pos needs its count: a plain count of the thresholded crop
+    hipLaunchKernelGGL(mask_count_kernel, dim3(64, G), dim3(RF_NT), 0, s, pos, counts, H * W);
+  } else {
+    const int r = k / 2;
+    hipLaunchKernelGGL((crop_mask_kernel<1, false>), dim3(bx, G), dim3(RF_NT), 0, s, map_fg, t0, crops, mx, 0.0f, 0, r, t1,
+                       counts, H, W);
+    hipLaunchKernelGGL((crop_mask_kernel<2, true>), dim3(bx, G), dim3(RF_NT), 0, s, map_fg, t1, crops, mx, 0.0f, 0, r, pos,
+                       counts, H, W);
+  }
+  AS_CHECK_LAUNCH("mask_candidates");
+  return AS_OK;
+}
 
 extern "C" size_t as_rank_select_workspace_bytes(int M, int HW) {
   if (M <= 0 || HW <= 0) return 0;

@@ -471,6 +471,23 @@ def crop_threshold_erode(maps, crops, thr, relative, k):
     return mask, counts
 
 
+def mask_candidates(map_fg, map_bg, crops, pos_thr, neg_thr, mask_thr, k):
+    """map_fg, map_bg [G,H,W] fp32, crops [G,4] int32 -> (pos, neg, pseudo uint8 [G,H,W], counts int32 [3,G]):
+    the foreground / background point candidates of stdroi:442-443 and the pseudo mask of :2357 in one call."""
+    lib = _lib.load()
+    _chk(map_fg, map_bg, dtype=torch.float32)
+    _chk(crops, dtype=torch.int32)
+    G, H, W = map_fg.shape
+    pos, neg, pseudo = (torch.empty(G, H, W, device=map_fg.device, dtype=torch.uint8) for _ in range(3))
+    counts = torch.empty(3, G, device=map_fg.device, dtype=torch.int32)
+    nbytes = lib.as_mask_candidates_workspace_bytes(G, H, W)
+    ws = torch.empty(nbytes, device=map_fg.device, dtype=torch.uint8)
+    _lib.check(lib.as_mask_candidates(_p(map_fg), _p(map_bg), _p(crops), float(pos_thr), float(neg_thr), float(mask_thr),
+                                      int(k), _p(pos), _p(neg), _p(pseudo), _p(counts), _p(ws), nbytes, G, H, W,
+                                      _stream()), "as_mask_candidates")
+    return pos, neg, pseudo, counts
+
+
 def mask_count(mask):
     """mask bool/uint8 [M,HW] (HW % 16 == 0) -> int32 [M] number of set elements per row."""
     lib = _lib.load()

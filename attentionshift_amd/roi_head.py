@@ -336,6 +336,15 @@ def mask_points_issue(map_fg, map_bg, rois, pos_thr, neg_thr, corr_size):
     return dict(pos=pos, neg=neg, cp=cp, crops=crops, counts=torch.stack((cp, cn), dim=1), shape=tuple(map_fg.shape))
 
 
+def mask_points_and_pseudo_issue(map_fg, map_bg, rois, pos_thr, neg_thr, corr_size, mask_thr):
+    """mask_points_issue plus the pseudo mask of stdroi:2357 from ONE fused call (ops.mask_candidates): the three
+    thresholds share their maxima pass and their thresholding pass.  Returns (pending dict, pseudo mask uint8)."""
+    crops = rois.int().contiguous()                      # stdroi:1981: rois[i].int().tolist()
+    pos, neg, pseudo, counts = ops.mask_candidates(map_fg.contiguous(), map_bg.contiguous(), crops, pos_thr, neg_thr,
+                                                   mask_thr, corr_size)
+    return dict(pos=pos, neg=neg, cp=counts[0], crops=crops, counts=counts[:2].t(), shape=tuple(map_fg.shape)), pseudo
+
+
 def mask_points_finish(pend, num_gt, rng_mode="reference"):
     """Host half of mask_sample_points: ONE sync (the counts), the draws, and the rank lookups."""
     pos, neg, cp, crops = pend["pos"], pend["neg"], pend["cp"], pend["crops"]
@@ -823,9 +832,9 @@ class AttnShiftRoIHead(nn.Module):
             map_idx = (cam_off[i] + gt_box_index[i] * counts[i] + ar).to(torch.int32)      # rows of cams_lr (layer-major)
             map_fg, map_bg, _pa, _pb, feats_fg, feats_bg = self.refine_maps(
                 None, feats[i], pseudo_boxes[i], gt_points[i], 2, obj_tau, cam_src=(cams_lr, map_idx, cam_minmax))
-            mp = mask_points_issue(map_fg[-1], map_bg[-1], pseudo_boxes[i], pos_mask_thr, neg_mask_thr, corr_size)
+            mp, mask_u8 = mask_points_and_pseudo_issue(map_fg[-1], map_bg[-1], pseudo_boxes[i], pos_mask_thr, neg_mask_thr,
+                                                       corr_size, pos_mask_thr)                # B2' + B6 (stdroi:2356)
             fg_inter, _map_fg_patch, gs = self._semantic_pre(map_fg[-1], map_bg[-1], pos_mask_thr)   # gs: >= 0.35 of a 0/1 map
-            mask_u8, _ = ops.crop_threshold_erode(map_fg[-1].contiguous(), None, pos_mask_thr, True, 1)   # stdroi:2356
             pm = _to_host_issue(mask_u8)
             return mp, gs, map_fg, map_bg, feats_fg, feats_bg, fg_inter, pm
 

@@ -186,6 +186,17 @@ int as_cam_sample_masks(const float* cams /*[M,Hp,Wp]*/, const int32_t* map_idx 
                         const float* minmax /*[M,2]*/, int G, int Hp, int Wp, int up, float thr_bg, float thr_fg,
                         uint8_t* masks, int32_t* counts, void* ws, size_t ws_bytes, as_stream_t stream);
 
+/* The three candidate masks of one image's G objects in one call (stdroi:433-461, :2356-2358); crops [G,4] int32
+ * half-open (x0,y0,x1,y1):
+ *   pos    [G,H,W] uint8 = erode_k(in_crop && map_fg > max_crop(map_fg) * pos_thr)
+ *   neg    [G,H,W] uint8 =          in_crop && map_bg > max_crop(map_bg) * neg_thr
+ *   pseudo [G,H,W] uint8 =                     map_fg > max(map_fg)      * mask_thr
+ *   counts [3,G] int32 set pixels of pos / neg / pseudo (written by the call). */
+size_t as_mask_candidates_workspace_bytes(int G, int H, int W);
+int as_mask_candidates(const float* map_fg, const float* map_bg, const int32_t* crops, float pos_thr, float neg_thr,
+                       float mask_thr, int k, uint8_t* pos, uint8_t* neg, uint8_t* pseudo, int32_t* counts, void* ws,
+                       size_t ws_bytes, int G, int H, int W, as_stream_t stream);
+
 /* Patch-grid foreground of get_semantic_centers (stdroi:2011-2012, 2020), one launch:
  *   fg_inter [G,Hp*Wp] = bilinear x(1/up) of erode_k(map_fg > thr)   (map_fg [G, Hp*up, Wp*up])
  *   mask     [G,Hp*Wp] uint8 = fg_inter > thr,  counts [G] = set entries per object (the grid-seed candidates, :1784) */

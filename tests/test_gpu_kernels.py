@@ -410,6 +410,23 @@ def test_cam_sample_masks_bit_exact(ops, G, hp, wp):
     assert_equal(want.flatten(1).sum(1).int(), counts, "candidate counts")
 
 
+@pytest.mark.parametrize("k", [21, 1])
+def test_mask_candidates_equal_the_three_separate_calls(ops, k):
+    """as_mask_candidates == crop_threshold_erode(fg, crops, k) / (bg, crops, 1) / (fg, whole image, 1), bitwise."""
+    gen = torch.Generator().manual_seed(23)
+    G, H, W = 3, 160, 224
+    low = torch.rand(2, G, H // 16, W // 16, generator=gen)
+    fg, bg = (torch.nn.functional.interpolate(low[i][None], scale_factor=16, mode="bilinear")[0].contiguous() for i in range(2))
+    crops = torch.tensor([[10, 5, 150, 140], [0, 0, W, H], [200, 100, 190, 120]], dtype=torch.int32)   # last: empty crop
+    pos, neg, pseudo, counts = ops.mask_candidates(dev(fg), dev(bg), dev(crops), 0.35, 0.8, 0.5, k)
+    p0, c0 = ops.crop_threshold_erode(dev(fg), dev(crops), 0.35, True, k)
+    p1, c1 = ops.crop_threshold_erode(dev(bg), dev(crops), 0.8, True, 1)
+    p2, c2 = ops.crop_threshold_erode(dev(fg), None, 0.5, True, 1)
+    assert_equal(p0, pos, "pos candidates"); assert_equal(p1, neg, "neg candidates"); assert_equal(p2, pseudo, "pseudo mask")
+    assert_equal(torch.stack((c0, c1, c2)), counts, "counts")
+    assert int(counts[0, 0]) > 0 and int(counts[1, 1]) > 0 and int(counts[0, 2]) == 0
+
+
 @pytest.mark.parametrize("G,hp,wp,thr", [(3, 14, 14, 0.35), (2, 9, 20, 0.5), (5, 6, 6, 0.35)])
 def test_semantic_prestage_matches_oracle(ops, G, hp, wp, thr):
     """erode_11(map > thr) -> bilinear /16 -> binarise (stdroi:2011-2020) in one launch vs max-pool + interpolate."""
