@@ -252,6 +252,64 @@ def sample_points_from_cams(cams_lr, map_idx, minmax, gt_points, num_points, thr
     return out
 
 
+# ---- fast-RNG mode: draws on the device, no host sync -------------------------------------------------------------
+# rng_mode="fast" does not reproduce the reference's generator stream, only its distributions, so the draws need not
+# happen on the host: the candidate counts stay on the device, uniform numbers come from a device generator and
+# rank = floor(u * n).  The rare branches that need host logic (fewer candidates than points, tiny candidate sets) only
+# raise a device FLAG; the caller reads it with a readback it needs anyway and redoes that image on the synchronous
+# path (same distributions, different draws).
+
+def sample_points_from_cams_nosync(cams_lr, map_idx, minmax, num_points, gen, thr_bg=0.1, thr_fg=0.2):
+    """sample_points_from_cams without the count readback.  Returns (pts_bg, pts_fg, pts_supp, flag) with flag a
+    device bool: some candidate set is smaller than num_points (the reference's refill branches, stdroi:354-364)."""
+    G = map_idx.shape[0]
+    masks, counts = ops.cam_sample_masks(cams_lr, map_idx, minmax, thr_bg, thr_fg, STRIDE)
+    W = masks.shape[-1]
+    n = counts.float()[:, None]
+    u = torch.rand(2 * G + 1, num_points, device=masks.device, generator=gen)
+    ranks = torch.minimum((u * n).to(torch.int32), (counts[:, None] - 1).clamp(min=0))
+    flat = ops.rank_select(masks.flatten(1), ranks.contiguous())
+    pts = torch.stack((flat % W, flat // W), dim=-1)
+    return pts[:G], pts[G:2 * G], pts[2 * G:], (counts < num_points).any()
+
+
+def mask_points_nosync(pend, num_gt, gen):
+    """mask_points_finish without the count readback: num_gt DISTINCT uniform ranks among the n = n_pos + n_neg
+    candidates of each object (the first num_gt entries of a random permutation, stdroi:447) = the first num_gt
+    distinct values of 32 uniform draws.  flag: an object with fewer than 4*num_gt candidates (the host path's
+    randperm / refill / empty branches) or, with probability < 1e-12, too few distinct draws."""
+    pos, neg, cp = pend["pos"], pend["neg"], pend["cp"]
+    G, H, W = pend["shape"]
+    counts = pend["counts"]                                           # [G, 2] = (n_pos, n_neg)
+    n = counts.sum(1)
+    m = 32
+    c = torch.minimum((torch.rand(G, m, device=pos.device, generator=gen) * n.float()[:, None]).long(),
+                      (n.long()[:, None] - 1).clamp(min=0))
+    dup = (c[:, :, None] == c[:, None, :]).tril(-1).any(dim=2)          # equals an EARLIER draw
+    order = (~dup).long().cumsum(1) - 1                                 # position among the distinct draws
+    take = (~dup) & (order < num_gt)
+    ranks = torch.zeros(G, num_gt, dtype=torch.long, device=pos.device)
+    ranks.scatter_add_(1, order.clamp(0, num_gt - 1), torch.where(take, c, torch.zeros_like(c)))
+    flag = (n < 4 * num_gt).any() | (take.sum(1) < num_gt).any()
+    n_pos = cp.long()[:, None]
+    is_pos = ranks < n_pos
+    idx_pos = ops.rank_select(pos.flatten(1), torch.where(is_pos, ranks, torch.zeros_like(ranks)).int().contiguous())
+    idx_neg = ops.rank_select(neg.flatten(1), torch.where(is_pos, torch.zeros_like(ranks), ranks - n_pos).int().contiguous())
+    flat = torch.where(is_pos, idx_pos, idx_neg).long().clamp(min=0, max=H * W - 1)
+    coords = torch.stack((flat % W, flat // W), dim=-1).float()
+    return coords, is_pos, flag
+
+
+def grid_seed_nosync(mask, count_dev, n_points=20):
+    """grid_seed_finish without the count readback, for objects with at least n_points positives (stdroi:1790-1792:
+    every (n // n_points)-th positive in raster order).  flag: an object with fewer (refill / box-centre branches)."""
+    G, hp, wp = mask.shape
+    step = (count_dev // n_points).clamp(min=1)
+    ranks = torch.arange(n_points, device=mask.device, dtype=torch.int32)[None, :] * step[:, None].int()
+    flat = rank_select(mask.flatten(1), ranks.contiguous()).long().clamp(min=0)
+    return torch.stack((flat // wp, flat % wp), dim=-1), (count_dev < n_points).any()
+
+
 def _sample_point_grid_slow(maps, num_points, thr, is_pos, gt_points=None):
     """The rare branches of stdroi:354-364 (fewer candidates than points), one object at a time."""
     out = []
@@ -433,13 +491,21 @@ def merge_plan(keep, link):
     return groups
 
 
-def merge_parts(prot, keep, thr):
+def merge_parts(prot, keep, thr, extra=None):
     """stdroi:278-294 merge_maps for all objects: prot [G,P,C], keep [G,P] ->
-    (list over objects of merged prototypes [m_g, C] or []).  One host sync for the whole image."""
+    (list over objects of merged prototypes [m_g, C] or []).  One host sync for the whole image; `extra` (a list that
+    holds device bool scalars) rides on the same transfer and is replaced by its host values."""
     G, P, C = prot.shape
     u = _unit(prot)
     link = (u @ u.transpose(1, 2)) >= thr
-    host = torch.cat((keep[:, None, :], link), dim=1).cpu().numpy()          # [G, 1+P, P]
+    packed = torch.cat((keep[:, None, :], link), dim=1)                      # [G, 1+P, P]
+    if extra:
+        tail = torch.stack([e.reshape(()) for e in extra]).to(packed.dtype)
+        both = torch.cat((packed.flatten(), tail)).cpu().numpy()
+        extra[:] = [bool(v) for v in both[packed.numel():]]
+        host = both[:packed.numel()].reshape(G, 1 + P, P)
+    else:
+        host = packed.cpu().numpy()
     plans = [merge_plan(host[g, 0], host[g, 1:]) for g in range(G)]
     m_max = max((len(p) for p in plans), default=0)
     if m_max == 0:
@@ -566,6 +632,8 @@ class AttnShiftRoIHead(nn.Module):
         self.parallel_images = parallel_images
         self.batch_mean_shift = True              # one as_cosine_shift call for all images of a batch
         self.image_streams = True                 # one HIP stream per image in the single-threaded fast-RNG path
+        self.device_draws = True                  # fast-RNG mode: draws on the device, no readback before the merge plan
+        self._dev_gens = {}
         self._pool, self._streams = None, []
         self.visualize = visualize
         self.epoch, self.epoch_semantic_centers = epoch, epoch_semantic_centers
@@ -590,13 +658,18 @@ class AttnShiftRoIHead(nn.Module):
                             "(dense [B,N,N] attention maps are never materialised on this path)")
         return ops.rollout_rows(states, num_proposals)
 
-    def refine_maps(self, attn_sel, feat_chw, rois, gt_points, refine_times, obj_tau, minmax=None, cam_src=None):
+    def refine_maps(self, attn_sel, feat_chw, rois, gt_points, refine_times, obj_tau, minmax=None, cam_src=None,
+                    draw_gen=None, flags_out=None):
         """B2 (stdroi:1000-1019).  attn_sel [G,H,W], feat [C,hp,wp]; minmax [G,2] = per-map (min,max) if the
         caller already has them (as_cam_boxes does).  cam_src = (cams_lr [M,hp,wp], map_idx [G] int32, minmax [M,2])
         replaces attn_sel: the seed sampling then reads the low-resolution CAMs and the upsampled maps are never
         materialised.  Returns map_fg, map_bg [R+1,G,H,W], points_fg, points_bg, fg_feat, bg_feat."""
         C, hp, wp = feat_chw.shape
-        if cam_src is not None:
+        if cam_src is not None and draw_gen is not None:          # fast-RNG mode: no readback, flag instead
+            G = cam_src[1].shape[0]
+            pts_bg, pts_fg, pts_supp, short = sample_points_from_cams_nosync(cam_src[0], cam_src[1], cam_src[2], 20, draw_gen)
+            flags_out.append(short)
+        elif cam_src is not None:
             G = cam_src[1].shape[0]
             pts_bg, pts_fg, pts_supp = sample_points_from_cams(cam_src[0], cam_src[1], cam_src[2], gt_points, 20)
         else:
@@ -684,6 +757,17 @@ class AttnShiftRoIHead(nn.Module):
         CLOCK.mark("  sc:mean_shift")
         return self._semantic_post(prot, sim, fg_inter, rois, vit_feat, gt_labels, merge_thr, num_semantic_points)
 
+    def _device_gen(self, device, reseed=False):
+        """Device generator of the fast RNG mode.  `reseed` (once per seed_pseudo_gt call) draws its seed from torch's
+        global CPU generator, so that equal global seeds give equal samples, as in the reference mode."""
+        key = str(device)
+        if key not in self._dev_gens:
+            self._dev_gens[key] = torch.Generator(device=device)
+            reseed = True
+        if reseed:
+            self._dev_gens[key].manual_seed(int(torch.randint(2 ** 62, (1,)).item()))
+        return self._dev_gens[key]
+
     def _semantic_pre(self, map_cos_fg, map_cos_bg, pos_thr):
         """First part of get_semantic_centers (stdroi:2011-2020): the patch-grid foreground maps, one fused launch
         (ops.semantic_prestage).  The reference also down-samples max_g(map_cos_bg) here (bg_inter, :2013), but its
@@ -693,12 +777,15 @@ class AttnShiftRoIHead(nn.Module):
         CLOCK.mark("  sc:prestage")
         return fg_inter, mask.to(fg_inter.dtype), (mask, counts)
 
-    def _semantic_post(self, prot, sim, fg_inter, rois, vit_feat, gt_labels, merge_thr, num_semantic_points):
-        """Last part of get_semantic_centers (stdroi:2022-2031): filter / merge the shifted prototypes, part centres."""
+    def _semantic_post(self, prot, sim, fg_inter, rois, vit_feat, gt_labels, merge_thr, num_semantic_points, extra=None):
+        """Last part of get_semantic_centers (stdroi:2022-2031): filter / merge the shifted prototypes, part centres.
+        `extra`: device flags read back with the merge plan (see merge_parts); returns None if any of them is set."""
         G = fg_inter.shape[0]
         P = sim.shape[0] // G
         keep = filter_parts(sim.unflatten(0, (G, P)), fg_inter)
-        merged = merge_parts(prot.unflatten(0, (G, P)), keep, merge_thr)
+        merged = merge_parts(prot.unflatten(0, (G, P)), keep, merge_thr, extra)
+        if extra and any(extra):
+            return None
         CLOCK.mark("  sc:filter+merge")
         sim_parts = part_similarity(merged, vit_feat)
         CLOCK.mark("  sc:part_similarity")
@@ -845,9 +932,73 @@ class AttnShiftRoIHead(nn.Module):
             seeds = grid_seed_finish(gs[0], gs[1], pseudo_boxes[i], 20)
             return coord_point, labels_point, map_fg, map_bg, feats_fg, feats_bg, (fg_inter, seeds), pm
 
+        def phase_a_nosync(i):
+            """phase_a + phase_a_finish with every draw made on the device (fast RNG mode): nothing is read back.  The
+            last element is the list of device flags that ask for the synchronous path (rare refill branches)."""
+            flags = []
+            ar = torch.arange(counts[i], device=boxes.device)
+            map_idx = (cam_off[i] + gt_box_index[i] * counts[i] + ar).to(torch.int32)
+            map_fg, map_bg, _pa, _pb, feats_fg, feats_bg = self.refine_maps(
+                None, feats[i], pseudo_boxes[i], gt_points[i], 2, obj_tau, cam_src=(cams_lr, map_idx, cam_minmax),
+                draw_gen=self._device_gen(boxes.device), flags_out=flags)
+            mp, mask_u8 = mask_points_and_pseudo_issue(map_fg[-1], map_bg[-1], pseudo_boxes[i], pos_mask_thr, neg_mask_thr,
+                                                       corr_size, pos_mask_thr)
+            fg_inter, _map_fg_patch, gs = self._semantic_pre(map_fg[-1], map_bg[-1], pos_mask_thr)
+            pm = _to_host_issue(mask_u8)
+            coord_point, labels_point, f1 = mask_points_nosync(mp, num_mask_point_gt, self._device_gen(boxes.device))
+            seeds, f2 = grid_seed_nosync(gs[0], gs[1], 20)
+            flags += [f1, f2]
+            return coord_point, labels_point, map_fg, map_bg, feats_fg, feats_bg, (fg_inter, seeds), pm, flags
+
+        nosync = (self.rng_mode == "fast" and self.device_draws and not self.parallel_images and self.image_streams
+                  and self.batch_mean_shift and torch.cuda.is_available() and not CLOCK.on and not self.visualize)
         multi = (self.rng_mode == "fast" and num_imgs > 1 and not self.parallel_images and self.image_streams
                  and torch.cuda.is_available() and not CLOCK.on)
-        if multi:
+        if nosync:
+            # Fast RNG mode, device-side draws: the host queues the WHOLE chain of every image (refinement, candidate
+            # masks, draws, seeds), the batched mean shift and the merge inputs without reading anything back, i.e. while
+            # the device is still in the backbone; the first readback is the merge plan of stdroi:278-294, which also
+            # carries the flags of the rare branches that need the synchronous path (and the deferred CAM check).
+            if len(self._streams) < num_imgs:
+                self._streams = [torch.cuda.Stream() for _ in range(num_imgs)]
+            main = torch.cuda.current_stream()
+            self._device_gen(boxes.device, reseed=True)
+
+            def on_stream(i, fn, *args):
+                with torch.cuda.stream(self._streams[i]):
+                    return fn(i, *args)
+
+            for st in self._streams[:num_imgs]:
+                st.wait_stream(main)
+            ra = [on_stream(i, phase_a_nosync) for i in range(num_imgs)]
+            for st in self._streams[:num_imgs]:
+                main.wait_stream(st)
+            shifted = self.mean_shift_batch([r[6][1] for r in ra], feats, pseudo_boxes, self.mean_shift_times_local,
+                                            feat_tok=feat_tok)
+
+            def image_chain_nosync(i):
+                prot, sim = shifted[i]
+                extra = [bad_cam] + ra[i][8]
+                sc = self._semantic_post(prot, sim, ra[i][6][0], pseudo_boxes[i], feats[i], gt_labels[i], 0.85,
+                                         self.num_semantic_points, extra=extra)
+                if sc is None:
+                    if extra[0]:
+                        raise RuntimeError("seed_pseudo_gt: a CAM has no foreground component (constant attention map)")
+                    r = phase_a_finish(i, phase_a(i))            # a rare branch needs host logic: synchronous path
+                    prot, sim = self.mean_shift_batch([r[6][1]], [feats[i]], [pseudo_boxes[i]],
+                                                      self.mean_shift_times_local)[0]
+                    sc = self._semantic_post(prot, sim, r[6][0], pseudo_boxes[i], feats[i], gt_labels[i], 0.85,
+                                             self.num_semantic_points)
+                    return r[:6] + (sc, _to_host_finish(r[7]))
+                return ra[i][:6] + (sc, _to_host_finish(ra[i][7]))
+
+            for st in self._streams[:num_imgs]:
+                st.wait_stream(main)
+            results = [on_stream(i, image_chain_nosync) for i in range(num_imgs)]
+            for st in self._streams[:num_imgs]:
+                main.wait_stream(st)
+            ra = None
+        elif multi:
             # One HIP stream per image, one host thread.  Every image's device work is queued first and only then are
             # the counts read back: a host sync waits for ITS image's stream only, so image i+1's refinement runs on
             # the device while the host draws and resolves image i's points (the draw ORDER across images changes,
@@ -871,9 +1022,11 @@ class AttnShiftRoIHead(nn.Module):
             ra = [phase_a_finish(i, issued[i]) for i in range(num_imgs)]
         else:
             ra = self._run_images(lambda i: phase_a_finish(i, phase_a(i)), num_imgs)
-        if bool(bad_cam):
+        if ra is not None and bool(bad_cam):
             raise RuntimeError("seed_pseudo_gt: a CAM has no foreground component (constant attention map)")
-        if self.batch_mean_shift or num_imgs == 1:           # ONE mean-shift call for the whole batch
+        if ra is None:
+            pass                                             # the sync-free path has already produced `results`
+        elif self.batch_mean_shift or num_imgs == 1:         # ONE mean-shift call for the whole batch
             shifted = self.mean_shift_batch([r[6][1] for r in ra], feats, pseudo_boxes, self.mean_shift_times_local,
                                             feat_tok=feat_tok)
         else:
@@ -889,7 +1042,9 @@ class AttnShiftRoIHead(nn.Module):
             CLOCK.mark("pseudo_masks")
             return ra[i][:6] + (sc, mask_np)
 
-        if multi:
+        if ra is None:
+            pass
+        elif multi:
             for st in self._streams[:num_imgs]:
                 st.wait_stream(main)                         # shifted prototypes come from the caller's stream
             results = [on_stream(i, image_chain) for i in range(num_imgs)]
