@@ -298,3 +298,82 @@ def test_vit_large_shape_step(monkeypatch):
     m = out["pseudo_gt_masks"][0]
     assert m.shape == (G, H, H) and m.reshape(G, -1).any(1).all()
     assert torch.isfinite(out["map_cos_fg"][0]).all() and len(out["num_parts"][0]) == G
+
+
+# ---- fast-RNG mode: device-side draws -----------------------------------------------------------------------------
+def _dev_gen(seed=7):
+    g = torch.Generator(device="cuda")
+    g.manual_seed(seed)
+    return g
+
+
+def test_grid_seed_nosync_equals_host_path_and_flags_short_objects():
+    """The strided grid seeds are deterministic: the device-side ranks must select exactly what the host path selects
+    whenever every object has >= 20 positives; an object with fewer raises the flag."""
+    from attentionshift_amd import roi_head as RH
+    gen = torch.Generator().manual_seed(3)
+    mask = (torch.rand(4, 24, 20, generator=gen) > 0.6).to(torch.uint8).cuda()
+    counts = mask.flatten(1).sum(1).int()
+    rois = torch.tensor([[0, 0, 320, 384]] * 4, dtype=torch.float32).cuda()
+    want = RH.grid_seed_finish(mask, counts, rois, 20)
+    got, flag = RH.grid_seed_nosync(mask, counts, 20)
+    assert_equal(want, got, "grid seeds")
+    assert not bool(flag)
+    mask[2] = 0
+    mask[2, 3, 4:9] = 1                                     # 5 positives: the refill branch
+    _, flag = RH.grid_seed_nosync(mask, mask.flatten(1).sum(1).int(), 20)
+    assert bool(flag)
+
+
+def test_mask_points_nosync_draws_distinct_candidates_with_right_labels():
+    from attentionshift_amd import roi_head as RH
+    gen = torch.Generator().manual_seed(5)
+    G, H, W = 3, 64, 80
+    pos = (torch.rand(G, H, W, generator=gen) > 0.7).to(torch.uint8).cuda()
+    neg = ((torch.rand(G, H, W, generator=gen) > 0.5).to(torch.uint8).cuda()) & (1 - pos)
+    counts = torch.stack((pos.flatten(1).sum(1), neg.flatten(1).sum(1)), dim=1).int()
+    pend = dict(pos=pos, neg=neg, cp=counts[:, 0], counts=counts, shape=(G, H, W), crops=None)
+    coords, labels, flag = RH.mask_points_nosync(pend, 10, _dev_gen())
+    assert not bool(flag) and coords.shape == (G, 10, 2) and labels.shape == (G, 10)
+    x, y = coords[..., 0].long(), coords[..., 1].long()
+    for g in range(G):
+        assert (pos[g][y[g][labels[g]], x[g][labels[g]]] == 1).all()          # positive labels sit on pos candidates
+        assert (neg[g][y[g][~labels[g]], x[g][~labels[g]]] == 1).all()
+        assert len({(int(a), int(b), bool(c)) for a, b, c in zip(x[g], y[g], labels[g])}) == 10     # distinct
+    # both label kinds occur over many draws, in proportion to the candidate counts
+    lab = torch.stack([RH.mask_points_nosync(pend, 10, _dev_gen(100 + k))[1] for k in range(40)]).float().mean((0, 2))
+    frac = counts[:, 0].float() / counts.sum(1).float()
+    assert (lab - frac).abs().max() < 0.12
+    small = dict(pend, counts=torch.tensor([[3, 2]] * G, dtype=torch.int32).cuda(), cp=torch.tensor([3] * G, dtype=torch.int32).cuda())
+    assert bool(RH.mask_points_nosync(small, 10, _dev_gen())[2])            # tiny candidate sets -> synchronous path
+
+
+def test_fast_mode_flagged_image_falls_back_to_the_synchronous_path(monkeypatch):
+    """Force the device flag of one stage: the step must still complete through the synchronous path and satisfy the
+    same invariants (the fallback redoes the image with host-side draws)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from attentionshift_amd import roi_head as RH
+    monkeypatch.setattr(bench, "CFG", dict(bench.CFG, img=512, depth=8))
+    step = bench.build(torch.device("cuda", 0), "fast")
+    real = RH.grid_seed_nosync
+    calls = []
+
+    def flagged(mask, count_dev, n_points=20):
+        coords, flag = real(mask, count_dev, n_points)
+        calls.append(1)
+        return coords, torch.ones_like(flag) if len(calls) == 1 else flag      # flag image 0 only
+
+    monkeypatch.setattr(RH, "grid_seed_nosync", flagged)
+    torch.manual_seed(0)
+    out = step()
+    assert len(calls) == 2
+    H = 512
+    for i in range(2):
+        box = out["pseudo_gt_bboxes"][i]
+        assert (box[:, :2] >= 0).all() and (box[:, 2:] <= H).all()
+        m = out["pseudo_gt_masks"][i]
+        assert m.shape[1:] == (H, H) and m.reshape(m.shape[0], -1).any(1).all()
+        assert out["mask_points_coords"][i].shape[1:] == (10, 2)
