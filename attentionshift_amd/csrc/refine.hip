@@ -239,6 +239,44 @@ extern "C" int as_crop_threshold_erode(const float* maps, const int32_t* crops, 
 }
 
 // =====================================================================================================
+// Greedy grouping of merge_maps (stdroi:278-294) for all objects on the device: keep [G,P] (0/1), link [G,P,P] (0/1,
+// cos >= thr) -> groups [G,P] int32 bit sets over the ORIGINAL prototype ids in the order the reference's loop emits
+// them (0 = unused slot), ngroups [G].  Row i of the upper-triangular kept sub-matrix starts a group with every kept
+// j >= i it links to, unless an earlier group already cleared row i (`sim_triu[weight > 0] *= 0`); columns are not
+// cleared, exactly as in the reference.  One thread per object (P <= 32: a row is one word).
+// =====================================================================================================
+namespace {
+__global__ void merge_plan_kernel(const uint8_t* __restrict__ keep, const uint8_t* __restrict__ link,
+                                  int32_t* __restrict__ groups, int32_t* __restrict__ ngroups, int G, int P) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= G) return;
+  unsigned kept = 0u;
+  for (int p = 0; p < P; ++p) kept |= (keep[g * P + p] != 0 ? 1u : 0u) << p;
+  unsigned cleared = 0u;
+  int n = 0;
+  for (int i = 0; i < P; ++i) {
+    groups[g * P + i] = 0;
+    if (!((kept >> i) & 1u) || ((cleared >> i) & 1u)) continue;
+    unsigned row = 0u;
+    for (int j = i; j < P; ++j) row |= (link[((size_t)g * P + i) * P + j] != 0 ? 1u : 0u) << j;
+    row &= kept;
+    if (row) { groups[g * P + n] = (int32_t)row; ++n; cleared |= row; }
+  }
+  ngroups[g] = n;
+}
+}  // namespace
+
+extern "C" int as_merge_plan(const uint8_t* keep, const uint8_t* link, int32_t* groups, int32_t* ngroups, int G, int P,
+                             as_stream_t stream) {
+  AS_REQUIRE(keep && link && groups && ngroups, AS_E_BADARG, "as_merge_plan: null pointer");
+  AS_REQUIRE(G > 0 && P > 0 && P <= 32, AS_E_UNSUPPORTED, "as_merge_plan: P=%d prototypes per object (max 32)", P);
+  hipLaunchKernelGGL(merge_plan_kernel, dim3(as_ceil_div(G, 64)), dim3(64), 0, (hipStream_t)stream, keep, link, groups,
+                     ngroups, G, P);
+  AS_CHECK_LAUNCH("merge_plan");
+  return AS_OK;
+}
+
+// =====================================================================================================
 // Patch-grid foreground of get_semantic_centers (stdroi:2011-2012, 2020): erode(map_fg > thr, k) at full resolution,
 // bilinear DOWN to the patch grid.  For an exact integer factor `up` the down-sampled value is the mean of the 2x2
 // pixels (up/2-1, up/2) of the patch with weights 0.5/0.5, so only those four erosions are evaluated: a 16-lane group

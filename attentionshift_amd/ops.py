@@ -488,6 +488,20 @@ def mask_candidates(map_fg, map_bg, crops, pos_thr, neg_thr, mask_thr, k):
     return pos, neg, pseudo, counts
 
 
+def merge_plan(keep, link):
+    """keep [G,P] bool/uint8, link [G,P,P] bool/uint8 -> (groups [G,P] int32 bit sets, ngroups [G] int32): the greedy
+    grouping of stdroi:278-294 for every object, on the device."""
+    lib = _lib.load()
+    k8 = keep.to(torch.uint8).contiguous()
+    l8 = link.to(torch.uint8).contiguous()
+    _chk(k8, l8)
+    G, P = k8.shape
+    groups = torch.empty(G, P, device=k8.device, dtype=torch.int32)
+    ngroups = torch.empty(G, device=k8.device, dtype=torch.int32)
+    _lib.check(lib.as_merge_plan(_p(k8), _p(l8), _p(groups), _p(ngroups), G, P, _stream()), "as_merge_plan")
+    return groups, ngroups
+
+
 def mask_count(mask):
     """mask bool/uint8 [M,HW] (HW % 16 == 0) -> int32 [M] number of set elements per row."""
     lib = _lib.load()

@@ -793,6 +793,82 @@ class AttnShiftRoIHead(nn.Module):
             sim_parts, rois, gt_labels, vit_feat, num_max_obj=num_semantic_points)
         return centers, split, sim_parts, feat_split, feats, num_parts, coords_org, labels_org, corres
 
+    def _semantic_post_device(self, prot, sim, fg_inter, rois, vit_feat, gt_labels, merge_thr, num_semantic_points,
+                              extra=None, num_max_keep=50):
+        """_semantic_post with ONE readback at its end (fast-RNG path): the greedy merge plan (ops.merge_plan), the
+        merged prototypes, their similarity maps and the per-part statistics are computed for all P group slots of
+        every object (unused slots are zero prototypes), the visiting order / cap logic of stdroi:222-262 becomes a
+        stable rank over the slots, and only the choice bits, ranks and group counts are read back -- together with
+        the `extra` flags, whose host values replace the list's entries; returns None if any of them is set."""
+        G = fg_inter.shape[0]
+        P = sim.shape[0] // G
+        hp, wp = vit_feat.shape[-2:]
+        dev = prot.device
+        protg = prot.unflatten(0, (G, P))
+        keep = filter_parts(sim.unflatten(0, (G, P)), fg_inter)
+        u = _unit(protg)
+        groups, ngroups = ops.merge_plan(keep, (u @ u.transpose(1, 2)) >= merge_thr)
+        ar = torch.arange(P, device=dev)
+        wgt = ((groups[..., None] >> ar.int()) & 1).float()                           # [G, slot, member]
+        merged = torch.bmm(wgt, protg) / (wgt.sum(-1, keepdim=True) + 1e-8)            # matmul(weight, prot) / (sum + 1e-8)
+        feat_tok = vit_feat.flatten(1).t().contiguous()
+        allp = merged.flatten(0, 1).contiguous()
+        sims = torch.cat([ops.refine_similarity(feat_tok, allp[o:o + 32], None, 0, 0, 1.0, False, hp, wp)[0][0]
+                          for o in range(0, G * P, 32)]).reshape(G, P, hp, wp)
+        # per-slot statistics exactly as part_centers computes them per part
+        peak = sims.flatten(2).max(2)[0][..., None, None]
+        at_peak = (sims >= peak).float()
+        cnt = at_peak.sum(dim=[-2, -1])
+        ys = torch.arange(hp, device=dev, dtype=torch.float32)[None, None, :, None]
+        xs = torch.arange(wp, device=dev, dtype=torch.float32)[None, None, None, :]
+        cy = (at_peak * ys).sum(dim=[-2, -1]) / cnt
+        cx = (at_peak * xs).sum(dim=[-2, -1]) / cnt
+        area = (sims > 0.9).sum(dim=[-2, -1])
+        c = (torch.stack((cx, cy), dim=-1) + 0.5) * STRIDE                             # [G, P, 2]
+        box = rois[:, None, :]
+        inside = (c[..., 0] >= box[..., 0]) & (c[..., 0] <= box[..., 2]) & (c[..., 1] >= box[..., 1]) & (c[..., 1] <= box[..., 3])
+        valid = ar[None, :] < ngroups[:, None]
+        a = torch.where(valid, area, torch.full_like(area, -1))
+        before = (a[:, None, :] > a[:, :, None]) | ((a[:, None, :] == a[:, :, None]) & (ar[None, None, :] < ar[None, :, None]))
+        rank = before.sum(-1)                                # position in argsort(descending, stable)
+        chosen = valid & inside & (rank <= num_semantic_points)                       # `if i > num_max_obj: break`
+        pieces = [chosen.flatten().int(), rank.flatten().int(), ngroups]
+        if extra:
+            pieces.append(torch.stack([e.reshape(()) for e in extra]).int())
+        host = torch.cat(pieces).cpu().numpy()                                         # the one sync
+        if extra:
+            extra[:] = [bool(v) for v in host[2 * G * P + G:]]
+            if any(extra):
+                return None
+        ch, rk, ng = host[:G * P].reshape(G, P), host[G * P:2 * G * P].reshape(G, P), host[2 * G * P:2 * G * P + G]
+        sim_parts = [sims[g, :int(ng[g])] if ng[g] else torch.zeros(0, 0) for g in range(G)]
+        split = [0] * G
+        dt_c, dt_l = rois.dtype, gt_labels.dtype
+        empty = ([torch.zeros(0, 2, dtype=dt_c, device=dev), torch.zeros(0, dtype=dt_l, device=dev)], [], [], [], split,
+                 torch.zeros(0, 2, dtype=dt_c, device=dev), torch.zeros(0, dtype=dt_l, device=dev),
+                 torch.zeros(0, dtype=torch.long, device=dev))
+        sel_g, sel_p = [], []
+        for g in range(G):
+            ps = [p_ for p_ in np.argsort(rk[g], kind="stable") if ch[g, p_]]
+            split[g] = len(ps)
+            sel_g += [g] * len(ps)
+            sel_p += [int(p_) for p_ in ps]
+        if not sel_g:
+            pc = empty
+        else:
+            sg = torch.as_tensor(sel_g, device=dev, dtype=torch.long)
+            sp = torch.as_tensor(sel_p, device=dev, dtype=torch.long)
+            coords, labels = c[sg, sp], gt_labels[sg]
+            feats = vit_feat[:, cy[sg, sp].long(), cx[sg, sp].long()].t()
+            coords_org, labels_org = coords.clone(), labels.clone()
+            coord_split, feats_split = list(coords.split(split, dim=0)), list(feats.split(split, dim=0))
+            if coords.shape[0] > num_max_keep:
+                pick = torch.randperm(coords.shape[0], device=coords.device)[:num_max_keep]
+                coords, labels = coords[pick], labels[pick]
+            pc = ([coords, labels], coord_split, feats_split, feats, split, coords_org, labels_org, sg)
+        (centers, csplit, feat_split, feats, num_parts, coords_org, labels_org, corres) = pc
+        return centers, csplit, sim_parts, feat_split, feats, num_parts, coords_org, labels_org, corres
+
     # ---- the hot-path entry point -------------------------------------------------------------------
     @torch.no_grad()
     def _run_images(self, fn, num_imgs):
@@ -979,8 +1055,8 @@ class AttnShiftRoIHead(nn.Module):
             def image_chain_nosync(i):
                 prot, sim = shifted[i]
                 extra = [bad_cam] + ra[i][8]
-                sc = self._semantic_post(prot, sim, ra[i][6][0], pseudo_boxes[i], feats[i], gt_labels[i], 0.85,
-                                         self.num_semantic_points, extra=extra)
+                sc = self._semantic_post_device(prot, sim, ra[i][6][0], pseudo_boxes[i], feats[i], gt_labels[i], 0.85,
+                                                self.num_semantic_points, extra=extra)
                 if sc is None:
                     if extra[0]:
                         raise RuntimeError("seed_pseudo_gt: a CAM has no foreground component (constant attention map)")

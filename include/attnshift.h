@@ -197,6 +197,11 @@ int as_mask_candidates(const float* map_fg, const float* map_bg, const int32_t* 
                        float mask_thr, int k, uint8_t* pos, uint8_t* neg, uint8_t* pseudo, int32_t* counts, void* ws,
                        size_t ws_bytes, int G, int H, int W, as_stream_t stream);
 
+/* Greedy grouping of merge_maps (stdroi:278-294) for G objects: keep [G,P] uint8, link [G,P,P] uint8 (cos >= thr)
+ * -> groups [G,P] int32 bit sets over the prototype ids, in the reference's emission order (0 = unused), ngroups [G]. */
+int as_merge_plan(const uint8_t* keep, const uint8_t* link, int32_t* groups, int32_t* ngroups, int G, int P,
+                  as_stream_t stream);
+
 /* Patch-grid foreground of get_semantic_centers (stdroi:2011-2012, 2020), one launch:
  *   fg_inter [G,Hp*Wp] = bilinear x(1/up) of erode_k(map_fg > thr)   (map_fg [G, Hp*up, Wp*up])
  *   mask     [G,Hp*Wp] uint8 = fg_inter > thr,  counts [G] = set entries per object (the grid-seed candidates, :1784) */

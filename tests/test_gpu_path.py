@@ -377,3 +377,38 @@ def test_fast_mode_flagged_image_falls_back_to_the_synchronous_path(monkeypatch)
         m = out["pseudo_gt_masks"][i]
         assert m.shape[1:] == (H, H) and m.reshape(m.shape[0], -1).any(1).all()
         assert out["mask_points_coords"][i].shape[1:] == (10, 2)
+
+
+@pytest.mark.parametrize("tag", ["tiny224", "mid320"])
+def test_semantic_post_device_matches_reference_fixture_and_host_path(golden, tag):
+    """The one-readback form of the filter / merge / part-centre stage (stdroi:2022-2031) gives the reference's part
+    counts, centres, owners and centre features, and the same similarity maps as the host-logic form."""
+    import attentionshift_amd as A
+    from attentionshift_amd import ops
+    g = golden(f"shift_{tag}")
+    inp = shift_case_inputs(g)
+    hp, wp, G = int(g["hp"]), int(g["wp"]), int(g["G"])
+    head = A.AttnShiftRoIHead(num_semantic_points=int(g["num_semantic_points"]), mean_shift_times_local=int(g["n_shift"]))
+    rois = t(g["rois"]).cuda()
+    feat = inp["vit_feat"].cuda()
+    labels = inp["labels"].cuda()
+    fg_inter, map_fg, _ = head._semantic_pre(t(g["map_fg_last"]).cuda(), t(g["map_bg_last"]).cuda(), float(g["pos_thr"]))
+    prot, sim = head.mean_shift_grid_prototype(map_fg, feat, rois, tau=0.1, temp=0.1, n_shift=int(g["n_shift"]))
+    args = (prot, sim, fg_inter, rois, feat, labels, 0.85, int(g["num_semantic_points"]))
+    want = head._semantic_post(*args)
+    flags = [torch.zeros((), dtype=torch.bool, device="cuda")]
+    got = head._semantic_post_device(*args, extra=flags)
+    assert flags == [False]
+    assert_equal(g["num_parts"], np.array(got[5]), "num_parts")
+    assert_close(t(g["coords_org"]), got[6], 0, 0, "centre coords")
+    assert_equal(g["corres_gt"], got[8], "corres_gt")
+    assert_equal(g["labels_org"], got[7], "labels")
+    assert_equal(want[0][0], got[0][0], "centres"); assert_equal(want[0][1], got[0][1], "centre labels")
+    assert want[5] == got[5]
+    if g["feats_all"].shape[0]:
+        assert_close(t(g["feats_all"]), got[4], 0, 0, "centre features")
+    for a_, b_ in zip(want[2], got[2]):
+        assert a_.shape == b_.shape
+        if a_.numel():
+            assert_close(a_, b_, 1e-5, 1e-6, "part similarity maps")
+    assert head._semantic_post_device(*args, extra=[torch.ones((), dtype=torch.bool, device="cuda")]) is None
