@@ -31,3 +31,16 @@ __device__ __forceinline__ unsigned f2ord(float f) {
 __device__ __forceinline__ float ord2f(unsigned u) {
   return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
 }
+
+// Row-block evaluation of the x`up` bilinear map.  bilerp(y, x) = fma(ly.l0, top, ly.l1 * bot) where
+// top / bot = the horizontal interpolation in source rows ly.i0 / ly.i1 depend on (x, source row) only: a thread
+// keeps the columns it owns, walks the rows of its block and recomputes top / bot only when the source row pair
+// changes (every `up` rows) -- 2 flops per pixel instead of two index computations, four loads and 7 flops, with
+// exactly the same operations and rounding as bilerp().
+struct ColLerp { Lerp lx; float top, bot; };
+__device__ __forceinline__ void col_refresh(ColLerp& c, const float* __restrict__ src, int Wp, const Lerp& ly) {
+  c.top = fmaf(c.lx.l0, src[ly.i0 * Wp + c.lx.i0], c.lx.l1 * src[ly.i0 * Wp + c.lx.i1]);
+  c.bot = fmaf(c.lx.l0, src[ly.i1 * Wp + c.lx.i0], c.lx.l1 * src[ly.i1 * Wp + c.lx.i1]);
+}
+__device__ __forceinline__ float col_value(const ColLerp& c, const Lerp& ly) { return fmaf(ly.l0, c.top, ly.l1 * c.bot); }
+

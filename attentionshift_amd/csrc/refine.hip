@@ -39,6 +39,9 @@ __device__ __forceinline__ float block_max(float v, float* sh) {
 }
 
 // PASS 1: max ret, max up_bg      PASS 2: max bg      PASS 3: write map_fg, map_bg
+// grid (ceil(H / IM_RB), L*G): a workgroup owns a block of rows, a thread its columns (x = tid, tid + 256, ...); the
+// horizontal interpolation of a column is kept while the rows share a source row pair (bilinear.h, ColLerp).
+constexpr int IM_RB = 16;
 template <int PASS>
 __global__ __launch_bounds__(RF_NT) void instance_maps_kernel(const float* __restrict__ sim_fg,
                                                               const float* __restrict__ sim_bg,
@@ -52,27 +55,35 @@ __global__ __launch_bounds__(RF_NT) void instance_maps_kernel(const float* __res
   const float* fg = sim_fg + ((size_t)l * Gp + g) * Np;
   const float* bg = sim_bg + ((size_t)l * G + g) * Np;
   const float sy = (float)Hp / (float)H, sx = (float)Wp / (float)W;
+  const int y0 = blockIdx.x * IM_RB, y1 = min(y0 + IM_RB, H);
   float mret = 0.0f, mupbg = 0.0f, mbg = 0.0f;
   float a1 = -INFINITY, a2 = -INFINITY;
   if (PASS >= 2) { mret = ord2f(meta[lg].max_ret); mupbg = ord2f(meta[lg].max_upbg); }
   if (PASS == 3) mbg = ord2f(meta[lg].max_bg);
-  for (int i = blockIdx.x * RF_NT + threadIdx.x; i < H * W; i += gridDim.x * RF_NT) {
-    const int y = i / W, x = i - y * W;
-    const Lerp ly = lerp_axis(y, Hp, sy), lx = lerp_axis(x, Wp, sx);
-    const float ufg = bilerp(fg, Wp, ly, lx), ubg = bilerp(bg, Wp, ly, lx);
-    const float ret = (1.0f - ubg) * ufg;
-    if (PASS == 1) {
-      a1 = fmaxf(a1, ret);
-      a2 = fmaxf(a2, ubg);
-    } else {
-      const float nb = ubg / (mupbg + 1e-8f);
-      const float nf = ret / (mret + 1e-8f);
-      const float b = nb + (1.0f - (nf * 0.5f + nb * 0.5f));
-      if (PASS == 2) {
-        a1 = fmaxf(a1, b);
+  for (int x = threadIdx.x; x < W; x += RF_NT) {
+    ColLerp cf, cb;
+    cf.lx = lerp_axis(x, Wp, sx);
+    cb.lx = cf.lx;
+    int cur = -1;
+    for (int y = y0; y < y1; ++y) {
+      const Lerp ly = lerp_axis(y, Hp, sy);
+      if (ly.i0 != cur) { col_refresh(cf, fg, Wp, ly); col_refresh(cb, bg, Wp, ly); cur = ly.i0; }
+      const float ufg = col_value(cf, ly), ubg = col_value(cb, ly);
+      const float ret = (1.0f - ubg) * ufg;
+      if (PASS == 1) {
+        a1 = fmaxf(a1, ret);
+        a2 = fmaxf(a2, ubg);
       } else {
-        map_fg[(size_t)lg * H * W + i] = ret / fmaxf(mret, 1e-8f);
-        map_bg[(size_t)lg * H * W + i] = b / fmaxf(mbg, 1e-8f);
+        const float nb = ubg / (mupbg + 1e-8f);
+        const float nf = ret / (mret + 1e-8f);
+        const float b = nb + (1.0f - (nf * 0.5f + nb * 0.5f));
+        if (PASS == 2) {
+          a1 = fmaxf(a1, b);
+        } else {
+          const size_t i = (size_t)lg * H * W + (size_t)y * W + x;
+          map_fg[i] = ret / fmaxf(mret, 1e-8f);
+          map_bg[i] = b / fmaxf(mbg, 1e-8f);
+        }
       }
     }
   }
@@ -100,17 +111,15 @@ extern "C" int as_instance_maps(const float* sim_fg, const float* sim_bg, int L,
   hipStream_t s = (hipStream_t)stream;
   MapMeta* meta = (MapMeta*)ws;
   const int n = L * G;
-  const size_t hw = (size_t)Hp * up * Wp * up;
-  const int bx = (int)((hw + RF_NT * 4 - 1) / (RF_NT * 4));
-  // the reduction passes end in ONE atomic per workgroup on a per-map word: same-address atomics serialise at ~10 ns,
-  // so 1024 workgroups per map made those passes atomic-bound (160 / 92 us); grid-stride over fewer, fatter workgroups
-  const int bxr = bx < 96 ? bx : 96;
+  // the reduction passes end in one or two atomics per workgroup on a per-map word (same-address atomics serialise
+  // at ~10 ns): 64 workgroups per map at 1024 rows
+  const int by = as_ceil_div(Hp * up, IM_RB);
   hipLaunchKernelGGL(meta_init_kernel, dim3(as_ceil_div(n, 64)), dim3(64), 0, s, meta, n);
-  hipLaunchKernelGGL((instance_maps_kernel<1>), dim3(bxr, n), dim3(RF_NT), 0, s, sim_fg, sim_bg, meta, map_fg, map_bg, G,
+  hipLaunchKernelGGL((instance_maps_kernel<1>), dim3(by, n), dim3(RF_NT), 0, s, sim_fg, sim_bg, meta, map_fg, map_bg, G,
                      Gp, Hp, Wp, up);
-  hipLaunchKernelGGL((instance_maps_kernel<2>), dim3(bxr, n), dim3(RF_NT), 0, s, sim_fg, sim_bg, meta, map_fg, map_bg, G,
+  hipLaunchKernelGGL((instance_maps_kernel<2>), dim3(by, n), dim3(RF_NT), 0, s, sim_fg, sim_bg, meta, map_fg, map_bg, G,
                      Gp, Hp, Wp, up);
-  hipLaunchKernelGGL((instance_maps_kernel<3>), dim3(bx, n), dim3(RF_NT), 0, s, sim_fg, sim_bg, meta, map_fg, map_bg, G,
+  hipLaunchKernelGGL((instance_maps_kernel<3>), dim3(by, n), dim3(RF_NT), 0, s, sim_fg, sim_bg, meta, map_fg, map_bg, G,
                      Gp, Hp, Wp, up);
   AS_CHECK_LAUNCH("instance_maps");
   return AS_OK;
@@ -598,7 +607,7 @@ extern "C" int as_mask_candidates(const float* map_fg, const float* map_bg, cons
   (void)hipMemsetAsync(mx, 0, (size_t)3 * G * 4, s);
   (void)hipMemsetAsync(counts, 0, (size_t)3 * G * 4, s);
   // atomics per workgroup on a few words per object: keep the workgroup count per object small
-  hipLaunchKernelGGL(cand_max_kernel, dim3(bx < 64 ? bx : 64, G), dim3(RF_NT), 0, s, map_fg, map_bg, crops, mx, G, H, W);
+  hipLaunchKernelGGL(cand_max_kernel, dim3(bx < 256 ? bx : 256, G), dim3(RF_NT), 0, s, map_fg, map_bg, crops, mx, G, H, W);
   hipLaunchKernelGGL(cand_threshold_kernel, dim3(bx < 96 ? bx : 96, G), dim3(RF_NT), 0, s, map_fg, map_bg, crops, mx,
                      pos_thr, neg_thr, mask_thr, k == 1 ? pos : t0, neg, pseudo, counts, G, H, W);
   if (k == 1) {

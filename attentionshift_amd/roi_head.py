@@ -659,7 +659,7 @@ class AttnShiftRoIHead(nn.Module):
         return ops.rollout_rows(states, num_proposals)
 
     def refine_maps(self, attn_sel, feat_chw, rois, gt_points, refine_times, obj_tau, minmax=None, cam_src=None,
-                    draw_gen=None, flags_out=None):
+                    draw_gen=None, flags_out=None, last_level_only=False):
         """B2 (stdroi:1000-1019).  attn_sel [G,H,W], feat [C,hp,wp]; minmax [G,2] = per-map (min,max) if the
         caller already has them (as_cam_boxes does).  cam_src = (cams_lr [M,hp,wp], map_idx [G] int32, minmax [M,2])
         replaces attn_sel: the seed sampling then reads the low-resolution CAMs and the upsampled maps are never
@@ -690,7 +690,9 @@ class AttnShiftRoIHead(nn.Module):
         sim_bg, bg_feat = ops.refine_similarity(feat_tok, seed_features(pts_bg, feat_chw).contiguous(), box_patch, G,
                                                 refine_times, obj_tau, False, hp, wp)
         CLOCK.mark("  refine_similarity")
-        map_fg, map_bg = ops.instance_maps(sim_fg, sim_bg, G, hp, wp, STRIDE)
+        if last_level_only:                                     # the chain below only consumes the last refinement level
+            sim_fg, sim_bg = sim_fg[-1:], sim_bg[-1:]
+        map_fg, map_bg = ops.instance_maps(sim_fg.contiguous(), sim_bg.contiguous(), G, hp, wp, STRIDE)
         CLOCK.mark("  instance_maps")
         return map_fg, map_bg, pts_fg, pts_bg, fg_feat[:, :, None, None], bg_feat[:, :, None, None]
 
@@ -994,7 +996,8 @@ class AttnShiftRoIHead(nn.Module):
             ar = torch.arange(counts[i], device=boxes.device)
             map_idx = (cam_off[i] + gt_box_index[i] * counts[i] + ar).to(torch.int32)      # rows of cams_lr (layer-major)
             map_fg, map_bg, _pa, _pb, feats_fg, feats_bg = self.refine_maps(
-                None, feats[i], pseudo_boxes[i], gt_points[i], 2, obj_tau, cam_src=(cams_lr, map_idx, cam_minmax))
+                None, feats[i], pseudo_boxes[i], gt_points[i], 2, obj_tau, cam_src=(cams_lr, map_idx, cam_minmax),
+                last_level_only=True)
             mp, mask_u8 = mask_points_and_pseudo_issue(map_fg[-1], map_bg[-1], pseudo_boxes[i], pos_mask_thr, neg_mask_thr,
                                                        corr_size, pos_mask_thr)                # B2' + B6 (stdroi:2356)
             fg_inter, _map_fg_patch, gs = self._semantic_pre(map_fg[-1], map_bg[-1], pos_mask_thr)   # gs: >= 0.35 of a 0/1 map
@@ -1016,7 +1019,7 @@ class AttnShiftRoIHead(nn.Module):
             map_idx = (cam_off[i] + gt_box_index[i] * counts[i] + ar).to(torch.int32)
             map_fg, map_bg, _pa, _pb, feats_fg, feats_bg = self.refine_maps(
                 None, feats[i], pseudo_boxes[i], gt_points[i], 2, obj_tau, cam_src=(cams_lr, map_idx, cam_minmax),
-                draw_gen=self._device_gen(boxes.device), flags_out=flags)
+                draw_gen=self._device_gen(boxes.device), flags_out=flags, last_level_only=True)
             mp, mask_u8 = mask_points_and_pseudo_issue(map_fg[-1], map_bg[-1], pseudo_boxes[i], pos_mask_thr, neg_mask_thr,
                                                        corr_size, pos_mask_thr)
             fg_inter, _map_fg_patch, gs = self._semantic_pre(map_fg[-1], map_bg[-1], pos_mask_thr)
