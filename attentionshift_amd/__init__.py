@@ -9,5 +9,6 @@ from .registry import BACKBONES, HEADS, Registry, build_backbone, build_from_cfg
 from .config import Config, ConfigDict  # noqa: F401
 from .backbone import VisionTransformerDet  # noqa: F401
 from .roi_head import AttnShiftRoIHead  # noqa: F401
+from .checkpoint import load_checkpoint, save_checkpoint  # noqa: F401
 
 __version__ = "0.1.0"

@@ -156,10 +156,10 @@ class VisionTransformerDet(nn.Module):
         if isinstance(pretrained, str):
             import os
             if os.path.isfile(pretrained):
-                ckpt = torch.load(pretrained, map_location="cpu")
-                sd = ckpt.get("state_dict", ckpt.get("model", ckpt))
-                sd = {k[len("backbone."):] if k.startswith("backbone.") else k: v for k, v in sd.items()}
-                self.load_state_dict(sd, strict=False)
+                from .checkpoint import load_checkpoint
+                load_checkpoint(self, pretrained, strict=False)
+            else:
+                print(f"checkpoint path {pretrained} is invalid, we skip it and initialize net randomly")
         self.invalidate_cache()
 
     def train(self, mode=True):
