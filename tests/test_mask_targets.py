@@ -56,11 +56,12 @@ def test_targets_and_loss_literal_vs_intended(golden):
     gen = torch.Generator().manual_seed(1)
     pred = torch.randn(3, 5, 14, 14, generator=gen, requires_grad=True)
     cls = torch.tensor([1, 4, 0])
-    loss = MT.point_mask_loss(pred, sites, tg, cls)
-    logits = MT.point_sample(pred, sites)[torch.arange(3), cls]
-    want = (torch.nn.functional.binary_cross_entropy_with_logits(logits, (tg == 1).float(), reduction="none") * (tg != 2)).sum() / tg.numel()
-    assert torch.allclose(loss, want, atol=1e-6)                          # ignored points weigh 0, mean over ALL points
-    loss.backward()
+    with torch.enable_grad():                                             # (the suite runs with grad disabled)
+        loss = MT.point_mask_loss(pred, sites, tg, cls)
+        logits = MT.point_sample(pred, sites)[torch.arange(3), cls]
+        want = (torch.nn.functional.binary_cross_entropy_with_logits(logits, (tg == 1).float(), reduction="none") * (tg != 2)).sum() / tg.numel()
+        assert torch.allclose(loss, want, atol=1e-6)                      # ignored points weigh 0, mean over ALL points
+        loss.backward()
     assert pred.grad is not None and torch.isfinite(pred.grad).all()
     assert MT.point_mask_loss(pred[:0], sites[:0], tg[:0], cls[:0]).item() == 0.0
     assert MT.point_mask_loss(pred, sites_l, tg_l, cls) > 0               # literal targets: nothing ignored
