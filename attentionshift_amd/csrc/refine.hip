@@ -248,6 +248,63 @@ extern "C" int as_crop_threshold_erode(const float* maps, const int32_t* crops, 
 }
 
 // =====================================================================================================
+// Per-part statistics of get_center_coord_with_feat (stdroi:222-262) for M similarity maps [M, Hp*Wp] in one launch:
+// peak, centroid of the pixels at the peak (mean of their integer coordinates), number of pixels > 0.9, the centre in
+// image coordinates ((x, y) + 0.5) * stride and whether it lies inside the owner's box.  One workgroup per map; the
+// coordinate sums are integers, so the result does not depend on the reduction order.
+//   out_c [M,2] (x,y) float, out_yx [M,2] (y,x) int32 = trunc of the centroid, out_area [M] int32, out_inside [M] uint8
+// =====================================================================================================
+namespace {
+__global__ __launch_bounds__(RF_NT) void part_stats_kernel(const float* __restrict__ maps, const float* __restrict__ rois,
+                                                           const int32_t* __restrict__ owner, float stride,
+                                                           float* __restrict__ out_c, int32_t* __restrict__ out_yx,
+                                                           int32_t* __restrict__ out_area, uint8_t* __restrict__ out_inside,
+                                                           int Hp, int Wp) {
+  __shared__ float sh[RF_NT];
+  __shared__ int shi[4][RF_NT];
+  const int m = blockIdx.x, tid = threadIdx.x, Np = Hp * Wp;
+  const float* src = maps + (size_t)m * Np;
+  float mx = -INFINITY;
+  for (int n = tid; n < Np; n += RF_NT) mx = fmaxf(mx, src[n]);
+  const float peak = block_max(mx, sh);
+  int cnt = 0, sy = 0, sx = 0, area = 0;
+  for (int n = tid; n < Np; n += RF_NT) {
+    const float v = src[n];
+    if (v >= peak) { const int y = n / Wp; ++cnt; sy += y; sx += n - y * Wp; }
+    if (v > 0.9f) ++area;
+  }
+  shi[0][tid] = cnt; shi[1][tid] = sy; shi[2][tid] = sx; shi[3][tid] = area;
+  __syncthreads();
+  for (int o = RF_NT / 2; o > 0; o >>= 1) {
+    if (tid < o)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) shi[q][tid] += shi[q][tid + o];
+    __syncthreads();
+  }
+  if (tid != 0) return;
+  const float c = (float)shi[0][0];
+  const float cy = (float)shi[1][0] / c, cx = (float)shi[2][0] / c;        // mean of nonzero().float() rows
+  const float px = (cx + 0.5f) * stride, py = (cy + 0.5f) * stride;
+  out_c[m * 2 + 0] = px; out_c[m * 2 + 1] = py;
+  out_yx[m * 2 + 0] = (int)cy; out_yx[m * 2 + 1] = (int)cx;
+  out_area[m] = shi[3][0];
+  const float* b = rois + (size_t)owner[m] * 4;
+  out_inside[m] = (px >= b[0] && px <= b[2] && py >= b[1] && py <= b[3]) ? 1 : 0;
+}
+}  // namespace
+
+extern "C" int as_part_stats(const float* maps, const float* rois, const int32_t* owner, float stride, float* out_c,
+                             int32_t* out_yx, int32_t* out_area, uint8_t* out_inside, int M, int Hp, int Wp,
+                             as_stream_t stream) {
+  AS_REQUIRE(maps && rois && owner && out_c && out_yx && out_area && out_inside, AS_E_BADARG, "as_part_stats: null pointer");
+  AS_REQUIRE(M > 0 && Hp > 0 && Wp > 0, AS_E_BADARG, "as_part_stats: bad sizes");
+  hipLaunchKernelGGL(part_stats_kernel, dim3(M), dim3(RF_NT), 0, (hipStream_t)stream, maps, rois, owner, stride, out_c,
+                     out_yx, out_area, out_inside, Hp, Wp);
+  AS_CHECK_LAUNCH("part_stats");
+  return AS_OK;
+}
+
+// =====================================================================================================
 // Greedy grouping of merge_maps (stdroi:278-294) for all objects on the device: keep [G,P] (0/1), link [G,P,P] (0/1,
 // cos >= thr) -> groups [G,P] int32 bit sets over the ORIGINAL prototype ids in the order the reference's loop emits
 // them (0 = unused slot), ngroups [G].  Row i of the upper-triangular kept sub-matrix starts a group with every kept

@@ -488,6 +488,24 @@ def mask_candidates(map_fg, map_bg, crops, pos_thr, neg_thr, mask_thr, k):
     return pos, neg, pseudo, counts
 
 
+def part_stats(maps, rois, owner, stride=16):
+    """maps [M,hp,wp] fp32, rois [G,4] fp32, owner [M] int -> (c [M,2] (x,y) image coords of the peak centroid,
+    yx [M,2] long (integer centroid), area [M] long (pixels > 0.9), inside [M] bool) -- stdroi:222-262 per part."""
+    lib = _lib.load()
+    maps = maps.contiguous()
+    rois = rois.contiguous().float()
+    own = owner.to(torch.int32).contiguous()
+    _chk(maps, rois, dtype=torch.float32)
+    M, hp, wp = maps.shape
+    c = torch.empty(M, 2, device=maps.device, dtype=torch.float32)
+    yx = torch.empty(M, 2, device=maps.device, dtype=torch.int32)
+    area = torch.empty(M, device=maps.device, dtype=torch.int32)
+    inside = torch.empty(M, device=maps.device, dtype=torch.uint8)
+    _lib.check(lib.as_part_stats(_p(maps), _p(rois), _p(own), float(stride), _p(c), _p(yx), _p(area), _p(inside), M, hp, wp,
+                                 _stream()), "as_part_stats")
+    return c, yx.long(), area.long(), inside.bool()
+
+
 def merge_plan(keep, link):
     """keep [G,P] bool/uint8, link [G,P,P] bool/uint8 -> (groups [G,P] int32 bit sets, ngroups [G] int32): the greedy
     grouping of stdroi:278-294 for every object, on the device."""

@@ -551,18 +551,8 @@ def part_centers(maps, rois, obj_label, feat_chw, num_max_keep=50, num_max_obj=3
         return empty
     allm = torch.cat([m for m in maps if m.shape[0] > 0])                     # [M, hp, wp]
     owner = torch.cat([torch.full((n,), g, dtype=torch.long) for g, n in enumerate(sizes)]).to(dev)
-    hp, wp = allm.shape[-2:]
-    peak = allm.flatten(1).max(1)[0][:, None, None]
-    at_peak = (allm >= peak).float()
-    cnt = at_peak.sum(dim=[-2, -1])
-    ys = torch.arange(hp, device=dev, dtype=torch.float32)[None, :, None]
-    xs = torch.arange(wp, device=dev, dtype=torch.float32)[None, None, :]
-    cy = (at_peak * ys).sum(dim=[-2, -1]) / cnt                                # mean of nonzero().float() rows
-    cx = (at_peak * xs).sum(dim=[-2, -1]) / cnt
-    area = (allm > 0.9).sum(dim=[-2, -1])
-    c = (torch.stack((cx, cy), dim=1) + 0.5) * STRIDE
-    box = rois[owner]
-    inside = (c[:, 0] >= box[:, 0]) & (c[:, 0] <= box[:, 2]) & (c[:, 1] >= box[:, 1]) & (c[:, 1] <= box[:, 3])
+    c, cyx, area, inside = ops.part_stats(allm, rois, owner, STRIDE)         # one launch for all parts
+    cy, cx = cyx[:, 0], cyx[:, 1]
     host = torch.stack((area.float(), inside.float()), dim=1).cpu().numpy()    # the one sync
     chosen, off = [], 0
     for g, n in enumerate(sizes):
@@ -581,7 +571,7 @@ def part_centers(maps, rois, obj_label, feat_chw, num_max_keep=50, num_max_obj=3
         return empty
     sel = torch.as_tensor(chosen, device=dev, dtype=torch.long)
     coords, labels = c[sel], obj_label[owner[sel]]
-    feats = feat_chw[:, cy[sel].long(), cx[sel].long()].t()
+    feats = feat_chw[:, cy[sel], cx[sel]].t()
     coords_org, labels_org = coords.clone(), labels.clone()
     coord_split, feats_split = list(coords.split(split, dim=0)), list(feats.split(split, dim=0))
     if coords.shape[0] > num_max_keep:
@@ -817,18 +807,11 @@ class AttnShiftRoIHead(nn.Module):
         allp = merged.flatten(0, 1).contiguous()
         sims = torch.cat([ops.refine_similarity(feat_tok, allp[o:o + 32], None, 0, 0, 1.0, False, hp, wp)[0][0]
                           for o in range(0, G * P, 32)]).reshape(G, P, hp, wp)
-        # per-slot statistics exactly as part_centers computes them per part
-        peak = sims.flatten(2).max(2)[0][..., None, None]
-        at_peak = (sims >= peak).float()
-        cnt = at_peak.sum(dim=[-2, -1])
-        ys = torch.arange(hp, device=dev, dtype=torch.float32)[None, None, :, None]
-        xs = torch.arange(wp, device=dev, dtype=torch.float32)[None, None, None, :]
-        cy = (at_peak * ys).sum(dim=[-2, -1]) / cnt
-        cx = (at_peak * xs).sum(dim=[-2, -1]) / cnt
-        area = (sims > 0.9).sum(dim=[-2, -1])
-        c = (torch.stack((cx, cy), dim=-1) + 0.5) * STRIDE                             # [G, P, 2]
-        box = rois[:, None, :]
-        inside = (c[..., 0] >= box[..., 0]) & (c[..., 0] <= box[..., 2]) & (c[..., 1] >= box[..., 1]) & (c[..., 1] <= box[..., 3])
+        # per-slot statistics exactly as part_centers computes them per part (one launch)
+        slot_owner = torch.arange(G, device=dev).repeat_interleave(P)
+        c, cyx, area, inside = ops.part_stats(sims.flatten(0, 1), rois, slot_owner, STRIDE)
+        c, cy, cx = c.unflatten(0, (G, P)), cyx[:, 0].unflatten(0, (G, P)), cyx[:, 1].unflatten(0, (G, P))
+        area, inside = area.unflatten(0, (G, P)), inside.unflatten(0, (G, P))
         valid = ar[None, :] < ngroups[:, None]
         a = torch.where(valid, area, torch.full_like(area, -1))
         before = (a[:, None, :] > a[:, :, None]) | ((a[:, None, :] == a[:, :, None]) & (ar[None, None, :] < ar[None, :, None]))
@@ -861,7 +844,7 @@ class AttnShiftRoIHead(nn.Module):
             sg = torch.as_tensor(sel_g, device=dev, dtype=torch.long)
             sp = torch.as_tensor(sel_p, device=dev, dtype=torch.long)
             coords, labels = c[sg, sp], gt_labels[sg]
-            feats = vit_feat[:, cy[sg, sp].long(), cx[sg, sp].long()].t()
+            feats = vit_feat[:, cy[sg, sp], cx[sg, sp]].t()
             coords_org, labels_org = coords.clone(), labels.clone()
             coord_split, feats_split = list(coords.split(split, dim=0)), list(feats.split(split, dim=0))
             if coords.shape[0] > num_max_keep:

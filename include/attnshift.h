@@ -197,6 +197,12 @@ int as_mask_candidates(const float* map_fg, const float* map_bg, const int32_t* 
                        float mask_thr, int k, uint8_t* pos, uint8_t* neg, uint8_t* pseudo, int32_t* counts, void* ws,
                        size_t ws_bytes, int G, int H, int W, as_stream_t stream);
 
+/* Per-part statistics of get_center_coord_with_feat (stdroi:222-262) for M part maps [M, Hp*Wp]; rois [G,4],
+ * owner [M] = object of each part: out_c [M,2] = ((x, y) of the peak centroid + 0.5) * stride, out_yx [M,2] = its
+ * integer (y, x), out_area [M] = pixels > 0.9, out_inside [M] = centre inside the owner's box. */
+int as_part_stats(const float* maps, const float* rois, const int32_t* owner, float stride, float* out_c,
+                  int32_t* out_yx, int32_t* out_area, uint8_t* out_inside, int M, int Hp, int Wp, as_stream_t stream);
+
 /* Greedy grouping of merge_maps (stdroi:278-294) for G objects: keep [G,P] uint8, link [G,P,P] uint8 (cos >= thr)
  * -> groups [G,P] int32 bit sets over the prototype ids, in the reference's emission order (0 = unused), ngroups [G]. */
 int as_merge_plan(const uint8_t* keep, const uint8_t* link, int32_t* groups, int32_t* ngroups, int G, int P,

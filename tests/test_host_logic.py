@@ -175,7 +175,20 @@ def test_semantic_center_host_logic_with_oracle_backed_shift(golden, tag, monkey
         fg_inter, _bg, fg_bin = O.semantic_prestage(map_fg, map_fg, (map_fg.shape[-2] // up, map_fg.shape[-1] // up), thr)
         return fg_inter, fg_bin.to(torch.uint8), fg_bin.flatten(1).sum(1).int()
 
+    def fake_part_stats(maps, rois, owner, stride=16):       # stdroi:222-262 per part, plain torch
+        peak = maps.flatten(1).max(1)[0][:, None, None]
+        at = (maps >= peak).float()
+        cnt = at.sum(dim=[-2, -1])
+        ys = torch.arange(maps.shape[1], dtype=torch.float32)[None, :, None]
+        xs = torch.arange(maps.shape[2], dtype=torch.float32)[None, None, :]
+        cy, cx = (at * ys).sum(dim=[-2, -1]) / cnt, (at * xs).sum(dim=[-2, -1]) / cnt
+        c = (torch.stack((cx, cy), dim=1) + 0.5) * stride
+        box = rois[owner.long()]
+        inside = (c[:, 0] >= box[:, 0]) & (c[:, 0] <= box[:, 2]) & (c[:, 1] >= box[:, 1]) & (c[:, 1] <= box[:, 3])
+        return c, torch.stack((cy.long(), cx.long()), dim=1), (maps > 0.9).sum(dim=[-2, -1]), inside
+
     monkeypatch.setattr(RH.ops, "cosine_shift", fake_cosine_shift)
+    monkeypatch.setattr(RH.ops, "part_stats", fake_part_stats)
     monkeypatch.setattr(RH.ops, "semantic_prestage", fake_semantic_prestage)
     monkeypatch.setattr(RH.ops, "refine_similarity", fake_refine_similarity)
     monkeypatch.setattr(RH.ops, "crop_threshold_erode", fake_crop_threshold_erode)
