@@ -305,6 +305,86 @@ extern "C" int as_part_stats(const float* maps, const float* rois, const int32_t
 }
 
 // =====================================================================================================
+// filter_maps (stdroi:263-271) for all G*P shifted prototypes in one launch: the share of a prototype's > sim_thr
+// support that lies on the object's patch-grid foreground, keep = share >= pos_thr.  fg_inter holds multiples of 1/4
+// and the support is 0/1, so both sums are exact in fp32 whatever the order.
+// =====================================================================================================
+namespace {
+__global__ __launch_bounds__(RF_NT) void filter_parts_kernel(const float* __restrict__ sim, const float* __restrict__ fg_inter,
+                                                             float sim_thr, float pos_thr, uint8_t* __restrict__ keep, int P,
+                                                             int Np) {
+  __shared__ float sa[RF_NT], sb[RF_NT];
+  const int gp = blockIdx.x, g = gp / P, tid = threadIdx.x;
+  const float* srow = sim + (size_t)gp * Np;
+  const float* frow = fg_inter + (size_t)g * Np;
+  float a = 0.0f, b = 0.0f;
+  for (int n = tid; n < Np; n += RF_NT) {
+    const float sup = srow[n] > sim_thr ? 1.0f : 0.0f;
+    a += frow[n] * sup;
+    b += sup;
+  }
+  sa[tid] = a; sb[tid] = b;
+  __syncthreads();
+  for (int o = RF_NT / 2; o > 0; o >>= 1) {
+    if (tid < o) { sa[tid] += sa[tid + o]; sb[tid] += sb[tid + o]; }
+    __syncthreads();
+  }
+  if (tid == 0) keep[gp] = (sa[0] / fmaxf(sb[0], 1e-6f)) >= pos_thr ? 1 : 0;
+}
+
+// The first K distinct values of M uniform draws floor(u * n) per object (= the head of a random permutation of the n
+// candidates, stdroi:447), split into positive / negative candidate ranks.  flag |= an object with n < 4K candidates
+// or fewer than K distinct draws (the caller then takes the host path for that image).
+__global__ void draw_distinct_kernel(const int32_t* __restrict__ counts /*[G,2] (n_pos, n_neg)*/,
+                                     const float* __restrict__ u /*[G,M]*/, int32_t* __restrict__ rank_pos,
+                                     int32_t* __restrict__ rank_neg, uint8_t* __restrict__ is_pos,
+                                     int32_t* __restrict__ flag, int G, int M, int K) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= G) return;
+  const int n_pos = counts[g * 2 + 0], n = n_pos + counts[g * 2 + 1];
+  int got = 0;
+  int picked[32];
+  for (int j = 0; j < M && got < K; ++j) {
+    int c = (int)(u[g * M + j] * (float)n);
+    c = min(c, max(n - 1, 0));
+    bool dup = false;
+    for (int q = 0; q < got; ++q) dup = dup || picked[q] == c;
+    if (!dup) picked[got++] = c;
+  }
+  if (n < 4 * K || got < K) atomicOr(flag, 1);
+  for (int q = 0; q < K; ++q) {
+    const int r = q < got ? picked[q] : 0;
+    const bool pos = r < n_pos;
+    is_pos[g * K + q] = pos ? 1 : 0;
+    rank_pos[g * K + q] = pos ? r : 0;
+    rank_neg[g * K + q] = pos ? 0 : r - n_pos;
+  }
+}
+}  // namespace
+
+extern "C" int as_filter_parts(const float* sim, const float* fg_inter, float sim_thr, float pos_thr, uint8_t* keep, int G,
+                               int P, int Np, as_stream_t stream) {
+  AS_REQUIRE(sim && fg_inter && keep, AS_E_BADARG, "as_filter_parts: null pointer");
+  AS_REQUIRE(G > 0 && P > 0 && Np > 0, AS_E_BADARG, "as_filter_parts: bad sizes");
+  hipLaunchKernelGGL(filter_parts_kernel, dim3(G * P), dim3(RF_NT), 0, (hipStream_t)stream, sim, fg_inter, sim_thr, pos_thr,
+                     keep, P, Np);
+  AS_CHECK_LAUNCH("filter_parts");
+  return AS_OK;
+}
+
+extern "C" int as_draw_distinct(const int32_t* counts, const float* u, int32_t* rank_pos, int32_t* rank_neg, uint8_t* is_pos,
+                                int32_t* flag, int G, int M, int K, as_stream_t stream) {
+  AS_REQUIRE(counts && u && rank_pos && rank_neg && is_pos && flag, AS_E_BADARG, "as_draw_distinct: null pointer");
+  AS_REQUIRE(G > 0 && M > 0 && K > 0 && K <= 32 && M >= K, AS_E_UNSUPPORTED, "as_draw_distinct: K=%d of M=%d draws (K <= 32)", K, M);
+  hipStream_t s = (hipStream_t)stream;
+  (void)hipMemsetAsync(flag, 0, 4, s);
+  hipLaunchKernelGGL(draw_distinct_kernel, dim3(as_ceil_div(G, 64)), dim3(64), 0, s, counts, u, rank_pos, rank_neg, is_pos,
+                     flag, G, M, K);
+  AS_CHECK_LAUNCH("draw_distinct");
+  return AS_OK;
+}
+
+// =====================================================================================================
 // Greedy grouping of merge_maps (stdroi:278-294) for all objects on the device: keep [G,P] (0/1), link [G,P,P] (0/1,
 // cos >= thr) -> groups [G,P] int32 bit sets over the ORIGINAL prototype ids in the order the reference's loop emits
 // them (0 = unused slot), ngroups [G].  Row i of the upper-triangular kept sub-matrix starts a group with every kept

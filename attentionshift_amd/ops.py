@@ -506,6 +506,36 @@ def part_stats(maps, rois, owner, stride=16):
     return c, yx.long(), area.long(), inside.bool()
 
 
+def filter_parts(sim, fg_inter, sim_thr=0.8, pos_thr=0.85):
+    """sim [G,P,hp,wp] fp32, fg_inter [G,hp,wp] fp32 -> keep [G,P] bool (stdroi:263-271 filter_maps)."""
+    lib = _lib.load()
+    sim = sim.contiguous()
+    fg = fg_inter.contiguous()
+    _chk(sim, fg, dtype=torch.float32)
+    G, P = sim.shape[:2]
+    keep = torch.empty(G, P, device=sim.device, dtype=torch.uint8)
+    _lib.check(lib.as_filter_parts(_p(sim), _p(fg), float(sim_thr), float(pos_thr), _p(keep), G, P, sim[0, 0].numel(),
+                                   _stream()), "as_filter_parts")
+    return keep.bool()
+
+
+def draw_distinct(counts, u, k):
+    """counts [G,2] int32 (n_pos, n_neg), u [G,M] fp32 uniform -> (rank_pos, rank_neg int32 [G,k], is_pos bool [G,k],
+    flag int32 [1]): the first k distinct floor(u * n) per object, split by candidate kind."""
+    lib = _lib.load()
+    counts = counts.to(torch.int32).contiguous()
+    u = u.contiguous()
+    _chk(u, dtype=torch.float32)
+    G, M = u.shape
+    rp = torch.empty(G, k, device=u.device, dtype=torch.int32)
+    rn = torch.empty(G, k, device=u.device, dtype=torch.int32)
+    ip = torch.empty(G, k, device=u.device, dtype=torch.uint8)
+    flag = torch.empty(1, device=u.device, dtype=torch.int32)
+    _lib.check(lib.as_draw_distinct(_p(counts), _p(u), _p(rp), _p(rn), _p(ip), _p(flag), G, M, int(k), _stream()),
+               "as_draw_distinct")
+    return rp, rn, ip.bool(), flag
+
+
 def merge_plan(keep, link):
     """keep [G,P] bool/uint8, link [G,P,P] bool/uint8 -> (groups [G,P] int32 bit sets, ngroups [G] int32): the greedy
     grouping of stdroi:278-294 for every object, on the device."""

@@ -278,26 +278,15 @@ def mask_points_nosync(pend, num_gt, gen):
     candidates of each object (the first num_gt entries of a random permutation, stdroi:447) = the first num_gt
     distinct values of 32 uniform draws.  flag: an object with fewer than 4*num_gt candidates (the host path's
     randperm / refill / empty branches) or, with probability < 1e-12, too few distinct draws."""
-    pos, neg, cp = pend["pos"], pend["neg"], pend["cp"]
+    pos, neg = pend["pos"], pend["neg"]
     G, H, W = pend["shape"]
-    counts = pend["counts"]                                           # [G, 2] = (n_pos, n_neg)
-    n = counts.sum(1)
-    m = 32
-    c = torch.minimum((torch.rand(G, m, device=pos.device, generator=gen) * n.float()[:, None]).long(),
-                      (n.long()[:, None] - 1).clamp(min=0))
-    dup = (c[:, :, None] == c[:, None, :]).tril(-1).any(dim=2)          # equals an EARLIER draw
-    order = (~dup).long().cumsum(1) - 1                                 # position among the distinct draws
-    take = (~dup) & (order < num_gt)
-    ranks = torch.zeros(G, num_gt, dtype=torch.long, device=pos.device)
-    ranks.scatter_add_(1, order.clamp(0, num_gt - 1), torch.where(take, c, torch.zeros_like(c)))
-    flag = (n < 4 * num_gt).any() | (take.sum(1) < num_gt).any()
-    n_pos = cp.long()[:, None]
-    is_pos = ranks < n_pos
-    idx_pos = ops.rank_select(pos.flatten(1), torch.where(is_pos, ranks, torch.zeros_like(ranks)).int().contiguous())
-    idx_neg = ops.rank_select(neg.flatten(1), torch.where(is_pos, torch.zeros_like(ranks), ranks - n_pos).int().contiguous())
-    flat = torch.where(is_pos, idx_pos, idx_neg).long().clamp(min=0, max=H * W - 1)
+    u = torch.rand(G, 32, device=pos.device, generator=gen)
+    rank_pos, rank_neg, is_pos, flag = ops.draw_distinct(pend["counts"], u, num_gt)      # counts [G, 2] = (n_pos, n_neg)
+    idx_pos = ops.rank_select(pos.flatten(1), rank_pos)
+    idx_neg = ops.rank_select(neg.flatten(1), rank_neg)
+    flat = torch.where(is_pos, idx_pos, idx_neg).clamp(min=0, max=H * W - 1)
     coords = torch.stack((flat % W, flat // W), dim=-1).float()
-    return coords, is_pos, flag
+    return coords, is_pos, flag[0] != 0
 
 
 def grid_seed_nosync(mask, count_dev, n_points=20):
@@ -774,7 +763,7 @@ class AttnShiftRoIHead(nn.Module):
         `extra`: device flags read back with the merge plan (see merge_parts); returns None if any of them is set."""
         G = fg_inter.shape[0]
         P = sim.shape[0] // G
-        keep = filter_parts(sim.unflatten(0, (G, P)), fg_inter)
+        keep = ops.filter_parts(sim.unflatten(0, (G, P)), fg_inter)                  # one launch (stdroi:263-271)
         merged = merge_parts(prot.unflatten(0, (G, P)), keep, merge_thr, extra)
         if extra and any(extra):
             return None
@@ -797,7 +786,7 @@ class AttnShiftRoIHead(nn.Module):
         hp, wp = vit_feat.shape[-2:]
         dev = prot.device
         protg = prot.unflatten(0, (G, P))
-        keep = filter_parts(sim.unflatten(0, (G, P)), fg_inter)
+        keep = ops.filter_parts(sim.unflatten(0, (G, P)), fg_inter)                  # one launch (stdroi:263-271)
         u = _unit(protg)
         groups, ngroups = ops.merge_plan(keep, (u @ u.transpose(1, 2)) >= merge_thr)
         ar = torch.arange(P, device=dev)

@@ -203,6 +203,16 @@ int as_mask_candidates(const float* map_fg, const float* map_bg, const int32_t* 
 int as_part_stats(const float* maps, const float* rois, const int32_t* owner, float stride, float* out_c,
                   int32_t* out_yx, int32_t* out_area, uint8_t* out_inside, int M, int Hp, int Wp, as_stream_t stream);
 
+/* filter_maps (stdroi:263-271) for G*P prototypes: keep[g,p] = share of sim[g,p] > sim_thr lying on fg_inter[g] >= pos_thr. */
+int as_filter_parts(const float* sim /*[G,P,Np]*/, const float* fg_inter /*[G,Np]*/, float sim_thr, float pos_thr,
+                    uint8_t* keep /*[G,P]*/, int G, int P, int Np, as_stream_t stream);
+
+/* Device-side draw of the mask points (fast-RNG mode; the head of a random permutation, stdroi:447): the first K
+ * distinct values of floor(u[g,:] * n_g), n_g = counts[g,0] + counts[g,1], split into ranks among the positive /
+ * negative candidates.  flag (int32, written) != 0: some object needs the host path (n_g < 4K or too few distinct). */
+int as_draw_distinct(const int32_t* counts /*[G,2]*/, const float* u /*[G,M]*/, int32_t* rank_pos /*[G,K]*/,
+                     int32_t* rank_neg, uint8_t* is_pos, int32_t* flag, int G, int M, int K, as_stream_t stream);
+
 /* Greedy grouping of merge_maps (stdroi:278-294) for G objects: keep [G,P] uint8, link [G,P,P] uint8 (cos >= thr)
  * -> groups [G,P] int32 bit sets over the prototype ids, in the reference's emission order (0 = unused), ngroups [G]. */
 int as_merge_plan(const uint8_t* keep, const uint8_t* link, int32_t* groups, int32_t* ngroups, int G, int P,

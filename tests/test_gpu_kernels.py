@@ -427,6 +427,34 @@ def test_mask_candidates_equal_the_three_separate_calls(ops, k):
     assert int(counts[0, 0]) > 0 and int(counts[1, 1]) > 0 and int(counts[0, 2]) == 0
 
 
+def test_filter_parts_and_part_stats_equal_the_torch_forms(ops):
+    """as_filter_parts / as_part_stats vs the tensor-op restatements of stdroi:263-271 and :222-262 (exact: integer /
+    quarter-valued sums)."""
+    from attentionshift_amd import roi_head as RH
+    gen = torch.Generator().manual_seed(31)
+    G, P, hp, wp = 3, 20, 20, 24
+    sim = torch.rand(G, P, hp, wp, generator=gen)
+    sim[:, ::3] = sim[:, ::3] * 0.5 + 0.5
+    fg = (torch.randint(0, 5, (G, hp, wp), generator=gen).float() / 4)
+    assert_equal(RH.filter_parts(sim, fg, 0.85), ops.filter_parts(dev(sim), dev(fg)), "keep")
+    maps = sim.flatten(0, 1)
+    maps[5] = 0.3                                              # a constant map: every pixel is at the peak
+    owner = torch.arange(G).repeat_interleave(P)
+    rois = torch.tensor([[0., 0., 200., 200.], [100., 50., 384., 320.], [0., 0., 10., 10.]])
+    c, yx, area, inside = ops.part_stats(dev(maps), dev(rois), dev(owner), 16)
+    peak = maps.flatten(1).max(1)[0][:, None, None]
+    at = (maps >= peak).float()
+    cnt = at.sum(dim=[-2, -1])
+    cy = (at * torch.arange(hp).float()[None, :, None]).sum(dim=[-2, -1]) / cnt
+    cx = (at * torch.arange(wp).float()[None, None, :]).sum(dim=[-2, -1]) / cnt
+    want_c = (torch.stack((cx, cy), dim=1) + 0.5) * 16
+    box = rois[owner]
+    assert_equal(want_c, c, "centres"); assert_equal(torch.stack((cy.long(), cx.long()), 1), yx, "integer centroids")
+    assert_equal((maps > 0.9).sum(dim=[-2, -1]), area, "areas")
+    assert_equal((want_c[:, 0] >= box[:, 0]) & (want_c[:, 0] <= box[:, 2]) & (want_c[:, 1] >= box[:, 1]) & (want_c[:, 1] <= box[:, 3]),
+                 inside, "inside")
+
+
 @pytest.mark.parametrize("G,hp,wp,thr", [(3, 14, 14, 0.35), (2, 9, 20, 0.5), (5, 6, 6, 0.35)])
 def test_semantic_prestage_matches_oracle(ops, G, hp, wp, thr):
     """erode_11(map > thr) -> bilinear /16 -> binarise (stdroi:2011-2020) in one launch vs max-pool + interpolate."""

@@ -189,6 +189,7 @@ def test_semantic_center_host_logic_with_oracle_backed_shift(golden, tag, monkey
 
     monkeypatch.setattr(RH.ops, "cosine_shift", fake_cosine_shift)
     monkeypatch.setattr(RH.ops, "part_stats", fake_part_stats)
+    monkeypatch.setattr(RH.ops, "filter_parts", lambda sim, fg, sim_thr=0.8, pos_thr=0.85: RH.filter_parts(sim, fg, pos_thr))
     monkeypatch.setattr(RH.ops, "semantic_prestage", fake_semantic_prestage)
     monkeypatch.setattr(RH.ops, "refine_similarity", fake_refine_similarity)
     monkeypatch.setattr(RH.ops, "crop_threshold_erode", fake_crop_threshold_erode)
