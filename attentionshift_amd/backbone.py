@@ -354,7 +354,7 @@ class VisionTransformerDet(nn.Module):
         x = self._prepare_tokens_train(x) if grad_path else self.prepare_tokens(x)
         if self.recompute_last_feat:
             last_feat = x
-        features, taps, attns = [], [], []
+        features, taps, attns, org_features = [], [], [], None
         delta = None                                       # inference path: MLP output not yet added to x
         if not grad_path:
             x = x.contiguous()
@@ -370,10 +370,19 @@ class VisionTransformerDet(nn.Module):
                 attns.append(st)
             if i in self.out_indices:
                 taps.append(x[:, 1:-T])                                  # token-major view [B, Np, D]
-                features.append(x[:, 1:, :][:, :-T].permute(0, 2, 1).reshape(B, -1, hp, wp).contiguous())
+                tap = x[:, 1:, :][:, :-T].permute(0, 2, 1).unflatten(2, (hp, wp))
+                if grad_path:
+                    features.append(tap.contiguous())
+                else:                          # no-grad: transpose straight into its slot of org_feats (no torch.stack copy)
+                    if org_features is None:
+                        org_features = torch.empty(B, len(self.out_indices), tap.shape[1], hp, wp, device=x.device,
+                                                   dtype=x.dtype)
+                    org_features[:, len(features)].copy_(tap)
+                    features.append(org_features[:, len(features)])
             if self.last_feat and not self.recompute_last_feat and i == len(self.blocks) - 1:
                 last_feat = x[:, :-T]
-        org_features = torch.stack(features, dim=1)
+        if org_features is None:
+            org_features = torch.stack(features, dim=1)
         if self.with_fpn and grad_path:
             features = [self._fpn_train(i, features[i], taps[i]) for i in range(len(features))]
         elif self.with_fpn:
