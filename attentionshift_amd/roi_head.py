@@ -602,6 +602,18 @@ class AttnShiftRoIHead(nn.Module):
         self.with_mil = mil_head is not None
         self.with_mask = mask_head is not None
         self.with_bbox = bbox_head is not None
+        # the depth selector: the caller's, else the MIL head of the config when it carries its construction
+        # arguments (it then needs `roi_feature_map` in seed_pseudo_gt), else the median-area stand-in
+        self.mil_head = None
+        if layer_selector is None and isinstance(mil_head, dict) and mil_head.get("type") == "MAEBoxHeadMIL" \
+                and "in_channels" in mil_head:
+            from .mil_head import MAEBoxHeadMIL, MILLayerSelector
+            rl = dict((bbox_roi_extractor or {}).get("roi_layer", {}))
+            self.mil_head = MAEBoxHeadMIL(**{k: v for k, v in mil_head.items() if k != "type"})
+            self._mil_selector = MILLayerSelector(self.mil_head, rl.get("output_size", 7),
+                                                  (bbox_roi_extractor or {}).get("featmap_strides", [STRIDE])[0],
+                                                  rl.get("sampling_ratio", 0))
+            layer_selector = self._select_with_mil
         self.layer_selector = layer_selector or median_area_selector
         assert rng_mode in ("reference", "fast")
         self.rng_mode = rng_mode          # "reference": the reference's exact torch RNG stream; "fast": O(k) draws
@@ -620,6 +632,13 @@ class AttnShiftRoIHead(nn.Module):
         self.semantic_to_token, self.pca_dim = semantic_to_token, pca_dim
         self.mean_shift_times_local = mean_shift_times_local
         self.num_reppoints_head = num_reppoints_head
+
+    def _select_with_mil(self, boxes_per_img, labels_per_img, roi_feature_map):
+        """stdroi:2308-2312: the MIL head on the RoI-aligned stride-16 features; without a feature map (callers that
+        only exercise the pseudo-label path) the median-area stand-in."""
+        if roi_feature_map is None:
+            return median_area_selector(boxes_per_img, labels_per_img, roi_feature_map)
+        return self._mil_selector(boxes_per_img, labels_per_img, roi_feature_map)
 
     def forward_train(self, *a, **k):
         raise NotImplementedError("forward_train (trainable bbox/mask heads) is outside the hot path: SURVEY 8f")
@@ -949,6 +968,8 @@ class AttnShiftRoIHead(nn.Module):
         pseudo_boxes = [gt_scale_bboxes[i][torch.arange(counts[i], device=boxes.device), gt_box_index[i]]
                         for i in range(num_imgs)]
         mil_losses = {}
+        if self.mil_head is not None and roi_feature_map is not None and self._mil_selector.last_loss is not None:
+            mil_losses["mil_loss"] = self._mil_selector.last_loss                # stdroi:2961
 
         out = dict(pseudo_gt_labels=gt_labels, pseudo_gt_bboxes=pseudo_boxes, mil_losses=mil_losses,
                    best_attn_idx=gt_box_index, map_cos_fg=[], mask_points_coords=[], mask_points_labels=[],

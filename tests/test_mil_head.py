@@ -1,0 +1,80 @@
+"""MIL head / RoIAlign.  CPU only; mmcv is absent, so RoIAlign is checked against its definition."""
+import torch
+
+import attentionshift_amd as A
+from attentionshift_amd import mil_head as MH
+
+
+def test_roi_align_definition_cases():
+    gen = torch.Generator().manual_seed(2)
+    feat = torch.rand(2, 3, 8, 10, generator=gen)
+    # a box covering whole pixels, aligned: bins of 1x1 feature pixels centred on pixel centres -> the pixel values
+    rois = torch.tensor([[1.0, 16 * 2.0, 16 * 1.0, 16 * 9.0, 16 * 8.0]])          # x 2..9, y 1..8 in feature pixels (7x7)
+    out = MH.roi_align(feat, rois, 7, 1 / 16, 0, True)
+    assert torch.allclose(out[0], feat[1, :, 1:8, 2:9], atol=1e-6)
+    # a 14x14-pixel box: 2x2 feature pixels per bin, adaptive grid 2 -> mean of the four pixel centres
+    rois = torch.tensor([[0.0, 0.0, 0.0, 16 * 14.0 / 2, 16 * 14.0 / 2]])           # 7x7 feature pixels -> grid 1
+    out1 = MH.roi_align(feat, rois, 7, 1 / 16, 0, True)
+    assert torch.allclose(out1[0][:, :7, :7], feat[0, :, :7, :7], atol=1e-6)
+    # fixed sampling ratio 2 on a constant map returns the constant; samples outside the map contribute zero
+    const = torch.full((1, 1, 6, 6), 3.0)
+    inside = MH.roi_align(const, torch.tensor([[0.0, 16.0, 16.0, 80.0, 80.0]]), 2, 1 / 16, 2, True)
+    assert torch.allclose(inside, torch.full_like(inside, 3.0))
+    far = MH.roi_align(const, torch.tensor([[0.0, 16 * 20.0, 16 * 20.0, 16 * 24.0, 16 * 24.0]]), 2, 1 / 16, 2, True)
+    assert float(far.abs().max()) == 0.0
+    assert MH.roi_align(feat, torch.zeros(0, 5), 7).shape == (0, 3, 7, 7)
+
+
+def test_mil_head_forward_matches_its_definition_and_keys():
+    torch.manual_seed(0)
+    head = A.build_head(dict(type="MAEBoxHeadMIL", in_channels=12, embed_dim=8, num_classes=5, num_layers_query=3,
+                             hidden_dim=16, roi_size=2, pretrained=True, use_checkpoint=False, with_cls=False,
+                             with_reg=False))
+    assert sorted(head.state_dict()) == sorted(
+        [f"{m}.{p}" for m in ("norm", "decoder_embed", "fc1", "fc2", "proposal_branch", "classification_branch")
+         for p in ("weight", "bias")])
+    G, Lc = 4, 3
+    x = torch.randn(G * Lc, 12, 2, 2)
+    labels = [torch.tensor([1, 4]), torch.tensor([0, 2])]
+    idx, loss = head(x, gt_labels=labels)
+    t = x.flatten(2).transpose(1, 2)
+    t = head.decoder_embed(head.norm(t)).reshape(G * Lc, -1)
+    t = torch.relu(head.fc2(torch.relu(head.fc1(t))))
+    cls = head.classification_branch(t).reshape(G, Lc, 5).softmax(-1)
+    prop = head.proposal_branch(t).reshape(G, Lc, 5).softmax(1)
+    bag = cls * prop
+    lab = torch.cat(labels)
+    assert torch.equal(idx, bag[torch.arange(G), :, lab].argmax(1))
+    s = bag.sum(1).clamp(1e-6, 1 - 1e-6)
+    onehot = torch.nn.functional.one_hot(lab, 5).float()
+    want = (-onehot * s.log() - (1 - onehot) * (1 - s).log()).mean()
+    assert torch.allclose(loss, want)
+
+
+def test_mil_layer_selector_shapes_and_split():
+    torch.manual_seed(1)
+    head = MH.MAEBoxHeadMIL(in_channels=6, embed_dim=6, num_classes=4, num_layers_query=3, hidden_dim=8, roi_size=7)
+    sel = MH.MILLayerSelector(head)
+    fmap = torch.rand(2, 6, 14, 14)
+    boxes = [torch.tensor([[[10., 10., 100., 120.]] * 3, [[50., 40., 200., 210.]] * 3]), torch.tensor([[[0., 0., 224., 224.]] * 3])]
+    out = sel(boxes, [torch.tensor([1, 3]), torch.tensor([0])], fmap)
+    assert [o.shape[0] for o in out] == [2, 1] and all(int(o.max()) < 3 for o in out)
+    assert sel.last_loss is not None and float(sel.last_loss) > 0
+
+
+def test_roi_head_builds_the_mil_head_from_the_reference_config():
+    head = A.build_head(dict(
+        type="AttnShiftRoIHead", num_semantic_points=5, mean_shift_times_local=10,
+        bbox_roi_extractor=dict(type="SingleRoIExtractor", roi_layer=dict(type="RoIAlign", output_size=7, sampling_ratio=0),
+                                out_channels=384, featmap_strides=[16]),
+        mil_head=dict(type="MAEBoxHeadMIL", pretrained=True, use_checkpoint=False, in_channels=384, img_size=224,
+                      patch_size=16, embed_dim=256, depth=4, num_heads=8, mlp_ratio=4., num_classes=20,
+                      num_layers_query=7, loss_mil_factor=1.0, with_cls=False, with_reg=False),
+        bbox_head=dict(type="MAEBoxHeadRec", seed_thr=0.2, seed_multiple=0.5, cam_layer=7, num_classes=20)))
+    assert isinstance(head.mil_head, MH.MAEBoxHeadMIL) and any(k.startswith("mil_head.fc1") for k in head.state_dict())
+    boxes = [torch.tensor([[[16., 16., 160., 200.]] * 7] * 2)]
+    labels = [torch.tensor([3, 7])]
+    idx = head.layer_selector(boxes, labels, torch.rand(1, 384, 14, 14))
+    assert idx[0].shape == (2,) and head._mil_selector.last_loss is not None
+    # without a feature map the median-area stand-in answers (callers that only run the pseudo-label path)
+    assert head.layer_selector(boxes, labels, None)[0].shape == (2,)
