@@ -412,3 +412,36 @@ def test_semantic_post_device_matches_reference_fixture_and_host_path(golden, ta
         if a_.numel():
             assert_close(a_, b_, 1e-5, 1e-6, "part similarity maps")
     assert head._semantic_post_device(*args, extra=[torch.ones((), dtype=torch.bool, device="cuda")]) is None
+
+
+def test_seed_pseudo_gt_with_the_mil_head_selecting_the_depth(golden, monkeypatch):
+    """The MIL head built from the reference's config (not the median-area stand-in) picks gt_box_index from the
+    RoI-aligned stride-16 map inside seed_pseudo_gt; its loss comes back as mil_losses['mil_loss']."""
+    import attentionshift_amd as A
+    g = golden("shift_tiny224")
+    inp = shift_case_inputs(g)
+    hp, wp, G, Lc, C = int(g["hp"]), int(g["wp"]), int(g["G"]), int(g["Lc"]), int(g["C"])
+    T, N = 10, 1 + hp * wp + 10
+    torch.manual_seed(3)
+    head = A.build_head(dict(type="AttnShiftRoIHead", num_semantic_points=int(g["num_semantic_points"]),
+                             mean_shift_times_local=int(g["n_shift"]), rng_mode="fast",
+                             bbox_roi_extractor=dict(type="SingleRoIExtractor", featmap_strides=[16],
+                                                     roi_layer=dict(type="RoIAlign", output_size=7, sampling_ratio=0)),
+                             mil_head=dict(type="MAEBoxHeadMIL", in_channels=C, embed_dim=64, num_classes=20,
+                                           num_layers_query=Lc, hidden_dim=128),
+                             bbox_head=dict(type="MAEBoxHeadRec", seed_thr=float(g["cam_thr"]),
+                                            seed_multiple=float(g["area_ratio"]), cam_layer=Lc, num_classes=20))).cuda()
+    rows = torch.zeros(1, Lc, T, N)
+    rows[0, :, :G, 1:-T] = inp["cams"].flatten(2)
+    monkeypatch.setattr(head, "rollout_cams", lambda attns, n: rows.cuda())
+    feat = inp["vit_feat"][None].cuda()
+    out = head.seed_pseudo_gt(None, [dict(img_shape=(hp * 16, wp * 16, 3))], None, None, None, vit_feat=feat,
+                              point_cls=torch.zeros(1, T, 20).cuda(), point_reg=torch.zeros(1, T, 2).cuda(), attns=None,
+                              gt_points=[inp["points"].cuda()], gt_points_labels=[inp["labels"].cuda()], return_mask=True,
+                              roi_feature_map=feat, pos_mask_thr=float(g["pos_thr"]), neg_mask_thr=float(g["neg_thr"]),
+                              num_mask_point_gt=int(g["num_gt"]), corr_size=int(g["corr_size"]), obj_tau=float(g["obj_tau"]),
+                              pos_inds=[torch.arange(G).cuda()], matched_gt=[torch.arange(G).cuda()])
+    idx = out["best_attn_idx"][0]
+    assert idx.shape == (G,) and int(idx.min()) >= 0 and int(idx.max()) < Lc
+    assert "mil_loss" in out["mil_losses"] and float(out["mil_losses"]["mil_loss"]) > 0
+    assert out["pseudo_gt_bboxes"][0].shape == (G, 4) and len(out["pseudo_gt_masks"][0]) == G
