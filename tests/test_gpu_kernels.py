@@ -357,6 +357,42 @@ def test_cam_boxes_match_golden(ops, golden, tag):
     assert_equal(t(g["ref_kept_area"]).int(), status.reshape(Lc, G).t().cpu(), "kept-pixel counts")
 
 
+def _boxes_from_pixel_ccl(ops, up, mm, thr, ratio, pts):
+    nmap = (up - mm[:, 0, None, None]) / (mm[:, 1, None, None] - mm[:, 0, None, None]).clamp_min(1e-6)
+    labels = ops.ccl_2d((nmap >= thr).to(torch.uint8).contiguous()).cpu()
+    H, W = up.shape[-2:]
+    out = []
+    for m in range(up.shape[0]):
+        lab = labels[m]
+        ids, areas = torch.unique(lab[lab > 0], return_counts=True)
+        kept = torch.isin(lab, ids[areas.float() >= ratio * areas.max().float()])
+        ys, xs = kept.nonzero(as_tuple=True)
+        xmin, xmax, ymin, ymax = float(xs.min()), float(xs.max()), float(ys.min()), float(ys.max())
+        xc, yc = float(pts[m, 0]), float(pts[m, 1])
+        bx = (xmin, min(2 * xc - xmin, float(W))) if abs(xc - xmin) > abs(xc - xmax) else (max(2 * xc - xmax, 0.0), xmax)
+        by = (ymin, min(2 * yc - ymin, float(H))) if abs(yc - ymin) > abs(yc - ymax) else (max(2 * yc - ymax, 0.0), ymax)
+        out.append((int(kept.sum()), [bx[0], by[0], bx[1], by[1]]))
+    return out
+
+
+def test_cam_boxes_wide_maps_match_pixel_ccl(ops):
+    """1280-pixel-wide maps (ViT-L, BASELINE config 4): rows span more 64-column words than the run kernel keeps in
+    registers, so runs are carried across its column trips; foreground touching the right border included."""
+    gen = torch.Generator().manual_seed(19)
+    M, hp, wp = 4, 80, 80
+    cams = 0.3 * torch.rand(M, hp, wp, generator=gen)
+    cams[0, 10:60, 5:78] += 1.0                               # crosses the 1024-column trip boundary
+    cams[1, 20:40, 60:80] += 1.0                              # touches the right border
+    cams[2, 5:15, 2:30] += 1.0
+    cams[2, 40:70, 50:79] += 0.9                              # two blobs, one filtered by area
+    cams[3, :, :] += torch.linspace(0, 1, wp)[None, :]         # a ramp: one run per row ending at the border
+    pts = torch.tensor([[600., 500.]] * M)
+    boxes, status, up, mm = ops.cam_boxes(dev(cams), dev(pts), 0.5, 0.5, 16, True)
+    for m, (area, box) in enumerate(_boxes_from_pixel_ccl(ops, up, mm, 0.5, 0.5, pts)):
+        assert int(status[m]) == area, m
+        assert boxes[m].tolist() == box, m
+
+
 def test_cam_boxes_noise_maps_match_pixel_ccl(ops):
     """Speckled maps (hundreds of components, dozens of runs per row): the run-based box stage must give what the
     per-pixel labelling (as_ccl_2d, itself pinned to scipy) gives -- kept area and tight box per map."""
