@@ -128,3 +128,125 @@ class SwinTransformerBlock(nn.Module):
         z = ops.linear(z.reshape(B * L, C).contiguous(), w(self.mlp.fc1.weight), self.mlp.fc1.bias.detach().float(), act="gelu")
         z = ops.linear(z, w(self.mlp.fc2.weight), self.mlp.fc2.bias.detach().float())
         return x + z.reshape(B, L, C).float(), attn
+
+
+# ---- the whole backbone around the block (BASELINE config 5: Swin-B = embed 128, depths 2/2/18/2, heads 4/8/16/32) ------
+class PatchMerging(nn.Module):
+    """models/swin_transformer.py:337-377: 2x2 neighbourhood -> 4C, LayerNorm, Linear(4C -> 2C, no bias)."""
+
+    def __init__(self, input_resolution, dim):
+        super().__init__()
+        self.input_resolution, self.dim = tuple(input_resolution), dim
+        self.reduction = nn.Linear(4 * dim, 2 * dim, bias=False)
+        self.norm = nn.LayerNorm(4 * dim, eps=1e-6)
+
+    def forward(self, x):
+        B, L, C = x.shape
+        H = W = int(math.sqrt(L))
+        x = x.view(B, H, W, C)
+        if H % 2 or W % 2:
+            x = F.pad(x, (0, 0, 0, W % 2, 0, H % 2))
+        x = torch.cat([x[:, 0::2, 0::2], x[:, 1::2, 0::2], x[:, 0::2, 1::2], x[:, 1::2, 1::2]], -1).reshape(B, -1, 4 * C)
+        return self.reduction(self.norm(x))
+
+
+class BasicLayer(nn.Module):
+    """models/swin_transformer.py:393-460: `depth` blocks alternating shift 0 / window_size // 2, then the merge."""
+
+    def __init__(self, dim, input_resolution, depth, num_heads, window_size, mlp_ratio=4., qkv_bias=True,
+                 downsample=False, compute_dtype=torch.bfloat16, return_attention=False):
+        super().__init__()
+        self.blocks = nn.ModuleList([
+            SwinTransformerBlock(dim, input_resolution, num_heads, window_size, 0 if i % 2 == 0 else window_size // 2,
+                                 mlp_ratio, qkv_bias, compute_dtype=compute_dtype, return_attention=return_attention)
+            for i in range(depth)])
+        for blk in self.blocks:                               # the reference's norm_layer = LayerNorm(eps=1e-6)
+            blk.norm1.eps = blk.norm2.eps = 1e-6
+        self.downsample = PatchMerging(input_resolution, dim) if downsample else None
+
+    def forward(self, x):
+        for blk in self.blocks:
+            x, _ = blk(x)
+        return self.downsample(x) if self.downsample is not None else x
+
+    def forward_with_features(self, x):
+        feats = []
+        for blk in self.blocks:
+            x, _ = blk(x)
+            feats.append(x)
+        return (self.downsample(x) if self.downsample is not None else x), feats
+
+
+class SwinPatchEmbed(nn.Module):
+    """models/swin_transformer.py:474-509: conv patch x patch / patch, optional LayerNorm over channels, NCHW out."""
+
+    def __init__(self, img_size=224, patch_size=4, in_chans=3, embed_dim=96, patch_norm=True):
+        super().__init__()
+        self.patches_resolution = [img_size // patch_size, img_size // patch_size]
+        self.num_patches = self.patches_resolution[0] * self.patches_resolution[1]
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size)
+        self.norm = nn.LayerNorm(embed_dim, eps=1e-6) if patch_norm else None
+
+    def forward(self, x):
+        x = self.proj(x)
+        B, C, H, W = x.shape
+        t = x.flatten(2).transpose(1, 2)
+        if self.norm is not None:
+            t = self.norm(t)
+        return t.transpose(1, 2).reshape(B, C, H, W)
+
+
+class SwinTransformer(nn.Module):
+    """models/swin_transformer.py:519-645 with the same constructor arguments, module names and state-dict keys
+    (`patch_embed.*`, `layers.i.blocks.j.*`, `layers.i.downsample.*`, `norm.*`, `head.*`, optional
+    `absolute_pos_embed`).  Every window attention runs on `as_window_attn_fwd` / `_bwd` through the block above; the
+    patch embedding / merging / norms are tensor-op glue.  `forward` returns what the reference returns (pooled feature,
+    or [pooled | tokens] with return_all_tokens); `forward_stages` additionally returns the tokens after every stage."""
+
+    def __init__(self, img_size=224, patch_size=4, in_chans=3, num_classes=1000, embed_dim=96, depths=(2, 2, 6, 2),
+                 num_heads=(3, 6, 12, 24), window_size=7, mlp_ratio=4., qkv_bias=True, qk_scale=None, drop_rate=0.,
+                 attn_drop_rate=0., drop_path_rate=0., ape=False, patch_norm=True, return_all_tokens=False,
+                 compute_dtype=torch.bfloat16, **kwargs):
+        super().__init__()
+        self.num_classes, self.depths, self.num_layers = num_classes, list(depths), len(depths)
+        self.embed_dim, self.ape, self.return_all_tokens = embed_dim, ape, return_all_tokens
+        self.num_features = int(embed_dim * 2 ** (self.num_layers - 1))
+        self.patch_embed = SwinPatchEmbed(img_size, patch_size, in_chans, embed_dim, patch_norm)
+        res = self.patch_embed.patches_resolution
+        self.patches_resolution = res
+        if ape:
+            self.absolute_pos_embed = nn.Parameter(torch.zeros(1, self.patch_embed.num_patches, embed_dim))
+            nn.init.trunc_normal_(self.absolute_pos_embed, std=.02)
+        self.layers = nn.ModuleList([
+            BasicLayer(int(embed_dim * 2 ** i), (res[0] // 2 ** i, res[1] // 2 ** i), depths[i], num_heads[i], window_size,
+                       mlp_ratio, qkv_bias, downsample=i < self.num_layers - 1, compute_dtype=compute_dtype)
+            for i in range(self.num_layers)])
+        self.norm = nn.LayerNorm(self.num_features, eps=1e-6)
+        self.head = nn.Linear(self.num_features, num_classes) if num_classes > 0 else nn.Identity()
+        self.apply(self._init_weights)
+
+    @staticmethod
+    def _init_weights(m):
+        if isinstance(m, nn.Linear):
+            nn.init.trunc_normal_(m.weight, std=.02)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.constant_(m.bias, 0)
+            nn.init.constant_(m.weight, 1.0)
+
+    def forward_stages(self, x):
+        x = self.patch_embed(x).flatten(2).transpose(1, 2)
+        if self.ape:
+            x = x + self.absolute_pos_embed
+        stages = []
+        for layer in self.layers:
+            x = layer(x)
+            stages.append(x)
+        return self.norm(x), stages
+
+    def forward(self, x, return_all_tokens=None):
+        x_region, _ = self.forward_stages(x)
+        pooled = x_region.mean(dim=1)                          # AdaptiveAvgPool1d(1) over the tokens
+        rat = self.return_all_tokens if return_all_tokens is None else return_all_tokens
+        return torch.cat([pooled.unsqueeze(1), x_region], dim=1) if rat else pooled

@@ -769,3 +769,32 @@ def test_swin_block_backward_matches_autograd(ops, golden, tag, dtype, tol):
         assert params[n].grad is not None, n
         mx, mean = rel_to_range(p64[n].grad.float(), params[n].grad.float())
         assert mx < tol, (n, mx, mean)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-4), (torch.bfloat16, 6e-2)])
+def test_swin_backbone_matches_reference(golden, dtype, tol):
+    """The whole Swin backbone (patch embed, two stages of (shifted-)window blocks on as_window_attn_fwd, patch merging,
+    final norm, pooled output) vs the reference's own SwinTransformer on a grid that needs window padding in both
+    stages (30x30 and 15x15 tokens, window 7).  Same state-dict keys as the reference."""
+    from attentionshift_amd import synthetic
+    from attentionshift_amd.swin import SwinTransformer
+    g = golden("swin_net_pad120")
+    img = int(g["img"])
+    net = SwinTransformer(img_size=img, patch_size=4, in_chans=3, num_classes=0, embed_dim=int(g["cfg_embed_dim"]),
+                          depths=g["cfg_depths"].tolist(), num_heads=g["cfg_heads"].tolist(), window_size=7,
+                          compute_dtype=dtype)
+    own = net.state_dict()
+    names = [k for k in own if "relative_position_index" not in k]
+    assert sorted(names) == sorted(g["param_names"].tolist())
+    net.load_state_dict(synthetic.det_state_dict({k: tuple(own[k].shape) for k in names}), strict=False)
+    net = net.cuda().eval()
+    x = torch.randn(2, 3, img, img, generator=torch.Generator().manual_seed(int(g["seed"]))).cuda()
+    with torch.no_grad():
+        out = net(x, return_all_tokens=True)
+        _, stages = net.forward_stages(x)
+    for i, s in enumerate(stages):
+        ref = t(g[f"stage{i}"])
+        err = float((s.float().cpu() - ref).abs().max() / ref.abs().max())
+        assert err < tol, (i, err)
+    ref = t(g["out"])
+    assert float((out.float().cpu() - ref).abs().max() / ref.abs().max()) < tol
