@@ -536,6 +536,34 @@ def draw_distinct(counts, u, k):
     return rp, rn, ip.bool(), flag
 
 
+def chamfer_2d_fwd(xyz1, xyz2):
+    """xyz1 [B,n,2], xyz2 [B,m,2] fp32 -> (dist1 [B,n], dist2 [B,m] squared nearest distances, idx1, idx2 int32)."""
+    lib = _lib.load()
+    xyz1, xyz2 = xyz1.contiguous(), xyz2.contiguous()
+    _chk(xyz1, xyz2, dtype=torch.float32)
+    B, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    d1 = torch.empty(B, n, device=xyz1.device, dtype=torch.float32)
+    d2 = torch.empty(B, m, device=xyz1.device, dtype=torch.float32)
+    i1 = torch.empty(B, n, device=xyz1.device, dtype=torch.int32)
+    i2 = torch.empty(B, m, device=xyz1.device, dtype=torch.int32)
+    _lib.check(lib.as_chamfer_2d_fwd(_p(xyz1), _p(xyz2), _p(d1), _p(d2), _p(i1), _p(i2), B, n, m, _stream()), "as_chamfer_2d_fwd")
+    return d1, d2, i1, i2
+
+
+def chamfer_2d_bwd(xyz1, xyz2, g1, g2, idx1, idx2):
+    lib = _lib.load()
+    xyz1, xyz2, g1, g2 = xyz1.contiguous(), xyz2.contiguous(), g1.contiguous().float(), g2.contiguous().float()
+    _chk(xyz1, xyz2, g1, g2, dtype=torch.float32)
+    _chk(idx1, idx2, dtype=torch.int32)
+    B, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    gx1, gx2 = torch.empty_like(xyz1), torch.empty_like(xyz2)
+    _lib.check(lib.as_chamfer_2d_bwd(_p(xyz1), _p(xyz2), _p(g1), _p(g2), _p(idx1), _p(idx2), _p(gx1), _p(gx2), B, n, m,
+                                     _stream()), "as_chamfer_2d_bwd")
+    return gx1, gx2
+
+
 def merge_plan(keep, link):
     """keep [G,P] bool/uint8, link [G,P,P] bool/uint8 -> (groups [G,P] int32 bit sets, ngroups [G] int32): the greedy
     grouping of stdroi:278-294 for every object, on the device."""

@@ -276,6 +276,15 @@ size_t as_rank_select_workspace_bytes(int M, int HW);
 int as_rank_select(const uint8_t* mask /*[M,HW] 0/1*/, const int32_t* ranks /*[M,K]*/, int32_t* out /*[M,K]*/, void* ws,
                    size_t ws_bytes, int M, int HW, int K, as_stream_t stream);
 
+/* 2-D chamfer distance, the reference's second native op (mmdet/ops/chamfer_2d/src/chamfer_2d.cu:12-161 behind
+ * mmdet/ops/chamfer_2d/dist_chamfer_2d.py:11-58; off the hot path): xyz1 [B,n,2], xyz2 [B,m,2] fp32 ->
+ * dist1 [B,n] / dist2 [B,m] = squared distance to the nearest point of the other set, idx1 / idx2 int32 its index
+ * (lowest on ties); backward: gxyz += 2 * gdist * (p - q) on the point, -= on its neighbour (both outputs written). */
+int as_chamfer_2d_fwd(const float* xyz1, const float* xyz2, float* dist1, float* dist2, int32_t* idx1, int32_t* idx2,
+                      int B, int n, int m, as_stream_t stream);
+int as_chamfer_2d_bwd(const float* xyz1, const float* xyz2, const float* gdist1, const float* gdist2, const int32_t* idx1,
+                      const int32_t* idx2, float* gxyz1, float* gxyz2, int B, int n, int m, as_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

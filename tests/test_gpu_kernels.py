@@ -798,3 +798,36 @@ def test_swin_backbone_matches_reference(golden, dtype, tol):
         assert err < tol, (i, err)
     ref = t(g["out"])
     assert float((out.float().cpu() - ref).abs().max() / ref.abs().max()) < tol
+
+
+def test_chamfer_2d_forward_backward(ops):
+    """The reference's second native op (mmdet/ops/chamfer_2d): nearest squared distances / indices by brute force in
+    float64, lowest index on exact ties (integer coordinates), gradients vs autograd of the gathered form."""
+    from attentionshift_amd.chamfer import Chamfer2D
+    gen = torch.Generator().manual_seed(41)
+    B, n, m = 3, 1300, 777                                   # more than one LDS tile, sizes 1 and 3 mod 4
+    a = torch.rand(B, n, 2, generator=gen) * 100
+    b = torch.rand(B, m, 2, generator=gen) * 100
+    d1, d2, i1, i2 = ops.chamfer_2d_fwd(dev(a), dev(b))
+    full = ((a.double()[:, :, None, :] - b.double()[:, None, :, :]) ** 2).sum(-1)             # [B,n,m]
+    assert_close(full.min(2)[0], d1, 1e-5, 1e-6, "dist1"); assert_close(full.min(1)[0], d2, 1e-5, 1e-6, "dist2")
+    got1 = torch.gather(full, 2, i1.cpu().long()[..., None])[..., 0]
+    assert_close(full.min(2)[0], got1, 1e-5, 1e-6, "idx1 points at a nearest neighbour")
+    got2 = torch.gather(full, 1, i2.cpu().long()[:, None, :])[:, 0]
+    assert_close(full.min(1)[0], got2, 1e-5, 1e-6, "idx2 points at a nearest neighbour")
+    # exact ties: integer grid, duplicated points -> the lowest index wins (exact arithmetic)
+    ai = torch.tensor([[[0., 0.], [5., 5.], [2., 1.]]])
+    bi = torch.tensor([[[1., 0.], [0., 1.], [5., 5.], [5., 5.], [-1., 0.]]])
+    _, _, t1, t2 = ops.chamfer_2d_fwd(dev(ai), dev(bi))
+    assert t1.tolist() == [[0, 2, 0]] and t2.tolist() == [[0, 0, 1, 1, 0]]
+    # backward
+    with torch.enable_grad():
+        x1, x2 = dev(a).requires_grad_(True), dev(b).requires_grad_(True)
+        o1, o2, j1, j2 = Chamfer2D()(x1, x2)
+        w1, w2 = dev(torch.rand(B, n, generator=gen)), dev(torch.rand(B, m, generator=gen))
+        ((o1 * w1).sum() + (o2 * w2).sum()).backward()
+        y1, y2 = dev(a).double().requires_grad_(True), dev(b).double().requires_grad_(True)
+        r1 = ((y1 - torch.gather(y2, 1, j1.long()[..., None].expand(-1, -1, 2))) ** 2).sum(-1)
+        r2 = ((y2 - torch.gather(y1, 1, j2.long()[..., None].expand(-1, -1, 2))) ** 2).sum(-1)
+        ((r1 * w1.double()).sum() + (r2 * w2.double()).sum()).backward()
+    assert_close(y1.grad, x1.grad, 1e-4, 1e-4, "grad xyz1"); assert_close(y2.grad, x2.grad, 1e-4, 1e-4, "grad xyz2")
