@@ -1,0 +1,139 @@
+"""MAE-decoder RoI heads on the small-N batched attention kernel.
+
+    SmallAttnFn       autograd bridge of as_small_attn_fwd / as_small_attn_bwd
+    DecoderBlock      models/vision_transformer.py:88-124 `Block` (pre-LN attention + MLP) with the reference's
+                      parameter names (norm1, attn.qkv, attn.proj, norm2, mlp.fc1, mlp.fc2); the attention core runs on
+                      the HIP kernel, LayerNorm / Linear / GELU are library ops (four 256-wide GEMMs per block)
+    MAEBoxHeadRec     mmdet/models/roi_heads/bbox_heads/mae_bbox_head_rec.py:24-168: det token + decoder over the 7x7
+                      RoI tokens, `fc_cls` / `fc_reg` on the det token (the optional pixel reconstruction branch too).
+                      Losses, target assignment and box coding belong to mmdet's BBoxHead and are not restated.
+"""
+import math
+from functools import partial
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .registry import HEADS
+
+
+class SmallAttnFn(torch.autograd.Function):
+    """qkv [Bp,N,3,h,32] -> out [Bp,N,h*32]."""
+
+    @staticmethod
+    def forward(ctx, qkv):
+        out, lse = ops.small_attention_fwd(qkv)
+        ctx.save_for_backward(qkv, out, lse)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        qkv, out, lse = ctx.saved_tensors
+        return ops.small_attention_bwd(qkv, out, d_out, lse)
+
+
+class _Attention(nn.Module):
+    def __init__(self, dim, num_heads, qkv_bias=True):
+        super().__init__()
+        assert dim % num_heads == 0 and dim // num_heads == 32, "the small-N attention kernel is built for head dim 32"
+        self.num_heads = num_heads
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.proj = nn.Linear(dim, dim)
+
+    def forward(self, x):
+        B, N, C = x.shape
+        qkv = self.qkv(x).reshape(B, N, 3, self.num_heads, C // self.num_heads)       # the reference's packed layout
+        return self.proj(SmallAttnFn.apply(qkv))
+
+
+class _Mlp(nn.Module):
+    def __init__(self, dim, hidden):
+        super().__init__()
+        self.fc1 = nn.Linear(dim, hidden)
+        self.fc2 = nn.Linear(hidden, dim)
+
+    def forward(self, x):
+        return self.fc2(F.gelu(self.fc1(x)))
+
+
+class DecoderBlock(nn.Module):
+    def __init__(self, dim, num_heads, mlp_ratio=4., qkv_bias=True):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim, eps=1e-6)
+        self.attn = _Attention(dim, num_heads, qkv_bias)
+        self.norm2 = nn.LayerNorm(dim, eps=1e-6)
+        self.mlp = _Mlp(dim, int(dim * mlp_ratio))
+
+    def forward(self, x):
+        x = x + self.attn(self.norm1(x))
+        return x + self.mlp(self.norm2(x))
+
+
+@HEADS.register_module()
+class MAEBoxHeadRec(nn.Module):
+    def __init__(self, in_channels=384, img_size=224, patch_size=16, embed_dim=256, depth=4, num_heads=8, mlp_ratio=4.,
+                 qkv_bias=True, num_classes=20, with_cls=True, with_reg=True, reg_class_agnostic=False,
+                 with_reconstruct=True, seed_score_thr=0.2, seed_thr=0.2, seed_multiple=0.5, cam_layer=-1, **kwargs):
+        super().__init__()
+        self.patch_size, self.num_classes = patch_size, num_classes
+        self.with_cls, self.with_reg, self.with_reconstruct = with_cls, with_reg, with_reconstruct
+        num_patches = (img_size // patch_size) ** 2
+        self.det_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
+        self.with_decoder_embed = in_channels != embed_dim
+        if self.with_decoder_embed:
+            self.norm = partial(nn.LayerNorm, eps=1e-6)(in_channels)
+            self.decoder_embed = nn.Linear(in_channels, embed_dim, bias=True)
+        self.decoder_blocks = nn.ModuleList([DecoderBlock(embed_dim, num_heads, mlp_ratio, qkv_bias) for _ in range(depth)])
+        self.decoder_pos_embed = nn.Parameter(torch.zeros(1, num_patches + 1, embed_dim), requires_grad=False)
+        self.decoder_box_norm = nn.LayerNorm(embed_dim, eps=1e-6)
+        if with_cls:
+            self.fc_cls = nn.Linear(embed_dim, num_classes + 1)
+        if with_reg:
+            self.fc_reg = nn.Linear(embed_dim, 4 if reg_class_agnostic else 4 * num_classes)
+        if with_reconstruct:
+            self.fc_rec = nn.Linear(embed_dim, 3 * patch_size * patch_size)
+        self.seed_score_thr, self.seed_thr, self.seed_multiple, self.cam_layer = seed_score_thr, seed_thr, seed_multiple, cam_layer
+        nn.init.trunc_normal_(self.det_token, std=.02)
+        self.apply(self._init_weights)
+
+    @staticmethod
+    def _init_weights(m):
+        if isinstance(m, nn.Linear):
+            nn.init.trunc_normal_(m.weight, std=.02)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.constant_(m.bias, 0)
+            nn.init.constant_(m.weight, 1.0)
+
+    def interpolate_pos_encoding(self, x, w, h):
+        """mae_bbox_head_rec.py:126-146 (bicubic resize of the patch part, the +0.1 trick)."""
+        npatch, n0 = x.shape[1] - 1, self.decoder_pos_embed.shape[1] - 1
+        if npatch == n0 and w == h:
+            return self.decoder_pos_embed
+        cls_pe, patch_pe = self.decoder_pos_embed[:, 0], self.decoder_pos_embed[:, 1:]
+        dim = x.shape[-1]
+        w0, h0 = w // self.patch_size + 0.1, h // self.patch_size + 0.1
+        s = int(math.sqrt(n0))
+        patch_pe = F.interpolate(patch_pe.reshape(1, s, s, dim).permute(0, 3, 1, 2),
+                                 scale_factor=(w0 / math.sqrt(n0), h0 / math.sqrt(n0)), mode="bicubic")
+        assert int(w0) == patch_pe.shape[-2] and int(h0) == patch_pe.shape[-1]
+        return torch.cat((cls_pe.unsqueeze(0), patch_pe.permute(0, 2, 3, 1).reshape(1, -1, dim)), dim=1)
+
+    def forward(self, x, img=None):
+        """x [R, C, 7, 7] RoI features -> (cls_score [R, K+1] | None, bbox_pred | None, img_rec | None)."""
+        B, C, W, H = x.shape
+        x = x.flatten(2).transpose(1, 2)
+        if self.with_decoder_embed:
+            x = self.decoder_embed(self.norm(x))
+        x = torch.cat([self.det_token.expand(B, -1, -1), x], dim=1)
+        x = x + self.interpolate_pos_encoding(x, W * self.patch_size, H * self.patch_size)
+        for blk in self.decoder_blocks:
+            x = blk(x)
+        x = self.decoder_box_norm(x)
+        cls_score = self.fc_cls(x[:, 0]) if self.with_cls else None
+        bbox_pred = self.fc_reg(x[:, 0]) if self.with_reg else None
+        img_rec = self.fc_rec(x[:, 1:]).transpose(1, 2).reshape(B, -1, W, H) if self.with_reconstruct else None
+        return cls_score, bbox_pred, img_rec

@@ -536,6 +536,29 @@ def draw_distinct(counts, u, k):
     return rp, rn, ip.bool(), flag
 
 
+def small_attention_fwd(qkv):
+    """qkv [Bp,N,3,h,32] fp32/bf16 -> (out [Bp,N,h*32] same dtype, lse [Bp,h,N] fp32): batched small-N self-attention."""
+    lib = _lib.load()
+    qkv = qkv.contiguous()
+    _chk(qkv)
+    Bp, N, _, h, d = qkv.shape
+    out = torch.empty(Bp, N, h * d, device=qkv.device, dtype=qkv.dtype)
+    lse = torch.empty(Bp, h, N, device=qkv.device, dtype=torch.float32)
+    _lib.check(lib.as_small_attn_fwd(_p(qkv), _p(out), _p(lse), Bp, N, h, d, _dt(qkv), _stream()), "as_small_attn_fwd")
+    return out, lse
+
+
+def small_attention_bwd(qkv, out, d_out, lse):
+    lib = _lib.load()
+    qkv, out, d_out = qkv.contiguous(), out.contiguous(), d_out.contiguous().to(qkv.dtype)
+    _chk(qkv, out, d_out)
+    Bp, N, _, h, d = qkv.shape
+    dqkv = torch.empty_like(qkv)
+    _lib.check(lib.as_small_attn_bwd(_p(qkv), _p(out), _p(d_out), _p(lse), _p(dqkv), Bp, N, h, d, _dt(qkv), _stream()),
+               "as_small_attn_bwd")
+    return dqkv
+
+
 def chamfer_2d_fwd(xyz1, xyz2):
     """xyz1 [B,n,2], xyz2 [B,m,2] fp32 -> (dist1 [B,n], dist2 [B,m] squared nearest distances, idx1, idx2 int32)."""
     lib = _lib.load()

@@ -276,6 +276,15 @@ size_t as_rank_select_workspace_bytes(int M, int HW);
 int as_rank_select(const uint8_t* mask /*[M,HW] 0/1*/, const int32_t* ranks /*[M,K]*/, int32_t* out /*[M,K]*/, void* ws,
                    size_t ws_bytes, int M, int HW, int K, as_stream_t stream);
 
+/* Small-N batched multi-head self-attention (the MAE-decoder box / mask heads: thousands of 50- / 197-token problems of
+ * head dim 32 per step; models/vision_transformer.py:62-86 as used by mae_bbox_head_rec.py:148-168):
+ *   qkv  [Bp, N, 3, h, d]  the packed output of the reference's qkv Linear (fp32 or bf16), d = 32
+ *   out  [Bp, N, h*d]      softmax(q k^T d^-0.5) v, same dtype;   lse [Bp, h, N] fp32 (kept for the backward)
+ *   dqkv [Bp, N, 3, h, d]  gradient of qkv given d_out (recomputes the probabilities from q, k, lse; no atomics). */
+int as_small_attn_fwd(const void* qkv, void* out, float* lse, int Bp, int N, int h, int d, int dtype, as_stream_t stream);
+int as_small_attn_bwd(const void* qkv, const void* out, const void* d_out, const float* lse, void* dqkv, int Bp, int N,
+                      int h, int d, int dtype, as_stream_t stream);
+
 /* 2-D chamfer distance, the reference's second native op (mmdet/ops/chamfer_2d/src/chamfer_2d.cu:12-161 behind
  * mmdet/ops/chamfer_2d/dist_chamfer_2d.py:11-58; off the hot path): xyz1 [B,n,2], xyz2 [B,m,2] fp32 ->
  * dist1 [B,n] / dist2 [B,m] = squared distance to the nearest point of the other set, idx1 / idx2 int32 its index

@@ -831,3 +831,73 @@ def test_chamfer_2d_forward_backward(ops):
         r2 = ((y2 - torch.gather(y1, 1, j2.long()[..., None].expand(-1, -1, 2))) ** 2).sum(-1)
         ((r1 * w1.double()).sum() + (r2 * w2.double()).sum()).backward()
     assert_close(y1.grad, x1.grad, 1e-4, 1e-4, "grad xyz1"); assert_close(y2.grad, x2.grad, 1e-4, 1e-4, "grad xyz2")
+
+
+def _ref_small_attn(qkv):
+    q, k, v = (qkv[:, :, i].permute(0, 2, 1, 3).double() for i in range(3))                  # [B,h,N,d]
+    p = torch.softmax(q @ k.transpose(-1, -2) * q.shape[-1] ** -0.5, dim=-1)
+    return (p @ v).permute(0, 2, 1, 3).flatten(2)
+
+
+@pytest.mark.parametrize("N,dtype,tol", [(50, torch.float32, 2e-5), (197, torch.float32, 2e-5), (50, torch.bfloat16, 2e-2),
+                                         (300, torch.bfloat16, 2e-2), (1, torch.float32, 2e-5)])
+def test_small_attention_forward_backward(ops, N, dtype, tol):
+    """as_small_attn_fwd / _bwd (head dim 32, packed qkv) vs fp64 softmax attention and its autograd gradient."""
+    gen = torch.Generator().manual_seed(N)
+    Bp, h = 5, 8
+    qkv = (torch.randn(Bp, N, 3, h, 32, generator=gen) * 1.5).to(dtype)
+    out, lse = ops.small_attention_fwd(dev(qkv))
+    with torch.enable_grad():
+        x = qkv.double().requires_grad_(True)
+        ref = _ref_small_attn(x)
+        g = torch.randn(Bp, N, h * 32, generator=gen).to(dtype)
+        (ref * g.double()).sum().backward()
+    rng = float(ref.abs().max())
+    assert float((out.double().cpu() - ref.detach()).abs().max()) < tol * rng
+    q, k = qkv[:, :, 0].permute(0, 2, 1, 3).double(), qkv[:, :, 1].permute(0, 2, 1, 3).double()
+    want_lse = torch.logsumexp(q @ k.transpose(-1, -2) * 32 ** -0.5, dim=-1)
+    assert_close(want_lse, lse, 1e-4 if dtype == torch.float32 else 1e-2, 1e-4 if dtype == torch.float32 else 1e-2, "lse")
+    if N <= 295:                                                   # the backward keeps q, k, v, dO of a problem in LDS
+        dqkv = ops.small_attention_bwd(dev(qkv), out, dev(g), lse)
+        gr = float(x.grad.abs().max())
+        assert float((dqkv.double().cpu() - x.grad).abs().max()) < (5 * tol) * gr
+
+
+def test_mae_box_head_matches_tensor_op_decoder():
+    """MAEBoxHeadRec (reference parameter names) on the HIP small-N attention vs the same weights through
+    torch's scaled_dot_product_attention, forward and parameter gradients."""
+    import attentionshift_amd as A
+    torch.manual_seed(5)
+    head = A.build_head(dict(type="MAEBoxHeadRec", in_channels=96, img_size=224, patch_size=16, embed_dim=64, depth=2,
+                             num_heads=2, mlp_ratio=4., num_classes=20, with_reconstruct=False, pretrained=True,
+                             use_checkpoint=False, rec_weight=1.0)).cuda()
+    keys = set(head.state_dict())
+    assert {"det_token", "decoder_pos_embed", "norm.weight", "decoder_embed.weight", "decoder_blocks.1.attn.qkv.bias",
+            "decoder_blocks.0.mlp.fc2.weight", "decoder_box_norm.bias", "fc_cls.weight", "fc_reg.bias"} <= keys
+    torch.nn.init.normal_(head.decoder_pos_embed, std=0.02)
+    x = torch.randn(6, 96, 7, 7).cuda()
+    with torch.enable_grad():
+        cls, reg, rec = head(x)
+        assert cls.shape == (6, 21) and reg.shape == (6, 80) and rec is None
+        (cls.square().sum() + reg.square().sum()).backward()
+        got = {n: p.grad.clone() for n, p in head.named_parameters() if p.grad is not None}
+        head.zero_grad()
+
+        def ref_attn(self, t):
+            B, N, C = t.shape
+            qkv = self.qkv(t).reshape(B, N, 3, self.num_heads, 32).permute(2, 0, 3, 1, 4)
+            o = torch.nn.functional.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2])
+            return self.proj(o.transpose(1, 2).reshape(B, N, C))
+
+        from attentionshift_amd import mae_heads
+        orig = mae_heads._Attention.forward
+        mae_heads._Attention.forward = ref_attn
+        try:
+            cls2, reg2, _ = head(x)
+            (cls2.square().sum() + reg2.square().sum()).backward()
+        finally:
+            mae_heads._Attention.forward = orig
+    assert_close(cls2, cls, 1e-4, 1e-5, "cls_score"); assert_close(reg2, reg, 1e-4, 1e-5, "bbox_pred")
+    for n, p in head.named_parameters():
+        if p.grad is not None:
+            assert_close(p.grad, got[n], 2e-3, 1e-5, f"grad {n}")
