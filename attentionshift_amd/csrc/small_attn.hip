@@ -2,15 +2,14 @@
 // 50- / 197-token attention problems of head dim 32 per step -- models/vision_transformer.py:62-86 `Attention.forward`
 // as used by mmdet/models/roi_heads/bbox_heads/mae_bbox_head_rec.py:148-168 and mask_heads/mae_mask_head_pointSup.py).
 //
-// One workgroup per (problem, head).  At these sizes the work is a few hundred KFLOP per workgroup and the MFMA tiles
-// of the long-sequence kernel (sdpa.hip: 128 queries x 64 keys, head dim 64) would be mostly padding, so this is the
-// "latency / HBM" shape: K and V of the problem-head live in LDS as fp32, a thread owns a query row (q, the output
-// accumulator and the running softmax state in registers), keys are broadcast reads.  fp32 accumulation throughout;
-// operands fp32 or bf16 in the packed layout the reference's `qkv(x).reshape(B, N, 3, h, d)` produces.
+// At these sizes a problem-head is a few hundred KFLOP: the tiles of the long-sequence kernel (sdpa.hip: 128 queries x
+// 64 keys per workgroup, K / V through an LDS ring) would be mostly padding and staging, so here a single WAVE takes a
+// (problem, head, 32-query block), reads its operands straight from the packed qkv tensor the reference's
+// `qkv(x).reshape(B, N, 3, h, d)` produces (fp32 or bf16) and keeps everything else in registers; fp32 accumulation.
 //
 //   forward   out[b,n,h*d] = softmax(q k^T d^-0.5) v,  lse[b,h,n] (natural log) kept for the backward
-//   backward  recomputes P from q, k, lse (no [N,N] tensor): phase 1, a thread per query row -> dq;
-//             phase 2, a thread per key row -> dk, dv.  No atomics, fixed summation order.
+//   backward  recomputes P from q, k, lse (no [N,N] tensor): one MFMA kernel with a lane per query -> dq (+ delta),
+//             one with a lane per key -> dk, dv.  No atomics, fixed summation order.
 #include "common.h"
 
 namespace {
@@ -108,86 +107,154 @@ __global__ __launch_bounds__(SA_NT) void small_attn_fwd_kernel(const T* __restri
   }
 }
 
-// grid (h, Bp); dynamic LDS = (4 * N * D + 2 * N) floats: Q (pre-scaled), K, V, dO, lse, delta
+// ---- backward: two MFMA kernels in the same arrangement, probabilities recomputed from q, k, lse ---------------
+// gather 8 values `stride` apart (the transposed operand of the second product of each kernel)
+template <typename T> __device__ __forceinline__ void gather8(Frag<T>& f, const T* p, int first, int limit, size_t stride) {
+#pragma unroll
+  for (int t = 0; t < 8; ++t) f.v[t] = p[(size_t)min(first + t, limit) * stride];
+}
+
+// dq: wave task = (query block, head); lane owns a query.  Also writes delta[b,h,q] = dO_q . O_q for the dk/dv pass.
+//   S^T = K Q^T,  dP^T = V dO^T (same accumulator layout),  dS^T = P^T (dP^T - delta_q),  dQ^T = K^T dS
 template <typename T>
-__global__ __launch_bounds__(SA_NT) void small_attn_bwd_kernel(const T* __restrict__ qkv, const T* __restrict__ out,
-                                                               const T* __restrict__ d_out, const float* __restrict__ lse,
-                                                               T* __restrict__ dqkv, int N, int h, float scale) {
-  extern __shared__ float sm[];
-  float* Qs = sm;
-  float* Ks = Qs + (size_t)N * SA_D;
-  float* Vs = Ks + (size_t)N * SA_D;
-  float* Gs = Vs + (size_t)N * SA_D;
-  float* Ls = Gs + (size_t)N * SA_D;
-  float* Ds = Ls + N;
-  const int hh = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
-  const size_t row_stride = (size_t)3 * h * SA_D;
-  const T* base = qkv + (size_t)b * N * row_stride + (size_t)hh * SA_D;
-  T* dbase = dqkv + (size_t)b * N * row_stride + (size_t)hh * SA_D;
-  const size_t orow = (size_t)h * SA_D;
-  const T* obase = out + (size_t)b * N * orow + (size_t)hh * SA_D;
-  const T* gbase = d_out + (size_t)b * N * orow + (size_t)hh * SA_D;
-  for (int i = tid; i < N * SA_D; i += SA_NT) {
-    const int n = i / SA_D, c = i - n * SA_D;
-    Qs[i] = to_f32<T>(base[n * row_stride + c]) * scale;
-    Ks[i] = to_f32<T>(base[n * row_stride + (size_t)h * SA_D + c]);
-    Vs[i] = to_f32<T>(base[n * row_stride + (size_t)2 * h * SA_D + c]);
-    Gs[i] = to_f32<T>(gbase[n * orow + c]);
+__global__ __launch_bounds__(SA_NT) void small_attn_bwd_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ out,
+                                                                  const T* __restrict__ d_out, const float* __restrict__ lse,
+                                                                  T* __restrict__ dqkv, float* __restrict__ delta, int N,
+                                                                  int h, float scale) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nqb = (N + 31) / 32;
+  const int task = blockIdx.x * 4 + wave, b = blockIdx.y;
+  if (task >= nqb * h) return;
+  const int hh = task / nqb, qb = task - hh * nqb;
+  const int li = lane & 31, half = lane >> 5;
+  const size_t rs = (size_t)3 * h * SA_D, os = (size_t)h * SA_D;
+  const T* base = qkv + (size_t)b * N * rs + (size_t)hh * SA_D;
+  const int q_row = min(qb * 32 + li, N - 1);
+  const T* orow = out + ((size_t)b * N + q_row) * os + (size_t)hh * SA_D;
+  const T* grow = d_out + ((size_t)b * N + q_row) * os + (size_t)hh * SA_D;
+  Frag<T> fq[2], fg[2];
+  float dl = 0.0f;
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    fq[ks].load16B(base + (size_t)q_row * rs + ks * 16 + half * 8);
+    fg[ks].load16B(grow + ks * 16 + half * 8);
+    Frag<T> fo;
+    fo.load16B(orow + ks * 16 + half * 8);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) dl = fmaf(to_f32<T>(fg[ks].v[t]), to_f32<T>(fo.v[t]), dl);
   }
-  for (int n = tid; n < N; n += SA_NT) {
-    Ls[n] = lse[((size_t)b * h + hh) * N + n];
-    float d = 0.0f;
+  dl += __shfl_xor(dl, 32);                                   // the halves hold complementary head-dim slices
+  const float l2 = lse[((size_t)b * h + hh) * N + q_row] * LOG2E;
+  const int pi = (li & ~12) | ((li & 4) << 1) | ((li & 8) >> 1);
+  const float c2 = scale * LOG2E;
+  f32x16 acc;
 #pragma unroll
-    for (int c = 0; c < SA_D; ++c) d = fmaf(to_f32<T>(gbase[n * orow + c]), to_f32<T>(obase[n * orow + c]), d);
-    Ds[n] = d;                                        // delta_i = dO_i . O_i
+  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+  for (int k0 = 0; k0 < N; k0 += 32) {
+    const int k_row = min(k0 + pi, N - 1);
+    Frag<T> fk[2], fv[2], fkt[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      fk[ks].load16B(base + (size_t)k_row * rs + (size_t)h * SA_D + ks * 16 + half * 8);
+      fv[ks].load16B(base + (size_t)k_row * rs + (size_t)2 * h * SA_D + ks * 16 + half * 8);
+      gather8<T>(fkt[ks], base + (size_t)h * SA_D + li, k0 + 16 * ks + 8 * half, N - 1, rs);       // K^T: row = d index
+    }
+    f32x16 sc, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { sc[r] = 0.0f; dp[r] = 0.0f; }
+    sc = mma32(fk[0], fq[0], sc); sc = mma32(fk[1], fq[1], sc);
+    dp = mma32(fv[0], fg[0], dp); dp = mma32(fv[1], fg[1], dp);
+    Frag<T> fs[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = k0 + 8 * half + (r & 7) + 16 * (r >> 3);
+      const float p = key < N ? __builtin_amdgcn_exp2f(sc[r] * c2 - l2) : 0.0f;
+      fs[r >> 3].set(r & 7, p * (dp[r] - dl));
+    }
+    acc = mma32(fkt[0], fs[0], acc);
+    acc = mma32(fkt[1], fs[1], acc);
   }
-  __syncthreads();
-  // phase 1: thread = query row i -> dq_i = scale * sum_j P_ij (dO_i . v_j - delta_i) k_j
-  for (int i = tid; i < N; i += SA_NT) {
-    float q[SA_D], g[SA_D], dq[SA_D];
+  const int q = qb * 32 + li;
+  if (q < N) {
+    T* o = dqkv + ((size_t)b * N + q) * rs + (size_t)hh * SA_D;
 #pragma unroll
-    for (int c = 0; c < SA_D; ++c) { q[c] = Qs[i * SA_D + c]; g[c] = Gs[i * SA_D + c]; dq[c] = 0.0f; }
-    const float li = Ls[i], di = Ds[i];
-    for (int j = 0; j < N; ++j) {
-      const float* kj = Ks + j * SA_D;
-      const float* vj = Vs + j * SA_D;
-      float s = 0.0f, dp = 0.0f;
-#pragma unroll
-      for (int c = 0; c < SA_D; ++c) { s = fmaf(q[c], kj[c], s); dp = fmaf(g[c], vj[c], dp); }
-      const float ds = __expf(s - li) * (dp - di);
-#pragma unroll
-      for (int c = 0; c < SA_D; ++c) dq[c] = fmaf(ds, kj[c], dq[c]);
-    }
-#pragma unroll
-    for (int c = 0; c < SA_D; ++c) dbase[i * row_stride + c] = from_f32<T>(dq[c] * scale);
-  }
-  // phase 2: thread = key row j -> dv_j = sum_i P_ij dO_i ;  dk_j = sum_i P_ij (dO_i . v_j - delta_i) q_i  (q pre-scaled)
-  for (int j = tid; j < N; j += SA_NT) {
-    float k[SA_D], v[SA_D], dk[SA_D], dv[SA_D];
-#pragma unroll
-    for (int c = 0; c < SA_D; ++c) { k[c] = Ks[j * SA_D + c]; v[c] = Vs[j * SA_D + c]; dk[c] = 0.0f; dv[c] = 0.0f; }
-    for (int i = 0; i < N; ++i) {
-      const float* qi = Qs + i * SA_D;
-      const float* gi = Gs + i * SA_D;
-      float s = 0.0f, dp = 0.0f;
-#pragma unroll
-      for (int c = 0; c < SA_D; ++c) { s = fmaf(qi[c], k[c], s); dp = fmaf(gi[c], v[c], dp); }
-      const float p = __expf(s - Ls[i]);
-      const float ds = p * (dp - Ds[i]);
-#pragma unroll
-      for (int c = 0; c < SA_D; ++c) { dv[c] = fmaf(p, gi[c], dv[c]); dk[c] = fmaf(ds, qi[c], dk[c]); }
-    }
-#pragma unroll
-    for (int c = 0; c < SA_D; ++c) {
-      dbase[j * row_stride + (size_t)h * SA_D + c] = from_f32<T>(dk[c]);
-      dbase[j * row_stride + (size_t)2 * h * SA_D + c] = from_f32<T>(dv[c]);
-    }
+    for (int r = 0; r < 16; ++r) o[acc_row(r, half)] = from_f32<T>(acc[r] * scale);
+    if (half == 0) delta[((size_t)b * h + hh) * N + q] = dl;
   }
 }
 
-template <typename K> int set_lds(K kern, size_t bytes) {
-  if (bytes > 48 * 1024) return (int)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-  return 0;
+// dk, dv: wave task = (key block, head); lane owns a key, registers run over 8 consecutive queries.
+//   S = Q K^T,  dP = dO V^T,  dV^T = dO^T P,  dK^T = Q^T dS * scale
+template <typename T>
+__global__ __launch_bounds__(SA_NT) void small_attn_bwd_dkv_kernel(const T* __restrict__ qkv, const T* __restrict__ d_out,
+                                                                   const float* __restrict__ lse,
+                                                                   const float* __restrict__ delta, T* __restrict__ dqkv,
+                                                                   int N, int h, float scale) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nkb = (N + 31) / 32;
+  const int task = blockIdx.x * 4 + wave, b = blockIdx.y;
+  if (task >= nkb * h) return;
+  const int hh = task / nkb, kb = task - hh * nkb;
+  const int li = lane & 31, half = lane >> 5;
+  const size_t rs = (size_t)3 * h * SA_D, os = (size_t)h * SA_D;
+  const T* base = qkv + (size_t)b * N * rs + (size_t)hh * SA_D;
+  const T* gbase = d_out + (size_t)b * N * os + (size_t)hh * SA_D;
+  const float* lrow = lse + ((size_t)b * h + hh) * N;
+  const float* drow = delta + ((size_t)b * h + hh) * N;
+  const int k_row = min(kb * 32 + li, N - 1);
+  Frag<T> fk[2], fv[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    fk[ks].load16B(base + (size_t)k_row * rs + (size_t)h * SA_D + ks * 16 + half * 8);
+    fv[ks].load16B(base + (size_t)k_row * rs + (size_t)2 * h * SA_D + ks * 16 + half * 8);
+  }
+  const int pi = (li & ~12) | ((li & 4) << 1) | ((li & 8) >> 1);
+  const float c2 = scale * LOG2E;
+  f32x16 adk, adv;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { adk[r] = 0.0f; adv[r] = 0.0f; }
+  for (int q0 = 0; q0 < N; q0 += 32) {
+    const int q_row = min(q0 + pi, N - 1);
+    Frag<T> fq[2], fg[2], fqt[2], fgt[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      fq[ks].load16B(base + (size_t)q_row * rs + ks * 16 + half * 8);
+      fg[ks].load16B(gbase + (size_t)q_row * os + ks * 16 + half * 8);
+      gather8<T>(fqt[ks], base + li, q0 + 16 * ks + 8 * half, N - 1, rs);                        // Q^T: row = d index
+      gather8<T>(fgt[ks], gbase + li, q0 + 16 * ks + 8 * half, N - 1, os);                       // dO^T
+    }
+    float l2[16], dl[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int q = min(q0 + 8 * half + (r & 7) + 16 * (r >> 3), N - 1);
+      l2[r] = lrow[q] * LOG2E;
+      dl[r] = drow[q];
+    }
+    f32x16 sc, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { sc[r] = 0.0f; dp[r] = 0.0f; }
+    sc = mma32(fq[0], fk[0], sc); sc = mma32(fq[1], fk[1], sc);           // [query (pi order), key]
+    dp = mma32(fg[0], fv[0], dp); dp = mma32(fg[1], fv[1], dp);
+    Frag<T> fp[2], fs[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int q = q0 + 8 * half + (r & 7) + 16 * (r >> 3);
+      const float p = q < N ? __builtin_amdgcn_exp2f(sc[r] * c2 - l2[r]) : 0.0f;
+      fp[r >> 3].set(r & 7, p);
+      fs[r >> 3].set(r & 7, p * (dp[r] - dl[r]));
+    }
+    adv = mma32(fgt[0], fp[0], adv); adv = mma32(fgt[1], fp[1], adv);
+    adk = mma32(fqt[0], fs[0], adk); adk = mma32(fqt[1], fs[1], adk);
+  }
+  const int k = kb * 32 + li;
+  if (k < N) {
+    T* o = dqkv + ((size_t)b * N + k) * rs + (size_t)hh * SA_D;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      o[(size_t)h * SA_D + acc_row(r, half)] = from_f32<T>(adk[r] * scale);
+      o[(size_t)2 * h * SA_D + acc_row(r, half)] = from_f32<T>(adv[r]);
+    }
+  }
 }
 
 }  // namespace
@@ -212,24 +279,34 @@ extern "C" int as_small_attn_fwd(const void* qkv, void* out, float* lse, int Bp,
   return AS_OK;
 }
 
-extern "C" int as_small_attn_bwd(const void* qkv, const void* out, const void* d_out, const float* lse, void* dqkv, int Bp,
-                                 int N, int h, int d, int dtype, as_stream_t stream) {
-  AS_REQUIRE(qkv && out && d_out && lse && dqkv, AS_E_BADARG, "as_small_attn_bwd: null pointer");
+extern "C" size_t as_small_attn_bwd_workspace_bytes(int Bp, int N, int h) {
+  if (Bp <= 0 || N <= 0 || h <= 0) return 0;
+  return (size_t)Bp * h * N * sizeof(float);                 // delta = dO . O per (problem, head, query)
+}
+
+extern "C" int as_small_attn_bwd(const void* qkv, const void* out, const void* d_out, const float* lse, void* dqkv,
+                                 void* workspace, size_t workspace_bytes, int Bp, int N, int h, int d, int dtype,
+                                 as_stream_t stream) {
+  AS_REQUIRE(qkv && out && d_out && lse && dqkv && workspace, AS_E_BADARG, "as_small_attn_bwd: null pointer");
   AS_REQUIRE(Bp > 0 && N > 0 && h > 0, AS_E_BADARG, "as_small_attn_bwd: bad sizes");
   AS_REQUIRE(d == SA_D && (dtype == AS_F32 || dtype == AS_BF16), AS_E_UNSUPPORTED,
              "as_small_attn_bwd: head dim %d (only %d), dtype %d", d, SA_D, dtype);
-  const size_t lds = ((size_t)4 * N * SA_D + 2 * N) * sizeof(float);
-  AS_REQUIRE(lds <= 150 * 1024, AS_E_UNSUPPORTED, "as_small_attn_bwd: N=%d tokens exceed the LDS-resident form (<= 295)", N);
+  AS_REQUIRE(workspace_bytes >= as_small_attn_bwd_workspace_bytes(Bp, N, h), AS_E_WORKSPACE,
+             "as_small_attn_bwd: workspace too small");
   hipStream_t s = (hipStream_t)stream;
   const float scale = 1.0f / sqrtf((float)d);
+  const dim3 grid(as_ceil_div(as_ceil_div(N, 32) * h, 4), Bp);
+  float* delta = (float*)workspace;
   if (dtype == AS_F32) {
-    set_lds(small_attn_bwd_kernel<float>, lds);
-    hipLaunchKernelGGL((small_attn_bwd_kernel<float>), dim3(h, Bp), dim3(SA_NT), lds, s, (const float*)qkv, (const float*)out,
-                       (const float*)d_out, lse, (float*)dqkv, N, h, scale);
+    hipLaunchKernelGGL((small_attn_bwd_dq_kernel<float>), grid, dim3(SA_NT), 0, s, (const float*)qkv, (const float*)out,
+                       (const float*)d_out, lse, (float*)dqkv, delta, N, h, scale);
+    hipLaunchKernelGGL((small_attn_bwd_dkv_kernel<float>), grid, dim3(SA_NT), 0, s, (const float*)qkv, (const float*)d_out,
+                       lse, delta, (float*)dqkv, N, h, scale);
   } else {
-    set_lds(small_attn_bwd_kernel<__bf16>, lds);
-    hipLaunchKernelGGL((small_attn_bwd_kernel<__bf16>), dim3(h, Bp), dim3(SA_NT), lds, s, (const __bf16*)qkv,
-                       (const __bf16*)out, (const __bf16*)d_out, lse, (__bf16*)dqkv, N, h, scale);
+    hipLaunchKernelGGL((small_attn_bwd_dq_kernel<__bf16>), grid, dim3(SA_NT), 0, s, (const __bf16*)qkv, (const __bf16*)out,
+                       (const __bf16*)d_out, lse, (__bf16*)dqkv, delta, N, h, scale);
+    hipLaunchKernelGGL((small_attn_bwd_dkv_kernel<__bf16>), grid, dim3(SA_NT), 0, s, (const __bf16*)qkv, (const __bf16*)d_out,
+                       lse, delta, (__bf16*)dqkv, N, h, scale);
   }
   AS_CHECK_LAUNCH("small_attn_bwd");
   return AS_OK;

@@ -554,8 +554,10 @@ def small_attention_bwd(qkv, out, d_out, lse):
     _chk(qkv, out, d_out)
     Bp, N, _, h, d = qkv.shape
     dqkv = torch.empty_like(qkv)
-    _lib.check(lib.as_small_attn_bwd(_p(qkv), _p(out), _p(d_out), _p(lse), _p(dqkv), Bp, N, h, d, _dt(qkv), _stream()),
-               "as_small_attn_bwd")
+    nbytes = lib.as_small_attn_bwd_workspace_bytes(Bp, N, h)
+    ws = torch.empty(nbytes, device=qkv.device, dtype=torch.uint8)
+    _lib.check(lib.as_small_attn_bwd(_p(qkv), _p(out), _p(d_out), _p(lse), _p(dqkv), _p(ws), nbytes, Bp, N, h, d, _dt(qkv),
+                                     _stream()), "as_small_attn_bwd")
     return dqkv
 
 

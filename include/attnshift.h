@@ -282,8 +282,9 @@ int as_rank_select(const uint8_t* mask /*[M,HW] 0/1*/, const int32_t* ranks /*[M
  *   out  [Bp, N, h*d]      softmax(q k^T d^-0.5) v, same dtype;   lse [Bp, h, N] fp32 (kept for the backward)
  *   dqkv [Bp, N, 3, h, d]  gradient of qkv given d_out (recomputes the probabilities from q, k, lse; no atomics). */
 int as_small_attn_fwd(const void* qkv, void* out, float* lse, int Bp, int N, int h, int d, int dtype, as_stream_t stream);
-int as_small_attn_bwd(const void* qkv, const void* out, const void* d_out, const float* lse, void* dqkv, int Bp, int N,
-                      int h, int d, int dtype, as_stream_t stream);
+size_t as_small_attn_bwd_workspace_bytes(int Bp, int N, int h);
+int as_small_attn_bwd(const void* qkv, const void* out, const void* d_out, const float* lse, void* dqkv, void* workspace,
+                      size_t workspace_bytes, int Bp, int N, int h, int d, int dtype, as_stream_t stream);
 
 /* 2-D chamfer distance, the reference's second native op (mmdet/ops/chamfer_2d/src/chamfer_2d.cu:12-161 behind
  * mmdet/ops/chamfer_2d/dist_chamfer_2d.py:11-58; off the hot path): xyz1 [B,n,2], xyz2 [B,m,2] fp32 ->

@@ -49,7 +49,8 @@ def test_bad_arguments_return_error_codes_without_launching():
     assert lib.as_mask_count(None, None, 1, 16, None) == -1
     assert lib.as_merge_plan(None, None, None, None, 3, 20, None) == -1
     assert lib.as_small_attn_fwd(None, None, None, 4, 50, 8, 32, 1, None) == -1
-    assert lib.as_small_attn_bwd(None, None, None, None, None, 4, 50, 8, 32, 1, None) == -1
+    assert lib.as_small_attn_bwd(None, None, None, None, None, None, 0, 4, 50, 8, 32, 1, None) == -1
+    assert lib.as_small_attn_bwd_workspace_bytes(4, 50, 8) == 4 * 8 * 50 * 4
     assert lib.as_chamfer_2d_fwd(None, None, None, None, None, None, 2, 9, 7, None) == -1
     assert lib.as_chamfer_2d_bwd(*([None] * 8), 2, 9, 7, None) == -1
     assert lib.as_filter_parts(None, None, 0.8, 0.85, None, 3, 20, 4096, None) == -1

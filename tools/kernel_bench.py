@@ -138,14 +138,14 @@ def main():
         for Bp, N in ((1024, 50), (128, 197)):
             qkv = torch.randn(Bp, N, 3, 8, 32, generator=g).to(torch.bfloat16).to(dev)
             ms = timeit(lambda: ops.small_attention_fwd(qkv), a.reps)
-            emit(f"small_attn_fwd_bf16_{Bp}x{N}x8h", ms, flops=4 * Bp * 8 * N * N * 32, peak=PEAK_F32, note="fp32 VALU kernel: frac vs the fp32 vector peak")
+            emit(f"small_attn_fwd_bf16_{Bp}x{N}x8h", ms, flops=4 * Bp * 8 * N * N * 32, peak=PEAK_BF16, note="one wave per 32-query block, operands straight from the packed qkv")
             o, lse = ops.small_attention_fwd(qkv)
             go = torch.randn_like(o)
             ms = timeit(lambda: ops.small_attention_bwd(qkv, o, go, lse), a.reps)
-            emit(f"small_attn_bwd_bf16_{Bp}x{N}x8h", ms, flops=8 * Bp * 8 * N * N * 32, peak=PEAK_F32, note="2x-forward flop convention")
+            emit(f"small_attn_bwd_bf16_{Bp}x{N}x8h", ms, flops=8 * Bp * 8 * N * N * 32, peak=PEAK_BF16, note="2x-forward flop convention")
             q, k, v = (qkv[:, :, i].permute(0, 2, 1, 3).contiguous() for i in range(3))
             ms = timeit(lambda: torch.nn.functional.scaled_dot_product_attention(q, k, v), a.reps)
-            emit(f"torch_sdpa_fwd_bf16_{Bp}x{N}x8h", ms, flops=4 * Bp * 8 * N * N * 32, peak=PEAK_F32)
+            emit(f"torch_sdpa_fwd_bf16_{Bp}x{N}x8h", ms, flops=4 * Bp * 8 * N * N * 32, peak=PEAK_BF16)
     if want("cam"):
         hp = wp = 64
         M = 21 * B
