@@ -137,3 +137,56 @@ class MAEBoxHeadRec(nn.Module):
         bbox_pred = self.fc_reg(x[:, 0]) if self.with_reg else None
         img_rec = self.fc_rec(x[:, 1:]).transpose(1, 2).reshape(B, -1, W, H) if self.with_reconstruct else None
         return cls_score, bbox_pred, img_rec
+
+
+@HEADS.register_module()
+class MAEMaskHeadPointSup(nn.Module):
+    """mmdet/models/roi_heads/mask_heads/mae_mask_head_pointSup.py:30-273: the MAE decoder over the 14x14 RoI tokens (no
+    det token), x`scale_factor` interpolation, 1x1 conv to per-class mask logits; `loss` is the point-supervised BCE on
+    logits sampled at the mask points (targets built by attentionshift_amd.mask_targets)."""
+
+    def __init__(self, roi_feat_size=14, num_classes=80, class_agnostic=False, in_channels=256, img_size=224, patch_size=16,
+                 embed_dim=256, depth=4, num_heads=8, mlp_ratio=4., qkv_bias=True, scale_factor=2, scale_mode="bilinear",
+                 loss_weight_mask_start=1.0, **kwargs):
+        super().__init__()
+        self.patch_size, self.num_classes, self.class_agnostic = patch_size, num_classes, class_agnostic
+        self.scale_factor, self.scale_mode, self.loss_weight_mask_start = scale_factor, scale_mode, loss_weight_mask_start
+        self.roi_feat_size = (roi_feat_size, roi_feat_size) if isinstance(roi_feat_size, int) else tuple(roi_feat_size)
+        self.num_patches = (img_size // patch_size) ** 2
+        self.with_decoder_embed = in_channels != embed_dim
+        if self.with_decoder_embed:
+            self.norm = nn.LayerNorm(in_channels, eps=1e-6)
+            self.decoder_embed = nn.Linear(in_channels, embed_dim, bias=True)
+        self.decoder_blocks = nn.ModuleList([DecoderBlock(embed_dim, num_heads, mlp_ratio, qkv_bias) for _ in range(depth)])
+        self.decoder_pos_embed = nn.Parameter(torch.zeros(1, self.num_patches + 1, embed_dim), requires_grad=False)
+        self.decoder_box_norm = nn.LayerNorm(embed_dim, eps=1e-6)
+        self.conv_logits = nn.Conv2d(embed_dim, 1 if class_agnostic else num_classes, 1)
+        self.apply(MAEBoxHeadRec._init_weights)
+
+    interpolate_pos_encoding = MAEBoxHeadRec.interpolate_pos_encoding
+
+    def forward(self, x):
+        """x [R, C, 14, 14] RoI features -> mask logits [R, K, 14 * scale, 14 * scale]."""
+        B, _, W, H = x.shape
+        x = x.flatten(2).transpose(1, 2)
+        if self.with_decoder_embed:
+            x = self.decoder_embed(self.norm(x))
+        C = x.shape[-1]
+        # as the reference: x carries no class token here, so `npatch = x.shape[1] - 1` never equals the table size and
+        # the patch part always goes through the bicubic resize (scale (W + 0.1) / sqrt(N)), even at the native size
+        x = x + self.interpolate_pos_encoding(x, W * self.patch_size, H * self.patch_size)[:, 1:]
+        for blk in self.decoder_blocks:
+            x = blk(x)
+        x = self.decoder_box_norm(x).view(B, W, H, C).permute(0, 3, 1, 2)
+        x = F.interpolate(x, scale_factor=self.scale_factor, mode=self.scale_mode, align_corners=True)
+        return self.conv_logits(x)
+
+    def loss(self, mask_pred, mask_targets, labels):
+        """mask_pred [R, K, P] logits already sampled at the points (stdroi:3154), mask_targets [R, P] with 2 = ignore."""
+        if mask_pred.size(0) == 0:
+            return dict(loss_mask=mask_pred.sum() * self.loss_weight_mask_start)
+        cls = torch.zeros_like(labels) if self.class_agnostic else labels
+        logits = mask_pred[torch.arange(mask_pred.size(0), device=mask_pred.device), cls]
+        loss = F.binary_cross_entropy_with_logits(logits, mask_targets.to(torch.float32), reduction="mean",
+                                                  weight=~(mask_targets == 2))
+        return dict(loss_mask=loss * self.loss_weight_mask_start)

@@ -900,3 +900,49 @@ def test_mae_box_head_matches_tensor_op_decoder():
     for n, p in head.named_parameters():
         if p.grad is not None:
             assert_close(p.grad, got[n], 2e-3, 1e-5, f"grad {n}")
+
+
+def test_mae_mask_head_forward_loss_and_gradients():
+    """MAEMaskHeadPointSup on the HIP small-N attention (196 tokens per RoI) vs the same weights through torch's
+    scaled_dot_product_attention; point-sampled BCE loss with ignored points; gradients reach every parameter."""
+    import attentionshift_amd as A
+    from attentionshift_amd import mae_heads, mask_targets as MT
+    torch.manual_seed(9)
+    head = A.build_head(dict(type="MAEMaskHeadPointSup", in_channels=48, img_size=224, patch_size=16, embed_dim=64,
+                             depth=2, num_heads=2, mlp_ratio=4., num_classes=20, scale_factor=2, scale_mode="bicubic",
+                             use_checkpoint=False, init_cfg=None)).cuda()
+    torch.nn.init.normal_(head.decoder_pos_embed, std=0.02)
+    assert {"decoder_blocks.1.attn.proj.weight", "conv_logits.weight", "decoder_embed.bias", "decoder_box_norm.weight"} <= set(head.state_dict())
+    x = torch.randn(5, 48, 14, 14).cuda()
+    sites = torch.rand(5, 12, 2).cuda()
+    targets = torch.randint(0, 3, (5, 12)).cuda()
+    labels = torch.tensor([0, 3, 19, 7, 7]).cuda()
+
+    def run():
+        pred = head(x)
+        assert pred.shape == (5, 20, 28, 28)
+        return pred, head.loss(MT.point_sample(pred, sites), targets, labels)["loss_mask"]
+
+    def ref_attn(self, t):
+        B, N, C = t.shape
+        qkv = self.qkv(t).reshape(B, N, 3, self.num_heads, 32).permute(2, 0, 3, 1, 4)
+        o = torch.nn.functional.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2])
+        return self.proj(o.transpose(1, 2).reshape(B, N, C))
+
+    with torch.enable_grad():
+        pred, loss = run()
+        loss.backward()
+        got = {n: p.grad.clone() for n, p in head.named_parameters() if p.grad is not None}
+        head.zero_grad()
+        orig = mae_heads._Attention.forward
+        mae_heads._Attention.forward = ref_attn
+        try:
+            pred2, loss2 = run()
+            loss2.backward()
+        finally:
+            mae_heads._Attention.forward = orig
+    assert_close(pred2, pred, 1e-4, 1e-5, "mask logits"); assert_close(loss2, loss, 1e-5, 1e-6, "loss_mask")
+    assert set(got) == {n for n, p in head.named_parameters() if p.requires_grad}
+    for n, p in head.named_parameters():
+        if p.grad is not None:
+            assert_close(p.grad, got[n], 2e-3, 1e-6, f"grad {n}")
