@@ -624,6 +624,7 @@ class AttnShiftRoIHead(nn.Module):
         self.batch_mean_shift = True              # one as_cosine_shift call for all images of a batch
         self.image_streams = True                 # one HIP stream per image in the single-threaded fast-RNG path
         self.device_draws = True                  # fast-RNG mode: draws on the device, no readback before the merge plan
+        self.part_slots = 8                       # merged-part slots per object carried by the one-readback merge stage
         self._dev_gens = {}
         self._pool, self._streams = None, []
         self.visualize = visualize
@@ -808,11 +809,22 @@ class AttnShiftRoIHead(nn.Module):
         keep = ops.filter_parts(sim.unflatten(0, (G, P)), fg_inter)                  # one launch (stdroi:263-271)
         u = _unit(protg)
         groups, ngroups = ops.merge_plan(keep, (u @ u.transpose(1, 2)) >= merge_thr)
-        ar = torch.arange(P, device=dev)
-        wgt = ((groups[..., None] >> ar.int()) & 1).float()                           # [G, slot, member]
+        # objects rarely keep more than a few merged parts: carry `slots` group slots per object through the
+        # similarity / statistics passes; an object with more raises a flag (synchronous path), like the other rare cases
+        slots = min(P, self.part_slots)
+        if extra is not None:
+            extra.append((ngroups > slots).any())
+        else:
+            slots = P
+        groups = groups[:, :slots]
+        ar_p = torch.arange(P, device=dev)
+        wgt = ((groups[..., None] >> ar_p.int()) & 1).float()                         # [G, slot, member]
         merged = torch.bmm(wgt, protg) / (wgt.sum(-1, keepdim=True) + 1e-8)            # matmul(weight, prot) / (sum + 1e-8)
         feat_tok = vit_feat.flatten(1).t().contiguous()
         allp = merged.flatten(0, 1).contiguous()
+        P = slots                                                                      # from here on: slots per object
+        ngroups = ngroups.clamp(max=P)
+        ar = torch.arange(P, device=dev)
         sims = torch.cat([ops.refine_similarity(feat_tok, allp[o:o + 32], None, 0, 0, 1.0, False, hp, wp)[0][0]
                           for o in range(0, G * P, 32)]).reshape(G, P, hp, wp)
         # per-slot statistics exactly as part_centers computes them per part (one launch)
