@@ -8,7 +8,7 @@
 //                get_bbox_from_cam_fast (:60-116): min-max normalise, threshold, CCL, area filter,
 //                tight box, 'expand' about the point.
 //
-// Run-based union-find (the CAM foreground is a few huge blobs; per-pixel unions would serialise on the
+// as_ccl_2d, run-based union-find over a label image (blobs are huge; per-pixel unions would serialise on the
 // root's atomics):
 //   rowscan   one workgroup per image row: prefix-max scan of the last background column, so every
 //             foreground pixel points at the first pixel of its horizontal run (no atomics)
@@ -16,8 +16,9 @@
 //             run or the upper run starts (plus the two diagonal contacts)
 //   compress  run starts find their root; then every pixel takes root = L[L[p]]
 // Links always go from the larger raster index to the smaller (atomicMin), so a set's root is its minimum
-// index whatever the scheduling: labels are bit-exact and deterministic.  Areas and extents are
-// accumulated per run / per row with integer arithmetic only.
+// index whatever the scheduling: labels are bit-exact and deterministic.
+// as_cam_boxes needs only the PARTITION (areas, kept set, extents) and never builds the label image: see the
+// run-based path below (cam_minmax / cam_runs / cam_cc) and the fused sampling masks (cam_sample_masks).
 // Compiled with -ffp-contract=off (bilinear.h).
 #include "bilinear.h"
 
@@ -65,20 +66,6 @@ struct CamMeta {            // per map, in workspace
   int max_area;
   int pad;
 };
-struct FgCam {              // upsample + min-max normalise + threshold, recomputed on the fly
-  const float* cams;
-  const CamMeta* meta;
-  float thr;
-  int Hp, Wp;
-  __device__ __forceinline__ bool operator()(int m, int y, int x, int H, int W) const {
-    const float* src = cams + (size_t)m * Hp * Wp;
-    const float sy = (float)Hp / (float)H, sx = (float)Wp / (float)W;
-    const float v = bilerp(src, Wp, lerp_axis(y, Hp, sy), lerp_axis(x, Wp, sx));
-    const float mn = ord2f(meta[m].mn), mx = ord2f(meta[m].mx);
-    return (v - mn) / fmaxf(mx - mn, 1e-6f) >= thr;       // stdroi:63-66
-  }
-};
-
 // ---- rowscan: grid (H, M).  L[p] = first pixel of p's run, or -1 -----------------------------------
 template <typename Fg>
 __global__ __launch_bounds__(CC_NT) void ccl_rowscan_kernel(Fg fg, int32_t* __restrict__ Lall, int H, int W) {
@@ -148,10 +135,8 @@ __global__ __launch_bounds__(CC_NT) void ccl_compress_runs_kernel(int32_t* __res
 }
 
 // every pixel: root = L[L[p]] (start pixels already hold their root and L[root] == root).
-// PLUS1: write the final label root+1 / 0.  area != null: add each run's length at its root.
-template <bool PLUS1>
-__global__ __launch_bounds__(CC_NT) void ccl_finalize_kernel(int32_t* __restrict__ Lall, int32_t* __restrict__ area,
-                                                             int M, int H, int W) {
+// every pixel takes its component's root (a run start already holds it; the others hold their run start)
+__global__ __launch_bounds__(CC_NT) void ccl_finalize_kernel(int32_t* __restrict__ Lall, int M, int H, int W) {
   const size_t i = (size_t)blockIdx.x * CC_NT + threadIdx.x;
   const int HW = H * W;
   if (i >= (size_t)M * HW) return;
@@ -159,21 +144,13 @@ __global__ __launch_bounds__(CC_NT) void ccl_finalize_kernel(int32_t* __restrict
   int32_t* L = Lall + (size_t)m * HW;
   const int s = L[p];
   const int x = p % W;
-  // everything this thread needs from its neighbours is read BEFORE anything is written
-  const bool w_fg = x > 0 && L[p - 1] >= 0;
-  const bool e_fg = x + 1 < W && L[p + 1] >= 0;
-  if (s < 0) return;
-  const bool is_start = !w_fg;
-  // a start pixel already holds its root; any other pixel holds its run start, whose entry is the root.
-  // (A start entry is only ever rewritten with the same value, so concurrent in-place writes are benign.)
-  const int root = is_start ? s : __hip_atomic_load(&L[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (area != nullptr && !e_fg) {
-    const int xs = is_start ? x : (s % W);
-    atomicAdd(&area[(size_t)m * HW + root], x - xs + 1);
-  }
-  if (!is_start) __hip_atomic_store(&L[p], root, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const bool w_fg = x > 0 && L[p - 1] >= 0;        // read BEFORE anything is written
+  if (s < 0 || !w_fg) return;
+  // (a start entry is only ever rewritten with the same value, so concurrent in-place writes are benign)
+  __hip_atomic_store(&L[p], __hip_atomic_load(&L[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
 }
-// parent array -> labels: root + 1 for foreground, 0 for background
+
 __global__ __launch_bounds__(CC_NT) void ccl_plus1_kernel(int32_t* __restrict__ L, size_t total) {
   const size_t i = (size_t)blockIdx.x * CC_NT + threadIdx.x;
   if (i < total) L[i] = L[i] + 1;
@@ -590,8 +567,7 @@ extern "C" int as_ccl_2d(const uint8_t* img, int32_t* labels, int M, int H, int 
   hipLaunchKernelGGL((ccl_rowscan_kernel<FgImage>), dim3(H, M), dim3(CC_NT), 0, s, fg, labels, H, W);
   hipLaunchKernelGGL(ccl_merge_kernel, dim3(blocks_for(total)), dim3(CC_NT), 0, s, labels, M, H, W);
   hipLaunchKernelGGL(ccl_compress_runs_kernel, dim3(blocks_for(total)), dim3(CC_NT), 0, s, labels, M, H, W);
-  hipLaunchKernelGGL((ccl_finalize_kernel<true>), dim3(blocks_for(total)), dim3(CC_NT), 0, s, labels,
-                     (int32_t*)nullptr, M, H, W);
+  hipLaunchKernelGGL(ccl_finalize_kernel, dim3(blocks_for(total)), dim3(CC_NT), 0, s, labels, M, H, W);
   hipLaunchKernelGGL(ccl_plus1_kernel, dim3(blocks_for(total)), dim3(CC_NT), 0, s, labels, total);
   AS_CHECK_LAUNCH("ccl_2d");
   return AS_OK;
