@@ -393,6 +393,21 @@ def test_cam_boxes_wide_maps_match_pixel_ccl(ops):
         assert boxes[m].tolist() == box, m
 
 
+def test_cam_boxes_more_runs_than_fit_lds_match_pixel_ccl(ops):
+    """A 64x64 checkerboard upsampled to 1024^2 has ~32 runs in every row (> 18432 per map): the component stage then
+    works on its workspace arrays instead of LDS.  Same partition as the per-pixel labelling."""
+    yy, xx = torch.meshgrid(torch.arange(64), torch.arange(64), indexing="ij")
+    board = ((yy + xx) % 2).float()
+    cams = torch.stack((board, 1 - board))
+    cams[0, 20:30, 20:30] = 1.0                               # one block larger than the rest
+    cams[1, 5:9, 40:50] = 1.0
+    pts = torch.tensor([[400., 400.], [700., 100.]])
+    boxes, status, up, mm = ops.cam_boxes(dev(cams), dev(pts), 0.6, 0.5, 16, True)
+    for m, (area, box) in enumerate(_boxes_from_pixel_ccl(ops, up, mm, 0.6, 0.5, pts)):
+        assert int(status[m]) == area, m
+        assert boxes[m].tolist() == box, m
+
+
 def test_cam_boxes_noise_maps_match_pixel_ccl(ops):
     """Speckled maps (hundreds of components, dozens of runs per row): the run-based box stage must give what the
     per-pixel labelling (as_ccl_2d, itself pinned to scipy) gives -- kept area and tight box per map."""
