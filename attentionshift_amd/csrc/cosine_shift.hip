@@ -762,22 +762,24 @@ __global__ __launch_bounds__(S1_NT) void refine_sim_kernel(const float* __restri
     const int n = tile * CS_TILE1 + tid;
     const bool nvalid = n < Np;
     const int nc = min(n, Np - 1);
+    // the first `is_select` maps form the selection group (0 = none, the refinement of the background seeds; Gp = all,
+    // the foreground seeds; in between = both seed sets refined by one call, the group first)
+    const int nsel = is_select;
     auto masked = [&](int g) {
       float v = val[g][tid];
-      if (is_select && g < G) v = v * (in_box(load_box(boxes, g, Hp, Wp), nc, Wp) ? 1.0f : 0.0f);
+      if (g < nsel && g < G) v = v * (in_box(load_box(boxes, g, Hp, Wp), nc, Wp) ? 1.0f : 0.0f);
       return v;
     };
     int best = 0;
     float bv = -INFINITY;
-    if (is_select)
-      for (int g = 0; g < Gp; ++g) {
-        const float v = masked(g);
-        if (v > bv) { bv = v; best = g; }        // strict: ties keep the lowest map index
-      }
+    for (int g = 0; g < nsel; ++g) {
+      const float v = masked(g);
+      if (v > bv) { bv = v; best = g; }          // strict: ties keep the lowest map index
+    }
     for (int g = 0; g < Gp; ++g) {
       const float raw = val[g][tid], mv = masked(g);
-      const float o = is_select ? (g == best ? mv : 0.0f) : raw;
-      const float wv = (is_select && mask_work) ? mv : raw;
+      const float o = g < nsel ? (g == best ? mv : 0.0f) : raw;
+      const float wv = (g < nsel && mask_work) ? mv : raw;
       if (nvalid) {
         out[(size_t)g * Np + n] = o;
         work[(size_t)g * Np + n] = wv;
@@ -907,6 +909,8 @@ extern "C" int as_refine_similarity(const float* feat, const float* seeds, const
                                     size_t ws_bytes, int C, int Hp, int Wp, as_stream_t stream) {
   AS_REQUIRE(feat && seeds && maps && seeds_out && ws && (boxes || !is_select), AS_E_BADARG, "as_refine_similarity: null pointer");
   AS_REQUIRE(G >= 0 && Gp > 0 && G <= Gp && Gp <= PMAX, AS_E_UNSUPPORTED, "as_refine_similarity: Gp=%d seeds (max %d)", Gp, PMAX);
+  AS_REQUIRE(is_select >= 0 && is_select <= Gp && (is_select == 0 || G <= is_select), AS_E_BADARG,
+             "as_refine_similarity: selection group of %d maps (0..Gp, at least the G boxed ones)", is_select);
   AS_REQUIRE(C % SH_CH == 0 && C <= 4 * CS_NT && Hp > 0 && Wp > 0 && refine_times >= 0, AS_E_UNSUPPORTED,
              "as_refine_similarity: C=%d must be a multiple of %d and <= 1024", C, SH_CH);
   const int Np = Hp * Wp;

@@ -421,7 +421,8 @@ def cosine_shift(feat, box_patch, obj_img, prot, n_shift, hp, wp, tau0=0.1, temp
 
 
 def refine_similarity(feat, seeds, boxes_patch, num_obj, refine_times, tau, is_select, hp, wp):
-    """feat [Np,C], seeds [Gp,C], boxes_patch [G,4] int32 -> (maps [R+1,Gp,Np], seeds_out [Gp,C])."""
+    """feat [Np,C], seeds [Gp,C], boxes_patch [G,4] int32 -> (maps [R+1,Gp,Np], seeds_out [Gp,C]).
+    is_select: False / True as the reference's flag, or an int = size of the leading selection group (see the header)."""
     lib = _lib.load()
     _chk(feat, seeds, dtype=torch.float32)
     if boxes_patch is not None:
@@ -432,8 +433,9 @@ def refine_similarity(feat, seeds, boxes_patch, num_obj, refine_times, tau, is_s
     seeds_out = torch.empty(Gp, C, device=feat.device, dtype=torch.float32)
     nbytes = lib.as_refine_similarity_workspace_bytes(C, Np_, Gp)
     ws = torch.empty(nbytes, device=feat.device, dtype=torch.uint8)
+    n_select = (Gp if is_select else 0) if isinstance(is_select, bool) else int(is_select)
     _lib.check(lib.as_refine_similarity(_p(feat), _p(seeds), _p(boxes_patch), int(num_obj), Gp, int(refine_times),
-                                        float(tau), 1 if is_select else 0, _p(maps), _p(seeds_out), _p(ws), nbytes, C,
+                                        float(tau), n_select, _p(maps), _p(seeds_out), _p(ws), nbytes, C,
                                         hp, wp, _stream()), "as_refine_similarity")
     return maps, seeds_out
 

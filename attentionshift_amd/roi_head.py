@@ -684,10 +684,12 @@ class AttnShiftRoIHead(nn.Module):
         CLOCK.mark("  sampling")
         feat_tok = feat_chw.flatten(1).t().contiguous()
         box_patch = (rois // STRIDE).to(torch.int32).contiguous()
-        sim_fg, fg_feat = ops.refine_similarity(feat_tok, seed_features(pts_fg, feat_chw).contiguous(), box_patch, G,
-                                                refine_times, obj_tau, True, hp, wp)
-        sim_bg, bg_feat = ops.refine_similarity(feat_tok, seed_features(pts_bg, feat_chw).contiguous(), box_patch, G,
-                                                refine_times, obj_tau, False, hp, wp)
+        # foreground (G + 1 seeds, selection group) and background (G seeds) sets refined by ONE call
+        seeds = seed_features(torch.cat((pts_fg, pts_bg), dim=0), feat_chw).contiguous()
+        n_fg = pts_fg.shape[0]
+        sims, seeds_out = ops.refine_similarity(feat_tok, seeds, box_patch, G, refine_times, obj_tau, n_fg, hp, wp)
+        sim_fg, sim_bg = sims[:, :n_fg], sims[:, n_fg:]
+        fg_feat, bg_feat = seeds_out[:n_fg], seeds_out[n_fg:]
         CLOCK.mark("  refine_similarity")
         if last_level_only:                                     # the chain below only consumes the last refinement level
             sim_fg, sim_bg = sim_fg[-1:], sim_bg[-1:]

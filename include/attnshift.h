@@ -240,11 +240,14 @@ int as_cosine_shift(const float* feat, const int32_t* box_patch, const int32_t* 
 
 /* Cosine-affinity refinement on the patch grid (stdroi:668-707 get_refined_similarity):
  *   feat   [Np,C] one image, seeds [Gp,C] (mean feature of the sampled points, :335-338)
- *   boxes  [G,4] inclusive patch boxes of the first G maps (is_select path)
+ *   boxes  [G,4] inclusive patch boxes of the first G maps (selection group only)
+ *   n_select  the first n_select maps form the selection group of `is_select=True` (box masking of its first G maps,
+ *             keep-the-winner among the group, :676-683 / :697-703); 0 = none (`is_select=False`), Gp = all, a value in
+ *             between refines the foreground and the background seed sets of an image in ONE call (group first)
  *   maps   [R+1,Gp,Np] ;  seeds_out [Gp,C] = refined seed features of the last round */
 size_t as_refine_similarity_workspace_bytes(int C, int Np, int Gp);
 int as_refine_similarity(const float* feat, const float* seeds, const int32_t* boxes, int G, int Gp,
-                         int refine_times, float tau, int is_select, float* maps, float* seeds_out, void* ws,
+                         int refine_times, float tau, int n_select, float* maps, float* seeds_out, void* ws,
                          size_t ws_bytes, int C, int Hp, int Wp, as_stream_t stream);
 
 /* Full-resolution instance maps from the patch-grid refinement (stdroi:1010-1019):
