@@ -134,6 +134,20 @@ def main():
         full = torch.tensor([[0, 0, wp - 1, hp - 1]] * G, dtype=torch.int32, device=dev)
         ms = timeit(lambda: ops.cosine_shift(feat, full, obj_img, prot, S, hp, wp), a.reps, sync_each=True)
         emit("cosine_shift_S5_fullboxes", ms, bytes_=alg, note="worst case: every box covers the image")
+    if want("refine"):                                                  # B2 (201 MB/image algorithmic)
+        hp = wp = 64
+        inp = synthetic.shift_inputs(100, hp, wp, D, 3, 1)
+        f = inp["vit_feat"].flatten(1).t().contiguous().to(dev)
+        seeds = torch.stack([f[(20 + 3 * i) * wp + 10 + 5 * i] for i in range(7)]).contiguous()      # 4 fg + 3 bg seeds
+        bp = inp["patch_boxes"].int().to(dev)
+
+        def b2():
+            sims, _ = ops.refine_similarity(f, seeds, bp, 3, 2, 0.9, 4, hp, wp)
+            return ops.instance_maps(sims[-1:, :4].contiguous(), sims[-1:, 4:].contiguous(), 3, hp, wp, 16)
+
+        ms = timeit(b2, a.reps, sync_each=True)
+        emit("refine_similarity+instance_maps_1img", ms, bytes_=2 * 3 * 4 * 1024 * 1024 * 4 * 2,
+             note="B2 of one image (7 seeds, 2 refinement levels, last-level instance maps); bytes = SURVEY 8d's 201 MB/image")
     if want("small"):                                                   # MAE-decoder heads
         for Bp, N in ((1024, 50), (128, 197)):
             qkv = torch.randn(Bp, N, 3, 8, 32, generator=g).to(torch.bfloat16).to(dev)
