@@ -7,7 +7,10 @@
     bbox_head_loss            mae_bbox_head_rec.py:170-228: cross entropy over K + 1 classes normalised by the number of
                               weighted samples, L1 on the positives' deltas of THEIR class normalised by the number of
                               samples, top-1 accuracy
-Proposal generation, IoU assignment and sampling (mmdet's RPN / assigners / samplers) are not part of this build.
+    giou_loss                 mmdet/models/losses/iou_loss.py:87-102 + iou2d_calculator.py:127-158 (aligned GIoU, the
+                              union and the enclosing area clamped to eps); the shipped config regresses DECODED boxes
+                              with it (reg_decoded_bbox=True, GIoULoss weight 10, attnshift_voc12aug.py:110-114)
+IoU assignment and sampling are in attentionshift_amd.assign; proposal generation (mmdet's RPN) is not part of this build.
 """
 import math
 
@@ -45,8 +48,20 @@ def delta2bbox(rois, deltas, means=(0., 0., 0., 0.), stds=(1., 1., 1., 1.), max_
     return torch.stack([x1, y1, x2, y2], dim=-1).flatten(-2)
 
 
+def giou_loss(pred, target, eps=1e-6):
+    """1 - GIoU of aligned xyxy boxes [n,4] -> [n]."""
+    area_p = (pred[:, 2] - pred[:, 0]) * (pred[:, 3] - pred[:, 1])
+    area_t = (target[:, 2] - target[:, 0]) * (target[:, 3] - target[:, 1])
+    wh = (torch.min(pred[:, 2:], target[:, 2:]) - torch.max(pred[:, :2], target[:, :2])).clamp(min=0)
+    overlap = wh[:, 0] * wh[:, 1]
+    union = (area_p + area_t - overlap).clamp(min=eps)
+    enc = (torch.max(pred[:, 2:], target[:, 2:]) - torch.min(pred[:, :2], target[:, :2])).clamp(min=0)
+    enc_area = (enc[:, 0] * enc[:, 1]).clamp(min=eps)
+    return 1 - (overlap / union - (enc_area - union) / enc_area)
+
+
 def bbox_targets(pos_bboxes, neg_bboxes, pos_gt_bboxes, pos_gt_labels, num_classes, means=(0., 0., 0., 0.),
-                 stds=(0.1, 0.1, 0.2, 0.2), pos_weight=-1):
+                 stds=(0.1, 0.1, 0.2, 0.2), pos_weight=-1, reg_decoded_bbox=False):
     """Per-image lists -> concatenated (labels, label_weights, bbox_targets [n,4], bbox_weights [n,4]); positives first
     inside every image, as mmdet's samplers order them."""
     out = ([], [], [], [])
@@ -57,7 +72,7 @@ def bbox_targets(pos_bboxes, neg_bboxes, pos_gt_bboxes, pos_gt_labels, num_class
         if n_pos:
             labels[:n_pos] = gl
             lw[:n_pos] = 1.0 if pos_weight <= 0 else pos_weight
-            bt[:n_pos] = bbox2delta(pb, gb, means, stds)
+            bt[:n_pos] = gb if reg_decoded_bbox else bbox2delta(pb, gb, means, stds)
             bw[:n_pos] = 1
         lw[n_pos:] = 1.0
         for lst, v in zip(out, (labels, lw, bt, bw)):
@@ -66,8 +81,10 @@ def bbox_targets(pos_bboxes, neg_bboxes, pos_gt_bboxes, pos_gt_labels, num_class
 
 
 def bbox_head_loss(cls_score, bbox_pred, labels, label_weights, bbox_targets_, bbox_weights, num_classes,
-                   reg_class_agnostic=False, loss_cls_weight=1.0, loss_bbox_weight=1.0):
-    """cls_score [n, K+1] | None, bbox_pred [n, 4 or 4K] | None -> dict(loss_cls, acc, loss_bbox)."""
+                   reg_class_agnostic=False, loss_cls_weight=1.0, loss_bbox_weight=1.0, rois=None, loss_bbox_type="L1Loss",
+                   means=(0., 0., 0., 0.), stds=(0.1, 0.1, 0.2, 0.2)):
+    """cls_score [n, K+1] | None, bbox_pred [n, 4 or 4K] | None -> dict(loss_cls, acc, loss_bbox).  With `rois` [n,4]
+    the predictions are decoded against them first (reg_decoded_bbox) and `bbox_targets_` are absolute boxes."""
     losses = {}
     if cls_score is not None and cls_score.numel() > 0:
         avg = max(float((label_weights > 0).sum()), 1.0)
@@ -77,10 +94,15 @@ def bbox_head_loss(cls_score, bbox_pred, labels, label_weights, bbox_targets_, b
     if bbox_pred is not None:
         pos = (labels >= 0) & (labels < num_classes)
         if pos.any():
+            if rois is not None:
+                bbox_pred = delta2bbox(rois, bbox_pred, means, stds)
             pred = bbox_pred.view(bbox_pred.size(0), 4)[pos] if reg_class_agnostic else \
                 bbox_pred.view(bbox_pred.size(0), -1, 4)[pos, labels[pos]]
-            l1 = (pred - bbox_targets_[pos]).abs() * bbox_weights[pos]
-            losses["loss_bbox"] = loss_bbox_weight * l1.sum() / bbox_targets_.size(0)
+            if loss_bbox_type == "GIoULoss":
+                per = giou_loss(pred, bbox_targets_[pos]) * bbox_weights[pos].mean(-1)
+            else:
+                per = (pred - bbox_targets_[pos]).abs() * bbox_weights[pos]
+            losses["loss_bbox"] = loss_bbox_weight * per.sum() / bbox_targets_.size(0)
         else:
             losses["loss_bbox"] = bbox_pred[pos].sum()
     return losses

@@ -95,6 +95,18 @@ class MAEBoxHeadRec(nn.Module):
         if with_reconstruct:
             self.fc_rec = nn.Linear(embed_dim, 3 * patch_size * patch_size)
         self.seed_score_thr, self.seed_thr, self.seed_multiple, self.cam_layer = seed_score_thr, seed_thr, seed_multiple, cam_layer
+        # the loss configuration the RoI head reads off the box head (mae_bbox_head_rec.py:36-70)
+        self.reg_class_agnostic = reg_class_agnostic
+        self.reg_decoded_bbox = kwargs.get("reg_decoded_bbox", False)
+        coder = kwargs.get("bbox_coder") or {}
+        self.target_means = tuple(coder.get("target_means", (0., 0., 0., 0.)))
+        self.target_stds = tuple(coder.get("target_stds", (0.1, 0.1, 0.2, 0.2)))
+        self.loss_cls_cfg = dict(kwargs.get("loss_cls") or dict(type="CrossEntropyLoss", loss_weight=1.0))
+        self.loss_bbox_cfg = dict(kwargs.get("loss_bbox") or dict(type="L1Loss", loss_weight=1.0))
+        self.loss_point_cfg = dict(kwargs.get("loss_point") or dict(type="L1Loss", loss_weight=10.0))
+        self.loss_point_cls_cfg = dict(kwargs.get("loss_point_cls") or dict(type="FocalLoss", gamma=2.0, alpha=0.25,
+                                                                            loss_weight=1.0))
+        self.loss_weight_bbox_start = kwargs.get("loss_weight_bbox_start", 1.0)
         nn.init.trunc_normal_(self.det_token, std=.02)
         self.apply(self._init_weights)
 
@@ -137,6 +149,24 @@ class MAEBoxHeadRec(nn.Module):
         bbox_pred = self.fc_reg(x[:, 0]) if self.with_reg else None
         img_rec = self.fc_rec(x[:, 1:]).transpose(1, 2).reshape(B, -1, W, H) if self.with_reconstruct else None
         return cls_score, bbox_pred, img_rec
+
+    def get_targets(self, sampling_results, pos_weight=-1):
+        """BBoxHead.get_targets as the RoI head calls it (stdroi:2980): (labels, label_weights, bbox_targets, bbox_weights)."""
+        from .bbox_loss import bbox_targets
+        return bbox_targets([r.pos_bboxes for r in sampling_results], [r.neg_bboxes for r in sampling_results],
+                            [r.pos_gt_bboxes for r in sampling_results], [r.pos_gt_labels for r in sampling_results],
+                            self.num_classes, self.target_means, self.target_stds, pos_weight, self.reg_decoded_bbox)
+
+    def loss(self, cls_score, bbox_pred, rois, labels, label_weights, bbox_targets, bbox_weights):
+        """mae_bbox_head_rec.py:170-221 (the reconstruction term needs with_reconstruct, off in the shipped config)."""
+        from .bbox_loss import bbox_head_loss
+        out = bbox_head_loss(cls_score, bbox_pred, labels, label_weights, bbox_targets, bbox_weights, self.num_classes,
+                             self.reg_class_agnostic, self.loss_cls_cfg.get("loss_weight", 1.0),
+                             self.loss_bbox_cfg.get("loss_weight", 1.0),
+                             rois=rois[:, 1:] if self.reg_decoded_bbox else None,
+                             loss_bbox_type=self.loss_bbox_cfg.get("type", "L1Loss"), means=self.target_means,
+                             stds=self.target_stds)
+        return {k: (v * self.loss_weight_bbox_start if k != "acc" else v) for k, v in out.items()}
 
 
 @HEADS.register_module()

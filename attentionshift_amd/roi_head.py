@@ -599,6 +599,15 @@ class AttnShiftRoIHead(nn.Module):
         self.bbox_head = types.SimpleNamespace(cam_layer=bh.get("cam_layer", 7), seed_thr=bh.get("seed_thr", 0.2),
                                                seed_multiple=bh.get("seed_multiple", 0.5),
                                                num_classes=bh.get("num_classes", 20))
+        # the trainable box / mask heads are built when their configs carry construction arguments (in_channels); the
+        # attribute-only form keeps the pseudo-label path usable on its own
+        self.mask_head = None
+        if isinstance(bbox_head, dict) and bbox_head.get("type") == "MAEBoxHeadRec" and "in_channels" in bbox_head:
+            from .mae_heads import MAEBoxHeadRec
+            self.bbox_head = MAEBoxHeadRec(**{k: v for k, v in bbox_head.items() if k != "type"})
+        if isinstance(mask_head, dict) and mask_head.get("type") == "MAEMaskHeadPointSup" and "in_channels" in mask_head:
+            from .mae_heads import MAEMaskHeadPointSup
+            self.mask_head = MAEMaskHeadPointSup(**{k: v for k, v in mask_head.items() if k != "type"})
         self.with_mil = mil_head is not None
         self.with_mask = mask_head is not None
         self.with_bbox = bbox_head is not None
@@ -641,8 +650,93 @@ class AttnShiftRoIHead(nn.Module):
             return median_area_selector(boxes_per_img, labels_per_img, roi_feature_map)
         return self._mil_selector(boxes_per_img, labels_per_img, roi_feature_map)
 
-    def forward_train(self, *a, **k):
-        raise NotImplementedError("forward_train (trainable bbox/mask heads) is outside the hot path: SURVEY 8f")
+    def _roi_extract(self, x, rois, which="bbox_roi_extractor"):
+        """SingleRoIExtractor with one stride-16 level (attnshift_voc12aug.py:64-68): RoIAlign on x[0]."""
+        from .mil_head import roi_align
+        cfg = dict(self.sub_cfgs.get(which) or {})
+        rl = dict(cfg.get("roi_layer", {}))
+        fmap = x[0] if isinstance(x, (list, tuple)) else x
+        return roi_align(fmap.float(), rois, rl.get("output_size", 7), 1.0 / cfg.get("featmap_strides", [STRIDE])[0],
+                         rl.get("sampling_ratio", 0), True)
+
+    def forward_train(self, x, img_metas, proposal_list, gt_bboxes, gt_labels, gt_bboxes_ignore=None, gt_masks=None,
+                      vit_feat=None, img=None, point_init=None, point_cls=None, point_reg=None, imgs_whwh=None,
+                      attns=None, gt_points=None, gt_points_labels=None, mask_point_labels=None, mask_point_coords=None,
+                      semantic_centers=None, semantic_centers_split=None, sc_corres_gts=None, generator=None, **kwargs):
+        """stdroi:2513-2727, the shipped configuration (no RepPoints heads, no MAE reconstruction head): the point-token
+        loss, IoU assignment + random sampling of the proposals against the PSEUDO boxes, the box branch on the 7x7
+        RoI features and the point-supervised mask branch on the positives' features.  `gt_bboxes` / `gt_labels` /
+        `mask_point_*` / `semantic_centers_split` are what seed_pseudo_gt returned (two_stage_point_align.py:95-135)."""
+        from . import assign as A
+        from .mask_targets import mask_point_targets, point_sample
+        from .point_loss import point_token_loss
+        if not isinstance(self.bbox_head, nn.Module):
+            raise RuntimeError("forward_train needs the box head built from its config (bbox_head with in_channels)")
+        num_imgs = len(img_metas)
+        rcnn = self.train_cfg
+        losses = {}
+        pa = _get(rcnn, "point_assigner", None)
+        if pa:                                                                 # :2568-2602
+            bh = self.bbox_head
+            losses.update(point_token_loss(
+                point_cls, point_reg, gt_points, gt_points_labels, [m["img_shape"] for m in img_metas],
+                num_classes=bh.num_classes, loss_point_weight=bh.loss_point_cfg.get("loss_weight", 10.0),
+                loss_cls_weight=bh.loss_point_cls_cfg.get("loss_weight", 1.0),
+                gamma=bh.loss_point_cls_cfg.get("gamma", 2.0), alpha=bh.loss_point_cls_cfg.get("alpha", 0.25),
+                point_pos_weight=_get(rcnn, "point_pos_weight", 1),
+                cls_cost=_get(pa, "cls_cost", {}).get("weight", 1.0), reg_cost=_get(pa, "reg_cost", {}).get("weight", 1.0)))
+        asg = dict(_get(rcnn, "assigner", None) or {})
+        smp = dict(_get(rcnn, "sampler", None) or {})
+        sampling_results = []
+        for i in range(num_imgs):                                              # :2624-2636
+            props = proposal_list[i][:, :4]
+            assigned, _ = A.max_iou_assign(props, gt_bboxes[i], asg.get("pos_iou_thr", 0.5), asg.get("neg_iou_thr", 0.5),
+                                           asg.get("min_pos_iou", 0.5), asg.get("match_low_quality", False))
+            sampling_results.append(A.random_sample(props, gt_bboxes[i], gt_labels[i], assigned, smp.get("num", 512),
+                                                    smp.get("pos_fraction", 0.25), smp.get("add_gt_as_proposals", True),
+                                                    generator))
+        # ---- box branch (:2974-3020) ----
+        rois = torch.cat([torch.cat((r.bboxes.new_full((r.bboxes.shape[0], 1), float(i)), r.bboxes), dim=1)
+                          for i, r in enumerate(sampling_results)])
+        bbox_feats = self._roi_extract(x, rois)
+        cls_score, bbox_pred, _rec = self.bbox_head(bbox_feats)
+        targets = self.bbox_head.get_targets(sampling_results, _get(rcnn, "pos_weight", -1))
+        losses.update(self.bbox_head.loss(cls_score, bbox_pred, rois, *targets))
+        # ---- mask branch (:3094-3160): the positives' BOX features through the mask head, BCE at the mask points ----
+        if self.mask_head is not None and mask_point_coords is not None:
+            pos = torch.cat([torch.cat((torch.ones(r.pos_bboxes.shape[0], dtype=torch.bool, device=rois.device),
+                                        torch.zeros(r.neg_bboxes.shape[0], dtype=torch.bool, device=rois.device)))
+                             for r in sampling_results])
+            mask_pred = self.mask_head(bbox_feats[pos])
+            sites, mask_t = mask_point_targets([r.pos_bboxes for r in sampling_results],
+                                               [r.pos_assigned_gt_inds for r in sampling_results],
+                                               mask_point_coords, mask_point_labels, semantic_centers_split)
+            pos_labels = torch.cat([r.pos_gt_labels for r in sampling_results])
+            if mask_pred.shape[0]:
+                losses.update(self.mask_head.loss(point_sample(mask_pred, sites, align_corners=False), mask_t, pos_labels))
+            else:
+                losses.update(self.mask_head.loss(mask_pred, mask_t, pos_labels))
+        self.last_sampling_results = sampling_results
+        return losses
+
+    def train_losses(self, roi_feature_map, img_metas, proposal_list, vit_feat, attns, point_cls, point_reg, gt_points,
+                     gt_points_labels, generator=None, **seed_kw):
+        """The RoI-head half of the detector's training step with precomputed proposals
+        (two_stage_point_align.py:75-150, the `proposal_list = proposals` branch): pseudo labels from the attention
+        shift, then the box / mask / point / MIL losses against them.  Returns (losses, seed_pseudo_gt's dict)."""
+        seed = self.seed_pseudo_gt(None, img_metas, None, None, None, vit_feat=vit_feat, point_cls=point_cls,
+                                   point_reg=point_reg, attns=attns, gt_points=gt_points,
+                                   gt_points_labels=gt_points_labels, roi_feature_map=roi_feature_map, return_mask=True,
+                                   **seed_kw)
+        losses = dict(seed["mil_losses"])
+        losses.update(self.forward_train(
+            roi_feature_map, img_metas, proposal_list, seed["pseudo_gt_bboxes"], seed["pseudo_gt_labels"], None,
+            seed["pseudo_gt_masks"], vit_feat=vit_feat, point_cls=point_cls, point_reg=point_reg, attns=attns,
+            gt_points=gt_points, gt_points_labels=gt_points_labels, mask_point_coords=seed["mask_points_coords"],
+            mask_point_labels=seed["mask_points_labels"], semantic_centers=seed["semantic_centers"],
+            semantic_centers_split=seed["semantic_centers_split"], sc_corres_gts=seed.get("corres_gts"),
+            generator=generator))
+        return losses, seed
 
     def simple_test(self, *a, **k):
         raise NotImplementedError("inference heads are outside the hot path: SURVEY 8f")

@@ -1,0 +1,24 @@
+"""IoU assignment / random sampling of the R-CNN branches.  CPU only."""
+import torch
+
+from attentionshift_amd import assign as AS
+
+
+def test_iou_assign_and_sample():
+    gts = torch.tensor([[0., 0., 100., 100.], [200., 200., 300., 280.]])
+    props = torch.tensor([[5., 5., 100., 100.], [0., 0., 40., 40.], [210., 205., 300., 280.], [400., 400., 450., 450.],
+                          [190., 190., 310., 300.]])
+    iou = AS.bbox_overlaps(gts, props)
+    assert abs(float(iou[0, 0]) - 0.9025) < 1e-4 and float(iou[1, 3]) == 0.0
+    assigned, best = AS.max_iou_assign(props, gts)
+    assert assigned.tolist() == [1, 0, 2, 0, 2]                    # IoU(gt1, prop4) = 8000 / 13200 = 0.606
+    assert AS.max_iou_assign(props, gts[:0])[0].tolist() == [0] * 5
+    gen = torch.Generator().manual_seed(0)
+    res = AS.random_sample(props, gts, torch.tensor([3, 7]), assigned, num=6, pos_fraction=0.5, generator=gen)
+    assert res.pos_inds.numel() == 3 and res.neg_inds.numel() == 2            # 5 positives (2 gt + 3), capped at 3
+    assert (res.pos_gt_labels == torch.tensor([3, 7])[res.pos_assigned_gt_inds]).all()
+    assert res.bboxes.shape == (5, 4)
+    boxes = torch.cat((gts, props))
+    assert torch.equal(res.pos_bboxes, boxes[res.pos_inds]) and torch.equal(res.pos_gt_bboxes, gts[res.pos_assigned_gt_inds])
+    none = AS.random_sample(props, gts[:0], torch.zeros(0, dtype=torch.long), torch.zeros(5, dtype=torch.long), num=4)
+    assert none.pos_inds.numel() == 0 and none.neg_inds.numel() == 4

@@ -48,3 +48,18 @@ def test_targets_and_loss_definitions():
     assert float(none["loss_bbox"]) == 0.0
     agn = BL.bbox_head_loss(None, reg.detach()[:, :4], labels, lw, bt, bw, K, reg_class_agnostic=True)
     assert "loss_cls" not in agn and float(agn["loss_bbox"]) > 0
+
+
+def test_giou_and_decoded_regression():
+    a = torch.tensor([[0., 0., 10., 10.], [0., 0., 10., 10.], [0., 0., 10., 10.]])
+    b = torch.tensor([[0., 0., 10., 10.], [5., 0., 15., 10.], [20., 0., 30., 10.]])
+    # identical: 0; half overlap: IoU 1/3, enclosing 150, union 150 -> 1 - 1/3; disjoint: IoU 0, enclose 300, union 200
+    assert torch.allclose(BL.giou_loss(a, b), torch.tensor([0., 2. / 3., 1. + 100. / 300.]), atol=1e-6)
+    K = 2
+    pos, neg = [a[:2]], [torch.tensor([[50., 50., 60., 60.]])]
+    labels, lw, bt, bw = BL.bbox_targets(pos, neg, [b[:2]], [torch.tensor([0, 1])], K, reg_decoded_bbox=True)
+    assert torch.equal(bt[:2], b[:2])
+    rois = torch.cat((a[:2], neg[0]))
+    reg = torch.zeros(3, 4 * K)                                               # zero deltas decode to the rois
+    out = BL.bbox_head_loss(None, reg, labels, lw, bt, bw, K, rois=rois, loss_bbox_type="GIoULoss", loss_bbox_weight=10.0)
+    assert torch.allclose(out["loss_bbox"], torch.tensor(10.0 * (0.0 + 2.0 / 3.0) / 3), atol=1e-5)

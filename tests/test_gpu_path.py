@@ -445,3 +445,60 @@ def test_seed_pseudo_gt_with_the_mil_head_selecting_the_depth(golden, monkeypatc
     assert idx.shape == (G,) and int(idx.min()) >= 0 and int(idx.max()) < Lc
     assert "mil_loss" in out["mil_losses"] and float(out["mil_losses"]["mil_loss"]) > 0
     assert out["pseudo_gt_bboxes"][0].shape == (G, 4) and len(out["pseudo_gt_masks"][0]) == G
+
+
+def test_train_losses_pseudo_labels_into_the_box_and_mask_branches(golden, monkeypatch):
+    """two_stage_point_align.py:75-150 with precomputed proposals: seed_pseudo_gt's boxes / labels / mask points feed
+    forward_train (IoU assignment, sampling, the MAE box and mask heads on the HIP small-N attention); every loss is
+    finite, differentiable down to the RoI feature map, and the pseudo boxes themselves are sampled as positives."""
+    import attentionshift_amd as A
+    g = golden("shift_tiny224")
+    inp = shift_case_inputs(g)
+    hp, wp, G, Lc, C = int(g["hp"]), int(g["wp"]), int(g["G"]), int(g["Lc"]), int(g["C"])
+    T, N = 10, 1 + hp * wp + 10
+    torch.manual_seed(3)
+    dec = dict(in_channels=C, embed_dim=64, depth=1, num_heads=2, num_classes=20)
+    head = A.build_head(dict(
+        type="AttnShiftRoIHead", num_semantic_points=int(g["num_semantic_points"]), mean_shift_times_local=int(g["n_shift"]),
+        rng_mode="fast",
+        bbox_roi_extractor=dict(type="SingleRoIExtractor", featmap_strides=[16],
+                                roi_layer=dict(type="RoIAlign", output_size=7, sampling_ratio=0)),
+        mil_head=dict(type="MAEBoxHeadMIL", in_channels=C, embed_dim=64, num_classes=20, num_layers_query=Lc, hidden_dim=128),
+        bbox_head=dict(type="MAEBoxHeadRec", seed_thr=float(g["cam_thr"]), seed_multiple=float(g["area_ratio"]),
+                       cam_layer=Lc, with_reconstruct=False, reg_decoded_bbox=True,
+                       loss_bbox=dict(type="GIoULoss", loss_weight=10.0), **dec),
+        mask_head=dict(type="MAEMaskHeadPointSup", scale_factor=2, scale_mode="bicubic", **dec),
+        train_cfg=dict(assigner=dict(type="MaxIoUAssigner", pos_iou_thr=0.5, neg_iou_thr=0.5, min_pos_iou=0.5),
+                       sampler=dict(type="RandomSampler", num=32, pos_fraction=0.25, add_gt_as_proposals=True),
+                       point_assigner=dict(type="HungarianPointAssigner", cls_cost=dict(weight=1.0),
+                                           reg_cost=dict(weight=10.0))))).cuda()
+    rows = torch.zeros(1, Lc, T, N)
+    rows[0, :, :G, 1:-T] = inp["cams"].flatten(2)
+    monkeypatch.setattr(head, "rollout_cams", lambda attns, n: rows.cuda())
+    gen = torch.Generator().manual_seed(11)
+    xy = torch.rand(40, 2, generator=gen) * (wp * 16 - 60)
+    props = [torch.cat((xy, xy + 20 + torch.rand(40, 2, generator=gen) * 40), 1).cuda()]
+    with torch.enable_grad():
+        feat = inp["vit_feat"][None].cuda().requires_grad_(True)
+        losses, seed = head.train_losses(
+            feat, [dict(img_shape=(hp * 16, wp * 16, 3))], props, feat.detach(), None,
+            torch.randn(1, T, 20, generator=gen).cuda().requires_grad_(True),
+            torch.rand(1, T, 2, generator=gen).cuda().requires_grad_(True),
+            [inp["points"].cuda()], [inp["labels"].cuda()], generator=torch.Generator().manual_seed(4),
+            pos_mask_thr=float(g["pos_thr"]), neg_mask_thr=float(g["neg_thr"]), num_mask_point_gt=int(g["num_gt"]),
+            corr_size=int(g["corr_size"]), obj_tau=float(g["obj_tau"]),
+            pos_inds=[torch.arange(G).cuda()], matched_gt=[torch.arange(G).cuda()])
+        want = {"mil_loss", "loss_point_cls", "loss_point", "pos_point_acc", "loss_cls", "acc", "loss_bbox", "loss_mask"}
+        assert set(losses) == want, set(losses)
+        total = sum(v for k, v in losses.items() if "loss" in k)
+        assert bool(torch.isfinite(total))
+        total.backward()
+    assert float(feat.grad.abs().sum()) > 0
+    for name in ("bbox_head.fc_cls.weight", "bbox_head.decoder_blocks.0.attn.qkv.weight", "mask_head.conv_logits.weight",
+                 "mask_head.decoder_blocks.0.attn.qkv.weight"):
+        assert float(dict(head.named_parameters())[name].grad.abs().sum()) > 0, name
+    res = head.last_sampling_results[0]
+    from attentionshift_amd.assign import bbox_overlaps
+    iou = bbox_overlaps(res.pos_bboxes, seed["pseudo_gt_bboxes"][0])
+    assert res.pos_inds.numel() >= min(G, 8) and bool((iou[torch.arange(iou.shape[0]), res.pos_assigned_gt_inds] >= 0.5).all())
+    assert res.pos_inds.numel() + res.neg_inds.numel() <= 32
