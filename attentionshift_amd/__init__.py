@@ -12,5 +12,6 @@ from .roi_head import AttnShiftRoIHead  # noqa: F401
 from .checkpoint import load_checkpoint, save_checkpoint  # noqa: F401
 from .mil_head import MAEBoxHeadMIL  # noqa: F401  (registers into HEADS)
 from .mae_heads import MAEBoxHeadRec, MAEMaskHeadPointSup  # noqa: F401
+from .annotations import PointAnnotations, parse_ann_info  # noqa: F401
 
 __version__ = "0.1.0"
