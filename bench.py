@@ -130,6 +130,16 @@ def sdpa_traffic():
         return None
 
 
+def shift_traffic():
+    """HBM bytes per as_cosine_shift call (all 16 launches) from the PMC passes kept under profiles/ (same shape as the
+    bench: 2 images x 3 objects, S=5); None if the summary is absent."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_shift_traffic.json")) as f:
+            return float(json.load(f)["per_call_bytes"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline():
     """The CPU oracle (a port of the reference's PyTorch path) on this box's host cores, bounded sample:
     ONE image; 2 of the 12 ViT-B blocks at N=4197 incl. the dense head-mean attention the reference keeps
@@ -294,7 +304,8 @@ def main():
                          "flops_per_launch": flops_sdpa},
             "roofline_affinity": {"kernel": "as_cosine_shift (similarity / assign / aggregate x S + final similarity)", "bound": "hbm",
                                   "achieved": round(gbps, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
-                                  "frac": round(gbps / PEAK_HBM_GBPS, 4), "traffic": None, "calls_timed": n_cs, "images_per_call": imgs_per_call,
+                                  "frac": round(gbps / PEAK_HBM_GBPS, 4), "traffic": shift_traffic() if imgs_per_call == 2 else None,
+                                  "calls_timed": n_cs, "images_per_call": imgs_per_call,
                                   "ms_per_call": round(ms_cs, 4), "algorithmic_bytes_per_call": bytes_cs},
         }
         if train_rec is not None:
