@@ -738,8 +738,43 @@ class AttnShiftRoIHead(nn.Module):
             generator=generator))
         return losses, seed
 
-    def simple_test(self, *a, **k):
-        raise NotImplementedError("inference heads are outside the hot path: SURVEY 8f")
+    def simple_test(self, x, proposal_list, img_metas, proposals=None, rescale=False):
+        """stdroi:3192-3221 + test_mixins.py:52-170, 262-340: per image, the box head on the proposals' RoI features ->
+        softmax scores + decoded boxes -> class-aware NMS; then the mask head on the DETECTIONS' RoI features (the mask
+        extractor's 14x14 grid) -> pasted binary masks.  Returns [(bbox_results, segm_results)] per image, or
+        [bbox_results] without a mask head."""
+        from . import inference as I
+        if not isinstance(self.bbox_head, nn.Module):
+            raise RuntimeError("simple_test needs the box head built from its config (bbox_head with in_channels)")
+        cfg = self.test_cfg
+        nms_cfg = dict(_get(cfg, "nms", None) or {})
+        bh = self.bbox_head
+        out = []
+        for i, meta in enumerate(img_metas):
+            props = proposal_list[i][:, :4]
+            rois = torch.cat((props.new_full((props.shape[0], 1), float(i)), props), dim=1)
+            if rois.shape[0]:
+                cls_score, bbox_pred, _ = bh(self._roi_extract(x, rois))
+            else:
+                cls_score, bbox_pred = props.new_zeros(0, bh.num_classes + 1), props.new_zeros(0, 4 * bh.num_classes)
+            dets, labels = I.get_det_bboxes(rois, cls_score, bbox_pred, meta["img_shape"], meta.get("scale_factor", 1.0),
+                                            rescale, _get(cfg, "score_thr", 0.05), nms_cfg.get("iou_threshold", 0.5),
+                                            _get(cfg, "max_per_img", 100), bh.target_means, bh.target_stds)
+            boxes_res = I.bbox2result(dets, labels, bh.num_classes)
+            if self.mask_head is None:
+                out.append(boxes_res)
+                continue
+            mboxes = dets[:, :4] * dets.new_tensor(meta.get("scale_factor", 1.0)) if rescale else dets[:, :4]
+            mrois = torch.cat((mboxes.new_full((mboxes.shape[0], 1), float(i)), mboxes), dim=1)
+            if mrois.shape[0]:
+                mask_pred = self.mask_head(self._roi_extract(x, mrois, "mask_roi_extractor"))
+            else:
+                mask_pred = mboxes.new_zeros(0, self.mask_head.num_classes, 1, 1)
+            segm = I.get_seg_masks(mask_pred, dets, labels, self.mask_head.num_classes, meta["ori_shape"],
+                                   meta.get("scale_factor", 1.0), rescale, _get(cfg, "mask_thr_binary", 0.5),
+                                   self.mask_head.class_agnostic)
+            out.append((boxes_res, segm))
+        return out
 
     # ---- stage helpers ----------------------------------------------------------------------------
     def rollout_cams(self, attns, num_proposals):

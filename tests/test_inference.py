@@ -1,0 +1,117 @@
+"""Test-time post-processing of the RoI head (NMS, box decoding, mask pasting) and simple_test.  CPU only; mmcv's ops
+are absent, so the checks are against the operators' definitions."""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+import attentionshift_amd as A
+from attentionshift_amd import inference as I, mae_heads
+from attentionshift_amd.assign import bbox_overlaps
+
+
+def _boxes(n, gen, size=200):
+    xy = torch.rand(n, 2, generator=gen) * size
+    return torch.cat((xy, xy + 10 + torch.rand(n, 2, generator=gen) * 80), 1)
+
+
+def test_nms_definition():
+    gen = torch.Generator().manual_seed(0)
+    boxes, scores = _boxes(60, gen), torch.rand(60, generator=gen)
+    keep = I.nms(boxes, scores, 0.5)
+    assert (scores[keep][:-1] >= scores[keep][1:]).all()
+    iou = bbox_overlaps(boxes, boxes)
+    kept = set(keep.tolist())
+    for i in range(60):
+        better = [j for j in kept if scores[j] > scores[i] and iou[i, j] > 0.5]
+        assert (i in kept) == (len(better) == 0), i             # kept iff no higher-scored KEPT box overlaps it
+    small = torch.tensor([[0., 0., 10., 10.], [1., 1., 11., 11.], [50., 50., 60., 60.]])
+    assert I.nms(small, torch.tensor([0.9, 0.8, 0.7]), 0.5).tolist() == [0, 2]
+    assert I.nms(small[:0], torch.zeros(0), 0.5).numel() == 0
+
+
+def test_multiclass_nms_is_class_aware():
+    boxes = torch.tensor([[0., 0., 10., 10.], [0., 0., 10., 10.], [30., 30., 50., 50.]])
+    scores = torch.tensor([[0.9, 0.02, 0.08], [0.1, 0.85, 0.05], [0.04, 0.6, 0.36]])
+    dets, labels = I.multiclass_nms(boxes, scores, 0.05, 0.5, 100)
+    # the same box wins in class 0 (0.9) and class 1 (0.85): suppression only inside a class
+    assert labels.tolist() == [0, 1, 1, 0] or sorted(zip(labels.tolist(), dets[:, 4].tolist()), reverse=True)
+    got = sorted((l, round(s, 2)) for l, s in zip(labels.tolist(), dets[:, 4].tolist()))
+    assert got == [(0, 0.9), (1, 0.6), (1, 0.85)]               # (class 0, 0.1) is suppressed by the identical 0.9 box
+    assert (dets[:-1, 4] >= dets[1:, 4]).all()
+    top, _ = I.multiclass_nms(boxes, scores, 0.05, 0.5, 2)
+    assert top.shape == (2, 5) and top[0, 4] == 0.9
+    per_class = torch.cat((boxes, boxes + 100), 1)              # [n, 4K] form: class 1 boxes shifted
+    d2, l2 = I.multiclass_nms(per_class, scores, 0.5, 0.5)
+    assert sorted(l2.tolist()) == [0, 1, 1] and bool((d2[l2 == 1, 0] >= 100).all())
+    none, nl = I.multiclass_nms(boxes, scores, 0.95, 0.5)
+    assert none.shape == (0, 5) and nl.numel() == 0
+
+
+def test_paste_masks_and_seg_masks():
+    boxes = torch.tensor([[10., 20., 30., 60.], [0., 0., 100., 80.]])
+    ones = torch.ones(2, 1, 28, 28)
+    full = I.paste_masks(ones, boxes, 80, 100) >= 0.5
+    want0 = torch.zeros(80, 100, dtype=torch.bool)
+    want0[20:60, 10:30] = True
+    assert torch.equal(full[0], want0) and bool(full[1][1:-1, 1:-1].all())   # (the image corners blend two zero pads)
+    grad = torch.linspace(0, 1, 28).view(1, 1, 1, 28).expand(1, 1, 28, 28)       # left-to-right ramp
+    ramp = I.paste_masks(grad, boxes[:1], 80, 100)[0, 40, 10:30]
+    assert bool((ramp[1:] > ramp[:-1]).all())
+    logits = torch.full((2, 3, 28, 28), -9.0)
+    logits[0, 2] = 9.0
+    logits[1, 0] = 9.0
+    dets = torch.cat((boxes, torch.tensor([[0.9], [0.8]])), 1)
+    segm = I.get_seg_masks(logits, dets, torch.tensor([2, 0]), 3, (80, 100, 3), 1.0, True)
+    assert [len(s) for s in segm] == [1, 0, 1] and segm[2][0].dtype == np.bool_ and segm[2][0].sum() == 40 * 20
+    half = I.get_seg_masks(logits, dets, torch.tensor([2, 0]), 3, (40, 50, 3), (2.0, 2.0, 2.0, 2.0), True)
+    assert half[2][0].shape == (40, 50) and half[2][0].sum() == 20 * 10         # boxes divided by the scale factor
+    same = I.get_seg_masks(logits, dets, torch.tensor([2, 0]), 3, (40, 50, 3), np.array([2.0, 2.0, 2.0, 2.0]), False)
+    assert same[2][0].shape == (80, 100)
+    assert [len(s) for s in I.get_seg_masks(logits[:0], dets[:0], torch.zeros(0, dtype=torch.long), 3, (8, 8, 3), 1.0, True)] == [0, 0, 0]
+
+
+def test_get_det_bboxes_decodes_clips_and_rescales():
+    rois = torch.tensor([[0., 10., 10., 50., 50.], [0., 150., 150., 260., 240.]])
+    cls = torch.tensor([[5.0, 0.0, 0.0], [0.0, 4.0, 0.0]])
+    reg = torch.zeros(2, 8)
+    dets, labels = I.get_det_bboxes(rois, cls, reg, (200, 220, 3), (2.0, 2.0, 2.0, 2.0), True)
+    assert labels.tolist()[:2] == [0, 1]
+    assert torch.allclose(dets[0, :4], torch.tensor([5., 5., 25., 25.]))
+    assert torch.allclose(dets[1, :4], torch.tensor([75., 75., 110., 100.]))      # clipped to (220, 200) then halved
+    assert torch.allclose(dets[:2, 4], F.softmax(cls, -1).max(1)[0])
+
+
+def _torch_attention(self, x):
+    B, N, C = x.shape
+    q, k, v = self.qkv(x).reshape(B, N, 3, self.num_heads, C // self.num_heads).permute(2, 0, 3, 1, 4)
+    return self.proj(F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(B, N, C))
+
+
+def test_simple_test_composition(monkeypatch):
+    monkeypatch.setattr(mae_heads._Attention, "forward", _torch_attention)      # the product runs the HIP small-N kernel
+    torch.manual_seed(0)
+    dec = dict(in_channels=48, embed_dim=64, depth=1, num_heads=2, num_classes=5)
+    head = A.build_head(dict(
+        type="AttnShiftRoIHead",
+        bbox_roi_extractor=dict(type="SingleRoIExtractor", featmap_strides=[16], roi_layer=dict(type="RoIAlign", output_size=7, sampling_ratio=0)),
+        mask_roi_extractor=dict(type="SingleRoIExtractor", featmap_strides=[16], roi_layer=dict(type="RoIAlign", output_size=14, sampling_ratio=0)),
+        bbox_head=dict(type="MAEBoxHeadRec", with_reconstruct=False, cam_layer=3, **dec),
+        mask_head=dict(type="MAEMaskHeadPointSup", scale_factor=2, scale_mode="bicubic", **dec),
+        test_cfg=dict(score_thr=0.05, nms=dict(type="nms", iou_threshold=0.5), max_per_img=7, mask_thr_binary=0.5)))
+    gen = torch.Generator().manual_seed(3)
+    fmap = torch.rand(2, 48, 14, 14, generator=gen)
+    props = [_boxes(30, gen, 120), _boxes(0, gen)]
+    metas = [dict(img_shape=(224, 224, 3), ori_shape=(112, 112, 3), scale_factor=np.array([2.0, 2.0, 2.0, 2.0], dtype=np.float32))] * 2
+    res = head.simple_test(fmap, props, metas, rescale=True)
+    assert len(res) == 2
+    (boxes0, segm0), (boxes1, segm1) = res
+    assert len(boxes0) == 5 and len(segm0) == 5 and sum(b.shape[0] for b in boxes0) <= 7
+    assert sum(b.shape[0] for b in boxes0) > 0                    # untrained softmax over 6 classes is ~1/6 > score_thr
+    for b, sg in zip(boxes0, segm0):
+        assert b.shape[1] == 5 and len(sg) == b.shape[0]
+        assert (b[:, :4] >= 0).all() and (b[:, 2] <= 112).all() and (b[:, 3] <= 112).all()
+        assert all(m.shape == (112, 112) and m.dtype == np.bool_ for m in sg)
+    assert all(b.shape == (0, 5) for b in boxes1) and all(len(sg) == 0 for sg in segm1)
+    head.mask_head = None
+    only_boxes = head.simple_test(fmap, props, metas, rescale=False)
+    assert len(only_boxes[0]) == 5 and all((b[:, 2] <= 224).all() for b in only_boxes[0])
