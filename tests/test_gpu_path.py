@@ -502,3 +502,41 @@ def test_train_losses_pseudo_labels_into_the_box_and_mask_branches(golden, monke
     iou = bbox_overlaps(res.pos_bboxes, seed["pseudo_gt_bboxes"][0])
     assert res.pos_inds.numel() >= min(G, 8) and bool((iou[torch.arange(iou.shape[0]), res.pos_assigned_gt_inds] >= 0.5).all())
     assert res.pos_inds.numel() + res.neg_inds.numel() <= 32
+
+
+def test_simple_test_on_the_hip_small_attention(monkeypatch):
+    """Test-time path of the RoI head on the GPU: the box / mask decoders run on as_small_attn_fwd; the best detection
+    agrees with the same weights through torch's SDPA."""
+    import numpy as np
+    import torch.nn.functional as F
+    import attentionshift_amd as A
+    from attentionshift_amd import mae_heads
+    torch.manual_seed(0)
+    dec = dict(in_channels=48, embed_dim=64, depth=1, num_heads=2, num_classes=5)
+    head = A.build_head(dict(
+        type="AttnShiftRoIHead",
+        bbox_roi_extractor=dict(type="SingleRoIExtractor", featmap_strides=[16], roi_layer=dict(type="RoIAlign", output_size=7, sampling_ratio=0)),
+        mask_roi_extractor=dict(type="SingleRoIExtractor", featmap_strides=[16], roi_layer=dict(type="RoIAlign", output_size=14, sampling_ratio=0)),
+        bbox_head=dict(type="MAEBoxHeadRec", with_reconstruct=False, cam_layer=3, **dec),
+        mask_head=dict(type="MAEMaskHeadPointSup", scale_factor=2, scale_mode="bicubic", **dec),
+        test_cfg=dict(score_thr=0.05, nms=dict(type="nms", iou_threshold=0.5), max_per_img=10, mask_thr_binary=0.5))).cuda()
+    gen = torch.Generator().manual_seed(3)
+    fmap = torch.rand(1, 48, 14, 14, generator=gen).cuda()
+    xy = torch.rand(40, 2, generator=gen) * 120
+    props = [torch.cat((xy, xy + 10 + torch.rand(40, 2, generator=gen) * 80), 1).cuda()]
+    metas = [dict(img_shape=(224, 224, 3), ori_shape=(224, 224, 3), scale_factor=np.ones(4, dtype=np.float32))]
+    with torch.no_grad():
+        (boxes, segm), = head.simple_test(fmap, props, metas, rescale=False)
+
+        def ref_attn(self, x):
+            B, N, C = x.shape
+            q, k, v = self.qkv(x).reshape(B, N, 3, self.num_heads, C // self.num_heads).permute(2, 0, 3, 1, 4)
+            return self.proj(F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(B, N, C))
+        monkeypatch.setattr(mae_heads._Attention, "forward", ref_attn)
+        (boxes_ref, _), = head.simple_test(fmap, props, metas, rescale=False)
+    n = sum(b.shape[0] for b in boxes)
+    assert 0 < n <= 10 and all(len(s) == b.shape[0] for s, b in zip(segm, boxes))
+    assert all(m.shape == (224, 224) for s in segm for m in s)
+    best = max((b[:, 4].max(), c) for c, b in enumerate(boxes) if b.shape[0])
+    best_ref = max((b[:, 4].max(), c) for c, b in enumerate(boxes_ref) if b.shape[0])
+    assert best[1] == best_ref[1] and abs(best[0] - best_ref[0]) < 2e-3
