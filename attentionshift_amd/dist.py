@@ -118,3 +118,83 @@ class GradAllReducer:
     def close(self):
         for h in getattr(self, "_hooks", []):
             h.remove()
+
+
+class _SyncBNFn(torch.autograd.Function):
+    """Batch norm over the GLOBAL batch: one all-reduce of [sum, sum of squares, count] (2C+1 floats) forward, one of
+    [sum dy, sum dy*xhat] backward -- the exchange torch.nn.SyncBatchNorm does, written on plain all_reduce so that it
+    also runs on gloo (CPU tests) and needs no GPU-only kernel."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps, ranks):
+        C = x.shape[1]
+        dims = [0] + list(range(2, x.dim()))
+        xf = x.float()
+        stat = torch.cat((xf.sum(dims), (xf * xf).sum(dims), xf.new_tensor([xf.numel() / C])))
+        ranks.dist.all_reduce(stat, op=ranks.dist.ReduceOp.SUM)
+        n = stat[-1]
+        mean = stat[:C] / n
+        var = (stat[C:2 * C] / n - mean * mean).clamp_min(0)                    # biased, as batch norm normalises with
+        invstd = torch.rsqrt(var + eps)
+        shape = [1, C] + [1] * (x.dim() - 2)
+        xhat = (xf - mean.view(shape)) * invstd.view(shape)
+        ctx.save_for_backward(xhat, weight, invstd)
+        ctx.ranks, ctx.n, ctx.dims, ctx.shape = ranks, n, dims, shape
+        ctx.mark_non_differentiable(mean, var, n)
+        y = xhat * weight.float().view(shape) + bias.float().view(shape)
+        return y.to(x.dtype), mean, var, n
+
+    @staticmethod
+    def backward(ctx, dy, _dm, _dv, _dn):
+        xhat, weight, invstd = ctx.saved_tensors
+        dyf = dy.float()
+        C = xhat.shape[1]
+        s_dy, s_dyx = dyf.sum(ctx.dims), (dyf * xhat).sum(ctx.dims)
+        both = torch.cat((s_dy, s_dyx))
+        ctx.ranks.dist.all_reduce(both, op=ctx.ranks.dist.ReduceOp.SUM)
+        m_dy, m_dyx = (both[:C] / ctx.n).view(ctx.shape), (both[C:] / ctx.n).view(ctx.shape)
+        dx = (weight.float() * invstd).view(ctx.shape) * (dyf - m_dy - xhat * m_dyx)
+        # weight / bias gradients stay LOCAL sums: the data-parallel gradient average reduces them like every parameter
+        return dx.to(dy.dtype), s_dyx.to(weight.dtype), s_dy.to(weight.dtype), None, None
+
+
+class SyncBatchNorm2d(torch.nn.BatchNorm2d):
+    """nn.BatchNorm2d whose training statistics span all ranks (the reference converts every BatchNorm of the detector
+    with torch.nn.SyncBatchNorm.convert_sync_batchnorm before wrapping it in DDP, mmdet/apis/train.py:95; on this path
+    that is the one BatchNorm of the FPN's stride-4 branch, visual_transformer_det.py:109).  Same parameters, buffers and
+    state-dict keys as nn.BatchNorm2d; with one rank, or in eval mode, it IS nn.BatchNorm2d."""
+
+    def __init__(self, num_features, ranks=None, **kw):
+        super().__init__(num_features, **kw)
+        self.ranks = ranks
+
+    def forward(self, x):
+        r = self.ranks
+        if not self.training or r is None or r.dist is None or r.world == 1:
+            return super().forward(x)
+        y, mean, var, n = _SyncBNFn.apply(x, self.weight, self.bias, self.eps, r)
+        if self.track_running_stats:
+            with torch.no_grad():
+                self.num_batches_tracked += 1
+                mom = self.momentum if self.momentum is not None else 1.0 / float(self.num_batches_tracked)
+                self.running_mean.mul_(1 - mom).add_(mean.to(self.running_mean.dtype), alpha=mom)
+                self.running_var.mul_(1 - mom).add_((var * (n / (n - 1).clamp_min(1))).to(self.running_var.dtype), alpha=mom)
+        return y
+
+
+def convert_sync_batchnorm(module, ranks):
+    """Replace every nn.BatchNorm2d under `module` by SyncBatchNorm2d sharing its parameters and buffers."""
+    for name, child in list(module.named_children()):
+        if isinstance(child, torch.nn.BatchNorm2d) and not isinstance(child, SyncBatchNorm2d):
+            new = SyncBatchNorm2d(child.num_features, ranks, eps=child.eps, momentum=child.momentum, affine=child.affine,
+                                  track_running_stats=child.track_running_stats)
+            if child.affine:
+                new.weight, new.bias = child.weight, child.bias
+            if child.track_running_stats:
+                new.running_mean, new.running_var, new.num_batches_tracked = \
+                    child.running_mean, child.running_var, child.num_batches_tracked
+            new.train(child.training)
+            setattr(module, name, new)
+        else:
+            convert_sync_batchnorm(child, ranks)
+    return module

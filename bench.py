@@ -97,7 +97,9 @@ def build(device, rng_mode="fast", train=False, ranks=None):
     # no-grad attention shift on its outputs, backward (HIP attention bwd), bucketed RCCL gradient all-reduce
     # overlapped with backward, AdamW.  The detection losses belong to heads outside this path, so the scalar that is
     # differentiated is a fixed surrogate over every backbone output those heads consume.
-    from attentionshift_amd.dist import GradAllReducer
+    from attentionshift_amd.dist import GradAllReducer, convert_sync_batchnorm
+    if ranks is not None and ranks.world > 1:
+        convert_sync_batchnorm(bb, ranks)              # as mmdet/apis/train.py:95 does before wrapping the model in DDP
     params = [p for p in bb.parameters() if p.requires_grad]
     opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=0.05, fused=True)
     reducer = GradAllReducer(params, ranks)

@@ -120,3 +120,74 @@ def test_two_rank_gloo_bucketed_gradient_allreduce():
             for got in (a["avg"][i], b["avg"][i]):
                 assert max(abs(g - w) for g, w in zip(got, want)) < 1e-5
         assert a["unused"] == [0.0] * 5 and b["unused"] == [0.0] * 5
+
+
+SYNCBN_WORKER = textwrap.dedent("""
+    import os, sys, json
+    sys.path.insert(0, %r)
+    import torch
+    from attentionshift_amd.dist import Ranks, convert_sync_batchnorm, SyncBatchNorm2d
+    r = Ranks(backend="gloo")
+    gen = torch.Generator().manual_seed(5)
+    x_all = torch.randn(6, 4, 5, 3, generator=gen) * 2 + 1            # global batch: rank 0 takes 4 images, rank 1 two
+    w_out = torch.randn(6, 4, 5, 3, generator=gen)
+    torch.manual_seed(0)
+    ref = torch.nn.Sequential(torch.nn.Conv2d(4, 4, 1), torch.nn.BatchNorm2d(4))
+    with torch.no_grad():
+        ref[1].weight.copy_(torch.tensor([1.5, 0.5, -1.0, 2.0])); ref[1].bias.copy_(torch.tensor([0.1, -0.2, 0.3, 0.0]))
+    import copy
+    net = convert_sync_batchnorm(copy.deepcopy(ref), r)
+    assert isinstance(net[1], SyncBatchNorm2d) and list(net.state_dict()) == list(ref.state_dict())
+    lo, hi = (0, 4) if r.rank == 0 else (4, 6)
+    x = x_all[lo:hi].clone().requires_grad_(True)
+    y = net(x)
+    (y * w_out[lo:hi]).sum().backward()
+    xr = x_all.clone().requires_grad_(True)                             # the single-process reference on the whole batch
+    yr = ref(xr)
+    (yr * w_out).sum().backward()
+    gw = net[1].weight.grad.clone(); gb = net[1].bias.grad.clone(); gc = net[0].weight.grad.clone()
+    for g in (gw, gb, gc):
+        r.dist.all_reduce(g)                                            # what the gradient all-reduce would sum
+    ok = dict(
+        y=bool(torch.allclose(y, yr[lo:hi], atol=1e-5)), dx=bool(torch.allclose(x.grad, xr.grad[lo:hi], atol=1e-5)),
+        gw=bool(torch.allclose(gw, ref[1].weight.grad, atol=1e-4)), gb=bool(torch.allclose(gb, ref[1].bias.grad, atol=1e-4)),
+        gc=bool(torch.allclose(gc, ref[0].weight.grad, atol=1e-4)),
+        rm=bool(torch.allclose(net[1].running_mean, ref[1].running_mean, atol=1e-6)),
+        rv=bool(torch.allclose(net[1].running_var, ref[1].running_var, atol=1e-5)),
+        nb=int(net[1].num_batches_tracked) == 1)
+    net.eval()
+    ok["eval"] = bool(torch.allclose(net(x_all[lo:hi]), ref.eval()(x_all[lo:hi]), atol=1e-5))
+    print(json.dumps(dict(rank=r.rank, **ok)), flush=True)
+    r.close()
+""") % ROOT
+
+
+def test_sync_batchnorm_matches_single_process_batchnorm_on_the_global_batch():
+    import json
+    port = free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, "-c", SYNCBN_WORKER], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    for p in procs:
+        o, e = p.communicate(timeout=180)
+        assert p.returncode == 0, e[-3000:]
+        rec = json.loads(o.strip().splitlines()[-1])
+        assert all(v is True for k, v in rec.items() if k != "rank"), rec
+
+
+def test_sync_batchnorm_single_rank_is_plain_batchnorm():
+    import torch
+    from attentionshift_amd.dist import Ranks, SyncBatchNorm2d
+    env = {k: os.environ.pop(k, None) for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    try:
+        torch.manual_seed(0)
+        a, b = torch.nn.BatchNorm2d(3), SyncBatchNorm2d(3, Ranks())
+        x = torch.randn(4, 3, 5, 5)
+        assert torch.equal(a(x), b(x)) and torch.equal(a.running_var, b.running_var)
+    finally:
+        for k, v in env.items():
+            if v is not None:
+                os.environ[k] = v
