@@ -12,12 +12,15 @@ Stage map -> where it runs:
   B1  upsample + CAM boxes via connected components  ops.cam_boxes      (csrc/ccl.hip)
   B2  cosine-affinity refinement, instance maps      ops.refine_similarity / ops.instance_maps
   B4  mean-shift token clustering                    ops.cosine_shift   (csrc/cosine_shift.hip)
-  B2', B3, B5, B6 (point sampling, erosion, part filtering/merging, masks): small data-dependent
-      host logic kept in torch ops on the device, drawing random numbers from torch's global CPU
-      generator in exactly the reference's order (so equal seeds give equal samples).
-The trainable MIL / bbox / mask sub-heads are out of this path's scope: their configs are
-accepted and kept, and the one value the path needs from the MIL head -- which roll-out depth to use per
-object -- comes from `layer_selector` (a callable; default: the depth whose CAM box has the median area).
+  B2', B3, B5, B6 (point sampling, erosion, part filtering/merging, masks): fused HIP kernels for the data-parallel
+      parts (ops.mask_candidates / semantic_prestage / filter_parts / part_stats / merge_plan / rank_select) around
+      small data-dependent host logic; rng_mode "reference" draws from torch's global CPU generator in exactly the
+      reference's order (equal seeds give equal samples), "fast" draws on the device with one readback per image.
+The consumers of the pseudo labels sit on the same class: the MIL / box / mask sub-heads are built when
+their configs carry construction arguments (mil_head.py, mae_heads.py), `forward_train` (stdroi:2513-2727) and
+`simple_test` (:3192-3221) compose them; with attribute-only configs the one value the pseudo-label path needs from
+the MIL head -- which roll-out depth to use per object -- comes from `layer_selector` (a callable; default: the depth
+whose CAM box has the median area).
 """
 import types
 

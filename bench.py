@@ -95,8 +95,8 @@ def build(device, rng_mode="fast", train=False, ranks=None):
 
     # DDP training step (BASELINE configs[2] shape per GPU): backbone forward under autograd (HIP attention fwd), the
     # no-grad attention shift on its outputs, backward (HIP attention bwd), bucketed RCCL gradient all-reduce
-    # overlapped with backward, AdamW.  The detection losses belong to heads outside this path, so the scalar that is
-    # differentiated is a fixed surrogate over every backbone output those heads consume.
+    # overlapped with backward, AdamW.  The detection losses need proposals from the RPN, which is not part of this build,
+    # so the scalar that is differentiated is a fixed surrogate over every backbone output the heads consume.
     from attentionshift_amd.dist import GradAllReducer, convert_sync_batchnorm
     if ranks is not None and ranks.world > 1:
         convert_sync_batchnorm(bb, ranks)              # as mmdet/apis/train.py:95 does before wrapping the model in DDP
