@@ -208,3 +208,16 @@ def test_semantic_center_host_logic_with_oracle_backed_shift(golden, tag, monkey
     for i, n in enumerate(g["n_sim_parts"].tolist()):
         if n:
             assert_close(t(g[f"sim_parts{i}"]), sim_parts[i], 1e-4, 1e-5, f"sim_parts{i}")
+
+
+def test_hungarian_matching_equals_the_reference_assigner(golden):
+    """Fixture = the reference's HungarianPointAssigner.assign with FocalLossCost + PointL1Cost(10) executed on seeded
+    cases (tools/gen_golden_hungarian.py): more tokens than points, more points than tokens, one point, no point."""
+    g = golden("hungarian")
+    for i in range(int(g["n"])):
+        tt = lambda k: torch.from_numpy(g[f"{k}{i}"])
+        pos, gt = RH.hungarian_point_match(tt("pred"), tt("cls"), tt("pts"), tt("labels"), tuple(int(v) for v in g[f"shape{i}"]),
+                                           cls_weight=1.0, reg_weight=10.0)
+        want = tt("gt_inds")                                          # 0 = unmatched, k + 1 = matched to point k
+        assert torch.equal(pos, torch.nonzero(want > 0).flatten()), i
+        assert torch.equal(gt, want[want > 0] - 1), i
