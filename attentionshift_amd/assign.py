@@ -1,7 +1,8 @@
 """Proposal -> pseudo-GT assignment and sampling for the R-CNN branches (host-side tensor logic; mmdet's
 MaxIoUAssigner and RandomSampler as configured at configs/mae/attnshift_voc12aug.py:160-175: pos / neg / min-pos IoU
 0.5, no low-quality matches, 512 samples per image, at most a quarter positive, GT boxes added to the proposals).
-mmdet's assigner / sampler sources are in the reference tree but need mmcv to import: restated from their definition."""
+bbox_overlaps and the assignment rule are pinned to the reference's own functions by tests/golden/mmdet_pure.npz (tools/
+gen_golden_mmdet_pure.py executes them); the sampler is restated from its definition."""
 from types import SimpleNamespace
 
 import torch
