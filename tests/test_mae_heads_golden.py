@@ -1,0 +1,60 @@
+"""MAE-decoder heads vs the REFERENCE's modules: tests/golden/mae_heads.npz holds the reference heads' state dicts, inputs
+and outputs (tools/gen_golden_mae_heads.py instantiates and runs them).  The same weights are loaded STRICTLY into this
+repo's heads -- identical state-dict keys -- and the outputs compared.  CPU: the decoder attention (the HIP small-N
+kernel in the product) is swapped for torch's SDPA; the GPU twin of this test runs the product path."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import attentionshift_amd as A
+from attentionshift_amd import mae_heads
+
+
+def _torch_attention(self, x):
+    B, N, C = x.shape
+    q, k, v = self.qkv(x).reshape(B, N, 3, self.num_heads, C // self.num_heads).permute(2, 0, 3, 1, 4)
+    return self.proj(F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(B, N, C))
+
+
+def build_and_load(g, tag, cfg, device="cpu"):
+    head = A.build_head(cfg)
+    keys = [str(k) for k in g[f"{tag}_keys"]]
+    sd = {k: torch.from_numpy(g[f"{tag}.{k}"]) for k in keys}
+    assert sorted(head.state_dict().keys()) == sorted(keys), (tag, set(head.state_dict()) ^ set(keys))
+    head.load_state_dict(sd, strict=True)
+    return head.to(device).eval()
+
+
+CFG = dict(in_channels=48, img_size=224, patch_size=16, embed_dim=64, depth=2, num_heads=2, num_classes=5)
+
+
+def check_heads(g, device, atol):
+    t = lambda k: torch.from_numpy(g[k]).to(device)
+    box = build_and_load(g, "box", dict(type="MAEBoxHeadRec", with_reconstruct=True, cam_layer=3, **CFG), device)
+    with torch.no_grad():
+        for tag in ("box7", "box59"):
+            cls, reg, rec = box(t(f"{tag}_x"))
+            for got, key in ((cls, "cls"), (reg, "reg"), (rec, "rec")):
+                want = t(f"{tag}_{key}")
+                assert got.shape == want.shape and float((got - want).abs().max()) <= atol * max(1.0, float(want.abs().max())), (tag, key)
+        mil = build_and_load(g, "mil", dict(type="MAEBoxHeadMIL", in_channels=48, embed_dim=64, num_classes=5,
+                                            num_layers_query=3, hidden_dim=32, roi_size=7), device)
+        labels = t("mil_labels")
+        idx, loss = mil(t("mil_x"), gt_labels=[labels[:3], labels[3:]])
+        assert torch.equal(idx.cpu(), torch.from_numpy(g["mil_idx"])) and abs(float(loss) - float(g["mil_loss"])) < 1e-4
+        mask = build_and_load(g, "mask", dict(type="MAEMaskHeadPointSup", roi_feat_size=14, scale_factor=2,
+                                              scale_mode="bicubic", **CFG), device)
+        for tag in ("mask14", "mask7"):
+            got, want = mask(t(f"{tag}_x")), t(f"{tag}_out")
+            assert got.shape == want.shape and float((got - want).abs().max()) <= atol * max(1.0, float(want.abs().max())), tag
+
+
+def test_heads_equal_the_reference_modules(golden, monkeypatch):
+    monkeypatch.setattr(mae_heads._Attention, "forward", _torch_attention)
+    check_heads(golden("mae_heads"), "cpu", 2e-4)
+
+
+@pytest.mark.gpu
+def test_heads_equal_the_reference_modules_on_the_hip_attention(golden):
+    check_heads(golden("mae_heads"), "cuda", 2e-3)
