@@ -47,3 +47,29 @@ def test_losses_match_their_definitions_and_backpropagate():
     assert torch.isfinite(cls.grad).all() and reg.grad.abs().sum() > 0
     none = PL.point_token_loss(cls.detach(), reg.detach(), [torch.zeros(0, 2)] * 2, [torch.zeros(0, dtype=torch.long)] * 2, shapes, K)
     assert float(none["loss_point"]) == 0.0 and torch.isfinite(none["loss_point_cls"])
+
+
+def test_point_token_loss_equals_the_reference_roi_head_loss(golden):
+    """Fixture = the reference RoI head's own get_targets + loss (stdroi:3284-3514) with its Hungarian assigner, FocalLoss
+    (python path) and L1Loss modules executed on two-image batches (tools/gen_golden_point_loss.py)."""
+    import numpy as np
+    from attentionshift_amd import point_loss as PL
+    g = golden("point_loss")
+    for c in range(int(g["n"])):
+        cls, reg = torch.from_numpy(g[f"cls{c}"]), torch.from_numpy(g[f"reg{c}"])
+        pts = [torch.from_numpy(g[f"pts{c}_{i}"]).reshape(-1, 2) for i in range(2)]
+        labels = [torch.from_numpy(g[f"labels{c}_{i}"]) for i in range(2)]
+        shapes = [tuple(int(v) for v in s) for s in g[f"shapes{c}"]]
+        tl, tw, _, _ = PL.point_targets(cls, reg, pts, labels, shapes, 20, point_pos_weight=1, cls_cost=1.0, reg_cost=10.0)
+        assert torch.equal(tl, torch.from_numpy(g[f"labels_all{c}"])) and torch.equal(tw, torch.from_numpy(g[f"label_w{c}"]))
+        out = PL.point_token_loss(cls, reg, pts, labels, shapes, num_classes=20, loss_point_weight=10.0, loss_cls_weight=1.0,
+                                  cls_cost=1.0, reg_cost=10.0)
+        want_cls = float(g[f"loss_point_cls{c}"][0])
+        if np.isfinite(want_cls):
+            assert abs(float(out["loss_point_cls"]) - want_cls) <= 1e-5 * abs(want_cls), c
+            assert abs(float(out["loss_point"]) - float(g[f"loss_point{c}"][0])) <= 1e-5, c
+            assert abs(float(out["pos_point_acc"]) - float(g[f"pos_point_acc{c}"][0])) <= 1e-4, c
+        else:
+            # a batch without any object: the reference divides by avg_factor = 0 (inf); this build clamps the divisor
+            # (such batches never reach the loss: the dataset filters images without annotations)
+            assert bool(torch.isfinite(out["loss_point_cls"])) and float(out["loss_point"]) == 0.0
