@@ -2,7 +2,8 @@
 MaxIoUAssigner and RandomSampler as configured at configs/mae/attnshift_voc12aug.py:160-175: pos / neg / min-pos IoU
 0.5, no low-quality matches, 512 samples per image, at most a quarter positive, GT boxes added to the proposals).
 bbox_overlaps and the assignment rule are pinned to the reference's own functions by tests/golden/mmdet_pure.npz (tools/
-gen_golden_mmdet_pure.py executes them); the sampler is restated from its definition."""
+gen_golden_mmdet_pure.py executes them); the sampler reproduces the reference's RandomSampler draw for draw under the same
+torch seed (tests/golden/sampler.npz, tools/gen_golden_sampler.py)."""
 from types import SimpleNamespace
 
 import torch

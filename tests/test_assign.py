@@ -22,3 +22,17 @@ def test_iou_assign_and_sample():
     assert torch.equal(res.pos_bboxes, boxes[res.pos_inds]) and torch.equal(res.pos_gt_bboxes, gts[res.pos_assigned_gt_inds])
     none = AS.random_sample(props, gts[:0], torch.zeros(0, dtype=torch.long), torch.zeros(5, dtype=torch.long), num=4)
     assert none.pos_inds.numel() == 0 and none.neg_inds.numel() == 4
+
+
+def test_assign_and_sample_equal_the_reference_sampler(golden):
+    """Fixture = the reference's MaxIoUAssigner.assign + RandomSampler.sample (add_gt_as_proposals) executed under
+    torch.manual_seed (tools/gen_golden_sampler.py): the same seed gives the same sampled index sets here."""
+    g = golden("sampler")
+    for c in range(int(g["n"])):
+        t = lambda k: torch.from_numpy(g[f"{k}{c}"])
+        props, gts, labels = t("props").reshape(-1, 4), t("gts").reshape(-1, 4), t("labels")
+        assigned, _ = AS.max_iou_assign(props, gts, 0.5, 0.5, 0.5, False)
+        torch.manual_seed(int(g[f"seed{c}"]))
+        res = AS.random_sample(props, gts, labels, assigned, num=int(g[f"num{c}"]), pos_fraction=0.25, add_gt_as_proposals=True)
+        assert torch.equal(res.pos_inds, t("pos_inds")) and torch.equal(res.neg_inds, t("neg_inds")), c
+        assert torch.equal(res.pos_assigned_gt_inds, t("pos_assigned")) and torch.equal(res.pos_gt_labels, t("pos_gt_labels")), c
