@@ -93,3 +93,40 @@ def test_swin_relative_position_tables_are_resized(tmp_path):
     table = src.relative_position_bias_table.detach()
     want = torch.nn.functional.interpolate(table.permute(1, 0).reshape(1, 4, 13, 13), size=(23, 23), mode="bicubic")
     assert torch.allclose(dst.relative_position_bias_table, want.reshape(4, 23 * 23).permute(1, 0))
+
+
+def test_loading_equals_the_reference_loader(tmp_path, golden):
+    """Fixture = the reference's own mmcv_custom/checkpoint.py load_checkpoint executed on a Swin-shaped module for the
+    `module.`-prefixed runner schema, the MoBY `encoder.` container and a bare state dict, with window-5 relative
+    position tables going into a window-3 model (tools/gen_golden_checkpoint.py): same final parameters here."""
+    import torch.nn as nn
+    from attentionshift_amd import checkpoint as CK
+    g = golden("checkpoint_load")
+
+    class Attn(nn.Module):
+        def __init__(self, window, heads):
+            super().__init__()
+            self.relative_position_bias_table = nn.Parameter(torch.zeros((2 * window - 1) ** 2, heads))
+            self.qkv = nn.Linear(8, 24)
+
+    class Net(nn.Module):
+        def __init__(self, window=3, heads=2):
+            super().__init__()
+            self.patch_embed = nn.Conv2d(3, 8, 2, 2)
+            self.layers = nn.ModuleList([nn.ModuleDict(dict(attn=Attn(window, heads), norm=nn.BatchNorm2d(8)))])
+            self.head_only_in_model = nn.Linear(8, 4)
+
+    base = {str(k): torch.from_numpy(g[f"ckpt.{k}"]) for k in g["ckpt_keys"]}
+    files = {"module_state_dict": dict(state_dict={"module." + k: v for k, v in base.items()}, meta=dict(epoch=3)),
+             "moby_model": dict(model={**{"encoder." + k: v for k, v in base.items()}, "projector.w": torch.zeros(2)}),
+             "bare": dict(base)}
+    for name in [str(v) for v in g["variants"]]:
+        path = tmp_path / f"{name}.pth"
+        torch.save(files[name], path)
+        torch.manual_seed(5)
+        model = Net()
+        CK.load_checkpoint(model, str(path), strict=False)
+        sd = model.state_dict()
+        assert list(sd) == [str(k) for k in g[f"{name}_keys"]]
+        for k, v in sd.items():
+            assert torch.allclose(v.float(), torch.from_numpy(g[f"{name}.{k}"]).float(), atol=1e-6), (name, k)
