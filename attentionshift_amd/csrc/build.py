@@ -39,7 +39,8 @@ def _digest(paths, extra=""):
 def build(force=False, verbose=True):
     os.makedirs(OBJ, exist_ok=True)
     hipcc = _hipcc()
-    headers = [os.path.join(HERE, "common.h"), os.path.join(os.path.dirname(PKG), "include", "attnshift.h")]
+    headers = sorted(os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith((".h", ".inc")))
+    headers.append(os.path.join(os.path.dirname(PKG), "include", "attnshift.h"))
     objs, rebuilt = [], False
     for src in SOURCES:
         path = os.path.join(HERE, src)

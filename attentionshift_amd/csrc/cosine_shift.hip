@@ -72,8 +72,8 @@ __global__ __launch_bounds__(CS_NT) void stats_kernel(const float* __restrict__ 
                                                       const int32_t* __restrict__ cnt,
                                                       const int32_t* __restrict__ box_patch_,
                                                       float* __restrict__ stats, float* __restrict__ tau_out,
-                                                      float tau0, float temp, int it, int Hp, int Wp, int P, int G,
-                                                      int nt1, int density_only) {
+                                                      float tau0, float temp, float tt0, int it, int Hp, int Wp, int P,
+                                                      int G, int nt1, int density_only) {
   __shared__ float sh_a[CS_NT], sh_b[CS_NT];
   const int Np = Hp * Wp;
   const int p = blockIdx.x, g = blockIdx.y, tid = threadIdx.x;
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(CS_NT) void stats_kernel(const float* __restrict__ 
     if (tau_out != nullptr && tid == 0) tau_out[((size_t)(it - 1) * G + g) * P + p] = tau;
   }
   if (density_only) return;
-  const float tt = temp * tau;
+  const float tt = it == 0 ? tt0 : temp * tau;
   const float mlog = maxsim / tt;
   float z = 0.0f;
   const float* srow = sim + ((size_t)g * P + p) * Np;
@@ -348,8 +348,8 @@ __global__ __launch_bounds__(CS_NT) void shift_assign_kernel(const float* __rest
                                                              const int32_t* __restrict__ box_patch_,
                                                              float* __restrict__ stats, float* __restrict__ tau_out,
                                                              int2* __restrict__ aw, int32_t* __restrict__ assign_out,
-                                                             float tau0, float temp, int it, int Hp, int Wp, int P,
-                                                             int G, int nt1) {
+                                                             float tau0, float temp, float tt0, int it, int Hp, int Wp,
+                                                             int P, int G, int nt1) {
   __shared__ float sh_mx[8][32], sh_ds[8][32];
   __shared__ float st_s[PMAX * 4], zs_s[PMAX * 2];
   const int Np = Hp * Wp;
@@ -414,7 +414,9 @@ __global__ __launch_bounds__(CS_NT) void shift_assign_kernel(const float* __rest
       tau = fmaxf(1.0f - mean, 1e-10f);
       if (tau_out != nullptr && tile == 0 && p < P) tau_out[((size_t)(it - 1) * G + g) * P + p] = tau;
     }
-    const float tt = temp * tau;
+    // iteration 0 divides by the python float temp*tau0 rounded ONCE to fp32 (stdroi:834 with scalar tau); later
+    // iterations by the fp32 product temp * tau[g][p] of a tensor tau
+    const float tt = it == 0 ? tt0 : temp * tau;
     st_s[p * 4 + 0] = tt; st_s[p * 4 + 1] = maxsim / tt; st_s[p * 4 + 3] = tau;
     zs_s[p * 2 + 0] = maxsim; zs_s[p * 2 + 1] = 1.4426950408889634f / tt;
   }
@@ -625,7 +627,7 @@ extern "C" size_t as_cosine_shift_workspace_bytes(int B, int C, int Hp, int Wp, 
 }
 
 extern "C" int as_cosine_shift(const float* feat, const int32_t* box_patch, const int32_t* obj_img, float* prot,
-                               float tau0, float temp, int n_shift, float* sim_out, int32_t* assign_out,
+                               double tau0_d, double temp_d, int n_shift, float* sim_out, int32_t* assign_out,
                                float* tau_out, void* ws, size_t ws_bytes, int B, int C, int Hp, int Wp, int G, int P,
                                as_stream_t stream) {
   AS_REQUIRE(feat && box_patch && obj_img && prot && sim_out && ws, AS_E_BADARG, "as_cosine_shift: null pointer");
@@ -634,6 +636,7 @@ extern "C" int as_cosine_shift(const float* feat, const int32_t* box_patch, cons
   AS_REQUIRE(C % SH_CH == 0 && C <= 4 * CS_NT, AS_E_UNSUPPORTED,
              "as_cosine_shift: C=%d must be a multiple of %d and <= 1024", C, SH_CH);
   const int Np = Hp * Wp;
+  const float tau0 = (float)tau0_d, temp = (float)temp_d, tt0 = (float)(temp_d * tau0_d);
   const WsLayout L = ws_layout(B, C, Np, G, P);
   AS_REQUIRE(ws_bytes >= L.total, AS_E_WORKSPACE, "as_cosine_shift: workspace %zu < %zu bytes", ws_bytes, L.total);
   hipStream_t s = (hipStream_t)stream;
@@ -656,7 +659,7 @@ extern "C" int as_cosine_shift(const float* feat, const int32_t* box_patch, cons
                        Wp, P, L.nt1);
     int32_t* aout = assign_out ? assign_out + (size_t)it * G * Np : nullptr;
     hipLaunchKernelGGL(shift_assign_kernel, dim3(L.nt1, G), dim3(CS_NT), 0, s, sim_c, part_stats, cnt, box_patch,
-                       stats, tau_out, aw, aout, tau0, temp, it, Hp, Wp, P, G, L.nt1);
+                       stats, tau_out, aw, aout, tau0, temp, tt0, it, Hp, Wp, P, G, L.nt1);
     hipLaunchKernelGGL(shift_aggregate_kernel, dim3(L.nchunk, G), dim3(CS_NT), 0, s, feat, aw, stats, box_patch,
                        obj_img, prot, pn2, cnt, C, Hp, Wp, P);
   }
@@ -666,7 +669,7 @@ extern "C" int as_cosine_shift(const float* feat, const int32_t* box_patch, cons
                      part_stats, C, Hp, Wp, P, G, L.nt1);
   if (n_shift > 0 && tau_out != nullptr)
     hipLaunchKernelGGL(stats_kernel, dim3(P, G), dim3(CS_NT), 0, s, sim_out, part_stats, cnt, box_patch, stats,
-                       tau_out, tau0, temp, n_shift, Hp, Wp, P, G, L.nt1, 1);
+                       tau_out, tau0, temp, tt0, n_shift, Hp, Wp, P, G, L.nt1, 1);
   AS_CHECK_LAUNCH("cosine_shift");
   return AS_OK;
 }

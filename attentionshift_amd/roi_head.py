@@ -639,6 +639,9 @@ class AttnShiftRoIHead(nn.Module):
         self.part_slots = 8                       # merged-part slots per object carried by the one-readback merge stage
         self._dev_gens = {}
         self._pool, self._streams = None, []
+        # parity tests set this to a list: every image's sampled refinement points and grid seeds are appended to it
+        # (the fast RNG mode draws on the device, so a checker needs the draws to re-run the chain on the same samples)
+        self.capture = None
         self.visualize = visualize
         self.epoch, self.epoch_semantic_centers = epoch, epoch_semantic_centers
         self.num_semantic_points = num_semantic_points
@@ -813,6 +816,8 @@ class AttnShiftRoIHead(nn.Module):
             pts_bg, pts_fg, pts_supp = sample_point_grid_multi(
                 [(nm, 0.1, False, None), (nm, 0.2, True, gt_points), (nm.mean(0, keepdim=True), 0.1, False, None)], 20)
         pts_fg = torch.cat((pts_fg, pts_supp), dim=0)
+        if self.capture is not None:
+            self.capture.append(dict(points_fg=pts_fg, points_bg=pts_bg))
         CLOCK.mark("  sampling")
         feat_tok = feat_chw.flatten(1).t().contiguous()
         box_patch = (rois // STRIDE).to(torch.int32).contiguous()
@@ -1148,6 +1153,8 @@ class AttnShiftRoIHead(nn.Module):
             coord_point, labels_point = mask_points_finish(mp, num_mask_point_gt, self.rng_mode)
             CLOCK.mark("refine+mask_points")
             seeds = grid_seed_finish(gs[0], gs[1], pseudo_boxes[i], 20)
+            if self.capture is not None:
+                self.capture.append(dict(image=i, seeds=seeds, fg_inter=fg_inter))
             return coord_point, labels_point, map_fg, map_bg, feats_fg, feats_bg, (fg_inter, seeds), pm
 
         def phase_a_nosync(i):
@@ -1165,6 +1172,8 @@ class AttnShiftRoIHead(nn.Module):
             pm = _to_host_issue(mask_u8)
             coord_point, labels_point, f1 = mask_points_nosync(mp, num_mask_point_gt, self._device_gen(boxes.device))
             seeds, f2 = grid_seed_nosync(gs[0], gs[1], 20)
+            if self.capture is not None:
+                self.capture.append(dict(image=i, seeds=seeds, fg_inter=fg_inter))
             flags += [f1, f2]
             return coord_point, labels_point, map_fg, map_bg, feats_fg, feats_bg, (fg_inter, seeds), pm, flags
 

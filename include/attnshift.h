@@ -232,10 +232,12 @@ int as_semantic_prestage(const float* map_fg, float thr, int k, int G, int Hp, i
  *   prot      [G,P,C]   in: seed prototypes; out: shifted prototypes (unnormalised, as the reference)
  *   sim_out   [G,P,Np]  cos(prot, UNMASKED feat) (not clamped)
  *   assign_out[S,G,Np]  (optional) argmax prototype per patch per iteration, ties -> lowest index
- *   tau_out   [S,G,P]   (optional) per-prototype density after each iteration */
+ *   tau_out   [S,G,P]   (optional) per-prototype density after each iteration
+ *   tau0, temp          doubles: the first iteration divides by the python float temp*tau0 rounded once to fp32, exactly
+ *                       as `sim_map/(temp*tau)` with scalar arguments does (stdroi:834) */
 size_t as_cosine_shift_workspace_bytes(int B, int C, int Hp, int Wp, int G, int P);
 int as_cosine_shift(const float* feat, const int32_t* box_patch, const int32_t* obj_img, float* prot,
-                    float tau0, float temp, int n_shift, float* sim_out, int32_t* assign_out, float* tau_out,
+                    double tau0, double temp, int n_shift, float* sim_out, int32_t* assign_out, float* tau_out,
                     void* ws, size_t ws_bytes, int B, int C, int Hp, int Wp, int G, int P, as_stream_t stream);
 
 /* Cosine-affinity refinement on the patch grid (stdroi:668-707 get_refined_similarity):

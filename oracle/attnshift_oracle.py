@@ -37,6 +37,32 @@ def cos_matrix(a, b, eps=EPS_COS):
     return unit_rows(a, eps=eps) @ unit_rows(b, eps=eps).transpose(-1, -2)
 
 
+def cos_broadcast(a, b, eps=EPS_COS, chunk=4):
+    """cos(a_i, b_j) for a [G,P,C], b [G,M,C] or [M,C] -> [G,P,M] with the reference's OWN arithmetic:
+    F.cosine_similarity on the broadcast pair (stdroi:832, :848, :883), i.e. both operands normalised, multiplied
+    element-wise into a [P,M,C] temporary and summed over C by torch's reduction.  The rounding of that sum differs
+    from a matmul's in the last bits, which decides near-tied argmaxes at full size, so the fixtures are
+    pinned through this form.  Evaluated `chunk` prototypes at a time: each output element's reduction is independent
+    of the others, the chunking only bounds the temporary (755 MB at 64x64x768 otherwise)."""
+    if b.dim() == 2:
+        b = b[None].expand(a.shape[0], -1, -1)
+    out = []
+    for g in range(a.shape[0]):
+        # all-zero rows of b (patches outside the object's box, stdroi:1819) give exactly 0 (0 / eps * ... = 0): only the
+        # non-zero rows are evaluated, the result is bit-identical to the full broadcast
+        nz = (b[g] != 0).any(-1)
+        # keep the operand's memory order: the reference's features are a transposed VIEW of the [C, Np] map
+        # (stdroi:1816-1824), torch then reduces over C as the OUTER dimension (a sequential sum per patch), and a
+        # contiguous [n, C] copy would be reduced in a different order
+        bn = b[g][nz] if b[g].stride(-1) == 1 else b[g].t()[:, nz].t()
+        rows = [F.cosine_similarity(a[g, p0:p0 + chunk, None, :], bn[None, :, :], dim=-1, eps=eps)
+                for p0 in range(0, a.shape[1], chunk)]
+        full = torch.zeros(a.shape[1], b.shape[1], dtype=a.dtype)
+        full[:, nz] = torch.cat(rows, dim=0)
+        out.append(full)
+    return torch.stack(out)
+
+
 def box_mask(boxes, size, default_val=0.0):
     """stdroi:303-309 box2mask: inclusive integer box [x0..x1] x [y0..y1] set to 1."""
     n = boxes.shape[0]
@@ -461,34 +487,62 @@ def grid_seed_coords(maps, rois, thr=0.35, n_points=20):
     return torch.stack(out)
 
 
-def update_density(prot, feats, onehot):
+def update_density(prot, feats, onehot, faithful=False):
     """stdroi:882-908 update_density_batch -> tau [G,P,1]."""
-    sim = cos_matrix(prot, feats)
+    sim = cos_broadcast(prot, feats) if faithful else cos_matrix(prot, feats)
     cnt = onehot.sum(-1)
     dens = (sim * onehot).sum(-1)
     dens = 1 - torch.where(cnt >= 1, dens / cnt, torch.zeros_like(dens))
     return dens.clamp(1e-10).unsqueeze(-1)
 
 
-def cosine_shift(prot, feats, feats_org, tau=0.1, temp=0.1, n_shift=5, trace=None):
+def cosine_shift(prot, feats, feats_org, tau=0.1, temp=0.1, n_shift=5, trace=None, faithful=False):
     """stdroi:830-854 cosine_shift_batch.  prot [G,P,C]; feats [G,Np,C] (zero outside each
     object's box); feats_org [Np,C].  Returns (prot [G*P,C], sim [G*P,Np]).
-    `trace`, if a list, receives (assign [G,Np] long, tau [G,P]) per iteration."""
+    `trace`, if a list, receives (assign [G,Np] long, tau [G,P]) per iteration.
+    faithful=True evaluates every cosine in the reference's broadcast form (cos_broadcast): bit-identical to
+    the reference on the same host, ~6 s at 64x64x768; the default normalised matmul agrees to fp32 round-off."""
     G, P, _ = prot.shape
+    cosf = cos_broadcast if faithful else cos_matrix
     for _ in range(n_shift):
-        sim = cos_matrix(prot, feats)
+        sim = cosf(prot, feats)
         w = F.softmax(sim / (temp * tau), dim=-1)
         win = w.argmax(1, keepdim=True)                               # [G,1,Np], ties -> lowest p
         onehot = (torch.arange(P)[None, :, None] == win).to(w.dtype)
         prot = (w * onehot) @ feats
-        tau = update_density(prot, feats, onehot)
+        tau = update_density(prot, feats, onehot, faithful)
         if trace is not None:
             trace.append((win[:, 0].clone(), tau[..., 0].clone()))
-    sim = cos_matrix(prot, feats_org)
+    sim = cosf(prot, feats_org)
     return prot.flatten(0, 1), sim.flatten(0, 1)
 
 
-def mean_shift_prototypes(maps, feat, rois, n_shift, thr=0.35, tau=0.1, temp=0.1, n_points=20, trace=None):
+def cosine_shift_step(prot, feats, tau, temp=0.1, faithful=False):
+    """ONE iteration of cosine_shift_batch (stdroi:833-841) from a given state: prot [G,P,C], tau scalar or [G,P,1].
+    Returns dict(sim, w, win [G,Np], prot [G,P,C], tau [G,P,1]).  Used by the full-size parity tests to check every
+    iteration of the HIP kernel from the kernel's OWN state, so that one flipped near-tie cannot compound."""
+    G, P, _ = prot.shape
+    cosf = cos_broadcast if faithful else cos_matrix
+    sim = cosf(prot, feats)
+    w = F.softmax(sim / (temp * tau), dim=-1)
+    win = w.argmax(1, keepdim=True)
+    onehot = (torch.arange(P)[None, :, None] == win).to(w.dtype)
+    new = (w * onehot) @ feats
+    return dict(sim=sim, w=w, win=win[:, 0], prot=new, tau=update_density(new, feats, onehot, faithful))
+
+
+def shift_log_weights64(prot, feats, tau, temp=0.1):
+    """float64 log softmax weights log w[g,p,n] of one iteration (stdroi:833-834) -- the exact-arithmetic value of what
+    the fp32 reference evaluates; |log w[a] - log w[b]| is the margin by which prototype a beats b for patch n."""
+    prot, feats = prot.double(), feats.double()
+    tau = torch.as_tensor(tau, dtype=torch.float64)
+    sim = cos_matrix(prot, feats)
+    logit = sim / (temp * tau)
+    return logit - torch.logsumexp(logit, dim=-1, keepdim=True)
+
+
+def mean_shift_prototypes(maps, feat, rois, n_shift, thr=0.35, tau=0.1, temp=0.1, n_points=20, trace=None,
+                          faithful=False):
     """stdroi:1778-1840 mean_shift_grid_prototype (rois given).  maps [G,Hp,Wp] binary,
     feat [C,Hp,Wp].  Returns (prot [G*P,C], sim [G*P,Hp,Wp] clamped at 0, seed coords [G,P,2])."""
     C, Hp, Wp = feat.shape
@@ -496,7 +550,7 @@ def mean_shift_prototypes(maps, feat, rois, n_shift, thr=0.35, tau=0.1, temp=0.1
     tokens = feat.flatten(1).t()
     prot = feat.permute(1, 2, 0)[coords[..., 0], coords[..., 1]].clone()          # [G,P,C]
     inbox = box_mask(rois // 16, (Hp, Wp), 0.0).flatten(1)                        # [G,Np]
-    prot, sim = cosine_shift(prot, tokens[None] * inbox[..., None], tokens, tau, temp, n_shift, trace)
+    prot, sim = cosine_shift(prot, tokens[None] * inbox[..., None], tokens, tau, temp, n_shift, trace, faithful)
     return prot, sim.reshape(-1, Hp, Wp).clamp(0), coords
 
 
@@ -577,11 +631,11 @@ def part_centers(maps, rois, obj_label, feat, num_max_keep=50, num_max_obj=3):
 
 
 def semantic_centers(map_fg, map_bg, rois, feat, pos_thr, n_shift, gt_labels, merge_thr=0.85,
-                     num_semantic_points=3, trace=None):
+                     num_semantic_points=3, trace=None, faithful=False):
     """stdroi:1995-2031 get_semantic_centers for one image."""
     C, Hp, Wp = feat.shape
     fg_inter, bg_inter, fg_bin = semantic_prestage(map_fg, map_bg, (Hp, Wp), pos_thr)
-    prot, sim, seeds = mean_shift_prototypes(fg_bin, feat, rois, n_shift, trace=trace)
+    prot, sim, seeds = mean_shift_prototypes(fg_bin, feat, rois, n_shift, trace=trace, faithful=faithful)
     G = map_fg.shape[0]
     P = sim.shape[0] // G
     kept_maps, keep = filter_parts(sim.reshape(G, P, Hp, Wp), fg_inter)

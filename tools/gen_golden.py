@@ -102,7 +102,10 @@ class _Dummy:
 
 
 def shift_case(tag, seed, hp, wp, C, G, Lc, n_shift, pos_thr=0.35, neg_thr=0.8, obj_tau=0.9,
-               num_gt=10, corr_size=21, num_semantic_points=5, cam_thr=0.2, area_ratio=0.5):
+               num_gt=10, corr_size=21, num_semantic_points=5, cam_thr=0.2, area_ratio=0.5, slim=False):
+    """slim=True (full-size cases): the 1024^2 maps are not stored (12 MB each); the fixture keeps a stride-16
+    subsample of every level, the reference's pseudo masks as packed bits and all integer / prototype outputs, and
+    the tests run the chain END TO END from the seeded inputs instead of stage-wise from stored maps."""
     ns = ref_import.load_roi_functions()
     inp = synthetic.shift_inputs(seed, hp, wp, C, G, Lc)
     H, W = hp * 16, wp * 16
@@ -144,11 +147,16 @@ def shift_case(tag, seed, hp, wp, C, G, Lc, n_shift, pos_thr=0.35, neg_thr=0.8, 
     save["t_refine"] = time.time() - t0
     # reference return order: (..., points_fg(cat supp) , points_bg, ...) under swapped names
     points_fg, points_bg = pts_a, pts_b
-    sub = 4
+    sub = 16 if slim else 4
     save.update(points_fg=npy(points_fg), points_bg=npy(points_bg), mask_coords=npy(coords),
-                mask_labels=npy(labels), map_fg_last=npy(map_fg[-1]), map_bg_last=npy(map_bg[-1]),
+                mask_labels=npy(labels), map_sub=sub,
                 map_fg_sub=npy(map_fg[:, :, ::sub, ::sub]), map_bg_sub=npy(map_bg[:, :, ::sub, ::sub]),
                 fg_feat=npy(f_fg).reshape(f_fg.shape[0], -1), bg_feat=npy(f_bg).reshape(f_bg.shape[0], -1))
+    ref_masks = (map_fg[-1] > map_fg[-1].flatten(1).max(1)[0][:, None, None] * pos_thr).to(torch.uint8)   # stdroi:2356
+    if slim:
+        save.update(pseudo_masks_packed=np.packbits(npy(ref_masks), axis=-1), map_fg_peak=npy(map_fg[-1].flatten(1).max(1)[0]))
+    else:
+        save.update(map_fg_last=npy(map_fg[-1]), map_bg_last=npy(map_bg[-1]))
 
     torch.manual_seed(seed + 1)
     attn_sel = cams[best, torch.arange(G)]
@@ -191,7 +199,8 @@ def shift_case(tag, seed, hp, wp, C, G, Lc, n_shift, pos_thr=0.35, neg_thr=0.8, 
     fg_inter, bg_inter, fg_bin = O.semantic_prestage(map_fg[-1], map_bg[-1], (hp, wp), pos_thr)
     prot_ref, sim_ref = ns["mean_shift_grid_prototype"](dummy_with(ns), fg_bin, feat, rois, tau=0.1, temp=0.1, n_shift=n_shift)
     ns["update_density_batch"] = orig_ud
-    save.update(ref_prot=npy(prot_ref), ref_sim=npy(sim_ref),
+    save.update(ref_prot=npy(prot_ref), ref_sim=npy(sim_ref), seed_coords=npy(O.grid_seed_coords(fg_bin, rois)),
+                fg_inter=npy(fg_inter),
                 ref_assign=np.stack([npy(t[0]) for t in ref_trace]).astype(np.int32),
                 ref_count=np.stack([npy(t[1]) for t in ref_trace]),
                 ref_tau=np.stack([npy(t[2]) for t in ref_trace]),
@@ -205,7 +214,7 @@ def shift_case(tag, seed, hp, wp, C, G, Lc, n_shift, pos_thr=0.35, neg_thr=0.8, 
 
     my_trace = []
     mine = O.semantic_centers(map_fg[-1], map_bg[-1], rois, feat, pos_thr, n_shift, gt_labels,
-                              num_semantic_points=num_semantic_points, trace=my_trace)
+                              num_semantic_points=num_semantic_points, trace=my_trace, faithful=slim)
     report("B3 fg_inter (vs own prestage on ref maps)", fg_inter, mine["fg_inter"])
     report("B4 prototypes", prot_ref, mine["prot"])
     report("B4 sim", sim_ref, mine["sim"])
@@ -219,8 +228,20 @@ def shift_case(tag, seed, hp, wp, C, G, Lc, n_shift, pos_thr=0.35, neg_thr=0.8, 
         report("B5 feats", feats_all, mine["feats"])
     for g, s in enumerate(sim_parts):
         report(f"B5 sim_parts[{g}]", s, mine["sim_parts"][g])
-    report("B6 pseudo masks", (map_fg[-1] > map_fg[-1].flatten(1).max(1)[0][:, None, None] * pos_thr).to(torch.uint8),
-           O.pseudo_masks(m_fg[-1], pos_thr), exact=True)
+    report("B6 pseudo masks", ref_masks, O.pseudo_masks(m_fg[-1], pos_thr), exact=True)
+    if slim:        # what the end-to-end tests will see: the oracle chained on ITS OWN maps, not the reference's
+        torch.manual_seed(seed + 1)
+        O.sample_refine_inputs(attn_sel, points)
+        e_coords, e_labels = O.mask_sample_points(m_fg[-1], m_bg[-1], rois, pos_thr, neg_thr, num_gt, corr_size)
+        report("end-to-end B2' mask coords", coords, e_coords, exact=True)
+        report("end-to-end B2' mask labels", labels, e_labels, exact=True)
+        e_tr = []
+        e2e = O.semantic_centers(m_fg[-1], m_bg[-1], rois, feat, pos_thr, n_shift, gt_labels,
+                                 num_semantic_points=num_semantic_points, trace=e_tr, faithful=True)
+        for it, (a, tau) in enumerate(e_tr):
+            report(f"end-to-end B4 assign it{it}", ref_trace[it][0], a, exact=True)
+        report("end-to-end B5 num_parts", np.array(num_parts), np.array(e2e["num_parts"]), exact=True)
+        report("end-to-end B5 coords_org", coords_org, e2e["coords_org"])
     np.savez_compressed(os.path.join(OUT, f"shift_{tag}.npz"), **save)
 
 
@@ -264,6 +285,10 @@ def swin_case(tag, seed, C, heads, hw, shift, B=2, ws=7):
 def main():
     os.makedirs(OUT, exist_ok=True)
     assert ref_import.reference_available(), "needs /root/reference"
+    if "--cfg2-only" in sys.argv:
+        # a BASELINE config-2 slice: 64x64 patches, C=768, G=3, 7 roll-out layers, 5 shift iterations (one image)
+        shift_case("cfg2", seed=2024, hp=64, wp=64, C=768, G=3, Lc=7, n_shift=5, slim=True)
+        return
     if "--swin-only" in sys.argv:
         swin_case("w14_s0", 11, 64, 2, 14, 0)
         swin_case("w14_s3", 12, 64, 2, 14, 3)
@@ -276,6 +301,7 @@ def main():
                                   point_tokens_num=100, num_classes=20, batch=1, seed=0), (224, 224), (11,), 7)
     shift_case("tiny224", seed=1234, hp=14, wp=14, C=192, G=3, Lc=7, n_shift=3)
     shift_case("mid320", seed=77, hp=20, wp=20, C=96, G=3, Lc=3, n_shift=5)
+    shift_case("cfg2", seed=2024, hp=64, wp=64, C=768, G=3, Lc=7, n_shift=5, slim=True)
     swin_case("w14_s0", 11, 64, 2, 14, 0)
     swin_case("w14_s3", 12, 64, 2, 14, 3)
     swin_case("w16_s3_pad", 13, 96, 3, 16, 3)
