@@ -50,21 +50,6 @@ __device__ __forceinline__ bool in_box(const Box& b, int n, int Wp) {
   return x >= b.x0 && x <= b.x1 && y >= b.y0 && y <= b.y1;
 }
 
-// 1 / max(||row||, eps) for `rows` rows of length C; one wave per row
-__global__ __launch_bounds__(CS_NT) void row_invnorm_kernel(const float* __restrict__ x, float* __restrict__ out,
-                                                            int rows, int C) {
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (row >= rows) return;
-  const float* p = x + (size_t)row * C;
-  float s = 0.0f;
-  for (int c = lane * 4; c < C; c += 256) {
-    const float4 v = *reinterpret_cast<const float4*>(p + c);
-    s = fmaf(v.x, v.x, s); s = fmaf(v.y, v.y, s); s = fmaf(v.z, v.z, s); s = fmaf(v.w, v.w, s);
-  }
-  s = wave_sum(s);
-  if (lane == 0) out[row] = 1.0f / fmaxf(sqrtf(s), COS_EPS);
-}
-
 // ---- stats pass: grid (P, G) ------------------------------------------------------------------------
 // stats[g][p] = {tt = temp*tau, mlog = max logit, Z, tau}
 __global__ __launch_bounds__(CS_NT) void stats_kernel(const float* __restrict__ sim,
@@ -136,42 +121,41 @@ __device__ __forceinline__ int outside_cluster(const float* st_g, int P) {
 }
 
 // ---- shift iteration, pass 1: similarity tiles (8 waves split the channel range) ---------------------
-// grid (tiles, G).  FULL=false: tile indexes the object's in-box patches, sim is written COMPACT
-// ([g][p][in-box index]); FULL=true: the whole grid, sim written by patch index.  pn2 holds `npart` partial squared
-// norms per prototype (1 for the caller's prototypes, C/SH_CH after an aggregation pass), summed here in fixed order.
+// grid (tiles, G): tile indexes the object's in-box patches, sim is written COMPACT ([g][p][in-box index]).
 constexpr int S1_NT = 512;
 constexpr int SH_CH = 32;        // channels per aggregation workgroup
 
-template <bool FULL>
-__global__ __launch_bounds__(S1_NT) void shift_sim_kernel(const float* __restrict__ feat, const float* __restrict__ invn,
-                                                          const float* __restrict__ prot, const float* __restrict__ pn2,
-                                                          int npart, const int32_t* __restrict__ box_patch_,
+// The patch norms and (first iteration) the prototype norms are accumulated from the MFMA operand fragments, so there is
+// no norm pass over the feature map; later iterations sum the `npart` squared-norm partials of the aggregation pass with
+// one lane per partial and a fixed shuffle tree.
+__global__ __launch_bounds__(S1_NT) void shift_sim_kernel(const float* __restrict__ feat, const float* __restrict__ prot,
+                                                          const float* __restrict__ pn2, int npart,
+                                                          const int32_t* __restrict__ box_patch_,
                                                           const int32_t* __restrict__ obj_img,
                                                           const int2* __restrict__ aw_prev,   // [G][Np] compact or null
                                                           float* __restrict__ sim, float* __restrict__ part_stats,
                                                           int C, int Hp, int Wp, int P, int nt1) {
   __shared__ float red[8][32][33];
+  __shared__ float nrm[2][16][32];
   __shared__ float invnp_s[PMAX];
   const int Np = Hp * Wp;
   const int g = blockIdx.y, tile = blockIdx.x;
   const Box ob = load_box(box_patch_, g, Hp, Wp);
-  const int nb = FULL ? Np : box_count(ob);
+  const int nb = box_count(ob);
   if (tile * CS_TILE1 >= nb) return;
   const int b = obj_img[g];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, half = lane >> 5;
 
-  if (tid < PMAX) {
-    float s = 0.0f;
-    if (tid < P)
-      for (int k = 0; k < npart; ++k) s += pn2[((size_t)g * npart + k) * PMAX + tid];
-    invnp_s[tid] = tid < P ? 1.0f / fmaxf(sqrtf(s), COS_EPS) : 0.0f;
+  if (pn2 != nullptr) {                         // |prot_p|^2 = sum of npart (<= 64) partials: wave w owns p = w, w+8, ...
+    for (int p = wave; p < PMAX; p += 8) {
+      float s = (p < P && lane < npart) ? pn2[((size_t)g * npart + lane) * PMAX + p] : 0.0f;
+      s = wave_sum(s);
+      if (lane == 0) invnp_s[p] = p < P ? 1.0f / fmaxf(sqrtf(s), COS_EPS) : 0.0f;
+    }
   }
 
-  auto patch_of = [&](int local) {
-    const int t = min(tile * CS_TILE1 + local, nb - 1);
-    return FULL ? t : box_patch(ob, t, Wp);
-  };
+  auto patch_of = [&](int local) { return box_patch(ob, min(tile * CS_TILE1 + local, nb - 1), Wp); };
   const int n_mine = patch_of(li);
   const float* frow = feat + ((size_t)b * Np + n_mine) * C;
   const float* prow = prot + ((size_t)g * P + min(li, P - 1)) * C;
@@ -181,21 +165,13 @@ __global__ __launch_bounds__(S1_NT) void shift_sim_kernel(const float* __restric
   const int nn = tid & 31, pq = tid >> 5;
   const int t_loc = tile * CS_TILE1 + nn;
   const bool nvalid = t_loc < nb;
-  const int n = patch_of(nn);
-  const float fin = invn[(size_t)b * Np + n];
   int a_prev = -1;
-  if (aw_prev != nullptr && nvalid) {
-    if (!FULL) {
-      a_prev = aw_prev[(size_t)g * Np + t_loc].x;
-    } else if (in_box(ob, n, Wp)) {
-      const int y = n / Wp, x = n - y * Wp;
-      a_prev = aw_prev[(size_t)g * Np + (y - ob.y0) * box_w(ob) + (x - ob.x0)].x;
-    }
-  }
+  if (aw_prev != nullptr && nvalid) a_prev = aw_prev[(size_t)g * Np + t_loc].x;
 
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+  float qa = 0.0f, qb = 0.0f;                    // squared-norm partials of this lane's operand fragments
   const int nsteps = (C + 15) / 16;
   constexpr int SU = 6;
   for (int s = wave; s < nsteps; s += 8 * SU) {
@@ -208,7 +184,7 @@ __global__ __launch_bounds__(S1_NT) void shift_sim_kernel(const float* __restric
       const int k0 = ok ? su * 16 + half * 8 : 0;
       fb[u].load16B(frow + k0);
       fa[u].load16B(prow + k0);
-      keep[u] = (ok && pvalid) ? 1.0f : 0.0f;
+      keep[u] = ok ? 1.0f : 0.0f;
     }
     // keep all 4*SU operand loads in flight: without the fence the scheduler sinks each load to its MFMA to save
     // registers and the loop degenerates into SU dependent memory round trips
@@ -216,21 +192,41 @@ __global__ __launch_bounds__(S1_NT) void shift_sim_kernel(const float* __restric
 #pragma unroll
     for (int u = 0; u < SU; ++u) {
 #pragma unroll
-      for (int t = 0; t < 8; ++t) fa[u].v[t] *= keep[u];
+      for (int t = 0; t < 8; ++t) {
+        fa[u].v[t] *= pvalid ? keep[u] : 0.0f;
+        fb[u].v[t] *= keep[u];
+        qa = fmaf(fa[u].v[t], fa[u].v[t], qa);
+        qb = fmaf(fb[u].v[t], fb[u].v[t], qb);
+      }
       acc = mma32(fa[u], fb[u], acc);          // D[p][n]
     }
   }
 #pragma unroll
   for (int r = 0; r < 16; ++r) red[wave][acc_row(r, half)][li] = acc[r];
+  nrm[0][wave * 2 + half][li] = qa;
+  nrm[1][wave * 2 + half][li] = qb;
   __syncthreads();
 
+  float fn = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) fn += nrm[1][k][nn];
+  const float fin = 1.0f / fmaxf(sqrtf(fn), COS_EPS);
 #pragma unroll
   for (int qd = 0; qd < 2; ++qd) {
     const int p = pq + 16 * qd;
+    float pin;
+    if (pn2 != nullptr) {
+      pin = invnp_s[p];
+    } else {
+      float sn = 0.0f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) sn += nrm[0][k][p];
+      pin = 1.0f / fmaxf(sqrtf(sn), COS_EPS);
+    }
     float v = (((red[0][p][nn] + red[1][p][nn]) + (red[2][p][nn] + red[3][p][nn])) +
                ((red[4][p][nn] + red[5][p][nn]) + (red[6][p][nn] + red[7][p][nn])));
-    v = v * invnp_s[p] * fin;
-    if (p < P && nvalid) sim[((size_t)g * P + p) * Np + (FULL ? n : t_loc)] = v;
+    v = v * pin * fin;
+    if (p < P && nvalid) sim[((size_t)g * P + p) * Np + t_loc] = v;
     float mx = (nvalid && p < P) ? v : -INFINITY;
     float ds = (a_prev == p) ? v : 0.0f;
 #pragma unroll
@@ -243,98 +239,6 @@ __global__ __launch_bounds__(S1_NT) void shift_sim_kernel(const float* __restric
       ps[0] = mx;
       ps[1] = ds;
     }
-  }
-}
-
-// ---- final similarity over the UNMASKED grid: grid (tiles, B) ----------------------------------------------
-// One workgroup per (32-patch tile, image): the tile's feature fragments are loaded ONCE and contracted with the
-// prototypes of every object of that image in turn (the per-object form re-streamed the 12.6 MB map per object).
-// Also reduces the density sums of the last assignment (tau trace) like the per-object pass.
-constexpr int SF_SU = 8;          // k16 steps per wave held in registers: covers C <= 8 * 8 * 16 = 1024
-
-__global__ __launch_bounds__(S1_NT) void shift_sim_full_kernel(const float* __restrict__ feat,
-                                                               const float* __restrict__ invn,
-                                                               const float* __restrict__ prot,
-                                                               const float* __restrict__ pn2, int npart,
-                                                               const int32_t* __restrict__ box_patch_,
-                                                               const int32_t* __restrict__ obj_img,
-                                                               const int2* __restrict__ aw_prev,
-                                                               float* __restrict__ sim, float* __restrict__ part_stats,
-                                                               int C, int Hp, int Wp, int P, int G, int nt1) {
-  __shared__ float red[8][32][33];
-  __shared__ float invnp_s[PMAX];
-  const int Np = Hp * Wp;
-  const int b = blockIdx.y, tile = blockIdx.x;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int li = lane & 31, half = lane >> 5;
-  const int n_mine = min(tile * CS_TILE1 + li, Np - 1);
-  const float* frow = feat + ((size_t)b * Np + n_mine) * C;
-  const int nsteps = (C + 15) / 16;
-
-  Frag<float> fb[SF_SU];
-  bool okk[SF_SU];
-#pragma unroll
-  for (int u = 0; u < SF_SU; ++u) {
-    const int su = wave + 8 * u;
-    okk[u] = su < nsteps && su * 16 + half * 8 + 8 <= C;
-    fb[u].load16B(frow + (okk[u] ? su * 16 + half * 8 : 0));
-  }
-  const int nn = tid & 31, pq = tid >> 5;
-  const int n = tile * CS_TILE1 + nn;
-  const bool nvalid = n < Np;
-  const float fin = invn[(size_t)b * Np + min(n, Np - 1)];
-
-  for (int g = 0; g < G; ++g) {
-    if (obj_img[g] != b) continue;                         // workgroup-uniform
-    const float* prow = prot + ((size_t)g * P + min(li, P - 1)) * C;
-    Frag<float> fa[SF_SU];
-#pragma unroll
-    for (int u = 0; u < SF_SU; ++u) fa[u].load16B(prow + (okk[u] ? (wave + 8 * u) * 16 + half * 8 : 0));
-    if (tid < PMAX) {
-      float s2 = 0.0f;
-      if (tid < P)
-        for (int k = 0; k < npart; ++k) s2 += pn2[((size_t)g * npart + k) * PMAX + tid];
-      invnp_s[tid] = tid < P ? 1.0f / fmaxf(sqrtf(s2), COS_EPS) : 0.0f;
-    }
-    const Box ob = load_box(box_patch_, g, Hp, Wp);
-    int a_prev = -1;
-    if (aw_prev != nullptr && nvalid && in_box(ob, n, Wp)) {
-      const int y = n / Wp, x = n - y * Wp;
-      a_prev = aw_prev[(size_t)g * Np + (y - ob.y0) * box_w(ob) + (x - ob.x0)].x;
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-#pragma unroll
-    for (int u = 0; u < SF_SU; ++u) {
-      const float keep = (okk[u] && li < P) ? 1.0f : 0.0f;
-#pragma unroll
-      for (int t = 0; t < 8; ++t) fa[u].v[t] *= keep;
-      acc = mma32(fa[u], fb[u], acc);          // D[p][n]
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) red[wave][acc_row(r, half)][li] = acc[r];
-    __syncthreads();
-#pragma unroll
-    for (int qd = 0; qd < 2; ++qd) {
-      const int p = pq + 16 * qd;
-      float v = (((red[0][p][nn] + red[1][p][nn]) + (red[2][p][nn] + red[3][p][nn])) +
-                 ((red[4][p][nn] + red[5][p][nn]) + (red[6][p][nn] + red[7][p][nn])));
-      v = v * invnp_s[p] * fin;
-      if (p < P && nvalid) sim[((size_t)g * P + p) * Np + n] = v;
-      if (aw_prev != nullptr) {
-        float ds = (a_prev == p) ? v : 0.0f;
-#pragma unroll
-        for (int o = 16; o > 0; o >>= 1) ds += __shfl_xor(ds, o);
-        if (nn == 0) {
-          float* ps = part_stats + (((size_t)g * nt1 + tile) * PMAX + p) * 2;
-          ps[0] = 0.0f;
-          ps[1] = ds;
-        }
-      }
-    }
-    __syncthreads();
   }
 }
 
@@ -587,19 +491,8 @@ __global__ __launch_bounds__(CS_NT) void shift_aggregate_kernel(const float* __r
   }
 }
 
-// squared norms of the caller's prototypes in the pn2 layout with one partial: [G][1][PMAX]
-__global__ void prot_norm2_kernel(const float* __restrict__ prot, float* __restrict__ pn2, int G, int P, int C) {
-  const int gp = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (gp >= G * P) return;
-  const float* r = prot + (size_t)gp * C;
-  float s = 0.0f;
-  for (int c = lane; c < C; c += 64) s = fmaf(r[c], r[c], s);
-  s = wave_sum(s);
-  if (lane == 0) pn2[(gp / P) * PMAX + gp % P] = s;
-}
-
 struct WsLayout {
-  size_t invn, pn2, cnt, stats, part_stats, sim_c, aw, total;
+  size_t pn2, cnt, stats, part_stats, sim_c, aw, total;
   int nt1, nchunk;
 };
 WsLayout ws_layout(int B, int C, int Np, int G, int P) {
@@ -608,7 +501,6 @@ WsLayout ws_layout(int B, int C, int Np, int G, int P) {
   w.nt1 = as_ceil_div(Np, CS_TILE1);
   w.nchunk = as_ceil_div(C, SH_CH);
   size_t o = 0;
-  w.invn = o; o = al(o + (size_t)B * Np * 4);
   w.pn2 = o; o = al(o + (size_t)G * w.nchunk * PMAX * 4);
   w.cnt = o; o = al(o + (size_t)G * PMAX * 4);
   w.stats = o; o = al(o + (size_t)G * PMAX * 16);
@@ -621,27 +513,32 @@ WsLayout ws_layout(int B, int C, int Np, int G, int P) {
 
 }  // namespace
 
+void as_shift_final_sim_launch(const float* feat, const float* prot, const int32_t* box_patch, const int32_t* obj_img,
+                               const int2* aw, float* sim_out, float* part_stats, int B, int C, int Hp, int Wp, int P, int G,
+                               int nt1, hipStream_t s);                       // shift_final.hip
+
 extern "C" size_t as_cosine_shift_workspace_bytes(int B, int C, int Hp, int Wp, int G, int P) {
   if (B <= 0 || C <= 0 || Hp <= 0 || Wp <= 0 || G <= 0 || P <= 0) return 0;
   return ws_layout(B, C, Hp * Wp, G, P).total;
 }
 
-extern "C" int as_cosine_shift(const float* feat, const int32_t* box_patch, const int32_t* obj_img, float* prot,
-                               double tau0_d, double temp_d, int n_shift, float* sim_out, int32_t* assign_out,
-                               float* tau_out, void* ws, size_t ws_bytes, int B, int C, int Hp, int Wp, int G, int P,
-                               as_stream_t stream) {
-  AS_REQUIRE(feat && box_patch && obj_img && prot && sim_out && ws, AS_E_BADARG, "as_cosine_shift: null pointer");
+extern "C" int as_cosine_shift(const float* feat, const int32_t* box_patch, const int32_t* obj_img, const float* prot_in,
+                               float* prot_out, double tau0_d, double temp_d, int n_shift, float* sim_out,
+                               int32_t* assign_out, float* tau_out, void* ws, size_t ws_bytes, int B, int C, int Hp, int Wp,
+                               int G, int P, as_stream_t stream) {
+  AS_REQUIRE(feat && box_patch && obj_img && prot_in && prot_out && sim_out && ws, AS_E_BADARG, "as_cosine_shift: null pointer");
   AS_REQUIRE(B > 0 && Hp > 0 && Wp > 0 && G > 0 && n_shift >= 0, AS_E_BADARG, "as_cosine_shift: bad sizes");
   AS_REQUIRE(P > 0 && P <= PMAX, AS_E_UNSUPPORTED, "as_cosine_shift: P=%d prototypes per object (max %d)", P, PMAX);
   AS_REQUIRE(C % SH_CH == 0 && C <= 4 * CS_NT, AS_E_UNSUPPORTED,
              "as_cosine_shift: C=%d must be a multiple of %d and <= 1024", C, SH_CH);
+  AS_REQUIRE(G <= 256, AS_E_UNSUPPORTED, "as_cosine_shift: %d objects per call (max 256)", G);
   const int Np = Hp * Wp;
   const float tau0 = (float)tau0_d, temp = (float)temp_d, tt0 = (float)(temp_d * tau0_d);
   const WsLayout L = ws_layout(B, C, Np, G, P);
   AS_REQUIRE(ws_bytes >= L.total, AS_E_WORKSPACE, "as_cosine_shift: workspace %zu < %zu bytes", ws_bytes, L.total);
+  AS_REQUIRE(L.nchunk <= 64, AS_E_UNSUPPORTED, "as_cosine_shift: C=%d gives more than 64 channel blocks", C);
   hipStream_t s = (hipStream_t)stream;
   char* w = (char*)ws;
-  float* invn = (float*)(w + L.invn);
   float* pn2 = (float*)(w + L.pn2);
   int32_t* cnt = (int32_t*)(w + L.cnt);
   float* stats = (float*)(w + L.stats);
@@ -649,24 +546,24 @@ extern "C" int as_cosine_shift(const float* feat, const int32_t* box_patch, cons
   float* sim_c = (float*)(w + L.sim_c);
   int2* aw = (int2*)(w + L.aw);
 
-  hipLaunchKernelGGL(row_invnorm_kernel, dim3(as_ceil_div(B * Np, 4)), dim3(CS_NT), 0, s, feat, invn, B * Np, C);
-  hipLaunchKernelGGL(prot_norm2_kernel, dim3(as_ceil_div(G * P, 4)), dim3(CS_NT), 0, s, prot, pn2, G, P, C);
+  if (n_shift == 0 && prot_out != prot_in)
+    (void)hipMemcpyAsync(prot_out, prot_in, (size_t)G * P * C * 4, hipMemcpyDeviceToDevice, s);
   // three launches per iteration (a dependent launch boundary costs ~1.5 us, a grid barrier more):
-  //   similarity tiles -> statistics + assignment per tile -> channel-major aggregation (no partial prototypes)
+  //   similarity tiles -> statistics + assignment per tile -> channel-major aggregation (no partial prototypes).
+  // Iteration 0 reads the caller's seeds; every aggregation writes prot_out (which may alias prot_in).
   for (int it = 0; it < n_shift; ++it) {
-    hipLaunchKernelGGL((shift_sim_kernel<false>), dim3(L.nt1, G), dim3(S1_NT), 0, s, feat, invn, prot, pn2,
-                       it == 0 ? 1 : L.nchunk, box_patch, obj_img, it > 0 ? aw : nullptr, sim_c, part_stats, C, Hp,
-                       Wp, P, L.nt1);
+    hipLaunchKernelGGL(shift_sim_kernel, dim3(L.nt1, G), dim3(S1_NT), 0, s, feat, it == 0 ? prot_in : prot_out,
+                       it == 0 ? nullptr : pn2, L.nchunk, box_patch, obj_img, it > 0 ? aw : nullptr, sim_c, part_stats,
+                       C, Hp, Wp, P, L.nt1);
     int32_t* aout = assign_out ? assign_out + (size_t)it * G * Np : nullptr;
     hipLaunchKernelGGL(shift_assign_kernel, dim3(L.nt1, G), dim3(CS_NT), 0, s, sim_c, part_stats, cnt, box_patch,
                        stats, tau_out, aw, aout, tau0, temp, tt0, it, Hp, Wp, P, G, L.nt1);
     hipLaunchKernelGGL(shift_aggregate_kernel, dim3(L.nchunk, G), dim3(CS_NT), 0, s, feat, aw, stats, box_patch,
-                       obj_img, prot, pn2, cnt, C, Hp, Wp, P);
+                       obj_img, prot_out, pn2, cnt, C, Hp, Wp, P);
   }
   // final similarity on the UNMASKED map (+ the density of the last assignment for tau_out)
-  hipLaunchKernelGGL(shift_sim_full_kernel, dim3(L.nt1, B), dim3(S1_NT), 0, s, feat, invn, prot, pn2,
-                     n_shift > 0 ? L.nchunk : 1, box_patch, obj_img, (n_shift > 0 && tau_out) ? aw : nullptr, sim_out,
-                     part_stats, C, Hp, Wp, P, G, L.nt1);
+  as_shift_final_sim_launch(feat, n_shift > 0 ? prot_out : prot_in, box_patch, obj_img, (n_shift > 0 && tau_out) ? aw : nullptr,
+                            sim_out, part_stats, B, C, Hp, Wp, P, G, L.nt1, s);
   if (n_shift > 0 && tau_out != nullptr)
     hipLaunchKernelGGL(stats_kernel, dim3(P, G), dim3(CS_NT), 0, s, sim_out, part_stats, cnt, box_patch, stats,
                        tau_out, tau0, temp, tt0, n_shift, Hp, Wp, P, G, L.nt1, 1);

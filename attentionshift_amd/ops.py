@@ -3,6 +3,8 @@
 PyTorch is plumbing here: device memory, the current HIP stream, autograd bookkeeping.  Every
 function validates device/dtype/contiguity, passes raw pointers and raises on any non-zero return.
 """
+import ctypes
+
 import torch
 
 from . import _lib
@@ -395,8 +397,11 @@ def semantic_prestage(map_fg, thr, k=11, up=16):
     return fg_inter, mask, counts
 
 
+_shift_ws = {}          # (device, stream, shape) -> workspace, reused across calls (stream-ordered)
+
+
 def cosine_shift(feat, box_patch, obj_img, prot, n_shift, hp, wp, tau0=0.1, temp=0.1, return_trace=False):
-    """feat [B,Np,C] fp32 token-major; box_patch [G,4] int32; obj_img [G] int32; prot [G,P,C] (seeds).
+    """feat [B,Np,C] fp32 token-major; box_patch [G,4] int32; obj_img [G] int32; prot [G,P,C] (seeds, not modified).
     Returns (prot_out [G,P,C], sim [G,P,Np]) and, with return_trace, (assign [S,G,Np], tau [S,G,P])."""
     lib = _lib.load()
     _chk(feat, prot, dtype=torch.float32)
@@ -405,19 +410,24 @@ def cosine_shift(feat, box_patch, obj_img, prot, n_shift, hp, wp, tau0=0.1, temp
     G, P, _ = prot.shape
     if Np_ != hp * wp:
         raise AttnShiftError("cosine_shift: Np != hp*wp")
-    prot = prot.clone()
+    prot_out = torch.empty_like(prot)
     sim = torch.empty(G, P, Np_, device=feat.device, dtype=torch.float32)
     assign = torch.empty(max(n_shift, 1), G, Np_, device=feat.device, dtype=torch.int32) if return_trace else None
     tau = torch.empty(max(n_shift, 1), G, P, device=feat.device, dtype=torch.float32) if return_trace else None
-    nbytes = lib.as_cosine_shift_workspace_bytes(B, C, hp, wp, G, P)
-    ws = torch.empty(nbytes, device=feat.device, dtype=torch.uint8)
+    key = (feat.device, torch.cuda.current_stream(feat.device).cuda_stream, B, C, hp, wp, G, P)
+    ws = _shift_ws.get(key)
+    if ws is None:
+        if len(_shift_ws) > 64:
+            _shift_ws.clear()
+        ws = torch.empty(lib.as_cosine_shift_workspace_bytes(B, C, hp, wp, G, P), device=feat.device, dtype=torch.uint8)
+        _shift_ws[key] = ws
     with _timed("cosine_shift"):
-        _lib.check(lib.as_cosine_shift(_p(feat), _p(box_patch), _p(obj_img), _p(prot), float(tau0), float(temp),
-                                       int(n_shift), _p(sim), _p(assign), _p(tau), _p(ws), nbytes, B, C, hp, wp, G, P,
+        _lib.check(lib.as_cosine_shift(_p(feat), _p(box_patch), _p(obj_img), _p(prot), _p(prot_out), float(tau0), float(temp),
+                                       int(n_shift), _p(sim), _p(assign), _p(tau), _p(ws), ws.numel(), B, C, hp, wp, G, P,
                                        _stream()), "as_cosine_shift")
     if return_trace:
-        return prot, sim, assign[:n_shift], tau[:n_shift]
-    return prot, sim
+        return prot_out, sim, assign[:n_shift], tau[:n_shift]
+    return prot_out, sim
 
 
 def refine_similarity(feat, seeds, boxes_patch, num_obj, refine_times, tau, is_select, hp, wp):

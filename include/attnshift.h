@@ -229,16 +229,18 @@ int as_semantic_prestage(const float* map_fg, float thr, int k, int G, int Hp, i
  *   feat      [B,Np,C]  token-major ViT features (Np = Hp*Wp)
  *   box_patch [G,4]     inclusive patch-grid box (x0,y0,x1,y1) of each object = rois // 16
  *   obj_img   [G]       image index of each object
- *   prot      [G,P,C]   in: seed prototypes; out: shifted prototypes (unnormalised, as the reference)
+ *   prot_in   [G,P,C]   seed prototypes;  prot_out [G,P,C] shifted prototypes (unnormalised, as the reference); the
+ *                       two may be the same buffer
  *   sim_out   [G,P,Np]  cos(prot, UNMASKED feat) (not clamped)
  *   assign_out[S,G,Np]  (optional) argmax prototype per patch per iteration, ties -> lowest index
  *   tau_out   [S,G,P]   (optional) per-prototype density after each iteration
  *   tau0, temp          doubles: the first iteration divides by the python float temp*tau0 rounded once to fp32, exactly
  *                       as `sim_map/(temp*tau)` with scalar arguments does (stdroi:834) */
 size_t as_cosine_shift_workspace_bytes(int B, int C, int Hp, int Wp, int G, int P);
-int as_cosine_shift(const float* feat, const int32_t* box_patch, const int32_t* obj_img, float* prot,
-                    double tau0, double temp, int n_shift, float* sim_out, int32_t* assign_out, float* tau_out,
-                    void* ws, size_t ws_bytes, int B, int C, int Hp, int Wp, int G, int P, as_stream_t stream);
+int as_cosine_shift(const float* feat, const int32_t* box_patch, const int32_t* obj_img, const float* prot_in,
+                    float* prot_out, double tau0, double temp, int n_shift, float* sim_out, int32_t* assign_out,
+                    float* tau_out, void* ws, size_t ws_bytes, int B, int C, int Hp, int Wp, int G, int P,
+                    as_stream_t stream);
 
 /* Cosine-affinity refinement on the patch grid (stdroi:668-707 get_refined_similarity):
  *   feat   [Np,C] one image, seeds [Gp,C] (mean feature of the sampled points, :335-338)

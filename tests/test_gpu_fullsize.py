@@ -42,6 +42,14 @@ def unpack_masks(g):
     return np.unpackbits(g["pseudo_masks_packed"], axis=-1)[..., :W].reshape(-1, H, W)
 
 
+def _rows_close(ref, got, what):
+    """Unnormalised prototypes = sum of w * feature with w = softmax(cos / (temp * tau)): at tau ~ 1e-3 a cosine's fp32
+    round-off (1e-7) moves a weight by 1e-3 relative, so the SCALE of a row carries that noise (the consumers normalise
+    it away); compared to 1e-3 of each row's magnitude."""
+    scale = ref.abs().amax(dim=-1, keepdim=True).clamp_min(1e-30)
+    assert_close(ref / scale, got / scale, 0, 1e-3, what)
+
+
 def test_cosine_shift_every_iteration_is_the_reference_argmax(ops, cfg2):
     """B4 at config-2 size: each of the 5 iterations of as_cosine_shift is checked from the kernel's own state
     (prototypes after k iterations = a call with n_shift=k; tau from the trace) against ONE iteration of the reference
@@ -67,7 +75,7 @@ def test_cosine_shift_every_iteration_is_the_reference_argmax(ops, cfg2):
         for gi, ni in zip(*bad.nonzero(as_tuple=True)):
             same[gi, assign[k][gi, ni].long()] = False
             same[gi, step["win"][gi, ni]] = False
-        assert_close(step["prot"][same], states[k + 1][same], 1e-3, 1e-4, f"prototypes after iteration {k}")
+        _rows_close(step["prot"][same], states[k + 1][same], f"prototypes after iteration {k}")
         assert_close(step["tau"][..., 0][same], tau[k].cpu()[same], 1e-3, 2e-6, f"tau after iteration {k}")
         print(f"[cfg2] iteration {k}: {n} coin-flip patches (near ties {near}, underflow {under}) of {assign[k].numel()}")
     # against the reference's own trajectory (fixture): identical unless a coin flip moved a patch
@@ -76,7 +84,7 @@ def test_cosine_shift_every_iteration_is_the_reference_argmax(ops, cfg2):
     print(f"[cfg2] patches assigned differently from the reference run, per iteration: {diff}; coin flips {flips_total}")
     if flips_total == 0:
         assert sum(diff) == 0, "no coin flips, so the whole trajectory must equal the reference's"
-        assert_close(t(g["ref_prot"]), pout.reshape(-1, pout.shape[-1]), 1e-3, 1e-4, "prototypes vs reference")
+        _rows_close(t(g["ref_prot"]), pout.reshape(-1, pout.shape[-1]).cpu(), "prototypes vs reference")
         assert_close(t(g["ref_sim"]).flatten(1), sim.reshape(-1, hp * wp).clamp(min=0), 1e-3, 1e-5, "sim vs reference")
     assert max(diff) <= 0.01 * ref_assign[0].numel()
     direct = O.cos_matrix(pout.cpu(), tok)

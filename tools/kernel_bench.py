@@ -128,12 +128,14 @@ def main():
         prot = torch.stack(prots).to(dev)
         obj_img = torch.tensor(obj, dtype=torch.int32, device=dev)
         S, G, P = 5, len(obj), 20
-        ms = timeit(lambda: ops.cosine_shift(feat, box_patch, obj_img, prot, S, hp, wp), a.reps, sync_each=True)
         alg = (2 * S + 1) * B * hp * wp * D * 4 + G * P * hp * wp * 4
-        emit("cosine_shift_S5", ms, bytes_=alg, note="algorithmic bytes per SURVEY 8d")
+        ms = timeit(lambda: ops.cosine_shift(feat, box_patch, obj_img, prot, S, hp, wp), a.reps)
+        emit("cosine_shift_S5", ms, bytes_=alg, note="algorithmic bytes per SURVEY 8d; back-to-back calls (HIP events)")
+        ms = timeit(lambda: ops.cosine_shift(feat, box_patch, obj_img, prot, S, hp, wp), a.reps, sync_each=True)
+        emit("cosine_shift_S5_sync_each", ms, bytes_=alg, note="host wall time per call incl. launch + sync")
         if os.environ.get("AS_KB_NO_FULLBOXES") != "1":               # (PMC traffic passes measure the typical case only)
             full = torch.tensor([[0, 0, wp - 1, hp - 1]] * G, dtype=torch.int32, device=dev)
-            ms = timeit(lambda: ops.cosine_shift(feat, full, obj_img, prot, S, hp, wp), a.reps, sync_each=True)
+            ms = timeit(lambda: ops.cosine_shift(feat, full, obj_img, prot, S, hp, wp), a.reps)
             emit("cosine_shift_S5_fullboxes", ms, bytes_=alg, note="worst case: every box covers the image")
     if want("refine"):                                                  # B2 (201 MB/image algorithmic)
         hp = wp = 64
