@@ -53,13 +53,18 @@ class Ranks:
 
 class GradAllReducer:
     """Data-parallel gradient averaging for the trainable backbone (reference: mmdet's MMDistributedDataParallel around
-    the detector, tools/train.py; NCCL all-reduce of every parameter gradient once per step).
+    the detector, mmdet/apis/train.py:95-100; NCCL all-reduce of every parameter gradient once per optimizer step).
 
     Gradients are packed into a few large flat buckets (default 64 MiB of bf16: xGMI is point-to-point, 7 links of
     ~153 GB/s per GPU, so a handful of big RCCL all-reduces beats hundreds of per-tensor ones) in REVERSE parameter order
     (the order backward produces them).  A bucket's all-reduce is launched asynchronously from the autograd hook of its
-    last gradient, so communication of late layers overlaps the backward of early ones; `finish()` waits, averages and
-    writes the result back into `p.grad`.  With one rank everything is a no-op."""
+    last gradient, so communication of late layers overlaps the backward of early ones -- but always in BUCKET ORDER on
+    every rank: bucket k is only launched once buckets < k are, and whatever is left (buckets holding a parameter that
+    got no gradient on this rank, e.g. the mask head on a rank without positives) is launched in order by `finish()`,
+    which waits, averages and writes the result back into `p.grad`.  Ranks may therefore differ in which parameters
+    receive gradients without mis-pairing collectives.  `no_sync()` skips the exchange for the micro-steps of a gradient
+    accumulation (the reference's update_interval=2, mmdet/utils/optimizer.py:23-32): gradients accumulate in p.grad and
+    the step that leaves the context reduces the accumulated values.  With one rank everything is a no-op."""
 
     def __init__(self, params, ranks, bucket_mb=64, comm_dtype=torch.bfloat16):
         self.ranks = ranks
@@ -67,6 +72,8 @@ class GradAllReducer:
         self.params = [p for p in params if p.requires_grad]
         self.buckets = []
         self._where = {}
+        self._sync = True
+        self._next = 0                       # first bucket whose all-reduce has not been launched yet
         if ranks.world == 1:
             return
         limit = int(bucket_mb * (1 << 20)) // torch.empty((), dtype=comm_dtype).element_size()
@@ -83,29 +90,60 @@ class GradAllReducer:
 
     def _seal(self, items, numel):
         dev = items[0][0].device
-        b = dict(items=items, flat=torch.zeros(numel, dtype=self.comm_dtype, device=dev), ready=0, work=None)
+        b = dict(items=items, flat=torch.zeros(numel, dtype=self.comm_dtype, device=dev), seen=set(), work=None,
+                 index=len(self.buckets))
         for p, off in items:
             self._where[id(p)] = (b, off)
         self.buckets.append(b)
 
-    def _on_grad(self, p):
-        b, off = self._where[id(p)]
-        b["flat"][off:off + p.numel()].copy_(p.grad.reshape(-1))
-        b["ready"] += 1
-        if b["ready"] == len(b["items"]):
+    def no_sync(self):
+        """Context manager: backward passes inside it only accumulate into p.grad (no copy, no collective)."""
+        reducer = self
+
+        class _NoSync:
+            def __enter__(self):
+                reducer._sync = False
+
+            def __exit__(self, *exc):
+                reducer._sync = True
+                return False
+
+        return _NoSync()
+
+    def _launch_ready(self):
+        while self._next < len(self.buckets):
+            b = self.buckets[self._next]
+            if len(b["seen"]) < len(b["items"]):
+                return
             b["work"] = self.ranks.dist.all_reduce(b["flat"], op=self.ranks.dist.ReduceOp.SUM, async_op=True)
+            self._next += 1
+
+    def _on_grad(self, p):
+        if not self._sync:
+            return
+        b, off = self._where[id(p)]
+        if b["work"] is not None:            # a second backward before finish(): this bucket is already in flight
+            raise RuntimeError("GradAllReducer: backward ran again before finish(); use no_sync() for accumulation steps")
+        b["flat"][off:off + p.numel()].copy_(p.grad.reshape(-1))
+        b["seen"].add(id(p))
+        if b["index"] == self._next:
+            self._launch_ready()
 
     def finish(self):
-        """Call after loss.backward(): completes every bucket and leaves the rank-averaged gradient in p.grad."""
+        """Call after the (last) loss.backward() of a step: completes every bucket in order and leaves the rank-averaged
+        gradient in p.grad."""
         if self.ranks.world == 1:
             return
         inv = 1.0 / self.ranks.world
-        for b in self.buckets:
-            if b["work"] is None:              # some parameter got no gradient this step: contribute zeros for it
-                for p, off in b["items"]:
+        for b in self.buckets[self._next:]:   # buckets with a parameter that got no gradient: zeros for it, in order
+            for p, off in b["items"]:
+                if id(p) not in b["seen"]:
                     if p.grad is None:
                         b["flat"][off:off + p.numel()].zero_()
-                b["work"] = self.ranks.dist.all_reduce(b["flat"], op=self.ranks.dist.ReduceOp.SUM, async_op=True)
+                    else:                      # accumulated earlier under no_sync() but untouched by the last backward
+                        b["flat"][off:off + p.numel()].copy_(p.grad.reshape(-1))
+            b["work"] = self.ranks.dist.all_reduce(b["flat"], op=self.ranks.dist.ReduceOp.SUM, async_op=True)
+        for b in self.buckets:
             b["work"].wait()
             for p, off in b["items"]:
                 avg = b["flat"][off:off + p.numel()].reshape(p.shape)
@@ -113,11 +151,37 @@ class GradAllReducer:
                     p.grad = (avg * inv).to(p.dtype)
                 else:
                     p.grad.copy_(avg).mul_(inv)
-            b["ready"], b["work"] = 0, None
+            b["seen"], b["work"] = set(), None
+        self._next = 0
 
     def close(self):
         for h in getattr(self, "_hooks", []):
             h.remove()
+
+
+def parse_losses(losses, ranks=None):
+    """mmdet/models/detectors/base.py:185-218 `_parse_losses`: per-key means, `loss` = sum of the keys containing 'loss',
+    and the logged values averaged over ranks -- with ONE all-reduce of the stacked scalars instead of one blocking
+    all-reduce per key (the reference issues len(losses)+1 of them per step).  Returns (loss tensor, log_vars dict of
+    python floats)."""
+    from collections import OrderedDict
+    log_vars = OrderedDict()
+    for name, value in losses.items():
+        if isinstance(value, torch.Tensor):
+            log_vars[name] = value.mean()
+        elif isinstance(value, list):
+            log_vars[name] = sum(v.mean() for v in value)
+        else:
+            raise TypeError(f"{name} is not a tensor or list of tensors")
+    loss = sum(v for k, v in log_vars.items() if "loss" in k)
+    log_vars["loss"] = loss
+    keys = list(log_vars.keys())
+    flat = torch.stack([log_vars[k].detach().float().reshape(()) for k in keys])
+    if ranks is not None and ranks.dist is not None and ranks.world > 1:
+        flat = flat / ranks.world
+        ranks.dist.all_reduce(flat)
+    vals = flat.tolist()
+    return loss, OrderedDict((k, v) for k, v in zip(keys, vals))
 
 
 class _SyncBNFn(torch.autograd.Function):

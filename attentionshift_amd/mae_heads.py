@@ -19,6 +19,41 @@ from . import ops
 from .registry import HEADS
 
 
+def sincos_pos_embed_2d(embed_dim, grid_size, cls_token=False):
+    """mmdet/models/utils/positional_encoding.py:175-225 get_2d_sincos_pos_embed (MAE / MoCo v3): [grid^2 (+1), D] float64
+    numpy table; first half of the channels encodes the w coordinate (meshgrid puts w first), second half h."""
+    import numpy as np
+
+    def one_dim(dim, pos):
+        omega = 1.0 / 10000 ** (np.arange(dim // 2, dtype=np.float64) / (dim / 2.0))
+        out = np.einsum("m,d->md", pos.reshape(-1), omega)
+        return np.concatenate([np.sin(out), np.cos(out)], axis=1)
+
+    assert embed_dim % 4 == 0
+    gh = np.arange(grid_size, dtype=np.float32)
+    grid = np.stack(np.meshgrid(gh, gh), axis=0).reshape(2, 1, grid_size, grid_size)
+    emb = np.concatenate([one_dim(embed_dim // 2, grid[0]), one_dim(embed_dim // 2, grid[1])], axis=1)
+    if cls_token:
+        emb = np.concatenate([np.zeros([1, embed_dim]), emb], axis=0)
+    return emb
+
+
+def load_mae_decoder_weights(module, pretrained, logger=None):
+    """The `init_weights` loading branch shared by the three MAE-decoder heads (mae_bbox_head_rec.py:95-125,
+    mae_bbox_head_mil.py:73-103, mae_mask_head_pointSup.py:108-138): take the MAE pre-training checkpoint, drop the
+    encoder's `patch_embed*` / `blocks*` / `pos_embed` entries and load the rest (decoder_embed, decoder_blocks,
+    decoder_pos_embed, ...) non-strictly."""
+    import os
+    from collections import OrderedDict
+    from .checkpoint import _state_dict_of, load_state_dict
+    if not os.path.isfile(pretrained):
+        raise ValueError(f"checkpoint path {pretrained} is invalid")
+    checkpoint = torch.load(pretrained, map_location="cpu", weights_only=False)
+    sd = OrderedDict((k, v) for k, v in _state_dict_of(checkpoint).items()
+                     if not (k.startswith("patch_embed") or k.startswith("blocks") or k == "pos_embed"))
+    load_state_dict(module, sd, strict=False, logger=logger)
+
+
 class SmallAttnFn(torch.autograd.Function):
     """qkv [Bp,N,3,h,32] -> out [Bp,N,h*32]."""
 
@@ -75,8 +110,10 @@ class DecoderBlock(nn.Module):
 class MAEBoxHeadRec(nn.Module):
     def __init__(self, in_channels=384, img_size=224, patch_size=16, embed_dim=256, depth=4, num_heads=8, mlp_ratio=4.,
                  qkv_bias=True, num_classes=20, with_cls=True, with_reg=True, reg_class_agnostic=False,
-                 with_reconstruct=True, seed_score_thr=0.2, seed_thr=0.2, seed_multiple=0.5, cam_layer=-1, **kwargs):
+                 with_reconstruct=True, seed_score_thr=0.2, seed_thr=0.2, seed_multiple=0.5, cam_layer=-1, pretrained=False,
+                 init_cfg=None, **kwargs):
         super().__init__()
+        self.pretrained, self.init_cfg = pretrained, init_cfg
         self.patch_size, self.num_classes = patch_size, num_classes
         self.with_cls, self.with_reg, self.with_reconstruct = with_cls, with_reg, with_reconstruct
         num_patches = (img_size // patch_size) ** 2
@@ -119,6 +156,16 @@ class MAEBoxHeadRec(nn.Module):
         elif isinstance(m, nn.LayerNorm):
             nn.init.constant_(m.bias, 0)
             nn.init.constant_(m.weight, 1.0)
+
+    def init_weights(self, pretrained=None):
+        """mae_bbox_head_rec.py:95-125: with `pretrained=True` in the config and a checkpoint path here (or in
+        init_cfg['checkpoint']) the MAE decoder weights are loaded; otherwise the constructor's truncated-normal
+        initialisation stands (the reference re-applies it)."""
+        path = pretrained if isinstance(pretrained, str) else (self.init_cfg or {}).get("checkpoint")
+        if self.pretrained and isinstance(path, str):
+            load_mae_decoder_weights(self, path)
+        elif path is not None and not isinstance(path, str):
+            raise TypeError("pretrained must be a str or None")
 
     def interpolate_pos_encoding(self, x, w, h):
         """mae_bbox_head_rec.py:126-146 (bicubic resize of the patch part, the +0.1 trick)."""
@@ -177,8 +224,9 @@ class MAEMaskHeadPointSup(nn.Module):
 
     def __init__(self, roi_feat_size=14, num_classes=80, class_agnostic=False, in_channels=256, img_size=224, patch_size=16,
                  embed_dim=256, depth=4, num_heads=8, mlp_ratio=4., qkv_bias=True, scale_factor=2, scale_mode="bilinear",
-                 loss_weight_mask_start=1.0, **kwargs):
+                 loss_weight_mask_start=1.0, init_cfg=None, **kwargs):
         super().__init__()
+        self.init_cfg = init_cfg
         self.patch_size, self.num_classes, self.class_agnostic = patch_size, num_classes, class_agnostic
         self.scale_factor, self.scale_mode, self.loss_weight_mask_start = scale_factor, scale_mode, loss_weight_mask_start
         self.roi_feat_size = (roi_feat_size, roi_feat_size) if isinstance(roi_feat_size, int) else tuple(roi_feat_size)
@@ -192,6 +240,26 @@ class MAEMaskHeadPointSup(nn.Module):
         self.decoder_box_norm = nn.LayerNorm(embed_dim, eps=1e-6)
         self.conv_logits = nn.Conv2d(embed_dim, 1 if class_agnostic else num_classes, 1)
         self.apply(MAEBoxHeadRec._init_weights)
+        self._fill_sincos()
+
+    def _fill_sincos(self):
+        """mae_mask_head_pointSup.py:105-106: the frozen decoder position table starts as the 2-D sin-cos encoding."""
+        table = sincos_pos_embed_2d(self.decoder_pos_embed.shape[-1], int(self.num_patches ** .5), cls_token=True)
+        with torch.no_grad():
+            self.decoder_pos_embed.copy_(torch.from_numpy(table).float().unsqueeze(0))
+
+    def init_weights(self):
+        """mae_mask_head_pointSup.py:108-148: init_cfg=dict(type='Pretrained', checkpoint=...) loads the MAE decoder
+        weights (encoder entries skipped); without it the sin-cos table + truncated-normal initialisation stand.  The
+        mask-logit convolution is always re-initialised (kaiming normal, fan_out, relu; zero bias)."""
+        if self.init_cfg is not None:
+            assert "checkpoint" in self.init_cfg, "only init_cfg=dict(type='Pretrained', checkpoint=...) is supported"
+            load_mae_decoder_weights(self, self.init_cfg["checkpoint"])
+        else:
+            self.apply(MAEBoxHeadRec._init_weights)
+            self._fill_sincos()
+        nn.init.kaiming_normal_(self.conv_logits.weight, mode="fan_out", nonlinearity="relu")
+        nn.init.constant_(self.conv_logits.bias, 0)
 
     interpolate_pos_encoding = MAEBoxHeadRec.interpolate_pos_encoding
 

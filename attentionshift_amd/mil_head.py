@@ -21,15 +21,29 @@ def _trunc_normal_(tensor, std=0.02):
     return nn.init.trunc_normal_(tensor, std=std, a=-2.0, b=2.0)
 
 
-def roi_align(feat, rois, output_size=7, spatial_scale=1.0 / 16, sampling_ratio=0, aligned=True):
+def roi_align(feat, rois, output_size=7, spatial_scale=1.0 / 16, sampling_ratio=0, aligned=True, max_bytes=1 << 28):
     """feat [B,C,H,W], rois [R,5] (batch index, x1, y1, x2, y2 in image coordinates) -> [R,C,out,out].
     Average of bilinear samples on a regular grid inside each bin; `sampling_ratio=0` uses ceil(roi size / out)
-    samples per bin and axis; `aligned` shifts the box by half a pixel (no minimum size of 1)."""
+    samples per bin and axis; `aligned` shifts the box by half a pixel (no minimum size of 1); a RoI whose adaptive
+    sample grid is empty (non-positive size with aligned=True) gives 0, as mmcv's kernel does.
+    The gathered rows are [R, C, out*g, W]: RoIs are processed in chunks so that this stays under `max_bytes`
+    (512 sampled RoIs x 2 images x 384 channels on an 84x50 map would otherwise be several GB)."""
     out = output_size
     B, C, H, W = feat.shape
     R = rois.shape[0]
     if R == 0:
         return feat.new_zeros(0, C, out, out)
+    per_roi = C * max(H, out * 2) * W * feat.element_size() * 2        # feat[bidx] row + its gathered rows (g ~ 2)
+    chunk = max(1, int(max_bytes // max(per_roi, 1)))
+    if R > chunk:
+        return torch.cat([_roi_align_chunk(feat, rois[i:i + chunk], out, spatial_scale, sampling_ratio, aligned)
+                          for i in range(0, R, chunk)])
+    return _roi_align_chunk(feat, rois, out, spatial_scale, sampling_ratio, aligned)
+
+
+def _roi_align_chunk(feat, rois, out, spatial_scale, sampling_ratio, aligned):
+    B, C, H, W = feat.shape
+    R = rois.shape[0]
     off = 0.5 if aligned else 0.0
     bidx = rois[:, 0].long()
     x1, y1 = rois[:, 1] * spatial_scale - off, rois[:, 2] * spatial_scale - off
@@ -38,6 +52,7 @@ def roi_align(feat, rois, output_size=7, spatial_scale=1.0 / 16, sampling_ratio=
     if not aligned:
         rw, rh = rw.clamp(min=1.0), rh.clamp(min=1.0)
     bw, bh = rw / out, rh / out
+    empty = ((torch.ceil(rw / out) <= 0) | (torch.ceil(rh / out) <= 0)) if sampling_ratio <= 0 else torch.zeros_like(bidx, dtype=torch.bool)
     gw = torch.ceil(rw / out).clamp(min=1).long() if sampling_ratio <= 0 else torch.full_like(bidx, sampling_ratio)
     gh = torch.ceil(rh / out).clamp(min=1).long() if sampling_ratio <= 0 else torch.full_like(bidx, sampling_ratio)
     gmax_w, gmax_h = int(gw.max()), int(gh.max())
@@ -73,7 +88,8 @@ def roi_align(feat, rois, output_size=7, spatial_scale=1.0 / 16, sampling_ratio=
         return fy.gather(3, idx.reshape(R, 1, 1, -1).expand(R, C, out * gmax_h, out * gmax_w))
     fxy = cols(xlo) * wx0.reshape(R, 1, 1, -1) + cols(xhi) * wx1.reshape(R, 1, 1, -1)         # [R,C,out*gh,out*gw]
     fxy = fxy.reshape(R, C, out, gmax_h, out, gmax_w).sum(dim=(3, 5))
-    return fxy / (gh * gw).to(dt)[:, None, None, None]
+    res = fxy / (gh * gw).to(dt)[:, None, None, None]
+    return torch.where(empty[:, None, None, None], torch.zeros_like(res), res)
 
 
 @HEADS.register_module()
@@ -85,6 +101,7 @@ class MAEBoxHeadMIL(nn.Module):
                  num_classes=20, num_layers_query=12, loss_mil_factor=1.0, hidden_dim=1024, roi_size=7, pretrained=False,
                  **kwargs):
         super().__init__()
+        self.pretrained, self.init_cfg = pretrained, kwargs.get("init_cfg")
         self.num_classes, self.num_layers_query = num_classes, num_layers_query
         self.loss_mil_factor, self.hidden_dim, self.roi_size = loss_mil_factor, hidden_dim, roi_size
         self.with_decoder_embed = in_channels != embed_dim
@@ -106,6 +123,16 @@ class MAEBoxHeadMIL(nn.Module):
         elif isinstance(m, nn.LayerNorm):
             nn.init.constant_(m.bias, 0)
             nn.init.constant_(m.weight, 1.0)
+
+    def init_weights(self, pretrained=None):
+        """mae_bbox_head_mil.py:73-103: `pretrained=True` + a checkpoint path loads the MAE decoder entries that exist in
+        this head (decoder_embed, norm); otherwise the constructor's initialisation stands."""
+        from .mae_heads import load_mae_decoder_weights
+        path = pretrained if isinstance(pretrained, str) else (self.init_cfg or {}).get("checkpoint")
+        if self.pretrained and isinstance(path, str):
+            load_mae_decoder_weights(self, path)
+        elif path is not None and not isinstance(path, str):
+            raise TypeError("pretrained must be a str or None")
 
     def mil_losses(self, cls_score, labels):
         cls_score = cls_score.clamp(1e-6, 1 - 1e-6)

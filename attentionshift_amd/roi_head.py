@@ -642,6 +642,7 @@ class AttnShiftRoIHead(nn.Module):
         # parity tests set this to a list: every image's sampled refinement points and grid seeds are appended to it
         # (the fast RNG mode draws on the device, so a checker needs the draws to re-run the chain on the same samples)
         self.capture = None
+        self.ranks = None                         # dist.Ranks of a multi-rank run: loss normalisers are averaged over ranks
         self.visualize = visualize
         self.epoch, self.epoch_semantic_centers = epoch, epoch_semantic_centers
         self.num_semantic_points = num_semantic_points
@@ -690,7 +691,8 @@ class AttnShiftRoIHead(nn.Module):
                 loss_cls_weight=bh.loss_point_cls_cfg.get("loss_weight", 1.0),
                 gamma=bh.loss_point_cls_cfg.get("gamma", 2.0), alpha=bh.loss_point_cls_cfg.get("alpha", 0.25),
                 point_pos_weight=_get(rcnn, "point_pos_weight", 1),
-                cls_cost=_get(pa, "cls_cost", {}).get("weight", 1.0), reg_cost=_get(pa, "reg_cost", {}).get("weight", 1.0)))
+                cls_cost=_get(pa, "cls_cost", {}).get("weight", 1.0), reg_cost=_get(pa, "reg_cost", {}).get("weight", 1.0),
+                ranks=getattr(self, "ranks", None)))        # reduce_mean of the matched-token count (stdroi:3430-3514)
         asg = dict(_get(rcnn, "assigner", None) or {})
         smp = dict(_get(rcnn, "sampler", None) or {})
         sampling_results = []
@@ -776,7 +778,8 @@ class AttnShiftRoIHead(nn.Module):
                 mask_pred = self.mask_head(self._roi_extract(x, mrois, "mask_roi_extractor"))
             else:
                 mask_pred = mboxes.new_zeros(0, self.mask_head.num_classes, 1, 1)
-            segm = I.get_seg_masks(mask_pred, dets, labels, self.mask_head.num_classes, meta["ori_shape"],
+            # the INPUT-scale boxes go in (test_mixins.py:293-331): get_seg_masks divides by scale_factor once itself
+            segm = I.get_seg_masks(mask_pred, mboxes, labels, self.mask_head.num_classes, meta["ori_shape"],
                                    meta.get("scale_factor", 1.0), rescale, _get(cfg, "mask_thr_binary", 0.5),
                                    self.mask_head.class_agnostic)
             out.append((boxes_res, segm))

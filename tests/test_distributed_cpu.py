@@ -191,3 +191,113 @@ def test_sync_batchnorm_single_rank_is_plain_batchnorm():
         for k, v in env.items():
             if v is not None:
                 os.environ[k] = v
+
+
+TRAIN_WORKER = textwrap.dedent("""
+    import os, sys, json
+    sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+    import torch
+    import test_forward_train as TF
+    from attentionshift_amd import mae_heads
+    from attentionshift_amd.dist import Ranks, GradAllReducer, parse_losses
+    mae_heads._Attention.forward = TF._torch_attention          # CPU stand-in for the HIP small-N attention
+    r = Ranks(backend="gloo")
+    torch.manual_seed(0)                                         # identical replicas
+    stem = torch.nn.Conv2d(3, 48, 16, 16)                        # stands in for the backbone: image -> stride-16 map
+    head = TF._head()
+    params = [p for p in list(stem.parameters()) + list(head.parameters()) if p.requires_grad]
+    d = TF._inputs(torch.Generator().manual_seed(1))
+    img = torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(7))
+    empty_rank = int(os.environ.get("EMPTY_RANK", "-1"))         # this rank's image has no object: no mask-head gradient
+
+    def losses_of(i, micro=0):
+        gts, labels = d["gts"][i], d["labels"][i]
+        if i == empty_rank:
+            gts, labels = gts[:0], labels[:0]
+        fmap = stem(img[i:i + 1] + 0.1 * micro)
+        return head.forward_train(
+            fmap, [d["metas"][i]], [d["props"][i]], [gts], [labels], point_cls=d["point_cls"][i:i + 1],
+            point_reg=d["point_reg"][i:i + 1], gt_points=[d["gt_points"][i][:gts.shape[0]]], gt_points_labels=[labels],
+            mask_point_coords=[d["coords"][i][:gts.shape[0]]], mask_point_labels=[d["plabels"][i][:gts.shape[0]]],
+            semantic_centers_split=[d["centres"][i][:gts.shape[0]]], generator=torch.Generator().manual_seed(5 + i))
+
+    def grads():
+        return [None if p.grad is None else p.grad.clone() for p in params]
+
+    # ---- single-process reference: every rank computes BOTH images' steps and averages by hand ----
+    accum = int(os.environ.get("ACCUM", "1"))
+    want, logs = None, []
+    for i in range(2):
+        for p in params:
+            p.grad = None
+        for micro in range(accum):
+            loss, lv = parse_losses(losses_of(i, micro))
+            (loss / accum).backward()
+            if micro == accum - 1:
+                logs.append(lv)
+        g = [torch.zeros_like(p) if p.grad is None else p.grad.clone() for p in params]
+        want = g if want is None else [a + b for a, b in zip(want, g)]
+    want = [w / 2 for w in want]
+    # ---- the data-parallel step: this rank's image only ----
+    for p in params:
+        p.grad = None
+    red = GradAllReducer(params, r, bucket_mb=0.02, comm_dtype=torch.float32)
+    for micro in range(accum):
+        loss, lv = parse_losses(losses_of(r.rank, micro), r)
+        if micro < accum - 1:
+            with red.no_sync():
+                (loss / accum).backward()
+        else:
+            (loss / accum).backward()
+    red.finish()
+    err = max(float((p.grad - w).abs().max() / (w.abs().max() + 1e-12)) for p, w in zip(params, want))
+    mean_logs = {k: 0.5 * (logs[0][k] + logs[1][k]) for k in logs[0] if k in logs[1]}
+    log_err = max(abs(lv[k] - v) for k, v in mean_logs.items())
+    print(json.dumps(dict(rank=r.rank, nb=len(red.buckets), err=err, log_err=log_err, keys=sorted(lv))), flush=True)
+    red.close()
+    r.close()
+""") % (ROOT, ROOT)
+
+
+def _run_train_workers(extra_env):
+    import json
+    port = free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), OMP_NUM_THREADS="2", **extra_env)
+        procs.append(subprocess.Popen([sys.executable, "-c", TRAIN_WORKER], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        o, e = p.communicate(timeout=300)
+        assert p.returncode == 0, e[-3000:]
+        outs.append(json.loads(o.strip().splitlines()[-1]))
+    return outs
+
+
+def test_two_rank_training_step_reproduces_single_process_gradients():
+    """The TRAINING STEP, not just the reducer: each rank runs the RoI head's forward_train (point / box / mask losses on
+    its own image) + parse_losses + backward with the hook-launched bucketed all-reduce; the averaged gradients of every
+    parameter (stem, box head, mask head) equal the hand-averaged single-process gradients, and the logged losses equal
+    the rank means (one fused all-reduce, base.py:185-218)."""
+    outs = _run_train_workers({})
+    for o in outs:
+        assert o["nb"] >= 2 and o["err"] < 1e-5 and o["log_err"] < 1e-5, o
+        assert "loss" in o["keys"] and "loss_mask" in o["keys"]
+
+
+def test_two_rank_training_step_with_a_rank_that_skips_the_mask_head():
+    """Rank 1's image has no object: its mask head (and box regression) get NO gradient there while rank 0's do -- the
+    collectives still pair up because buckets are launched in bucket order on every rank."""
+    outs = _run_train_workers({"EMPTY_RANK": "1"})
+    for o in outs:
+        assert o["err"] < 1e-5, o
+
+
+def test_two_rank_gradient_accumulation_with_no_sync():
+    """update_interval = 2 (mmdet/utils/optimizer.py:23-32): the first micro-step only accumulates (no_sync), the second
+    reduces the accumulated gradients."""
+    outs = _run_train_workers({"ACCUM": "2"})
+    for o in outs:
+        assert o["err"] < 1e-5, o

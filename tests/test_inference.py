@@ -115,3 +115,27 @@ def test_simple_test_composition(monkeypatch):
     head.mask_head = None
     only_boxes = head.simple_test(fmap, props, metas, rescale=False)
     assert len(only_boxes[0]) == 5 and all((b[:, 2] <= 224).all() for b in only_boxes[0])
+
+
+def test_simple_test_pastes_masks_at_the_rescaled_box(monkeypatch):
+    """scale_factor 2, rescale=True: a detection at input-scale box [100, 100, 200, 200] must put its mask at
+    [50, 50, 100, 100] of the ORIGINAL image (boxes divided by the scale factor ONCE, test_mixins.py:293-331)."""
+    monkeypatch.setattr(mae_heads._Attention, "forward", _torch_attention)
+    torch.manual_seed(0)
+    dec = dict(in_channels=48, embed_dim=64, depth=1, num_heads=2, num_classes=5)
+    head = A.build_head(dict(
+        type="AttnShiftRoIHead",
+        bbox_roi_extractor=dict(type="SingleRoIExtractor", featmap_strides=[16], roi_layer=dict(type="RoIAlign", output_size=7, sampling_ratio=0)),
+        mask_roi_extractor=dict(type="SingleRoIExtractor", featmap_strides=[16], roi_layer=dict(type="RoIAlign", output_size=14, sampling_ratio=0)),
+        bbox_head=dict(type="MAEBoxHeadRec", with_reconstruct=False, cam_layer=3, **dec),
+        mask_head=dict(type="MAEMaskHeadPointSup", scale_factor=2, scale_mode="bicubic", **dec),
+        test_cfg=dict(score_thr=0.0, nms=dict(type="nms", iou_threshold=0.5), max_per_img=1, mask_thr_binary=0.5)))
+    det = torch.tensor([[100.0, 100.0, 200.0, 200.0, 0.9]])
+    monkeypatch.setattr(I, "get_det_bboxes", lambda *a, **k: (det / torch.tensor([2.0, 2.0, 2.0, 2.0, 1.0]), torch.tensor([1])))
+    monkeypatch.setattr(head.mask_head, "forward", lambda feats: torch.full((feats.shape[0], 5, 28, 28), 8.0))   # all-foreground
+    fmap = torch.rand(1, 48, 14, 14)
+    metas = [dict(img_shape=(224, 224, 3), ori_shape=(112, 112, 3), scale_factor=np.array([2.0, 2.0, 2.0, 2.0], dtype=np.float32))]
+    (boxes, segm), = head.simple_test(fmap, [torch.tensor([[100.0, 100.0, 200.0, 200.0]])], metas, rescale=True)
+    mask = segm[1][0]
+    ys, xs = np.nonzero(mask)
+    assert (ys.min(), ys.max(), xs.min(), xs.max()) == (50, 99, 50, 99), (ys.min(), ys.max(), xs.min(), xs.max())

@@ -78,3 +78,16 @@ def test_roi_head_builds_the_mil_head_from_the_reference_config():
     assert idx[0].shape == (2,) and head._mil_selector.last_loss is not None
     # without a feature map the median-area stand-in answers (callers that only run the pseudo-label path)
     assert head.layer_selector(boxes, labels, None)[0].shape == (2,)
+
+
+def test_roi_align_chunked_equals_unchunked_and_degenerate_rois_are_zero():
+    from attentionshift_amd.mil_head import roi_align
+    gen = torch.Generator().manual_seed(5)
+    feat = torch.randn(2, 6, 20, 24, generator=gen)
+    xy = torch.rand(37, 2, generator=gen) * 200
+    rois = torch.cat((torch.randint(0, 2, (37, 1), generator=gen).float(), xy, xy + 5 + torch.rand(37, 2, generator=gen) * 150), 1)
+    rois[3, 3:] = rois[3, 1:3] - 4.0                       # x2 < x1, y2 < y1: empty adaptive grid
+    full = roi_align(feat, rois, 7, 1.0 / 16, 0, True)
+    small = roi_align(feat, rois, 7, 1.0 / 16, 0, True, max_bytes=1)      # one RoI per chunk
+    assert torch.equal(full, small)
+    assert (full[3] == 0).all() and full[4].abs().sum() > 0
