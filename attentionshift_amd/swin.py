@@ -78,9 +78,12 @@ class SwinTransformerBlock(nn.Module):
     def __init__(self, dim, input_resolution, num_heads, window_size=7, shift_size=0, mlp_ratio=4., qkv_bias=True,
                  qk_scale=None, drop=0., attn_drop=0., drop_path=0., compute_dtype=torch.bfloat16, return_attention=True):
         super().__init__()
-        self.dim, self.input_resolution, self.num_heads = dim, tuple(input_resolution), num_heads
+        # input_resolution=None: the detection variant (mmdet/models/backbones/swin_transformer.py:170-200) -- the grid is
+        # given per call and padded to a window multiple inside the kernel, the window is never shrunk
+        self.dim, self.num_heads = dim, num_heads
+        self.input_resolution = None if input_resolution is None else tuple(input_resolution)
         self.window_size, self.shift_size = window_size, shift_size
-        if min(self.input_resolution) <= self.window_size:          # :211-214
+        if self.input_resolution is not None and min(self.input_resolution) <= self.window_size:          # :211-214
             self.shift_size = 0
             self.window_size = min(self.input_resolution)
         assert 0 <= self.shift_size < self.window_size
@@ -91,11 +94,11 @@ class SwinTransformerBlock(nn.Module):
         self.compute_dtype = compute_dtype
         self.return_attention = return_attention
 
-    def _forward_train(self, x):
+    def _forward_train(self, x, hw=None):
         """Autograd path (train() + grad enabled): the window attention core runs on the HIP forward / backward kernels
         (WindowAttnFn); LayerNorm, the Linear layers and GELU are torch ops (library GEMMs)."""
         B, L, C = x.shape
-        H = W = int(math.sqrt(L))
+        H, W = hw if hw is not None else (int(math.sqrt(L)),) * 2
         cd = self.compute_dtype
         y = F.layer_norm(x, (C,), self.norm1.weight, self.norm1.bias, self.norm1.eps).to(cd)
         qkv = F.linear(y, self.attn.qkv.weight.to(cd)).reshape(B, H, W, 3 * C)
@@ -109,11 +112,13 @@ class SwinTransformerBlock(nn.Module):
                      self.mlp.fc2.weight.to(cd), self.mlp.fc2.bias.to(cd))
         return x + z.float(), None
 
-    def forward(self, x):
+    def forward(self, x, hw=None):
+        """x [B, H*W, C]; hw = (H, W) of the token grid (default: square)."""
         if self.training and torch.is_grad_enabled():
-            return self._forward_train(x)
+            return self._forward_train(x, hw)
         B, L, C = x.shape
-        H = W = int(math.sqrt(L))
+        H, W = hw if hw is not None else (int(math.sqrt(L)),) * 2
+        assert H * W == L, "token count does not match the grid"
         cd = self.compute_dtype
         w = lambda p: p.detach().to(cd).contiguous()
         y = F.layer_norm(x, (C,), self.norm1.weight, self.norm1.bias, self.norm1.eps).to(cd)

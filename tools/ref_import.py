@@ -122,3 +122,20 @@ def load_swin():
     _stub("timm.models.layers", DropPath=DropPath, to_2tuple=lambda v: (v, v) if not isinstance(v, tuple) else v,
           trunc_normal_=lambda t, std=0.02: nn.init.trunc_normal_(t, std=std, a=-2 * std, b=2 * std))
     return _load_by_path("ref_swin", os.path.join(REF, "models/swin_transformer.py"))
+
+
+def load_swin_det():
+    """mmdet/models/backbones/swin_transformer.py (the BACKBONES-registered detection backbone, :448-630) with timm /
+    mmcv_custom / mmdet stubbed as above."""
+    import logging
+    load_swin()                                  # installs the timm.models.layers stub
+    _stub("mmcv_custom", load_checkpoint=lambda *a, **k: None)
+    _stub("mmdet"); _stub("mmdet.utils", get_root_logger=lambda *a, **k: logging.getLogger("ref"))
+    _stub("mmdet.models"); _stub("mmdet.models.builder", BACKBONES=_FakeRegistry())
+    _stub("mmdet.models.backbones")
+    path = os.path.join(REF, "mmdet/models/backbones/swin_transformer.py")
+    spec = importlib.util.spec_from_file_location("mmdet.models.backbones.swin_transformer", path)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["mmdet.models.backbones.swin_transformer"] = mod
+    spec.loader.exec_module(mod)
+    return mod
