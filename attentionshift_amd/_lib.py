@@ -51,6 +51,8 @@ SIGNATURES = {
     "as_small_attn_fwd": (_c_int, [_c_void_p] * 3 + [_c_int] * 5 + [_c_void_p]),
     "as_small_attn_bwd_workspace_bytes": (_c_size_t, [_c_int] * 3),
     "as_small_attn_bwd": (_c_int, [_c_void_p] * 6 + [_c_size_t] + [_c_int] * 5 + [_c_void_p]),
+    "as_roi_align_fwd": (_c_int, [_c_void_p] * 3 + [_c_int] * 6 + [_c_float] + [_c_int] * 2 + [_c_void_p]),
+    "as_roi_align_bwd": (_c_int, [_c_void_p] * 3 + [_c_int] * 6 + [_c_float] + [_c_int] * 2 + [_c_void_p]),
     "as_chamfer_2d_fwd": (_c_int, [_c_void_p] * 6 + [_c_int] * 3 + [_c_void_p]),
     "as_chamfer_2d_bwd": (_c_int, [_c_void_p] * 8 + [_c_int] * 3 + [_c_void_p]),
     "as_merge_plan": (_c_int, [_c_void_p] * 4 + [_c_int] * 2 + [_c_void_p]),

@@ -19,6 +19,21 @@ from . import ops
 from .registry import HEADS
 
 
+_RESIZE = {}
+
+
+def _resize_matrix(n, scale, mode, device, dtype):
+    """[n * scale, n] matrix of F.interpolate(..., scale_factor=scale, mode=mode, align_corners=True) along one axis
+    (obtained from ATen itself on the identity, so the coefficients are exactly the library's), cached."""
+    key = (n, scale, mode, str(device), dtype)
+    if key not in _RESIZE:
+        eye = torch.eye(n, dtype=torch.float32).view(1, n, n, 1)           # channel = input index, H = the resized axis
+        with torch.no_grad():
+            a = F.interpolate(eye, scale_factor=(scale, 1), mode=mode, align_corners=True)[0, :, :, 0].t().contiguous()
+        _RESIZE[key] = a.to(device=device, dtype=dtype)
+    return _RESIZE[key]
+
+
 def sincos_pos_embed_2d(embed_dim, grid_size, cls_token=False):
     """mmdet/models/utils/positional_encoding.py:175-225 get_2d_sincos_pos_embed (MAE / MoCo v3): [grid^2 (+1), D] float64
     numpy table; first half of the channels encodes the w coordinate (meshgrid puts w first), second half h."""
@@ -275,9 +290,16 @@ class MAEMaskHeadPointSup(nn.Module):
         x = x + self.interpolate_pos_encoding(x, W * self.patch_size, H * self.patch_size)[:, 1:]
         for blk in self.decoder_blocks:
             x = blk(x)
-        x = self.decoder_box_norm(x).view(B, W, H, C).permute(0, 3, 1, 2)
-        x = F.interpolate(x, scale_factor=self.scale_factor, mode=self.scale_mode, align_corners=True)
-        return self.conv_logits(x)
+        x = self.decoder_box_norm(x).view(B, W, H, C)                      # [R, h, w, C] tokens on the RoI grid
+        # F.interpolate(scale_factor, mode, align_corners=True) is a fixed separable linear map: applied as two small
+        # matrix products (ATen's bicubic BACKWARD kernel needs 0.74 s for 256 RoIs x 256 channels on this GPU), and the
+        # 1x1 mask-logit convolution as a matmul over the channel axis (MIOpen falls back to a naive weight-gradient
+        # kernel for it).  Same operations in the same order as mae_mask_head_pointSup.py:186-189.
+        Ah = _resize_matrix(x.shape[1], self.scale_factor, self.scale_mode, x.device, x.dtype)
+        Aw = _resize_matrix(x.shape[2], self.scale_factor, self.scale_mode, x.device, x.dtype)
+        x = torch.einsum("oh,bhwc,pw->bopc", Ah, x, Aw)
+        wl = self.conv_logits.weight.view(self.conv_logits.out_channels, -1)
+        return F.linear(x, wl, self.conv_logits.bias).permute(0, 3, 1, 2)
 
     def loss(self, mask_pred, mask_targets, labels):
         """mask_pred [R, K, P] logits already sampled at the points (stdroi:3154), mask_targets [R, P] with 2 = ignore."""

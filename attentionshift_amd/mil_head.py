@@ -21,6 +21,26 @@ def _trunc_normal_(tensor, std=0.02):
     return nn.init.trunc_normal_(tensor, std=std, a=-2.0, b=2.0)
 
 
+class _RoIAlignFn(torch.autograd.Function):
+    """as_roi_align_fwd / as_roi_align_bwd under autograd.  feat [B,C,H,W] (any strides) -> [R, out*out, C]."""
+
+    @staticmethod
+    def forward(ctx, feat, rois, out, scale, sampling_ratio, aligned):
+        from . import ops
+        nhwc = feat.permute(0, 2, 3, 1).contiguous()             # a no-op copy when feat views token-major storage
+        ctx.save_for_backward(rois)
+        ctx.cfg = (tuple(nhwc.shape), out, scale, sampling_ratio, aligned)
+        return ops.roi_align_fwd(nhwc, rois, out, scale, sampling_ratio, aligned)
+
+    @staticmethod
+    def backward(ctx, dout):
+        from . import ops
+        (rois,) = ctx.saved_tensors
+        shape, out, scale, sampling_ratio, aligned = ctx.cfg
+        dfeat = ops.roi_align_bwd(dout.contiguous().float(), rois, shape, out, scale, sampling_ratio, aligned)
+        return dfeat.permute(0, 3, 1, 2), None, None, None, None, None
+
+
 def roi_align(feat, rois, output_size=7, spatial_scale=1.0 / 16, sampling_ratio=0, aligned=True, max_bytes=1 << 28):
     """feat [B,C,H,W], rois [R,5] (batch index, x1, y1, x2, y2 in image coordinates) -> [R,C,out,out].
     Average of bilinear samples on a regular grid inside each bin; `sampling_ratio=0` uses ceil(roi size / out)
@@ -33,6 +53,11 @@ def roi_align(feat, rois, output_size=7, spatial_scale=1.0 / 16, sampling_ratio=
     R = rois.shape[0]
     if R == 0:
         return feat.new_zeros(0, C, out, out)
+    if feat.is_cuda and C % 4 == 0:
+        # the HIP kernel (csrc/roi_align.hip): token-major in, [R, out*out, C] out; the [R, C, out, out] the heads expect
+        # is a permuted VIEW of it (they flatten straight back to tokens)
+        y = _RoIAlignFn.apply(feat.float(), rois.float().contiguous(), out, float(spatial_scale), int(sampling_ratio), bool(aligned))
+        return y.view(R, out, out, C).permute(0, 3, 1, 2).to(feat.dtype)
     per_roi = C * max(H, out * 2) * W * feat.element_size() * 2        # feat[bidx] row + its gathered rows (g ~ 2)
     chunk = max(1, int(max_bytes // max(per_roi, 1)))
     if R > chunk:

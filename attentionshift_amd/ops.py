@@ -640,3 +640,26 @@ def rank_select(mask, ranks):
     ws = torch.empty(nbytes, device=mask.device, dtype=torch.uint8)
     _lib.check(lib.as_rank_select(_p(mask), _p(r32), _p(out), _p(ws), nbytes, M, HW, K, _stream()), "as_rank_select")
     return out.long()
+
+
+def roi_align_fwd(feat_nhwc, rois, out_size, spatial_scale, sampling_ratio=0, aligned=True):
+    """feat [B,H,W,C] fp32 token-major, rois [R,5] fp32 -> [R, out*out, C] (csrc/roi_align.hip)."""
+    lib = _lib.load()
+    _chk(feat_nhwc, rois, dtype=torch.float32)
+    B, H, W, C = feat_nhwc.shape
+    R = rois.shape[0]
+    out = torch.empty(R, out_size * out_size, C, device=feat_nhwc.device, dtype=torch.float32)
+    _lib.check(lib.as_roi_align_fwd(_p(feat_nhwc), _p(rois), _p(out), B, H, W, C, R, int(out_size), float(spatial_scale),
+                                    int(sampling_ratio), int(bool(aligned)), _stream()), "as_roi_align_fwd")
+    return out
+
+
+def roi_align_bwd(dout, rois, shape, out_size, spatial_scale, sampling_ratio=0, aligned=True):
+    """dout [R, out*out, C] -> dfeat [B,H,W,C] (float atomics)."""
+    lib = _lib.load()
+    _chk(dout, rois, dtype=torch.float32)
+    B, H, W, C = shape
+    dfeat = torch.empty(B, H, W, C, device=dout.device, dtype=torch.float32)
+    _lib.check(lib.as_roi_align_bwd(_p(dout), _p(rois), _p(dfeat), B, H, W, C, rois.shape[0], int(out_size),
+                                    float(spatial_scale), int(sampling_ratio), int(bool(aligned)), _stream()), "as_roi_align_bwd")
+    return dfeat

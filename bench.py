@@ -198,8 +198,10 @@ def build(device, rng_mode="fast", train=False, ranks=None, mil=False):
     def train_step():
         out = bb(img)
         fmap = out["feature"][2].float()               # the stride-16 map the RoI extractors read (roi_skip_fpn=True)
-        losses, labels = head.train_losses(fmap, metas, proposals, vit_feat, out["attns"], out["outputs_class"].float(),
-                                           out["outputs_coord"].float(), gt_points, gt_labels, generator=gen, **train_kw)
+        # the heads' Linear layers in bf16 (the reference trains under apex O1: fp16 GEMMs, fp32 norms / losses)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            losses, labels = head.train_losses(fmap, metas, proposals, vit_feat, out["attns"], out["outputs_class"].float(),
+                                               out["outputs_coord"].float(), gt_points, gt_labels, generator=gen, **train_kw)
         loss, log_vars = parse_losses(losses, ranks)
         loss.backward()
         reducer.finish()

@@ -293,6 +293,18 @@ size_t as_small_attn_bwd_workspace_bytes(int Bp, int N, int h);
 int as_small_attn_bwd(const void* qkv, const void* out, const void* d_out, const float* lse, void* dqkv, void* workspace,
                       size_t workspace_bytes, int Bp, int N, int h, int d, int dtype, as_stream_t stream);
 
+/* RoIAlign on the stride-16 feature map (mmcv.ops.RoIAlign as configured at
+ * configs/mae/attnshift_voc12aug.py:64-68, 123-127; call sites stdroi:2958 and the RoI head's bbox / mask forward):
+ * adaptive sampling (sampling_ratio = 0 -> ceil(roi size / out) samples per bin and axis), aligned half-pixel shift,
+ * average pooling.  Token-major layouts:
+ *   feat [B,H,W,C] fp32, rois [R,5] = (batch index, x1, y1, x2, y2) in image coordinates, out [R, out*out, C] fp32
+ *   backward: dfeat [B,H,W,C] is written completely by a deterministic gather (no atomics; C a multiple of 8, maps of up
+ *   to 8192 pixels) */
+int as_roi_align_fwd(const float* feat, const float* rois, float* out, int B, int H, int W, int C, int R, int out_size,
+                     float spatial_scale, int sampling_ratio, int aligned, as_stream_t stream);
+int as_roi_align_bwd(const float* dout, const float* rois, float* dfeat, int B, int H, int W, int C, int R, int out_size,
+                     float spatial_scale, int sampling_ratio, int aligned, as_stream_t stream);
+
 /* 2-D chamfer distance, the reference's second native op (mmdet/ops/chamfer_2d/src/chamfer_2d.cu:12-161 behind
  * mmdet/ops/chamfer_2d/dist_chamfer_2d.py:11-58; off the hot path): xyz1 [B,n,2], xyz2 [B,m,2] fp32 ->
  * dist1 [B,n] / dist2 [B,m] = squared distance to the nearest point of the other set, idx1 / idx2 int32 its index

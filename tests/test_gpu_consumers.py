@@ -1,0 +1,104 @@
+"""SURVEY 8f-1 on the DEVICE path: the consumers of the pseudo labels (box targets / losses, the point-supervised mask
+loss, the point-token loss incl. its Hungarian targets, the mask-point targets) evaluated on CUDA tensors against the
+fixtures produced by executing the reference's own functions (tools/gen_golden_head_losses.py,
+gen_golden_point_loss.py, gen_golden_consumers.py) -- the GPU twins of tests/test_head_losses_golden.py,
+tests/test_point_loss.py and tests/test_mask_targets.py."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+import attentionshift_amd as A
+from attentionshift_amd import mae_heads, mask_targets as MT, point_loss as PL
+
+pytestmark = pytest.mark.gpu
+
+
+def test_box_targets_and_losses_equal_the_reference_on_the_device(golden):
+    g = golden("head_losses")
+    t = lambda k: torch.from_numpy(g[k]).cuda()
+    K = int(g["K"])
+    res = [types.SimpleNamespace(pos_bboxes=t(f"pos_bboxes{i}").reshape(-1, 4), neg_bboxes=t(f"neg_bboxes{i}").reshape(-1, 4),
+                                 pos_gt_bboxes=t(f"pos_gt_bboxes{i}").reshape(-1, 4), pos_gt_labels=t(f"pos_gt_labels{i}"))
+           for i in range(int(g["n_img"]))]
+    for tag, decoded, loss_cfg in (("giou", True, dict(type="GIoULoss", loss_weight=10.0)), ("l1", False, dict(type="L1Loss", loss_weight=1.0))):
+        head = A.build_head(dict(type="MAEBoxHeadRec", in_channels=32, embed_dim=32, depth=1, num_heads=1, num_classes=K,
+                                 with_reconstruct=False, reg_decoded_bbox=decoded, loss_bbox=loss_cfg,
+                                 bbox_coder=dict(type="DeltaXYWHBBoxCoder", target_means=[0.] * 4, target_stds=[.1, .1, .2, .2]))).cuda()
+        targets = head.get_targets(res)
+        for got, name in zip(targets, ("labels", "label_weights", "bbox_targets", "bbox_weights")):
+            want = t(f"{tag}_{name}")
+            assert got.is_cuda and got.shape == want.shape and torch.allclose(got.float(), want.float(), atol=1e-5), (tag, name)
+        out = head.loss(t("cls_score"), t("bbox_pred"), t("rois"), *targets)
+        for k in ("loss_cls", "acc", "loss_bbox"):
+            assert abs(float(out[k]) - float(g[f"{tag}_{k}"][0])) <= 5e-5 * max(1.0, abs(float(g[f"{tag}_{k}"][0]))), (tag, k)
+
+
+def test_mask_point_loss_equals_the_reference_on_the_device(golden):
+    g = golden("head_losses")
+    t = lambda k: torch.from_numpy(g[k]).cuda()
+    head = mae_heads.MAEMaskHeadPointSup(num_classes=int(g["K"]), in_channels=32, embed_dim=32, depth=1, num_heads=1).cuda()
+    for kind in ("bool", "long"):
+        got = head.loss(t("mask_pred"), t(f"mask_tgt_{kind}"), t("mask_labels"))["loss_mask"]
+        assert got.is_cuda and abs(float(got) - float(g[f"mask_loss_{kind}"][0])) < 2e-6, kind
+    assert float(head.loss(t("mask_pred")[:0], t("mask_tgt_long")[:0], t("mask_labels")[:0])["loss_mask"]) == 0.0
+
+
+def test_point_token_loss_equals_the_reference_roi_head_loss_on_the_device(golden):
+    g = golden("point_loss")
+    for c in range(int(g["n"])):
+        cls, reg = torch.from_numpy(g[f"cls{c}"]).cuda(), torch.from_numpy(g[f"reg{c}"]).cuda()
+        pts = [torch.from_numpy(g[f"pts{c}_{i}"]).reshape(-1, 2).cuda() for i in range(2)]
+        labels = [torch.from_numpy(g[f"labels{c}_{i}"]).cuda() for i in range(2)]
+        shapes = [tuple(int(v) for v in s) for s in g[f"shapes{c}"]]
+        tl, tw, _, _ = PL.point_targets(cls, reg, pts, labels, shapes, 20, point_pos_weight=1, cls_cost=1.0, reg_cost=10.0)
+        assert torch.equal(tl.cpu(), torch.from_numpy(g[f"labels_all{c}"])) and torch.equal(tw.cpu(), torch.from_numpy(g[f"label_w{c}"]))
+        out = PL.point_token_loss(cls, reg, pts, labels, shapes, num_classes=20, loss_point_weight=10.0, loss_cls_weight=1.0,
+                                  cls_cost=1.0, reg_cost=10.0)
+        want_cls = float(g[f"loss_point_cls{c}"][0])
+        if np.isfinite(want_cls):
+            assert abs(float(out["loss_point_cls"]) - want_cls) <= 2e-5 * abs(want_cls), c
+            assert abs(float(out["loss_point"]) - float(g[f"loss_point{c}"][0])) <= 2e-5, c
+            assert abs(float(out["pos_point_acc"]) - float(g[f"pos_point_acc{c}"][0])) <= 1e-4, c
+
+
+def test_mask_point_targets_match_the_reference_on_the_device(golden):
+    g = golden("consumers")
+    t = lambda a: torch.from_numpy(np.asarray(a)).cuda()
+    coords = [t(g[f"coords{i}"]) for i in range(3)]
+    labels = [t(g[f"labels{i}"]) for i in range(3)]
+    centers = [[t(g[f"center{i}_{k}"]) for k in range(len(g[f"ncenters{i}"]))] for i in range(3)]
+    out_c, out_l = MT.update_coords_with_semantic_centers(coords, labels, centers)
+    for i in range(3):
+        assert out_c[i].is_cuda and np.array_equal(g[f"out_coords{i}"], out_c[i].cpu().numpy()), i
+        assert np.array_equal(g[f"out_labels{i}"], out_l[i].cpu().numpy()), i
+    got = MT.get_point_coords_wrt_box(t(g["boxes"]), t(g["pts"]))
+    assert np.array_equal(g["pts_wrt_box"], got.cpu().numpy())
+
+
+@pytest.mark.parametrize("out,C,hw", [(7, 48, (14, 17)), (14, 768, (64, 64))])
+def test_roi_align_hip_matches_the_tensor_op_restatement(out, C, hw):
+    """as_roi_align_fwd / _bwd (csrc/roi_align.hip) vs mil_head's tensor-op RoIAlign (the restatement of mmcv's adaptive,
+    aligned, average-pooled RoIAlign that the CPU tests hold to its definition): forward 1e-5, backward (float atomics)
+    1e-4 of the gradient range; boxes that leave the map, a degenerate box (empty sample grid -> 0) and several images."""
+    from attentionshift_amd.mil_head import _roi_align_chunk, roi_align
+    gen = torch.Generator().manual_seed(9)
+    H, W = hw
+    feat = torch.randn(2, C, H, W, generator=gen)
+    n = 40
+    xy = torch.rand(n, 2, generator=gen) * torch.tensor([W * 16.0, H * 16.0]) - 20
+    rois = torch.cat((torch.randint(0, 2, (n, 1), generator=gen).float(), xy, xy + 8 + torch.rand(n, 2, generator=gen) * 300), 1)
+    rois[5, 3:] = rois[5, 1:3] - 3.0
+    wgt = torch.randn(n, C, out, out, generator=gen)
+    with torch.enable_grad():
+        f_ref = feat.clone().requires_grad_(True)
+        y_ref = _roi_align_chunk(f_ref, rois, out, 1.0 / 16, 0, True)
+        (y_ref * wgt).sum().backward()
+        f_hip = feat.cuda().requires_grad_(True)
+        y_hip = roi_align(f_hip, rois.cuda(), out, 1.0 / 16, 0, True)
+        (y_hip * wgt.cuda()).sum().backward()
+    assert y_hip.shape == y_ref.shape and (y_hip[5] == 0).all()
+    assert float((y_hip.cpu() - y_ref).abs().max()) <= 1e-5 * max(1.0, float(y_ref.abs().max()))
+    gscale = float(f_ref.grad.abs().max())
+    assert float((f_hip.grad.cpu() - f_ref.grad).abs().max()) <= 1e-4 * gscale
