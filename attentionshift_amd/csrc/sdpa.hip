@@ -266,6 +266,9 @@ __device__ __forceinline__ void lds_wait8(u32x2 (&v)[8]) {
   __builtin_amdgcn_sched_barrier(0);
 }
 
+#ifndef AS_SDPA_ABLATE
+#define AS_SDPA_ABLATE 0          // timing experiments only (tools/experiments/sdpa_ablate.py): 1 no exp2, 2 no softmax
+#endif                            // VALU, 3 no P.V MFMAs, 4 no Q.K MFMAs, 5 no LDS-DMA in the loop, 6 no barrier
 constexpr int GL_TILE = SD_KB * HD * 2;          // 8 KiB per K (or V^T) tile
 constexpr int GL_NBUF = 3;                       // LDS ring: tiles kt, kt+1, kt+2 (48 KiB per workgroup)
 
@@ -372,7 +375,7 @@ __global__ __launch_bounds__(SD_NT, 3) void sdpa_fwd_glds_kernel(const __bf16* _
     constexpr int slot = decltype(slot_c)::value;
     const int kt = kt0 + slot;
     if (kt >= nkt) return;
-    if (kt + 2 < nkt) stage(kt + 2, (slot + 2) % GL_NBUF);
+    if (kt + 2 < nkt && AS_SDPA_ABLATE != 5) stage(kt + 2, (slot + 2) % GL_NBUF);
     char* Ks = smem + slot * (2 * GL_TILE);
     char* Vs = Ks + GL_TILE;
     const int ktg = kt_off + kt;                    // absolute key tile
@@ -400,7 +403,8 @@ __global__ __launch_bounds__(SD_NT, 3) void sdpa_fwd_glds_kernel(const __bf16* _
       for (int ks = 0; ks < 4; ++ks) {
         Frag<__bf16> fk;
         fk.v = *reinterpret_cast<bf16x8*>(&kf[ks]);
-        sacc[kb] = mma32(fk, fq[ks], sacc[kb]);
+        if (AS_SDPA_ABLATE == 4) { asm volatile("" :: "v"(fk.v)); sacc[kb][ks] += 1e-3f; }
+        else sacc[kb] = mma32(fk, fq[ks], sacc[kb]);
       }
     });
     if (ragged) {
@@ -434,9 +438,18 @@ __global__ __launch_bounds__(SD_NT, 3) void sdpa_fwd_glds_kernel(const __bf16* _
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
+#if AS_SDPA_ABLATE == 1
+        const float p = fmaf(sacc[kb][r], c2, -mc) * 1e-3f;
+        ps4[r & 3] += p;
+        fp[kb][r >> 3].set(r & 7, p);
+#elif AS_SDPA_ABLATE == 2
+        asm volatile("" :: "v"(sacc[kb][r]));
+        fp[kb][r >> 3].set(r & 7, 0.001f);
+#else
         const float p = __builtin_amdgcn_exp2f(fmaf(sacc[kb][r], c2, -mc));
         ps4[r & 3] += p;
         fp[kb][r >> 3].set(r & 7, p);
+#endif
       }
     float psum = (ps4[0] + ps4[1]) + (ps4[2] + ps4[3]);
     if (__any(!(psum < 1e20f))) {                       // rare: re-reference this wave's rows to the true running max
@@ -470,7 +483,8 @@ __global__ __launch_bounds__(SD_NT, 3) void sdpa_fwd_glds_kernel(const __bf16* _
       for (int c = 0; c < 4; ++c) {
         Frag<__bf16> fv;
         fv.v = *reinterpret_cast<bf16x8*>(&vf[c]);
-        oacc[db] = mma32(fv, fp[c >> 1][c & 1], oacc[db]);
+        if (AS_SDPA_ABLATE == 3) { asm volatile("" :: "v"(fv.v), "v"(fp[c >> 1][c & 1].v)); oacc[db][c] += 1e-3f; }
+        else oacc[db] = mma32(fv, fp[c >> 1][c & 1], oacc[db]);
       }
     });
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my LDS reads of this tile are done
@@ -479,7 +493,7 @@ __global__ __launch_bounds__(SD_NT, 3) void sdpa_fwd_glds_kernel(const __bf16* _
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    __builtin_amdgcn_s_barrier();
+    if (AS_SDPA_ABLATE != 6) __builtin_amdgcn_s_barrier();
    });
   }
 
