@@ -79,7 +79,11 @@ int launch_add_ln(const float* x_in, const void* delta, const float* gamma, cons
     case 4: AS_LN(4); break;
     case 5: AS_LN(5); break;
     case 6: AS_LN(6); break;
-    default: AS_REQUIRE(false, AS_E_UNSUPPORTED, "as_add_layernorm: D=%d (max 1536)", D);
+    case 7: AS_LN(7); break;
+    case 8: AS_LN(8); break;
+    case 9: case 10: AS_LN(10); break;
+    case 11: case 12: AS_LN(12); break;
+    default: AS_REQUIRE(false, AS_E_UNSUPPORTED, "as_add_layernorm: D=%d (max 3072)", D);
   }
 #undef AS_LN
   AS_CHECK_LAUNCH("add_layernorm");

@@ -11,8 +11,9 @@
 // and the relative-position bias is gathered from the [(2w-1)^2, h] table through the closed-form index (:120-130).
 // Results are scattered straight back to the original token positions: no pad / roll / partition / reverse copies.
 //
-// One wave per (window, head): lane i owns query row i (49 of 64 lanes), K and V of the window live in LDS as fp32 and
-// are read as broadcasts; all arithmetic is fp32 (the softmax in exp(x - max) / sum form, as torch's).
+// fp32 tensors: one wave per (window, head), lane i owns query row i (49 of 64 lanes), K and V of the window live in LDS
+// as fp32 and are read as broadcasts; all arithmetic is fp32 (the softmax in exp(x - max) / sum form, as torch's).
+// bf16 tensors: window_attn_mfma_kernel below (both products on v_mfma_f32_32x32x16_bf16, fp32 softmax).
 #include "common.h"
 
 namespace {
@@ -115,6 +116,190 @@ __global__ __launch_bounds__(64) void window_attn_fwd_kernel(const T* __restrict
   }
 }
 
+// ---- bf16 path on the matrix cores -------------------------------------------------------------------------
+// One wave per (window, head), four independent waves per workgroup.  The 49 tokens of the window are padded to 64 and
+// both products run "swapped" (as in sdpa.hip) so that a lane owns ONE query column from the scores to the output:
+//   S^T[key][query] = K . Q^T      A = K, B = Q^T: both operand fragments are 16-byte loads straight from the token rows
+//                                  of the un-partitioned qkv grid (lane = token, 8 channels), + bias, rounded to bf16
+//   O^T[c][query]   = V^T . P^T    A = V^T from a [32][64] LDS image the wave writes transposed; B = P^T taken from the
+//                                  S^T accumulators in place (the key order of both operands is acc_row's)
+// Scale, relative-position bias (LDS table, index = lin_i - lin_j + 84 with lin = 13 a + c), the -100 shift mask (region
+// ids, LDS broadcast per key), softmax (in-lane over 32 keys + one cross-half exchange) and 1/sum are fp32 on the
+// accumulators.  Padded tokens (outside the image) are the bias itself; tokens 49..63 do not exist (K = V = 0, score -inf).
+template <int WS, int HD>
+__global__ __launch_bounds__(256, 4) void window_attn_mfma_kernel(const __bf16* __restrict__ qkv, const float* __restrict__ bqkv,
+                                                               const float* __restrict__ table, __bf16* __restrict__ out,
+                                                               float* __restrict__ attn_out, int B, int H, int W, int h,
+                                                               int shift, int nitems) {
+  static_assert(WS == 7 && HD == 32, "tiling is written for 7x7 windows of head dim 32");
+  constexpr int N = WS * WS, TB = (2 * WS - 1) * (2 * WS - 1), VP = 72;      // V^T row pitch in elements (144 B)
+  __shared__ __attribute__((aligned(16))) __bf16 Vt_s[4][HD * VP];
+  __shared__ float tab_s[4][TB + 7];
+  __shared__ int info_s[4][64];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, hf = lane >> 5;
+  const int raw_item = blockIdx.x * 4 + wave;
+  const bool live = raw_item < nitems;
+  const int item = min(raw_item, nitems - 1);
+  const int win = item / h, head = item - win * h;
+  const int C = h * HD;
+  const int nWh = as_ceil_div_dev(H, WS), nWw = as_ceil_div_dev(W, WS);
+  const int Hp = nWh * WS, Wp = nWw * WS;
+  const int b = win / (nWh * nWw), wrem = win - b * (nWh * nWw), wi = wrem / nWw, wj = wrem - wi * nWw;
+
+  // the two tokens this lane feeds into the MFMAs: t = li and t = 32 + li (as key rows and as query columns)
+  bool valid[2], real[2];
+  size_t tokidx[2];
+  int lin[2], rid[2];
+#pragma unroll
+  for (int x = 0; x < 2; ++x) {
+    const int t = li + 32 * x;
+    valid[x] = t < N;
+    const int tc = min(t, N - 1);
+    const int a = tc / WS, c_ = tc - a * WS;
+    const int hs = wi * WS + a, ws_ = wj * WS + c_;
+    int ho = hs + shift, wo = ws_ + shift;
+    ho -= ho >= Hp ? Hp : 0;
+    wo -= wo >= Wp ? Wp : 0;
+    real[x] = valid[x] && ho < H && wo < W;
+    tokidx[x] = ((size_t)b * H + (real[x] ? ho : 0)) * W + (real[x] ? wo : 0);
+    lin[x] = a * (2 * WS - 1) + c_;
+    const int rh = hs < Hp - WS ? 0 : (hs < Hp - shift ? 1 : 2), rw = ws_ < Wp - WS ? 0 : (ws_ < Wp - shift ? 1 : 2);
+    rid[x] = shift > 0 ? 3 * rh + rw : 0;
+  }
+  info_s[wave][lane] = (valid[hf] ? 0 : 0x10000) | (rid[hf] << 8) | lin[hf];       // token `lane` = li + 32 hf
+  for (int t = lane; t < TB; t += 64) tab_s[wave][t] = table[(size_t)t * h + head];
+
+  // operand fragments: channels ks*16 + hf*8 + 0..7 of q / k / v of both tokens
+  Frag<__bf16> fq[2][2], fk[2][2];
+  __bf16* Vt = Vt_s[wave];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const int ch = head * HD + ks * 16 + hf * 8;
+    float bq[8], bk[8], bv[8];
+#pragma unroll
+    for (int e = 0; e < 8; e += 4) {
+      const float4 q4 = bqkv ? *reinterpret_cast<const float4*>(bqkv + ch + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 k4 = bqkv ? *reinterpret_cast<const float4*>(bqkv + C + ch + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 v4 = bqkv ? *reinterpret_cast<const float4*>(bqkv + 2 * C + ch + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+      bq[e] = q4.x; bq[e + 1] = q4.y; bq[e + 2] = q4.z; bq[e + 3] = q4.w;
+      bk[e] = k4.x; bk[e + 1] = k4.y; bk[e + 2] = k4.z; bk[e + 3] = k4.w;
+      bv[e] = v4.x; bv[e + 1] = v4.y; bv[e + 2] = v4.z; bv[e + 3] = v4.w;
+    }
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+      const __bf16* tok = qkv + tokidx[x] * (size_t)(3 * C) + ch;
+      const bf16x8 rq = *reinterpret_cast<const bf16x8*>(tok);
+      const bf16x8 rk = *reinterpret_cast<const bf16x8*>(tok + C);
+      const bf16x8 rv = *reinterpret_cast<const bf16x8*>(tok + 2 * C);
+      const float keep = real[x] ? 1.0f : 0.0f, exist = valid[x] ? 1.0f : 0.0f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        fq[x][ks].v[e] = (__bf16)(exist * fmaf(keep, (float)rq[e], bq[e]));
+        fk[x][ks].v[e] = (__bf16)(exist * fmaf(keep, (float)rk[e], bk[e]));
+        Vt[(ks * 16 + hf * 8 + e) * VP + li + 32 * x] = (__bf16)(exist * fmaf(keep, (float)rv[e], bv[e]));
+      }
+    }
+  }
+  __syncthreads();
+
+  // S^T tiles: acc[jb][ib], key = jb*32 + acc_row(r, hf), query = ib*32 + li
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[jb][ib][r] = 0.0f;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) acc[jb][ib] = mma32(fk[jb][ks], fq[ib][ks], acc[jb][ib]);
+    }
+  const float scale = rsqrtf((float)HD);
+  const float* tab = tab_s[wave];
+  float mx[2] = {-INFINITY, -INFINITY};
+#pragma unroll
+  for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int inf = info_s[wave][jb * 32 + acc_row(r, hf)];
+      const int lj = inf & 0xff, rj = (inf >> 8) & 0xff;
+      const bool gone = inf >= 0x10000;
+#pragma unroll
+      for (int ib = 0; ib < 2; ++ib) {
+        float s = fmaf(acc[jb][ib][r], scale, tab[lin[ib] - lj + (WS - 1) * (2 * WS - 1) + (WS - 1)]);
+        s += rj != rid[ib] ? -100.0f : 0.0f;
+        s = gone ? -INFINITY : s;
+        acc[jb][ib][r] = s;
+        mx[ib] = fmaxf(mx[ib], s);
+      }
+    }
+  float inv[2];
+#pragma unroll
+  for (int ib = 0; ib < 2; ++ib) {
+    mx[ib] = fmaxf(mx[ib], __shfl_xor(mx[ib], 32));
+    float sum = 0.0f;
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float e = __expf(acc[jb][ib][r] - mx[ib]);
+        acc[jb][ib][r] = e;
+        sum += e;
+      }
+    sum += __shfl_xor(sum, 32);
+    inv[ib] = 1.0f / sum;
+  }
+  if (attn_out != nullptr && live) {
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib)
+      if (valid[ib]) {
+        float* row = attn_out + ((size_t)item * N + li + 32 * ib) * N;
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int j = jb * 32 + acc_row(r, hf);
+            if (j < N) row[j] = acc[jb][ib][r] * inv[ib];
+          }
+      }
+  }
+  // O^T[c][query]: A = V^T fragment of (jb, s) in acc_row's key order, B = the 8 probabilities of registers 8s..8s+7
+  f32x16 oacc[2];
+#pragma unroll
+  for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[ib][r] = 0.0f;
+  const char* vrow = reinterpret_cast<const char*>(Vt + li * VP);
+#pragma unroll
+  for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int key0 = jb * 32 + 16 * s + 4 * hf;
+      Frag<__bf16> fv;
+      const uint2 lo = *reinterpret_cast<const uint2*>(vrow + key0 * 2);
+      const uint2 hi = *reinterpret_cast<const uint2*>(vrow + (key0 + 8) * 2);
+      uint4 u = make_uint4(lo.x, lo.y, hi.x, hi.y);
+      fv.v = *reinterpret_cast<bf16x8*>(&u);
+#pragma unroll
+      for (int ib = 0; ib < 2; ++ib) {
+        Frag<__bf16> fp;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) fp.v[t] = (__bf16)acc[jb][ib][8 * s + t];
+        oacc[ib] = mma32(fv, fp, oacc[ib]);
+      }
+    }
+#pragma unroll
+  for (int ib = 0; ib < 2; ++ib)
+    if (live && real[ib]) {
+      __bf16* dst = out + tokidx[ib] * (size_t)C + head * HD + 4 * hf;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        bf16x4 v = {(__bf16)(oacc[ib][4 * g] * inv[ib]), (__bf16)(oacc[ib][4 * g + 1] * inv[ib]),
+                    (__bf16)(oacc[ib][4 * g + 2] * inv[ib]), (__bf16)(oacc[ib][4 * g + 3] * inv[ib])};
+        *reinterpret_cast<bf16x4*>(dst + 8 * g) = v;
+      }
+    }
+}
+
 template <typename T>
 int launch_window_attn(const void* qkv, const float* bqkv, const float* table, void* out, float* attn_out, int B, int H,
                        int W, int h, int shift, hipStream_t s) {
@@ -122,6 +307,15 @@ int launch_window_attn(const void* qkv, const float* bqkv, const float* table, v
   hipLaunchKernelGGL((window_attn_fwd_kernel<T, 7, 32>), dim3(B * nW, h), dim3(64), 0, s, (const T*)qkv, bqkv, table,
                      (T*)out, attn_out, B, H, W, h, shift);
   AS_CHECK_LAUNCH("window_attn_fwd");
+  return AS_OK;
+}
+
+int launch_window_attn_mfma(const void* qkv, const float* bqkv, const float* table, void* out, float* attn_out, int B,
+                            int H, int W, int h, int shift, hipStream_t s) {
+  const int nitems = B * as_ceil_div(H, 7) * as_ceil_div(W, 7) * h;
+  hipLaunchKernelGGL((window_attn_mfma_kernel<7, 32>), dim3(as_ceil_div(nitems, 4)), dim3(256), 0, s, (const __bf16*)qkv,
+                     bqkv, table, (__bf16*)out, attn_out, B, H, W, h, shift, nitems);
+  AS_CHECK_LAUNCH("window_attn_mfma");
   return AS_OK;
 }
 
@@ -136,7 +330,7 @@ extern "C" int as_window_attn_fwd(const void* qkv, const float* bqkv, const floa
              ws, C, h);
   AS_REQUIRE(shift >= 0 && shift < ws, AS_E_BADARG, "as_window_attn_fwd: need 0 <= shift < ws");
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == AS_BF16) return launch_window_attn<__bf16>(qkv, bqkv, table, out, attn_out, B, H, W, h, shift, s);
+  if (dtype == AS_BF16) return launch_window_attn_mfma(qkv, bqkv, table, out, attn_out, B, H, W, h, shift, s);
   if (dtype == AS_F32) return launch_window_attn<float>(qkv, bqkv, table, out, attn_out, B, H, W, h, shift, s);
   AS_REQUIRE(false, AS_E_UNSUPPORTED, "as_window_attn_fwd: dtype %d", dtype);
 }

@@ -93,6 +93,7 @@ class SwinTransformerBlock(nn.Module):
         self.mlp = _Mlp(dim, int(dim * mlp_ratio))
         self.compute_dtype = compute_dtype
         self.return_attention = return_attention
+        self._wcache = {}
 
     def _forward_train(self, x, hw=None):
         """Autograd path (train() + grad enabled): the window attention core runs on the HIP forward / backward kernels
@@ -112,42 +113,111 @@ class SwinTransformerBlock(nn.Module):
                      self.mlp.fc2.weight.to(cd), self.mlp.fc2.bias.to(cd))
         return x + z.float(), None
 
+    def _w(self, prm, dtype=None):
+        """`dtype` (default: compute dtype) copy of a parameter, cached while it does not change (no-grad path only)."""
+        dtype = self.compute_dtype if dtype is None else dtype
+        if prm.dtype == dtype and prm.is_contiguous():
+            return prm.detach()
+        key = (id(prm), dtype)
+        hit = self._wcache.get(key)
+        if hit is None or hit[0] != prm._version or hit[1].device != prm.device:
+            hit = (prm._version, prm.detach().to(dtype).contiguous())
+            self._wcache[key] = hit
+        return hit[1]
+
+    def forward_pending(self, x, delta, hw):
+        """No-grad path with the residual adds fused into the LayerNorms (ops.add_layernorm, as the ViT blocks):
+        x fp32 [B,L,C] residual stream, delta = the previous block's MLP output not added yet (compute dtype | None).
+        Returns (x after the attention residual, this block's MLP output still pending, attn | None)."""
+        B, L, C = x.shape
+        H, W = hw
+        assert H * W == L, "token count does not match the grid"
+        cd, f32 = self.compute_dtype, torch.float32
+        x, y = ops.add_layernorm(x, delta, self._w(self.norm1.weight, f32), self._w(self.norm1.bias, f32), self.norm1.eps, cd)
+        qkv = ops.linear(y.reshape(B * L, C), self._w(self.attn.qkv.weight), None).reshape(B, H, W, 3 * C)
+        bq = None if self.attn.qkv.bias is None else self._w(self.attn.qkv.bias, f32)
+        o, attn = ops.window_attention_fwd(qkv, bq, self._w(self.attn.relative_position_bias_table, f32), self.num_heads,
+                                           self.window_size, self.shift_size, return_attn=self.return_attention)
+        a = ops.linear(o.reshape(B * L, C), self._w(self.attn.proj.weight), self._w(self.attn.proj.bias, f32))
+        x, z = ops.add_layernorm(x, a.reshape(B, L, C), self._w(self.norm2.weight, f32), self._w(self.norm2.bias, f32),
+                                 self.norm2.eps, cd)
+        z = ops.linear(z.reshape(B * L, C), self._w(self.mlp.fc1.weight), self._w(self.mlp.fc1.bias, f32), act="gelu")
+        z = ops.linear(z, self._w(self.mlp.fc2.weight), self._w(self.mlp.fc2.bias, f32))
+        return x, z.reshape(B, L, C), attn
+
     def forward(self, x, hw=None):
         """x [B, H*W, C]; hw = (H, W) of the token grid (default: square)."""
         if self.training and torch.is_grad_enabled():
             return self._forward_train(x, hw)
-        B, L, C = x.shape
-        H, W = hw if hw is not None else (int(math.sqrt(L)),) * 2
-        assert H * W == L, "token count does not match the grid"
-        cd = self.compute_dtype
-        w = lambda p: p.detach().to(cd).contiguous()
-        y = F.layer_norm(x, (C,), self.norm1.weight, self.norm1.bias, self.norm1.eps).to(cd)
-        qkv = ops.linear(y.reshape(B * L, C).contiguous(), w(self.attn.qkv.weight), None).reshape(B, H, W, 3 * C)
-        bq = None if self.attn.qkv.bias is None else self.attn.qkv.bias.detach().float().contiguous()
-        o, attn = ops.window_attention_fwd(qkv, bq, self.attn.relative_position_bias_table.detach().float().contiguous(),
-                                           self.num_heads, self.window_size, self.shift_size,
-                                           return_attn=self.return_attention)
-        y = ops.linear(o.reshape(B * L, C), w(self.attn.proj.weight), self.attn.proj.bias.detach().float())
-        x = x + y.reshape(B, L, C).float()
-        z = F.layer_norm(x, (C,), self.norm2.weight, self.norm2.bias, self.norm2.eps).to(cd)
-        z = ops.linear(z.reshape(B * L, C).contiguous(), w(self.mlp.fc1.weight), self.mlp.fc1.bias.detach().float(), act="gelu")
-        z = ops.linear(z, w(self.mlp.fc2.weight), self.mlp.fc2.bias.detach().float())
-        return x + z.reshape(B, L, C).float(), attn
+        L = x.shape[1]
+        hw = hw if hw is not None else (int(math.sqrt(L)),) * 2
+        x, z, attn = self.forward_pending(x.float().contiguous(), None, hw)
+        x, _ = ops.add_layernorm(x, z, None, None, 0.0, self.compute_dtype, want_y=False)
+        return x, attn
+
+
+def run_blocks(blocks, x, hw):
+    """A stage's blocks on the no-grad path: every residual add rides in the next LayerNorm, the last one is applied here."""
+    x, delta = x.float().contiguous(), None
+    for blk in blocks:
+        x, delta, _ = blk.forward_pending(x, delta, hw)
+    x, _ = ops.add_layernorm(x, delta, None, None, 0.0, blocks[-1].compute_dtype, want_y=False)
+    return x
+
+
+def fused_path(module):
+    return not (module.training and torch.is_grad_enabled())
+
+
+def patch_embed_tokens(proj, norm, x, compute_dtype=torch.float32):
+    """Non-overlapping patch convolution (+ LayerNorm) as an unfold + `as_linear_fwd` GEMM in fp32 (K = 3 p^2, zero-padded
+    to a multiple of 32) + `as_add_layernorm`: img [B,3,H,W] (H, W multiples of the patch) -> tokens [B, Hp*Wp, C] fp32."""
+    B, Cin, H, W = x.shape
+    ph, pw = proj.kernel_size
+    Hp, Wp = H // ph, W // pw
+    K = Cin * ph * pw
+    Kp = -(-K // 32) * 32
+    cols = x[:, :, :Hp * ph, :Wp * pw].float().reshape(B, Cin, Hp, ph, Wp, pw).permute(0, 2, 4, 1, 3, 5).reshape(B * Hp * Wp, K)
+    wgt = proj.weight.detach().float().reshape(proj.out_channels, K)
+    if Kp != K:
+        cols = F.pad(cols, (0, Kp - K))
+        wgt = F.pad(wgt, (0, Kp - K))
+    t = ops.linear(cols.contiguous(), wgt.contiguous(), None if proj.bias is None else proj.bias.detach().float())
+    t = t.view(B, Hp * Wp, proj.out_channels)
+    if norm is not None:
+        _, t = ops.add_layernorm(t, None, norm.weight.detach().float(), norm.bias.detach().float(), norm.eps,
+                                 torch.float32, want_x=False)
+    return t, Hp, Wp
+
+
+def merge_tokens(x, H, W, norm, reduction, compute_dtype):
+    """Patch merging on the no-grad path: 2x2 gather (one copy), LayerNorm -> compute dtype, bias-free GEMM, fp32 out."""
+    B, L, C = x.shape
+    x = x.view(B, H, W, C)
+    if H % 2 or W % 2:
+        x = F.pad(x, (0, 0, 0, W % 2, 0, H % 2))
+    x = torch.cat([x[:, 0::2, 0::2], x[:, 1::2, 0::2], x[:, 0::2, 1::2], x[:, 1::2, 1::2]], -1).reshape(B, -1, 4 * C)
+    _, y = ops.add_layernorm(x.float().contiguous(), None, norm.weight.detach().float(), norm.bias.detach().float(), norm.eps,
+                             compute_dtype, want_x=False)
+    wgt = reduction.weight.detach().to(compute_dtype).contiguous()
+    return ops.linear(y.reshape(-1, 4 * C), wgt, None).reshape(B, -1, 2 * C).float()
 
 
 # ---- the whole backbone around the block (BASELINE config 5: Swin-B = embed 128, depths 2/2/18/2, heads 4/8/16/32) ------
 class PatchMerging(nn.Module):
     """models/swin_transformer.py:337-377: 2x2 neighbourhood -> 4C, LayerNorm, Linear(4C -> 2C, no bias)."""
 
-    def __init__(self, input_resolution, dim):
+    def __init__(self, input_resolution, dim, compute_dtype=torch.bfloat16):
         super().__init__()
-        self.input_resolution, self.dim = tuple(input_resolution), dim
+        self.input_resolution, self.dim, self.compute_dtype = tuple(input_resolution), dim, compute_dtype
         self.reduction = nn.Linear(4 * dim, 2 * dim, bias=False)
         self.norm = nn.LayerNorm(4 * dim, eps=1e-6)
 
     def forward(self, x):
         B, L, C = x.shape
         H = W = int(math.sqrt(L))
+        if fused_path(self) and x.is_cuda:
+            return merge_tokens(x, H, W, self.norm, self.reduction, self.compute_dtype)
         x = x.view(B, H, W, C)
         if H % 2 or W % 2:
             x = F.pad(x, (0, 0, 0, W % 2, 0, H % 2))
@@ -167,11 +237,15 @@ class BasicLayer(nn.Module):
             for i in range(depth)])
         for blk in self.blocks:                               # the reference's norm_layer = LayerNorm(eps=1e-6)
             blk.norm1.eps = blk.norm2.eps = 1e-6
-        self.downsample = PatchMerging(input_resolution, dim) if downsample else None
+        self.downsample = PatchMerging(input_resolution, dim, compute_dtype) if downsample else None
 
     def forward(self, x):
-        for blk in self.blocks:
-            x, _ = blk(x)
+        if fused_path(self) and x.is_cuda:
+            L = x.shape[1]
+            x = run_blocks(self.blocks, x, (int(math.sqrt(L)),) * 2)
+        else:
+            for blk in self.blocks:
+                x, _ = blk(x)
         return self.downsample(x) if self.downsample is not None else x
 
     def forward_with_features(self, x):
@@ -192,7 +266,14 @@ class SwinPatchEmbed(nn.Module):
         self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size)
         self.norm = nn.LayerNorm(embed_dim, eps=1e-6) if patch_norm else None
 
+    def tokens(self, x):
+        """No-grad path: tokens [B, Hp*Wp, C] fp32 without the NCHW round trip."""
+        return patch_embed_tokens(self.proj, self.norm, x)[0]
+
     def forward(self, x):
+        if fused_path(self) and x.is_cuda:
+            t, H, W = patch_embed_tokens(self.proj, self.norm, x)
+            return t.transpose(1, 2).reshape(x.shape[0], -1, H, W)
         x = self.proj(x)
         B, C, H, W = x.shape
         t = x.flatten(2).transpose(1, 2)
@@ -241,7 +322,10 @@ class SwinTransformer(nn.Module):
             nn.init.constant_(m.weight, 1.0)
 
     def forward_stages(self, x):
-        x = self.patch_embed(x).flatten(2).transpose(1, 2)
+        if fused_path(self) and x.is_cuda:
+            x = self.patch_embed.tokens(x)
+        else:
+            x = self.patch_embed(x).flatten(2).transpose(1, 2)
         if self.ape:
             x = x + self.absolute_pos_embed
         stages = []

@@ -15,21 +15,24 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .registry import BACKBONES
-from .swin import SwinTransformerBlock
+from . import ops
+from .swin import SwinTransformerBlock, fused_path, merge_tokens, patch_embed_tokens, run_blocks
 
 
 class PatchMergingDet(nn.Module):
     """mmdet/models/backbones/swin_transformer.py:250-298: pad to even, 2x2 neighbourhood -> 4C, LayerNorm, Linear 4C -> 2C."""
 
-    def __init__(self, dim):
+    def __init__(self, dim, compute_dtype=torch.bfloat16):
         super().__init__()
-        self.dim = dim
+        self.dim, self.compute_dtype = dim, compute_dtype
         self.reduction = nn.Linear(4 * dim, 2 * dim, bias=False)
         self.norm = nn.LayerNorm(4 * dim)
 
     def forward(self, x, H, W):
         B, L, C = x.shape
         assert L == H * W, "input feature has wrong size"
+        if fused_path(self) and x.is_cuda:
+            return merge_tokens(x, H, W, self.norm, self.reduction, self.compute_dtype)
         x = x.view(B, H, W, C)
         if H % 2 or W % 2:
             x = F.pad(x, (0, 0, 0, W % 2, 0, H % 2))
@@ -49,9 +52,14 @@ class BasicLayerDet(nn.Module):
             SwinTransformerBlock(dim, None, num_heads, window_size, 0 if i % 2 == 0 else window_size // 2, mlp_ratio,
                                  qkv_bias, compute_dtype=compute_dtype, return_attention=False)
             for i in range(depth)])
-        self.downsample = PatchMergingDet(dim) if downsample else None
+        self.downsample = PatchMergingDet(dim, compute_dtype) if downsample else None
 
     def forward(self, x, H, W):
+        if fused_path(self) and x.is_cuda:
+            x = run_blocks(self.blocks, x, (H, W))
+            if self.downsample is not None:
+                return x, H, W, self.downsample(x, H, W), (H + 1) // 2, (W + 1) // 2
+            return x, H, W, x, H, W
         for blk in self.blocks:
             if self.use_checkpoint and self.training and torch.is_grad_enabled():
                 import torch.utils.checkpoint as cp
@@ -73,13 +81,23 @@ class PatchEmbedDet(nn.Module):
         self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=self.patch_size, stride=self.patch_size)
         self.norm = nn.LayerNorm(embed_dim) if norm else None
 
-    def forward(self, x):
+    def _pad(self, x):
         _, _, H, W = x.shape
         if W % self.patch_size[1]:
             x = F.pad(x, (0, self.patch_size[1] - W % self.patch_size[1]))
         if H % self.patch_size[0]:
             x = F.pad(x, (0, 0, 0, self.patch_size[0] - H % self.patch_size[0]))
-        x = self.proj(x)
+        return x
+
+    def tokens(self, x):
+        """No-grad path: (tokens [B, Wh*Ww, C] fp32, Wh, Ww) without the NCHW round trip."""
+        return patch_embed_tokens(self.proj, self.norm, self._pad(x))
+
+    def forward(self, x):
+        if fused_path(self) and x.is_cuda:
+            t, Wh, Ww = self.tokens(x)
+            return t.transpose(1, 2).reshape(x.shape[0], self.embed_dim, Wh, Ww)
+        x = self.proj(self._pad(x))
         if self.norm is not None:
             Wh, Ww = x.shape[2:]
             x = self.norm(x.flatten(2).transpose(1, 2)).transpose(1, 2).reshape(-1, self.embed_dim, Wh, Ww)
@@ -152,16 +170,26 @@ class SwinTransformerDet(nn.Module):
 
     def forward(self, x):
         """img [B,3,H,W] -> tuple of NCHW maps of the stages in out_indices (:595-622)."""
-        x = self.patch_embed(x)
-        Wh, Ww = x.shape[2:]
-        if self.ape:
-            x = x + F.interpolate(self.absolute_pos_embed, size=(Wh, Ww), mode="bicubic")
-        x = x.flatten(2).transpose(1, 2)
+        if fused_path(self) and x.is_cuda:
+            x, Wh, Ww = self.patch_embed.tokens(x)
+            if self.ape:
+                x = x + F.interpolate(self.absolute_pos_embed, size=(Wh, Ww), mode="bicubic").flatten(2).transpose(1, 2)
+        else:
+            x = self.patch_embed(x)
+            Wh, Ww = x.shape[2:]
+            if self.ape:
+                x = x + F.interpolate(self.absolute_pos_embed, size=(Wh, Ww), mode="bicubic")
+            x = x.flatten(2).transpose(1, 2)
         outs = []
         for i, layer in enumerate(self.layers):
             x_out, H, W, x, Wh, Ww = layer(x, Wh, Ww)
             if i in self.out_indices:
-                y = getattr(self, f"norm{i}")(x_out)
+                nrm = getattr(self, f"norm{i}")
+                if fused_path(self) and x_out.is_cuda:
+                    _, y = ops.add_layernorm(x_out.float().contiguous(), None, nrm.weight.detach().float(),
+                                             nrm.bias.detach().float(), nrm.eps, torch.float32, want_x=False)
+                else:
+                    y = nrm(x_out)
                 outs.append(y.view(-1, H, W, self.num_features[i]).permute(0, 3, 1, 2).contiguous())
         return tuple(outs)
 

@@ -115,7 +115,7 @@ int as_window_attn_fwd(const void* qkv, const float* bqkv, const float* table, v
 
 /* Fused residual add + LayerNorm of the pre-LN block (vision_transformer.py:109-124: x = x + sublayer(norm(x))):
  *   x_out = x_in + delta (fp32 residual stream; delta [M,D] in `dtype`, or NULL),  y_out = LN(x_out)*gamma + beta (`dtype`)
- * x_out may alias x_in; either output may be NULL (x_out NULL: LN only; y_out NULL: add only).  D % 4 == 0, D <= 1536. */
+ * x_out may alias x_in; either output may be NULL (x_out NULL: LN only; y_out NULL: add only).  D % 4 == 0, D <= 3072. */
 int as_add_layernorm(const float* x_in, const void* delta, const float* gamma, const float* beta, float eps,
                      float* x_out, void* y_out, int M, int D, int dtype, as_stream_t stream);
 

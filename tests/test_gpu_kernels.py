@@ -715,6 +715,32 @@ def test_swin_block_matches_reference(ops, golden, tag, dtype, tol):
     assert mx < tol, ("attention probabilities", mx)
 
 
+@pytest.mark.parametrize("H,W,heads,shift", [(14, 14, 2, 0), (14, 14, 4, 3), (16, 23, 3, 3), (9, 30, 8, 0), (37, 5, 5, 6)])
+def test_window_attention_mfma_matches_the_fp32_kernel(ops, H, W, heads, shift):
+    """bf16 tensors take the MFMA kernel, fp32 tensors the fp32 VALU kernel (which the reference fixtures pin at 1e-4):
+    same bf16-rounded inputs through both -- outputs, and the softmax itself, for shifted / padded / ragged grids,
+    head counts that do not fill a 4-wave workgroup, with and without the qkv bias."""
+    g = torch.Generator().manual_seed(H * 100 + W + shift)
+    B, C = 2, heads * 32
+    qkv = (torch.randn(B, H, W, 3 * C, generator=g) * 1.5).bfloat16()
+    bias = torch.randn(3 * C, generator=g) * 0.5
+    table = torch.randn(169, heads, generator=g)
+    for b_qkv in (bias, None):
+        bq = None if b_qkv is None else dev(b_qkv)
+        zeros = dev(torch.zeros(3 * C))
+        ref_o, ref_a = ops.window_attention_fwd(dev(qkv.float()), zeros if bq is None else bq, dev(table), heads, 7, shift,
+                                                return_attn=True)
+        for want in (True, False):
+            o, a = ops.window_attention_fwd(dev(qkv), zeros if bq is None else bq, dev(table), heads, 7, shift,
+                                            return_attn=want)
+            assert o.dtype == torch.bfloat16
+            mx, mean = rel_to_range(ref_o.cpu(), o.float().cpu())
+            assert mx < 2e-2 and mean < 2e-3, (H, W, heads, shift, want, mx, mean)
+            if want:
+                assert float((a - ref_a).abs().max()) < 2e-2
+                assert float((a.sum(-1) - 1).abs().max()) < 1e-5
+
+
 def test_mask_count_matches_torch(ops):
     g = torch.Generator().manual_seed(4)
     for (M, HW) in ((3, 1024 * 1024), (7, 4096), (1, 16), (5, 208)):
