@@ -210,14 +210,31 @@ class VisionTransformerDet(nn.Module):
             self._wcache[key] = hit
         return hit[1]
 
-    def _deconv2x2(self, x_nhwc, conv):
+    def _deconv2x2(self, x_nhwc, conv, bn=None, act="none"):
         """nn.ConvTranspose2d(k=2, s=2) on a channels-last map as ONE GEMM over its pixels:
-        y[b, 2i+di, 2j+dj, co] = sum_ci x[b,i,j,ci] W[ci,co,di,dj] + bias[co]  (visual_transformer_det.py:107-117)."""
+        y[b, 2i+di, 2j+dj, co] = act(BN(sum_ci x[b,i,j,ci] W[ci,co,di,dj] + bias[co]))  (visual_transformer_det.py:107-117).
+        An eval-mode BatchNorm `bn` is a per-channel affine map: it is folded into the cached GEMM weight / bias, the GELU
+        runs in the GEMM epilogue, and the epilogue scatters to the interleaved output pixel (as_deconv2x2_fwd)."""
         B, h, w, cin = x_nhwc.shape
         cout = conv.weight.shape[1]
-        wmat = self._derived(conv.weight, "deconv", lambda t: t.permute(2, 3, 1, 0).reshape(4 * cout, cin))
-        bias = None if conv.bias is None else conv.bias.float().repeat(4)
-        y = ops.linear(x_nhwc.reshape(B * h * w, cin), wmat, bias)
+        srcs = [conv.weight, conv.bias] + ([bn.weight, bn.bias, bn.running_mean, bn.running_var] if bn is not None else [])
+        stamp = tuple(-1 if t is None else t._version for t in srcs) + (x_nhwc.device,)
+        key = (id(conv), "deconv")
+        hit = self._wcache.get(key)
+        if hit is None or hit[0] != stamp:
+            with torch.no_grad():
+                wmat = conv.weight.detach().float().permute(2, 3, 1, 0).reshape(4 * cout, cin)
+                bias = torch.zeros(cout, device=wmat.device) if conv.bias is None else conv.bias.detach().float()
+                if bn is not None:
+                    scale = bn.weight.detach().float() * torch.rsqrt(bn.running_var.float() + bn.eps)
+                    wmat = wmat * scale.repeat(4)[:, None]
+                    bias = (bias - bn.running_mean.float()) * scale + bn.bias.detach().float()
+                hit = (stamp, wmat.to(self.compute_dtype).contiguous(), bias.repeat(4).contiguous())
+            self._wcache[key] = hit
+        _, wmat, bias4 = hit
+        if x_nhwc.is_cuda and self.compute_dtype == torch.bfloat16 and cin % 32 == 0 and cout % 8 == 0:
+            return ops.deconv2x2(x_nhwc.contiguous(), wmat, bias4, act=act)
+        y = ops.linear(x_nhwc.reshape(B * h * w, cin), wmat, bias4, act=act)
         return y.reshape(B, h, w, 2, 2, cout).permute(0, 1, 3, 2, 4, 5).reshape(B, 2 * h, 2 * w, cout)
 
     def _deconv2x2_train(self, x_nhwc, conv):
@@ -250,11 +267,17 @@ class VisionTransformerDet(nn.Module):
         ops_ = [self.fpn1, self.fpn2, self.fpn3, self.fpn4]
         op = ops_[i]
         if isinstance(op, nn.Sequential) and isinstance(op[0], nn.ConvTranspose2d):
-            y = self._deconv2x2(tok.to(self.compute_dtype).reshape(B, hp, wp, D), op[0]).permute(0, 3, 1, 2)
+            x0 = tok.to(self.compute_dtype).reshape(B, hp, wp, D)
             if len(op) == 4:                                             # ConvT -> BN -> GELU -> ConvT (fpn1, patch 16)
-                y = op[2](op[1](y.float())).to(self.compute_dtype)
-                y = self._deconv2x2(y.permute(0, 2, 3, 1), op[3]).permute(0, 3, 1, 2)
-            return y
+                bn = op[1]
+                if isinstance(bn, nn.modules.batchnorm._BatchNorm) and not bn.training and bn.running_mean is not None \
+                        and isinstance(op[2], nn.GELU) and getattr(op[2], "approximate", "none") == "none":
+                    y = self._deconv2x2(x0, op[0], bn=bn, act="gelu")
+                else:
+                    y = self._deconv2x2(x0, op[0]).permute(0, 3, 1, 2)
+                    y = op[2](op[1](y.float())).to(self.compute_dtype).permute(0, 2, 3, 1)
+                return self._deconv2x2(y, op[3]).permute(0, 3, 1, 2)
+            return self._deconv2x2(x0, op[0]).permute(0, 3, 1, 2)
         return op(feat_nchw)
 
     def interpolate_pos_encoding(self, n_patch_tokens, w, h):
@@ -275,14 +298,18 @@ class VisionTransformerDet(nn.Module):
         B, C, w, h = img.shape
         ps = self.patch_size
         hp, wp = w // ps, h // ps
-        patches = img.reshape(B, C, hp, ps, wp, ps).permute(0, 2, 4, 1, 3, 5).reshape(B, hp * wp, C * ps * ps)
+        # unfold + cast in one pass, then cls / position / point tokens are written straight into the token buffer
+        patches = torch.empty(B, hp, wp, C, ps, ps, device=img.device, dtype=self.compute_dtype)
+        patches.copy_(img.reshape(B, C, hp, ps, wp, ps).permute(0, 2, 4, 1, 3, 5))
         wmat = self.patch_embed.proj.weight.reshape(self.embed_dim, -1)
-        x = ops.linear(patches.to(self.compute_dtype).contiguous(), self._w(wmat).contiguous(),
-                       self.patch_embed.proj.bias.float()).float()
-        x = torch.cat((self.cls_token.expand(B, -1, -1), x), dim=1)
-        x = x + self.interpolate_pos_encoding(x.shape[1] - 1, w, h)
-        pt = (self.point_token + self.point_pos_embed).expand(B, -1, -1)
-        return torch.cat((x, pt), dim=1)
+        emb = ops.linear(patches.view(B, hp * wp, C * ps * ps), self._w(wmat).contiguous(), self.patch_embed.proj.bias.float())
+        pos = self.interpolate_pos_encoding(hp * wp, w, h)
+        T, Np = self.point_token.shape[1], hp * wp
+        x = torch.empty(B, 1 + Np + T, self.embed_dim, device=img.device, dtype=torch.float32)
+        torch.add(emb.float() if emb.dtype != torch.bfloat16 else emb, pos[:, 1:], out=x[:, 1:1 + Np])
+        x[:, :1] = self.cls_token + pos[:, :1]
+        x[:, 1 + Np:] = self.point_token + self.point_pos_embed
+        return x
 
     def _block(self, blk, x, delta, keep_state, need_x):
         """models/vision_transformer.py:109-124 with the residual stream kept in fp32 and every residual add fused into
@@ -373,10 +400,13 @@ class VisionTransformerDet(nn.Module):
                 tap = x[:, 1:, :][:, :-T].permute(0, 2, 1).unflatten(2, (hp, wp))
                 if grad_path:
                     features.append(tap.contiguous())
-                else:                          # no-grad: transpose straight into its slot of org_feats (no torch.stack copy)
+                else:
+                    # no-grad: org_feats [B, L, D, hp, wp] is a VIEW of token-major storage [L, B, hp, wp, D] (every tap a
+                    # channels-last map): filling a slot is a straight copy of the tokens, not a transpose, and the
+                    # channels-last consumers (FPN GEMMs, RoIAlign, the attention-shift kernels) read it without a copy
                     if org_features is None:
-                        org_features = torch.empty(B, len(self.out_indices), tap.shape[1], hp, wp, device=x.device,
-                                                   dtype=x.dtype)
+                        store = torch.empty(len(self.out_indices), B, hp, wp, tap.shape[1], device=x.device, dtype=x.dtype)
+                        org_features = store.permute(1, 0, 4, 2, 3)
                     org_features[:, len(features)].copy_(tap)
                     features.append(org_features[:, len(features)])
             if self.last_feat and not self.recompute_last_feat and i == len(self.blocks) - 1:

@@ -205,10 +205,25 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const T* __restrict__ A, const
 // leaves as 16-byte fully coalesced global stores (row-major out, k, fragment-major q); V^T tiles are stored straight
 // from the accumulators (lanes run along tokens: 128 contiguous bytes per store instruction).
 // ---------------------------------------------------------------------------------------------------------
+#ifndef AS_GEMM_ABLATE
+#define AS_GEMM_ABLATE 0                     // timing ablations (tools/experiments/gemm_ablate.py); results are wrong when != 0
+#endif
 constexpr int GK = 32;                       // K step (elements)
-constexpr int G_TILE_BYTES = BM * GK * 2;    // 8 KiB per operand tile
-constexpr int G_STAGE = 2 * G_TILE_BYTES;    // A tile | W tile
-constexpr int G_NSTAGE = 3;              // ring depth: 2 K steps in flight + 1 consumed; 48 KiB -> 3 workgroups per CU
+constexpr int G_W_BYTES = BN * GK * 2;       // 8 KiB: the W tile of one K step (128 output columns)
+constexpr int G_NSTAGE = 3;                  // ring depth: 2 K steps in flight + 1 consumed
+// The kernel is built for two tile heights, WM = wave rows of 64 tokens: WM = 2 -> 128 x 128 tile, 256 threads, 48 KiB
+// ring, 3 workgroups per CU; WM = 4 -> 256 x 128 tile, 512 threads, 72 KiB ring, 2 workgroups per CU.  The per-wave code
+// (64 x 64 outputs, 8 MFMAs per K step) is the same; the tall tile moves 3/4 of the operand bytes per flop through the
+// L2 -> LDS path (which is what bounds this kernel: tools/experiments/gemm_ablate.py), the short one balances better
+// when there are few tiles.
+template <int WM> struct GTile {
+  static constexpr int BM_ = 64 * WM, NT_ = 128 * WM;
+  static constexpr int A_BYTES = BM_ * GK * 2;
+  static constexpr int STAGE = A_BYTES + G_W_BYTES;          // A tile | W tile
+  static constexpr int A_PIECES = A_BYTES / 1024 / (2 * WM); // 1-KiB pieces (16 rows) per wave per K step: 2 / 2
+  static constexpr int W_PIECES_X2 = 2 * 8 / (2 * WM);       // W pieces per wave, doubled: 4 -> 2 per wave, 2 -> 1 per wave
+  static constexpr int LOADS = A_PIECES + W_PIECES_X2 / 2;   // LDS-DMA instructions per wave per K step (4 / 3)
+};
 constexpr int G_EPI_PITCH = BN * 2 + 16;     // bytes per staged output row
 
 typedef __attribute__((ext_vector_type(4))) unsigned g_u32x4;
@@ -229,11 +244,13 @@ template <int N, typename F> __device__ __forceinline__ void g_static_for(F&& f)
   g_static_for_impl(std::make_integer_sequence<int, N>{}, f);
 }
 
-template <int MODE>
-__global__ __launch_bounds__(NT, 3) void gemm_glds_kernel(const __bf16* __restrict__ A, const __bf16* __restrict__ W,
+template <int MODE, int WM>
+__global__ __launch_bounds__(128 * WM, WM == 2 ? 3 : 2) void gemm_glds_kernel(const __bf16* __restrict__ A, const __bf16* __restrict__ W,
                                                           const float* __restrict__ bias, __bf16* __restrict__ out,
                                                           int M, int Nout, int K, int act, QkvEpi epi) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];     // [4 stages][A tile | W tile]; reused by the epilogue
+  using GT = GTile<WM>;
+  constexpr int BM = GT::BM_, NT = GT::NT_, G_TILE_BYTES = GT::A_BYTES, G_STAGE = GT::STAGE;
+  extern __shared__ __attribute__((aligned(16))) char smem[];     // [3 stages][A tile | W tile]; reused by the epilogue
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -248,27 +265,33 @@ __global__ __launch_bounds__(NT, 3) void gemm_glds_kernel(const __bf16* __restri
   if (tile >= tiles) return;
   const int m0 = (tile / nt_n) * BM, n0 = (tile % nt_n) * BN;
 
-  // loader: per K step wave w moves 2 one-KiB pieces of A and 2 of W; piece p covers tile rows 16p .. 16p+15
+  // loader: per K step wave w moves 2 one-KiB pieces of A (tile rows 16p .. 16p+15 of piece p = 2w + j) and its share of
+  // the 8 pieces of W (2 per wave at 4 waves, 1 per wave at 8)
   const int lr = lane >> 2, lc = lane & 3;
+  constexpr int NWP = GT::W_PIECES_X2 / 2;
   const char* srcA[2];
-  const char* srcW[2];
+  const char* srcW[NWP];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int r = (wave * 2 + j) * 16 + lr;
-    const int cs = lc ^ ((r >> 2) & 3);
-    srcA[j] = reinterpret_cast<const char*>(A + (size_t)min(m0 + r, M - 1) * K) + cs * 16;
-    srcW[j] = reinterpret_cast<const char*>(W + (size_t)min(n0 + r, Nout - 1) * K) + cs * 16;
+    srcA[j] = reinterpret_cast<const char*>(A + (size_t)min(m0 + r, M - 1) * K) + (lc ^ ((r >> 2) & 3)) * 16;
+  }
+#pragma unroll
+  for (int j = 0; j < NWP; ++j) {
+    const int r = (wave * NWP + j) * 16 + lr;
+    srcW[j] = reinterpret_cast<const char*>(W + (size_t)min(n0 + r, Nout - 1) * K) + (lc ^ ((r >> 2) & 3)) * 16;
   }
   auto stage = [&](int kt, int buf) {
     char* base = smem + buf * G_STAGE;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int piece = (wave * 2 + j) * 1024;
+    for (int j = 0; j < 2; ++j)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[j] + (size_t)kt * GK * 2),
-                                       (__attribute__((address_space(3))) void*)(base + piece), 16, 0, 0);
+                                       (__attribute__((address_space(3))) void*)(base + (wave * 2 + j) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int j = 0; j < NWP; ++j)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcW[j] + (size_t)kt * GK * 2),
-                                       (__attribute__((address_space(3))) void*)(base + G_TILE_BYTES + piece), 16, 0, 0);
-    }
+                                       (__attribute__((address_space(3))) void*)(base + G_TILE_BYTES + (wave * NWP + j) * 1024),
+                                       16, 0, 0);
   };
 
   f32x16 acc[2][2];                                  // [i: 32-row block of m][j: 32-col block of n], D[n][m] orientation
@@ -305,13 +328,19 @@ __global__ __launch_bounds__(NT, 3) void gemm_glds_kernel(const __bf16* __restri
       if (kt >= nk) return;
       // my pieces of stage kt have landed when at most the (up to G_NSTAGE-2) newer stages are still in flight
       const int newer = min(G_NSTAGE - 2, nk - 1 - kt);
-      if (newer >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else if (newer == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();                  // publishes stage kt; everyone is done reading stage kt-1
-      if (kt + G_NSTAGE - 1 < nk) stage(kt + G_NSTAGE - 1, (slot + G_NSTAGE - 1) % G_NSTAGE);
+      if (AS_GEMM_ABLATE != 1) {
+        if (newer >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * GT::LOADS) : "memory");
+        else if (newer == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GT::LOADS) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      if (AS_GEMM_ABLATE != 4) __builtin_amdgcn_s_barrier();   // publishes stage kt; everyone is done reading stage kt-1
+      if (AS_GEMM_ABLATE != 1 && kt + G_NSTAGE - 1 < nk) stage(kt + G_NSTAGE - 1, (slot + G_NSTAGE - 1) % G_NSTAGE);
       g_u32x4 f[8];                                  // [ks][A0, A1, W0, W1]
-      g_static_for<2>([&](auto ks_c) {
+      if (AS_GEMM_ABLATE == 3) {
+#pragma unroll
+        for (int x = 0; x < 8; ++x) asm volatile("" : "=v"(f[x]));
+      }
+      if (AS_GEMM_ABLATE != 3) g_static_for<2>([&](auto ks_c) {
         constexpr int ks = decltype(ks_c)::value;
         g_lds_read128<slot * G_STAGE>(f[ks * 4 + 0], offA[ks]);
         g_lds_read128<slot * G_STAGE + 2048>(f[ks * 4 + 1], offA[ks]);
@@ -321,8 +350,11 @@ __global__ __launch_bounds__(NT, 3) void gemm_glds_kernel(const __bf16* __restri
       // the first half's MFMAs start as soon as ITS four fragments are back; the second half's reads finish under them
       g_static_for<2>([&](auto ks_c) {
         constexpr int ks = decltype(ks_c)::value;
-        if (ks == 0) g_lds_wait4<4>(f[0], f[1], f[2], f[3]);
-        else g_lds_wait4<0>(f[4], f[5], f[6], f[7]);
+        if (AS_GEMM_ABLATE != 3) {
+          if (ks == 0) g_lds_wait4<4>(f[0], f[1], f[2], f[3]);
+          else g_lds_wait4<0>(f[4], f[5], f[6], f[7]);
+        }
+        if (AS_GEMM_ABLATE == 2) return;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -391,7 +423,13 @@ __global__ __launch_bounds__(NT, 3) void gemm_glds_kernel(const __bf16* __restri
     const int row = m0 + rr, col = n0 + ch * 8;
     if (row >= M || col >= Nout) continue;
     const uint4 v = *reinterpret_cast<const uint4*>(smem + rr * G_EPI_PITCH + ch * 16);
-    if (MODE == 0) {
+    if (MODE == 2) {
+      // 2x2 / stride-2 transposed convolution: GEMM row = input pixel (b*h + i, j) of a grid epi.N wide, column =
+      // (di, dj, co) with co < epi.D -> NHWC output pixel (2 (b*h + i) + di, 2 j + dj); a 16-byte chunk never straddles
+      const int bi = row / epi.N, j = row - bi * epi.N;
+      const int tap = col / epi.D, co = col - tap * epi.D;
+      *reinterpret_cast<uint4*>(out + ((size_t)(2 * bi + (tap >> 1)) * (2 * epi.N) + 2 * j + (tap & 1)) * epi.D + co) = v;
+    } else if (MODE == 0) {
       if (col + 8 <= Nout) {
         *reinterpret_cast<uint4*>(out + (size_t)row * Nout + col) = v;
       } else {
@@ -411,21 +449,40 @@ __global__ __launch_bounds__(NT, 3) void gemm_glds_kernel(const __bf16* __restri
   }
 }
 
-template <int MODE>
-int launch_gemm_glds(const void* A, const void* W, const float* bias, void* out, int M, int Nout, int K, int act,
-                     QkvEpi epi, hipStream_t s) {
-  const int tiles = as_ceil_div(M, BM) * as_ceil_div(Nout, BN);
+template <int MODE, int WM>
+int launch_gemm_glds_wm(const void* A, const void* W, const float* bias, void* out, int M, int Nout, int K, int act,
+                        QkvEpi epi, hipStream_t s) {
+  using GT = GTile<WM>;
+  const int tiles = as_ceil_div(M, GT::BM_) * as_ceil_div(Nout, BN);
   dim3 grid(8 * as_ceil_div(tiles, 8));              // 1-D, padded to a multiple of the 8 XCDs (see the tile order)
-  const size_t lds = (size_t)G_NSTAGE * G_STAGE;     // 48 KiB (epilogue staging: 128 x 272 B + 512 B bias = 35 KiB)
+  // ring 48 / 72 KiB; the epilogue restages the output tile in it: BM x 272 B + 512 B bias = 35 / 70 KiB
+  const size_t lds = (size_t)G_NSTAGE * GT::STAGE;
+  static_assert(GT::BM_ * G_EPI_PITCH + BN * 4 <= G_NSTAGE * GT::STAGE, "epilogue staging must fit the ring");
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_glds_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)gemm_glds_kernel<MODE, WM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_glds_kernel<MODE>), grid, dim3(NT), lds, s, (const __bf16*)A, (const __bf16*)W, bias,
+  hipLaunchKernelGGL((gemm_glds_kernel<MODE, WM>), grid, dim3(GT::NT_), lds, s, (const __bf16*)A, (const __bf16*)W, bias,
                      (__bf16*)out, M, Nout, K, act, epi);
   AS_CHECK_LAUNCH("gemm_glds");
   return AS_OK;
+}
+
+// Tile height.  AS_GEMM_TILE_M=128|256 forces one; otherwise the cheaper of the two under a per-CU round model: a CU
+// works through ceil(tiles / 256) tiles, a tall tile is two short ones of work done 1.28x as fast (measured at 4096^3:
+// 662 -> 846 TFLOP/s), e.g. M = 8394: N = 768 -> 198 tall tiles, one round of 2/1.28 < two short rounds; M = 8192,
+// N = 512 -> 128 tall tiles would leave half the CUs idle: short.
+template <int MODE>
+int launch_gemm_glds(const void* A, const void* W, const float* bias, void* out, int M, int Nout, int K, int act,
+                     QkvEpi epi, hipStream_t s) {
+  static const int forced = [] { const char* e = getenv("AS_GEMM_TILE_M"); return e ? atoi(e) : 0; }();
+  const int nt_n = as_ceil_div(Nout, BN);
+  const float tall_cost = (float)as_ceil_div(as_ceil_div(M, 256) * nt_n, 256) * (2.0f / 1.28f);
+  const float short_cost = (float)as_ceil_div(as_ceil_div(M, 128) * nt_n, 256);
+  const bool tall = forced == 256 || (forced != 128 && tall_cost < short_cost);
+  return tall ? launch_gemm_glds_wm<MODE, 4>(A, W, bias, out, M, Nout, K, act, epi, s)
+              : launch_gemm_glds_wm<MODE, 2>(A, W, bias, out, M, Nout, K, act, epi, s);
 }
 
 template <typename T, int MODE>
@@ -454,6 +511,17 @@ extern "C" int as_linear_fwd(const void* x, const void* W, const float* bias, vo
   if (dtype == AS_BF16) return launch_gemm<__bf16, 0>(x, W, bias, out, M, Nout, K, act, epi, s);
   if (dtype == AS_F32) return launch_gemm<float, 0>(x, W, bias, out, M, Nout, K, act, epi, s);
   AS_REQUIRE(false, AS_E_UNSUPPORTED, "as_linear_fwd: dtype %d", dtype);
+}
+
+extern "C" int as_deconv2x2_fwd(const void* x, const void* W4, const float* bias4, void* out, int M, int w, int cin, int cout,
+                                int dtype, int act, as_stream_t stream) {
+  AS_REQUIRE(x && W4 && out, AS_E_BADARG, "as_deconv2x2_fwd: null pointer");
+  AS_REQUIRE(M > 0 && w > 0 && M % w == 0 && cin > 0 && cout > 0, AS_E_BADARG, "as_deconv2x2_fwd: bad sizes");
+  AS_REQUIRE(dtype == AS_BF16 && cin % GK == 0 && cout % 8 == 0, AS_E_UNSUPPORTED,
+             "as_deconv2x2_fwd: bf16 with cin %% 32 == 0 and cout %% 8 == 0 only (cin=%d cout=%d dtype=%d)", cin, cout, dtype);
+  AS_REQUIRE(act == 0 || act == 1, AS_E_BADARG, "as_deconv2x2_fwd: act must be 0 or 1");
+  QkvEpi epi{nullptr, nullptr, nullptr, w, 0, cout, 0};
+  return launch_gemm_glds<2>(x, W4, bias4, out, M, 4 * cout, cin, act, epi, (hipStream_t)stream);
 }
 
 extern "C" int as_qkv_fwd(const void* x, const void* Wqkv, const float* bqkv, void* q, void* k, void* vt, int B,

@@ -267,11 +267,41 @@ __global__ __launch_bounds__(RO_NT) void rollout_step2_kernel(const T* __restric
 // ---------------------------------------------------------------------------------------------------------
 // rollout_step3: barrier-free inner loop.  Each WAVE takes whole 32-row contraction blocks (all heads) of the
 // workgroup's range, so the head-mean tile never leaves its registers: no per-block LDS exchange, no per-block
-// barrier, LDS holds only the K_j tile (48 KiB at h = 12).  Per block a wave runs, per head, one exact-fp32 MFMA that
-// injects -8*lse in accumulator layout + 4 MFMAs q.k^T and 16 exp2, then 8 MFMAs R . Pbar for all four 32-row blocks
+// barrier, LDS holds only the K_j tile (48 KiB at h = 12).  Per block a wave runs, per head, one MFMA that injects
+// -8*lse in accumulator layout (inject_rows) + 4 MFMAs q.k^T and 16 exp2, then 8 MFMAs R . Pbar for all four 32-row blocks
 // of R.  Q fragments are prefetched one head ahead, R fragments at the top of the block.  The four waves'
 // accumulators are summed once at the end (two passes through LDS, fixed order).
 // ---------------------------------------------------------------------------------------------------------
+#ifndef AS_ROLLOUT_ABLATE
+#define AS_ROLLOUT_ABLATE 0                    // timing ablations (tools/experiments/rollout_ablate.py); wrong results when != 0
+#endif
+// -8*lse[row] enters the score accumulators through an MFMA (it has to land in accumulator layout: 16 different rows per
+// lane).  fp32 tensors: one exact v_mfma_f32_32x32x2_f32.  bf16 tensors: the value is split into three bf16 terms
+// (8 + 8 + 8 mantissa bits: hi + mid + lo == x to the last fp32 bit) on k-slots 0..2 of ONE bf16 MFMA against ones --
+// half the matrix-pipe time of the fp32 instruction.
+template <typename T> __device__ __forceinline__ f32x16 inject_rows(float x, int half);
+template <> __device__ __forceinline__ f32x16 inject_rows<float>(float x, int half) {
+  f32x16 z;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) z[r] = 0.0f;
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(half == 0 ? x : 0.0f, 1.0f, z, 0, 0, 0);
+}
+template <> __device__ __forceinline__ f32x16 inject_rows<__bf16>(float x, int half) {
+  f32x16 z;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) z[r] = 0.0f;
+  x = half == 0 ? x : 0.0f;
+  const __bf16 hi = (__bf16)x;
+  const float r1 = x - (float)hi;
+  const __bf16 mid = (__bf16)r1;
+  const __bf16 lo = (__bf16)(r1 - (float)mid);
+  const __bf16 zero = (__bf16)0.0f, one = (__bf16)1.0f;
+  Frag<__bf16> fa, fb;
+  fa.v = bf16x8{hi, mid, lo, zero, zero, zero, zero, zero};
+  fb.v = bf16x8{one, one, one, zero, zero, zero, zero, zero};
+  return mma32(fa, fb, z);
+}
+
 template <typename T>
 __global__ __launch_bounds__(RO_NT, 3) void rollout_step3_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                                  const float* __restrict__ lse,
@@ -324,24 +354,25 @@ __global__ __launch_bounds__(RO_NT, 3) void rollout_step3_kernel(const T* __rest
 #pragma unroll
     for (int r = 0; r < 16; ++r) pbar[r] = 0.0f;
     auto head = [&](int hh) {
-      f32x16 sc;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) sc[r] = 0.0f;
-      sc = __builtin_amdgcn_mfma_f32_32x32x2f32(half == 0 ? l8 : 0.0f, 1.0f, sc, 0, 0, 0);   // -8*lse[row i], exact
+      f32x16 sc = inject_rows<T>(AS_ROLLOUT_ABLATE == 3 ? 0.0f : l8, half);       // -8*lse[row i]
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         Frag<T> fk;
         fk.load16B(reinterpret_cast<const T*>(kj + Kj2<T>::off(hh * 32 + li, ks * 16 + half * 8)));
-        sc = mma32(fq[ks], fk, sc);
+        if (AS_ROLLOUT_ABLATE != 4) sc = mma32(fq[ks], fk, sc);
+        else sc[ks] += (float)fk.v[0];
       }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) pbar[r] += __builtin_amdgcn_exp2f(sc[r] * c2);
+      for (int r = 0; r < 16; ++r) pbar[r] += AS_ROLLOUT_ABLATE == 2 ? sc[r] * c2 : __builtin_amdgcn_exp2f(sc[r] * c2);
     };
     for (int hh = 0; hh + 1 < h; ++hh) {                  // heads 0 .. h-2: next head's Q fragments in flight
       Frag<T> fn[4];
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) fn[ks].load16B(q + qf_frag((size_t)b * h + hh + 1, Npad, row, ks, half));
-      const float l8n = -8.0f * lse[((size_t)b * h + hh + 1) * N + row];
+      for (int ks = 0; ks < 4; ++ks) {
+        if (AS_ROLLOUT_ABLATE == 1) fn[ks] = fq[ks];
+        else fn[ks].load16B(q + qf_frag((size_t)b * h + hh + 1, Npad, row, ks, half));
+      }
+      const float l8n = AS_ROLLOUT_ABLATE == 1 ? l8 : -8.0f * lse[((size_t)b * h + hh + 1) * N + row];
       head(hh);
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) fq[ks] = fn[ks];

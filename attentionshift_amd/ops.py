@@ -117,6 +117,21 @@ def linear(x, weight, bias=None, act="none"):
     return out.reshape(*x.shape[:-1], weight.shape[0])
 
 
+def deconv2x2(x_nhwc, w4, bias4=None, act="none"):
+    """ConvTranspose2d(k=2, s=2) on a channels-last bf16 map [B,h,w,cin] -> [B,2h,2w,cout] (one GEMM, scattered epilogue).
+    w4 [4*cout, cin] bf16 (row (di*2+dj)*cout + co), bias4 [4*cout] fp32 | None."""
+    lib = _lib.load()
+    B, h, w, cin = x_nhwc.shape
+    cout = w4.shape[0] // 4
+    _chk(x_nhwc, w4)
+    if bias4 is not None:
+        _chk(bias4, dtype=torch.float32)
+    out = torch.empty(B, 2 * h, 2 * w, cout, device=x_nhwc.device, dtype=x_nhwc.dtype)
+    _lib.check(lib.as_deconv2x2_fwd(_p(x_nhwc), _p(w4), _p(bias4), _p(out), B * h * w, w, cin, cout, _dt(x_nhwc),
+                                    1 if act == "gelu" else 0, _stream()), "as_deconv2x2_fwd")
+    return out
+
+
 def add_layernorm(x, delta, gamma, beta, eps, out_dtype, want_x=True, want_y=True):
     """x_new = x + delta (fp32; delta may be None), y = LayerNorm(x_new) in `out_dtype` -- one pass (csrc/layernorm.hip).
     Returns (x_new | None, y | None)."""

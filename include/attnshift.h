@@ -56,6 +56,15 @@ int as_npad(int N);
 int as_linear_fwd(const void* x, const void* W, const float* bias, void* out, int M, int Nout, int K,
                   int dtype, int act, as_stream_t stream);
 
+/* nn.ConvTranspose2d(cin, cout, kernel 2, stride 2) on a channels-last map as one GEMM over its pixels
+ * (mmdet/models/backbones/visual_transformer_det.py:107-117, the FPN taps): x [M = B*h*w, cin] (pixel-major, grid w wide),
+ * W4 [4*cout, cin] with row (di*2 + dj)*cout + co = weight[ci, co, di, dj], bias4 [4*cout] fp32 or NULL ->
+ * out NHWC [B, 2h, 2w, cout]: out[b, 2i+di, 2j+dj, co] = act(sum_ci x[b,i,j,ci] W[ci,co,di,dj] + bias[co]); the epilogue
+ * scatters straight to the interleaved pixel (no layout copy).  act as as_linear_fwd (an eval-mode BatchNorm that follows
+ * is folded into W4 / bias4 by the caller).  bf16 only; cin % 32 == 0, cout % 8 == 0. */
+int as_deconv2x2_fwd(const void* x, const void* W4, const float* bias4, void* out, int M, int w, int cin, int cout,
+                     int dtype, int act, as_stream_t stream);
+
 /* QKV projection with the head split fused into the epilogue (vision_transformer.py:75-77):
  *   k : [B,h,Npad,64]   vt : [B,h,64,Npad]  (V transposed so the P.V MFMA reads keys contiguously)
  *   q : [B,h,Npad,64] elements, FRAGMENT-MAJOR inside every 32-row x 64-d tile: element (r, d) of a tile sits at

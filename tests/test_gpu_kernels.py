@@ -715,6 +715,25 @@ def test_swin_block_matches_reference(ops, golden, tag, dtype, tol):
     assert mx < tol, ("attention probabilities", mx)
 
 
+@pytest.mark.parametrize("B,h,w,cin,cout", [(2, 5, 7, 96, 40), (1, 16, 16, 64, 128), (2, 64, 64, 768, 768)])
+@pytest.mark.parametrize("act", ["none", "gelu"])
+def test_deconv2x2_matches_conv_transpose(ops, B, h, w, cin, cout, act):
+    """as_deconv2x2_fwd (one GEMM over the pixels, epilogue scattering to the interleaved NHWC pixel) vs
+    F.conv_transpose2d(kernel 2, stride 2) (+ exact GELU) on the same bf16-rounded operands; includes the FPN shape."""
+    g = torch.Generator().manual_seed(cin + cout)
+    x = torch.randn(B, h, w, cin, generator=g).bfloat16()
+    wt = (torch.randn(cin, cout, 2, 2, generator=g) * cin ** -0.5).bfloat16()
+    bias = torch.randn(cout, generator=g)
+    ref = torch.nn.functional.conv_transpose2d(x.float().permute(0, 3, 1, 2), wt.float(), bias, stride=2)
+    if act == "gelu":
+        ref = torch.nn.functional.gelu(ref)
+    w4 = wt.permute(2, 3, 1, 0).reshape(4 * cout, cin).contiguous()
+    got = ops.deconv2x2(dev(x), dev(w4), dev(bias.repeat(4)), act=act)
+    assert got.shape == (B, 2 * h, 2 * w, cout) and got.dtype == torch.bfloat16
+    mx, mean = rel_to_range(ref.permute(0, 2, 3, 1), got.float())
+    assert mx < 1e-2 and mean < 1e-3, (mx, mean)
+
+
 @pytest.mark.parametrize("H,W,heads,shift", [(14, 14, 2, 0), (14, 14, 4, 3), (16, 23, 3, 3), (9, 30, 8, 0), (37, 5, 5, 6)])
 def test_window_attention_mfma_matches_the_fp32_kernel(ops, H, W, heads, shift):
     """bf16 tensors take the MFMA kernel, fp32 tensors the fp32 VALU kernel (which the reference fixtures pin at 1e-4):

@@ -20,7 +20,23 @@ def main(db, out, title):
                      f"{100.0 * tot / total:.1f} | {vg} | {lds} |")
     lines.append("")
     lines.append(f"total kernel time {total / 1e6:.3f} ms over {sum(r[1] for r in rows)} dispatches")
+    pat = __import__("os").environ.get("PROF_BY_GRID")        # e.g. PROF_BY_GRID=gemm: split matching kernels by grid size
+    if pat:
+        cols = [r[1] for r in c.execute("pragma table_info(kernels)").fetchall()]
+        gcol = "grid_x" if "grid_x" in cols else ("grid_size_x" if "grid_size_x" in cols else None)
+        if gcol:
+            lines += ["", f"## kernels matching `{pat}` by grid size", "", "| kernel | grid x | calls | avg us | min us | max us |",
+                      "|---|---|---|---|---|---|"]
+            q = (f"select name, {gcol}, count(*), avg(duration), min(duration), max(duration) from kernels where name like ? "
+                 f"group by name, {gcol} order by sum(duration) desc")
+            for name, gx, n, avg, mn, mx in c.execute(q, (f"%{pat}%",)).fetchall()[:40]:
+                lines.append(f"| `{name[:60]}` | {gx} | {n} | {avg / 1e3:.2f} | {mn / 1e3:.2f} | {mx / 1e3:.2f} |")
+        else:
+            lines += ["", f"(no grid column among {cols})"]
     open(out, "w").write("\n".join(lines) + "\n")
+    if pat:
+        print("\n".join(lines[-44:]))
+        return
     print("\n".join(lines[:40]))
 
 
