@@ -938,7 +938,15 @@ class AttnShiftRoIHead(nn.Module):
 
     def _semantic_post_device(self, prot, sim, fg_inter, rois, vit_feat, gt_labels, merge_thr, num_semantic_points,
                               extra=None, num_max_keep=50):
-        """_semantic_post with ONE readback at its end (fast-RNG path): the greedy merge plan (ops.merge_plan), the
+        """_semantic_post_issue + _semantic_post_finish back to back (one image at a time)."""
+        return self._semantic_post_finish(self._semantic_post_issue(prot, sim, fg_inter, rois, vit_feat, gt_labels,
+                                                                   merge_thr, num_semantic_points, extra), num_max_keep)
+
+    def _semantic_post_issue(self, prot, sim, fg_inter, rois, vit_feat, gt_labels, merge_thr, num_semantic_points,
+                             extra=None):
+        """_semantic_post with ONE readback (fast-RNG path), first half: everything up to and including the START of
+        that readback (a device -> pinned-host copy + event), so that a caller with several images can queue all of them
+        before it waits for the first: the greedy merge plan (ops.merge_plan), the
         merged prototypes, their similarity maps and the per-part statistics are computed for all P group slots of
         every object (unused slots are zero prototypes), the visiting order / cap logic of stdroi:222-262 becomes a
         stable rank over the slots, and only the choice bits, ranks and group counts are read back -- together with
@@ -982,7 +990,15 @@ class AttnShiftRoIHead(nn.Module):
         pieces = [chosen.flatten().int(), rank.flatten().int(), ngroups]
         if extra:
             pieces.append(torch.stack([e.reshape(()) for e in extra]).int())
-        host = torch.cat(pieces).cpu().numpy()                                         # the one sync
+        return dict(pending=_to_host_issue(torch.cat(pieces)), extra=extra, G=G, P=P, sims=sims, rois=rois, c=c, cy=cy, cx=cx,
+                    gt_labels=gt_labels, vit_feat=vit_feat, dev=dev)
+
+    def _semantic_post_finish(self, st, num_max_keep=50):
+        """Second half: wait for the readback (the one sync of the image), resolve the visiting order on the host and
+        gather the chosen parts.  Returns None when a flag asks for the synchronous path."""
+        host = _to_host_finish(st["pending"])
+        extra, G, P, sims, rois, c, cy, cx = (st[k] for k in ("extra", "G", "P", "sims", "rois", "c", "cy", "cx"))
+        gt_labels, vit_feat, dev = st["gt_labels"], st["vit_feat"], st["dev"]
         if extra:
             extra[:] = [bool(v) for v in host[2 * G * P + G:]]
             if any(extra):
@@ -1206,13 +1222,16 @@ class AttnShiftRoIHead(nn.Module):
             shifted = self.mean_shift_batch([r[6][1] for r in ra], feats, pseudo_boxes, self.mean_shift_times_local,
                                             feat_tok=feat_tok)
 
-            def image_chain_nosync(i):
+            def chain_issue(i):
                 prot, sim = shifted[i]
                 extra = [bad_cam] + ra[i][8]
-                sc = self._semantic_post_device(prot, sim, ra[i][6][0], pseudo_boxes[i], feats[i], gt_labels[i], 0.85,
-                                                self.num_semantic_points, extra=extra)
+                return self._semantic_post_issue(prot, sim, ra[i][6][0], pseudo_boxes[i], feats[i], gt_labels[i], 0.85,
+                                                 self.num_semantic_points, extra=extra)
+
+            def chain_finish(i, st):
+                sc = self._semantic_post_finish(st)
                 if sc is None:
-                    if extra[0]:
+                    if st["extra"][0]:
                         raise RuntimeError("seed_pseudo_gt: a CAM has no foreground component (constant attention map)")
                     r = phase_a_finish(i, phase_a(i))            # a rare branch needs host logic: synchronous path
                     prot, sim = self.mean_shift_batch([r[6][1]], [feats[i]], [pseudo_boxes[i]],
@@ -1222,9 +1241,12 @@ class AttnShiftRoIHead(nn.Module):
                     return r[:6] + (sc, _to_host_finish(r[7]))
                 return ra[i][:6] + (sc, _to_host_finish(ra[i][7]))
 
+            # every image's merge inputs and readback are queued before the host waits for the first one: image i+1's
+            # device work and copy run while the host resolves image i's parts
             for st in self._streams[:num_imgs]:
                 st.wait_stream(main)
-            results = [on_stream(i, image_chain_nosync) for i in range(num_imgs)]
+            pend = [on_stream(i, chain_issue) for i in range(num_imgs)]
+            results = [on_stream(i, chain_finish, pend[i]) for i in range(num_imgs)]
             for st in self._streams[:num_imgs]:
                 main.wait_stream(st)
             ra = None
