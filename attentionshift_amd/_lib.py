@@ -46,6 +46,7 @@ SIGNATURES = {
     "as_mask_candidates_workspace_bytes": (_c_size_t, [_c_int] * 3),
     "as_mask_candidates": (_c_int, [_c_void_p] * 3 + [_c_float] * 3 + [_c_int] + [_c_void_p] * 5 + [_c_size_t]
                            + [_c_int] * 3 + [_c_void_p]),
+    "as_part_select": (_c_int, [_c_void_p] * 7 + [_c_int] * 5 + [_c_void_p] * 8 + [_c_void_p]),
     "as_part_stats": (_c_int, [_c_void_p] * 3 + [_c_float] + [_c_void_p] * 4 + [_c_int] * 3 + [_c_void_p]),
     "as_filter_parts": (_c_int, [_c_void_p] * 2 + [_c_float] * 2 + [_c_void_p] + [_c_int] * 3 + [_c_void_p]),
     "as_draw_distinct": (_c_int, [_c_void_p] * 6 + [_c_int] * 3 + [_c_void_p]),

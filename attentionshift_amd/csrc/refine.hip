@@ -305,6 +305,97 @@ extern "C" int as_part_stats(const float* maps, const float* rois, const int32_t
 }
 
 // =====================================================================================================
+// Part selection of get_center_coord_with_feat (stdroi:222-262) for all objects without a host decision.  Per object g
+// the P slots (the first ngroups[g] exist) are visited in stable descending-area order; a slot is taken when its centre
+// lies inside the object's box and its position in that order is <= num_points (`if i > num_max_obj: break`).  The
+// taken slots of object 0, 1, ... are compacted in visiting order: row r of the outputs holds the r-th taken slot's
+// centre (twice: the reference returns a clone), the object's label (twice), the object index, and the backbone
+// feature at the slot's integer centroid.  split[g] = slots taken by object g, split[G] = their total; rows >= total
+// are zero.  One workgroup walks the objects (a prefix over g is needed), a second launch copies the feature rows.
+// =====================================================================================================
+namespace {
+constexpr int PS_NT = 256;
+__global__ __launch_bounds__(PS_NT) void part_select_kernel(const int32_t* __restrict__ area, const uint8_t* __restrict__ inside,
+                                                            const int32_t* __restrict__ ngroups, const float* __restrict__ c,
+                                                            const int64_t* __restrict__ labels, int G, int P, int num_points,
+                                                            float* __restrict__ coords, float* __restrict__ coords_org,
+                                                            int64_t* __restrict__ out_labels, int64_t* __restrict__ labels_org,
+                                                            int64_t* __restrict__ corres, int32_t* __restrict__ sel_slot,
+                                                            int32_t* __restrict__ split) {
+  __shared__ int a_s[PS_NT], rank_s[PS_NT], chosen_s[PS_NT];
+  __shared__ int base_s;
+  const int p = threadIdx.x;
+  if (p == 0) base_s = 0;
+  for (int i = p; i < G * P; i += PS_NT) {            // rows that stay unused read as zeros
+    coords[2 * i] = coords[2 * i + 1] = coords_org[2 * i] = coords_org[2 * i + 1] = 0.0f;
+    out_labels[i] = labels_org[i] = corres[i] = 0;
+    sel_slot[i] = -1;
+  }
+  __syncthreads();
+  for (int g = 0; g < G; ++g) {
+    const bool valid = p < P && p < ngroups[g];
+    const int a = valid ? area[g * P + p] : -1;
+    a_s[p] = p < P ? a : -2;
+    __syncthreads();
+    int rank = 0;
+    for (int q = 0; q < P; ++q) rank += (a_s[q] > a || (a_s[q] == a && q < p)) ? 1 : 0;
+    const bool chosen = valid && inside[g * P + p] != 0 && rank <= num_points;
+    rank_s[p] = rank;
+    chosen_s[p] = chosen ? 1 : 0;
+    __syncthreads();
+    int pos = 0, n = 0;
+    for (int q = 0; q < P; ++q) {
+      n += chosen_s[q];
+      pos += (chosen_s[q] && rank_s[q] < rank) ? 1 : 0;
+    }
+    if (chosen) {
+      const int r = base_s + pos, slot = g * P + p;
+      const float x = c[2 * slot], y = c[2 * slot + 1];
+      coords[2 * r] = x; coords[2 * r + 1] = y;
+      coords_org[2 * r] = x; coords_org[2 * r + 1] = y;
+      out_labels[r] = labels[g]; labels_org[r] = labels[g];
+      corres[r] = g;
+      sel_slot[r] = slot;
+    }
+    __syncthreads();
+    if (p == 0) { split[g] = n; base_s += n; }
+    __syncthreads();
+  }
+  if (p == 0) split[G] = base_s;
+}
+
+// feats[r, :] = feat_tok[yx[slot_r].y * Wp + yx[slot_r].x, :]  (vit_feat[:, cy, cx] of the token-major features)
+__global__ __launch_bounds__(PS_NT) void part_feats_kernel(const int32_t* __restrict__ sel_slot, const int32_t* __restrict__ yx,
+                                                           const float* __restrict__ feat_tok, float* __restrict__ feats,
+                                                           int C, int Wp) {
+  const int r = blockIdx.x, slot = sel_slot[r];
+  float* dst = feats + (size_t)r * C;
+  if (slot < 0) {
+    for (int e = threadIdx.x; e < C; e += PS_NT) dst[e] = 0.0f;
+    return;
+  }
+  const float* src = feat_tok + ((size_t)yx[2 * slot] * Wp + yx[2 * slot + 1]) * C;
+  for (int e = threadIdx.x; e < C; e += PS_NT) dst[e] = src[e];
+}
+}  // namespace
+
+extern "C" int as_part_select(const int32_t* area, const uint8_t* inside, const int32_t* ngroups, const float* c,
+                              const int32_t* yx, const int64_t* labels, const float* feat_tok, int G, int P, int C, int Wp,
+                              int num_points, float* coords, float* coords_org, int64_t* out_labels, int64_t* labels_org,
+                              int64_t* corres, float* feats, int32_t* sel_slot, int32_t* split, as_stream_t stream) {
+  AS_REQUIRE(area && inside && ngroups && c && yx && labels && feat_tok && coords && coords_org && out_labels && labels_org &&
+                 corres && feats && sel_slot && split, AS_E_BADARG, "as_part_select: null pointer");
+  AS_REQUIRE(G > 0 && P > 0 && P <= PS_NT && C > 0 && Wp > 0, AS_E_BADARG, "as_part_select: need G > 0 and 0 < P <= 256 (P=%d)", P);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(part_select_kernel, dim3(1), dim3(PS_NT), 0, s, area, inside, ngroups, c, labels, G, P, num_points, coords,
+                     coords_org, out_labels, labels_org, corres, sel_slot, split);
+  AS_CHECK_LAUNCH("part_select");
+  hipLaunchKernelGGL(part_feats_kernel, dim3(G * P), dim3(PS_NT), 0, s, (const int32_t*)sel_slot, yx, feat_tok, feats, C, Wp);
+  AS_CHECK_LAUNCH("part_feats");
+  return AS_OK;
+}
+
+// =====================================================================================================
 // filter_maps (stdroi:263-271) for all G*P shifted prototypes in one launch: the share of a prototype's > sim_thr
 // support that lies on the object's patch-grid foreground, keep = share >= pos_thr.  fg_inter holds multiples of 1/4
 // and the support is 0/1, so both sums are exact in fp32 whatever the order.

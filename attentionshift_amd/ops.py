@@ -515,9 +515,8 @@ def mask_candidates(map_fg, map_bg, crops, pos_thr, neg_thr, mask_thr, k):
     return pos, neg, pseudo, counts
 
 
-def part_stats(maps, rois, owner, stride=16):
-    """maps [M,hp,wp] fp32, rois [G,4] fp32, owner [M] int -> (c [M,2] (x,y) image coords of the peak centroid,
-    yx [M,2] long (integer centroid), area [M] long (pixels > 0.9), inside [M] bool) -- stdroi:222-262 per part."""
+def part_stats_raw(maps, rois, owner, stride=16):
+    """as_part_stats with the kernel's own output types: (c [M,2] fp32, yx [M,2] int32, area [M] int32, inside [M] uint8)."""
     lib = _lib.load()
     maps = maps.contiguous()
     rois = rois.contiguous().float()
@@ -530,7 +529,35 @@ def part_stats(maps, rois, owner, stride=16):
     inside = torch.empty(M, device=maps.device, dtype=torch.uint8)
     _lib.check(lib.as_part_stats(_p(maps), _p(rois), _p(own), float(stride), _p(c), _p(yx), _p(area), _p(inside), M, hp, wp,
                                  _stream()), "as_part_stats")
+    return c, yx, area, inside
+
+
+def part_stats(maps, rois, owner, stride=16):
+    """maps [M,hp,wp] fp32, rois [G,4] fp32, owner [M] int -> (c [M,2] (x,y) image coords of the peak centroid,
+    yx [M,2] long (integer centroid), area [M] long (pixels > 0.9), inside [M] bool) -- stdroi:222-262 per part."""
+    c, yx, area, inside = part_stats_raw(maps, rois, owner, stride)
     return c, yx.long(), area.long(), inside.bool()
+
+
+def part_select(area, inside, ngroups, c, yx, labels, feat_tok, G, P, wp, num_points):
+    """Visiting order / cap logic of stdroi:222-262 + the gathers that follow it, on the device (as_part_select).
+    area / inside / c / yx: part_stats_raw outputs for G*P slots; ngroups [G] int32; labels [G] int64; feat_tok [Np,C]
+    fp32.  Returns padded (coords, coords_org [G*P,2], labels, labels_org, corres [G*P] int64, feats [G*P,C], split [G+1]
+    int32: per-object counts + total); rows >= total are zero."""
+    lib = _lib.load()
+    _chk(c, feat_tok, dtype=torch.float32)
+    _chk(area, yx, ngroups, dtype=torch.int32)
+    _chk(inside, dtype=torch.uint8)
+    _chk(labels, dtype=torch.int64)
+    dev, M, C = c.device, G * P, feat_tok.shape[-1]
+    coords = torch.empty(2, M, 2, device=dev, dtype=torch.float32)
+    lab = torch.empty(3, M, device=dev, dtype=torch.int64)
+    feats = torch.empty(M, C, device=dev, dtype=torch.float32)
+    ints = torch.empty(M + G + 1, device=dev, dtype=torch.int32)          # sel_slot | split
+    _lib.check(lib.as_part_select(_p(area), _p(inside), _p(ngroups), _p(c), _p(yx), _p(labels), _p(feat_tok), G, P, C, int(wp),
+                                  int(num_points), _p(coords[0]), _p(coords[1]), _p(lab[0]), _p(lab[1]), _p(lab[2]), _p(feats),
+                                  _p(ints[:M]), _p(ints[M:]), _stream()), "as_part_select")
+    return coords[0], coords[1], lab[0], lab[1], lab[2], feats, ints[M:]
 
 
 def filter_parts(sim, fg_inter, sim_thr=0.8, pos_thr=0.85):

@@ -76,12 +76,28 @@ def _gen():
     return getattr(_TLS, "gen", None)
 
 
-def _to_host_issue(t):
-    """Start the device -> pinned-host copy of `t` on the current stream; returns (pinned tensor, event)."""
+_COPY_STREAMS = {}
+
+
+def _to_host_issue(t, side_stream=False):
+    """Start the device -> pinned-host copy of `t`; returns (pinned tensor, event).  With `side_stream` the copy runs on
+    a per-device copy stream behind an event of the current stream, so the kernels queued after it on the current stream
+    do not wait for the PCIe transfer (the 3 MB pseudo-mask stack of an image takes ~0.1 ms)."""
     host = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
-    host.copy_(t, non_blocking=True)
+    cur = torch.cuda.current_stream()
+    if side_stream:
+        cs = _COPY_STREAMS.get(t.device)
+        if cs is None:
+            cs = _COPY_STREAMS[t.device] = torch.cuda.Stream(device=t.device)
+        cs.wait_stream(cur)
+        with torch.cuda.stream(cs):
+            host.copy_(t, non_blocking=True)
+        t.record_stream(cs)
+        cur = cs
+    else:
+        host.copy_(t, non_blocking=True)
     ev = torch.cuda.Event()
-    ev.record(torch.cuda.current_stream())
+    ev.record(cur)
     return host, ev
 
 
@@ -977,58 +993,46 @@ class AttnShiftRoIHead(nn.Module):
         ar = torch.arange(P, device=dev)
         sims = torch.cat([ops.refine_similarity(feat_tok, allp[o:o + 32], None, 0, 0, 1.0, False, hp, wp)[0][0]
                           for o in range(0, G * P, 32)]).reshape(G, P, hp, wp)
-        # per-slot statistics exactly as part_centers computes them per part (one launch)
+        # per-slot statistics exactly as part_centers computes them per part (one launch), then the visiting order / cap
+        # logic of stdroi:222-262 and the gathers behind it in as_part_select: nothing here waits for the host
         slot_owner = torch.arange(G, device=dev).repeat_interleave(P)
-        c, cyx, area, inside = ops.part_stats(sims.flatten(0, 1), rois, slot_owner, STRIDE)
-        c, cy, cx = c.unflatten(0, (G, P)), cyx[:, 0].unflatten(0, (G, P)), cyx[:, 1].unflatten(0, (G, P))
-        area, inside = area.unflatten(0, (G, P)), inside.unflatten(0, (G, P))
-        valid = ar[None, :] < ngroups[:, None]
-        a = torch.where(valid, area, torch.full_like(area, -1))
-        before = (a[:, None, :] > a[:, :, None]) | ((a[:, None, :] == a[:, :, None]) & (ar[None, None, :] < ar[None, :, None]))
-        rank = before.sum(-1)                                # position in argsort(descending, stable)
-        chosen = valid & inside & (rank <= num_semantic_points)                       # `if i > num_max_obj: break`
-        pieces = [chosen.flatten().int(), rank.flatten().int(), ngroups]
+        c, yx, area, inside = ops.part_stats_raw(sims.flatten(0, 1), rois, slot_owner, STRIDE)
+        ng32 = ngroups.to(torch.int32).contiguous()
+        coords, coords_org, labels, labels_org, corres, feats, split = ops.part_select(
+            area, inside, ng32, c, yx, gt_labels.long().contiguous(), feat_tok, G, P, wp, num_semantic_points)
+        pieces = [split, ng32]
         if extra:
             pieces.append(torch.stack([e.reshape(()) for e in extra]).int())
-        return dict(pending=_to_host_issue(torch.cat(pieces)), extra=extra, G=G, P=P, sims=sims, rois=rois, c=c, cy=cy, cx=cx,
-                    gt_labels=gt_labels, vit_feat=vit_feat, dev=dev)
+        return dict(pending=_to_host_issue(torch.cat(pieces)), extra=extra, G=G, P=P, sims=sims, rois=rois, dev=dev,
+                    gt_labels=gt_labels, picked=(coords, coords_org, labels, labels_org, corres, feats))
 
     def _semantic_post_finish(self, st, num_max_keep=50):
-        """Second half: wait for the readback (the one sync of the image), resolve the visiting order on the host and
-        gather the chosen parts.  Returns None when a flag asks for the synchronous path."""
+        """Second half: wait for the readback (the one sync of the image) and slice the padded device results by the
+        per-object counts.  Returns None when a flag asks for the synchronous path."""
         host = _to_host_finish(st["pending"])
-        extra, G, P, sims, rois, c, cy, cx = (st[k] for k in ("extra", "G", "P", "sims", "rois", "c", "cy", "cx"))
-        gt_labels, vit_feat, dev = st["gt_labels"], st["vit_feat"], st["dev"]
+        extra, G, P, sims, rois, dev, gt_labels = (st[k] for k in ("extra", "G", "P", "sims", "rois", "dev", "gt_labels"))
         if extra:
-            extra[:] = [bool(v) for v in host[2 * G * P + G:]]
+            extra[:] = [bool(v) for v in host[2 * G + 1:]]
             if any(extra):
                 return None
-        ch, rk, ng = host[:G * P].reshape(G, P), host[G * P:2 * G * P].reshape(G, P), host[2 * G * P:2 * G * P + G]
+        split, total, ng = [int(v) for v in host[:G]], int(host[G]), host[G + 1:2 * G + 1]
         sim_parts = [sims[g, :int(ng[g])] if ng[g] else torch.zeros(0, 0) for g in range(G)]
-        split = [0] * G
         dt_c, dt_l = rois.dtype, gt_labels.dtype
-        empty = ([torch.zeros(0, 2, dtype=dt_c, device=dev), torch.zeros(0, dtype=dt_l, device=dev)], [], [], [], split,
-                 torch.zeros(0, 2, dtype=dt_c, device=dev), torch.zeros(0, dtype=dt_l, device=dev),
-                 torch.zeros(0, dtype=torch.long, device=dev))
-        sel_g, sel_p = [], []
-        for g in range(G):
-            ps = [p_ for p_ in np.argsort(rk[g], kind="stable") if ch[g, p_]]
-            split[g] = len(ps)
-            sel_g += [g] * len(ps)
-            sel_p += [int(p_) for p_ in ps]
-        if not sel_g:
-            pc = empty
+        if total == 0:
+            pc = ([torch.zeros(0, 2, dtype=dt_c, device=dev), torch.zeros(0, dtype=dt_l, device=dev)], [], [], [], [0] * G,
+                  torch.zeros(0, 2, dtype=dt_c, device=dev), torch.zeros(0, dtype=dt_l, device=dev),
+                  torch.zeros(0, dtype=torch.long, device=dev))
         else:
-            sg = torch.as_tensor(sel_g, device=dev, dtype=torch.long)
-            sp = torch.as_tensor(sel_p, device=dev, dtype=torch.long)
-            coords, labels = c[sg, sp], gt_labels[sg]
-            feats = vit_feat[:, cy[sg, sp], cx[sg, sp]].t()
-            coords_org, labels_org = coords.clone(), labels.clone()
+            coords, coords_org, labels, labels_org, corres, feats = (t[:total] for t in st["picked"])
+            if dt_c != coords.dtype:
+                coords, coords_org = coords.to(dt_c), coords_org.to(dt_c)
+            if dt_l != labels.dtype:
+                labels, labels_org = labels.to(dt_l), labels_org.to(dt_l)
             coord_split, feats_split = list(coords.split(split, dim=0)), list(feats.split(split, dim=0))
-            if coords.shape[0] > num_max_keep:
-                pick = torch.randperm(coords.shape[0], device=coords.device)[:num_max_keep]
+            if total > num_max_keep:
+                pick = torch.randperm(total, device=coords.device)[:num_max_keep]
                 coords, labels = coords[pick], labels[pick]
-            pc = ([coords, labels], coord_split, feats_split, feats, split, coords_org, labels_org, sg)
+            pc = ([coords, labels], coord_split, feats_split, feats, split, coords_org, labels_org, corres)
         (centers, csplit, feat_split, feats, num_parts, coords_org, labels_org, corres) = pc
         return centers, csplit, sim_parts, feat_split, feats, num_parts, coords_org, labels_org, corres
 
@@ -1164,7 +1168,7 @@ class AttnShiftRoIHead(nn.Module):
             mp, mask_u8 = mask_points_and_pseudo_issue(map_fg[-1], map_bg[-1], pseudo_boxes[i], pos_mask_thr, neg_mask_thr,
                                                        corr_size, pos_mask_thr)                # B2' + B6 (stdroi:2356)
             fg_inter, _map_fg_patch, gs = self._semantic_pre(map_fg[-1], map_bg[-1], pos_mask_thr)   # gs: >= 0.35 of a 0/1 map
-            pm = _to_host_issue(mask_u8)
+            pm = _to_host_issue(mask_u8, side_stream=True)
             return mp, gs, map_fg, map_bg, feats_fg, feats_bg, fg_inter, pm
 
         def phase_a_finish(i, r):
@@ -1188,7 +1192,7 @@ class AttnShiftRoIHead(nn.Module):
             mp, mask_u8 = mask_points_and_pseudo_issue(map_fg[-1], map_bg[-1], pseudo_boxes[i], pos_mask_thr, neg_mask_thr,
                                                        corr_size, pos_mask_thr)
             fg_inter, _map_fg_patch, gs = self._semantic_pre(map_fg[-1], map_bg[-1], pos_mask_thr)
-            pm = _to_host_issue(mask_u8)
+            pm = _to_host_issue(mask_u8, side_stream=True)
             coord_point, labels_point, f1 = mask_points_nosync(mp, num_mask_point_gt, self._device_gen(boxes.device))
             seeds, f2 = grid_seed_nosync(gs[0], gs[1], 20)
             if self.capture is not None:

@@ -212,6 +212,16 @@ int as_mask_candidates(const float* map_fg, const float* map_bg, const int32_t* 
 int as_part_stats(const float* maps, const float* rois, const int32_t* owner, float stride, float* out_c,
                   int32_t* out_yx, int32_t* out_area, uint8_t* out_inside, int M, int Hp, int Wp, as_stream_t stream);
 
+/* Part selection of get_center_coord_with_feat (stdroi:222-262) for all G objects x P slots on the device: slots
+ * p < ngroups[g] visited in stable descending-area order, taken if inside and position <= num_points; taken slots
+ * compacted in (object, visiting) order into rows of coords / coords_org [G*P,2], out_labels / labels_org / corres
+ * [G*P] int64, feats [G*P,C] = feat_tok[yx.y * Wp + yx.x]; split [G+1] = per-object counts and their total; sel_slot
+ * [G*P] scratch.  area / inside / c / yx as as_part_stats writes them.  P <= 256. */
+int as_part_select(const int32_t* area, const uint8_t* inside, const int32_t* ngroups, const float* c, const int32_t* yx,
+                   const int64_t* labels, const float* feat_tok, int G, int P, int C, int Wp, int num_points, float* coords,
+                   float* coords_org, int64_t* out_labels, int64_t* labels_org, int64_t* corres, float* feats,
+                   int32_t* sel_slot, int32_t* split, as_stream_t stream);
+
 /* filter_maps (stdroi:263-271) for G*P prototypes: keep[g,p] = share of sim[g,p] > sim_thr lying on fg_inter[g] >= pos_thr. */
 int as_filter_parts(const float* sim /*[G,P,Np]*/, const float* fg_inter /*[G,Np]*/, float sim_thr, float pos_thr,
                     uint8_t* keep /*[G,P]*/, int G, int P, int Np, as_stream_t stream);
