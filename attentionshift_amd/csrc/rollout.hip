@@ -442,6 +442,221 @@ __global__ __launch_bounds__(RO_NT, 3) void rollout_step3_kernel(const T* __rest
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// rollout_step4 (bf16, h % 4 == 0): the step as a streamed-operand kernel.  rollout_step3 is bound by the L2 -> CU path:
+// every 32-column workgroup re-reads ALL of Q (1.7 GB per launch at B = 2, h = 12, N = 4197;
+// tools/experiments/rollout_ablate.py).  Here a workgroup owns 128 key columns x 4 HEADS: each of its four waves keeps
+// the K fragments of ITS 32 columns in registers (4 heads x 4 k16 steps), and the 32-row contraction blocks -- the Q
+// fragments of the four heads (16 KiB) and the R fragments (8 KiB), both already fragment-major in HBM -- stream once
+// per workgroup through a three-stage LDS-DMA ring shared by the four waves (counted vmcnt + one raw barrier per block,
+// as gemm.hip): a quarter of the bytes per MFMA.  The head groups and the contraction splits produce partial products
+// (linear in the head mean: each carries its 1/h) that rollout_finish_kernel adds in a fixed order; a wave finishes its
+// own 32 columns, so there is no cross-wave reduction.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int R4_HPG = 4;                                  // heads per workgroup
+constexpr int R4_QBYTES = R4_HPG * 4 * 1024;               // Q fragments of one contraction block: [head][k16 step][1 KiB]
+constexpr int R4_LSE = R4_QBYTES + 8 * 1024;               // + R fragments [ib][s2][1 KiB]
+constexpr int R4_STAGE = R4_LSE + 1024;                    // + lse rows [head][64 lanes] fp32 (lane l holds row l % 32)
+constexpr int R4_NSTAGE = 3;
+
+typedef __attribute__((ext_vector_type(4))) unsigned r4_u32x4;
+template <int OFF> __device__ __forceinline__ void r4_lds_read128(r4_u32x4& dst, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+__device__ __forceinline__ void r4_lds_read128_dyn(r4_u32x4& dst, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr));
+}
+__device__ __forceinline__ void r4_wait_lds(r4_u32x4& a, r4_u32x4& b, r4_u32x4& c, r4_u32x4& d) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+  __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ void r4_lds_read32(float& dst, unsigned addr) {
+  asm volatile("ds_read_b32 %0, %1" : "=v"(dst) : "v"(addr));
+}
+__device__ __forceinline__ void r4_wait_lds2(r4_u32x4& a, r4_u32x4& b) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b));
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+__global__ __launch_bounds__(RO_NT, 2) void rollout_step4_kernel(const __bf16* __restrict__ q, const __bf16* __restrict__ k,
+                                                                 const float* __restrict__ lse, const __bf16* __restrict__ rf_in,
+                                                                 float* __restrict__ part, int B, int N, int Npad, int h,
+                                                                 int Trows, int ksplit) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, half = lane >> 5;
+  const int ngroups = h / R4_HPG;
+  const int j0 = blockIdx.x * 128 + wave * 32, b = blockIdx.y;
+  const int hg = blockIdx.z % ngroups, split = blockIdx.z / ngroups;
+  const int nkb = (N + 31) / 32;
+  const int nib = (Trows + 31) / 32;
+  const int kb0 = (int)((long long)nkb * split / ksplit), kb1 = (int)((long long)nkb * (split + 1) / ksplit);
+  const int nblk = kb1 - kb0;
+  const size_t bh0 = (size_t)b * h + hg * R4_HPG;
+
+  // K fragments of this wave's 32 columns, all four heads: registers for the whole kernel
+  Frag<__bf16> fk[R4_HPG][4];
+  {
+    const int jrow = min(j0 + li, N - 1);
+#pragma unroll
+    for (int hh = 0; hh < R4_HPG; ++hh)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) fk[hh][ks].load16B(k + ((bh0 + hh) * Npad + jrow) * HD + ks * 16 + half * 8);
+  }
+  // loader: per block wave w moves the 4 KiB of head w's Q fragments, the 2 KiB of R block w and head w's 32 lse values
+  // (7 LDS-DMA instructions)
+  const int ibw = min(wave, nib - 1);
+  auto stage = [&](int kb, int buf) {
+    char* base = smem + buf * R4_STAGE;
+    const int row = min(kb * 32 + li, Npad - 1);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(q + qf_frag(bh0 + wave, Npad, row, ks, half)),
+                                       (__attribute__((address_space(3))) void*)(base + (wave * 4 + ks) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(rf_in + rf_frag(b, nkb, kb, ibw, s2, lane)),
+                                       (__attribute__((address_space(3))) void*)(base + R4_QBYTES + (wave * 2 + s2) * 1024), 16, 0, 0);
+    // lse of head `wave`, rows of the block (an ordinary load here would make hipcc drain vmcnt(0) every iteration)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(lse + (bh0 + wave) * N + min(kb * 32 + li, N - 1)),
+                                     (__attribute__((address_space(3))) void*)(base + R4_LSE + wave * 256), 4, 0, 0);
+  };
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[ib][r] = 0.0f;
+  const float c2 = 0.125f * LOG2E;
+  const float inv_h = 1.0f / (float)h;
+  const unsigned lbase = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)smem + lane * 16;
+
+  if (nblk > 0) stage(kb0, 0);
+  if (nblk > 1) stage(kb0 + 1, 1);
+  const unsigned lse_base = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)smem + R4_LSE + li * 4;
+
+  for (int it = 0; it < nblk; ++it) {
+    const int kb = kb0 + it, buf = it % R4_NSTAGE;
+    if (AS_ROLLOUT_ABLATE != 11) {
+      if (it + 1 < nblk) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");      // my pieces of block `it` have landed
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    if (AS_ROLLOUT_ABLATE != 14) __builtin_amdgcn_s_barrier();   // block `it` is complete; everyone is done with block it-1
+    if (AS_ROLLOUT_ABLATE != 11 && it + 2 < nblk) stage(kb + 2, (it + 2) % R4_NSTAGE);
+    float l8[R4_HPG];
+#pragma unroll
+    for (int hh = 0; hh < R4_HPG; ++hh) r4_lds_read32(l8[hh], lse_base + buf * R4_STAGE + hh * 256);
+    const unsigned sb = lbase + buf * R4_STAGE;
+    f32x16 pbar;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) pbar[r] = 0.0f;
+    // software pipeline over the heads: the q.k MFMAs of head hh+1 are issued before the exp2 pass of head hh, the R
+    // fragments are fetched under the last head's exp2 pass, and the eight R . Pbar MFMAs run as four independent chains
+    r4_u32x4 fa[2][4];
+    r4_lds_read128_dyn(fa[0][0], sb);
+    r4_lds_read128<1024>(fa[0][1], sb);
+    r4_lds_read128<2048>(fa[0][2], sb);
+    r4_lds_read128<3072>(fa[0][3], sb);
+    {
+      const unsigned a1 = sb + 4096;
+      r4_lds_read128_dyn(fa[1][0], a1);
+      r4_lds_read128<1024>(fa[1][1], a1);
+      r4_lds_read128<2048>(fa[1][2], a1);
+      r4_lds_read128<3072>(fa[1][3], a1);
+    }
+    asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[0][2]), "+v"(fa[0][3]), "+v"(l8[0]), "+v"(l8[1]),
+                 "+v"(l8[2]), "+v"(l8[3]));
+    __builtin_amdgcn_sched_barrier(0);
+    auto qk = [&](int hh, r4_u32x4 (&f)[4]) {
+      f32x16 sc = inject_rows<__bf16>(-8.0f * l8[hh], half);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        Frag<__bf16> fq;
+        fq.v = *reinterpret_cast<bf16x8*>(&f[ks]);
+        if (AS_ROLLOUT_ABLATE != 13) sc = mma32(fq, fk[hh][ks], sc);
+        else sc[ks] += (float)fq.v[0];
+      }
+      return sc;
+    };
+    f32x16 sc_cur = qk(0, fa[0]);
+    r4_u32x4 fr[4][2];
+#pragma unroll
+    for (int hh = 0; hh < R4_HPG; ++hh) {
+      f32x16 sc_next;
+      if (hh + 1 < R4_HPG) {
+        const int nx = (hh + 1) & 1;
+        r4_wait_lds(fa[nx][0], fa[nx][1], fa[nx][2], fa[nx][3]);
+        sc_next = qk(hh + 1, fa[nx]);
+        if (hh + 2 < R4_HPG) {                           // head hh+2's fragments into the buffer head hh just released
+          const unsigned a2 = sb + (hh + 2) * 4096;
+          r4_lds_read128_dyn(fa[hh & 1][0], a2);
+          r4_lds_read128<1024>(fa[hh & 1][1], a2);
+          r4_lds_read128<2048>(fa[hh & 1][2], a2);
+          r4_lds_read128<3072>(fa[hh & 1][3], a2);
+        }
+      } else {
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib) {
+          const unsigned a = sb + R4_QBYTES + min(ib, nib - 1) * 2048;
+          r4_lds_read128_dyn(fr[ib][0], a);
+          r4_lds_read128<1024>(fr[ib][1], a);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) pbar[r] += AS_ROLLOUT_ABLATE == 12 ? sc_cur[r] : __builtin_amdgcn_exp2f(sc_cur[r] * c2);
+      if (hh + 1 < R4_HPG) sc_cur = sc_next;
+    }
+    Frag<__bf16> fp[2];
+    if (kb * 32 + 32 <= N) {                             // (wave-uniform) every contraction row of the block exists
+#pragma unroll
+      for (int r = 0; r < 16; ++r) fp[r >> 3].set(r & 7, pbar[r]);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) fp[r >> 3].set(r & 7, kb * 32 + acc_row(r, half) < N ? pbar[r] : 0.0f);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fr[0][0]), "+v"(fr[0][1]), "+v"(fr[1][0]), "+v"(fr[1][1]), "+v"(fr[2][0]),
+                 "+v"(fr[2][1]), "+v"(fr[3][0]), "+v"(fr[3][1]));
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int ib = 0; ib < 4; ++ib)
+        if (ib < nib) {
+          Frag<__bf16> f;
+          f.v = *reinterpret_cast<bf16x8*>(&fr[ib][s2]);
+          if (AS_ROLLOUT_ABLATE != 15) acc[ib] = mma32(f, fp[s2], acc[ib]);
+          else acc[ib][0] += (float)f.v[0] + (float)fp[s2].v[0];
+        }
+  }
+
+  const int pidx = split * ngroups + hg;
+  const int j = j0 + li;
+  if (j < N) {
+#pragma unroll
+    for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = ib * 32 + acc_row(r, half);
+        if (i < Trows) part[(((size_t)pidx * B + b) * Trows + i) * N + j] = acc[ib][r] * inv_h;   // the head MEAN
+      }
+  }
+}
+
+// partial products of rollout_step4: (contraction splits) x (head groups), at most R4_MAXPARTS; the split count is chosen
+// so that the grid fills whole rounds of 2 workgroups per CU (e.g. 33 x 2 x 3 = 198 units -> 5 splits = 990 of 1024)
+constexpr int R4_MAXPARTS = 16;
+int rollout4_ksplit(int B, int N, int h) {
+  const int units = as_ceil_div(N, 128) * B * (h / R4_HPG);
+  int best = 1;
+  float best_eff = 0.0f;
+  for (int ks = 1; ks * (h / R4_HPG) <= R4_MAXPARTS && ks <= 8; ++ks) {
+    const int wgs = units * ks;
+    const float eff = (float)wgs / (float)(as_ceil_div(wgs, 512) * 512);
+    if (eff > best_eff + 0.02f) { best_eff = eff; best = ks; }
+  }
+  return best;
+}
+
 // R_out = 0.5 (sum of the contraction-split partials, in split order + R_in), plus the fragment-major copy (all 128 x
 // nkb*32 slots, zeros outside [Trows) x [N)).  grid (nkb*32/64, 128, B), 64 threads along j.
 template <typename T>
@@ -477,6 +692,21 @@ int launch_rollout_step2(const void* q, const void* k, const float* lse, const f
     hipLaunchKernelGGL((rollout_step2_kernel<T, HPW>), grid, dim3(RO_NT), lds, s, (const T*)q, (const T*)k, lse, Rin, \
                        (const T*)rf_in, Rout, (T*)rf_out, part, B, N, Npad, h, Trows, nsplit);                 \
   } while (0)
+  if (sizeof(T) == 2 && h % R4_HPG == 0 && part != nullptr && nsplit == R4_MAXPARTS && getenv("AS_ROLLOUT_V3") == nullptr) {
+    // bf16, heads in groups of four: streamed-operand kernel; `nsplit` here only says that the workspace holds
+    // R4_MAXPARTS partial products
+    const int ks = rollout4_ksplit(B, N, h), ng = h / R4_HPG;
+    const size_t lds4 = (size_t)R4_NSTAGE * R4_STAGE;
+    (void)hipFuncSetAttribute((const void*)rollout_step4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
+    hipLaunchKernelGGL(rollout_step4_kernel, dim3(as_ceil_div(N, 128), B, ks * ng), dim3(RO_NT), lds4, s, (const __bf16*)q,
+                       (const __bf16*)k, lse, (const __bf16*)rf_in, part, B, N, Npad, h, Trows, ks);
+    AS_CHECK_LAUNCH("rollout_step4");
+    dim3 fg(as_ceil_div(as_ceil_div(N, 32) * 32, 64), 128, B);
+    hipLaunchKernelGGL((rollout_finish_kernel<T>), fg, dim3(64), 0, s, (const float*)part, Rin, Rout, (T*)rf_out, B, N,
+                       Trows, ks * ng);
+    AS_CHECK_LAUNCH("rollout_finish");
+    return AS_OK;
+  }
   if (sizeof(T) == 2 && h >= 8 && (getenv("AS_ROLLOUT_V2") == nullptr)) {
     // bf16, 8..16 heads (K tile 32..64 KiB): barrier-free kernel, LDS = K tile only
     const size_t lds3 = (size_t)h * 32 * Kj2<T>::PITCH;
@@ -556,8 +786,8 @@ extern "C" int as_rollout_top(const void* q, const void* k, const float* lse, fl
 
 extern "C" size_t as_rollout_step_workspace_bytes(int B, int N, int T) {
   if (B <= 0 || N <= 0 || T <= 0) return 0;
-  const int ns = rollout_nsplit(B, N);
-  return ns > 1 ? (size_t)ns * B * T * N * sizeof(float) : 0;
+  // room for the R4_MAXPARTS partial products of rollout_step4 (>= the contraction splits of the older kernels)
+  return (size_t)R4_MAXPARTS * B * T * N * sizeof(float);
 }
 
 extern "C" int as_rollout_step(const void* q, const void* k, const float* lse, const float* R_in, const void* rf_in,
@@ -570,7 +800,9 @@ extern "C" int as_rollout_step(const void* q, const void* k, const float* lse, c
   hipStream_t s = (hipStream_t)stream;
   // without a workspace the step runs unsplit (one workgroup per 32-column block and image)
   const size_t need = as_rollout_step_workspace_bytes(B, N, T);
-  const int ns = (workspace != nullptr && workspace_bytes >= need && need > 0) ? rollout_nsplit(B, N) : 1;
+  const bool have_ws = workspace != nullptr && workspace_bytes >= need && need > 0;
+  const bool stream4 = have_ws && dtype == AS_BF16 && h % R4_HPG == 0 && getenv("AS_ROLLOUT_V3") == nullptr;
+  const int ns = stream4 ? R4_MAXPARTS : (have_ws ? rollout_nsplit(B, N) : 1);
   float* part = ns > 1 ? (float*)workspace : nullptr;
   if (dtype == AS_BF16)
     return launch_rollout_step2<__bf16>(q, k, lse, R_in, rf_in, R_out, rf_out, part, ns, B, N, h, T, s);

@@ -12,8 +12,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 CS = os.path.join(ROOT, "attentionshift_amd", "csrc")
 OUT = os.path.join(ROOT, "tools", "experiments", "_build")
-VARIANTS = {0: "baseline", 1: "no Q / lse loads in the head loop", 2: "exp2 -> multiply", 3: "no fp32 lse-injection MFMA",
-            4: "no q.k MFMAs"}
+VARIANTS = {0: "baseline", 11: "step4: no LDS-DMA / vmcnt in the loop", 12: "step4: no exp2", 13: "step4: no q.k MFMAs",
+            14: "step4: no barrier", 15: "step4: no R.Pbar MFMAs"}     # (1-4: the same hooks in rollout_step3, AS_ROLLOUT_V3=1)
 
 
 def build():
