@@ -301,8 +301,8 @@ class VisionTransformerDet(nn.Module):
         # unfold + cast in one pass, then cls / position / point tokens are written straight into the token buffer
         patches = torch.empty(B, hp, wp, C, ps, ps, device=img.device, dtype=self.compute_dtype)
         patches.copy_(img.reshape(B, C, hp, ps, wp, ps).permute(0, 2, 4, 1, 3, 5))
-        wmat = self.patch_embed.proj.weight.reshape(self.embed_dim, -1)
-        emb = ops.linear(patches.view(B, hp * wp, C * ps * ps), self._w(wmat).contiguous(), self.patch_embed.proj.bias.float())
+        wmat = self._derived(self.patch_embed.proj.weight, "patch", lambda t: t.reshape(self.embed_dim, -1))
+        emb = ops.linear(patches.view(B, hp * wp, C * ps * ps), wmat, self.patch_embed.proj.bias.float())
         pos = self.interpolate_pos_encoding(hp * wp, w, h)
         T, Np = self.point_token.shape[1], hp * wp
         x = torch.empty(B, 1 + Np + T, self.embed_dim, device=img.device, dtype=torch.float32)

@@ -455,8 +455,9 @@ __global__ __launch_bounds__(CCM_NT) void cam_cc_kernel(const uint32_t* __restri
 // code as the box stage, so the values are the ones the upsampled map would hold), and in ONE pass the three
 // candidate masks of sample_point_grid -- background nm < thr_bg per map, foreground nm >= thr_fg per map, shared
 // background mean_g(nm) < thr_bg -- with their candidate counts.  masks [2G+1][H*W] uint8, counts [2G+1].
-// grid (ceil(H / CAM_RB)); thread t owns the 4 columns 4t .. 4t+3 (and 4t + 1024 k), see ColLerp above.
+// grid (ceil(H / CSM_RB)); thread t owns the 4 columns 4t .. 4t+3 (and 4t + 1024 k), see ColLerp above.
 constexpr int CSM_G = 8;          // maps whose column state is kept in registers per pass
+constexpr int CSM_RB = 4;         // rows per workgroup (one launch per image: 256 workgroups at 1024 rows)
 __global__ __launch_bounds__(CC_NT) void cam_sample_masks_kernel(const float* __restrict__ cams,
                                                                  const int32_t* __restrict__ map_idx,
                                                                  const float* __restrict__ minmax, int G, int Hp, int Wp,
@@ -467,7 +468,7 @@ __global__ __launch_bounds__(CC_NT) void cam_sample_masks_kernel(const float* __
   const int H = Hp * up, W = Wp * up, tid = threadIdx.x;
   const size_t HW = (size_t)H * W;
   const float sy = (float)Hp / (float)H, sx = (float)Wp / (float)W;
-  const int y0 = blockIdx.x * CAM_RB, y1 = min(y0 + CAM_RB, H);
+  const int y0 = blockIdx.x * CSM_RB, y1 = min(y0 + CSM_RB, H);
   for (int k = tid; k < 2 * G + 1; k += CC_NT) cnt_s[k] = 0;
   __syncthreads();
   int c_supp = 0;
@@ -644,8 +645,8 @@ extern "C" int as_cam_sample_masks(const float* cams, const int32_t* map_idx, co
              ws_bytes, need);
   hipStream_t s = (hipStream_t)stream;
   (void)hipMemsetAsync(counts, 0, (size_t)(2 * G + 1) * 4, s);
-  // one atomic per counter per workgroup (64 workgroups at 1024 rows)
-  hipLaunchKernelGGL(cam_sample_masks_kernel, dim3(as_ceil_div(Hp * up, CAM_RB)), dim3(CC_NT), 0, s, cams, map_idx,
+  // one atomic per counter per workgroup (256 workgroups at 1024 rows)
+  hipLaunchKernelGGL(cam_sample_masks_kernel, dim3(as_ceil_div(Hp * up, CSM_RB)), dim3(CC_NT), 0, s, cams, map_idx,
                      minmax, G, Hp, Wp, up, thr_bg, thr_fg, masks, counts, (float*)ws);
   AS_CHECK_LAUNCH("cam_sample_masks");
   return AS_OK;

@@ -41,7 +41,7 @@ __device__ __forceinline__ float block_max(float v, float* sh) {
 // PASS 1: max ret, max up_bg      PASS 2: max bg      PASS 3: write map_fg, map_bg
 // grid (ceil(H / IM_RB), L*G): a workgroup owns a block of rows, a thread its columns (x = tid, tid + 256, ...); the
 // horizontal interpolation of a column is kept while the rows share a source row pair (bilinear.h, ColLerp).
-constexpr int IM_RB = 16;
+constexpr int IM_RB = 4;          // rows per workgroup: 256 workgroups per map at 1024 rows (3 maps per image: 16 rows left most CUs idle)
 template <int PASS>
 __global__ __launch_bounds__(RF_NT) void instance_maps_kernel(const float* __restrict__ sim_fg,
                                                               const float* __restrict__ sim_bg,
@@ -112,7 +112,7 @@ extern "C" int as_instance_maps(const float* sim_fg, const float* sim_bg, int L,
   MapMeta* meta = (MapMeta*)ws;
   const int n = L * G;
   // the reduction passes end in one or two atomics per workgroup on a per-map word (same-address atomics serialise
-  // at ~10 ns): 64 workgroups per map at 1024 rows
+  // at ~10 ns): 256 workgroups per map at 1024 rows
   const int by = as_ceil_div(Hp * up, IM_RB);
   hipLaunchKernelGGL(meta_init_kernel, dim3(as_ceil_div(n, 64)), dim3(64), 0, s, meta, n);
   hipLaunchKernelGGL((instance_maps_kernel<1>), dim3(by, n), dim3(RF_NT), 0, s, sim_fg, sim_bg, meta, map_fg, map_bg, G,
@@ -749,6 +749,7 @@ __global__ __launch_bounds__(64) void rank_select_kernel(const uint8_t* __restri
 // =====================================================================================================
 namespace {
 
+template <bool VEC>
 __global__ __launch_bounds__(RF_NT) void cand_max_kernel(const float* __restrict__ map_fg, const float* __restrict__ map_bg,
                                                          const int32_t* __restrict__ crops, unsigned* __restrict__ mx,
                                                          int G, int H, int W) {
@@ -757,13 +758,29 @@ __global__ __launch_bounds__(RF_NT) void cand_max_kernel(const float* __restrict
   const Crop c = load_crop(crops, g, H, W);
   const size_t base = (size_t)g * H * W;
   float vf = -INFINITY, vb = -INFINITY, va = -INFINITY;
-  for (int i = blockIdx.x * RF_NT + threadIdx.x; i < H * W; i += gridDim.x * RF_NT) {
-    const int y = i / W, x = i - y * W;
-    const float f = map_fg[base + i];
-    va = fmaxf(va, f);
-    if (x >= c.x0 && x < c.x1 && y >= c.y0 && y < c.y1) {
-      vf = fmaxf(vf, f);
-      vb = fmaxf(vb, map_bg[base + i]);
+  if (VEC) {                                             // W % 4 == 0: four pixels of one row per 16-byte load
+    const int n4 = H * W / 4;
+    for (int i4 = blockIdx.x * RF_NT + threadIdx.x; i4 < n4; i4 += gridDim.x * RF_NT) {
+      const int i = i4 * 4, y = i / W, x = i - y * W;
+      const float4 f = *reinterpret_cast<const float4*>(map_fg + base + i);
+      va = fmaxf(va, fmaxf(fmaxf(f.x, f.y), fmaxf(f.z, f.w)));
+      if (y >= c.y0 && y < c.y1 && x + 3 >= c.x0 && x < c.x1) {
+        const float4 b = *reinterpret_cast<const float4*>(map_bg + base + i);
+        const float fe[4] = {f.x, f.y, f.z, f.w}, be[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (x + j >= c.x0 && x + j < c.x1) { vf = fmaxf(vf, fe[j]); vb = fmaxf(vb, be[j]); }
+      }
+    }
+  } else {
+    for (int i = blockIdx.x * RF_NT + threadIdx.x; i < H * W; i += gridDim.x * RF_NT) {
+      const int y = i / W, x = i - y * W;
+      const float f = map_fg[base + i];
+      va = fmaxf(va, f);
+      if (x >= c.x0 && x < c.x1 && y >= c.y0 && y < c.y1) {
+        vf = fmaxf(vf, f);
+        vb = fmaxf(vb, map_bg[base + i]);
+      }
     }
   }
   const float rf = block_max(vf, sh), rb = block_max(vb, sh), ra = block_max(va, sh);
@@ -774,6 +791,7 @@ __global__ __launch_bounds__(RF_NT) void cand_max_kernel(const float* __restrict
   }
 }
 
+template <bool VEC>
 __global__ __launch_bounds__(RF_NT) void cand_threshold_kernel(const float* __restrict__ map_fg,
                                                                const float* __restrict__ map_bg,
                                                                const int32_t* __restrict__ crops,
@@ -787,17 +805,40 @@ __global__ __launch_bounds__(RF_NT) void cand_threshold_kernel(const float* __re
   const size_t base = (size_t)g * H * W;
   const float tp = ord2f(mx[g]) * pos_thr, tn = ord2f(mx[G + g]) * neg_thr, ta = ord2f(mx[2 * G + g]) * mask_thr;
   int cn = 0, ca = 0;
-  for (int i = blockIdx.x * RF_NT + threadIdx.x; i < H * W; i += gridDim.x * RF_NT) {
-    const int y = i / W, x = i - y * W;
-    const bool inside = x >= c.x0 && x < c.x1 && y >= c.y0 && y < c.y1;
-    const float f = map_fg[base + i];
-    const bool vp = inside && f > tp;
-    const bool vn = inside && map_bg[base + i] > tn;
-    const bool va = f > ta;
-    t0[base + i] = vp ? 1 : 0;
-    neg[base + i] = vn ? 1 : 0;
-    pseudo[base + i] = va ? 1 : 0;
-    cn += vn ? 1 : 0; ca += va ? 1 : 0;
+  if (VEC) {
+    const int n4 = H * W / 4;
+    for (int i4 = blockIdx.x * RF_NT + threadIdx.x; i4 < n4; i4 += gridDim.x * RF_NT) {
+      const int i = i4 * 4, y = i / W, x = i - y * W;
+      const float4 f = *reinterpret_cast<const float4*>(map_fg + base + i);
+      const bool rowin = y >= c.y0 && y < c.y1 && x + 3 >= c.x0 && x < c.x1;
+      float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (rowin) b = *reinterpret_cast<const float4*>(map_bg + base + i);
+      const float fe[4] = {f.x, f.y, f.z, f.w}, be[4] = {b.x, b.y, b.z, b.w};
+      unsigned vp4 = 0, vn4 = 0, va4 = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bool inside = rowin && x + j >= c.x0 && x + j < c.x1;
+        const bool vp = inside && fe[j] > tp, vn = inside && be[j] > tn, va = fe[j] > ta;
+        vp4 |= (vp ? 1u : 0u) << (8 * j); vn4 |= (vn ? 1u : 0u) << (8 * j); va4 |= (va ? 1u : 0u) << (8 * j);
+        cn += vn ? 1 : 0; ca += va ? 1 : 0;
+      }
+      *reinterpret_cast<unsigned*>(t0 + base + i) = vp4;
+      *reinterpret_cast<unsigned*>(neg + base + i) = vn4;
+      *reinterpret_cast<unsigned*>(pseudo + base + i) = va4;
+    }
+  } else {
+    for (int i = blockIdx.x * RF_NT + threadIdx.x; i < H * W; i += gridDim.x * RF_NT) {
+      const int y = i / W, x = i - y * W;
+      const bool inside = x >= c.x0 && x < c.x1 && y >= c.y0 && y < c.y1;
+      const float f = map_fg[base + i];
+      const bool vp = inside && f > tp;
+      const bool vn = inside && map_bg[base + i] > tn;
+      const bool va = f > ta;
+      t0[base + i] = vp ? 1 : 0;
+      neg[base + i] = vn ? 1 : 0;
+      pseudo[base + i] = va ? 1 : 0;
+      cn += vn ? 1 : 0; ca += va ? 1 : 0;
+    }
   }
   for (int which = 0; which < 2; ++which) {
     shc[threadIdx.x] = which == 0 ? cn : ca;
@@ -835,9 +876,18 @@ extern "C" int as_mask_candidates(const float* map_fg, const float* map_bg, cons
   (void)hipMemsetAsync(mx, 0, (size_t)3 * G * 4, s);
   (void)hipMemsetAsync(counts, 0, (size_t)3 * G * 4, s);
   // atomics per workgroup on a few words per object: keep the workgroup count per object small
-  hipLaunchKernelGGL(cand_max_kernel, dim3(bx < 256 ? bx : 256, G), dim3(RF_NT), 0, s, map_fg, map_bg, crops, mx, G, H, W);
-  hipLaunchKernelGGL(cand_threshold_kernel, dim3(bx < 96 ? bx : 96, G), dim3(RF_NT), 0, s, map_fg, map_bg, crops, mx,
-                     pos_thr, neg_thr, mask_thr, k == 1 ? pos : t0, neg, pseudo, counts, G, H, W);
+  // 16-byte accesses when rows are a multiple of 4 pixels and every plane (maps and byte masks, G*H*W apart) stays aligned
+  const bool vec = W % 4 == 0 && (((size_t)map_fg | (size_t)map_bg) % 16 == 0) &&
+                   (((size_t)(k == 1 ? pos : t0) | (size_t)neg | (size_t)pseudo) % 4 == 0);
+  if (vec) {
+    hipLaunchKernelGGL(cand_max_kernel<true>, dim3(bx < 256 ? bx : 256, G), dim3(RF_NT), 0, s, map_fg, map_bg, crops, mx, G, H, W);
+    hipLaunchKernelGGL(cand_threshold_kernel<true>, dim3(bx < 256 ? bx : 256, G), dim3(RF_NT), 0, s, map_fg, map_bg, crops, mx,
+                       pos_thr, neg_thr, mask_thr, k == 1 ? pos : t0, neg, pseudo, counts, G, H, W);
+  } else {
+    hipLaunchKernelGGL(cand_max_kernel<false>, dim3(bx < 256 ? bx : 256, G), dim3(RF_NT), 0, s, map_fg, map_bg, crops, mx, G, H, W);
+    hipLaunchKernelGGL(cand_threshold_kernel<false>, dim3(bx < 96 ? bx : 96, G), dim3(RF_NT), 0, s, map_fg, map_bg, crops, mx,
+                       pos_thr, neg_thr, mask_thr, k == 1 ? pos : t0, neg, pseudo, counts, G, H, W);
+  }
   if (k == 1) {
     // pos needs its count: a plain count of the thresholded crop
     hipLaunchKernelGGL(mask_count_kernel, dim3(64, G), dim3(RF_NT), 0, s, pos, counts, H * W);

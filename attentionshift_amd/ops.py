@@ -72,7 +72,9 @@ def collect_timing():
     """-> {name: (launches, mean_ms)}; call after a device synchronize."""
     out = {}
     for n, evs in (_TIMED or {}).items():
-        if evs:
+        if n.endswith(":bytes"):
+            out[n] = (len(evs), float(sum(evs)) / max(len(evs), 1))
+        elif evs:
             ms = [a.elapsed_time(b) for a, b in evs]
             out[n] = (len(ms), sum(ms) / len(ms))
     return out
@@ -285,8 +287,11 @@ def window_attention_fwd(qkv, b_qkv, table, num_heads, ws, shift, return_attn=Fa
     out = torch.empty(B, H, W, C, device=qkv.device, dtype=qkv.dtype)
     nW = -(-H // ws) * -(-W // ws)
     attn = torch.empty(B * nW, num_heads, ws * ws, ws * ws, device=qkv.device, dtype=torch.float32) if return_attn else None
-    _lib.check(lib.as_window_attn_fwd(_p(qkv), _p(b_qkv), _p(table), _p(out), _p(attn), B, H, W, C, num_heads, int(ws),
-                                      int(shift), _dt(qkv), _stream()), "as_window_attn_fwd")
+    with _timed("window_attn_fwd"):
+        _lib.check(lib.as_window_attn_fwd(_p(qkv), _p(b_qkv), _p(table), _p(out), _p(attn), B, H, W, C, num_heads, int(ws),
+                                          int(shift), _dt(qkv), _stream()), "as_window_attn_fwd")
+    if _TIMED is not None and "window_attn_fwd" in _TIMED:
+        _TIMED.setdefault("window_attn_fwd:bytes", []).append(qkv.numel() * qkv.element_size() + out.numel() * out.element_size())
     return out, attn
 
 

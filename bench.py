@@ -328,6 +328,8 @@ def main():
             step()
         if vit and os.environ.get("AS_BENCH_EVENTS", "1") == "1":
             ops.enable_timing(["sdpa_fwd", "cosine_shift"])
+        elif not vit and os.environ.get("AS_BENCH_EVENTS", "1") == "1":
+            ops.enable_timing(["window_attn_fwd"])
         elapsed = timed(step, ranks, a.steps)
     timing = ops.collect_timing()
     ops.disable_timing()
@@ -340,6 +342,18 @@ def main():
         "config": {"workload": CFG["workload"], "name": a.config, "global_batch": world * B,
                    "parallelism": f"dp{world} (image sharding, no data-path collective)"},
     }
+    if not vit and "window_attn_fwd" in timing:
+        # Swin (config 5): the fused window attention is HBM-bound -- its algorithmic traffic is one read of the qkv grid
+        # and one write of the output (49 x 49 x 32 per window-head of MFMA work is ~1 % of the matrix peak)
+        n_wa, ms_wa = timing["window_attn_fwd"]
+        _, bytes_wa = timing.get("window_attn_fwd:bytes", (0, float("nan")))
+        gbps_wa = bytes_wa / (ms_wa * 1e-3) / 1e9
+        rec["roofline"] = {
+            "kernel": "as_window_attn_fwd (bf16, window_attn_mfma_kernel): mean over the 24 launches of a pass "
+                      "(stage 1: 134 MB per launch ... stage 4: 8 MB)",
+            "bound": "hbm", "achieved": round(gbps_wa, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+            "frac": round(gbps_wa / PEAK_HBM_GBPS, 4), "traffic": None, "launches_timed": n_wa,
+            "ms_per_launch": round(ms_wa, 4), "algorithmic_bytes_per_launch": bytes_wa}
     if vit:
         rec["rng_mode"] = rng_mode
         other = "reference" if rng_mode == "fast" else "fast"
@@ -371,7 +385,7 @@ def main():
             "kernel": "as_cosine_shift (per iteration: similarity / assign / aggregate launches; packed final similarity)",
             "bound": "hbm", "achieved": round(gbps, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
             "frac": round(gbps / PEAK_HBM_GBPS, 4),
-            "traffic": _static_traffic("r01_shift_traffic.json", "per_call_bytes") if headline and imgs_per_call == 2 else None,
+            "traffic": _static_traffic("r02_shift_traffic.json", "per_call_bytes") if headline and imgs_per_call == 2 else None,
             "calls_timed": n_cs, "images_per_call": imgs_per_call, "ms_per_call": round(ms_cs, 4),
             "algorithmic_bytes_per_call": bytes_cs}
         # the same step with the trainable MIL head choosing the roll-out depth from RoI-aligned features (stdroi:2308-2312)

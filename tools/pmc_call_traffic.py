@@ -29,7 +29,7 @@ def main(d, marker, patterns, out):
             for disp, name, v in seq:
                 cur += v
                 if seen >= n_calls // 2:
-                    key = next(p for p in ("shift_sim_full", "shift_sim", "shift_assign", "shift_aggregate", "prot_norm2", name)
+                    key = next(p for p in ("shift_final_sim", "shift_sim_full", "shift_sim", "shift_assign", "shift_aggregate", "prot_norm2", name)
                                if p in name)
                     per_kernel[key] = per_kernel.get(key, 0.0) + v
                 if marker in name:
