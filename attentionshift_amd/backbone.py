@@ -356,20 +356,20 @@ class VisionTransformerDet(nn.Module):
         pt = (self.point_token + self.point_pos_embed).expand(B, -1, -1)
         return torch.cat((x, pt), dim=1)
 
-    def _block_train(self, blk, x, i, sink):
-        """Block.forward under autograd.  Attention = autograd.AttentionFn (as_attn_fwd / as_attn_bwd); LayerNorm,
-        MLP GEMMs + GELU and the residual adds are torch ops (library GEMMs acceptable)."""
+    def _block_train(self, blk, x, delta, i, sink):
+        """Block.forward under autograd with the residual stream in fp32 and the residual adds fused into the LayerNorms in
+        BOTH directions (autograd.AddLayerNormFn: as_add_layernorm / as_add_layernorm_bwd).  Attention =
+        autograd.AttentionFn (as_attn_fwd / as_attn_bwd); the MLP GEMMs + GELU are torch ops (library GEMMs, SURVEY
+        8a/A4).  `delta` = the previous block's MLP output not yet added; returns (x, this block's pending MLP output)."""
         from . import autograd as AG
         cd = self.compute_dtype
-        D = x.shape[-1]
-        y = F.layer_norm(x, (D,), blk.norm1.weight, blk.norm1.bias, blk.norm1.eps).to(cd)
+        x, y = AG.add_layernorm(x, delta, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps, cd)
         a = AG.attention(y, blk.attn.qkv.weight.to(cd), None if blk.attn.qkv.bias is None else blk.attn.qkv.bias.float(),
                          blk.attn.proj.weight.to(cd), blk.attn.proj.bias.float(), self.num_heads, sink)
-        x = x + self._drop_path(a.float(), i)
-        z = F.layer_norm(x, (D,), blk.norm2.weight, blk.norm2.bias, blk.norm2.eps).to(cd)
+        x, z = AG.add_layernorm(x, self._drop_path(a, i), blk.norm2.weight, blk.norm2.bias, blk.norm2.eps, cd)
         z = F.gelu(F.linear(z, blk.mlp.fc1.weight.to(cd), blk.mlp.fc1.bias.to(cd)))
         z = F.linear(z, blk.mlp.fc2.weight.to(cd), blk.mlp.fc2.bias.to(cd))
-        return x + self._drop_path(z.float(), i)
+        return x, self._drop_path(z, i)
 
     def forward(self, x):
         """visual_transformer_det.py:221-275.  Under no-grad / eval every GEMM and the attention run on the HIP
@@ -388,7 +388,9 @@ class VisionTransformerDet(nn.Module):
         for i, blk in enumerate(self.blocks):
             if grad_path:
                 sink = [] if self.return_attention else None
-                x = self._block_train(blk, x, i, sink)
+                x, delta = self._block_train(blk, x.float() if x.dtype != torch.float32 else x, delta, i, sink)
+                if i in self.out_indices or i == len(self.blocks) - 1:      # taps / output need the block's full result
+                    x, delta = x + delta.float(), None
                 st = sink[0] if sink else None
             else:
                 need_x = i in self.out_indices or i == len(self.blocks) - 1

@@ -92,6 +92,172 @@ int launch_add_ln(const float* x_in, const void* delta, const float* gamma, cons
 
 }  // namespace
 
+// =====================================================================================================
+// Backward of the fused residual add + LayerNorm (trainable path).  With x = x_in + delta (saved, fp32) and
+// y = LN(x) * gamma + beta:
+//     g = dy * gamma,  xhat = (x - mean) * rstd
+//     dx = dx_res + rstd * (g - mean(g) - xhat * mean(g * xhat))         (dx_res = the residual stream's own gradient)
+// dx is the gradient of BOTH x_in (fp32, dx_out) and delta (T, ddelta_out).  mean / rstd are recomputed from the row in
+// registers (two-pass, as the forward).  dgamma / dbeta: every workgroup walks its rows in order and leaves ONE partial
+// [2, D]; a second launch adds the partials in workgroup order (deterministic, no atomics).
+// =====================================================================================================
+namespace {
+
+template <typename T, int VPL>
+__global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(const float* __restrict__ x, const T* __restrict__ dy,
+                                                                const float* __restrict__ dx_res,
+                                                                const float* __restrict__ gamma, float* __restrict__ dx_out,
+                                                                T* __restrict__ ddelta_out, float* __restrict__ part, int M,
+                                                                int D, float eps) {
+  __shared__ float red[2][4][VPL * 256];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float dg[VPL][4], db[VPL][4], gm[VPL][4];
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const int c = (i * 64 + lane) * 4;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { dg[i][t] = 0.0f; db[i][t] = 0.0f; gm[i][t] = (gamma != nullptr && c < D) ? gamma[c + t] : 1.0f; }
+  }
+  for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+    const size_t base = (size_t)row * D;
+    float v[VPL][4], g[VPL][4];
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      if (c < D) {
+        const float4 a = *reinterpret_cast<const float4*>(x + base + c);
+        v[i][0] = a.x; v[i][1] = a.y; v[i][2] = a.z; v[i][3] = a.w;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) g[i][t] = dy != nullptr ? to_f32<T>(dy[base + c + t]) : 0.0f;
+        s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+      } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { v[i][t] = 0.0f; g[i][t] = 0.0f; }
+      }
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.0f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      if (c < D) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { const float d = v[i][t] - mean; q = fmaf(d, d, q); }
+      }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+    float sg = 0.0f, sgx = 0.0f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      if (c < D) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const float xh = (v[i][t] - mean) * rstd;
+          dg[i][t] = fmaf(g[i][t], xh, dg[i][t]);                 // dgamma += dy * xhat
+          db[i][t] += g[i][t];                                     // dbeta  += dy
+          const float gg = g[i][t] * gm[i][t];
+          g[i][t] = gg;
+          v[i][t] = xh;
+          sg += gg;
+          sgx = fmaf(gg, xh, sgx);
+        }
+      }
+    }
+    const float mg = wave_sum(sg) / (float)D, mgx = wave_sum(sgx) / (float)D;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      if (c < D) {
+        float o[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          o[t] = rstd * (g[i][t] - mg - v[i][t] * mgx);
+          if (dx_res != nullptr) o[t] += dx_res[base + c + t];
+        }
+        if (dx_out != nullptr) *reinterpret_cast<float4*>(dx_out + base + c) = make_float4(o[0], o[1], o[2], o[3]);
+        if (ddelta_out != nullptr) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) ddelta_out[base + c + t] = from_f32<T>(o[t]);
+        }
+      }
+    }
+  }
+  // the four waves' column partials, added in wave order
+#pragma unroll
+  for (int i = 0; i < VPL; ++i)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      red[0][wave][(i * 64 + lane) * 4 + t] = dg[i][t];
+      red[1][wave][(i * 64 + lane) * 4 + t] = db[i][t];
+    }
+  __syncthreads();
+  for (int c = threadIdx.x; c < D; c += 256) {
+    part[((size_t)blockIdx.x * 2 + 0) * D + c] = ((red[0][0][c] + red[0][1][c]) + red[0][2][c]) + red[0][3][c];
+    part[((size_t)blockIdx.x * 2 + 1) * D + c] = ((red[1][0][c] + red[1][1][c]) + red[1][2][c]) + red[1][3][c];
+  }
+}
+
+__global__ void add_layernorm_bwd_reduce_kernel(const float* __restrict__ part, float* __restrict__ dgamma,
+                                                float* __restrict__ dbeta, int nblk, int D) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= D) return;
+  float a = 0.0f, b = 0.0f;
+  for (int i = 0; i < nblk; ++i) { a += part[((size_t)i * 2 + 0) * D + c]; b += part[((size_t)i * 2 + 1) * D + c]; }
+  if (dgamma != nullptr) dgamma[c] = a;
+  if (dbeta != nullptr) dbeta[c] = b;
+}
+
+constexpr int LNB_BLOCKS = 512;
+
+template <typename T>
+int launch_add_ln_bwd(const float* x, const void* dy, const float* dx_res, const float* gamma, float* dx_out, void* ddelta,
+                      float* dgamma, float* dbeta, float* part, int M, int D, float eps, hipStream_t s) {
+  const int vpl = as_ceil_div(D, 256);
+  const int nblk = as_ceil_div(M, 4) < LNB_BLOCKS ? as_ceil_div(M, 4) : LNB_BLOCKS;
+#define AS_LNB(V)                                                                                                    \
+  hipLaunchKernelGGL((add_layernorm_bwd_kernel<T, V>), dim3(nblk), dim3(256), 0, s, x, (const T*)dy, dx_res, gamma, dx_out, \
+                     (T*)ddelta, part, M, D, eps)
+  switch (vpl) {
+    case 1: AS_LNB(1); break;
+    case 2: AS_LNB(2); break;
+    case 3: AS_LNB(3); break;
+    case 4: AS_LNB(4); break;
+    default: AS_REQUIRE(false, AS_E_UNSUPPORTED, "as_add_layernorm_bwd: D=%d (max 1024)", D);
+  }
+#undef AS_LNB
+  AS_CHECK_LAUNCH("add_layernorm_bwd");
+  if (dgamma != nullptr || dbeta != nullptr) {
+    hipLaunchKernelGGL(add_layernorm_bwd_reduce_kernel, dim3(as_ceil_div(D, 256)), dim3(256), 0, s, (const float*)part, dgamma,
+                       dbeta, nblk, D);
+    AS_CHECK_LAUNCH("add_layernorm_bwd_reduce");
+  }
+  return AS_OK;
+}
+
+}  // namespace
+
+extern "C" size_t as_add_layernorm_bwd_workspace_bytes(int M, int D) {
+  if (M <= 0 || D <= 0) return 0;
+  return (size_t)LNB_BLOCKS * 2 * D * sizeof(float);
+}
+
+extern "C" int as_add_layernorm_bwd(const float* x, const void* dy, const float* dx_res, const float* gamma, float eps,
+                                    float* dx_out, void* ddelta_out, float* dgamma, float* dbeta, void* workspace,
+                                    size_t workspace_bytes, int M, int D, int dtype, as_stream_t stream) {
+  AS_REQUIRE(x && (dy || dx_res) && (dx_out || ddelta_out) && workspace, AS_E_BADARG, "as_add_layernorm_bwd: null pointer");
+  AS_REQUIRE(M > 0 && D > 0 && D % 4 == 0, AS_E_BADARG, "as_add_layernorm_bwd: need M > 0 and D %% 4 == 0 (D=%d)", D);
+  AS_REQUIRE(workspace_bytes >= as_add_layernorm_bwd_workspace_bytes(M, D), AS_E_WORKSPACE,
+             "as_add_layernorm_bwd: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == AS_BF16)
+    return launch_add_ln_bwd<__bf16>(x, dy, dx_res, gamma, dx_out, ddelta_out, dgamma, dbeta, (float*)workspace, M, D, eps, s);
+  if (dtype == AS_F32)
+    return launch_add_ln_bwd<float>(x, dy, dx_res, gamma, dx_out, ddelta_out, dgamma, dbeta, (float*)workspace, M, D, eps, s);
+  AS_REQUIRE(false, AS_E_UNSUPPORTED, "as_add_layernorm_bwd: dtype %d", dtype);
+}
+
 extern "C" int as_add_layernorm(const float* x_in, const void* delta, const float* gamma, const float* beta, float eps,
                                 float* x_out, void* y_out, int M, int D, int dtype, as_stream_t stream) {
   AS_REQUIRE(x_in && (x_out || y_out), AS_E_BADARG, "as_add_layernorm: null pointer");

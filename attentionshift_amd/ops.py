@@ -154,6 +154,29 @@ def add_layernorm(x, delta, gamma, beta, eps, out_dtype, want_x=True, want_y=Tru
     return (xo if want_x else None), (None if y is None else y.reshape(x.shape))
 
 
+def add_layernorm_bwd(x_out, dy, dx_res, gamma, eps, dtype, want_dx=True, want_ddelta=True, want_affine=True):
+    """Backward of add_layernorm (csrc/layernorm.hip): x_out fp32 [.., D] saved by the forward, dy (`dtype`) | None,
+    dx_res fp32 | None, gamma fp32 [D] | None -> (dx fp32 | None, ddelta `dtype` | None, dgamma, dbeta fp32 [D] | None)."""
+    lib = _lib.load()
+    D = x_out.shape[-1]
+    x2 = x_out.reshape(-1, D)
+    _chk(x2, dx_res, gamma, dtype=torch.float32)
+    _chk(dy, dtype=dtype)
+    M = x2.shape[0]
+    dev = x_out.device
+    dx = torch.empty_like(x2) if want_dx else None
+    dd = torch.empty(x2.shape, device=dev, dtype=dtype) if want_ddelta else None
+    affine = want_affine and dy is not None
+    dg = torch.empty(D, device=dev, dtype=torch.float32) if affine else None
+    db = torch.empty(D, device=dev, dtype=torch.float32) if affine else None
+    nbytes = lib.as_add_layernorm_bwd_workspace_bytes(M, D)
+    ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+    dt = AS_BF16 if dtype == torch.bfloat16 else AS_F32
+    _lib.check(lib.as_add_layernorm_bwd(_p(x2), _p(dy), _p(dx_res), _p(gamma), float(eps), _p(dx), _p(dd), _p(dg), _p(db), _p(ws),
+                                        nbytes, M, D, dt, _stream()), "as_add_layernorm_bwd")
+    return (None if dx is None else dx.reshape(x_out.shape), None if dd is None else dd.reshape(x_out.shape), dg, db)
+
+
 class AttnLayerState:
     """What a layer must keep so its attention rows can be recomputed (q, k, lse)."""
 

@@ -128,6 +128,16 @@ int as_window_attn_fwd(const void* qkv, const float* bqkv, const float* table, v
 int as_add_layernorm(const float* x_in, const void* delta, const float* gamma, const float* beta, float eps,
                      float* x_out, void* y_out, int M, int D, int dtype, as_stream_t stream);
 
+/* Backward of as_add_layernorm for the trainable path.  x [M,D] fp32 = the x_out the forward wrote (x_in + delta); dy
+ * [M,D] in `dtype` = gradient of y_out (NULL: the call was add-only); dx_res [M,D] fp32 = gradient of x_out from the
+ * residual stream (NULL: none); gamma fp32 [D].  Writes dx_out [M,D] fp32 (gradient of x_in) and / or ddelta_out [M,D]
+ * in `dtype` (gradient of delta: the same values), dgamma / dbeta fp32 [D] (either may be NULL).  Column sums go through
+ * per-workgroup partials added in workgroup order (deterministic).  D % 4 == 0, D <= 1024. */
+size_t as_add_layernorm_bwd_workspace_bytes(int M, int D);
+int as_add_layernorm_bwd(const float* x, const void* dy, const float* dx_res, const float* gamma, float eps, float* dx_out,
+                         void* ddelta_out, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, int M, int D,
+                         int dtype, as_stream_t stream);
+
 /* Backward of as_window_attn_fwd (autograd of WindowAttention's core + the index maps around it):
  *   d_out     : [B,H,W,C] gradient of the attention output        dqkv : [B,H,W,3C] gradient w.r.t. the bias-free qkv
  *   dtable    : fp32 [(2*ws-1)^2, h] gradient of relative_position_bias_table

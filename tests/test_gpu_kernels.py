@@ -715,6 +715,37 @@ def test_swin_block_matches_reference(ops, golden, tag, dtype, tol):
     assert mx < tol, ("attention probabilities", mx)
 
 
+@pytest.mark.parametrize("M,D,dtype,tol", [(37, 768, torch.float32, 2e-5), (1030, 768, torch.bfloat16, 2e-2),
+                                            (5, 1024, torch.bfloat16, 2e-2), (300, 128, torch.float32, 2e-5)])
+@pytest.mark.parametrize("with_delta", [True, False])
+def test_add_layernorm_autograd_matches_torch(ops, M, D, dtype, tol, with_delta):
+    """autograd.AddLayerNormFn (as_add_layernorm forward, as_add_layernorm_bwd backward) vs torch autograd in fp64 of
+    x_out = x + delta, y = LayerNorm(x_out): gradients of x, delta, gamma, beta when BOTH outputs are used, more rows than
+    workgroups (grid-stride partials) and fewer than one workgroup."""
+    from attentionshift_amd import autograd as AG
+    g = torch.Generator().manual_seed(M + D)
+    x = torch.randn(M, D, generator=g) * 2 + 0.5
+    delta = (torch.randn(M, D, generator=g)).to(dtype) if with_delta else None
+    gamma, beta = torch.randn(D, generator=g) * 0.3 + 1, torch.randn(D, generator=g) * 0.1
+    w1, w2 = torch.randn(M, D, generator=g), torch.randn(M, D, generator=g)
+    x64, g64, b64 = x.double().requires_grad_(True), gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    d64 = None if delta is None else delta.double().requires_grad_(True)
+    with torch.enable_grad():
+        xo = x64 if d64 is None else x64 + d64
+        y64 = torch.nn.functional.layer_norm(xo, (D,), g64, b64, 1e-6)
+        ((xo * w1.double()).sum() + (y64 * w2.double()).sum()).backward()
+    xd, gd, bd = dev(x).requires_grad_(True), dev(gamma).requires_grad_(True), dev(beta).requires_grad_(True)
+    dd = None if delta is None else dev(delta).requires_grad_(True)
+    with torch.enable_grad():
+        xo_d, y_d = AG.add_layernorm(xd, dd, gd, bd, 1e-6, dtype)
+        ((xo_d * dev(w1)).sum() + (y_d.float() * dev(w2)).sum()).backward()
+    for name, ref, got in (("x_out", xo.detach(), xo_d.detach()), ("y", y64.detach(), y_d.detach()), ("dx", x64.grad, xd.grad),
+                           ("dgamma", g64.grad, gd.grad), ("dbeta", b64.grad, bd.grad)) + \
+            ((("ddelta", d64.grad, dd.grad),) if with_delta else ()):
+        mx, mean = rel_to_range(ref.float(), got.float())
+        assert mx < tol, (name, mx, mean)
+
+
 @pytest.mark.parametrize("B,h,w,cin,cout", [(2, 5, 7, 96, 40), (1, 16, 16, 64, 128), (2, 64, 64, 768, 768)])
 @pytest.mark.parametrize("act", ["none", "gelu"])
 def test_deconv2x2_matches_conv_transpose(ops, B, h, w, cin, cout, act):
