@@ -199,17 +199,27 @@ __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(const float* __r
   }
 }
 
-__global__ void add_layernorm_bwd_reduce_kernel(const float* __restrict__ part, float* __restrict__ dgamma,
-                                                float* __restrict__ dbeta, int nblk, int D) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= D) return;
-  float a = 0.0f, b = 0.0f;
-  for (int i = 0; i < nblk; ++i) { a += part[((size_t)i * 2 + 0) * D + c]; b += part[((size_t)i * 2 + 1) * D + c]; }
-  if (dgamma != nullptr) dgamma[c] = a;
-  if (dbeta != nullptr) dbeta[c] = b;
+// dgamma / dbeta = the workgroup partials added in a FIXED order: 16 groups of a 64-column slab each add every 16th
+// partial in index order, then the 16 group sums are added in group order.  grid (ceil(D / 64), 2), 1024 threads.
+__global__ __launch_bounds__(1024) void add_layernorm_bwd_reduce_kernel(const float* __restrict__ part,
+                                                                        float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                        int nblk, int D) {
+  __shared__ float red[16][64];
+  const int cl = threadIdx.x & 63, grp = threadIdx.x >> 6, c = blockIdx.x * 64 + cl, which = blockIdx.y;
+  float a = 0.0f;
+  if (c < D)
+    for (int i = grp; i < nblk; i += 16) a += part[((size_t)i * 2 + which) * D + c];
+  red[grp][cl] = a;
+  __syncthreads();
+  if (grp != 0 || c >= D) return;
+  float t = 0.0f;
+#pragma unroll
+  for (int g = 0; g < 16; ++g) t += red[g][cl];
+  float* dst = which == 0 ? dgamma : dbeta;
+  if (dst != nullptr) dst[c] = t;
 }
 
-constexpr int LNB_BLOCKS = 512;
+constexpr int LNB_BLOCKS = 256;
 
 template <typename T>
 int launch_add_ln_bwd(const float* x, const void* dy, const float* dx_res, const float* gamma, float* dx_out, void* ddelta,
@@ -229,8 +239,8 @@ int launch_add_ln_bwd(const float* x, const void* dy, const float* dx_res, const
 #undef AS_LNB
   AS_CHECK_LAUNCH("add_layernorm_bwd");
   if (dgamma != nullptr || dbeta != nullptr) {
-    hipLaunchKernelGGL(add_layernorm_bwd_reduce_kernel, dim3(as_ceil_div(D, 256)), dim3(256), 0, s, (const float*)part, dgamma,
-                       dbeta, nblk, D);
+    hipLaunchKernelGGL(add_layernorm_bwd_reduce_kernel, dim3(as_ceil_div(D, 64), 2), dim3(1024), 0, s, (const float*)part,
+                       dgamma, dbeta, nblk, D);
     AS_CHECK_LAUNCH("add_layernorm_bwd_reduce");
   }
   return AS_OK;
