@@ -160,9 +160,10 @@ int as_attn_mean_rows(const void* q, const void* k, const float* lse, float* out
  * with the tiles of mean_h P recomputed from q,k,lse of that layer.  as_rollout_top gives the top layer's
  * R = rows [N-T, N) of A_hat.  Next to the fp32 row-major R every call also emits a FRAGMENT-MAJOR copy `rf`
  * (as_rollout_rfrag_bytes; element dtype = `dtype`) that the next step reads as its MFMA A operand with fully
- * coalesced loads; rf_out may be NULL on the last step.  as_rollout_step splits the contraction over several
- * workgroups when given a workspace of as_rollout_step_workspace_bytes (partials summed in a fixed order by a second
- * tiny launch: deterministic); with workspace == NULL it runs unsplit. */
+ * coalesced loads; rf_out may be NULL on the last step.  as_rollout_step splits the contraction (and, for bf16 with
+ * h % 4 == 0, the heads in groups of four: the streamed-operand kernel) over several workgroups when given a workspace
+ * of as_rollout_step_workspace_bytes (room for 16 partial products, summed in a fixed order by a second tiny launch:
+ * deterministic); with workspace == NULL it runs unsplit. */
 size_t as_rollout_rfrag_bytes(int B, int N, int dtype);
 size_t as_rollout_step_workspace_bytes(int B, int N, int T);
 int as_rollout_top(const void* q, const void* k, const float* lse, float* R_out, void* rf_out, int B, int N, int h,

@@ -65,7 +65,7 @@ def test_bad_arguments_return_error_codes_without_launching():
     # workspace size queries are pure host functions
     assert lib.as_sdpa_bwd_workspace_bytes(2, 4197, 12, 1) == 2 * 12 * 4224 * (5 * 64 * 2 + 4)
     assert lib.as_attn_bwd_workspace_bytes(2, 4197, 768, 12, 1) > lib.as_sdpa_bwd_workspace_bytes(2, 4197, 12, 1)
-    assert lib.as_rollout_step_workspace_bytes(2, 4197, 100) == 8 * 2 * 100 * 4197 * 4
+    assert lib.as_rollout_step_workspace_bytes(2, 4197, 100) == 16 * 2 * 100 * 4197 * 4      # up to 16 partial products
     assert lib.as_sdpa_bwd_workspace_bytes(0, 4197, 12, 1) == 0
 
 
