@@ -1,7 +1,7 @@
 """A/B of the RoI-head scheduling flags on one box: full-step time with each flag toggled (interleaved repeats)."""
 import os, sys, time
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import bench
 
 def loop(fn, n=20):
