@@ -658,9 +658,21 @@ __device__ __forceinline__ int wave_excl_scan(int v, int lane) {
   return inc - v;
 }
 
+// result of one (row, rank): the flat index, and / or its (x, y) [or (y, x)] coordinates on a W-wide grid as int64 with an
+// out-of-range rank (-1) clamped to pixel 0 -- what the callers' `clamp(min=0)`, `% W`, `// W`, `stack` chain produced
+__device__ __forceinline__ void rank_select_store(int32_t* out, long long* out_xy, size_t idx, int flat, int W, int yx) {
+  if (out != nullptr) out[idx] = flat;
+  if (out_xy != nullptr) {
+    const int f = flat < 0 ? 0 : flat, y = f / W, x = f - y * W;
+    out_xy[2 * idx + 0] = yx ? y : x;
+    out_xy[2 * idx + 1] = yx ? x : y;
+  }
+}
+
 __global__ __launch_bounds__(64) void rank_select_kernel(const uint8_t* __restrict__ mask, const int32_t* __restrict__ cc,
                                                          const int32_t* __restrict__ ranks, int32_t* __restrict__ out,
-                                                         int HW, int nchunk, int K) {
+                                                         long long* __restrict__ out_xy, int W, int yx, int HW, int nchunk,
+                                                         int K) {
   const int k = blockIdx.x, m = blockIdx.y, lane = threadIdx.x;
   int r = ranks[(size_t)m * K + k];
   const int32_t* c = cc + (size_t)m * nchunk;
@@ -679,7 +691,7 @@ __global__ __launch_bounds__(64) void rank_select_kernel(const uint8_t* __restri
   const int before = wave_excl_scan(mine, lane);
   const unsigned long long hit = __ballot(r >= before && r < before + mine);
   if (hit == 0ull || r < 0) {                    // rank beyond the population
-    if (lane == 0) out[(size_t)m * K + k] = -1;
+    if (lane == 0) rank_select_store(out, out_xy, (size_t)m * K + k, -1, W, yx);
     return;
   }
   const int owner = __ffsll((long long)hit) - 1;
@@ -733,7 +745,7 @@ __global__ __launch_bounds__(64) void rank_select_kernel(const uint8_t* __restri
       const int c = __popcll(occ & ((1ull << sft) - 1ull));
       if (left >= c) { occ >>= sft; left -= c; pos += sft; }
     }
-    out[(size_t)m * K + k] = chunk * RS_CHUNK + off + pos;
+    rank_select_store(out, out_xy, (size_t)m * K + k, chunk * RS_CHUNK + off + pos, W, yx);
   }
 }
 
@@ -907,18 +919,29 @@ extern "C" size_t as_rank_select_workspace_bytes(int M, int HW) {
   return ((size_t)M * as_ceil_div(HW, RS_CHUNK) * 4 + 255) / 256 * 256;
 }
 
-extern "C" int as_rank_select(const uint8_t* mask, const int32_t* ranks, int32_t* out, void* ws, size_t ws_bytes, int M,
-                              int HW, int K, as_stream_t stream) {
-  AS_REQUIRE(mask && ranks && out && ws, AS_E_BADARG, "as_rank_select: null pointer");
-  AS_REQUIRE(M > 0 && HW > 0 && K > 0 && HW % 16 == 0, AS_E_BADARG, "as_rank_select: bad sizes (HW %% 16 == 0)");
-  AS_REQUIRE(ws_bytes >= as_rank_select_workspace_bytes(M, HW), AS_E_WORKSPACE, "as_rank_select: workspace too small");
+static int rank_select_launch(const uint8_t* mask, const int32_t* ranks, int32_t* out, long long* out_xy, int W, int yx, void* ws,
+                              size_t ws_bytes, int M, int HW, int K, as_stream_t stream, const char* who) {
+  AS_REQUIRE(mask && ranks && (out || out_xy) && ws, AS_E_BADARG, "%s: null pointer", who);
+  AS_REQUIRE(M > 0 && HW > 0 && K > 0 && HW % 16 == 0 && W > 0, AS_E_BADARG, "%s: bad sizes (HW %% 16 == 0)", who);
+  AS_REQUIRE(ws_bytes >= as_rank_select_workspace_bytes(M, HW), AS_E_WORKSPACE, "%s: workspace too small", who);
   hipStream_t s = (hipStream_t)stream;
   const int nchunk = as_ceil_div(HW, RS_CHUNK);
   int32_t* cc = (int32_t*)ws;
   hipLaunchKernelGGL(rank_counts_kernel, dim3(nchunk, M), dim3(RF_NT), 0, s, mask, cc, HW, nchunk);
-  hipLaunchKernelGGL(rank_select_kernel, dim3(K, M), dim3(64), 0, s, mask, cc, ranks, out, HW, nchunk, K);
-  AS_CHECK_LAUNCH("rank_select");
+  hipLaunchKernelGGL(rank_select_kernel, dim3(K, M), dim3(64), 0, s, mask, cc, ranks, out, out_xy, W, yx, HW, nchunk, K);
+  AS_CHECK_LAUNCH(who);
   return AS_OK;
+}
+
+extern "C" int as_rank_select(const uint8_t* mask, const int32_t* ranks, int32_t* out, void* ws, size_t ws_bytes, int M,
+                              int HW, int K, as_stream_t stream) {
+  return rank_select_launch(mask, ranks, out, nullptr, 1, 0, ws, ws_bytes, M, HW, K, stream, "as_rank_select");
+}
+
+extern "C" int as_rank_select_xy(const uint8_t* mask, const int32_t* ranks, int64_t* out_xy, void* ws, size_t ws_bytes, int M,
+                                 int HW, int K, int W, int yx_order, as_stream_t stream) {
+  return rank_select_launch(mask, ranks, nullptr, (long long*)out_xy, W, yx_order ? 1 : 0, ws, ws_bytes, M, HW, K, stream,
+                            "as_rank_select_xy");
 }
 
 extern "C" int as_mask_count(const uint8_t* mask, int32_t* counts, int M, int HW, as_stream_t stream) {

@@ -712,6 +712,23 @@ def rank_select(mask, ranks):
     return out.long()
 
 
+def rank_select_xy(mask, ranks, W, yx=False):
+    """rank_select returning coordinates: int64 [M,K,2] = (x, y) (or (y, x) with yx) of the ranks[m,k]-th set byte of row m
+    on a W-wide grid; out-of-range ranks give pixel 0 (one launch pair instead of rank_select + clamp / % / // / stack)."""
+    lib = _lib.load()
+    _chk(mask, dtype=torch.uint8)
+    r32 = ranks if ranks.dtype == torch.int32 and ranks.is_contiguous() else ranks.to(torch.int32).contiguous()
+    _chk(r32)
+    M, HW = mask.shape
+    K = r32.shape[1]
+    out = torch.empty(M, K, 2, device=mask.device, dtype=torch.int64)
+    nbytes = lib.as_rank_select_workspace_bytes(M, HW)
+    ws = torch.empty(nbytes, device=mask.device, dtype=torch.uint8)
+    _lib.check(lib.as_rank_select_xy(_p(mask), _p(r32), _p(out), _p(ws), nbytes, M, HW, K, int(W), 1 if yx else 0, _stream()),
+               "as_rank_select_xy")
+    return out
+
+
 def roi_align_fwd(feat_nhwc, rois, out_size, spatial_scale, sampling_ratio=0, aligned=True):
     """feat [B,H,W,C] fp32 token-major, rois [R,5] fp32 -> [R, out*out, C] (csrc/roi_align.hip)."""
     lib = _lib.load()

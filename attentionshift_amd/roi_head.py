@@ -191,6 +191,15 @@ def rank_select(mask_flat, ranks):
     return ops.rank_select(m.contiguous(), ranks)
 
 
+def rank_select_xy(mask_flat, ranks, W, yx=False):
+    """rank_select returning the (x, y) [or (y, x)] grid coordinates of the selected pixels, int64 [G,K,2]; ranks beyond
+    the population give pixel 0 (ops.rank_select_xy)."""
+    m = mask_flat if mask_flat.dtype == torch.uint8 else mask_flat.to(torch.uint8)
+    if m.shape[1] % 16:                                    # the kernel reads 16-byte groups: zero-pad the tail
+        m = F.pad(m, (0, 16 - m.shape[1] % 16))
+    return ops.rank_select_xy(m.contiguous(), ranks, W, yx)
+
+
 def sample_point_grid(maps, num_points, thr, is_pos, gt_points=None):
     """stdroi:343-371.  Random draws come from torch's global CPU generator exactly like the reference
     (`torch.randint(n, shape)` per object, in object order); candidate counts cost ONE host sync for all
@@ -287,8 +296,7 @@ def sample_points_from_cams_nosync(cams_lr, map_idx, minmax, num_points, gen, th
     n = counts.float()[:, None]
     u = torch.rand(2 * G + 1, num_points, device=masks.device, generator=gen)
     ranks = torch.minimum((u * n).to(torch.int32), (counts[:, None] - 1).clamp(min=0))
-    flat = ops.rank_select(masks.flatten(1), ranks.contiguous())
-    pts = torch.stack((flat % W, flat // W), dim=-1)
+    pts = rank_select_xy(masks.flatten(1), ranks, W)                           # (x, y) of every drawn candidate
     return pts[:G], pts[G:2 * G], pts[2 * G:], (counts < num_points).any()
 
 
@@ -301,10 +309,9 @@ def mask_points_nosync(pend, num_gt, gen):
     G, H, W = pend["shape"]
     u = torch.rand(G, 32, device=pos.device, generator=gen)
     rank_pos, rank_neg, is_pos, flag = ops.draw_distinct(pend["counts"], u, num_gt)      # counts [G, 2] = (n_pos, n_neg)
-    idx_pos = ops.rank_select(pos.flatten(1), rank_pos)
-    idx_neg = ops.rank_select(neg.flatten(1), rank_neg)
-    flat = torch.where(is_pos, idx_pos, idx_neg).clamp(min=0, max=H * W - 1)
-    coords = torch.stack((flat % W, flat // W), dim=-1).float()
+    xy_pos = rank_select_xy(pos.flatten(1), rank_pos, W)
+    xy_neg = rank_select_xy(neg.flatten(1), rank_neg, W)
+    coords = torch.where(is_pos[..., None], xy_pos, xy_neg).float()
     return coords, is_pos, flag[0] != 0
 
 
@@ -314,8 +321,7 @@ def grid_seed_nosync(mask, count_dev, n_points=20):
     G, hp, wp = mask.shape
     step = (count_dev // n_points).clamp(min=1)
     ranks = torch.arange(n_points, device=mask.device, dtype=torch.int32)[None, :] * step[:, None].int()
-    flat = rank_select(mask.flatten(1), ranks.contiguous()).long().clamp(min=0)
-    return torch.stack((flat // wp, flat % wp), dim=-1), (count_dev < n_points).any()
+    return rank_select_xy(mask.flatten(1), ranks, wp, yx=True), (count_dev < n_points).any()
 
 
 def _sample_point_grid_slow(maps, num_points, thr, is_pos, gt_points=None):
@@ -591,6 +597,11 @@ def part_centers(maps, rois, obj_label, feat_chw, num_max_keep=50, num_max_obj=3
 def median_area_selector(boxes_per_img, labels_per_img=None, roi_feature_map=None):
     """Stand-in for the trainable MIL head's choice (mae_bbox_head_mil.py:140-169): per object the roll-out
     depth whose CAM box has the median area.  boxes [G,Lc,4] -> index [G]."""
+    if len({b.shape[1] for b in boxes_per_img}) == 1:        # one pass for the whole batch (same launches as one image)
+        b = torch.cat(list(boxes_per_img)) if len(boxes_per_img) > 1 else boxes_per_img[0]
+        area = (b[..., 2] - b[..., 0]).clamp(min=0) * (b[..., 3] - b[..., 1]).clamp(min=0)
+        pick = area.argsort(dim=1, stable=True)[:, (b.shape[1] - 1) // 2]
+        return list(pick.split([x.shape[0] for x in boxes_per_img]))
     out = []
     for b in boxes_per_img:
         area = (b[..., 2] - b[..., 0]).clamp(min=0) * (b[..., 3] - b[..., 1]).clamp(min=0)

@@ -312,6 +312,11 @@ int as_mask_count(const uint8_t* mask, int32_t* counts, int M, int HW, as_stream
 size_t as_rank_select_workspace_bytes(int M, int HW);
 int as_rank_select(const uint8_t* mask /*[M,HW] 0/1*/, const int32_t* ranks /*[M,K]*/, int32_t* out /*[M,K]*/, void* ws,
                    size_t ws_bytes, int M, int HW, int K, as_stream_t stream);
+/* The same selection returning grid coordinates: out_xy [M,K,2] int64 = (flat % W, flat / W), or (flat / W, flat % W)
+ * with yx_order, of the selected pixel on a W-wide grid; an out-of-range rank gives pixel 0 (the `clamp(min=0)` of the
+ * callers, which flag that case separately). */
+int as_rank_select_xy(const uint8_t* mask /*[M,HW] 0/1*/, const int32_t* ranks /*[M,K]*/, int64_t* out_xy /*[M,K,2]*/, void* ws,
+                      size_t ws_bytes, int M, int HW, int K, int W, int yx_order, as_stream_t stream);
 
 /* Small-N batched multi-head self-attention (the MAE-decoder box / mask heads: thousands of 50- / 197-token problems of
  * head dim 32 per step; models/vision_transformer.py:62-86 as used by mae_bbox_head_rec.py:148-168):
