@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import torch
 from attentionshift_amd import ops
 
-SHAPES = [(4096, 4096, 4096), (8192, 8192, 8192), (8394, 2304, 768), (8394, 768, 768), (8394, 3072, 768), (8394, 768, 3072),
+SHAPES = [(7168, 2304, 768), (5376, 3072, 768), (3584, 2304, 768), (8394, 768, 1536), (16384, 768, 3072), (4096, 4096, 4096), (8192, 8192, 8192), (8394, 2304, 768), (8394, 768, 768), (8394, 3072, 768), (8394, 768, 3072),
           (8192, 1536, 512), (8192, 2048, 512), (8192, 512, 2048), (131072, 384, 128), (131072, 512, 128), (131072, 128, 512)]
 
 
