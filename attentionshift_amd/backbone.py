@@ -311,13 +311,16 @@ class VisionTransformerDet(nn.Module):
         x[:, 1 + Np:] = self.point_token + self.point_pos_embed
         return x
 
-    def _block(self, blk, x, delta, keep_state, need_x):
+    def _block(self, blk, x, delta, keep_state, need_x, on_full=None):
         """models/vision_transformer.py:109-124 with the residual stream kept in fp32 and every residual add fused into
         the LayerNorm that follows it (ops.add_layernorm).  `delta` is the previous block's MLP output that has not
-        been added to `x` yet (None for the first block); returns (x, pending MLP output, attention state); with
-        `need_x` the block's own MLP output is added before returning (feature taps, last block)."""
+        been added to `x` yet (None for the first block): the first fused add+LayerNorm completes the PREVIOUS block's
+        output, which `on_full` (a feature tap) may look at; returns (x, pending MLP output, attention state); with
+        `need_x` the block's own MLP output is added before returning (last block)."""
         cd = self.compute_dtype
         x, y = ops.add_layernorm(x, delta, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps, cd)
+        if on_full is not None:
+            on_full(x)
         a, st = ops.attention_fwd(y, self._w(blk.attn.qkv.weight),
                                   None if blk.attn.qkv.bias is None else blk.attn.qkv.bias.float(),
                                   self._w(blk.attn.proj.weight), blk.attn.proj.bias.float(), self.num_heads,
@@ -381,38 +384,52 @@ class VisionTransformerDet(nn.Module):
         x = self._prepare_tokens_train(x) if grad_path else self.prepare_tokens(x)
         if self.recompute_last_feat:
             last_feat = x
-        features, taps, attns, org_features = [], [], [], None
+        features, taps, attns = [], [], []
+        store = []                                         # no-grad: token-major storage behind org_feats
         delta = None                                       # inference path: MLP output not yet added to x
         if not grad_path:
             x = x.contiguous()
+
+        def take_tap(xf):
+            """xf = a tapped block's full output [B, N, D]: feature map view + its slot of org_feats."""
+            taps.append(xf[:, 1:-T])                                     # token-major view [B, Np, D]
+            tap = xf[:, 1:, :][:, :-T].permute(0, 2, 1).unflatten(2, (hp, wp))
+            if grad_path:
+                features.append(tap.contiguous())
+                return
+            # no-grad: org_feats [B, L, D, hp, wp] is a VIEW of token-major storage [L, B, hp, wp, D] (every tap a
+            # channels-last map): filling a slot is a straight copy of the tokens, not a transpose, and the
+            # channels-last consumers (FPN GEMMs, RoIAlign, the attention-shift kernels) read it without a copy
+            if not store:
+                store.append(torch.empty(len(self.out_indices), B, hp, wp, tap.shape[1], device=xf.device, dtype=xf.dtype))
+            org = store[0].permute(1, 0, 4, 2, 3)
+            org[:, len(features)].copy_(tap)
+            features.append(org[:, len(features)])
+
+        tap_due = False                                    # the previous block is a tap whose MLP output is still pending
+        nblk = len(self.blocks)
         for i, blk in enumerate(self.blocks):
             if grad_path:
                 sink = [] if self.return_attention else None
                 x, delta = self._block_train(blk, x.float() if x.dtype != torch.float32 else x, delta, i, sink)
-                if i in self.out_indices or i == len(self.blocks) - 1:      # taps / output need the block's full result
+                if i in self.out_indices or i == nblk - 1:                  # taps / output need the block's full result
                     x, delta = x + delta.float(), None
                 st = sink[0] if sink else None
+                if i in self.out_indices:
+                    take_tap(x)
             else:
-                need_x = i in self.out_indices or i == len(self.blocks) - 1
-                x, delta, st = self._block(blk, x, delta, self.return_attention, need_x)
+                # a tapped block's full output appears inside the NEXT block's first fused add+LayerNorm: the tap is taken
+                # there (no add-only pass); only the last block adds its own MLP output before returning
+                x, delta, st = self._block(blk, x, delta, self.return_attention, i == nblk - 1,
+                                           take_tap if tap_due else None)
+                tap_due = i in self.out_indices and i != nblk - 1
+                if i in self.out_indices and i == nblk - 1:
+                    take_tap(x)
             if self.return_attention:
                 attns.append(st)
-            if i in self.out_indices:
-                taps.append(x[:, 1:-T])                                  # token-major view [B, Np, D]
-                tap = x[:, 1:, :][:, :-T].permute(0, 2, 1).unflatten(2, (hp, wp))
-                if grad_path:
-                    features.append(tap.contiguous())
-                else:
-                    # no-grad: org_feats [B, L, D, hp, wp] is a VIEW of token-major storage [L, B, hp, wp, D] (every tap a
-                    # channels-last map): filling a slot is a straight copy of the tokens, not a transpose, and the
-                    # channels-last consumers (FPN GEMMs, RoIAlign, the attention-shift kernels) read it without a copy
-                    if org_features is None:
-                        store = torch.empty(len(self.out_indices), B, hp, wp, tap.shape[1], device=x.device, dtype=x.dtype)
-                        org_features = store.permute(1, 0, 4, 2, 3)
-                    org_features[:, len(features)].copy_(tap)
-                    features.append(org_features[:, len(features)])
-            if self.last_feat and not self.recompute_last_feat and i == len(self.blocks) - 1:
+            if self.last_feat and not self.recompute_last_feat and i == nblk - 1:
                 last_feat = x[:, :-T]
+        org_features = store[0].permute(1, 0, 4, 2, 3) if store else None
         if org_features is None:
             org_features = torch.stack(features, dim=1)
         if self.with_fpn and grad_path:
