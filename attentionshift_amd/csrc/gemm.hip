@@ -372,6 +372,7 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 3 : 2) void gemm_glds_kernel(co
   // lane -> token row m = m0 + wm*64 + i*32 + li; register r of block (i,j) -> column n0 + wn*64 + j*32 + acc_row(r,half)
   const bool vtile = MODE == 1 && n0 >= 2 * epi.D;   // block-uniform: the whole 128-column tile is V
   if (vtile) {
+    if (AS_GEMM_ABLATE == 5) return;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int row = m0 + wm * 64 + i * 32 + li;

@@ -12,7 +12,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 CS = os.path.join(ROOT, "attentionshift_amd", "csrc")
 OUT = os.path.join(ROOT, "tools", "experiments", "_build")
-VARIANTS = {0: "baseline", 1: "no LDS-DMA / vmcnt in the loop", 2: "no MFMAs", 3: "no fragment reads", 4: "no barrier"}
+VARIANTS = {0: "baseline", 1: "no LDS-DMA / vmcnt in the loop", 2: "no MFMAs", 3: "no fragment reads", 4: "no barrier",
+            5: "QKV only: no V^T tile stores"}
 SHAPES = [(4096, 4096, 4096), (8394, 3072, 768), (8394, 768, 3072)]
 
 
@@ -53,5 +54,32 @@ def run():
             print(f"{M}x{N}x{K} variant {v} ({name:32s}): {ms * 1e3:7.1f} us  ({2.0 * M * N * K / ms / 1e9:6.0f} TFLOP/s-equivalent)", flush=True)
 
 
+def run_qkv():
+    """as_qkv_fwd at config 2 (B=2, N=4197, D=768, h=12) for variants 0 and 5: what the V^T epilogue costs."""
+    import torch
+    B, N, D, h = 2, 4197, 768, 12
+    Npad = -(-N // 64) * 64
+    x = (torch.rand(B * N, D, device="cuda") * 2 - 1).bfloat16()
+    w = (torch.rand(3 * D, D, device="cuda") * 2 - 1).bfloat16()
+    q = torch.empty(B * h * Npad * 64, device="cuda", dtype=torch.bfloat16)
+    k, vt = torch.empty_like(q), torch.empty_like(q)
+    for v in (0, 5):
+        lib = ctypes.CDLL(os.path.join(OUT, f"libgemm_v{v}.so"))
+        lib.as_qkv_fwd.restype = ctypes.c_int
+        lib.as_qkv_fwd.argtypes = [ctypes.c_void_p] * 6 + [ctypes.c_int] * 5 + [ctypes.c_void_p]
+        st = torch.cuda.current_stream().cuda_stream
+        call = lambda: lib.as_qkv_fwd(x.data_ptr(), w.data_ptr(), None, q.data_ptr(), k.data_ptr(), vt.data_ptr(), B, N, D, h, 1, st)
+        for _ in range(5):
+            assert call() == 0
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(30):
+            call()
+        e1.record()
+        torch.cuda.synchronize()
+        print(f"as_qkv_fwd variant {v} ({VARIANTS[v]}): {e0.elapsed_time(e1) / 30 * 1e3:7.1f} us", flush=True)
+
+
 if __name__ == "__main__":
-    (build if sys.argv[1:] == ["build"] else run)()
+    {"build": build, "qkv": run_qkv}.get(sys.argv[1] if len(sys.argv) > 1 else "", run)()
