@@ -37,6 +37,7 @@ SIGNATURES = {
     "as_attn_fwd": (_c_int, [_c_void_p] * 12 + [_c_size_t] + [_c_int] * 5 + [_c_void_p]),
     "as_attn_mean_rows": (_c_int, [_c_void_p] * 4 + [_c_int] * 6 + [_c_void_p]),
     "as_rollout_rfrag_bytes": (_c_size_t, [_c_int] * 3),
+    "as_rollout_pack": (_c_int, [_c_void_p] * 2 + [_c_int] * 4 + [_c_void_p]),
     "as_rollout_top": (_c_int, [_c_void_p] * 5 + [_c_int] * 5 + [_c_void_p]),
     "as_rollout_step_workspace_bytes": (_c_size_t, [_c_int] * 3),
     "as_rollout_step": (_c_int, [_c_void_p] * 8 + [_c_size_t] + [_c_int] * 5 + [_c_void_p]),

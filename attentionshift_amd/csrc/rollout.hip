@@ -478,6 +478,7 @@ __device__ __forceinline__ void r4_wait_lds2(r4_u32x4& a, r4_u32x4& b) {
   __builtin_amdgcn_sched_barrier(0);
 }
 
+template <int NIB>                                       // 32-row blocks of R carried (1: Trows <= 32, else 4)
 __global__ __launch_bounds__(RO_NT, 2) void rollout_step4_kernel(const __bf16* __restrict__ q, const __bf16* __restrict__ k,
                                                                  const float* __restrict__ lse, const __bf16* __restrict__ rf_in,
                                                                  float* __restrict__ part, int B, int N, int Npad, int h,
@@ -489,7 +490,7 @@ __global__ __launch_bounds__(RO_NT, 2) void rollout_step4_kernel(const __bf16* _
   const int j0 = blockIdx.x * 128 + wave * 32, b = blockIdx.y;
   const int hg = blockIdx.z % ngroups, split = blockIdx.z / ngroups;
   const int nkb = (N + 31) / 32;
-  const int nib = (Trows + 31) / 32;
+  const int nib = min((Trows + 31) / 32, NIB);
   const int kb0 = (int)((long long)nkb * split / ksplit), kb1 = (int)((long long)nkb * (split + 1) / ksplit);
   const int nblk = kb1 - kb0;
   const size_t bh0 = (size_t)b * h + hg * R4_HPG;
@@ -522,9 +523,9 @@ __global__ __launch_bounds__(RO_NT, 2) void rollout_step4_kernel(const __bf16* _
                                      (__attribute__((address_space(3))) void*)(base + R4_LSE + wave * 256), 4, 0, 0);
   };
 
-  f32x16 acc[4];
+  f32x16 acc[NIB];
 #pragma unroll
-  for (int ib = 0; ib < 4; ++ib)
+  for (int ib = 0; ib < NIB; ++ib)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[ib][r] = 0.0f;
   const float c2 = 0.125f * LOG2E;
@@ -579,7 +580,7 @@ __global__ __launch_bounds__(RO_NT, 2) void rollout_step4_kernel(const __bf16* _
       return sc;
     };
     f32x16 sc_cur = qk(0, fa[0]);
-    r4_u32x4 fr[4][2];
+    r4_u32x4 fr[NIB][2];
 #pragma unroll
     for (int hh = 0; hh < R4_HPG; ++hh) {
       f32x16 sc_next;
@@ -596,7 +597,7 @@ __global__ __launch_bounds__(RO_NT, 2) void rollout_step4_kernel(const __bf16* _
         }
       } else {
 #pragma unroll
-        for (int ib = 0; ib < 4; ++ib) {
+        for (int ib = 0; ib < NIB; ++ib) {
           const unsigned a = sb + R4_QBYTES + min(ib, nib - 1) * 2048;
           r4_lds_read128_dyn(fr[ib][0], a);
           r4_lds_read128<1024>(fr[ib][1], a);
@@ -614,13 +615,17 @@ __global__ __launch_bounds__(RO_NT, 2) void rollout_step4_kernel(const __bf16* _
 #pragma unroll
       for (int r = 0; r < 16; ++r) fp[r >> 3].set(r & 7, kb * 32 + acc_row(r, half) < N ? pbar[r] : 0.0f);
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fr[0][0]), "+v"(fr[0][1]), "+v"(fr[1][0]), "+v"(fr[1][1]), "+v"(fr[2][0]),
-                 "+v"(fr[2][1]), "+v"(fr[3][0]), "+v"(fr[3][1]));
+    if constexpr (NIB == 1) {
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fr[0][0]), "+v"(fr[0][1]));
+    } else {
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fr[0][0]), "+v"(fr[0][1]), "+v"(fr[1][0]), "+v"(fr[1][1]), "+v"(fr[2][0]),
+                   "+v"(fr[2][1]), "+v"(fr[3][0]), "+v"(fr[3][1]));
+    }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-      for (int ib = 0; ib < 4; ++ib)
+      for (int ib = 0; ib < NIB; ++ib)
         if (ib < nib) {
           Frag<__bf16> f;
           f.v = *reinterpret_cast<bf16x8*>(&fr[ib][s2]);
@@ -633,7 +638,7 @@ __global__ __launch_bounds__(RO_NT, 2) void rollout_step4_kernel(const __bf16* _
   const int j = j0 + li;
   if (j < N) {
 #pragma unroll
-    for (int ib = 0; ib < 4; ++ib)
+    for (int ib = 0; ib < NIB; ++ib)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int i = ib * 32 + acc_row(r, half);
@@ -697,11 +702,17 @@ int launch_rollout_step2(const void* q, const void* k, const float* lse, const f
     // R4_MAXPARTS partial products
     const int ks = rollout4_ksplit(B, N, h), ng = h / R4_HPG;
     const size_t lds4 = (size_t)R4_NSTAGE * R4_STAGE;
-    (void)hipFuncSetAttribute((const void*)rollout_step4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
-    hipLaunchKernelGGL(rollout_step4_kernel, dim3(as_ceil_div(N, 128), B, ks * ng), dim3(RO_NT), lds4, s, (const __bf16*)q,
-                       (const __bf16*)k, lse, (const __bf16*)rf_in, part, B, N, Npad, h, Trows, ks);
+    if (Trows <= 32) {
+      (void)hipFuncSetAttribute((const void*)rollout_step4_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
+      hipLaunchKernelGGL(rollout_step4_kernel<1>, dim3(as_ceil_div(N, 128), B, ks * ng), dim3(RO_NT), lds4, s, (const __bf16*)q,
+                         (const __bf16*)k, lse, (const __bf16*)rf_in, part, B, N, Npad, h, Trows, ks);
+    } else {
+      (void)hipFuncSetAttribute((const void*)rollout_step4_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
+      hipLaunchKernelGGL(rollout_step4_kernel<4>, dim3(as_ceil_div(N, 128), B, ks * ng), dim3(RO_NT), lds4, s, (const __bf16*)q,
+                         (const __bf16*)k, lse, (const __bf16*)rf_in, part, B, N, Npad, h, Trows, ks);
+    }
     AS_CHECK_LAUNCH("rollout_step4");
-    dim3 fg(as_ceil_div(as_ceil_div(N, 32) * 32, 64), 128, B);
+    dim3 fg(as_ceil_div(as_ceil_div(N, 32) * 32, 64), as_round_up(Trows, 32), B);   // rows of the R blocks that exist
     hipLaunchKernelGGL((rollout_finish_kernel<T>), fg, dim3(64), 0, s, (const float*)part, Rin, Rout, (T*)rf_out, B, N,
                        Trows, ks * ng);
     AS_CHECK_LAUNCH("rollout_finish");
@@ -725,7 +736,7 @@ int launch_rollout_step2(const void* q, const void* k, const float* lse, const f
 #undef AS_RO2
   AS_CHECK_LAUNCH("rollout_step2");
   if (nsplit > 1) {
-    dim3 fg(as_ceil_div(as_ceil_div(N, 32) * 32, 64), 128, B);
+    dim3 fg(as_ceil_div(as_ceil_div(N, 32) * 32, 64), as_round_up(Trows, 32), B);   // rows of the R blocks that exist
     hipLaunchKernelGGL((rollout_finish_kernel<T>), fg, dim3(64), 0, s, (const float*)part, Rin, Rout, (T*)rf_out, B, N,
                        Trows, nsplit);
     AS_CHECK_LAUNCH("rollout_finish");
@@ -782,6 +793,32 @@ extern "C" int as_rollout_top(const void* q, const void* k, const float* lse, fl
   if (dtype == AS_BF16) return launch_mean_rows<__bf16>(q, k, lse, R_out, rf_out, B, N, h, N - T, T, true, s);
   if (dtype == AS_F32) return launch_mean_rows<float>(q, k, lse, R_out, rf_out, B, N, h, N - T, T, true, s);
   AS_REQUIRE(false, AS_E_UNSUPPORTED, "as_rollout_top: dtype %d", dtype);
+}
+
+namespace {
+// fragment-major copy of a row-major R [B, Trows, N] (zeros outside): the `rf` operand of as_rollout_step
+template <typename T>
+__global__ __launch_bounds__(64) void rollout_pack_kernel(const float* __restrict__ R, T* __restrict__ rf, int B, int N, int Trows) {
+  const int nkb = (N + 31) / 32;
+  const int j = blockIdx.x * 64 + threadIdx.x, i = blockIdx.y, b = blockIdx.z;
+  if (j >= nkb * 32) return;
+  const float v = (i < Trows && j < N) ? R[((size_t)b * Trows + i) * N + j] : 0.0f;
+  rf[rf_slot(b, nkb, i, j)] = from_f32<T>(v);
+}
+}  // namespace
+
+extern "C" int as_rollout_pack(const float* R, void* rf, int B, int N, int T, int dtype, as_stream_t stream) {
+  AS_REQUIRE(R && rf, AS_E_BADARG, "as_rollout_pack: null pointer");
+  AS_REQUIRE(B > 0 && N > 0 && T > 0 && T <= 128, AS_E_BADARG, "as_rollout_pack: bad sizes N=%d T=%d", N, T);
+  dim3 grid(as_ceil_div(as_ceil_div(N, 32) * 32, 64), as_round_up(T, 32), B);
+  if (dtype == AS_BF16)
+    hipLaunchKernelGGL(rollout_pack_kernel<__bf16>, grid, dim3(64), 0, (hipStream_t)stream, R, (__bf16*)rf, B, N, T);
+  else if (dtype == AS_F32)
+    hipLaunchKernelGGL(rollout_pack_kernel<float>, grid, dim3(64), 0, (hipStream_t)stream, R, (float*)rf, B, N, T);
+  else
+    AS_REQUIRE(false, AS_E_UNSUPPORTED, "as_rollout_pack: dtype %d", dtype);
+  AS_CHECK_LAUNCH("rollout_pack");
+  return AS_OK;
 }
 
 extern "C" size_t as_rollout_step_workspace_bytes(int B, int N, int T) {

@@ -345,10 +345,12 @@ def attn_mean_rows(state, row0, nrows):
     return out
 
 
-def rollout_rows(states, num_point_tokens):
+def rollout_rows(states, num_point_tokens, rows=None):
     """Row-sliced attention roll-out over `states` (ordered bottom -> top, as the reference's
     attns[-cam_layer:]).  Returns [B, Lc, T, N] fp32; index k = product of the top k+1 layers
-    (reference stdroi:1257-1272 + the row slice of :2272)."""
+    (reference stdroi:1257-1272 + the row slice of :2272).  `rows` (long [B, G], indices into the T point-token rows):
+    only those rows are pushed through the layers below the top one -> [B, Lc, G, N] (a row of the product depends on
+    that row of R alone, so the values are the ones the full roll-out holds)."""
     lib = _lib.load()
     top = states[-1]
     T = int(num_point_tokens)
@@ -356,11 +358,18 @@ def rollout_rows(states, num_point_tokens):
     nbytes = lib.as_rollout_rfrag_bytes(top.B, top.N, dt)
     outs = []
     R = torch.empty(top.B, T, top.N, device=dev, dtype=torch.float32)
-    rf = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+    lower = list(reversed(states[:-1]))
+    subset = rows is not None and len(lower) > 0
+    rf = torch.empty(nbytes, device=dev, dtype=torch.uint8) if not subset else None
     _lib.check(lib.as_rollout_top(_p(top.q), _p(top.k), _p(top.lse), _p(R), _p(rf), top.B, top.N, top.h, T, dt, _stream()),
                "as_rollout_top")
+    if rows is not None:
+        R = torch.gather(R, 1, rows[:, :, None].expand(-1, -1, top.N)).contiguous()
+        T = R.shape[1]
+        if subset:
+            rf = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+            _lib.check(lib.as_rollout_pack(_p(R), _p(rf), top.B, top.N, T, dt, _stream()), "as_rollout_pack")
     outs.append(R)
-    lower = list(reversed(states[:-1]))
     wbytes = lib.as_rollout_step_workspace_bytes(top.B, top.N, T) if lower else 0
     ws = torch.empty(wbytes, device=dev, dtype=torch.uint8) if wbytes else None     # contraction-split partials
     for n, st in enumerate(lower):

@@ -661,6 +661,7 @@ class AttnShiftRoIHead(nn.Module):
         # +-10 % of the sequential loop depending on the host (tools/phase_times.py)
         self.parallel_images = parallel_images
         self.batch_mean_shift = True              # one as_cosine_shift call for all images of a batch
+        self.rollout_matched_only = True          # roll out only the matched point tokens' rows (the only ones consumed)
         self.image_streams = True                 # one HIP stream per image in the single-threaded fast-RNG path
         self.device_draws = True                  # fast-RNG mode: draws on the device, no readback before the merge plan
         self.part_slots = 8                       # merged-part slots per object carried by the one-readback merge stage
@@ -813,14 +814,23 @@ class AttnShiftRoIHead(nn.Module):
         return out
 
     # ---- stage helpers ----------------------------------------------------------------------------
-    def rollout_cams(self, attns, num_proposals):
-        """A3 (stdroi:2261): [B, Lc, T, N] rows of the roll-out for the T point tokens."""
+    def rollout_cams(self, attns, num_proposals, pos_inds=None):
+        """A3 (stdroi:2261): [B, Lc, T, N] rows of the roll-out for the T point tokens.  With `pos_inds` (per-image index
+        lists of the matched point tokens) only THOSE rows are rolled out below the top layer -- the only ones stdroi:2272
+        + the pos_inds gather ever read; a row of the product depends on that row alone, so the values are unchanged --
+        and the result is [B, Lc, Gmax, N] with image i's rows in pos_inds[i] order (padded by repeating its last index)."""
         Lc = self.bbox_head.cam_layer
         states = attns[-Lc:]
         if not isinstance(states[0], ops.AttnLayerState):
             raise TypeError("attns must be the AttnLayerState handles returned by the MI355X VisionTransformerDet "
                             "(dense [B,N,N] attention maps are never materialised on this path)")
-        return ops.rollout_rows(states, num_proposals)
+        self._rows_matched_only = False
+        if pos_inds is None or min(int(p.numel()) for p in pos_inds) == 0:
+            return ops.rollout_rows(states, num_proposals)
+        self._rows_matched_only = True                       # tells seed_pseudo_gt how to index the result
+        gmax = max(int(p.numel()) for p in pos_inds)
+        sel = torch.stack([torch.cat((p, p[-1:].expand(gmax - p.numel()))) if p.numel() < gmax else p for p in pos_inds])
+        return ops.rollout_rows(states, num_proposals, rows=sel.to(states[0].q.device).long())
 
     def refine_maps(self, attn_sel, feat_chw, rois, gt_points, refine_times, obj_tau, minmax=None, cam_src=None,
                     draw_gen=None, flags_out=None, last_level_only=False):
@@ -1118,11 +1128,15 @@ class AttnShiftRoIHead(nn.Module):
         H, W = patch_h * STRIDE, patch_w * STRIDE
         Lc = self.bbox_head.cam_layer
         CLOCK.start()
-        rows = self.rollout_cams(attns, num_proposals)                       # [B, Lc, T, N]
-        CLOCK.mark("rollout")
         counts = [int(p.numel()) for p in pos_inds]
+        self._rows_matched_only = False
+        rows = (self.rollout_cams(attns, num_proposals, pos_inds) if self.rollout_matched_only
+                else self.rollout_cams(attns, num_proposals))
+        subset = self._rows_matched_only                                     # (an overridden rollout_cams may return all T rows)
+        CLOCK.mark("rollout")                                                # [B, Lc, T | Gmax, N]
         # B1, batched over every (image, layer, object): one launch sequence for the whole batch
-        cams_lr = torch.cat([rows[i][:, pos_inds[i], 1:-num_proposals].reshape(-1, patch_h, patch_w)
+        cams_lr = torch.cat([(rows[i][:, :counts[i], 1:-num_proposals] if subset else
+                              rows[i][:, pos_inds[i], 1:-num_proposals]).reshape(-1, patch_h, patch_w)
                              for i in range(num_imgs)]).contiguous()
         pts = torch.cat([point_targets[i].float().repeat(Lc, 1) for i in range(num_imgs)]).contiguous()
         if cams_lr.shape[0] == 0:

@@ -149,8 +149,8 @@ def build(device, rng_mode="fast", train=False, ranks=None, mil=False):
     gt_labels = [(s["labels"] % CFG["num_classes"]).to(device) for s in shift]
 
     class BenchHead(A.AttnShiftRoIHead):
-        def rollout_cams(self, attns, num_proposals):
-            rows = super().rollout_cams(attns, num_proposals)                   # real roll-out of this pass
+        def rollout_cams(self, attns, num_proposals, pos_inds=None):
+            rows = super().rollout_cams(attns, num_proposals, pos_inds)         # real roll-out of this pass
             rows[:, :, :G, 1:-num_proposals] = cams                              # seeded, non-degenerate CAMs
             return rows
 

@@ -165,6 +165,9 @@ int as_attn_mean_rows(const void* q, const void* k, const float* lse, float* out
  * of as_rollout_step_workspace_bytes (room for 16 partial products, summed in a fixed order by a second tiny launch:
  * deterministic); with workspace == NULL it runs unsplit. */
 size_t as_rollout_rfrag_bytes(int B, int N, int dtype);
+/* rf = the fragment-major copy of a row-major R [B,T,N] fp32: lets a caller continue the roll-out from a row SUBSET of a
+ * previous result (the RoI head only consumes the rows of the matched point tokens, stdroi:2272 + the pos_inds gather). */
+int as_rollout_pack(const float* R, void* rf, int B, int N, int T, int dtype, as_stream_t stream);
 size_t as_rollout_step_workspace_bytes(int B, int N, int T);
 int as_rollout_top(const void* q, const void* k, const float* lse, float* R_out, void* rf_out, int B, int N, int h,
                    int T, int dtype, as_stream_t stream);

@@ -104,7 +104,7 @@ def _run_head(head, g, inp, monkeypatch, images=1):
     T, N = 10, 1 + hp * wp + 10
     rows = torch.zeros(images, Lc, T, N)
     rows[:, :, :G, 1:-T] = inp["cams"].flatten(2)
-    monkeypatch.setattr(head, "rollout_cams", lambda attns, n: rows.cuda())
+    monkeypatch.setattr(head, "rollout_cams", lambda attns, n, pos_inds=None: rows.cuda())
     best = t(g["best_idx"]).cuda()
     head.layer_selector = lambda boxes, labels, fmap: [best] * images
     torch.manual_seed(int(g["seed"]) + 1)

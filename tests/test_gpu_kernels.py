@@ -746,6 +746,28 @@ def test_add_layernorm_autograd_matches_torch(ops, M, D, dtype, tol, with_delta)
         assert mx < tol, (name, mx, mean)
 
 
+@pytest.mark.parametrize("N,h,T,dtype", [(457, 4, 40, torch.bfloat16), (1090, 12, 100, torch.bfloat16), (457, 3, 40, torch.float32)])
+def test_rollout_of_a_row_subset_equals_those_rows_of_the_full_rollout(ops, N, h, T, dtype):
+    """ops.rollout_rows(states, T, rows=sel): only the selected point-token rows go through the layers below the top one
+    (T <= 32 variant of the step kernel, as_rollout_pack for the fragment-major operand).  A row of R . A depends on that
+    row of R alone, so the result must equal the same rows of the full roll-out BIT FOR BIT."""
+    g = torch.Generator().manual_seed(N + h)
+    B, D = 2, h * 64
+    x = torch.randn(B, N, D, generator=g).cuda().to(dtype)
+    states = []
+    for l in range(3):
+        wq = (torch.randn(3 * D, D, generator=g) * D ** -0.5).cuda().to(dtype)
+        wp = (torch.randn(D, D, generator=g) * D ** -0.5).cuda().to(dtype)
+        _, st = ops.attention_fwd(x, wq, torch.zeros(3 * D, device="cuda"), wp, torch.zeros(D, device="cuda"), h, keep_state=True)
+        states.append(st)
+    full = ops.rollout_rows(states, T)
+    sel = torch.tensor([[3, T - 1, 0, 17, 17], [5, 6, 7, 1, 2]], device="cuda")
+    sub = ops.rollout_rows(states, T, rows=sel)
+    assert sub.shape == (B, 3, sel.shape[1], N)
+    ref = torch.gather(full, 2, sel[:, None, :, None].expand(-1, 3, -1, N))
+    assert torch.equal(sub, ref), float((sub - ref).abs().max())
+
+
 @pytest.mark.parametrize("B,h,w,cin,cout", [(2, 5, 7, 96, 40), (1, 16, 16, 64, 128), (2, 64, 64, 768, 768)])
 @pytest.mark.parametrize("act", ["none", "gelu"])
 def test_deconv2x2_matches_conv_transpose(ops, B, h, w, cin, cout, act):

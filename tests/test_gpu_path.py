@@ -81,7 +81,7 @@ def test_seed_pseudo_gt_chain_matches_reference(golden, tag, monkeypatch):
                                             seed_multiple=float(g["area_ratio"]), cam_layer=Lc, num_classes=20)))
     rows = torch.zeros(1, Lc, T, N)
     rows[0, :, :G, 1:-T] = inp["cams"].flatten(2)
-    monkeypatch.setattr(head, "rollout_cams", lambda attns, n: rows.cuda())
+    monkeypatch.setattr(head, "rollout_cams", lambda attns, n, pos_inds=None: rows.cuda())
     best = t(g["best_idx"]).cuda()
     head.layer_selector = lambda boxes, labels, fmap: [best]
     torch.manual_seed(int(g["seed"]) + 1)
@@ -160,7 +160,7 @@ def test_seed_pseudo_gt_two_images_equals_per_image(golden, monkeypatch):
                                                 seed_multiple=float(g["area_ratio"]), cam_layer=Lc, num_classes=20)))
         rows = torch.zeros(nimg, Lc, T, N)
         rows[:, :, :G, 1:-T] = inp["cams"].flatten(2)
-        monkeypatch.setattr(head, "rollout_cams", lambda attns, n: rows.cuda())
+        monkeypatch.setattr(head, "rollout_cams", lambda attns, n, pos_inds=None: rows.cuda())
         best = t(g["best_idx"]).cuda()
         head.layer_selector = lambda boxes, labels, fmap: [best] * nimg
         torch.manual_seed(int(g["seed"]) + 1)
@@ -205,7 +205,7 @@ def test_seed_pseudo_gt_ragged_batch(golden, monkeypatch):
                                                 seed_multiple=float(g["area_ratio"]), cam_layer=Lc, num_classes=20)))
         rows = torch.zeros(nimg, Lc, T, N)
         rows[:, :, :G, 1:-T] = inp["cams"].flatten(2)
-        monkeypatch.setattr(head, "rollout_cams", lambda attns, n: rows.cuda())
+        monkeypatch.setattr(head, "rollout_cams", lambda attns, n, pos_inds=None: rows.cuda())
         best = t(g["best_idx"]).cuda()
         head.layer_selector = lambda boxes, labels, fmap: [best[:n] for n in ns]
         torch.manual_seed(int(g["seed"]) + 1)
@@ -431,7 +431,7 @@ def test_seed_pseudo_gt_with_the_mil_head_selecting_the_depth(golden, monkeypatc
                                             seed_multiple=float(g["area_ratio"]), cam_layer=Lc, num_classes=20))).cuda()
     rows = torch.zeros(1, Lc, T, N)
     rows[0, :, :G, 1:-T] = inp["cams"].flatten(2)
-    monkeypatch.setattr(head, "rollout_cams", lambda attns, n: rows.cuda())
+    monkeypatch.setattr(head, "rollout_cams", lambda attns, n, pos_inds=None: rows.cuda())
     feat = inp["vit_feat"][None].cuda()
     out = head.seed_pseudo_gt(None, [dict(img_shape=(hp * 16, wp * 16, 3))], None, None, None, vit_feat=feat,
                               point_cls=torch.zeros(1, T, 20).cuda(), point_reg=torch.zeros(1, T, 2).cuda(), attns=None,
@@ -472,7 +472,7 @@ def test_train_losses_pseudo_labels_into_the_box_and_mask_branches(golden, monke
                                            reg_cost=dict(weight=10.0))))).cuda()
     rows = torch.zeros(1, Lc, T, N)
     rows[0, :, :G, 1:-T] = inp["cams"].flatten(2)
-    monkeypatch.setattr(head, "rollout_cams", lambda attns, n: rows.cuda())
+    monkeypatch.setattr(head, "rollout_cams", lambda attns, n, pos_inds=None: rows.cuda())
     gen = torch.Generator().manual_seed(11)
     xy = torch.rand(40, 2, generator=gen) * (wp * 16 - 60)
     props = [torch.cat((xy, xy + 20 + torch.rand(40, 2, generator=gen) * 40), 1).cuda()]
