@@ -514,10 +514,12 @@ __global__ __launch_bounds__(RO_NT, 2) void rollout_step4_kernel(const __bf16* _
     for (int ks = 0; ks < 4; ++ks)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(q + qf_frag(bh0 + wave, Npad, row, ks, half)),
                                        (__attribute__((address_space(3))) void*)(base + (wave * 4 + ks) * 1024), 16, 0, 0);
+    if (NIB == 4 || wave == 0) {                         // NIB == 1: only R block 0 exists, wave 0 brings it
 #pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(rf_in + rf_frag(b, nkb, kb, ibw, s2, lane)),
-                                       (__attribute__((address_space(3))) void*)(base + R4_QBYTES + (wave * 2 + s2) * 1024), 16, 0, 0);
+      for (int s2 = 0; s2 < 2; ++s2)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(rf_in + rf_frag(b, nkb, kb, ibw, s2, lane)),
+                                         (__attribute__((address_space(3))) void*)(base + R4_QBYTES + (wave * 2 + s2) * 1024), 16, 0, 0);
+    }
     // lse of head `wave`, rows of the block (an ordinary load here would make hipcc drain vmcnt(0) every iteration)
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(lse + (bh0 + wave) * N + min(kb * 32 + li, N - 1)),
                                      (__attribute__((address_space(3))) void*)(base + R4_LSE + wave * 256), 4, 0, 0);
@@ -539,8 +541,10 @@ __global__ __launch_bounds__(RO_NT, 2) void rollout_step4_kernel(const __bf16* _
   for (int it = 0; it < nblk; ++it) {
     const int kb = kb0 + it, buf = it % R4_NSTAGE;
     if (AS_ROLLOUT_ABLATE != 11) {
-      if (it + 1 < nblk) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");      // my pieces of block `it` have landed
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // my pieces of block `it` have landed: all but the 7 (5 for the waves that carry no R block) of block it+1
+      if (it + 1 >= nblk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if (NIB == 4 || wave == 0) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
     }
     if (AS_ROLLOUT_ABLATE != 14) __builtin_amdgcn_s_barrier();   // block `it` is complete; everyone is done with block it-1
     if (AS_ROLLOUT_ABLATE != 11 && it + 2 < nblk) stage(kb + 2, (it + 2) % R4_NSTAGE);
