@@ -983,11 +983,11 @@ class AttnShiftRoIHead(nn.Module):
                              extra=None):
         """_semantic_post with ONE readback (fast-RNG path), first half: everything up to and including the START of
         that readback (a device -> pinned-host copy + event), so that a caller with several images can queue all of them
-        before it waits for the first: the greedy merge plan (ops.merge_plan), the
-        merged prototypes, their similarity maps and the per-part statistics are computed for all P group slots of
-        every object (unused slots are zero prototypes), the visiting order / cap logic of stdroi:222-262 becomes a
-        stable rank over the slots, and only the choice bits, ranks and group counts are read back -- together with
-        the `extra` flags, whose host values replace the list's entries; returns None if any of them is set."""
+        before it waits for the first: the greedy merge plan (ops.merge_plan), the merged prototypes, their similarity
+        maps and the per-part statistics are computed for all P group slots of every object (unused slots are zero
+        prototypes); the visiting order / cap logic of stdroi:222-262 and the gathers behind it run on the device too
+        (ops.part_select), so only the per-object counts and the group counts are read back -- together with the `extra`
+        flags.  Returns the state _semantic_post_finish consumes."""
         G = fg_inter.shape[0]
         P = sim.shape[0] // G
         hp, wp = vit_feat.shape[-2:]
