@@ -20,6 +20,37 @@ def main(db, out, title):
                      f"{100.0 * tot / total:.1f} | {vg} | {lds} |")
     lines.append("")
     lines.append(f"total kernel time {total / 1e6:.3f} ms over {sum(r[1] for r in rows)} dispatches")
+    if __import__("os").environ.get("PROF_GAPS"):            # device idle analysis: union of busy intervals, largest gaps
+        cols = [r[1] for r in c.execute("pragma table_info(kernels)").fetchall()]
+        sc, ec = ("start", "end") if "start" in cols else ("start_timestamp", "end_timestamp")
+        ev = c.execute(f"select {sc}, {ec}, name from kernels order by {sc}").fetchall()
+        n = len(ev)
+        ev = ev[n // 3:]                                   # skip warm-up / model build
+        busy, cur_end, gaps = 0, ev[0][0], []
+        for st, en, name in ev:
+            if st > cur_end:
+                gaps.append((st - cur_end, name))
+                busy += en - st
+                cur_end = en
+            elif en > cur_end:
+                busy += en - cur_end
+                cur_end = en
+        span = cur_end - ev[0][0]
+        lines += ["", f"## device idle (last two thirds of the trace): span {span / 1e6:.3f} ms, busy {busy / 1e6:.3f} ms "
+                      f"({100.0 * busy / span:.1f} %), {len(gaps)} gaps"]
+        big = sorted(gaps, reverse=True)[:int(__import__("os").environ.get("PROF_GAPS"))]
+        agg = {}
+        for g, name in gaps:
+            if g > 3000:
+                a = agg.setdefault(name[:70], [0, 0])
+                a[0] += 1
+                a[1] += g
+        lines += ["", "| gap before kernel (gaps > 3 us) | count | total us |", "|---|---|---|"]
+        for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:25]:
+            lines.append(f"| `{k}` | {v[0]} | {v[1] / 1e3:.1f} |")
+        open(out, "w").write("\n".join(lines) + "\n")
+        print("\n".join(lines[-32:]))
+        return
     pat = __import__("os").environ.get("PROF_BY_GRID")        # e.g. PROF_BY_GRID=gemm: split matching kernels by grid size
     if pat:
         cols = [r[1] for r in c.execute("pragma table_info(kernels)").fetchall()]
