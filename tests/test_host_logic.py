@@ -221,3 +221,21 @@ def test_hungarian_matching_equals_the_reference_assigner(golden):
         want = tt("gt_inds")                                          # 0 = unmatched, k + 1 = matched to point k
         assert torch.equal(pos, torch.nonzero(want > 0).flatten()), i
         assert torch.equal(gt, want[want > 0] - 1), i
+
+
+def test_median_area_selector_batched_equals_per_image():
+    """The depth selector of the attribute-only configuration computes all images in one pass (same launches as one image);
+    per image it must give what the per-image loop gives, also for ties (stable order) and unequal object counts."""
+    from attentionshift_amd.roi_head import median_area_selector
+    g = torch.Generator().manual_seed(3)
+    boxes = [torch.rand(3, 7, 4, generator=g) * 100, torch.rand(5, 7, 4, generator=g) * 100, torch.rand(1, 7, 4, generator=g)]
+    boxes[1][2] = boxes[1][2, :1]                       # seven identical boxes: a 7-way tie
+    for b in boxes:
+        b[..., 2:] += b[..., :2]
+    batched = median_area_selector(boxes)
+    single = [median_area_selector([b])[0] for b in boxes]
+    assert all(torch.equal(a, b) for a, b in zip(batched, single))
+    assert int(batched[1][2]) == 3                      # stable sort: the middle of 0..6
+    mixed = median_area_selector([boxes[0], boxes[1][:, :5]])           # different depth counts: per-image path
+    assert torch.equal(mixed[0], single[0]) and mixed[1].shape == (5,)
+
