@@ -651,6 +651,12 @@ __global__ __launch_bounds__(RO_NT, 2) void rollout_step4_kernel(const __bf16* _
   }
 }
 
+// AS_ROLLOUT_V3=1 (debug knob): take rollout_step3 where rollout_step4 would run; read ONCE per process
+bool rollout_force_v3() {
+  static const bool v = getenv("AS_ROLLOUT_V3") != nullptr;
+  return v;
+}
+
 // partial products of rollout_step4: (contraction splits) x (head groups), at most R4_MAXPARTS; the split count is chosen
 // so that the grid fills whole rounds of 2 workgroups per CU (e.g. 33 x 2 x 3 = 198 units -> 5 splits = 990 of 1024)
 constexpr int R4_MAXPARTS = 16;
@@ -701,7 +707,7 @@ int launch_rollout_step2(const void* q, const void* k, const float* lse, const f
     hipLaunchKernelGGL((rollout_step2_kernel<T, HPW>), grid, dim3(RO_NT), lds, s, (const T*)q, (const T*)k, lse, Rin, \
                        (const T*)rf_in, Rout, (T*)rf_out, part, B, N, Npad, h, Trows, nsplit);                 \
   } while (0)
-  if (sizeof(T) == 2 && h % R4_HPG == 0 && part != nullptr && nsplit == R4_MAXPARTS && getenv("AS_ROLLOUT_V3") == nullptr) {
+  if (sizeof(T) == 2 && h % R4_HPG == 0 && part != nullptr && nsplit == R4_MAXPARTS && !rollout_force_v3()) {
     // bf16, heads in groups of four: streamed-operand kernel; `nsplit` here only says that the workspace holds
     // R4_MAXPARTS partial products
     const int ks = rollout4_ksplit(B, N, h), ng = h / R4_HPG;
@@ -842,7 +848,7 @@ extern "C" int as_rollout_step(const void* q, const void* k, const float* lse, c
   // without a workspace the step runs unsplit (one workgroup per 32-column block and image)
   const size_t need = as_rollout_step_workspace_bytes(B, N, T);
   const bool have_ws = workspace != nullptr && workspace_bytes >= need && need > 0;
-  const bool stream4 = have_ws && dtype == AS_BF16 && h % R4_HPG == 0 && getenv("AS_ROLLOUT_V3") == nullptr;
+  const bool stream4 = have_ws && dtype == AS_BF16 && h % R4_HPG == 0 && !rollout_force_v3();
   const int ns = stream4 ? R4_MAXPARTS : (have_ws ? rollout_nsplit(B, N) : 1);
   float* part = ns > 1 ? (float*)workspace : nullptr;
   if (dtype == AS_BF16)

@@ -382,6 +382,27 @@ def rollout_rows(states, num_point_tokens, rows=None):
     return torch.stack(outs, dim=1)
 
 
+def rollout_rows_dense(states, num_point_tokens, rows=None):
+    """VALIDATION path for rollout_rows (bench.py's warm-up check and the full-size tests): the same rows through an
+    independent route -- the dense head-mean matrix of every layer from as_attn_mean_rows ([B,N,N] fp32, O(N^2) memory)
+    augmented and multiplied with fp32 torch matmuls exactly as stdroi:1257-1272 writes it.  Not used by the step."""
+    T = int(num_point_tokens)
+    run, outs = None, []
+    for st in reversed(states):
+        a = attn_mean_rows(st, 0, st.N)
+        a.diagonal(dim1=1, dim2=2).add_(1.0)
+        a /= a.sum(-1, keepdim=True)
+        if run is None:
+            run = a[:, st.N - T:, :]
+            if rows is not None:
+                run = torch.gather(run, 1, rows[:, :, None].expand(-1, -1, st.N))
+        else:
+            run = torch.bmm(run, a)
+        outs.append(run.contiguous())
+        del a
+    return torch.stack(outs, dim=1)
+
+
 # ------------------------------------------------------------------------------------------------
 # Part B
 # ------------------------------------------------------------------------------------------------

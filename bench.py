@@ -149,8 +149,26 @@ def build(device, rng_mode="fast", train=False, ranks=None, mil=False):
     gt_labels = [(s["labels"] % CFG["num_classes"]).to(device) for s in shift]
 
     class BenchHead(A.AttnShiftRoIHead):
+        rollout_check = None          # set by the FIRST call (a warm-up step): the real rows vs the dense route
+
         def rollout_cams(self, attns, num_proposals, pos_inds=None):
             rows = super().rollout_cams(attns, num_proposals, pos_inds)         # real roll-out of this pass
+            if self.rollout_check is None:
+                # the rows are replaced by seeded CAMs below (random-init weights give near-uniform attention), so the
+                # values the roll-out kernels produced are checked HERE, once, against the dense head-mean product
+                # (as_attn_mean_rows + fp32 torch matmuls); bf16 operands: 3e-2 of the range, as the parity tests
+                from attentionshift_amd import ops as _ops
+                sel = None
+                if getattr(self, "_rows_matched_only", False):
+                    sel = torch.stack([p for p in pos_inds]).to(rows.device).long()
+                ref = _ops.rollout_rows_dense(attns[-self.bbox_head.cam_layer:], num_proposals, rows=sel)
+                scale = float(ref.abs().max()) + 1e-30
+                err = (ref - rows).abs()
+                self.rollout_check = dict(max_rel=float(err.max()) / scale, mean_rel=float(err.mean()) / scale,
+                                                rows=list(rows.shape), vs="as_attn_mean_rows dense product (fp32 matmul)")
+                if not (self.rollout_check["max_rel"] < 3e-2):
+                    raise RuntimeError(f"roll-out rows differ from the dense product: {self.rollout_check}")
+                del ref, err
             rows[:, :, :G, 1:-num_proposals] = cams                              # seeded, non-degenerate CAMs
             return rows
 
@@ -356,6 +374,8 @@ def main():
             "ms_per_launch": round(ms_wa, 4), "algorithmic_bytes_per_launch": bytes_wa}
     if vit:
         rec["rng_mode"] = rng_mode
+        # the real roll-out rows of the first warm-up pass against the dense head-mean product (BenchHead.rollout_cams)
+        rec["rollout_check"] = getattr(step.head, "rollout_check", None)
         other = "reference" if rng_mode == "fast" else "fast"
         if os.environ.get("AS_BENCH_OTHER_RNG", "1") == "1":      # (0: profiling runs that want the headline leg alone)
             step.head.rng_mode = other

@@ -143,6 +143,19 @@ def attention(x, w_qkv, b_qkv, w_proj, b_proj, num_heads):
     return F.linear(o, w_proj, b_proj), p
 
 
+def attention_head_mean(x, w_qkv, b_qkv, num_heads):
+    """The `attn.mean(1)` the backbone keeps per layer (mmdet/models/backbones/visual_transformer_det.py:236,242) of
+    Attention.forward's softmax (models/vision_transformer.py:75-81), accumulated head by head so that the
+    [B,h,N,N] tensor of `attention` is never held (N = 4197: 845 MB per layer) -> [B,N,N]."""
+    B, N, D = x.shape
+    d = D // num_heads
+    qkv = F.linear(x, w_qkv, b_qkv).reshape(B, N, 3, num_heads, d).permute(2, 0, 3, 1, 4)
+    mean = torch.zeros(B, N, N, dtype=x.dtype)
+    for hd in range(num_heads):
+        mean += ((qkv[0][:, hd] @ qkv[1][:, hd].transpose(-2, -1)) * (d ** -0.5)).softmax(dim=-1)
+    return mean / num_heads
+
+
 def block(x, sd, prefix, num_heads, ln_eps=1e-6):
     """models/vision_transformer.py:109-124 Block.forward (gamma_1/2 None, drop_path identity in
     eval) -> (x, P)."""

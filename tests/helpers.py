@@ -65,7 +65,7 @@ def shift_state_inputs(g, inp):
     return tok[None] * inbox[..., None], tok, prot, (rois // 16).int()
 
 
-def check_shift_decisions(step, got_assign, prot, feats, tau, temp=0.1, what="", max_frac=0.02):
+def check_shift_decisions(step, got_assign, prot, feats, tau, temp=0.1, what="", max_flips=16):
     """`got_assign` [G,Np] must equal the reference arithmetic's argmax `step['win']` (one iteration of
     cosine_shift_batch evaluated in fp32 from the SAME state) wherever that argmax is determined.  A differing patch is
     accepted only if it is a rounding coin flip of the reference itself:
@@ -94,5 +94,7 @@ def check_shift_decisions(step, got_assign, prot, feats, tau, temp=0.1, what="",
     ok = near | under
     assert ok.all(), (f"{what}: {int((~ok).sum())} cluster assignments differ from the reference arithmetic on DETERMINED "
                       f"decisions (worst margin {float(margin[~ok].max()):.3e} vs noise {float(noise[~ok].min()):.3e})")
-    assert int(bad.sum()) <= max_frac * got.numel(), f"{what}: {int(bad.sum())} coin-flip patches is implausibly many"
+    # the CPU matmul-form oracle itself flips at most 16 of 12 288 decisions per iteration against the reference
+    # (test_full_size_matmul_oracle_differs_from_reference_only_on_coin_flips); more than that is a regression
+    assert int(bad.sum()) <= max_flips, f"{what}: {int(bad.sum())} coin-flip patches (> {max_flips}) is implausibly many"
     return int(bad.sum()), int(near.sum()), int((under & ~near).sum())

@@ -86,7 +86,7 @@ def test_cosine_shift_every_iteration_is_the_reference_argmax(ops, cfg2):
         assert sum(diff) == 0, "no coin flips, so the whole trajectory must equal the reference's"
         _rows_close(t(g["ref_prot"]), pout.reshape(-1, pout.shape[-1]).cpu(), "prototypes vs reference")
         assert_close(t(g["ref_sim"]).flatten(1), sim.reshape(-1, hp * wp).clamp(min=0), 1e-3, 1e-5, "sim vs reference")
-    assert max(diff) <= 0.01 * ref_assign[0].numel()
+    assert max(diff) <= 16, diff        # the bound the CPU matmul-form oracle itself meets against the reference
     direct = O.cos_matrix(pout.cpu(), tok)
     assert_close(direct, sim, 1e-3, 1e-5, "final sim == cos(returned prototypes, unmasked features)")
 
@@ -204,11 +204,19 @@ def test_seed_pseudo_gt_chain_full_size_fast_rng(golden, cfg2, monkeypatch):
             cand_fg = O.erode((crop_fg > crop_fg.max() * pos_thr).float()[None], int(g["corr_size"]))[0] > 0
             cand_bg = crop_bg > crop_bg.max() * neg_thr
             cx, cy = coords[o, :, 0].long() - x0, coords[o, :, 1].long() - y0
-            near_edge = lambda m, thr: ((m - m.max() * thr).abs() <= 2e-6)
+            # a drawn point may fall outside the CPU-evaluated candidate set only if the pixel that decides it sits on
+            # the threshold to within the maps' last-bit noise: the drawn pixel itself for a background point, a pixel of
+            # the drawn pixel's erosion window for a foreground point
+            edge_fg = (crop_fg - crop_fg.max() * pos_thr).abs() <= 2e-6
+            edge_bg = (crop_bg - crop_bg.max() * neg_thr).abs() <= 2e-6
+            rad = int(g["corr_size"]) // 2
             for j in range(coords.shape[1]):
-                inside = cand_fg[cy[j], cx[j]] if labels[o, j] else cand_bg[cy[j], cx[j]]
-                assert inside or bool(near_edge(crop_fg, pos_thr).any() or near_edge(crop_bg, neg_thr).any()), \
-                    f"mask point {j} of object {o} is not a candidate of its label"
+                y, x = int(cy[j]), int(cx[j])
+                if labels[o, j]:
+                    ok = bool(cand_fg[y, x]) or bool(edge_fg[max(y - rad, 0):y + rad + 1, max(x - rad, 0):x + rad + 1].any())
+                else:
+                    ok = bool(cand_bg[y, x]) or bool(edge_bg[y, x])
+                assert ok, f"mask point {j} of object {o} is not a candidate of its label"
             assert len({(int(a), int(b)) for a, b in coords[o]}) == coords.shape[1], "mask points must be distinct"
         fg_inter, _bg, fg_bin = O.semantic_prestage(m_fg[-1], m_bg[-1], (hp, wp), pos_thr)
         assert_equal(fg_inter, seeds["fg_inter"], "patch-grid foreground (B3)")

@@ -49,6 +49,24 @@ def test_linear_f32(ops, M, N, K, act):
     assert_close(ref, got, 1e-4, 1e-4, f"linear f32 {M}x{N}x{K} {act}")
 
 
+@pytest.mark.parametrize("M,N,K", [(8394, 3072, 768), (8394, 768, 3072), (4197, 768, 768)])
+@pytest.mark.parametrize("act", ["none", "gelu"])
+def test_linear_bf16_backbone_shapes(ops, M, N, K, act):
+    """as_linear_fwd in plain-linear mode on the shapes the ViT-B blocks launch (fc1 / fc2 / proj at 2 x 4197 tokens):
+    these pick the 256 x 128 tile (csrc/gemm.hip launch_gemm_glds; M = 513 below always gets the 128 x 128 one), ragged
+    in M (8394 = 32 * 256 + 202).  vs F.linear (+ exact erf GELU) in fp32 on the same bf16-rounded operands."""
+    g = torch.Generator().manual_seed(M + N)
+    x = torch.randn(M, K, generator=g).bfloat16()
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).bfloat16()
+    b = torch.randn(N, generator=g)
+    ref = torch.nn.functional.linear(x.float(), w.float(), b)
+    if act == "gelu":
+        ref = torch.nn.functional.gelu(ref)
+    got = ops.linear(dev(x), dev(w), dev(b), act=act).float()
+    mx, mean = rel_to_range(ref, got)
+    assert mx < 1e-2 and mean < 2e-3, (mx, mean)      # output rounding to bf16 dominates
+
+
 def test_linear_bf16(ops):
     g = torch.Generator().manual_seed(1)
     x, w, b = torch.randn(513, 768, generator=g), torch.randn(384, 768, generator=g) * 0.05, torch.randn(384, generator=g)

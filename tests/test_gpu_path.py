@@ -35,7 +35,7 @@ def rel(ref, got):
     return ((ref - got).abs().max() / (ref.abs().max() + 1e-30)).item()
 
 
-@pytest.mark.parametrize("tag", ["small", "tiny224"])
+@pytest.mark.parametrize("tag", ["small", "tiny224", "h4"])
 def test_backbone_fp32_matches_reference(golden, tag):
     from attentionshift_amd import ops
     g = golden(f"backbone_{tag}")
@@ -56,8 +56,10 @@ def test_backbone_fp32_matches_reference(golden, tag):
             assert_close(t(g[key]), dense, 1e-3, 1e-7, f"head-mean attention layer {key[4:]}")
 
 
-@pytest.mark.parametrize("tag", ["small", "tiny224"])
+@pytest.mark.parametrize("tag", ["small", "tiny224", "h4"])
 def test_backbone_bf16_close_to_reference(golden, tag):
+    """bf16 path; the "h4" case (4 heads) is the fixture-backed check of rollout_step4_kernel, the roll-out kernel of
+    every h % 4 == 0 configuration (ViT-B, ViT-L): the reference's own attns_project_to_feature rows."""
     from attentionshift_amd import ops
     g = golden(f"backbone_{tag}")
     bb, img, cfg = build_backbone(g, torch.bfloat16)

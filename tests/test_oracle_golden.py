@@ -15,7 +15,7 @@ from helpers import assert_close, assert_equal, backbone_cfg, backbone_state_dic
 torch.set_grad_enabled(False)
 
 
-@pytest.mark.parametrize("tag", ["small", "tiny224"])
+@pytest.mark.parametrize("tag", ["small", "tiny224", "h4"])
 def test_backbone_forward_matches_reference(golden, tag):
     g = golden(f"backbone_{tag}")
     cfg = backbone_cfg(g)
@@ -36,6 +36,16 @@ def test_backbone_forward_matches_reference(golden, tag):
     # A3: the row-sliced roll-out equals the rows of the reference's dense roll-out
     assert_close(t(g["rollout_rows"]), O.rollout_rows(out["attns"][-Lc:], T), 1e-5, 1e-7, "rollout_rows")
     assert_close(t(g["rollout_rows"]), O.rollout_full(out["attns"][-Lc:])[:, :, -T:, :], 1e-5, 1e-7, "rollout_full")
+
+
+def test_attention_head_mean_equals_mean_of_attention():
+    """the head-by-head accumulation used by the full-size roll-out tests == Attention.forward's P averaged over heads"""
+    g = torch.Generator().manual_seed(3)
+    B, N, h = 2, 77, 4
+    D = 64 * h
+    x, w, b = torch.randn(B, N, D, generator=g), torch.randn(3 * D, D, generator=g) * 0.1, torch.randn(3 * D, generator=g)
+    _, p = O.attention(x, w, b, torch.eye(D), torch.zeros(D), h)
+    assert_close(p.mean(1), O.attention_head_mean(x, w, b, h), 1e-6, 1e-8, "head mean")
 
 
 def test_upsample_formula_is_bit_identical_to_torch():

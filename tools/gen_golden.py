@@ -96,6 +96,13 @@ def backbone_case(tag, cfg, img_hw, store_attn_layers, cam_layer):
     np.savez_compressed(os.path.join(OUT, f"backbone_{tag}.npz"), **save)
 
 
+def backbone_h4():
+    # 4 heads: the bf16 roll-out of this case runs rollout_step4_kernel (h % 4 == 0), the kernel of the ViT-B / ViT-L
+    # configurations; 12 x 10 patches + cls + 20 point tokens = 141 tokens (two 128-column workgroups, ragged)
+    backbone_case("h4", dict(img_size=96, embed_dim=256, depth=4, num_heads=4, out_indices=(0, 1, 2, 3),
+                             point_tokens_num=20, num_classes=5, batch=2, seed=5), (192, 160), (3,), 3)
+
+
 # ----------------------------------------------------------------------------------------------
 class _Dummy:
     pass
@@ -295,10 +302,14 @@ def main():
         swin_case("w16_s3_pad", 13, 96, 3, 16, 3)
         swin_case("w9_s0_pad", 14, 64, 2, 9, 0, B=1)
         return
+    if "--h4-only" in sys.argv:
+        backbone_h4()
+        return
     backbone_case("small", dict(img_size=64, embed_dim=128, depth=4, num_heads=2, out_indices=(0, 1, 2, 3),
                                 point_tokens_num=10, num_classes=5, batch=2, seed=3), (96, 80), (0, 3), 3)
     backbone_case("tiny224", dict(img_size=224, embed_dim=192, depth=12, num_heads=3, out_indices=(3, 5, 7, 11),
                                   point_tokens_num=100, num_classes=20, batch=1, seed=0), (224, 224), (11,), 7)
+    backbone_h4()
     shift_case("tiny224", seed=1234, hp=14, wp=14, C=192, G=3, Lc=7, n_shift=3)
     shift_case("mid320", seed=77, hp=20, wp=20, C=96, G=3, Lc=3, n_shift=5)
     shift_case("cfg2", seed=2024, hp=64, wp=64, C=768, G=3, Lc=7, n_shift=5, slim=True)
