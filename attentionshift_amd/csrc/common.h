@@ -94,6 +94,14 @@ __device__ __forceinline__ size_t qf_elem(size_t bh, int Npad, int row, int d) {
   return qf_frag(bh, Npad, row, d >> 4, (d >> 3) & 1) + (d & 7);
 }
 
+// q is stored PRE-SCALED: q' = (x Wq^T + bq) * log2(e) / sqrt(64), rounded once from the fp32 accumulator (QKV epilogue,
+// gemm.hip).  Every consumer then gets base-2 logits straight from the MFMA, s' = q' . k = log2(e) * (q . k) / 8:
+// softmax weights are exp2(s' - lse * log2 e) with no multiply per score (sdpa.hip, rollout.hip, sdpa_bwd.hip), and
+// d/dk carries ln 2 instead of 1/8 (sdpa_bwd.hip).
+#define AS_LOG2E 1.44269504088896340736f
+#define AS_LN2 0.69314718055994530942f
+#define AS_QSCALE (0.125f * AS_LOG2E)
+
 // accumulator register r of a lane in half `half` -> row inside the 32x32 tile
 __device__ __forceinline__ int acc_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 

@@ -78,7 +78,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[2][2], const bool (&
               const int b = row / epi.N, n = row - b * epi.N;
               const size_t at = which == 0 ? qf_elem((size_t)(b * epi.h + head), epi.Npad, n, dd)   // fragment-major q
                                            : ((size_t)(b * epi.h + head) * epi.Npad + n) * 64 + dd;
-              dst[at] = from_f32<T>(acc[i][j][r] + bv);
+              dst[at] = from_f32<T>(which == 0 ? (acc[i][j][r] + bv) * AS_QSCALE : acc[i][j][r] + bv);   // q pre-scaled
             }
           }
         } else {
@@ -411,6 +411,9 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 3 : 2) void gemm_glds_kernel(co
         const float4 bv = *reinterpret_cast<const float4*>(bias_s + c0);
         float v0 = acc[i][j][4 * g] + bv.x, v1 = acc[i][j][4 * g + 1] + bv.y, v2 = acc[i][j][4 * g + 2] + bv.z,
               v3 = acc[i][j][4 * g + 3] + bv.w;
+        if (MODE == 1 && n0 + c0 < epi.D) {              // q columns: stored pre-scaled by log2(e)/8 (common.h)
+          v0 *= AS_QSCALE; v1 *= AS_QSCALE; v2 *= AS_QSCALE; v3 *= AS_QSCALE;
+        }
         if (act == 1) { v0 = gelu_bf16(v0); v1 = gelu_bf16(v1); v2 = gelu_bf16(v2); v3 = gelu_bf16(v3); }
         bf16x4 pk = {(__bf16)v0, (__bf16)v1, (__bf16)v2, (__bf16)v3};
         *reinterpret_cast<bf16x4*>(srow + c0 * 2) = pk;

@@ -43,7 +43,6 @@ __device__ __forceinline__ f32x16 pbar_tile(const T* __restrict__ q, const T* __
   for (int r = 0; r < 16; ++r) pbar[r] = 0.0f;
   const int irow = min(i0 + li, N - 1);
   const int jrow = min(j0 + li, N - 1);
-  const float c2 = 0.125f * LOG2E;
   for (int hh = 0; hh < h; ++hh) {
     const size_t bh = (size_t)b * h + hh;
     f32x16 s;
@@ -63,7 +62,7 @@ __device__ __forceinline__ f32x16 pbar_tile(const T* __restrict__ q, const T* __
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = min(i0 + acc_row(r, half), N - 1);
-      pbar[r] += __builtin_amdgcn_exp2f(fmaf(s[r], c2, -lrow[row] * LOG2E));
+      pbar[r] += __builtin_amdgcn_exp2f(s[r] - lrow[row] * LOG2E);          // q is pre-scaled: s = log2(e) q.k / 8
     }
   }
   const float inv_h = 1.0f / (float)h;
@@ -100,7 +99,7 @@ __global__ __launch_bounds__(RO_NT) void attn_mean_rows_kernel(const T* __restri
 // ---------------------------------------------------------------------------------------------------------
 // rollout_step2: latency-tolerant version.  All four waves of a workgroup work on the SAME 32-row contraction
 // block at a time, each on its own heads (wave w: heads w, w+4, ...):
-//   * the per-row -lse term is injected with ONE exact-fp32 MFMA per head (A = -8*lse[row] in the k=0 slot,
+//   * the per-row -lse term is injected with ONE exact-fp32 MFMA per head (A = -log2(e)*lse[row] in the k=0 slot,
 //     B = 1), which lands it directly in the accumulator layout -- no per-register lse loads;
 //   * Q fragments of the next block are prefetched into registers while the current block is computed (bf16);
 //   * the four partial head sums are exchanged through a double-buffered 16 KiB LDS slab (one barrier per
@@ -146,7 +145,6 @@ __global__ __launch_bounds__(RO_NT) void rollout_step2_kernel(const T* __restric
   __syncthreads();
 
   const int nkb = (N + 31) / 32;
-  const float c2 = 0.125f * LOG2E;
   const float inv_h = 1.0f / (float)h;
   const bool own_rows = wave * 32 < Trows;              // this wave's 32-row block of R exists
 
@@ -169,7 +167,7 @@ __global__ __launch_bounds__(RO_NT) void rollout_step2_kernel(const T* __restric
       const int hh = min(wave + 4 * t, h - 1);
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) f.fq[t][ks].load16B(q + qf_frag((size_t)b * h + hh, Npad, row, ks, half));
-      f.l8[t] = -8.0f * lse[((size_t)b * h + hh) * N + row];
+      f.l8[t] = -LOG2E * lse[((size_t)b * h + hh) * N + row];
     }
     if (own_rows) {
 #pragma unroll
@@ -211,7 +209,7 @@ __global__ __launch_bounds__(RO_NT) void rollout_step2_kernel(const T* __restric
           sc = mma32(cur.fq[t][ks], fk, sc);
         }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) pbar[r] += __builtin_amdgcn_exp2f(sc[r] * c2);
+        for (int r = 0; r < 16; ++r) pbar[r] += __builtin_amdgcn_exp2f(sc[r]);
       }
     }
     // publish this wave's partial head sum
@@ -332,7 +330,6 @@ __global__ __launch_bounds__(RO_NT, 3) void rollout_step3_kernel(const T* __rest
 
   const int nkb = (N + 31) / 32;
   const int nib = (Trows + 31) / 32;                      // 32-row blocks of R that exist (<= 4)
-  const float c2 = 0.125f * LOG2E;
   const float inv_h = 1.0f / (float)h;
   const int kb0 = (int)((long long)nkb * split / nsplit), kb1 = (int)((long long)nkb * (split + 1) / nsplit);
 
@@ -349,12 +346,12 @@ __global__ __launch_bounds__(RO_NT, 3) void rollout_step3_kernel(const T* __rest
     float l8;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) fq[ks].load16B(q + qf_frag((size_t)b * h, Npad, row, ks, half));
-    l8 = -8.0f * lse[((size_t)b * h) * N + row];
+    l8 = -LOG2E * lse[((size_t)b * h) * N + row];
     f32x16 pbar;
 #pragma unroll
     for (int r = 0; r < 16; ++r) pbar[r] = 0.0f;
     auto head = [&](int hh) {
-      f32x16 sc = inject_rows<T>(AS_ROLLOUT_ABLATE == 3 ? 0.0f : l8, half);       // -8*lse[row i]
+      f32x16 sc = inject_rows<T>(AS_ROLLOUT_ABLATE == 3 ? 0.0f : l8, half);       // -log2(e)*lse[row i]
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         Frag<T> fk;
@@ -363,7 +360,7 @@ __global__ __launch_bounds__(RO_NT, 3) void rollout_step3_kernel(const T* __rest
         else sc[ks] += (float)fk.v[0];
       }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) pbar[r] += AS_ROLLOUT_ABLATE == 2 ? sc[r] * c2 : __builtin_amdgcn_exp2f(sc[r] * c2);
+      for (int r = 0; r < 16; ++r) pbar[r] += AS_ROLLOUT_ABLATE == 2 ? sc[r] : __builtin_amdgcn_exp2f(sc[r]);
     };
     for (int hh = 0; hh + 1 < h; ++hh) {                  // heads 0 .. h-2: next head's Q fragments in flight
       Frag<T> fn[4];
@@ -372,7 +369,7 @@ __global__ __launch_bounds__(RO_NT, 3) void rollout_step3_kernel(const T* __rest
         if (AS_ROLLOUT_ABLATE == 1) fn[ks] = fq[ks];
         else fn[ks].load16B(q + qf_frag((size_t)b * h + hh + 1, Npad, row, ks, half));
       }
-      const float l8n = AS_ROLLOUT_ABLATE == 1 ? l8 : -8.0f * lse[((size_t)b * h + hh + 1) * N + row];
+      const float l8n = AS_ROLLOUT_ABLATE == 1 ? l8 : -LOG2E * lse[((size_t)b * h + hh + 1) * N + row];
       head(hh);
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) fq[ks] = fn[ks];
@@ -530,7 +527,6 @@ __global__ __launch_bounds__(RO_NT, 2) void rollout_step4_kernel(const __bf16* _
   for (int ib = 0; ib < NIB; ++ib)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[ib][r] = 0.0f;
-  const float c2 = 0.125f * LOG2E;
   const float inv_h = 1.0f / (float)h;
   const unsigned lbase = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)smem + lane * 16;
 
@@ -573,7 +569,7 @@ __global__ __launch_bounds__(RO_NT, 2) void rollout_step4_kernel(const __bf16* _
                  "+v"(l8[2]), "+v"(l8[3]));
     __builtin_amdgcn_sched_barrier(0);
     auto qk = [&](int hh, r4_u32x4 (&f)[4]) {
-      f32x16 sc = inject_rows<__bf16>(-8.0f * l8[hh], half);
+      f32x16 sc = inject_rows<__bf16>(-LOG2E * l8[hh], half);
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         Frag<__bf16> fq;
@@ -608,7 +604,7 @@ __global__ __launch_bounds__(RO_NT, 2) void rollout_step4_kernel(const __bf16* _
         }
       }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) pbar[r] += AS_ROLLOUT_ABLATE == 12 ? sc_cur[r] : __builtin_amdgcn_exp2f(sc_cur[r] * c2);
+      for (int r = 0; r < 16; ++r) pbar[r] += AS_ROLLOUT_ABLATE == 12 ? sc_cur[r] : __builtin_amdgcn_exp2f(sc_cur[r]);
       if (hh + 1 < R4_HPG) sc_cur = sc_next;
     }
     Frag<__bf16> fp[2];

@@ -127,7 +127,7 @@ __global__ __launch_bounds__(SD_NT) void sdpa_fwd_kernel(const T* __restrict__ q
 #pragma unroll
   for (int r = 0; r < 16; ++r) { oacc[0][r] = 0.0f; oacc[1][r] = 0.0f; }
   float m_run = -INFINITY, l_part = 0.0f;
-  const float c2 = 0.125f * 1.44269504088896340736f;   // d^-0.5 * log2(e)
+  // q is stored pre-scaled by log2(e) / 8 (common.h): the MFMA scores ARE the base-2 logits
 
   gload(0);
   lstore(0);
@@ -166,8 +166,8 @@ __global__ __launch_bounds__(SD_NT) void sdpa_fwd_kernel(const T* __restrict__ q
       for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, sacc[kb][r]);
     mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
     const float m_new = fmaxf(m_run, mloc);
-    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c2);
-    const float mc = m_new * c2;
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    const float mc = m_new;
     m_run = m_new;
     float psum = 0.0f;
     Frag<T> fp[2][2];
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(SD_NT) void sdpa_fwd_kernel(const T* __restrict__ q
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float p = __builtin_amdgcn_exp2f(fmaf(sacc[kb][r], c2, -mc));
+        const float p = __builtin_amdgcn_exp2f(sacc[kb][r] - mc);
         psum += p;
         fp[kb][r >> 3].set(r & 7, p);
       }
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(SD_NT) void sdpa_fwd_kernel(const T* __restrict__ q
         store4(orow + d, oacc[db][4 * g] * inv, oacc[db][4 * g + 1] * inv, oacc[db][4 * g + 2] * inv,
                oacc[db][4 * g + 3] * inv);
       }
-    if (half == 0) lse[(size_t)bh * N + query] = m_run * 0.125f + logf(l);
+    if (half == 0) lse[(size_t)bh * N + query] = m_run * AS_LN2 + logf(l);
   }
 }
 
@@ -334,8 +334,7 @@ __global__ __launch_bounds__(SD_NT, 3) void sdpa_fwd_glds_kernel(const __bf16* _
   f32x16 oacc[2];
 #pragma unroll
   for (int r = 0; r < 16; ++r) { oacc[0][r] = 0.0f; oacc[1][r] = 0.0f; }
-  float m_run = 0.0f, l_part = 0.0f;
-  const float c2 = 0.125f * 1.44269504088896340736f;
+  float m_run = 0.0f, l_part = 0.0f;                 // m_run in base-2 logit units (q is pre-scaled, common.h)
 
   // Ring protocol: at the top of iteration kt tiles kt and kt+1 are in flight or landed; tile kt+2 is issued into
   // the buffer last read in iteration kt-1 (every wave passed the barrier that ended it).  Each wave issues 4 LDS-DMA
@@ -429,7 +428,7 @@ __global__ __launch_bounds__(SD_NT, 3) void sdpa_fwd_glds_kernel(const __bf16* _
     };
     if (kt == 0) {
       m_run = rowmax();
-      mc = m_run * c2;
+      mc = m_run;
     }
     // four independent partial sums: one 32-deep chain of dependent v_add would sit on the critical path of the tile
     float ps4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -439,14 +438,14 @@ __global__ __launch_bounds__(SD_NT, 3) void sdpa_fwd_glds_kernel(const __bf16* _
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
 #if AS_SDPA_ABLATE == 1
-        const float p = fmaf(sacc[kb][r], c2, -mc) * 1e-3f;
+        const float p = (sacc[kb][r] - mc) * 1e-3f;
         ps4[r & 3] += p;
         fp[kb][r >> 3].set(r & 7, p);
 #elif AS_SDPA_ABLATE == 2
         asm volatile("" :: "v"(sacc[kb][r]));
         fp[kb][r >> 3].set(r & 7, 0.001f);
 #else
-        const float p = __builtin_amdgcn_exp2f(fmaf(sacc[kb][r], c2, -mc));
+        const float p = __builtin_amdgcn_exp2f(sacc[kb][r] - mc);
         ps4[r & 3] += p;
         fp[kb][r >> 3].set(r & 7, p);
 #endif
@@ -454,9 +453,9 @@ __global__ __launch_bounds__(SD_NT, 3) void sdpa_fwd_glds_kernel(const __bf16* _
     float psum = (ps4[0] + ps4[1]) + (ps4[2] + ps4[3]);
     if (__any(!(psum < 1e20f))) {                       // rare: re-reference this wave's rows to the true running max
       const float m_cand = fmaxf(m_run, rowmax());
-      const float alpha = __builtin_amdgcn_exp2f((m_run - m_cand) * c2);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_cand);
       m_run = m_cand;
-      mc = m_cand * c2;
+      mc = m_cand;
       l_part *= alpha;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { oacc[0][r] *= alpha; oacc[1][r] *= alpha; }
@@ -465,7 +464,7 @@ __global__ __launch_bounds__(SD_NT, 3) void sdpa_fwd_glds_kernel(const __bf16* _
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float p = __builtin_amdgcn_exp2f(fmaf(sacc[kb][r], c2, -mc));
+          const float p = __builtin_amdgcn_exp2f(sacc[kb][r] - mc);
           psum += p;
           fp[kb][r >> 3].set(r & 7, p);
         }
@@ -522,7 +521,320 @@ __global__ __launch_bounds__(SD_NT, 3) void sdpa_fwd_glds_kernel(const __bf16* _
         store4(orow + d, oacc[db][4 * g] * inv, oacc[db][4 * g + 1] * inv, oacc[db][4 * g + 2] * inv,
                oacc[db][4 * g + 3] * inv);
       }
-    if (half == 0) lse[(size_t)bh * N + query] = m_run * 0.125f + logf(l);
+    if (half == 0) lse[(size_t)bh * N + query] = m_run * AS_LN2 + logf(l);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// sdpa_fwd_pipe_kernel: the same dataflow (swapped MFMAs, pi key order, LDS-DMA ring, first-tile softmax reference) with
+// the tile loop SOFTWARE-PIPELINED INSIDE EACH WAVE.  sdpa_fwd_glds_kernel runs a tile as four serial phases (K reads ->
+// 8 MFMAs -> ~110 VALU -> V reads -> 8 MFMAs) and relies on the other waves of the SIMD to fill the pipes; the ablation
+//  showed that they do not: every phase costs 18-25 % and none hides under another.  Here the work
+// is cut into UNITS of 32 queries x 32 keys (4 QK MFMAs, 16 scores per lane, 4 PV MFMAs) and one STEP of the loop is
+//     matrix pipe :  S(u+1) = K(u+1) . Q^T      (4 MFMAs)      then      O += V^T(u-1) . P(u-1)     (4 MFMAs)
+//     VALU        :  P(u) = exp2(S(u) * c - m), row sums, bf16 packing                       (independent of both)
+//     LDS         :  V^T fragments of unit u-1 at the top, K fragments of unit u+2 in the middle (half a step ahead)
+// so every MFMA has ~7 independent VALU instructions of another unit to issue under it, in ONE wave.  NQ = 1: a wave
+// owns 32 queries and a tile is two units (key halves), 3 workgroups per CU as before (same grid, same split tail).
+// NQ = 2: a wave owns 64 queries (two query blocks), a tile is four units ordered (key half, query block) so each K / V^T
+// fragment read feeds two MFMAs; 2 workgroups per CU.
+//
+// The LDS-DMA is issued from inline asm, so hipcc sees no vm-counted LDS write and treats the fragment reads as ordinary
+// LDS loads: it places them, counts their lgkmcnt and interleaves them itself (the other kernel has to hide every
+// ds_read in asm).  Ring protocol, ONE barrier per tile: in the middle of the first step of tile kt (after the last LDS
+// read of tile kt-1, before the first of tile kt+1) every wave drains its reads, waits for its own pieces of tile kt+1
+// (the only DMA outstanding), passes the barrier and issues tile kt+2 into the slot of tile kt-1.
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void lds_dma16(const char* gsrc, unsigned lds_dst) {
+  // global_load_lds_dwordx4: 64 lanes x 16 B -> LDS [m0 + lane * 16]; m0 saved / restored in the same statement
+  // (cdna_hip_programming.md 5.7); `lds_dst` must be wave-uniform
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+template <int NQ, bool SPLIT, bool FAST = false>
+__global__ __launch_bounds__(SD_NT, NQ == 1 ? 3 : 2) void sdpa_fwd_pipe_kernel(
+    const __bf16* __restrict__ q, const __bf16* __restrict__ k, const __bf16* __restrict__ vt, __bf16* __restrict__ o,
+    float* __restrict__ lse, int B, int N, int Npad, int h, int qt_fixed, int nslices, float* __restrict__ part) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];     // [3][K tile | V^T tile]
+  constexpr int QROWS = SD_QB * NQ;                               // query rows of a workgroup
+  constexpr int UPT = 2 * NQ;                                     // units per tile
+  constexpr int SLOTB = 2 * GL_TILE;                              // bytes of a ring slot
+  const int BH = B * h;
+  const int bid = blockIdx.x;
+  const int bh = bid % BH, qt = SPLIT ? qt_fixed : bid / BH;
+  const int slice = SPLIT ? bid / BH : 0;
+  const int b = bh / h, head = bh % h;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, half = lane >> 5;
+  const int nkt_all = Npad / SD_KB;
+  const int per = SPLIT ? (nkt_all + nslices - 1) / nslices : nkt_all;
+  const int kt_off = slice * per;
+  const int nkt = min(nkt_all, kt_off + per) - kt_off;            // >= 1 by construction
+  const bool has_ragged = (N % SD_KB) != 0;
+
+  int query[NQ];
+  bf16x8 fq[NQ][4];
+#pragma unroll
+  for (int qb = 0; qb < NQ; ++qb) {
+    query[qb] = qt * QROWS + (wave * NQ + qb) * 32 + li;
+    const int qc = min(query[qb], N - 1);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) fq[qb][ks] = *reinterpret_cast<const bf16x8*>(q + qf_frag((size_t)bh, Npad, qc, ks, half));
+  }
+
+  // loader: per tile each wave moves 2 one-KiB pieces of K and 2 of V^T (8 rows x 128 B each), swizzle on the source
+  const char* pK[2];
+  const char* pV[2];
+  {
+    const int lr = lane >> 3, lc = lane & 7;
+    const int r = wave * 8 + lr;
+    const int key = (r >> 1) & 7;
+    pK[0] = reinterpret_cast<const char*>(k + ((size_t)bh * Npad + r) * HD) + ((lc ^ key) << 4) + (size_t)kt_off * SD_KB * HD * 2;
+    pV[0] = reinterpret_cast<const char*>(vt + ((size_t)bh * HD + r) * Npad) + ((lc ^ key) << 4) + (size_t)kt_off * SD_KB * 2;
+    pK[1] = pK[0] + 32 * HD * 2;
+    pV[1] = pV[0] + (size_t)32 * Npad * 2;
+  }
+  const unsigned smem_base = lds_addr(smem);
+  auto stage = [&](int slot) {                                    // tiles are staged strictly in order
+    const unsigned base = smem_base + slot * SLOTB;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const unsigned piece = (wave + 4 * j) * 1024;
+      lds_dma16(pK[j], base + piece);
+      lds_dma16(pV[j], base + GL_TILE + piece);
+      pK[j] += SD_KB * HD * 2;
+      pV[j] += SD_KB * 2;
+    }
+  };
+  stage(0);
+  if (nkt > 1) stage(1);
+
+  // per-lane fragment addresses (loop invariant): slot, key half and d block are immediates of the reads
+  const char* kptr[4];
+  const char* vptr[4];
+  {
+    const int krow = (li & 0x13) | ((li & 4) << 1) | ((li & 8) >> 1);                  // pi(li): bits 2 and 3 swapped
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) kptr[ks] = smem + krow * 128 + ((((ks << 1) | half) ^ ((krow >> 1) & 7)) << 4);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) vptr[c] = smem + GL_TILE + li * 128 + ((((c << 1) | half) ^ ((li >> 1) & 7)) << 4);
+  }
+  // the slot "before tile 0" feeds the first step's (all-zero) P.V product: its V^T half must hold finite numbers
+  {
+    uint4 z = make_uint4(0, 0, 0, 0);
+    *reinterpret_cast<uint4*>(smem + 2 * SLOTB + GL_TILE + tid * 16) = z;
+    *reinterpret_cast<uint4*>(smem + 2 * SLOTB + GL_TILE + 4096 + tid * 16) = z;
+  }
+  // make hipcc wait for the Q fragments HERE (ordinary loads), not inside the loop
+  asm volatile("; Q fragments landed" : "+v"(fq[0][0]), "+v"(fq[0][1]), "+v"(fq[0][2]), "+v"(fq[0][3]));
+  if (NQ == 2) asm volatile("" : "+v"(fq[NQ - 1][0]), "+v"(fq[NQ - 1][1]), "+v"(fq[NQ - 1][2]), "+v"(fq[NQ - 1][3]));
+  if (nkt > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  // zero the V^T columns of the padded keys of the last tile (P is exactly 0 there, but 0 * garbage must stay 0)
+  auto zero_pad_cols = [&](int slot) {
+    char* Vs = smem + slot * SLOTB + GL_TILE;
+    for (int e = tid; e < HD * SD_KB; e += SD_NT) {
+      const int d = e >> 6, key = e & 63;
+      if ((nkt_all - 1) * SD_KB + key >= N)
+        *reinterpret_cast<__bf16*>(Vs + d * 128 + (((key >> 3) ^ ((d >> 1) & 7)) << 4) + (key & 7) * 2) = (__bf16)0.0f;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+  if (has_ragged && kt_off == nkt_all - 1) zero_pad_cols(0);      // tile 0 of this workgroup is the ragged one
+
+  f32x16 oacc[NQ][2];
+#pragma unroll
+  for (int qb = 0; qb < NQ; ++qb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { oacc[qb][0][r] = 0.0f; oacc[qb][1][r] = 0.0f; }
+  float m_run[NQ], mc[NQ], l_part[NQ], lp4[NQ][4];
+#pragma unroll
+  for (int qb = 0; qb < NQ; ++qb) {
+    m_run[qb] = 0.0f; mc[qb] = 0.0f; l_part[qb] = 0.0f;
+    lp4[qb][0] = lp4[qb][1] = lp4[qb][2] = lp4[qb][3] = 0.0f;
+  }
+
+  auto load_k = [&](bf16x8 (&kf)[4], auto off_c) {                 // K fragments of one 32-key block: 4 x 16 B
+    constexpr int OFF = decltype(off_c)::value;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) kf[ks] = *reinterpret_cast<const bf16x8*>(kptr[ks] + OFF);
+  };
+  auto rowmax16 = [&](const f32x16& s) {
+    float m = s[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) m = fmaxf(m, s[r]);
+    return fmaxf(m, __shfl_xor(m, 32));
+  };
+  auto mask_ragged = [&](f32x16& s, int kb) {                      // keys >= N of the last tile -> -inf
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      if ((nkt_all - 1) * SD_KB + kb * 32 + 16 * (r >> 3) + 8 * half + (r & 7) >= N) s[r] = -INFINITY;
+  };
+
+  // pipeline state: scores of the current unit, K fragments for the next one, P of the previous one
+  f32x16 s_cur;
+  bf16x8 kf[4], vf[4], p_prev[2];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {                                   // the first step's P.V product is 0 x 0
+    p_prev[0][t] = (__bf16)0.0f; p_prev[1][t] = (__bf16)0.0f;
+    vf[0][t] = (__bf16)0.0f; vf[1][t] = (__bf16)0.0f; vf[2][t] = (__bf16)0.0f; vf[3][t] = (__bf16)0.0f;
+  }
+  {
+    const f32x16 zero = {0};
+    load_k(kf, std::integral_constant<int, 0>{});
+    s_cur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], fq[0][0], zero, 0, 0, 0);
+#pragma unroll
+    for (int ks = 1; ks < 4; ++ks) s_cur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], fq[0][ks], s_cur, 0, 0, 0);
+    if (NQ == 1) load_k(kf, std::integral_constant<int, 32 * 128>{});     // unit 1 = key half 1 (NQ = 2: same K, block 1)
+  }
+
+  for (int kt0 = 0; kt0 < nkt; kt0 += GL_NBUF) {
+   static_for<GL_NBUF>([&](auto slot_c) {
+    constexpr int SLOT = decltype(slot_c)::value;
+    const int kt = kt0 + SLOT;
+    if (kt >= nkt) return;
+    const int ktg = kt_off + kt;
+    const bool ragged = has_ragged && ktg == nkt_all - 1;
+    static_for<UPT>([&](auto i_c) {
+      constexpr int I = decltype(i_c)::value;
+      constexpr int KB = I / NQ, QB = I % NQ;
+      constexpr int IN = (I + 1) % UPT, QBN = IN % NQ;                                        // next unit
+      constexpr int IP = (I + UPT - 1) % UPT, KBP = IP / NQ, QBP = IP % NQ;                    // previous unit
+      constexpr int P_SLOT = I >= 1 ? SLOT : (SLOT + 2) % GL_NBUF;
+      constexpr int INN = (I + 2) % UPT, KBNN = INN / NQ, QBNN = INN % NQ;                     // the unit after the next
+      constexpr int NN_SLOT = I + 2 < UPT ? SLOT : (SLOT + 1) % GL_NBUF;
+      const f32x16 zero = {0};
+
+      // softmax reference of a query block = row max of its FIRST unit (see sdpa_fwd_glds_kernel)
+      if (!FAST && SLOT == 0 && I < NQ && kt == 0) {
+        if (ragged) mask_ragged(s_cur, KB);
+        m_run[QB] = rowmax16(s_cur);
+        mc[QB] = m_run[QB];
+      } else if (ragged) {
+        mask_ragged(s_cur, KB);
+      }
+
+      // ---- first half: V^T fragments of the previous unit; S(next) = K . Q^T; exp2 of this unit under the MFMAs ----
+      if (QBP == 0) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)            // (d block c >> 1, 16-key step c & 1) of key half KBP
+          vf[c] = *reinterpret_cast<const bf16x8*>(vptr[2 * KBP + (c & 1)] + P_SLOT * SLOTB + (c >> 1) * 32 * 128);
+      }
+      f32x16 s_next = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], fq[QBN][0], zero, 0, 0, 0);
+#pragma unroll
+      for (int ks = 1; ks < 4; ++ks) s_next = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], fq[QBN][ks], s_next, 0, 0, 0);
+
+      float p[16];
+      float ps[4];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if (FAST) {
+          p[r] = __builtin_amdgcn_exp2f(s_cur[r]);
+          lp4[QB][r & 3] += p[r];
+        } else {
+          p[r] = __builtin_amdgcn_exp2f(s_cur[r] - mc[QB]);
+          ps[r & 3] = r < 4 ? p[r] : ps[r & 3] + p[r];
+        }
+      }
+      bf16x8 p_cur[2];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) p_cur[r >> 3][r & 7] = (__bf16)p[r];
+
+      if (I == 0) {
+        // ---- ring hand-over (one barrier per tile) ----
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // my reads of tile kt-1 are done
+        if (kt + 1 < nkt) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // my pieces of tile kt+1 have landed
+          __builtin_amdgcn_s_barrier();
+          asm volatile("" ::: "memory");
+          if (kt + 2 < nkt) stage((SLOT + 2) % GL_NBUF);
+          if (has_ragged && ktg + 1 == nkt_all - 1) zero_pad_cols((SLOT + 1) % GL_NBUF);
+        }
+      }
+
+      // ---- second half: K fragments two units ahead; O += V^T . P of the previous unit ----
+      if (QBNN == 0) load_k(kf, std::integral_constant<int, NN_SLOT * SLOTB + KBNN * 32 * 128>{});
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        oacc[QBP][c >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[c], p_prev[c & 1], oacc[QBP][c >> 1], 0, 0, 0);
+
+      float psum = FAST ? 0.0f : (ps[0] + ps[1]) + (ps[2] + ps[3]);
+      if (!FAST && __any(!(psum < 1e20f))) {                        // rare: re-reference this wave's rows to the true running max
+        const float m_cand = fmaxf(m_run[QB], rowmax16(s_cur));
+        const float alpha = __builtin_amdgcn_exp2f(m_run[QB] - m_cand);
+        m_run[QB] = m_cand;
+        mc[QB] = m_cand;
+        l_part[QB] *= alpha;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { oacc[QB][0][r] *= alpha; oacc[QB][1][r] *= alpha; }
+        psum = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float pr = __builtin_amdgcn_exp2f(s_cur[r] - mc[QB]);
+          psum += pr;
+          p_cur[r >> 3][r & 7] = (__bf16)pr;
+        }
+      }
+      l_part[QB] += psum;
+      // without the rare-path branch a step is no longer its own basic block: keep hipcc from merging the steps'
+      // schedules (it stretches live ranges across steps and spills at NQ = 2)
+      if (FAST) __builtin_amdgcn_sched_barrier(0);
+      s_cur = s_next;
+      p_prev[0] = p_cur[0];
+      p_prev[1] = p_cur[1];
+    });
+   });
+  }
+  // drain: P.V of the last unit (its V^T fragments: key half 1 of the last tile)
+  {
+    constexpr int QBL = NQ - 1;
+    const int last_slot = (nkt - 1) % GL_NBUF;
+    if (NQ == 1) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        vf[c] = *reinterpret_cast<const bf16x8*>(vptr[2 + (c & 1)] + last_slot * SLOTB + (c >> 1) * 32 * 128);
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      oacc[QBL][c >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[c], p_prev[c & 1], oacc[QBL][c >> 1], 0, 0, 0);
+  }
+
+#pragma unroll
+  for (int qb = 0; qb < NQ; ++qb) {
+    if (FAST) l_part[qb] = (lp4[qb][0] + lp4[qb][1]) + (lp4[qb][2] + lp4[qb][3]);
+    const float l = l_part[qb] + __shfl_xor(l_part[qb], 32);
+    if (SPLIT) {
+      float* rec = part + (((size_t)bh * nslices + slice) * QROWS + (wave * NQ + qb) * 32 + li) * SD_REC;
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<float4*>(rec + db * 32 + 8 * g + 4 * half) =
+              make_float4(oacc[qb][db][4 * g], oacc[qb][db][4 * g + 1], oacc[qb][db][4 * g + 2], oacc[qb][db][4 * g + 3]);
+      if (half == 0) { rec[64] = m_run[qb]; rec[65] = l; }
+      continue;
+    }
+    const float inv = 1.0f / l;
+    if (query[qb] < N) {
+      __bf16* orow = o + ((size_t)b * N + query[qb]) * ((size_t)h * HD) + head * HD;
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int d = db * 32 + 8 * g + 4 * half;
+          store4(orow + d, oacc[qb][db][4 * g] * inv, oacc[qb][db][4 * g + 1] * inv, oacc[qb][db][4 * g + 2] * inv,
+                 oacc[qb][db][4 * g + 3] * inv);
+        }
+      if (half == 0) lse[(size_t)bh * N + query[qb]] = m_run[qb] * AS_LN2 + logf(l);
+    }
   }
 }
 
@@ -534,7 +846,6 @@ __global__ __launch_bounds__(256) void sdpa_combine_kernel(const float* __restri
   const int row = blockIdx.x * 16 + (threadIdx.x >> 4), dg = threadIdx.x & 15;
   const int query = qt * SD_QB + row;
   if (query >= N) return;
-  const float c2 = 0.125f * 1.44269504088896340736f;
   const float* base = part + ((size_t)bh * nslices * SD_QB + row) * SD_REC;
   const size_t step = (size_t)SD_QB * SD_REC;
   float m = -INFINITY;
@@ -542,14 +853,14 @@ __global__ __launch_bounds__(256) void sdpa_combine_kernel(const float* __restri
   float l = 0.0f, a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
   for (int s = 0; s < nslices; ++s) {
     const float* r = base + s * step;
-    const float sc = __builtin_amdgcn_exp2f((r[64] - m) * c2);
+    const float sc = __builtin_amdgcn_exp2f(r[64] - m);
     const float4 v = *reinterpret_cast<const float4*>(r + dg * 4);
     l += r[65] * sc;
     a0 += v.x * sc; a1 += v.y * sc; a2 += v.z * sc; a3 += v.w * sc;
   }
   const float inv = 1.0f / l;
   store4(o + ((size_t)b * N + query) * ((size_t)h * HD) + head * HD + dg * 4, a0 * inv, a1 * inv, a2 * inv, a3 * inv);
-  if (dg == 0) lse[(size_t)bh * N + query] = m * 0.125f + logf(l);
+  if (dg == 0) lse[(size_t)bh * N + query] = m * AS_LN2 + logf(l);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -560,6 +871,12 @@ __global__ __launch_bounds__(256) void sdpa_combine_kernel(const float* __restri
 // same kernel in SPLIT mode -- (image*head) x 11 key slices = 264 short workgroups that still share K/V tiles through
 // the LDS ring -- followed by a tiny merge of the 11 partial (max, sum, O) records per row (fixed order).
 // ---------------------------------------------------------------------------------------------------------
+// AS_SDPA_IMPL (development knob, read per call): 0 = sdpa_fwd_glds_kernel, 1 = sdpa_fwd_pipe_kernel<1>, 2 = <2>
+int sdpa_impl() {
+  const char* e = getenv("AS_SDPA_IMPL");
+  return e ? atoi(e) : 1;
+}
+
 int sdpa_slots() {                                    // resident workgroups of sdpa_fwd_glds_kernel: 3 per CU
   static int slots = 0;                               // read-only device-properties cache
   if (slots == 0) {
@@ -616,7 +933,31 @@ int launch_sdpa_glds(const void* q, const void* k, const void* vt, void* o, floa
   if (concurrent) {
     if (hipEventRecord(side.fork, s) != hipSuccess || hipStreamWaitEvent(side.st, side.fork, 0) != hipSuccess) s2 = s;
   }
+  const int impl = sdpa_impl();
+  if (impl == 2 || impl == 4) {                              // 64 queries per wave, 256 per workgroup, no split tail
+    if (impl == 2)
+      hipLaunchKernelGGL((sdpa_fwd_pipe_kernel<2, false>), dim3(as_ceil_div(N, 2 * SD_QB) * BH), dim3(SD_NT), lds, s,
+                         (const __bf16*)q, (const __bf16*)k, (const __bf16*)vt, (__bf16*)o, lse, B, N, Npad, h, 0, 1,
+                         (float*)nullptr);
+    else
+      hipLaunchKernelGGL((sdpa_fwd_pipe_kernel<2, false, true>), dim3(as_ceil_div(N, 2 * SD_QB) * BH), dim3(SD_NT), lds, s,
+                         (const __bf16*)q, (const __bf16*)k, (const __bf16*)vt, (__bf16*)o, lse, B, N, Npad, h, 0, 1,
+                         (float*)nullptr);
+    AS_CHECK_LAUNCH("sdpa_fwd_pipe<2>");
+    return AS_OK;
+  }
+  if (impl == 3) {                                           // prototype: reference-free NQ = 1 on the plain grid
+    hipLaunchKernelGGL((sdpa_fwd_pipe_kernel<1, false, true>), dim3(as_ceil_div(N, SD_QB) * BH), dim3(SD_NT), lds, s,
+                       (const __bf16*)q, (const __bf16*)k, (const __bf16*)vt, (__bf16*)o, lse, B, N, Npad, h, 0, 1,
+                       (float*)nullptr);
+    AS_CHECK_LAUNCH("sdpa_fwd_pipe<1,fast>");
+    return AS_OK;
+  }
   if (ns > 0) {
+    if (impl == 1)
+      hipLaunchKernelGGL((sdpa_fwd_pipe_kernel<1, true>), dim3(ns * BH), dim3(SD_NT), lds, s2, (const __bf16*)q,
+                         (const __bf16*)k, (const __bf16*)vt, (__bf16*)o, lse, B, N, Npad, h, qtiles, ns, (float*)ws);
+    else
     hipLaunchKernelGGL(sdpa_fwd_glds_kernel<true>, dim3(ns * BH), dim3(SD_NT), lds, s2, (const __bf16*)q, (const __bf16*)k,
                        (const __bf16*)vt, (__bf16*)o, lse, B, N, Npad, h, qtiles, ns, (float*)ws);
     AS_CHECK_LAUNCH("sdpa_fwd_glds<split>");
@@ -626,6 +967,10 @@ int launch_sdpa_glds(const void* q, const void* k, const void* vt, void* o, floa
     if (s2 != s) (void)hipEventRecord(side.join, s2);
   }
   if (qtiles > 0) {
+    if (impl == 1)
+      hipLaunchKernelGGL((sdpa_fwd_pipe_kernel<1, false>), dim3(qtiles * BH), dim3(SD_NT), lds, s, (const __bf16*)q,
+                         (const __bf16*)k, (const __bf16*)vt, (__bf16*)o, lse, B, N, Npad, h, 0, 1, (float*)nullptr);
+    else
     hipLaunchKernelGGL(sdpa_fwd_glds_kernel<false>, dim3(qtiles * BH), dim3(SD_NT), lds, s, (const __bf16*)q,
                        (const __bf16*)k, (const __bf16*)vt, (__bf16*)o, lse, B, N, Npad, h, 0, 1, (float*)nullptr);
     AS_CHECK_LAUNCH("sdpa_fwd_glds");

@@ -177,7 +177,6 @@ __global__ __launch_bounds__(BW_NT, sizeof(T) == 2 ? 2 : 1) void sdpa_bwd_dq_ker
   }
   const float lse2 = lse[(size_t)bh * N + qc] * 1.44269504088896340736f;
   const float dl = delta[(size_t)bh * Npad + qc];
-  const float c2 = 0.125f * 1.44269504088896340736f;
 
   const char* ksrc = reinterpret_cast<const char*>(k + (size_t)bh * Npad * BW_HD);
   const char* vsrc = reinterpret_cast<const char*>(vrow + (size_t)bh * Npad * BW_HD);
@@ -232,7 +231,7 @@ __global__ __launch_bounds__(BW_NT, sizeof(T) == 2 ? 2 : 1) void sdpa_bwd_dq_ker
       const bool ragged = (t + 1) * BW_TILE > N;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float p = __builtin_amdgcn_exp2f(fmaf(sacc[r], c2, -lse2));
+        const float p = __builtin_amdgcn_exp2f(sacc[r] - lse2);     // q pre-scaled (common.h): base-2 logits
         float ds = p * (pacc[r] - dl);                  // the softmax scale 1/8 is applied once, to the accumulators
         if (ragged && t * BW_TILE + kb * 32 + pi_acc_row(r, half) >= N) ds = 0.0f;   // padded key rows hold garbage
         fds[kb][r >> 3].set(r & 7, ds);
@@ -301,7 +300,6 @@ __global__ __launch_bounds__(BW_NT, sizeof(T) == 2 ? 2 : 1) void sdpa_bwd_dkv_ke
     fk[ks].load16B(k + ((size_t)bh * Npad + kc) * BW_HD + ks * 16 + half * 8);
     fv[ks].load16B(vrow + ((size_t)bh * Npad + kc) * BW_HD + ks * 16 + half * 8);
   }
-  const float c2 = 0.125f * 1.44269504088896340736f;
 
   const char* qsrc = reinterpret_cast<const char*>(q + (size_t)bh * Npad * BW_HD);
   const char* dosrc = reinterpret_cast<const char*>(dof + (size_t)bh * Npad * BW_HD);
@@ -380,8 +378,8 @@ __global__ __launch_bounds__(BW_NT, sizeof(T) == 2 ? 2 : 1) void sdpa_bwd_dkv_ke
 #pragma unroll
         for (int t8 = 0; t8 < 8; ++t8) {
           const int r = s2 * 8 + t8;
-          float p = __builtin_amdgcn_exp2f(fmaf(sacc[r], c2, -lv[t8]));
-          float ds = p * (pacc[r] - dv[t8]);            // scale 1/8 applied once to the dK accumulators
+          float p = __builtin_amdgcn_exp2f(sacc[r] - lv[t8]);        // q pre-scaled (common.h): base-2 logits
+          float ds = p * (pacc[r] - dv[t8]);            // scale applied once to the dK accumulators
           if (ragged && t * BW_TILE + q0 + t8 >= N) { p = 0.0f; ds = 0.0f; }   // padded query rows hold garbage
           fp[qb][s2].set(t8, p);
           fds[qb][s2].set(t8, ds);
@@ -414,8 +412,9 @@ __global__ __launch_bounds__(BW_NT, sizeof(T) == 2 ? 2 : 1) void sdpa_bwd_dkv_ke
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int d = db * 32 + 8 * g + 4 * half;
-        st4(row + D + d, dkacc[db][4 * g] * 0.125f, dkacc[db][4 * g + 1] * 0.125f, dkacc[db][4 * g + 2] * 0.125f,
-            dkacc[db][4 * g + 3] * 0.125f);
+        // dK = dS^T q / 8 with the STORED q' = q log2(e) / 8: dS^T q' ln 2
+        st4(row + D + d, dkacc[db][4 * g] * AS_LN2, dkacc[db][4 * g + 1] * AS_LN2, dkacc[db][4 * g + 2] * AS_LN2,
+            dkacc[db][4 * g + 3] * AS_LN2);
         st4(row + 2 * D + d, dvacc[db][4 * g], dvacc[db][4 * g + 1], dvacc[db][4 * g + 2], dvacc[db][4 * g + 3]);
       }
   }

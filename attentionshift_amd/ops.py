@@ -247,8 +247,15 @@ def attention_bwd(x, w_qkv, w_proj, dout, state, want_bias=(True, True)):
     return dx, dwqkv, dbqkv, dwproj, dbproj
 
 
+# as_qkv_fwd stores q PRE-SCALED by log2(e) / sqrt(64) (rounded once from the fp32 accumulator, csrc/common.h): the
+# scores q' . k of every consumer are base-2 logits.  Hand-built q workspaces must carry the same factor.
+QSCALE = 0.125 * 1.4426950408889634
+LN2 = 0.6931471805599453
+
+
 def q_to_fragment_major(q_rows):
-    """[B,h,Npad,64] row-major -> the fragment-major tile layout as_qkv_fwd writes (include/attnshift.h)."""
+    """[B,h,Npad,64] row-major -> the fragment-major tile layout as_qkv_fwd writes (include/attnshift.h).  Layout only:
+    the VALUES must already be q * QSCALE."""
     B, h, Np_, d = q_rows.shape
     t = q_rows.reshape(B, h, Np_ // 32, 32, 4, 2, 8)            # [.., tile, r, ks, half, e]
     return t.permute(0, 1, 2, 4, 5, 3, 6).contiguous().reshape(B, h, Np_, d)

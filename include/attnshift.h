@@ -68,12 +68,16 @@ int as_deconv2x2_fwd(const void* x, const void* W4, const float* bias4, void* ou
 /* QKV projection with the head split fused into the epilogue (vision_transformer.py:75-77):
  *   k : [B,h,Npad,64]   vt : [B,h,64,Npad]  (V transposed so the P.V MFMA reads keys contiguously)
  *   q : [B,h,Npad,64] elements, FRAGMENT-MAJOR inside every 32-row x 64-d tile: element (r, d) of a tile sits at
- *       ((d/16)*64 + r + 32*((d%16)/8))*8 + d%8, so the MFMA operand loads of sdpa / roll-out are coalesced
+ *       ((d/16)*64 + r + 32*((d%16)/8))*8 + d%8, so the MFMA operand loads of sdpa / roll-out are coalesced.
+ *       VALUES are pre-scaled: q holds (x Wq^T + bq) * log2(e) / sqrt(64), rounded once from the fp32 accumulator, so
+ *       that q . k is the base-2 logit every consumer (as_sdpa_fwd / _bwd, as_rollout_*, as_attn_mean_rows) feeds to
+ *       exp2 without a multiply per score.  A caller that fills q by hand applies the same factor.
  * rows/cols >= N of the padded layouts are never read unmasked, so they need no initialisation. */
 int as_qkv_fwd(const void* x /*[B,N,D]*/, const void* Wqkv /*[3D,D]*/, const float* bqkv /*[3D] or NULL*/,
                void* q, void* k, void* vt, int B, int N, int D, int h, int dtype, as_stream_t stream);
 
 /* softmax(q k^T / sqrt(64)) v without materialising [h,N,N] (vision_transformer.py:79-83).
+ *   q is the PRE-SCALED fragment-major workspace of as_qkv_fwd (see there): softmax(q' k^T ln 2) = softmax(q k^T / 8).
  *   o   : [B,N,h*64] (heads concatenated, ready for proj)        lse : [B,h,N] fp32, natural log
  *   workspace : optional, as_sdpa_fwd_workspace_bytes(...) bytes (0 for most shapes): lets the launch split the keys
  *               of the last q-tile over extra workgroups when the plain grid would leave a short second round

@@ -88,7 +88,8 @@ def test_qkv_layout(ops, dtype):
     ref = torch.nn.functional.linear(x.float(), w.float(), b).reshape(B, N, 3, h, 64).permute(2, 0, 3, 1, 4)
     q, k, vt = ops.qkv_fwd(dev(x), dev(w), dev(b), h)
     tol = 1e-4 if dtype == torch.float32 else 2e-2
-    assert_close(ref[0], ops.q_from_fragment_major(q)[:, :, :N].float(), tol, tol, "q (fragment-major workspace)")
+    # q is stored pre-scaled by log2(e) / 8 (one rounding, from the fp32 accumulator)
+    assert_close(ref[0] * ops.QSCALE, ops.q_from_fragment_major(q)[:, :, :N].float(), tol, tol, "q (fragment-major, pre-scaled)")
     assert_close(ref[1], k[:, :, :N].float(), tol, tol, "k")
     assert_close(ref[2].transpose(-1, -2), vt[:, :, :, :N].float(), tol, tol, "v^T")
 
@@ -141,9 +142,10 @@ def test_sdpa_spike_row_forces_rescale(ops):
     k[0, 0, 650] = q[0, 0, 5] * 4.0        # huge logit for query 5 at the 11th KV tile
     Np_ = ops.npad(N)
     qp = torch.zeros(B, h, Np_, 64); kp = torch.zeros(B, h, Np_, 64); vtp = torch.zeros(B, h, 64, Np_)
-    qp[:, :, :N], kp[:, :, :N], vtp[:, :, :, :N] = q, k, v.transpose(-1, -2)
+    qs = q * ops.QSCALE                    # the stored, pre-scaled q'; the reference uses exactly these values
+    qp[:, :, :N], kp[:, :, :N], vtp[:, :, :, :N] = qs, k, v.transpose(-1, -2)
     o, lse = ops.sdpa_fwd(ops.q_to_fragment_major(dev(qp)), dev(kp), dev(vtp), N)
-    p = ((q @ k.transpose(-1, -2)) * 0.125).softmax(-1)
+    p = ((qs @ k.transpose(-1, -2)) * ops.LN2).softmax(-1)
     ref = (p @ v).transpose(1, 2).reshape(B, N, 64)
     mx, _ = rel_to_range(ref, o)
     assert mx < 1e-4, mx
@@ -163,14 +165,14 @@ def test_sdpa_bf16_deferred_max_and_spikes(ops, monkeypatch, tail, N):
         qi, ki = qi % N, ki % N
         k[0, 0, ki] = q[0, 0, qi] * s / 8.0
         k[0, 1, ki] = q[0, 1, qi] * s / 8.0
-    qb, kb, vb = q.bfloat16(), k.bfloat16(), v.bfloat16()
+    qb, kb, vb = (q * ops.QSCALE).bfloat16(), k.bfloat16(), v.bfloat16()     # qb = the stored, pre-scaled q'
     Np_ = ops.npad(N)
     qp = torch.zeros(B, h, Np_, 64, dtype=torch.bfloat16); kp = torch.zeros_like(qp)
     vtp = torch.full((B, h, 64, Np_), float("nan"), dtype=torch.bfloat16)        # padded keys hold garbage on purpose
     qp[:, :, :N], kp[:, :, :N], vtp[:, :, :, :N] = qb, kb, vb.transpose(-1, -2)
     kp[:, :, N:] = float("nan")
     o, lse = ops.sdpa_fwd(ops.q_to_fragment_major(dev(qp)), dev(kp), dev(vtp), N)
-    s_ = (qb.float() @ kb.float().transpose(-1, -2)) * 0.125
+    s_ = (qb.float() @ kb.float().transpose(-1, -2)) * ops.LN2
     ref = (s_.softmax(-1) @ vb.float()).transpose(1, 2).reshape(B, N, h * 64)
     mx, mean = rel_to_range(ref, o.float())
     assert mx < 2e-2 and mean < 3e-3, (mx, mean)
@@ -227,10 +229,10 @@ def test_sdpa_bwd_matches_autograd(ops, dtype, tol, B, N, h):
     q, k, v = (torch.randn(B, h, N, 64, generator=g) for _ in range(3))
     q = q * 1.5
     d_o = torch.randn(B, N, h * 64, generator=g)
-    qd, kd, vd, dod = q.to(dtype), k.to(dtype), v.to(dtype), d_o.to(dtype)
-    # fp64 autograd reference on the rounded operands
+    qd, kd, vd, dod = (q * ops.QSCALE).to(dtype), k.to(dtype), v.to(dtype), d_o.to(dtype)     # qd = the stored q'
+    # fp64 autograd reference on the rounded operands; the gradient is taken w.r.t. the UNSCALED q = q' / QSCALE
     with torch.enable_grad():
-        q64, k64, v64 = (t.double().requires_grad_(True) for t in (qd, kd, vd))
+        q64, k64, v64 = (t.double().requires_grad_(True) for t in (qd.double() / ops.QSCALE, kd, vd))
         o64 = (torch.softmax(q64 @ k64.transpose(-1, -2) * 0.125, -1) @ v64).transpose(1, 2).reshape(B, N, h * 64)
         o64.backward(dod.double())
     ref = torch.stack([q64.grad, k64.grad, v64.grad], 0).permute(1, 3, 0, 2, 4).reshape(B, N, 3 * h * 64).float()
@@ -275,7 +277,7 @@ def test_sdpa_bwd_full_size_properties(ops):
     assert (colsum - N).abs().max().item() < 0.02 * N, (colsum.min().item(), colsum.max().item())
     # <q, dq> = <k, dk> per (image, head): both equal scale * sum_ij dS_ij S_ij (random dO run)
     gq = g1.float().reshape(B, N, 3, h, 64)
-    qr = ops.q_from_fragment_major(q)[:, :, :N].float()               # [B, h, N, 64]
+    qr = ops.q_from_fragment_major(q)[:, :, :N].float() / ops.QSCALE  # [B, h, N, 64]; the workspace holds q * QSCALE
     kr = k[:, :, :N].float()
     lhs = (qr * gq[:, :, 0].permute(0, 2, 1, 3)).sum(dim=(2, 3))
     rhs = (kr * gq[:, :, 1].permute(0, 2, 1, 3)).sum(dim=(2, 3))
