@@ -545,15 +545,22 @@ __global__ __launch_bounds__(SD_NT, 3) void sdpa_fwd_glds_kernel(const __bf16* _
 // read of tile kt-1, before the first of tile kt+1) every wave drains its reads, waits for its own pieces of tile kt+1
 // (the only DMA outstanding), passes the barrier and issues tile kt+2 into the slot of tile kt-1.
 // ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void lds_dma16(const char* gsrc, unsigned lds_dst) {
-  // global_load_lds_dwordx4: 64 lanes x 16 B -> LDS [m0 + lane * 16]; m0 saved / restored in the same statement
-  // (cdna_hip_programming.md 5.7); `lds_dst` must be wave-uniform
+__device__ __forceinline__ void lds_dma16(unsigned voff, const char* sbase, unsigned lds_dst) {
+  // global_load_lds_dwordx4, saddr form: 64 lanes x 16 B from sbase + voff[lane] -> LDS [m0 + lane * 16]; m0 is saved
+  // and restored in the same statement (cdna_hip_programming.md 5.7).  `sbase` and `lds_dst` must be wave-uniform.
   unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
 }
 
-template <int NQ, bool SPLIT, bool FAST = false>
+// MODE 0: softmax referenced to the row max of a query block's first unit, re-referenced when a unit sum leaves 1e20
+//         (exactly sdpa_fwd_glds_kernel's arithmetic).
+// MODE 1: reference-free first pass -- q is pre-scaled, so the MFMA output IS the base-2 logit and P = exp2(S) needs no
+//         per-score subtraction: 16 exp2 + 16 adds + 8 packs per unit.  Any fixed reference gives the same softmax as
+//         long as nothing leaves the fp32 range; a row whose sum ends outside [1e-30, 1e30] (logits beyond +-87 in
+//         natural units: not something LayerNorm-ed ViT tokens produce, but legal input) makes the WORKGROUP run the
+//         MODE 0 pass over its keys again.  Tested with spiked rows (tests/test_gpu_kernels.py).
+template <int NQ, bool SPLIT, int MODE>
 __global__ __launch_bounds__(SD_NT, NQ == 1 ? 3 : 2) void sdpa_fwd_pipe_kernel(
     const __bf16* __restrict__ q, const __bf16* __restrict__ k, const __bf16* __restrict__ vt, __bf16* __restrict__ o,
     float* __restrict__ lse, int B, int N, int Npad, int h, int qt_fixed, int nslices, float* __restrict__ part) {
@@ -585,32 +592,21 @@ __global__ __launch_bounds__(SD_NT, NQ == 1 ? 3 : 2) void sdpa_fwd_pipe_kernel(
     for (int ks = 0; ks < 4; ++ks) fq[qb][ks] = *reinterpret_cast<const bf16x8*>(q + qf_frag((size_t)bh, Npad, qc, ks, half));
   }
 
-  // loader: per tile each wave moves 2 one-KiB pieces of K and 2 of V^T (8 rows x 128 B each), swizzle on the source
-  const char* pK[2];
-  const char* pV[2];
+  // loader: per tile each wave moves 2 one-KiB pieces of K and 2 of V^T (8 rows x 128 B each); the bank swizzle sits on
+  // the source address.  Per-lane 32-bit offsets + a scalar tile base (advanced by one tile per stage() call).
+  unsigned offK[2], offV[2];
   {
     const int lr = lane >> 3, lc = lane & 7;
     const int r = wave * 8 + lr;
     const int key = (r >> 1) & 7;
-    pK[0] = reinterpret_cast<const char*>(k + ((size_t)bh * Npad + r) * HD) + ((lc ^ key) << 4) + (size_t)kt_off * SD_KB * HD * 2;
-    pV[0] = reinterpret_cast<const char*>(vt + ((size_t)bh * HD + r) * Npad) + ((lc ^ key) << 4) + (size_t)kt_off * SD_KB * 2;
-    pK[1] = pK[0] + 32 * HD * 2;
-    pV[1] = pV[0] + (size_t)32 * Npad * 2;
+    offK[0] = r * (HD * 2) + ((lc ^ key) << 4);
+    offK[1] = offK[0] + 32 * HD * 2;
+    offV[0] = r * (Npad * 2) + ((lc ^ key) << 4);
+    offV[1] = offV[0] + 32 * Npad * 2;
   }
+  const char* const k_first = reinterpret_cast<const char*>(k + ((size_t)bh * Npad + (size_t)kt_off * SD_KB) * HD);
+  const char* const v_first = reinterpret_cast<const char*>(vt + (size_t)bh * HD * Npad + (size_t)kt_off * SD_KB);
   const unsigned smem_base = lds_addr(smem);
-  auto stage = [&](int slot) {                                    // tiles are staged strictly in order
-    const unsigned base = smem_base + slot * SLOTB;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const unsigned piece = (wave + 4 * j) * 1024;
-      lds_dma16(pK[j], base + piece);
-      lds_dma16(pV[j], base + GL_TILE + piece);
-      pK[j] += SD_KB * HD * 2;
-      pV[j] += SD_KB * 2;
-    }
-  };
-  stage(0);
-  if (nkt > 1) stage(1);
 
   // per-lane fragment addresses (loop invariant): slot, key half and d block are immediates of the reads
   const char* kptr[4];
@@ -622,46 +618,35 @@ __global__ __launch_bounds__(SD_NT, NQ == 1 ? 3 : 2) void sdpa_fwd_pipe_kernel(
 #pragma unroll
     for (int c = 0; c < 4; ++c) vptr[c] = smem + GL_TILE + li * 128 + ((((c << 1) | half) ^ ((li >> 1) & 7)) << 4);
   }
-  // the slot "before tile 0" feeds the first step's (all-zero) P.V product: its V^T half must hold finite numbers
-  {
-    uint4 z = make_uint4(0, 0, 0, 0);
-    *reinterpret_cast<uint4*>(smem + 2 * SLOTB + GL_TILE + tid * 16) = z;
-    *reinterpret_cast<uint4*>(smem + 2 * SLOTB + GL_TILE + 4096 + tid * 16) = z;
-  }
   // make hipcc wait for the Q fragments HERE (ordinary loads), not inside the loop
-  asm volatile("; Q fragments landed" : "+v"(fq[0][0]), "+v"(fq[0][1]), "+v"(fq[0][2]), "+v"(fq[0][3]));
-  if (NQ == 2) asm volatile("" : "+v"(fq[NQ - 1][0]), "+v"(fq[NQ - 1][1]), "+v"(fq[NQ - 1][2]), "+v"(fq[NQ - 1][3]));
-  if (nkt > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
+#pragma unroll
+  for (int qb = 0; qb < NQ; ++qb) asm volatile("; Q fragments landed" : "+v"(fq[qb][0]), "+v"(fq[qb][1]), "+v"(fq[qb][2]), "+v"(fq[qb][3]));
 
-  // zero the V^T columns of the padded keys of the last tile (P is exactly 0 there, but 0 * garbage must stay 0)
-  auto zero_pad_cols = [&](int slot) {
-    char* Vs = smem + slot * SLOTB + GL_TILE;
-    for (int e = tid; e < HD * SD_KB; e += SD_NT) {
-      const int d = e >> 6, key = e & 63;
-      if ((nkt_all - 1) * SD_KB + key >= N)
-        *reinterpret_cast<__bf16*>(Vs + d * 128 + (((key >> 3) ^ ((d >> 1) & 7)) << 4) + (key & 7) * 2) = (__bf16)0.0f;
-    }
+  auto ring_barrier = [&]() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
   };
-  if (has_ragged && kt_off == nkt_all - 1) zero_pad_cols(0);      // tile 0 of this workgroup is the ragged one
-
-  f32x16 oacc[NQ][2];
+  // zero the V^T columns of the padded keys of the LAST tile (P is exactly 0 there, but 0 * garbage must stay 0):
+  // thread = (d row, 16-key group); followed by a barrier
+  auto zero_pad_cols = [&](int slot) {
+    const int nv = N - (nkt_all - 1) * SD_KB;                     // valid keys of the last tile, 1 .. 63
+    char* Vs = smem + slot * SLOTB + GL_TILE;
+    const int d = tid >> 2;
 #pragma unroll
-  for (int qb = 0; qb < NQ; ++qb)
+    for (int cc = 0; cc < 2; ++cc) {
+      const int c = (tid & 3) * 2 + cc;
+      if (8 * c + 8 > nv) {
+        bf16x8* pch = reinterpret_cast<bf16x8*>(Vs + d * 128 + ((c ^ ((d >> 1) & 7)) << 4));
+        bf16x8 v = *pch;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { oacc[qb][0][r] = 0.0f; oacc[qb][1][r] = 0.0f; }
-  float m_run[NQ], mc[NQ], l_part[NQ], lp4[NQ][4];
-#pragma unroll
-  for (int qb = 0; qb < NQ; ++qb) {
-    m_run[qb] = 0.0f; mc[qb] = 0.0f; l_part[qb] = 0.0f;
-    lp4[qb][0] = lp4[qb][1] = lp4[qb][2] = lp4[qb][3] = 0.0f;
-  }
-
+        for (int t = 0; t < 8; ++t)
+          if (8 * c + t >= nv) v[t] = (__bf16)0.0f;
+        *pch = v;
+      }
+    }
+    ring_barrier();
+  };
   auto load_k = [&](bf16x8 (&kf)[4], auto off_c) {                 // K fragments of one 32-key block: 4 x 16 B
     constexpr int OFF = decltype(off_c)::value;
 #pragma unroll
@@ -679,138 +664,202 @@ __global__ __launch_bounds__(SD_NT, NQ == 1 ? 3 : 2) void sdpa_fwd_pipe_kernel(
       if ((nkt_all - 1) * SD_KB + kb * 32 + 16 * (r >> 3) + 8 * half + (r & 7) >= N) s[r] = -INFINITY;
   };
 
-  // pipeline state: scores of the current unit, K fragments for the next one, P of the previous one
-  f32x16 s_cur;
-  bf16x8 kf[4], vf[4], p_prev[2];
-#pragma unroll
-  for (int t = 0; t < 8; ++t) {                                   // the first step's P.V product is 0 x 0
-    p_prev[0][t] = (__bf16)0.0f; p_prev[1][t] = (__bf16)0.0f;
-    vf[0][t] = (__bf16)0.0f; vf[1][t] = (__bf16)0.0f; vf[2][t] = (__bf16)0.0f; vf[3][t] = (__bf16)0.0f;
-  }
-  {
-    const f32x16 zero = {0};
-    load_k(kf, std::integral_constant<int, 0>{});
-    s_cur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], fq[0][0], zero, 0, 0, 0);
-#pragma unroll
-    for (int ks = 1; ks < 4; ++ks) s_cur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], fq[0][ks], s_cur, 0, 0, 0);
-    if (NQ == 1) load_k(kf, std::integral_constant<int, 32 * 128>{});     // unit 1 = key half 1 (NQ = 2: same K, block 1)
-  }
+  f32x16 oacc[NQ][2];
+  float m_run[NQ], l_row[NQ];
 
-  for (int kt0 = 0; kt0 < nkt; kt0 += GL_NBUF) {
-   static_for<GL_NBUF>([&](auto slot_c) {
-    constexpr int SLOT = decltype(slot_c)::value;
-    const int kt = kt0 + SLOT;
-    if (kt >= nkt) return;
-    const int ktg = kt_off + kt;
-    const bool ragged = has_ragged && ktg == nkt_all - 1;
-    static_for<UPT>([&](auto i_c) {
-      constexpr int I = decltype(i_c)::value;
-      constexpr int KB = I / NQ, QB = I % NQ;
-      constexpr int IN = (I + 1) % UPT, QBN = IN % NQ;                                        // next unit
-      constexpr int IP = (I + UPT - 1) % UPT, KBP = IP / NQ, QBP = IP % NQ;                    // previous unit
-      constexpr int P_SLOT = I >= 1 ? SLOT : (SLOT + 2) % GL_NBUF;
-      constexpr int INN = (I + 2) % UPT, KBNN = INN / NQ, QBNN = INN % NQ;                     // the unit after the next
-      constexpr int NN_SLOT = I + 2 < UPT ? SLOT : (SLOT + 1) % GL_NBUF;
+  // one pass over this workgroup's key tiles.  FASTP: reference-free (MODE 1 first pass)
+  auto run_pass = [&](auto fast_c) {
+    constexpr bool FASTP = decltype(fast_c)::value;
+    const char* k_tile = k_first;                                  // scalar: next tile to stage
+    const char* v_tile = v_first;
+    auto stage = [&](int slot) {                                   // tiles are staged strictly in order
+      const unsigned base = smem_base + slot * SLOTB;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const unsigned piece = (wave + 4 * j) * 1024;
+        lds_dma16(offK[j], k_tile, base + piece);
+        lds_dma16(offV[j], v_tile, base + GL_TILE + piece);
+      }
+      k_tile += SD_KB * HD * 2;
+      v_tile += SD_KB * 2;
+    };
+    stage(0);
+    if (nkt > 1) stage(1);
+    // the slot "before tile 0" feeds the first step's (all-zero) P.V product: its V^T half must hold finite numbers
+    {
+      const uint4 z = make_uint4(0, 0, 0, 0);
+      *reinterpret_cast<uint4*>(smem + 2 * SLOTB + GL_TILE + tid * 16) = z;
+      *reinterpret_cast<uint4*>(smem + 2 * SLOTB + GL_TILE + 4096 + tid * 16) = z;
+    }
+    if (nkt > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ring_barrier();
+    if (has_ragged && kt_off == nkt_all - 1) zero_pad_cols(0);     // tile 0 of this workgroup is the ragged one
+
+    float mc[NQ], lp4[NQ][4];
+#pragma unroll
+    for (int qb = 0; qb < NQ; ++qb) {
+      m_run[qb] = 0.0f; mc[qb] = 0.0f;
+      lp4[qb][0] = lp4[qb][1] = lp4[qb][2] = lp4[qb][3] = 0.0f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { oacc[qb][0][r] = 0.0f; oacc[qb][1][r] = 0.0f; }
+    }
+    // pipeline state: scores of the current unit, K fragments for the next one, P of the previous one
+    f32x16 s_cur;
+    bf16x8 kf[4], vf[4], p_prev[2];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {                                  // the first step's P.V product is 0 x 0
+      p_prev[0][t] = (__bf16)0.0f; p_prev[1][t] = (__bf16)0.0f;
+      vf[0][t] = (__bf16)0.0f; vf[1][t] = (__bf16)0.0f; vf[2][t] = (__bf16)0.0f; vf[3][t] = (__bf16)0.0f;
+    }
+    {
       const f32x16 zero = {0};
+      load_k(kf, std::integral_constant<int, 0>{});
+      s_cur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], fq[0][0], zero, 0, 0, 0);
+#pragma unroll
+      for (int ks = 1; ks < 4; ++ks) s_cur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], fq[0][ks], s_cur, 0, 0, 0);
+      if (NQ == 1) load_k(kf, std::integral_constant<int, 32 * 128>{});   // unit 1 = key half 1 (NQ = 2: same K, block 1)
+    }
 
-      // softmax reference of a query block = row max of its FIRST unit (see sdpa_fwd_glds_kernel)
-      if (!FAST && SLOT == 0 && I < NQ && kt == 0) {
+    for (int kt0 = 0; kt0 < nkt; kt0 += GL_NBUF) {
+     static_for<GL_NBUF>([&](auto slot_c) {
+      constexpr int SLOT = decltype(slot_c)::value;
+      const int kt = kt0 + SLOT;
+      if (kt >= nkt) return;
+      const int ktg = kt_off + kt;
+      const bool ragged = has_ragged && ktg == nkt_all - 1;
+      static_for<UPT>([&](auto i_c) {
+        constexpr int I = decltype(i_c)::value;
+        constexpr int KB = I / NQ, QB = I % NQ;
+        constexpr int IN = (I + 1) % UPT, QBN = IN % NQ;                                        // next unit
+        constexpr int IP = (I + UPT - 1) % UPT, KBP = IP / NQ, QBP = IP % NQ;                    // previous unit
+        constexpr int P_SLOT = I >= 1 ? SLOT : (SLOT + 2) % GL_NBUF;
+        constexpr int INN = (I + 2) % UPT, KBNN = INN / NQ, QBNN = INN % NQ;                     // the unit after the next
+        constexpr int NN_SLOT = I + 2 < UPT ? SLOT : (SLOT + 1) % GL_NBUF;
+        const f32x16 zero = {0};
+
         if (ragged) mask_ragged(s_cur, KB);
-        m_run[QB] = rowmax16(s_cur);
-        mc[QB] = m_run[QB];
-      } else if (ragged) {
-        mask_ragged(s_cur, KB);
-      }
-
-      // ---- first half: V^T fragments of the previous unit; S(next) = K . Q^T; exp2 of this unit under the MFMAs ----
-      if (QBP == 0) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c)            // (d block c >> 1, 16-key step c & 1) of key half KBP
-          vf[c] = *reinterpret_cast<const bf16x8*>(vptr[2 * KBP + (c & 1)] + P_SLOT * SLOTB + (c >> 1) * 32 * 128);
-      }
-      f32x16 s_next = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], fq[QBN][0], zero, 0, 0, 0);
-#pragma unroll
-      for (int ks = 1; ks < 4; ++ks) s_next = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], fq[QBN][ks], s_next, 0, 0, 0);
-
-      float p[16];
-      float ps[4];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        if (FAST) {
-          p[r] = __builtin_amdgcn_exp2f(s_cur[r]);
-          lp4[QB][r & 3] += p[r];
-        } else {
-          p[r] = __builtin_amdgcn_exp2f(s_cur[r] - mc[QB]);
-          ps[r & 3] = r < 4 ? p[r] : ps[r & 3] + p[r];
+        // softmax reference of a query block = row max of its FIRST unit (see sdpa_fwd_glds_kernel)
+        if (!FASTP && SLOT == 0 && I < NQ && kt == 0) {
+          m_run[QB] = rowmax16(s_cur);
+          mc[QB] = m_run[QB];
         }
-      }
-      bf16x8 p_cur[2];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) p_cur[r >> 3][r & 7] = (__bf16)p[r];
 
-      if (I == 0) {
-        // ---- ring hand-over (one barrier per tile) ----
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // my reads of tile kt-1 are done
-        if (kt + 1 < nkt) {
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // my pieces of tile kt+1 have landed
-          __builtin_amdgcn_s_barrier();
-          asm volatile("" ::: "memory");
-          if (kt + 2 < nkt) stage((SLOT + 2) % GL_NBUF);
-          if (has_ragged && ktg + 1 == nkt_all - 1) zero_pad_cols((SLOT + 1) % GL_NBUF);
+        // ---- first half: V^T fragments of the previous unit; S(next) = K . Q^T; exp2 of this unit under the MFMAs ----
+        if (QBP == 0) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c)            // (d block c >> 1, 16-key step c & 1) of key half KBP
+            vf[c] = *reinterpret_cast<const bf16x8*>(vptr[2 * KBP + (c & 1)] + P_SLOT * SLOTB + (c >> 1) * 32 * 128);
         }
-      }
-
-      // ---- second half: K fragments two units ahead; O += V^T . P of the previous unit ----
-      if (QBNN == 0) load_k(kf, std::integral_constant<int, NN_SLOT * SLOTB + KBNN * 32 * 128>{});
+        f32x16 s_next = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], fq[QBN][0], zero, 0, 0, 0);
 #pragma unroll
-      for (int c = 0; c < 4; ++c)
-        oacc[QBP][c >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[c], p_prev[c & 1], oacc[QBP][c >> 1], 0, 0, 0);
+        for (int ks = 1; ks < 4; ++ks) s_next = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], fq[QBN][ks], s_next, 0, 0, 0);
 
-      float psum = FAST ? 0.0f : (ps[0] + ps[1]) + (ps[2] + ps[3]);
-      if (!FAST && __any(!(psum < 1e20f))) {                        // rare: re-reference this wave's rows to the true running max
-        const float m_cand = fmaxf(m_run[QB], rowmax16(s_cur));
-        const float alpha = __builtin_amdgcn_exp2f(m_run[QB] - m_cand);
-        m_run[QB] = m_cand;
-        mc[QB] = m_cand;
-        l_part[QB] *= alpha;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { oacc[QB][0][r] *= alpha; oacc[QB][1][r] *= alpha; }
-        psum = 0.0f;
+        float p[16];
+        float ps[4];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float pr = __builtin_amdgcn_exp2f(s_cur[r] - mc[QB]);
-          psum += pr;
-          p_cur[r >> 3][r & 7] = (__bf16)pr;
+          if (FASTP) {
+            p[r] = __builtin_amdgcn_exp2f(s_cur[r]);
+            lp4[QB][r & 3] += p[r];
+          } else {
+            p[r] = __builtin_amdgcn_exp2f(s_cur[r] - mc[QB]);
+            ps[r & 3] = r < 4 ? p[r] : ps[r & 3] + p[r];
+          }
         }
+        bf16x8 p_cur[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) p_cur[r >> 3][r & 7] = (__bf16)p[r];
+
+        if (I == 0) {
+          // ---- ring hand-over (one barrier per tile) ----
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // my reads of tile kt-1 are done
+          if (kt + 1 < nkt) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // my pieces of tile kt+1 have landed
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (kt + 2 < nkt) stage((SLOT + 2) % GL_NBUF);
+            if (has_ragged && ktg + 1 == nkt_all - 1) zero_pad_cols((SLOT + 1) % GL_NBUF);
+          }
+        }
+
+        // ---- second half: K fragments two units ahead; O += V^T . P of the previous unit ----
+        if (QBNN == 0) load_k(kf, std::integral_constant<int, NN_SLOT * SLOTB + KBNN * 32 * 128>{});
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          oacc[QBP][c >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[c], p_prev[c & 1], oacc[QBP][c >> 1], 0, 0, 0);
+
+        if (!FASTP) {
+          float psum = (ps[0] + ps[1]) + (ps[2] + ps[3]);
+          if (__any(!(psum < 1e20f))) {                    // rare: re-reference this wave's rows to the true running max
+            const float m_cand = fmaxf(m_run[QB], rowmax16(s_cur));
+            const float alpha = __builtin_amdgcn_exp2f(m_run[QB] - m_cand);
+            m_run[QB] = m_cand;
+            mc[QB] = m_cand;
+#pragma unroll
+            for (int x = 0; x < 4; ++x) lp4[QB][x] *= alpha;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { oacc[QB][0][r] *= alpha; oacc[QB][1][r] *= alpha; }
+            psum = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const float pr = __builtin_amdgcn_exp2f(s_cur[r] - mc[QB]);
+              psum += pr;
+              p_cur[r >> 3][r & 7] = (__bf16)pr;
+            }
+          }
+          lp4[QB][0] += psum;
+        } else {
+          // without the rare-path branch a step is no longer its own basic block: keep hipcc from merging the steps'
+          // schedules (it stretches live ranges across steps and spills)
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        s_cur = s_next;
+        p_prev[0] = p_cur[0];
+        p_prev[1] = p_cur[1];
+      });
+     });
+    }
+    // drain: P.V of the last unit (its V^T fragments: key half 1 of the last tile)
+    {
+      constexpr int QBL = NQ - 1;
+      const int last_slot = (nkt - 1) % GL_NBUF;
+      if (NQ == 1) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          vf[c] = *reinterpret_cast<const bf16x8*>(vptr[2 + (c & 1)] + last_slot * SLOTB + (c >> 1) * 32 * 128);
       }
-      l_part[QB] += psum;
-      // without the rare-path branch a step is no longer its own basic block: keep hipcc from merging the steps'
-      // schedules (it stretches live ranges across steps and spills at NQ = 2)
-      if (FAST) __builtin_amdgcn_sched_barrier(0);
-      s_cur = s_next;
-      p_prev[0] = p_cur[0];
-      p_prev[1] = p_cur[1];
-    });
-   });
-  }
-  // drain: P.V of the last unit (its V^T fragments: key half 1 of the last tile)
-  {
-    constexpr int QBL = NQ - 1;
-    const int last_slot = (nkt - 1) % GL_NBUF;
-    if (NQ == 1) {
 #pragma unroll
       for (int c = 0; c < 4; ++c)
-        vf[c] = *reinterpret_cast<const bf16x8*>(vptr[2 + (c & 1)] + last_slot * SLOTB + (c >> 1) * 32 * 128);
+        oacc[QBL][c >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[c], p_prev[c & 1], oacc[QBL][c >> 1], 0, 0, 0);
     }
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
-      oacc[QBL][c >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[c], p_prev[c & 1], oacc[QBL][c >> 1], 0, 0, 0);
+    for (int qb = 0; qb < NQ; ++qb) {
+      const float lp = (lp4[qb][0] + lp4[qb][1]) + (lp4[qb][2] + lp4[qb][3]);
+      l_row[qb] = lp + __shfl_xor(lp, 32);
+    }
+  };
+
+  if (MODE == 1) {
+    run_pass(std::true_type{});
+    bool bad = false;
+#pragma unroll
+    for (int qb = 0; qb < NQ; ++qb) bad = bad || !(l_row[qb] > 1e-30f && l_row[qb] < 1e30f);
+    // workgroup vote through the (now idle) ring; no static __shared__ object (it would shift the dynamic base)
+    const int wave_bad = __any(bad) ? 1 : 0;              // (all lanes vote: not inside the lane-0 branch)
+    ring_barrier();
+    int* flags = reinterpret_cast<int*>(smem);
+    if (lane == 0) flags[wave] = wave_bad;
+    ring_barrier();
+    const bool redo = (flags[0] | flags[1] | flags[2] | flags[3]) != 0;
+    ring_barrier();
+    if (redo) run_pass(std::false_type{});
+  } else {
+    run_pass(std::false_type{});
   }
 
 #pragma unroll
   for (int qb = 0; qb < NQ; ++qb) {
-    if (FAST) l_part[qb] = (lp4[qb][0] + lp4[qb][1]) + (lp4[qb][2] + lp4[qb][3]);
-    const float l = l_part[qb] + __shfl_xor(l_part[qb], 32);
+    const float l = l_row[qb];
     if (SPLIT) {
       float* rec = part + (((size_t)bh * nslices + slice) * QROWS + (wave * NQ + qb) * 32 + li) * SD_REC;
 #pragma unroll
@@ -871,10 +920,11 @@ __global__ __launch_bounds__(256) void sdpa_combine_kernel(const float* __restri
 // same kernel in SPLIT mode -- (image*head) x 11 key slices = 264 short workgroups that still share K/V tiles through
 // the LDS ring -- followed by a tiny merge of the 11 partial (max, sum, O) records per row (fixed order).
 // ---------------------------------------------------------------------------------------------------------
-// AS_SDPA_IMPL (development knob, read per call): 0 = sdpa_fwd_glds_kernel, 1 = sdpa_fwd_pipe_kernel<1>, 2 = <2>
+// AS_SDPA_IMPL (development knob, read per call): 0 = sdpa_fwd_glds_kernel; sdpa_fwd_pipe_kernel: 1 = <NQ 1, MODE 0>,
+// 2 = <2, 0>, 3 = <1, 1> (default), 4 = <2, 1>
 int sdpa_impl() {
   const char* e = getenv("AS_SDPA_IMPL");
-  return e ? atoi(e) : 1;
+  return e ? atoi(e) : 3;
 }
 
 int sdpa_slots() {                                    // resident workgroups of sdpa_fwd_glds_kernel: 3 per CU
@@ -934,47 +984,37 @@ int launch_sdpa_glds(const void* q, const void* k, const void* vt, void* o, floa
     if (hipEventRecord(side.fork, s) != hipSuccess || hipStreamWaitEvent(side.st, side.fork, 0) != hipSuccess) s2 = s;
   }
   const int impl = sdpa_impl();
+#define AS_PIPE_LAUNCH(NQ_, SPLIT_, MODE_, GRID_, STREAM_, QT_, NS_, WS_)                                                  \
+  hipLaunchKernelGGL((sdpa_fwd_pipe_kernel<NQ_, SPLIT_, MODE_>), dim3(GRID_), dim3(SD_NT), lds, STREAM_, (const __bf16*)q,  \
+                     (const __bf16*)k, (const __bf16*)vt, (__bf16*)o, lse, B, N, Npad, h, QT_, NS_, (float*)(WS_))
   if (impl == 2 || impl == 4) {                              // 64 queries per wave, 256 per workgroup, no split tail
-    if (impl == 2)
-      hipLaunchKernelGGL((sdpa_fwd_pipe_kernel<2, false>), dim3(as_ceil_div(N, 2 * SD_QB) * BH), dim3(SD_NT), lds, s,
-                         (const __bf16*)q, (const __bf16*)k, (const __bf16*)vt, (__bf16*)o, lse, B, N, Npad, h, 0, 1,
-                         (float*)nullptr);
-    else
-      hipLaunchKernelGGL((sdpa_fwd_pipe_kernel<2, false, true>), dim3(as_ceil_div(N, 2 * SD_QB) * BH), dim3(SD_NT), lds, s,
-                         (const __bf16*)q, (const __bf16*)k, (const __bf16*)vt, (__bf16*)o, lse, B, N, Npad, h, 0, 1,
-                         (float*)nullptr);
+    const int grid2 = as_ceil_div(N, 2 * SD_QB) * BH;
+    if (impl == 2) AS_PIPE_LAUNCH(2, false, 0, grid2, s, 0, 1, nullptr);
+    else AS_PIPE_LAUNCH(2, false, 1, grid2, s, 0, 1, nullptr);
     AS_CHECK_LAUNCH("sdpa_fwd_pipe<2>");
     return AS_OK;
   }
-  if (impl == 3) {                                           // prototype: reference-free NQ = 1 on the plain grid
-    hipLaunchKernelGGL((sdpa_fwd_pipe_kernel<1, false, true>), dim3(as_ceil_div(N, SD_QB) * BH), dim3(SD_NT), lds, s,
-                       (const __bf16*)q, (const __bf16*)k, (const __bf16*)vt, (__bf16*)o, lse, B, N, Npad, h, 0, 1,
-                       (float*)nullptr);
-    AS_CHECK_LAUNCH("sdpa_fwd_pipe<1,fast>");
-    return AS_OK;
-  }
   if (ns > 0) {
-    if (impl == 1)
-      hipLaunchKernelGGL((sdpa_fwd_pipe_kernel<1, true>), dim3(ns * BH), dim3(SD_NT), lds, s2, (const __bf16*)q,
-                         (const __bf16*)k, (const __bf16*)vt, (__bf16*)o, lse, B, N, Npad, h, qtiles, ns, (float*)ws);
+    if (impl == 1) AS_PIPE_LAUNCH(1, true, 0, ns * BH, s2, qtiles, ns, ws);
+    else if (impl == 3) AS_PIPE_LAUNCH(1, true, 1, ns * BH, s2, qtiles, ns, ws);
     else
-    hipLaunchKernelGGL(sdpa_fwd_glds_kernel<true>, dim3(ns * BH), dim3(SD_NT), lds, s2, (const __bf16*)q, (const __bf16*)k,
-                       (const __bf16*)vt, (__bf16*)o, lse, B, N, Npad, h, qtiles, ns, (float*)ws);
-    AS_CHECK_LAUNCH("sdpa_fwd_glds<split>");
+      hipLaunchKernelGGL(sdpa_fwd_glds_kernel<true>, dim3(ns * BH), dim3(SD_NT), lds, s2, (const __bf16*)q, (const __bf16*)k,
+                         (const __bf16*)vt, (__bf16*)o, lse, B, N, Npad, h, qtiles, ns, (float*)ws);
+    AS_CHECK_LAUNCH("sdpa_fwd<split>");
     hipLaunchKernelGGL(sdpa_combine_kernel, dim3(SD_QB / 16, BH), dim3(256), 0, s2, (const float*)ws, (__bf16*)o, lse, B, N,
                        h, qtiles, ns);
     AS_CHECK_LAUNCH("sdpa_combine");
     if (s2 != s) (void)hipEventRecord(side.join, s2);
   }
   if (qtiles > 0) {
-    if (impl == 1)
-      hipLaunchKernelGGL((sdpa_fwd_pipe_kernel<1, false>), dim3(qtiles * BH), dim3(SD_NT), lds, s, (const __bf16*)q,
-                         (const __bf16*)k, (const __bf16*)vt, (__bf16*)o, lse, B, N, Npad, h, 0, 1, (float*)nullptr);
+    if (impl == 1) AS_PIPE_LAUNCH(1, false, 0, qtiles * BH, s, 0, 1, nullptr);
+    else if (impl == 3) AS_PIPE_LAUNCH(1, false, 1, qtiles * BH, s, 0, 1, nullptr);
     else
-    hipLaunchKernelGGL(sdpa_fwd_glds_kernel<false>, dim3(qtiles * BH), dim3(SD_NT), lds, s, (const __bf16*)q,
-                       (const __bf16*)k, (const __bf16*)vt, (__bf16*)o, lse, B, N, Npad, h, 0, 1, (float*)nullptr);
-    AS_CHECK_LAUNCH("sdpa_fwd_glds");
+      hipLaunchKernelGGL(sdpa_fwd_glds_kernel<false>, dim3(qtiles * BH), dim3(SD_NT), lds, s, (const __bf16*)q,
+                         (const __bf16*)k, (const __bf16*)vt, (__bf16*)o, lse, B, N, Npad, h, 0, 1, (float*)nullptr);
+    AS_CHECK_LAUNCH("sdpa_fwd");
   }
+#undef AS_PIPE_LAUNCH
   if (ns > 0 && s2 != s) (void)hipStreamWaitEvent(s, side.join, 0);     // join: later work on `s` sees the split rows
   return AS_OK;
 }
