@@ -266,6 +266,15 @@ __device__ __forceinline__ void lds_wait8(u32x2 (&v)[8]) {
   __builtin_amdgcn_sched_barrier(0);
 }
 
+#ifndef AS_SDPA_NBUF2
+#define AS_SDPA_NBUF2 3           // LDS ring depth of sdpa_fwd_pipe_kernel<2, ...> (3 or 4 slots of 16 KiB)
+#endif
+#ifndef AS_SDPA_PRIO
+#define AS_SDPA_PRIO 0            // experiments with static s_setprio (tools/experiments/sdpa_impl_bench.py)
+#endif
+#ifndef AS_SDPA_SGB
+#define AS_SDPA_SGB 1             // sched_group_barrier interleave of sdpa_fwd_pipe_kernel's reference-free step
+#endif
 #ifndef AS_SDPA_ABLATE
 #define AS_SDPA_ABLATE 0          // timing experiments only (tools/experiments/sdpa_ablate.py): 1 no exp2, 2 no softmax
 #endif                            // VALU, 3 no P.V MFMAs, 4 no Q.K MFMAs, 5 no LDS-DMA in the loop, 6 no barrier
@@ -568,6 +577,7 @@ __global__ __launch_bounds__(SD_NT, NQ == 1 ? 3 : 2) void sdpa_fwd_pipe_kernel(
   constexpr int QROWS = SD_QB * NQ;                               // query rows of a workgroup
   constexpr int UPT = 2 * NQ;                                     // units per tile
   constexpr int SLOTB = 2 * GL_TILE;                              // bytes of a ring slot
+  constexpr int NBUF = NQ == 2 ? AS_SDPA_NBUF2 : 3;               // ring depth: NBUF - 2 tiles in flight beyond the next
   const int BH = B * h;
   const int bid = blockIdx.x;
   const int bh = bid % BH, qt = SPLIT ? qt_fixed : bid / BH;
@@ -666,6 +676,12 @@ __global__ __launch_bounds__(SD_NT, NQ == 1 ? 3 : 2) void sdpa_fwd_pipe_kernel(
 
   f32x16 oacc[NQ][2];
   float m_run[NQ], l_row[NQ];
+#if AS_SDPA_PRIO == 1
+  // experiment: static issue priority for every second round of workgroups (the second workgroup a CU receives)
+  if ((blockIdx.x >> 8) & 1) __builtin_amdgcn_s_setprio(1);
+#elif AS_SDPA_PRIO == 2
+  if (wave & 1) __builtin_amdgcn_s_setprio(1);
+#endif
 
   // one pass over this workgroup's key tiles.  FASTP: reference-free (MODE 1 first pass)
   auto run_pass = [&](auto fast_c) {
@@ -685,13 +701,17 @@ __global__ __launch_bounds__(SD_NT, NQ == 1 ? 3 : 2) void sdpa_fwd_pipe_kernel(
     };
     stage(0);
     if (nkt > 1) stage(1);
+    if (NBUF == 4 && nkt > 2) stage(2);
     // the slot "before tile 0" feeds the first step's (all-zero) P.V product: its V^T half must hold finite numbers
     {
       const uint4 z = make_uint4(0, 0, 0, 0);
-      *reinterpret_cast<uint4*>(smem + 2 * SLOTB + GL_TILE + tid * 16) = z;
-      *reinterpret_cast<uint4*>(smem + 2 * SLOTB + GL_TILE + 4096 + tid * 16) = z;
+      *reinterpret_cast<uint4*>(smem + (NBUF - 1) * SLOTB + GL_TILE + tid * 16) = z;
+      *reinterpret_cast<uint4*>(smem + (NBUF - 1) * SLOTB + GL_TILE + 4096 + tid * 16) = z;
     }
-    if (nkt > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // wait for tile 0 only: the later tiles' pieces (4 LDS-DMA per wave and tile) may stay in flight
+    if (NBUF == 4 && nkt > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (nkt > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     ring_barrier();
     if (has_ragged && kt_off == nkt_all - 1) zero_pad_cols(0);     // tile 0 of this workgroup is the ragged one
 
@@ -718,10 +738,11 @@ __global__ __launch_bounds__(SD_NT, NQ == 1 ? 3 : 2) void sdpa_fwd_pipe_kernel(
 #pragma unroll
       for (int ks = 1; ks < 4; ++ks) s_cur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], fq[0][ks], s_cur, 0, 0, 0);
       if (NQ == 1) load_k(kf, std::integral_constant<int, 32 * 128>{});   // unit 1 = key half 1 (NQ = 2: same K, block 1)
+      if (has_ragged && kt_off == nkt_all - 1) mask_ragged(s_cur, 0);
     }
 
-    for (int kt0 = 0; kt0 < nkt; kt0 += GL_NBUF) {
-     static_for<GL_NBUF>([&](auto slot_c) {
+    for (int kt0 = 0; kt0 < nkt; kt0 += NBUF) {
+     static_for<NBUF>([&](auto slot_c) {
       constexpr int SLOT = decltype(slot_c)::value;
       const int kt = kt0 + SLOT;
       if (kt >= nkt) return;
@@ -732,12 +753,12 @@ __global__ __launch_bounds__(SD_NT, NQ == 1 ? 3 : 2) void sdpa_fwd_pipe_kernel(
         constexpr int KB = I / NQ, QB = I % NQ;
         constexpr int IN = (I + 1) % UPT, QBN = IN % NQ;                                        // next unit
         constexpr int IP = (I + UPT - 1) % UPT, KBP = IP / NQ, QBP = IP % NQ;                    // previous unit
-        constexpr int P_SLOT = I >= 1 ? SLOT : (SLOT + 2) % GL_NBUF;
+        constexpr int P_SLOT = I >= 1 ? SLOT : (SLOT + NBUF - 1) % NBUF;
         constexpr int INN = (I + 2) % UPT, KBNN = INN / NQ, QBNN = INN % NQ;                     // the unit after the next
-        constexpr int NN_SLOT = I + 2 < UPT ? SLOT : (SLOT + 1) % GL_NBUF;
+        constexpr int NN_SLOT = I + 2 < UPT ? SLOT : (SLOT + 1) % NBUF;
         const f32x16 zero = {0};
 
-        if (ragged) mask_ragged(s_cur, KB);
+        // (keys >= N of the ragged last tile were masked when these scores were produced: end of the previous step)
         // softmax reference of a query block = row max of its FIRST unit (see sdpa_fwd_glds_kernel)
         if (!FASTP && SLOT == 0 && I < NQ && kt == 0) {
           m_run[QB] = rowmax16(s_cur);
@@ -774,11 +795,13 @@ __global__ __launch_bounds__(SD_NT, NQ == 1 ? 3 : 2) void sdpa_fwd_pipe_kernel(
           // ---- ring hand-over (one barrier per tile) ----
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // my reads of tile kt-1 are done
           if (kt + 1 < nkt) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // my pieces of tile kt+1 have landed
+            // my pieces of tile kt+1 have landed (NBUF = 4: tile kt+2 may still be in flight)
+            if (NBUF == 4 && kt + 2 < nkt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            if (kt + 2 < nkt) stage((SLOT + 2) % GL_NBUF);
-            if (has_ragged && ktg + 1 == nkt_all - 1) zero_pad_cols((SLOT + 1) % GL_NBUF);
+            if (kt + NBUF - 1 < nkt) stage((SLOT + NBUF - 1) % NBUF);          // into the slot of tile kt-1
+            if (has_ragged && ktg + 1 == nkt_all - 1) zero_pad_cols((SLOT + 1) % NBUF);
           }
         }
 
@@ -809,9 +832,35 @@ __global__ __launch_bounds__(SD_NT, NQ == 1 ? 3 : 2) void sdpa_fwd_pipe_kernel(
           }
           lp4[QB][0] += psum;
         } else {
+          // Issue order of the step (cdna_hip_programming.md T19): every MFMA is followed by 5 of the step's 40 VALU
+          // (16 exp2, 16 adds, 8 packs) -- an in-order wave issues nothing while the next MFMA waits for the matrix pipe,
+          // so back-to-back MFMAs leave their 32-cycle shadows empty and a clump of VALU leaves the pipe idle.  Left to
+          // itself hipcc emits 16 exp2, then 8 MFMAs.  The V^T reads go under the first MFMA, the K reads under the fifth.
+          // P(u) and the row sums must be COMPUTED in this step: hipcc's IR passes otherwise sink the exp2 / pack / add
+          // chains down to their first use -- the P.V MFMAs of the NEXT step -- which undoes the software pipeline
+          // (sched_barrier only binds the machine scheduler).  An empty volatile asm makes the values opaque here.
+          asm volatile("" : "+v"(p_cur[0]), "+v"(p_cur[1]), "+v"(lp4[QB][0]), "+v"(lp4[QB][1]), "+v"(lp4[QB][2]), "+v"(lp4[QB][3]));
+          if (AS_SDPA_SGB) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);   // DS read
+            __builtin_amdgcn_sched_group_barrier(0x402, 5, 0);   // VALU | TRANS
+#pragma unroll
+            for (int m = 1; m < 8; ++m) {
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+              if (m == 4) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+              __builtin_amdgcn_sched_group_barrier(0x402, 5, 0);
+            }
+          }
           // without the rare-path branch a step is no longer its own basic block: keep hipcc from merging the steps'
           // schedules (it stretches live ranges across steps and spills)
           __builtin_amdgcn_sched_barrier(0);
+        }
+        // the scores of the NEXT unit: mask the padded keys if it lies in the ragged last tile.  Here, between two
+        // steps, the (uniform, almost never taken) branch does not cut a step's schedule in two.
+        {
+          constexpr int KBN = IN / NQ;
+          const bool ragged_next = I + 1 < UPT ? ragged : (has_ragged && ktg + 1 == nkt_all - 1);
+          if (ragged_next) mask_ragged(s_next, KBN);
         }
         s_cur = s_next;
         p_prev[0] = p_cur[0];
@@ -822,7 +871,7 @@ __global__ __launch_bounds__(SD_NT, NQ == 1 ? 3 : 2) void sdpa_fwd_pipe_kernel(
     // drain: P.V of the last unit (its V^T fragments: key half 1 of the last tile)
     {
       constexpr int QBL = NQ - 1;
-      const int last_slot = (nkt - 1) % GL_NBUF;
+      const int last_slot = (nkt - 1) % NBUF;
       if (NQ == 1) {
 #pragma unroll
         for (int c = 0; c < 4; ++c)
@@ -920,11 +969,12 @@ __global__ __launch_bounds__(256) void sdpa_combine_kernel(const float* __restri
 // same kernel in SPLIT mode -- (image*head) x 11 key slices = 264 short workgroups that still share K/V tiles through
 // the LDS ring -- followed by a tiny merge of the 11 partial (max, sum, O) records per row (fixed order).
 // ---------------------------------------------------------------------------------------------------------
-// AS_SDPA_IMPL (development knob, read per call): 0 = sdpa_fwd_glds_kernel; sdpa_fwd_pipe_kernel: 1 = <NQ 1, MODE 0>,
-// 2 = <2, 0>, 3 = <1, 1> (default), 4 = <2, 1>
-int sdpa_impl() {
+// Which forward kernel.  AS_SDPA_IMPL (read per call; tests and tools/experiments/sdpa_impl_bench.py) forces one:
+// 0 = sdpa_fwd_glds_kernel; sdpa_fwd_pipe_kernel: 1 = <NQ 1, MODE 0>, 2 = <2, 0>, 3 = <1, 1>, 4 = <2, 1>.  Unset: the
+// reference-free pipelined kernel with the query blocking (3 or 4) that sdpa_pick() prices cheaper for the shape.
+int sdpa_impl_forced() {
   const char* e = getenv("AS_SDPA_IMPL");
-  return e ? atoi(e) : 3;
+  return e ? atoi(e) : -1;
 }
 
 int sdpa_slots() {                                    // resident workgroups of sdpa_fwd_glds_kernel: 3 per CU
@@ -949,6 +999,33 @@ int sdpa_split_slices(int B, int N, int h) {           // 0 = no split for this 
   return as_ceil_div(nkt, per);                         // no empty slice
 }
 
+// NQ = 1 (128-row workgroups, 3 per CU, key-split tail) or NQ = 2 (256-row workgroups, 2 per CU, no tail)?  Per key
+// tile a CU that hosts w concurrent workgroups needs (measured on MI355X, profiles/r03_sdpa_variants.md):
+//   NQ = 1:  0.60 / 1.28 / 1.64 us for w = 1 / 2 / 3        NQ = 2:  1.15 us for w = 1, 1.75 .. 2.0 us for w = 2
+// and the key-split tail of NQ = 1 costs ~20 us per 66 tiles.  At ViT-B / 1024^2 / B = 2 (24 x 4197 rows): NQ = 1 is 768
+// workgroups + tail = 130 us, NQ = 2 is 408 workgroups on 512 slots = 121 us; at N = 4096 (no tail) NQ = 1 wins, 105 us.
+int sdpa_pick(int B, int N, int h, bool tail_ok) {
+  const int BH = B * h, cus = sdpa_slots() / 3;
+  const double tiles = (double)as_ceil_div(N, SD_KB);
+  auto layers = [&](int wgs, int per_cu, const double* cost, double partial_hi) {   // us per key tile
+    const int full = wgs / (per_cu * cus), rem = wgs % (per_cu * cus);
+    double t = full * cost[per_cu - 1];
+    if (rem > 0) {
+      const int w = as_ceil_div(rem, cus);                      // concurrent workgroups on the busiest CUs
+      double c = cost[w - 1];
+      if (w == per_cu && partial_hi > 0) c = partial_hi + (cost[w - 1] - partial_hi) * (double)(rem - (w - 1) * cus) / cus;
+      t += c;
+    }
+    return t;
+  };
+  const double c1[3] = {0.60, 1.28, 1.64}, c2[2] = {1.15, 2.0};
+  int q1 = as_ceil_div(N, SD_QB);
+  const bool tail = tail_ok && sdpa_split_slices(B, N, h) > 0;
+  const double t1 = tiles * layers((tail ? q1 - 1 : q1) * BH, 3, c1, 0.0) + (tail ? 0.30 * tiles : 0.0);
+  const double t2 = tiles * layers(as_ceil_div(N, 2 * SD_QB) * BH, 2, c2, 1.75);
+  return t2 < t1 ? 4 : 3;
+}
+
 int launch_sdpa_glds(const void* q, const void* k, const void* vt, void* o, float* lse, void* ws, size_t ws_bytes, int B,
                      int N, int h, hipStream_t s) {
   const int Npad = as_round_up(N, 64);
@@ -956,6 +1033,9 @@ int launch_sdpa_glds(const void* q, const void* k, const void* vt, void* o, floa
   int qtiles = as_ceil_div(N, SD_QB);
   int ns = sdpa_split_slices(B, N, h);
   if (ns > 0 && (ws == nullptr || ws_bytes < (size_t)BH * ns * SD_QB * SD_REC * sizeof(float))) ns = 0;
+  const int forced = sdpa_impl_forced();
+  const int impl = forced >= 0 ? forced : sdpa_pick(B, N, h, ns > 0);
+  if (impl == 2 || impl == 4) ns = 0;                        // 256-row workgroups: no split tail
   if (ns > 0) --qtiles;
   const size_t lds = (size_t)GL_NBUF * 2 * GL_TILE;        // 48 KiB
   // The split q-tile runs CONCURRENTLY with the main grid on a helper stream (fork / join with events on the caller's
@@ -983,12 +1063,20 @@ int launch_sdpa_glds(const void* q, const void* k, const void* vt, void* o, floa
   if (concurrent) {
     if (hipEventRecord(side.fork, s) != hipSuccess || hipStreamWaitEvent(side.st, side.fork, 0) != hipSuccess) s2 = s;
   }
-  const int impl = sdpa_impl();
 #define AS_PIPE_LAUNCH(NQ_, SPLIT_, MODE_, GRID_, STREAM_, QT_, NS_, WS_)                                                  \
   hipLaunchKernelGGL((sdpa_fwd_pipe_kernel<NQ_, SPLIT_, MODE_>), dim3(GRID_), dim3(SD_NT), lds, STREAM_, (const __bf16*)q,  \
                      (const __bf16*)k, (const __bf16*)vt, (__bf16*)o, lse, B, N, Npad, h, QT_, NS_, (float*)(WS_))
   if (impl == 2 || impl == 4) {                              // 64 queries per wave, 256 per workgroup, no split tail
     const int grid2 = as_ceil_div(N, 2 * SD_QB) * BH;
+    const size_t lds1 = lds;
+    const size_t lds = (size_t)AS_SDPA_NBUF2 * 2 * GL_TILE;
+    (void)lds1;
+    static bool attr_set = false;
+    if (!attr_set && lds > 64 * 1024 - 1) {
+      (void)hipFuncSetAttribute((const void*)sdpa_fwd_pipe_kernel<2, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      (void)hipFuncSetAttribute((const void*)sdpa_fwd_pipe_kernel<2, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr_set = true;
+    }
     if (impl == 2) AS_PIPE_LAUNCH(2, false, 0, grid2, s, 0, 1, nullptr);
     else AS_PIPE_LAUNCH(2, false, 1, grid2, s, 0, 1, nullptr);
     AS_CHECK_LAUNCH("sdpa_fwd_pipe<2>");
