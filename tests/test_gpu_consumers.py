@@ -80,8 +80,8 @@ def test_mask_point_targets_match_the_reference_on_the_device(golden):
 @pytest.mark.parametrize("out,C,hw", [(7, 48, (14, 17)), (14, 768, (64, 64))])
 def test_roi_align_hip_matches_the_tensor_op_restatement(out, C, hw):
     """as_roi_align_fwd / _bwd (csrc/roi_align.hip) vs mil_head's tensor-op RoIAlign (the restatement of mmcv's adaptive,
-    aligned, average-pooled RoIAlign that the CPU tests hold to its definition): forward 1e-5, backward (float atomics)
-    1e-4 of the gradient range; boxes that leave the map, a degenerate box (empty sample grid -> 0) and several images."""
+    aligned, average-pooled RoIAlign that the CPU tests hold to its definition): forward 1e-5, backward (the atomic-free
+    per-pixel gather, fixed summation order) 1e-4 of the gradient range; boxes that leave the map, a degenerate box (empty sample grid -> 0) and several images."""
     from attentionshift_amd.mil_head import _roi_align_chunk, roi_align
     gen = torch.Generator().manual_seed(9)
     H, W = hw
