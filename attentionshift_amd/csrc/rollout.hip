@@ -467,6 +467,11 @@ __device__ __forceinline__ void r4_wait_lds(r4_u32x4& a, r4_u32x4& b, r4_u32x4& 
   asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
   __builtin_amdgcn_sched_barrier(0);
 }
+__device__ __forceinline__ void r4_wait_lds8(r4_u32x4& a, r4_u32x4& b, r4_u32x4& c, r4_u32x4& d, r4_u32x4& e, r4_u32x4& f,
+                                             r4_u32x4& g, r4_u32x4& h) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h));
+  __builtin_amdgcn_sched_barrier(0);
+}
 __device__ __forceinline__ void r4_lds_read32(float& dst, unsigned addr) {
   asm volatile("ds_read_b32 %0, %1" : "=v"(dst) : "v"(addr));
 }
@@ -532,7 +537,6 @@ __global__ __launch_bounds__(RO_NT, 2) void rollout_step4_kernel(const __bf16* _
 
   if (nblk > 0) stage(kb0, 0);
   if (nblk > 1) stage(kb0 + 1, 1);
-  const unsigned lse_base = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)smem + R4_LSE + li * 4;
 
   for (int it = 0; it < nblk; ++it) {
     const int kb = kb0 + it, buf = it % R4_NSTAGE;
@@ -542,34 +546,55 @@ __global__ __launch_bounds__(RO_NT, 2) void rollout_step4_kernel(const __bf16* _
       else if (NIB == 4 || wave == 0) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
     }
+    {
+      // the lse rows this wave brought (head `wave`, lane l = row l % 32) become -log2(e) * lse IN PLACE: the scores'
+      // accumulators start from them (below), so the term costs no MFMA and no per-score VALU
+      float own;
+      const unsigned a_own = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)smem + buf * R4_STAGE + R4_LSE + wave * 256 + lane * 4;
+      asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(own) : "v"(a_own) : "memory");
+      own *= -LOG2E;
+      asm volatile("ds_write_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" :: "v"(a_own), "v"(own) : "memory");
+    }
     if (AS_ROLLOUT_ABLATE != 14) __builtin_amdgcn_s_barrier();   // block `it` is complete; everyone is done with block it-1
     if (AS_ROLLOUT_ABLATE != 11 && it + 2 < nblk) stage(kb + 2, (it + 2) % R4_NSTAGE);
-    float l8[R4_HPG];
-#pragma unroll
-    for (int hh = 0; hh < R4_HPG; ++hh) r4_lds_read32(l8[hh], lse_base + buf * R4_STAGE + hh * 256);
     const unsigned sb = lbase + buf * R4_STAGE;
+    // -log2(e) * lse of the block's 32 rows in ACCUMULATOR layout: register r of a lane in half `half` is row
+    // (r & 3) + 8 (r >> 2) + 4 half, i.e. four runs of 4 consecutive rows = four 16-byte (broadcast) reads per head
+    const unsigned cb = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)smem + buf * R4_STAGE + R4_LSE + half * 16;
+    r4_u32x4 fc[2][4];
+    auto read_c = [&](int hh, r4_u32x4 (&c)[4]) {
+      const unsigned a = cb + hh * 256;
+      r4_lds_read128_dyn(c[0], a);
+      r4_lds_read128<32>(c[1], a);
+      r4_lds_read128<64>(c[2], a);
+      r4_lds_read128<96>(c[3], a);
+    };
     f32x16 pbar;
 #pragma unroll
     for (int r = 0; r < 16; ++r) pbar[r] = 0.0f;
     // software pipeline over the heads: the q.k MFMAs of head hh+1 are issued before the exp2 pass of head hh, the R
     // fragments are fetched under the last head's exp2 pass, and the eight R . Pbar MFMAs run as four independent chains
     r4_u32x4 fa[2][4];
+    read_c(0, fc[0]);
     r4_lds_read128_dyn(fa[0][0], sb);
     r4_lds_read128<1024>(fa[0][1], sb);
     r4_lds_read128<2048>(fa[0][2], sb);
     r4_lds_read128<3072>(fa[0][3], sb);
     {
       const unsigned a1 = sb + 4096;
+      read_c(1, fc[1]);
       r4_lds_read128_dyn(fa[1][0], a1);
       r4_lds_read128<1024>(fa[1][1], a1);
       r4_lds_read128<2048>(fa[1][2], a1);
       r4_lds_read128<3072>(fa[1][3], a1);
     }
-    asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[0][2]), "+v"(fa[0][3]), "+v"(l8[0]), "+v"(l8[1]),
-                 "+v"(l8[2]), "+v"(l8[3]));
+    asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[0][2]), "+v"(fa[0][3]), "+v"(fc[0][0]),
+                 "+v"(fc[0][1]), "+v"(fc[0][2]), "+v"(fc[0][3]));
     __builtin_amdgcn_sched_barrier(0);
-    auto qk = [&](int hh, r4_u32x4 (&f)[4]) {
-      f32x16 sc = inject_rows<__bf16>(-LOG2E * l8[hh], half);
+    auto qk = [&](int hh, r4_u32x4 (&f)[4], r4_u32x4 (&c)[4]) {
+      f32x16 sc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sc[r] = __uint_as_float(c[r >> 2][r & 3]);
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         Frag<__bf16> fq;
@@ -579,17 +604,18 @@ __global__ __launch_bounds__(RO_NT, 2) void rollout_step4_kernel(const __bf16* _
       }
       return sc;
     };
-    f32x16 sc_cur = qk(0, fa[0]);
+    f32x16 sc_cur = qk(0, fa[0], fc[0]);
     r4_u32x4 fr[NIB][2];
 #pragma unroll
     for (int hh = 0; hh < R4_HPG; ++hh) {
       f32x16 sc_next;
       if (hh + 1 < R4_HPG) {
         const int nx = (hh + 1) & 1;
-        r4_wait_lds(fa[nx][0], fa[nx][1], fa[nx][2], fa[nx][3]);
-        sc_next = qk(hh + 1, fa[nx]);
+        r4_wait_lds8(fa[nx][0], fa[nx][1], fa[nx][2], fa[nx][3], fc[nx][0], fc[nx][1], fc[nx][2], fc[nx][3]);
+        sc_next = qk(hh + 1, fa[nx], fc[nx]);
         if (hh + 2 < R4_HPG) {                           // head hh+2's fragments into the buffer head hh just released
           const unsigned a2 = sb + (hh + 2) * 4096;
+          read_c(hh + 2, fc[hh & 1]);
           r4_lds_read128_dyn(fa[hh & 1][0], a2);
           r4_lds_read128<1024>(fa[hh & 1][1], a2);
           r4_lds_read128<2048>(fa[hh & 1][2], a2);
