@@ -278,6 +278,13 @@ class VisionTransformerDet(nn.Module):
                     y = op[2](op[1](y.float())).to(self.compute_dtype).permute(0, 2, 3, 1)
                 return self._deconv2x2(y, op[3]).permute(0, 3, 1, 2)
             return self._deconv2x2(x0, op[0]).permute(0, 3, 1, 2)
+        pool = op[0] if isinstance(op, nn.Sequential) and len(op) == 1 else op
+        if isinstance(pool, nn.MaxPool2d) and tok.is_cuda and tok.dtype == torch.float32 and tok.is_contiguous():
+            k = pool.kernel_size if isinstance(pool.kernel_size, int) else pool.kernel_size[0]
+            s_ = pool.stride if isinstance(pool.stride, int) else pool.stride[0]
+            if k == s_ and pool.padding in (0, (0, 0)) and not pool.ceil_mode and hp % k == 0 and wp % k == 0 and D % 4 == 0:
+                # the tap is token-major: pool it there (NCHW-shaped view of channels-last storage, like the other taps)
+                return ops.maxpool_nhwc(tok.reshape(B, hp, wp, D), k).permute(0, 3, 1, 2)
         return op(feat_nchw)
 
     def interpolate_pos_encoding(self, n_patch_tokens, w, h):

@@ -278,3 +278,47 @@ extern "C" int as_add_layernorm(const float* x_in, const void* delta, const floa
   if (dtype == AS_F32) return launch_add_ln<float>(x_in, delta, gamma, beta, x_out, y_out, M, D, eps, s);
   AS_REQUIRE(false, AS_E_UNSUPPORTED, "as_add_layernorm: dtype %d", dtype);
 }
+
+
+// ---------------------------------------------------------------------------------------------------------
+// k x k / stride-k max pooling of a token-major (NHWC) fp32 feature map: the FPN's stride-32 tap
+// (nn.MaxPool2d(2, 2) at patch 16, MaxPool2d(4, 4) / (2, 2) at patch 8; visual_transformer_det.py:107-127).  The taps live
+// token-major here, so a thread owns 4 consecutive channels of one output pixel: k*k float4 loads, one store
+// (ATen's NHWC kernel takes 42 us for the 25 MB of the ViT-B / 1024^2 tap; this one is a 31 MB stream).
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void maxpool_nhwc_kernel(const float* __restrict__ x, float* __restrict__ out, int B, int H,
+                                                           int W, int C, int k) {
+  const int Ho = H / k, Wo = W / k, C4 = C >> 2;
+  const size_t total = (size_t)B * Ho * Wo * C4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % C4);
+    size_t r = i / C4;
+    const int ow = (int)(r % Wo);
+    r /= Wo;
+    const int oh = (int)(r % Ho), b = (int)(r / Ho);
+    const float* src = x + (((size_t)b * H + (size_t)oh * k) * W + (size_t)ow * k) * C + c4 * 4;
+    float4 m = *reinterpret_cast<const float4*>(src);
+    for (int dy = 0; dy < k; ++dy)
+      for (int dx = 0; dx < k; ++dx) {
+        const float4 v = *reinterpret_cast<const float4*>(src + ((size_t)dy * W + dx) * C);
+        // NaN propagates as in ATen's max_pool2d (a NaN in the window is the result)
+        m.x = (v.x > m.x || v.x != v.x) ? v.x : m.x; m.y = (v.y > m.y || v.y != v.y) ? v.y : m.y;
+        m.z = (v.z > m.z || v.z != v.z) ? v.z : m.z; m.w = (v.w > m.w || v.w != v.w) ? v.w : m.w;
+      }
+    *reinterpret_cast<float4*>(out + i * 4) = m;
+  }
+}
+}  // namespace
+
+extern "C" int as_maxpool_nhwc(const float* x, float* out, int B, int H, int W, int C, int k, as_stream_t stream) {
+  AS_REQUIRE(x && out, AS_E_BADARG, "as_maxpool_nhwc: null pointer");
+  AS_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && k > 0, AS_E_BADARG, "as_maxpool_nhwc: bad sizes");
+  AS_REQUIRE(C % 4 == 0 && H % k == 0 && W % k == 0, AS_E_UNSUPPORTED,
+             "as_maxpool_nhwc: C %% 4 == 0 and H, W multiples of k only (C=%d H=%d W=%d k=%d)", C, H, W, k);
+  const size_t total = (size_t)B * (H / k) * (W / k) * (C / 4);
+  const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(maxpool_nhwc_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, out, B, H, W, C, k);
+  AS_CHECK_LAUNCH("maxpool_nhwc");
+  return AS_OK;
+}

@@ -154,6 +154,16 @@ def add_layernorm(x, delta, gamma, beta, eps, out_dtype, want_x=True, want_y=Tru
     return (xo if want_x else None), (None if y is None else y.reshape(x.shape))
 
 
+def maxpool_nhwc(x_nhwc, k):
+    """nn.MaxPool2d(k, k) of a token-major fp32 map [B,H,W,C] -> [B,H/k,W/k,C] (csrc/layernorm.hip as_maxpool_nhwc)."""
+    lib = _lib.load()
+    B, H, W, C = x_nhwc.shape
+    _chk(x_nhwc, dtype=torch.float32)
+    out = torch.empty(B, H // k, W // k, C, device=x_nhwc.device, dtype=torch.float32)
+    _lib.check(lib.as_maxpool_nhwc(_p(x_nhwc), _p(out), B, H, W, C, int(k), _stream()), "as_maxpool_nhwc")
+    return out
+
+
 def add_layernorm_bwd(x_out, dy, dx_res, gamma, eps, dtype, want_dx=True, want_ddelta=True, want_affine=True):
     """Backward of add_layernorm (csrc/layernorm.hip): x_out fp32 [.., D] saved by the forward, dy (`dtype`) | None,
     dx_res fp32 | None, gamma fp32 [D] | None -> (dx fp32 | None, ddelta `dtype` | None, dgamma, dbeta fp32 [D] | None)."""

@@ -216,6 +216,18 @@ def test_sdpa_bf16_out_of_range_logits_take_the_exact_pass(ops, monkeypatch, imp
     assert_close(torch.logsumexp(s_, dim=-1).float(), lse, 1e-4, 2e-3, "lse")
 
 
+@pytest.mark.parametrize("B,H,W,C,k", [(2, 64, 64, 768, 2), (1, 12, 20, 192, 4), (2, 6, 10, 128, 2)])
+def test_maxpool_nhwc_equals_max_pool2d(ops, B, H, W, C, k):
+    """as_maxpool_nhwc (the FPN's stride-32 tap on the token-major layout) == nn.MaxPool2d(k, k) bit for bit, NaN included."""
+    g = torch.Generator().manual_seed(H * W + C)
+    x = torch.randn(B, H, W, C, generator=g)
+    x[0, 1, 1, 3] = float("nan")
+    ref = torch.nn.functional.max_pool2d(x.permute(0, 3, 1, 2), k, k).permute(0, 2, 3, 1)
+    got = ops.maxpool_nhwc(dev(x), k).cpu()
+    assert got.shape == ref.shape
+    assert torch.equal(torch.nan_to_num(got, nan=-7.0), torch.nan_to_num(ref, nan=-7.0))
+
+
 @pytest.mark.parametrize("M,D", [(297, 192), (1000, 768), (77, 1024), (5, 128)])
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-6), (torch.bfloat16, 1e-2)])
 def test_add_layernorm_matches_torch(ops, dtype, tol, M, D):
