@@ -263,7 +263,7 @@ def _static_traffic(name, key):
         return None
 
 
-def cpu_baseline():
+def cpu_baseline(only_threads=None):
     """The CPU oracle (a port of the reference's PyTorch path) on this box's host cores, bounded sample per BASELINE.md
     section 3: ONE image; 1 of the 12 ViT-B blocks at N=4197 incl. the dense head-mean attention the reference keeps
     (extrapolated x12), the 7-layer row roll-out and the full attention-shift chain (G=3, S=5); 1 warm-up + 3 timed runs,
@@ -310,22 +310,43 @@ def cpu_baseline():
             t_shift = time.time() - t0
         return t_block, t_roll, t_shift
 
-    # BASELINE.md section 3 asks for torch.set_num_threads(os.cpu_count()); on a 256-thread host these mostly small ops
-    # thrash with that many threads, so the sample is timed twice -- every host thread, and a 32-thread pool -- and the
-    # FASTER one is the reported baseline (both rates are in the record).
-    rates = {}
-    best = None
-    for threads in sorted({host_cores, min(host_cores, 32)}, reverse=True):
+    # BASELINE.md section 3 asks for torch.set_num_threads(os.cpu_count()).  On a 256-thread host these mostly small ops
+    # thrash with that many threads (measured: 160 s per image against 6.7 s with 32), so the sample is timed with a
+    # 32-thread pool in this process and with every host thread in a child process under a 30 s limit; the faster
+    # setting is the reported baseline, both outcomes are recorded.
+    def sample(threads, max_runs=3):
         torch.set_num_threads(threads)
         t0 = time.time()
         one_run()                                       # warm-up
-        n_runs = 3 if time.time() - t0 < 6.0 else 1      # bound the sample (~10-30 s of CPU work in total)
+        n_runs = max_runs if time.time() - t0 < 6.0 else 1
         runs = sorted((one_run() for _ in range(n_runs)), key=lambda r: r[0] * c["depth"] + r[1] + r[2])
         t_block, t_roll, t_shift = runs[len(runs) // 2]     # median
-        per_image = t_block * c["depth"] + t_roll + t_shift
-        rates[str(torch.get_num_threads())] = round(1.0 / per_image, 4)
-        if best is None or per_image < best[0]:
-            best = (per_image, torch.get_num_threads(), t_block, t_roll, t_shift, n_runs)
+        return (t_block * c["depth"] + t_roll + t_shift, torch.get_num_threads(), t_block, t_roll, t_shift, n_runs)
+
+    if only_threads is not None:                        # child process of the all-threads leg (see below)
+        r = sample(only_threads, max_runs=1)
+        print(json.dumps({"cpu_sample": list(r)}), flush=True)
+        return None
+    rates = {}
+    best = sample(min(host_cores, 32))
+    rates[str(best[1])] = round(1.0 / best[0], 4)
+    if host_cores > 32:
+        # all host threads, in a child process with a hard time limit (the parent cannot interrupt a torch op)
+        import subprocess
+        limit = 30.0
+        try:
+            cp = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-sample", str(host_cores)], capture_output=True,
+                                text=True, timeout=limit, env=dict(os.environ, HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES=""))
+            line = [ln for ln in cp.stdout.splitlines() if ln.startswith('{"cpu_sample"')]
+            full = tuple(json.loads(line[-1])["cpu_sample"]) if line else None
+        except subprocess.TimeoutExpired:
+            full = None
+        if full is not None:
+            rates[str(int(full[1]))] = round(1.0 / full[0], 4)
+            if full[0] < best[0]:
+                best = full
+        else:
+            rates[f"{host_cores}: the sample did not finish within {limit:.0f}s"] = None
     per_image, cores, t_block, t_roll, t_shift, n_runs = best
     return dict(value=round(1.0 / per_image, 4), unit="images/sec", cores=cores, host_cores=host_cores, kind="port",
                 images_per_sec_by_threads=rates,
@@ -359,11 +380,15 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="vitb")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=0, help=argparse.SUPPRESS)     # child mode of cpu_baseline()
     ap.add_argument("--train-steps", type=int, default=5, help="steps of the DDP training-step leg (0 = skip)")
     ap.add_argument("--train-timeout", type=float, default=240.0, help="seconds before the watchdog gives up on the training leg")
     ap.add_argument("--train-accum", type=int, default=2, help="update_interval of the accumulation variant of the training leg (1 = skip)")
     ap.add_argument("--other-configs", default="vitl,swinb", help="short forward legs of the other BASELINE configs ('' = none)")
     a = ap.parse_args()
+    if a.cpu_sample > 0:
+        cpu_baseline(only_threads=a.cpu_sample)
+        return
     CFG.clear()
     CFG.update(CONFIGS[a.config])
 
