@@ -209,32 +209,48 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const T* __restrict__ A, const
 #define AS_GEMM_ABLATE 0                     // timing ablations (tools/experiments/gemm_ablate.py); results are wrong when != 0
 #endif
 constexpr int GK = 32;                       // K step (elements)
-constexpr int G_W_BYTES = BN * GK * 2;       // 8 KiB: the W tile of one K step (128 output columns)
 constexpr int G_NSTAGE = 3;                  // ring depth: 2 K steps in flight + 1 consumed
 // The kernel is built for two tile heights, WM = wave rows of 64 tokens: WM = 2 -> 128 x 128 tile, 256 threads, 48 KiB
 // ring, 3 workgroups per CU; WM = 4 -> 256 x 128 tile, 512 threads, 72 KiB ring, 2 workgroups per CU.  The per-wave code
 // (64 x 64 outputs, 8 MFMAs per K step) is the same; the tall tile moves 3/4 of the operand bytes per flop through the
 // L2 -> LDS path (which is what bounds this kernel: tools/experiments/gemm_ablate.py), the short one balances better
 // when there are few tiles.
-template <int WM> struct GTile {
-  static constexpr int BM_ = 64 * WM, NT_ = 128 * WM;
-  static constexpr int A_BYTES = BM_ * GK * 2;
-  static constexpr int STAGE = A_BYTES + G_W_BYTES;          // A tile | W tile
-  static constexpr int A_PIECES = A_BYTES / 1024 / (2 * WM); // 1-KiB pieces (16 rows) per wave per K step: 2 / 2
-  static constexpr int W_PIECES_X2 = 2 * 8 / (2 * WM);       // W pieces per wave, doubled: 4 -> 2 per wave, 2 -> 1 per wave
-  static constexpr int LOADS = A_PIECES + W_PIECES_X2 / 2;   // LDS-DMA instructions per wave per K step (4 / 3)
+// WN = wave columns of 64 outputs: WN = 2 -> 128 output columns; WN = 4 (with WM = 4) -> a 256 x 256 tile, 16 waves, 96 KiB
+// ring, ONE workgroup per CU: the same 64 x 64 per wave and the same waves per SIMD as two 256 x 128 workgroups, but the
+// CU stages (256 + 256) rows per K step instead of 2 x (256 + 128): two thirds of the L2 -> LDS bytes.
+#ifndef AS_GEMM_WIDE_STAGES
+#define AS_GEMM_WIDE_STAGES 3   // 3 / 4 / 5 stages measured equal (tools/experiments/gemm_variant_bench.py): not latency-bound
+#endif
+// RI = 32-row blocks per wave: RI = 4 (with WM = 2, WN = 4) -> the same 256 x 256 tile on 8 waves of 128 x 64: 6 fragment
+// reads per 8 MFMAs instead of 4 per 4 (LDS read bytes per flop x 3/4), accumulators 128 registers, 2 waves per SIMD.
+template <int WM, int WN = 2, int RI = 2> struct GTile {
+  static constexpr int BM_ = 32 * RI * WM, BN_ = 64 * WN, NT_ = 64 * WM * WN;
+  static constexpr int A_BYTES = BM_ * GK * 2, W_BYTES = BN_ * GK * 2;
+  static constexpr int STAGE = A_BYTES + W_BYTES;            // A tile | W tile
+  static constexpr int A_PIECES = (BM_ / 16) / (WM * WN);    // 1-KiB pieces (16 rows) per wave per K step: 2 / 2 / 1
+  static constexpr int W_PIECES = (BN_ / 16) / (WM * WN);    // 2 / 1 / 1
+  static constexpr int LOADS = A_PIECES + W_PIECES;          // LDS-DMA instructions per wave per K step (4 / 3 / 2)
+  static constexpr int EPI_PITCH = BN_ * 2 + 16;             // bytes per staged output row
+  static constexpr int EPI_BYTES = BM_ * EPI_PITCH + BN_ * 4;
+  static constexpr int NSTAGE = WN == 4 ? AS_GEMM_WIDE_STAGES : G_NSTAGE;   // one workgroup per CU: the ring can be deeper
+  static constexpr int LDS = NSTAGE * STAGE > EPI_BYTES ? NSTAGE * STAGE : EPI_BYTES;
 };
-constexpr int G_EPI_PITCH = BN * 2 + 16;     // bytes per staged output row
 
 typedef __attribute__((ext_vector_type(4))) unsigned g_u32x4;
 __device__ __forceinline__ unsigned g_lds_addr(const void* p) {
   return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;
 }
 template <int OFF> __device__ __forceinline__ void g_lds_read128(g_u32x4& dst, unsigned addr) {
-  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+  // the immediate is 16 bits; the 96 KiB ring of the 256 x 256 tile crosses it in its last stage (one v_add there)
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr + (unsigned)(OFF & ~0xFFFF)), "n"(OFF & 0xFFFF));
 }
 template <int LEFT> __device__ __forceinline__ void g_lds_wait4(g_u32x4& a, g_u32x4& b, g_u32x4& c, g_u32x4& d) {
   asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(LEFT));   // LDS returns in order
+  __builtin_amdgcn_sched_barrier(0);
+}
+template <int LEFT, int N> __device__ __forceinline__ void g_lds_waitn(g_u32x4* f) {
+  static_assert(N == 6, "128 x 64 wave tile: 4 + 2 fragments per k16 step");
+  asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]) : "n"(LEFT));
   __builtin_amdgcn_sched_barrier(0);
 }
 template <int... I, typename F> __device__ __forceinline__ void g_static_for_impl(std::integer_sequence<int, I...>, F&& f) {
@@ -244,16 +260,17 @@ template <int N, typename F> __device__ __forceinline__ void g_static_for(F&& f)
   g_static_for_impl(std::make_integer_sequence<int, N>{}, f);
 }
 
-template <int MODE, int WM>
-__global__ __launch_bounds__(128 * WM, WM == 2 ? 3 : 2) void gemm_glds_kernel(const __bf16* __restrict__ A, const __bf16* __restrict__ W,
-                                                          const float* __restrict__ bias, __bf16* __restrict__ out,
-                                                          int M, int Nout, int K, int act, QkvEpi epi) {
-  using GT = GTile<WM>;
-  constexpr int BM = GT::BM_, NT = GT::NT_, G_TILE_BYTES = GT::A_BYTES, G_STAGE = GT::STAGE;
+template <int MODE, int WM, int WN, int RI>
+__global__ __launch_bounds__(64 * WM * WN, WN == 4 ? 1 : (WM == 2 ? 3 : 2)) void gemm_glds_kernel(
+    const __bf16* __restrict__ A, const __bf16* __restrict__ W, const float* __restrict__ bias, __bf16* __restrict__ out,
+    int M, int Nout, int K, int act, QkvEpi epi) {
+  using GT = GTile<WM, WN, RI>;
+  constexpr int BM = GT::BM_, BN = GT::BN_, NT = GT::NT_, G_TILE_BYTES = GT::A_BYTES, G_STAGE = GT::STAGE;
+  constexpr int G_EPI_PITCH = GT::EPI_PITCH, NSTAGE = GT::NSTAGE;
   extern __shared__ __attribute__((aligned(16))) char smem[];     // [3 stages][A tile | W tile]; reused by the epilogue
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
   const int li = lane & 31, half = lane >> 5;
   // XCD-aware tile order.  Workgroup ids are dealt round-robin over the 8 XCDs (each with its own 4 MiB L2), so id
   // -> (xcd = id % 8, slot = id / 8) and XCD x walks the CONTIGUOUS range [x * per, (x+1) * per) of tiles, n fastest:
@@ -265,15 +282,15 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 3 : 2) void gemm_glds_kernel(co
   if (tile >= tiles) return;
   const int m0 = (tile / nt_n) * BM, n0 = (tile % nt_n) * BN;
 
-  // loader: per K step wave w moves 2 one-KiB pieces of A (tile rows 16p .. 16p+15 of piece p = 2w + j) and its share of
-  // the 8 pieces of W (2 per wave at 4 waves, 1 per wave at 8)
+  // loader: per K step wave w moves NAP one-KiB pieces of A (tile rows 16p .. 16p+15 of piece p = NAP*w + j) and NWP of
+  // the BN/16 pieces of W (2 + 2 per wave at 4 waves, 2 + 1 at 8, 1 + 1 at 16)
   const int lr = lane >> 2, lc = lane & 3;
-  constexpr int NWP = GT::W_PIECES_X2 / 2;
-  const char* srcA[2];
+  constexpr int NAP = GT::A_PIECES, NWP = GT::W_PIECES;
+  const char* srcA[NAP];
   const char* srcW[NWP];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int r = (wave * 2 + j) * 16 + lr;
+  for (int j = 0; j < NAP; ++j) {
+    const int r = (wave * NAP + j) * 16 + lr;
     srcA[j] = reinterpret_cast<const char*>(A + (size_t)min(m0 + r, M - 1) * K) + (lc ^ ((r >> 2) & 3)) * 16;
   }
 #pragma unroll
@@ -284,9 +301,9 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 3 : 2) void gemm_glds_kernel(co
   auto stage = [&](int kt, int buf) {
     char* base = smem + buf * G_STAGE;
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NAP; ++j)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[j] + (size_t)kt * GK * 2),
-                                       (__attribute__((address_space(3))) void*)(base + (wave * 2 + j) * 1024), 16, 0, 0);
+                                       (__attribute__((address_space(3))) void*)(base + (wave * NAP + j) * 1024), 16, 0, 0);
 #pragma unroll
     for (int j = 0; j < NWP; ++j)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcW[j] + (size_t)kt * GK * 2),
@@ -294,9 +311,9 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 3 : 2) void gemm_glds_kernel(co
                                        16, 0, 0);
   };
 
-  f32x16 acc[2][2];                                  // [i: 32-row block of m][j: 32-col block of n], D[n][m] orientation
+  f32x16 acc[RI][2];                                 // [i: 32-row block of m][j: 32-col block of n], D[n][m] orientation
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < RI; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -307,7 +324,7 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 3 : 2) void gemm_glds_kernel(co
   const unsigned smem_base = g_lds_addr(smem);
   unsigned offA[2], offW[2];
   {
-    const int ra = wm * 64 + li, rb = wn * 64 + li;
+    const int ra = wm * (32 * RI) + li, rb = wn * 64 + li;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int g = ks * 2 + half;
@@ -319,49 +336,58 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 3 : 2) void gemm_glds_kernel(co
   const int nk = K / GK;
   stage(0, 0);
 #pragma unroll
-  for (int p_ = 1; p_ < G_NSTAGE - 1; ++p_)
+  for (int p_ = 1; p_ < NSTAGE - 1; ++p_)
     if (nk > p_) stage(p_, p_);
-  for (int kt0 = 0; kt0 < nk; kt0 += G_NSTAGE) {
-    g_static_for<G_NSTAGE>([&](auto slot_c) {
+  for (int kt0 = 0; kt0 < nk; kt0 += NSTAGE) {
+    g_static_for<NSTAGE>([&](auto slot_c) {
       constexpr int slot = decltype(slot_c)::value;
       const int kt = kt0 + slot;
       if (kt >= nk) return;
-      // my pieces of stage kt have landed when at most the (up to G_NSTAGE-2) newer stages are still in flight
-      const int newer = min(G_NSTAGE - 2, nk - 1 - kt);
+      // my pieces of stage kt have landed when at most the (up to NSTAGE-2) newer stages are still in flight
+      const int newer = min(NSTAGE - 2, nk - 1 - kt);
       if (AS_GEMM_ABLATE != 1) {
-        if (newer >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * GT::LOADS) : "memory");
+        if (NSTAGE >= 5 && newer >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * GT::LOADS) : "memory");
+        else if (NSTAGE >= 4 && newer == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * GT::LOADS) : "memory");
         else if (newer == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GT::LOADS) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
       if (AS_GEMM_ABLATE != 4) __builtin_amdgcn_s_barrier();   // publishes stage kt; everyone is done reading stage kt-1
-      if (AS_GEMM_ABLATE != 1 && kt + G_NSTAGE - 1 < nk) stage(kt + G_NSTAGE - 1, (slot + G_NSTAGE - 1) % G_NSTAGE);
-      g_u32x4 f[8];                                  // [ks][A0, A1, W0, W1]
+      if (AS_GEMM_ABLATE != 1 && kt + NSTAGE - 1 < nk) stage(kt + NSTAGE - 1, (slot + NSTAGE - 1) % NSTAGE);
+      constexpr int NF = RI + 2;                     // fragments per k16 step: RI of A, 2 of W
+      g_u32x4 f[2 * NF];                             // [ks][A0 .. A(RI-1), W0, W1]
       if (AS_GEMM_ABLATE == 3) {
 #pragma unroll
-        for (int x = 0; x < 8; ++x) asm volatile("" : "=v"(f[x]));
+        for (int x = 0; x < 2 * NF; ++x) asm volatile("" : "=v"(f[x]));
       }
       if (AS_GEMM_ABLATE != 3) g_static_for<2>([&](auto ks_c) {
         constexpr int ks = decltype(ks_c)::value;
-        g_lds_read128<slot * G_STAGE>(f[ks * 4 + 0], offA[ks]);
-        g_lds_read128<slot * G_STAGE + 2048>(f[ks * 4 + 1], offA[ks]);
-        g_lds_read128<slot * G_STAGE>(f[ks * 4 + 2], offW[ks]);
-        g_lds_read128<slot * G_STAGE + 2048>(f[ks * 4 + 3], offW[ks]);
+        g_static_for<RI>([&](auto i_c) {
+          constexpr int i = decltype(i_c)::value;
+          g_lds_read128<slot * G_STAGE + i * 2048>(f[ks * NF + i], offA[ks]);
+        });
+        g_lds_read128<slot * G_STAGE>(f[ks * NF + RI], offW[ks]);
+        g_lds_read128<slot * G_STAGE + 2048>(f[ks * NF + RI + 1], offW[ks]);
       });
-      // the first half's MFMAs start as soon as ITS four fragments are back; the second half's reads finish under them
+      // the first half's MFMAs start as soon as ITS fragments are back; the second half's reads finish under them
       g_static_for<2>([&](auto ks_c) {
         constexpr int ks = decltype(ks_c)::value;
         if (AS_GEMM_ABLATE != 3) {
-          if (ks == 0) g_lds_wait4<4>(f[0], f[1], f[2], f[3]);
-          else g_lds_wait4<0>(f[4], f[5], f[6], f[7]);
+          if constexpr (RI == 2) {
+            if (ks == 0) g_lds_wait4<4>(f[0], f[1], f[2], f[3]);
+            else g_lds_wait4<0>(f[4], f[5], f[6], f[7]);
+          } else {
+            if (ks == 0) g_lds_waitn<NF, NF>(&f[0]);
+            else g_lds_waitn<0, NF>(&f[NF]);
+          }
         }
         if (AS_GEMM_ABLATE == 2) return;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < RI; ++i)
 #pragma unroll
           for (int j = 0; j < 2; ++j) {
             Frag<__bf16> fa, fb;
-            fa.v = *reinterpret_cast<bf16x8*>(&f[ks * 4 + i]);
-            fb.v = *reinterpret_cast<bf16x8*>(&f[ks * 4 + 2 + j]);
+            fa.v = *reinterpret_cast<bf16x8*>(&f[ks * NF + i]);
+            fb.v = *reinterpret_cast<bf16x8*>(&f[ks * NF + RI + j]);
             acc[i][j] = mma32(fb, fa, acc[i][j]);    // D[n][m]
           }
       });
@@ -374,8 +400,8 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 3 : 2) void gemm_glds_kernel(co
   if (vtile) {
     if (AS_GEMM_ABLATE == 5) return;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int row = m0 + wm * 64 + i * 32 + li;
+    for (int i = 0; i < RI; ++i) {
+      const int row = m0 + wm * (32 * RI) + i * 32 + li;
       if (row < M) {
         const int b = row / epi.N, n = row - b * epi.N;
 #pragma unroll
@@ -401,8 +427,8 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 3 : 2) void gemm_glds_kernel(co
   if (tid < BN) bias_s[tid] = (bias != nullptr && n0 + tid < Nout) ? bias[n0 + tid] : 0.0f;
   __syncthreads();
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    char* srow = smem + (wm * 64 + i * 32 + li) * G_EPI_PITCH;
+  for (int i = 0; i < RI; ++i) {
+    char* srow = smem + (wm * (32 * RI) + i * 32 + li) * G_EPI_PITCH;
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -423,7 +449,7 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 3 : 2) void gemm_glds_kernel(co
 #pragma unroll
   for (int t = 0; t < BM * (BN / 8) / NT; ++t) {
     const int c = tid + t * NT;
-    const int rr = c >> 4, ch = c & 15;               // 16 chunks of 8 columns per row
+    const int rr = c / (BN / 8), ch = c % (BN / 8);   // BN / 8 chunks of 8 columns per row
     const int row = m0 + rr, col = n0 + ch * 8;
     if (row >= M || col >= Nout) continue;
     const uint4 v = *reinterpret_cast<const uint4*>(smem + rr * G_EPI_PITCH + ch * 16);
@@ -453,40 +479,50 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 3 : 2) void gemm_glds_kernel(co
   }
 }
 
-template <int MODE, int WM>
+template <int MODE, int WM, int WN, int RI = 2>
 int launch_gemm_glds_wm(const void* A, const void* W, const float* bias, void* out, int M, int Nout, int K, int act,
                         QkvEpi epi, hipStream_t s) {
-  using GT = GTile<WM>;
-  const int tiles = as_ceil_div(M, GT::BM_) * as_ceil_div(Nout, BN);
+  using GT = GTile<WM, WN, RI>;
+  const int tiles = as_ceil_div(M, GT::BM_) * as_ceil_div(Nout, GT::BN_);
   dim3 grid(8 * as_ceil_div(tiles, 8));              // 1-D, padded to a multiple of the 8 XCDs (see the tile order)
-  // ring 48 / 72 KiB; the epilogue restages the output tile in it: BM x 272 B + 512 B bias = 35 / 70 KiB
-  const size_t lds = (size_t)G_NSTAGE * GT::STAGE;
-  static_assert(GT::BM_ * G_EPI_PITCH + BN * 4 <= G_NSTAGE * GT::STAGE, "epilogue staging must fit the ring");
+  // ring 48 / 72 / 96 KiB; the epilogue restages the output tile in the same memory (35 / 70 / 133 KiB)
+  const size_t lds = (size_t)GT::LDS;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_glds_kernel<MODE, WM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)gemm_glds_kernel<MODE, WM, WN, RI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_glds_kernel<MODE, WM>), grid, dim3(GT::NT_), lds, s, (const __bf16*)A, (const __bf16*)W, bias,
+  hipLaunchKernelGGL((gemm_glds_kernel<MODE, WM, WN, RI>), grid, dim3(GT::NT_), lds, s, (const __bf16*)A, (const __bf16*)W, bias,
                      (__bf16*)out, M, Nout, K, act, epi);
   AS_CHECK_LAUNCH("gemm_glds");
   return AS_OK;
 }
 
-// Tile height.  AS_GEMM_TILE_M=128|256 forces one; otherwise the cheaper of the two under a per-CU round model: a CU
-// works through ceil(tiles / 256) tiles, a tall tile is two short ones of work done 1.28x as fast (measured at 4096^3:
-// 662 -> 846 TFLOP/s), e.g. M = 8394: N = 768 -> 198 tall tiles, one round of 2/1.28 < two short rounds; M = 8192,
-// N = 512 -> 128 tall tiles would leave half the CUs idle: short.
+// Tile shape.  AS_GEMM_TILE_M=128|256 forces a height, AS_GEMM_WIDE=0|1|2 the 256 x 256 tile off / on 16 waves of 64 x 64 /
+// on 8 waves of 128 x 64; otherwise the cheapest under a per-CU round model: a CU works through ceil(tiles / 256) tiles; a
+// tall tile is two short ones of work done 1.28x as fast (measured at 4096^3: 662 -> 846 TFLOP/s), a wide tile four short
+// ones at 1.36x (4096^3: 924-953 -> 1000-1032; M = 8394, N = 3072, K = 768: 58.6-60.6 -> 55.0-56.9 us), e.g. M = 8394:
+// N = 768 -> 198 tall tiles, one round of 2/1.28 < two short rounds; N = 3072 -> 396 wide tiles, two rounds of 2.94 < four
+// tall rounds of 1.56; N = 4096 (ViT-L fc1) -> 528 wide tiles would need three rounds: tall.  M = 8192, N = 512 -> 128 tall
+// tiles would leave half the CUs idle: short.  The wide tile exists for the plain-linear mode only (QKV at 2304 columns is
+// 297 wide tiles = two rounds against three tall ones of half the work: tall wins).
 template <int MODE>
 int launch_gemm_glds(const void* A, const void* W, const float* bias, void* out, int M, int Nout, int K, int act,
                      QkvEpi epi, hipStream_t s) {
   static const int forced = [] { const char* e = getenv("AS_GEMM_TILE_M"); return e ? atoi(e) : 0; }();
+  static const int wide_forced = [] { const char* e = getenv("AS_GEMM_WIDE"); return e ? atoi(e) : -1; }();
   const int nt_n = as_ceil_div(Nout, BN);
   const float tall_cost = (float)as_ceil_div(as_ceil_div(M, 256) * nt_n, 256) * (2.0f / 1.28f);
   const float short_cost = (float)as_ceil_div(as_ceil_div(M, 128) * nt_n, 256);
+  const float wide_cost = (float)as_ceil_div(as_ceil_div(M, 256) * as_ceil_div(Nout, 256), 256) * (4.0f / 1.36f);
   const bool tall = forced == 256 || (forced != 128 && tall_cost < short_cost);
-  return tall ? launch_gemm_glds_wm<MODE, 4>(A, W, bias, out, M, Nout, K, act, epi, s)
-              : launch_gemm_glds_wm<MODE, 2>(A, W, bias, out, M, Nout, K, act, epi, s);
+  if (MODE == 0 && forced == 0) {
+    if (wide_forced == 2) return launch_gemm_glds_wm<MODE, 2, 4, 4>(A, W, bias, out, M, Nout, K, act, epi, s);
+    if (wide_forced == 1 || (wide_forced < 0 && wide_cost < tall_cost && wide_cost < short_cost))
+      return launch_gemm_glds_wm<MODE, 4, 4>(A, W, bias, out, M, Nout, K, act, epi, s);
+  }
+  return tall ? launch_gemm_glds_wm<MODE, 4, 2>(A, W, bias, out, M, Nout, K, act, epi, s)
+              : launch_gemm_glds_wm<MODE, 2, 2>(A, W, bias, out, M, Nout, K, act, epi, s);
 }
 
 template <typename T, int MODE>

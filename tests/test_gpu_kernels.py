@@ -49,12 +49,13 @@ def test_linear_f32(ops, M, N, K, act):
     assert_close(ref, got, 1e-4, 1e-4, f"linear f32 {M}x{N}x{K} {act}")
 
 
-@pytest.mark.parametrize("M,N,K", [(8394, 3072, 768), (8394, 768, 3072), (4197, 768, 768)])
+@pytest.mark.parametrize("M,N,K", [(8394, 3072, 768), (8394, 768, 3072), (4197, 768, 768), (8394, 3080, 768), (8394, 1000, 4096)])
 @pytest.mark.parametrize("act", ["none", "gelu"])
 def test_linear_bf16_backbone_shapes(ops, M, N, K, act):
     """as_linear_fwd in plain-linear mode on the shapes the ViT-B blocks launch (fc1 / fc2 / proj at 2 x 4197 tokens):
-    these pick the 256 x 128 tile (csrc/gemm.hip launch_gemm_glds; M = 513 below always gets the 128 x 128 one), ragged
-    in M (8394 = 32 * 256 + 202).  vs F.linear (+ exact erf GELU) in fp32 on the same bf16-rounded operands."""
+    fc2 / proj pick the 256 x 128 tile, fc1 (N = 3072) the 256 x 256 one (csrc/gemm.hip launch_gemm_glds; M = 513 below
+    always gets the 128 x 128 one), ragged in M (8394 = 32 * 256 + 202); the last two shapes are ragged in N on the
+    256 x 256 tile (3080 = 12 * 256 + 8, 1000 = 3 * 256 + 232; the second is ViT-L's fc2 depth).  vs F.linear (+ exact erf GELU) in fp32 on the same bf16-rounded operands."""
     g = torch.Generator().manual_seed(M + N)
     x = torch.randn(M, K, generator=g).bfloat16()
     w = (torch.randn(N, K, generator=g) * K ** -0.5).bfloat16()

@@ -14,7 +14,7 @@ CS = os.path.join(ROOT, "attentionshift_amd", "csrc")
 OUT = os.path.join(ROOT, "tools", "experiments", "_build")
 VARIANTS = {0: "baseline", 1: "no LDS-DMA / vmcnt in the loop", 2: "no MFMAs", 3: "no fragment reads", 4: "no barrier",
             5: "QKV only: no V^T tile stores"}
-SHAPES = [(4096, 4096, 4096), (8394, 3072, 768), (8394, 768, 3072)]
+SHAPES = [(4096, 4096, 4096), (8394, 3072, 768), (8394, 3072, 1536), (8394, 3072, 3072), (8394, 768, 3072)]
 
 
 def build():
