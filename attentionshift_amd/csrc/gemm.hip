@@ -215,24 +215,26 @@ constexpr int G_NSTAGE = 3;                  // ring depth: 2 K steps in flight 
 // (64 x 64 outputs, 8 MFMAs per K step) is the same; the tall tile moves 3/4 of the operand bytes per flop through the
 // L2 -> LDS path (which is what bounds this kernel: tools/experiments/gemm_ablate.py), the short one balances better
 // when there are few tiles.
-// WN = wave columns of 64 outputs: WN = 2 -> 128 output columns; WN = 4 (with WM = 4) -> a 256 x 256 tile, 16 waves, 96 KiB
-// ring, ONE workgroup per CU: the same 64 x 64 per wave and the same waves per SIMD as two 256 x 128 workgroups, but the
-// CU stages (256 + 256) rows per K step instead of 2 x (256 + 128): two thirds of the L2 -> LDS bytes.
-#ifndef AS_GEMM_WIDE_STAGES
-#define AS_GEMM_WIDE_STAGES 3   // 3 / 4 / 5 stages measured equal (tools/experiments/gemm_variant_bench.py): not latency-bound
+// WN = wave columns of 64 outputs (2 -> 128 output columns, 4 -> 256), RI = 32-row blocks per wave (2 -> 64 rows, 4 -> 128:
+// 6 fragment reads per 8 MFMAs instead of 4 per 4, accumulators 128 registers).
+// KS = k16 MFMA steps per stage: KS = 2 -> K step 32 (a 64-byte row segment per stage: every LDS-DMA instruction touches
+// 16 HALF cache lines, and the other half of each 128-byte line is requested again by the next stage); KS = 4 -> K step 64:
+// whole 128-byte lines per request, half the barriers; two stages of 64 KiB for the 256 x 256 tile.
+#ifndef AS_GEMM_K64_STAGES
+#define AS_GEMM_K64_STAGES 2
 #endif
-// RI = 32-row blocks per wave: RI = 4 (with WM = 2, WN = 4) -> the same 256 x 256 tile on 8 waves of 128 x 64: 6 fragment
-// reads per 8 MFMAs instead of 4 per 4 (LDS read bytes per flop x 3/4), accumulators 128 registers, 2 waves per SIMD.
-template <int WM, int WN = 2, int RI = 2> struct GTile {
+template <int WM, int WN = 2, int RI = 2, int KS = 2> struct GTile {
   static constexpr int BM_ = 32 * RI * WM, BN_ = 64 * WN, NT_ = 64 * WM * WN;
-  static constexpr int A_BYTES = BM_ * GK * 2, W_BYTES = BN_ * GK * 2;
+  static constexpr int GK_ = 16 * KS, ROWB = 2 * GK_;        // K elements / bytes of one tile row per stage
+  static constexpr int PROWS = 1024 / ROWB;                  // tile rows per 1-KiB LDS-DMA piece: 16 / 8
+  static constexpr int A_BYTES = BM_ * ROWB, W_BYTES = BN_ * ROWB;
   static constexpr int STAGE = A_BYTES + W_BYTES;            // A tile | W tile
-  static constexpr int A_PIECES = (BM_ / 16) / (WM * WN);    // 1-KiB pieces (16 rows) per wave per K step: 2 / 2 / 1
-  static constexpr int W_PIECES = (BN_ / 16) / (WM * WN);    // 2 / 1 / 1
-  static constexpr int LOADS = A_PIECES + W_PIECES;          // LDS-DMA instructions per wave per K step (4 / 3 / 2)
+  static constexpr int A_PIECES = (BM_ / PROWS) / (WM * WN); // 1-KiB pieces per wave per stage: 2 / 2 / 1 at KS = 2
+  static constexpr int W_PIECES = (BN_ / PROWS) / (WM * WN); // 2 / 1 / 1
+  static constexpr int LOADS = A_PIECES + W_PIECES;          // LDS-DMA instructions per wave per stage (4 / 3 / 2)
   static constexpr int EPI_PITCH = BN_ * 2 + 16;             // bytes per staged output row
   static constexpr int EPI_BYTES = BM_ * EPI_PITCH + BN_ * 4;
-  static constexpr int NSTAGE = WN == 4 ? AS_GEMM_WIDE_STAGES : G_NSTAGE;   // one workgroup per CU: the ring can be deeper
+  static constexpr int NSTAGE = KS == 4 ? AS_GEMM_K64_STAGES : G_NSTAGE;
   static constexpr int LDS = NSTAGE * STAGE > EPI_BYTES ? NSTAGE * STAGE : EPI_BYTES;
 };
 
@@ -260,17 +262,25 @@ template <int N, typename F> __device__ __forceinline__ void g_static_for(F&& f)
   g_static_for_impl(std::make_integer_sequence<int, N>{}, f);
 }
 
-template <int MODE, int WM, int WN, int RI>
-__global__ __launch_bounds__(64 * WM * WN, WN == 4 ? 1 : (WM == 2 ? 3 : 2)) void gemm_glds_kernel(
+// swizzle of the 16-byte chunk index inside a tile row, so that each ds_read_b128 lane group (16 lanes: rows {0-3, 12-15,
+// 20-27} or {4-11, 16-19, 28-31} of a 32-row block, one chunk column) covers the 16 slots of a 256-byte bank row once:
+// 64-byte rows (4 chunks): chunk ^ ((row >> 2) & 3); 128-byte rows (8 chunks): chunk ^ (((row >> 1) & 3) | ((row >> 4) & 1) << 2)
+template <int KS> __device__ __forceinline__ int g_swz(int r) {
+  return KS == 2 ? ((r >> 2) & 3) : (((r >> 1) & 3) | (((r >> 4) & 1) << 2));
+}
+
+template <int MODE, int WM, int WN, int RI, int KS>
+__global__ __launch_bounds__(64 * WM * WN, (WN == 4 || KS == 4) ? 1 : (WM == 2 ? 3 : 2)) void gemm_glds_kernel(
     const __bf16* __restrict__ A, const __bf16* __restrict__ W, const float* __restrict__ bias, __bf16* __restrict__ out,
     int M, int Nout, int K, int act, QkvEpi epi) {
-  using GT = GTile<WM, WN, RI>;
+  using GT = GTile<WM, WN, RI, KS>;
+  constexpr int GK = GT::GK_, ROWB = GT::ROWB, PROWS = GT::PROWS, CPR = ROWB / 16;   // CPR: 16-byte chunks per tile row
   constexpr int BM = GT::BM_, BN = GT::BN_, NT = GT::NT_, G_TILE_BYTES = GT::A_BYTES, G_STAGE = GT::STAGE;
   constexpr int G_EPI_PITCH = GT::EPI_PITCH, NSTAGE = GT::NSTAGE;
   extern __shared__ __attribute__((aligned(16))) char smem[];     // [3 stages][A tile | W tile]; reused by the epilogue
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / WN, wn = wave % WN;
+  const int wm = __builtin_amdgcn_readfirstlane(wave / WN), wn = __builtin_amdgcn_readfirstlane(wave % WN);
   const int li = lane & 31, half = lane >> 5;
   // XCD-aware tile order.  Workgroup ids are dealt round-robin over the 8 XCDs (each with its own 4 MiB L2), so id
   // -> (xcd = id % 8, slot = id / 8) and XCD x walks the CONTIGUOUS range [x * per, (x+1) * per) of tiles, n fastest:
@@ -284,19 +294,19 @@ __global__ __launch_bounds__(64 * WM * WN, WN == 4 ? 1 : (WM == 2 ? 3 : 2)) void
 
   // loader: per K step wave w moves NAP one-KiB pieces of A (tile rows 16p .. 16p+15 of piece p = NAP*w + j) and NWP of
   // the BN/16 pieces of W (2 + 2 per wave at 4 waves, 2 + 1 at 8, 1 + 1 at 16)
-  const int lr = lane >> 2, lc = lane & 3;
+  const int lr = lane / CPR, lc = lane % CPR;
   constexpr int NAP = GT::A_PIECES, NWP = GT::W_PIECES;
   const char* srcA[NAP];
   const char* srcW[NWP];
 #pragma unroll
   for (int j = 0; j < NAP; ++j) {
-    const int r = (wave * NAP + j) * 16 + lr;
-    srcA[j] = reinterpret_cast<const char*>(A + (size_t)min(m0 + r, M - 1) * K) + (lc ^ ((r >> 2) & 3)) * 16;
+    const int r = (wave * NAP + j) * PROWS + lr;
+    srcA[j] = reinterpret_cast<const char*>(A + (size_t)min(m0 + r, M - 1) * K) + (lc ^ g_swz<KS>(r)) * 16;
   }
 #pragma unroll
   for (int j = 0; j < NWP; ++j) {
-    const int r = (wave * NWP + j) * 16 + lr;
-    srcW[j] = reinterpret_cast<const char*>(W + (size_t)min(n0 + r, Nout - 1) * K) + (lc ^ ((r >> 2) & 3)) * 16;
+    const int r = (wave * NWP + j) * PROWS + lr;
+    srcW[j] = reinterpret_cast<const char*>(W + (size_t)min(n0 + r, Nout - 1) * K) + (lc ^ g_swz<KS>(r)) * 16;
   }
   auto stage = [&](int kt, int buf) {
     char* base = smem + buf * G_STAGE;
@@ -322,18 +332,19 @@ __global__ __launch_bounds__(64 * WM * WN, WN == 4 ? 1 : (WM == 2 ? 3 : 2)) void
   // per-lane fragment addresses (loop-invariant): [ks] for the A rows of block i = 0 and the W rows of block j = 0;
   // the second block (+32 rows = +2048 B) and the ring stage are immediates
   const unsigned smem_base = g_lds_addr(smem);
-  unsigned offA[2], offW[2];
+  unsigned offA[KS], offW[KS];
   {
     const int ra = wm * (32 * RI) + li, rb = wn * 64 + li;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    for (int ks = 0; ks < KS; ++ks) {
       const int g = ks * 2 + half;
-      offA[ks] = smem_base + ra * 64 + ((g ^ ((ra >> 2) & 3)) << 4);
-      offW[ks] = smem_base + G_TILE_BYTES + rb * 64 + ((g ^ ((rb >> 2) & 3)) << 4);
+      offA[ks] = smem_base + ra * ROWB + ((g ^ g_swz<KS>(ra)) << 4);
+      offW[ks] = smem_base + G_TILE_BYTES + rb * ROWB + ((g ^ g_swz<KS>(rb)) << 4);
     }
   }
 
   const int nk = K / GK;
+  {
   stage(0, 0);
 #pragma unroll
   for (int p_ = 1; p_ < NSTAGE - 1; ++p_)
@@ -354,6 +365,8 @@ __global__ __launch_bounds__(64 * WM * WN, WN == 4 ? 1 : (WM == 2 ? 3 : 2)) void
       if (AS_GEMM_ABLATE != 4) __builtin_amdgcn_s_barrier();   // publishes stage kt; everyone is done reading stage kt-1
       if (AS_GEMM_ABLATE != 1 && kt + NSTAGE - 1 < nk) stage(kt + NSTAGE - 1, (slot + NSTAGE - 1) % NSTAGE);
       constexpr int NF = RI + 2;                     // fragments per k16 step: RI of A, 2 of W
+      g_static_for<KS / 2>([&](auto kp_c) {          // pairs of k16 steps
+      constexpr int k0 = 2 * decltype(kp_c)::value;
       g_u32x4 f[2 * NF];                             // [ks][A0 .. A(RI-1), W0, W1]
       if (AS_GEMM_ABLATE == 3) {
 #pragma unroll
@@ -363,10 +376,10 @@ __global__ __launch_bounds__(64 * WM * WN, WN == 4 ? 1 : (WM == 2 ? 3 : 2)) void
         constexpr int ks = decltype(ks_c)::value;
         g_static_for<RI>([&](auto i_c) {
           constexpr int i = decltype(i_c)::value;
-          g_lds_read128<slot * G_STAGE + i * 2048>(f[ks * NF + i], offA[ks]);
+          g_lds_read128<slot * G_STAGE + i * 32 * ROWB>(f[ks * NF + i], offA[k0 + ks]);
         });
-        g_lds_read128<slot * G_STAGE>(f[ks * NF + RI], offW[ks]);
-        g_lds_read128<slot * G_STAGE + 2048>(f[ks * NF + RI + 1], offW[ks]);
+        g_lds_read128<slot * G_STAGE>(f[ks * NF + RI], offW[k0 + ks]);
+        g_lds_read128<slot * G_STAGE + 32 * ROWB>(f[ks * NF + RI + 1], offW[k0 + ks]);
       });
       // the first half's MFMAs start as soon as ITS fragments are back; the second half's reads finish under them
       g_static_for<2>([&](auto ks_c) {
@@ -391,7 +404,9 @@ __global__ __launch_bounds__(64 * WM * WN, WN == 4 ? 1 : (WM == 2 ? 3 : 2)) void
             acc[i][j] = mma32(fb, fa, acc[i][j]);    // D[n][m]
           }
       });
+      });
     });
+  }
   }
 
   // ---------------- epilogue ----------------
@@ -479,50 +494,62 @@ __global__ __launch_bounds__(64 * WM * WN, WN == 4 ? 1 : (WM == 2 ? 3 : 2)) void
   }
 }
 
-template <int MODE, int WM, int WN, int RI = 2>
+template <int MODE, int WM, int WN, int RI = 2, int KS = 2>
 int launch_gemm_glds_wm(const void* A, const void* W, const float* bias, void* out, int M, int Nout, int K, int act,
                         QkvEpi epi, hipStream_t s) {
-  using GT = GTile<WM, WN, RI>;
+  using GT = GTile<WM, WN, RI, KS>;
   const int tiles = as_ceil_div(M, GT::BM_) * as_ceil_div(Nout, GT::BN_);
   dim3 grid(8 * as_ceil_div(tiles, 8));              // 1-D, padded to a multiple of the 8 XCDs (see the tile order)
   // ring 48 / 72 / 96 KiB; the epilogue restages the output tile in the same memory (35 / 70 / 133 KiB)
   const size_t lds = (size_t)GT::LDS;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_glds_kernel<MODE, WM, WN, RI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)gemm_glds_kernel<MODE, WM, WN, RI, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_glds_kernel<MODE, WM, WN, RI>), grid, dim3(GT::NT_), lds, s, (const __bf16*)A, (const __bf16*)W, bias,
+  hipLaunchKernelGGL((gemm_glds_kernel<MODE, WM, WN, RI, KS>), grid, dim3(GT::NT_), lds, s, (const __bf16*)A, (const __bf16*)W, bias,
                      (__bf16*)out, M, Nout, K, act, epi);
   AS_CHECK_LAUNCH("gemm_glds");
   return AS_OK;
 }
 
-// Tile shape.  AS_GEMM_TILE_M=128|256 forces a height, AS_GEMM_WIDE=0|1|2 the 256 x 256 tile off / on 16 waves of 64 x 64 /
-// on 8 waves of 128 x 64; otherwise the cheapest under a per-CU round model: a CU works through ceil(tiles / 256) tiles; a
-// tall tile is two short ones of work done 1.28x as fast (measured at 4096^3: 662 -> 846 TFLOP/s), a wide tile four short
-// ones at 1.36x (4096^3: 924-953 -> 1000-1032; M = 8394, N = 3072, K = 768: 58.6-60.6 -> 55.0-56.9 us), e.g. M = 8394:
-// N = 768 -> 198 tall tiles, one round of 2/1.28 < two short rounds; N = 3072 -> 396 wide tiles, two rounds of 2.94 < four
-// tall rounds of 1.56; N = 4096 (ViT-L fc1) -> 528 wide tiles would need three rounds: tall.  M = 8192, N = 512 -> 128 tall
-// tiles would leave half the CUs idle: short.  The wide tile exists for the plain-linear mode only (QKV at 2304 columns is
-// 297 wide tiles = two rounds against three tall ones of half the work: tall wins).
+// Tile shape, from four instantiations of one kernel:
+//   short   128 x 128, 4 waves of 64 x 64, K step 32, 3-stage ring (48 KiB, 3 workgroups per CU)
+//   tall    256 x 128, 8 waves of 64 x 64, K step 32, 3-stage ring (72 KiB, 2 per CU)
+//   tall64  256 x 128, 8 waves of 64 x 64, K step 64, 2 stages     (96 KiB, 1 per CU)     K % 64 == 0
+//   wide64  256 x 256, 8 waves of 128 x 64, K step 64, 2 stages    (136 KiB with the staged epilogue, 1 per CU)  plain-linear mode
+// chosen by a per-CU round model in units of one short tile's work: a CU works through ceil(tiles / 256) tiles; a tall tile
+// is two short ones done 1.28x as fast (4096^3: 662 -> 846 TFLOP/s); when the tall tiles fit ONE round (<= 256) tall64 runs
+// them 4-8 % faster (whole 128-byte lines per LDS-DMA request, half the barriers; M = 8394: N = 768, K = 768: 18.4 -> 17.7 us,
+// K = 3072: 55.3 -> 51.2) and the second resident workgroup it gives up has nothing to run anyway; a wide tile is four short
+// ones at 1.43x (2/3 of the L2 -> LDS bytes per flop, 3/4 of the LDS reads per MFMA): it wins when it saves rounds --
+// M = 8394: N = 3072, K = 768 (fc1) 396 wide tiles, 2 rounds: 59.8 -> 52.6 us; N = 1024 (ViT-L proj / fc2) 132 tiles:
+// 33.6 -> 31.4, 113 -> 102; N = 4096 (ViT-L fc1) 528 tiles would need 3 rounds: tall (93.8 vs 95).  M = 8192, N = 512: 128
+// tall tiles would leave half the CUs idle: short.  QKV (2304 columns) is 297 wide tiles = 2 rounds of 2.8 against 3 tall
+// rounds of 1.56: tall (measured 45-47 vs 49.5 us).  Measured and not kept (tools/experiments/gemm_variant_bench.py,
+// gemm_pingpong.hip.inc): the 256 x 256 tile on 16 waves of 64 x 64 (K step 32: 1000-1039 TFLOP/s at 4096^3, K step 64: 1059;
+// wide64: 1106-1143), ring depths 3 / 4 / 5 for it (equal), and a ping-pong schedule of wide64 (1062-1140).
+// AS_GEMM_TILE=short|tall|tall64|wide64 forces one (experiments; wide64 only in the plain-linear mode, *64 only if K % 64 == 0).
 template <int MODE>
 int launch_gemm_glds(const void* A, const void* W, const float* bias, void* out, int M, int Nout, int K, int act,
                      QkvEpi epi, hipStream_t s) {
-  static const int forced = [] { const char* e = getenv("AS_GEMM_TILE_M"); return e ? atoi(e) : 0; }();
-  static const int wide_forced = [] { const char* e = getenv("AS_GEMM_WIDE"); return e ? atoi(e) : -1; }();
-  const int nt_n = as_ceil_div(Nout, BN);
-  const float tall_cost = (float)as_ceil_div(as_ceil_div(M, 256) * nt_n, 256) * (2.0f / 1.28f);
+  static const int forced = [] {
+    const char* e = getenv("AS_GEMM_TILE");
+    if (e == nullptr) return 0;
+    return !strcmp(e, "short") ? 1 : !strcmp(e, "tall") ? 2 : !strcmp(e, "tall64") ? 3 : !strcmp(e, "wide64") ? 4 : 0;
+  }();
+  const int nt_n = as_ceil_div(Nout, BN), tall_tiles = as_ceil_div(M, 256) * nt_n;
+  const bool k64 = K % 64 == 0;
   const float short_cost = (float)as_ceil_div(as_ceil_div(M, 128) * nt_n, 256);
-  const float wide_cost = (float)as_ceil_div(as_ceil_div(M, 256) * as_ceil_div(Nout, 256), 256) * (4.0f / 1.36f);
-  const bool tall = forced == 256 || (forced != 128 && tall_cost < short_cost);
-  if (MODE == 0 && forced == 0) {
-    if (wide_forced == 2) return launch_gemm_glds_wm<MODE, 2, 4, 4>(A, W, bias, out, M, Nout, K, act, epi, s);
-    if (wide_forced == 1 || (wide_forced < 0 && wide_cost < tall_cost && wide_cost < short_cost))
-      return launch_gemm_glds_wm<MODE, 4, 4>(A, W, bias, out, M, Nout, K, act, epi, s);
-  }
-  return tall ? launch_gemm_glds_wm<MODE, 4, 2>(A, W, bias, out, M, Nout, K, act, epi, s)
-              : launch_gemm_glds_wm<MODE, 2, 2>(A, W, bias, out, M, Nout, K, act, epi, s);
+  const float tall_cost = (float)as_ceil_div(tall_tiles, 256) * (tall_tiles <= 256 && k64 ? 1.47f : 2.0f / 1.28f);
+  const float wide_cost = (MODE == 0 && k64) ? (float)as_ceil_div(as_ceil_div(M, 256) * as_ceil_div(Nout, 256), 256) * 2.8f : 1e30f;
+  int pick = wide_cost < tall_cost && wide_cost < short_cost ? 4 : tall_cost < short_cost ? (tall_tiles <= 256 && k64 ? 3 : 2) : 1;
+  if (forced && (forced < 3 || k64) && (forced != 4 || MODE == 0)) pick = forced;
+  if constexpr (MODE == 0)
+    if (pick == 4) return launch_gemm_glds_wm<MODE, 2, 4, 4, 4>(A, W, bias, out, M, Nout, K, act, epi, s);
+  if (pick == 3) return launch_gemm_glds_wm<MODE, 4, 2, 2, 4>(A, W, bias, out, M, Nout, K, act, epi, s);
+  if (pick == 2) return launch_gemm_glds_wm<MODE, 4, 2, 2, 2>(A, W, bias, out, M, Nout, K, act, epi, s);
+  return launch_gemm_glds_wm<MODE, 2, 2, 2, 2>(A, W, bias, out, M, Nout, K, act, epi, s);
 }
 
 template <typename T, int MODE>

@@ -35,7 +35,7 @@ def main():
         lib = t0.elapsed_time(t1) / n
         err = float((ops.linear(x, w, b).float() - ref.float()).abs().max() / ref.float().abs().max())
         assert err < 2e-2, err
-        print(json.dumps(dict(tile=os.environ.get("AS_GEMM_TILE_M", "auto"), M=M, N=N, K=K, ms=round(ms, 4), tflops=round(2 * M * N * K / ms / 1e9, 1),
+        print(json.dumps(dict(tile=os.environ.get("AS_GEMM_TILE", "auto"), M=M, N=N, K=K, ms=round(ms, 4), tflops=round(2 * M * N * K / ms / 1e9, 1),
                               lib_ms=round(lib, 4), lib_tflops=round(2 * M * N * K / lib / 1e9, 1),
                               gbs=round((M * K + N * K + M * N) * 2 / ms / 1e6, 0))))
 

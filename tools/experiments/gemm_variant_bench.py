@@ -1,8 +1,9 @@
 """A/B of compile-time variants of csrc/gemm.hip (tile shape, ring depth, ...) on as_linear_fwd, with a refcheck.
 
-    python tools/experiments/gemm_variant_bench.py build s3=-DAS_GEMM_WIDE_STAGES=3 s5=-DAS_GEMM_WIDE_STAGES=5   (here or on the box)
-    python tools/experiments/gemm_variant_bench.py run --variants base,base@wide,s5@wide [--shapes MxNxK,...]     (GPU box)
-`name@wide` / `name@wide2` run the variant with AS_GEMM_WIDE=1 / 2 (the 256 x 256 tile on 16 waves of 64 x 64 / 8 waves of 128 x 64); `base` is the in-tree library.
+    python tools/experiments/gemm_variant_bench.py build s3=-DAS_GEMM_K64_STAGES=3 ...                      (here or on the box)
+    python tools/experiments/gemm_variant_bench.py run --variants base,base@wide64,s3@tall64 [--shapes MxNxK,...]  (GPU box)
+`name@tile` runs the variant with AS_GEMM_TILE=tile (short | tall | tall64 | wide64 forced, csrc/gemm.hip launch_gemm_glds);
+`base` is the in-tree library.  GEMM_ZEROS=1: zero-filled operands (power / clock probe), GEMM_LIB=1: also time F.linear.
 """
 import argparse
 import ctypes
@@ -43,6 +44,8 @@ def run_one(name, shapes, act):
         x = (torch.rand(M, K, device="cuda", generator=g) * 2 - 1).bfloat16()
         w = (torch.rand(N, K, device="cuda", generator=g) * 2 - 1).bfloat16()
         b = torch.rand(N, device="cuda", generator=g)
+        if os.environ.get("GEMM_ZEROS"):                      # power / DVFS probe: same instruction stream, no toggling
+            x.zero_(); w.zero_()
         out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
         call = lambda: lib.as_linear_fwd(x.data_ptr(), w.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, K, 1, act, st)
         for _ in range(5):
@@ -51,7 +54,18 @@ def run_one(name, shapes, act):
         ref = torch.nn.functional.linear(x.float(), w.float(), b)
         if act:
             ref = torch.nn.functional.gelu(ref)
-        err = float((out.float() - ref).abs().max() / ref.abs().max())
+        err = float((out.float() - ref).abs().max() / ref.abs().max().clamp(min=1e-6))
+        lib_tf = None
+        if os.environ.get("GEMM_LIB"):
+            t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            for _ in range(5):
+                torch.nn.functional.linear(x, w)
+            t0.record()
+            for _ in range(50):
+                torch.nn.functional.linear(x, w)
+            t1.record()
+            torch.cuda.synchronize()
+            lib_tf = round(2.0 * M * N * K / (t0.elapsed_time(t1) / 50) / 1e9)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(50):
@@ -59,8 +73,8 @@ def run_one(name, shapes, act):
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 50
-        print(json.dumps(dict(variant=name + {"1": "@wide", "2": "@wide2"}.get(os.environ.get("AS_GEMM_WIDE"), ""), M=M, N=N, K=K,
-                              us=round(ms * 1e3, 1), tflops=round(2.0 * M * N * K / ms / 1e9), err=round(err, 5))), flush=True)
+        print(json.dumps(dict(variant=name + "@" + os.environ.get("AS_GEMM_TILE", "auto"), M=M, N=N, K=K,
+                              us=round(ms * 1e3, 1), tflops=round(2.0 * M * N * K / ms / 1e9), err=round(err, 5), lib_tflops=lib_tf)), flush=True)
         assert err < 2e-2, err
 
 
@@ -80,7 +94,10 @@ def main():
     else:
         for v in a.variants.split(","):
             name, _, mode = v.partition("@")
-            env = dict(os.environ, AS_GEMM_WIDE={"wide": "1", "wide2": "2"}.get(mode, "0"))
+            env = dict(os.environ)
+            env.pop("AS_GEMM_TILE", None)
+            if mode:
+                env["AS_GEMM_TILE"] = mode
             subprocess.call([sys.executable, os.path.abspath(__file__), "_one", "--variants", name, "--act", str(a.act)]
                             + (["--shapes", a.shapes] if a.shapes else []), env=env)
 

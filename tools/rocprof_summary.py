@@ -20,6 +20,21 @@ def main(db, out, title):
                      f"{100.0 * tot / total:.1f} | {vg} | {lds} |")
     lines.append("")
     lines.append(f"total kernel time {total / 1e6:.3f} ms over {sum(r[1] for r in rows)} dispatches")
+    if __import__("os").environ.get("PROF_TIMELINE"):        # kernel sequence of the last N ms of the trace -> <out>.timeline.tsv
+        cols = [r[1] for r in c.execute("pragma table_info(kernels)").fetchall()]
+        sc, ec = ("start", "end") if "start" in cols else ("start_timestamp", "end_timestamp")
+        qcol = "queue_id" if "queue_id" in cols else ("stream_id" if "stream_id" in cols else "0")
+        ev = c.execute(f"select {sc}, {ec}, name, {qcol} from kernels order by {sc}").fetchall()
+        t_end = max(e[1] for e in ev)
+        win = float(__import__("os").environ["PROF_TIMELINE"]) * 1e6
+        ev = [e for e in ev if e[0] >= t_end - win]
+        t0 = ev[0][0]
+        with open(out.replace(".md", "") + ".timeline.tsv", "w") as f:
+            f.write("start_us\tdur_us\tgap_us\tqueue\tkernel\n")
+            prev_end = t0
+            for st, en, name, q in ev:
+                f.write(f"{(st - t0) / 1e3:.1f}\t{(en - st) / 1e3:.1f}\t{(st - prev_end) / 1e3:.1f}\t{q}\t{name[:90]}\n")
+                prev_end = max(prev_end, en)
     if __import__("os").environ.get("PROF_GAPS"):            # device idle analysis: union of busy intervals, largest gaps
         cols = [r[1] for r in c.execute("pragma table_info(kernels)").fetchall()]
         sc, ec = ("start", "end") if "start" in cols else ("start_timestamp", "end_timestamp")
