@@ -480,13 +480,26 @@ __device__ __forceinline__ void r4_wait_lds2(r4_u32x4& a, r4_u32x4& b) {
   __builtin_amdgcn_sched_barrier(0);
 }
 
+// global_load_lds, saddr form: 64 lanes x 16 (4) B from sbase + voff[lane] -> LDS [dst + 16 (4) * lane]; m0 is saved and
+// restored in the same statement; `sbase` and `dst` are wave-uniform (as sdpa.hip's lds_dma16)
+__device__ __forceinline__ void r4_dma16(unsigned voff, const char* sbase, unsigned dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(dst) : "memory");
+}
+__device__ __forceinline__ void r4_dma4(unsigned voff, const char* sbase, unsigned dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(dst) : "memory");
+}
+
 template <int NIB>                                       // 32-row blocks of R carried (1: Trows <= 32, else 4)
 __global__ __launch_bounds__(RO_NT, 2) void rollout_step4_kernel(const __bf16* __restrict__ q, const __bf16* __restrict__ k,
                                                                  const float* __restrict__ lse, const __bf16* __restrict__ rf_in,
                                                                  float* __restrict__ part, int B, int N, int Npad, int h,
                                                                  int Trows, int ksplit) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, half = lane >> 5;
   const int ngroups = h / R4_HPG;
   const int j0 = blockIdx.x * 128 + wave * 32, b = blockIdx.y;
@@ -507,24 +520,26 @@ __global__ __launch_bounds__(RO_NT, 2) void rollout_step4_kernel(const __bf16* _
       for (int ks = 0; ks < 4; ++ks) fk[hh][ks].load16B(k + ((bh0 + hh) * Npad + jrow) * HD + ks * 16 + half * 8);
   }
   // loader: per block wave w moves the 4 KiB of head w's Q fragments, the 2 KiB of R block w and head w's 32 lse values
-  // (7 LDS-DMA instructions)
+  // (7 LDS-DMA instructions).  Q and R are fragment-major: a piece is 1 KiB contiguous, lane l takes bytes 16 l, so the
+  // address is a wave-uniform base (scalar registers, advanced per block) + one loop-invariant lane offset.
   const int ibw = min(wave, nib - 1);
+  const unsigned smem_u = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)smem;
+  const unsigned voff = lane * 16;
+  const char* q_w = reinterpret_cast<const char*>(q) + ((bh0 + wave) * (size_t)(Npad >> 5)) * 4096;   // [row block][k16 step][1 KiB]
+  const char* r_w = reinterpret_cast<const char*>(rf_in) + rf_frag(b, nkb, 0, ibw, 0, 0) * sizeof(__bf16);
+  const char* l_w = reinterpret_cast<const char*>(lse + (bh0 + wave) * N);
   auto stage = [&](int kb, int buf) {
-    char* base = smem + buf * R4_STAGE;
-    const int row = min(kb * 32 + li, Npad - 1);
+    const unsigned base = smem_u + buf * R4_STAGE;
+    const char* qs = q_w + (size_t)kb * 4096;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(q + qf_frag(bh0 + wave, Npad, row, ks, half)),
-                                       (__attribute__((address_space(3))) void*)(base + (wave * 4 + ks) * 1024), 16, 0, 0);
+    for (int ks = 0; ks < 4; ++ks) r4_dma16(voff, qs + ks * 1024, base + (wave * 4 + ks) * 1024);
     if (NIB == 4 || wave == 0) {                         // NIB == 1: only R block 0 exists, wave 0 brings it
+      const char* rs = r_w + (size_t)kb * (4 * 2 * 1024);
 #pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(rf_in + rf_frag(b, nkb, kb, ibw, s2, lane)),
-                                         (__attribute__((address_space(3))) void*)(base + R4_QBYTES + (wave * 2 + s2) * 1024), 16, 0, 0);
+      for (int s2 = 0; s2 < 2; ++s2) r4_dma16(voff, rs + s2 * 1024, base + R4_QBYTES + (wave * 2 + s2) * 1024);
     }
     // lse of head `wave`, rows of the block (an ordinary load here would make hipcc drain vmcnt(0) every iteration)
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(lse + (bh0 + wave) * N + min(kb * 32 + li, N - 1)),
-                                     (__attribute__((address_space(3))) void*)(base + R4_LSE + wave * 256), 4, 0, 0);
+    r4_dma4((unsigned)min(kb * 32 + li, N - 1) * 4u, l_w, base + R4_LSE + wave * 256);
   };
 
   f32x16 acc[NIB];

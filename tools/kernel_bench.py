@@ -108,6 +108,9 @@ def main():
         states = [ops.attention_fwd(xb, wqb, bqkv, wpb, bproj, h)[1] for _ in range(7)]
         ms = timeit(lambda: ops.rollout_rows(states, T), max(a.reps // 4, 2))
         emit("rollout_rows_7layers_bf16", ms, B * 6 * (2.0 * N * N * 64 * h + 2.0 * 128 * N * N), peak=PEAK_BF16)
+        sel = torch.arange(3, device=dev)[None].repeat(B, 1)      # the headline step: 3 matched point tokens per image
+        ms = timeit(lambda: ops.rollout_rows(states, T, rows=sel), max(a.reps // 4, 2))
+        emit("rollout_rows_7layers_bf16_matched3", ms, B * 6 * (2.0 * N * N * 64 * h + 2.0 * 32 * N * N), peak=PEAK_BF16)
     if want("shift"):
         hp = wp = 64
         feats, boxes, prots, obj = [], [], [], []
