@@ -279,7 +279,7 @@ class VisionTransformerDet(nn.Module):
                 return self._deconv2x2(y, op[3]).permute(0, 3, 1, 2)
             return self._deconv2x2(x0, op[0]).permute(0, 3, 1, 2)
         pool = op[0] if isinstance(op, nn.Sequential) and len(op) == 1 else op
-        if isinstance(pool, nn.MaxPool2d) and tok.is_cuda and tok.dtype == torch.float32 and tok.is_contiguous():
+        if isinstance(pool, nn.MaxPool2d) and tok.is_cuda and tok.dtype == torch.float32 and tok.stride()[1:] == (D, 1):
             k = pool.kernel_size if isinstance(pool.kernel_size, int) else pool.kernel_size[0]
             s_ = pool.stride if isinstance(pool.stride, int) else pool.stride[0]
             if k == s_ and pool.padding in (0, (0, 0)) and not pool.ceil_mode and hp % k == 0 and wp % k == 0 and D % 4 == 0:

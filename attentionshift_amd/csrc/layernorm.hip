@@ -288,7 +288,7 @@ extern "C" int as_add_layernorm(const float* x_in, const void* delta, const floa
 // ---------------------------------------------------------------------------------------------------------
 namespace {
 __global__ __launch_bounds__(256) void maxpool_nhwc_kernel(const float* __restrict__ x, float* __restrict__ out, int B, int H,
-                                                           int W, int C, int k) {
+                                                           int W, int C, int k, size_t xbs) {
   const int Ho = H / k, Wo = W / k, C4 = C >> 2;
   const size_t total = (size_t)B * Ho * Wo * C4;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(256) void maxpool_nhwc_kernel(const float* __restri
     const int ow = (int)(r % Wo);
     r /= Wo;
     const int oh = (int)(r % Ho), b = (int)(r / Ho);
-    const float* src = x + (((size_t)b * H + (size_t)oh * k) * W + (size_t)ow * k) * C + c4 * 4;
+    const float* src = x + (size_t)b * xbs + (((size_t)oh * k) * W + (size_t)ow * k) * C + c4 * 4;
     float4 m = *reinterpret_cast<const float4*>(src);
     for (int dy = 0; dy < k; ++dy)
       for (int dx = 0; dx < k; ++dx) {
@@ -311,14 +311,18 @@ __global__ __launch_bounds__(256) void maxpool_nhwc_kernel(const float* __restri
 }
 }  // namespace
 
-extern "C" int as_maxpool_nhwc(const float* x, float* out, int B, int H, int W, int C, int k, as_stream_t stream) {
+extern "C" int as_maxpool_nhwc(const float* x, float* out, int B, int H, int W, int C, int k, long long x_batch_stride,
+                               as_stream_t stream) {
   AS_REQUIRE(x && out, AS_E_BADARG, "as_maxpool_nhwc: null pointer");
   AS_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && k > 0, AS_E_BADARG, "as_maxpool_nhwc: bad sizes");
+  AS_REQUIRE(x_batch_stride >= (long long)H * W * C && x_batch_stride % 4 == 0, AS_E_BADARG,
+             "as_maxpool_nhwc: batch stride %lld (elements) must be >= H*W*C and a multiple of 4", x_batch_stride);
   AS_REQUIRE(C % 4 == 0 && H % k == 0 && W % k == 0, AS_E_UNSUPPORTED,
              "as_maxpool_nhwc: C %% 4 == 0 and H, W multiples of k only (C=%d H=%d W=%d k=%d)", C, H, W, k);
   const size_t total = (size_t)B * (H / k) * (W / k) * (C / 4);
   const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-  hipLaunchKernelGGL(maxpool_nhwc_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, out, B, H, W, C, k);
+  hipLaunchKernelGGL(maxpool_nhwc_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, out, B, H, W, C, k,
+                     (size_t)x_batch_stride);
   AS_CHECK_LAUNCH("maxpool_nhwc");
   return AS_OK;
 }

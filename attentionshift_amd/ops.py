@@ -155,12 +155,17 @@ def add_layernorm(x, delta, gamma, beta, eps, out_dtype, want_x=True, want_y=Tru
 
 
 def maxpool_nhwc(x_nhwc, k):
-    """nn.MaxPool2d(k, k) of a token-major fp32 map [B,H,W,C] -> [B,H/k,W/k,C] (csrc/layernorm.hip as_maxpool_nhwc)."""
+    """nn.MaxPool2d(k, k) of a token-major fp32 map [B,H,W,C] -> [B,H/k,W/k,C] (csrc/layernorm.hip as_maxpool_nhwc).
+    Every image must be dense ([H,W,C] contiguous); the images may be strided (the patch-token slice of [B,N,C])."""
     lib = _lib.load()
     B, H, W, C = x_nhwc.shape
-    _chk(x_nhwc, dtype=torch.float32)
+    if not (x_nhwc.is_cuda and x_nhwc.dtype == torch.float32):
+        raise AttnShiftError("maxpool_nhwc: fp32 device tensor expected")
+    if x_nhwc.stride()[1:] != (W * C, C, 1) or (B > 1 and x_nhwc.stride(0) % 4):
+        x_nhwc = x_nhwc.contiguous()
+    bs = x_nhwc.stride(0) if B > 1 else H * W * C
     out = torch.empty(B, H // k, W // k, C, device=x_nhwc.device, dtype=torch.float32)
-    _lib.check(lib.as_maxpool_nhwc(_p(x_nhwc), _p(out), B, H, W, C, int(k), _stream()), "as_maxpool_nhwc")
+    _lib.check(lib.as_maxpool_nhwc(_p(x_nhwc), _p(out), B, H, W, C, int(k), int(bs), _stream()), "as_maxpool_nhwc")
     return out
 
 

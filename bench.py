@@ -502,7 +502,7 @@ def main():
                 with torch.no_grad():
                     for _ in range(2):
                         ostep()
-                    ops.enable_timing(["sdpa_fwd"] if ovit else ["window_attn_fwd"])
+                    ops.enable_timing(["sdpa_fwd", "cosine_shift"] if ovit else ["window_attn_fwd"])
                     o_steps = max(3, a.steps // 4)
                     t_o = timed(ostep, ranks, o_steps)
                 ot = ops.collect_timing()
@@ -514,6 +514,15 @@ def main():
                     fl = 4.0 * CFG["batch"] * ho * No * No * 64
                     leg["sdpa_fwd"] = {"ms_per_launch": round(ot["sdpa_fwd"][1], 4), "tflops": round(fl / ot["sdpa_fwd"][1] / 1e9, 1),
                                        "frac": round(fl / (ot["sdpa_fwd"][1] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4)}
+                if ovit and "cosine_shift" in ot:            # the affinity call at this config's G (7 objects, 80 x 80 patches)
+                    n_o, ms_o = ot["cosine_shift"]
+                    Npo, Co, So, Go = (CFG["img"] // CFG["patch"]) ** 2, CFG["embed_dim"], CFG["n_shift"], CFG["objects"]
+                    ipc = max(1, round(CFG["batch"] * o_steps / max(n_o, 1)))
+                    by_o = ipc * ((2 * So + 1) * Npo * Co * 4 + Go * 20 * Npo * 4)
+                    leg["roofline_affinity"] = {"bound": "hbm", "achieved": round(by_o / (ms_o * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBPS,
+                                                "unit": "GB/s", "frac": round(by_o / (ms_o * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4),
+                                                "ms_per_call": round(ms_o, 4), "objects_per_image": Go, "images_per_call": ipc,
+                                                "algorithmic_bytes_per_call": by_o}
                 if not ovit and "window_attn_fwd" in ot:
                     _, by = ot.get("window_attn_fwd:bytes", (0, float("nan")))
                     leg["window_attn_fwd"] = {"ms_per_launch": round(ot["window_attn_fwd"][1], 4),

@@ -132,10 +132,13 @@ int as_window_attn_fwd(const void* qkv, const float* bqkv, const float* table, v
 int as_add_layernorm(const float* x_in, const void* delta, const float* gamma, const float* beta, float eps,
                      float* x_out, void* y_out, int M, int D, int dtype, as_stream_t stream);
 
-/* k x k / stride-k max pooling of a token-major (NHWC) fp32 map [B,H,W,C] -> [B,H/k,W/k,C]: the FPN's coarsest tap,
- * nn.MaxPool2d(k, k) (mmdet/models/backbones/visual_transformer_det.py:107-127) on the layout the taps live in here.
- * C % 4 == 0, H and W multiples of k; NaNs propagate as in ATen. */
-int as_maxpool_nhwc(const float* x, float* out, int B, int H, int W, int C, int k, as_stream_t stream);
+/* k x k / stride-k max pooling of a token-major (NHWC) fp32 map [B,H,W,C] -> [B,H/k,W/k,C] (contiguous): the FPN's
+ * coarsest tap, nn.MaxPool2d(k, k) (mmdet/models/backbones/visual_transformer_det.py:120,129,133) on the layout the taps
+ * live in here.  x_batch_stride = elements between consecutive images of x (>= H*W*C, multiple of 4): the tap is the
+ * patch-token slice of the [B, 1+Np+T, C] token tensor, so its images are not adjacent.  C % 4 == 0, H and W multiples
+ * of k; NaNs propagate as in ATen. */
+int as_maxpool_nhwc(const float* x, float* out, int B, int H, int W, int C, int k, long long x_batch_stride,
+                    as_stream_t stream);
 
 /* Backward of as_add_layernorm for the trainable path.  x [M,D] fp32 = the x_out the forward wrote (x_in + delta); dy
  * [M,D] in `dtype` = gradient of y_out (NULL: the call was add-only); dx_res [M,D] fp32 = gradient of x_out from the

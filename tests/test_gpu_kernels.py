@@ -227,6 +227,14 @@ def test_maxpool_nhwc_equals_max_pool2d(ops, B, H, W, C, k):
     got = ops.maxpool_nhwc(dev(x), k).cpu()
     assert got.shape == ref.shape
     assert torch.equal(torch.nan_to_num(got, nan=-7.0), torch.nan_to_num(ref, nan=-7.0))
+    # the form the backbone uses: the patch-token slice of [B, 1 + Np + T, C] -- dense images, strided batch, no copy
+    tokens = torch.zeros(B, 1 + H * W + 5, C)
+    tokens[:, 1:1 + H * W] = x.reshape(B, H * W, C)
+    tok_dev = dev(tokens)
+    view = tok_dev[:, 1:1 + H * W].reshape(B, H, W, C) if B == 1 else tok_dev[:, 1:1 + H * W].unflatten(1, (H, W))
+    assert B == 1 or not view.is_contiguous()
+    got2 = ops.maxpool_nhwc(view, k).cpu()
+    assert torch.equal(torch.nan_to_num(got2, nan=-7.0), torch.nan_to_num(ref, nan=-7.0))
 
 
 @pytest.mark.parametrize("M,D", [(297, 192), (1000, 768), (77, 1024), (5, 128)])

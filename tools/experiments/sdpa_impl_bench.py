@@ -92,13 +92,15 @@ def main():
         w = (torch.randn(3 * D, D, generator=g) * a.scale).cuda().bfloat16()
         bias = (torch.randn(3 * D, generator=g) * 0.1).cuda()
         q, k, vt = ops.qkv_fwd(x, w, bias, h)
+        if os.environ.get("SDPA_ZEROS"):                     # power / clock probe: same instruction stream, operands all zero
+            q.zero_(); k.zero_(); vt.zero_()
         ref_o, ref_lse = reference(ops, ops.q_from_fragment_major(q), k, vt, N)
         flops = 4.0 * B * h * N * N * 64
         for v in variants:
             v.prepare(q, k, vt, N)
             v.call()
             torch.cuda.synchronize()
-            err = (v.o.float() - ref_o).abs().max().item() / ref_o.abs().max().item()
+            err = (v.o.float() - ref_o).abs().max().item() / max(ref_o.abs().max().item(), 1e-30)
             lerr = (v.lse - ref_lse).abs().max().item()
             print(f"[{shp}] {v.spec:10s}: max err / range {err:.3e}   lse max abs err {lerr:.3e}   finite {bool(torch.isfinite(v.o.float()).all())}", flush=True)
         times = {v.spec: [] for v in variants}

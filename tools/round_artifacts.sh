@@ -1,0 +1,22 @@
+#!/bin/bash
+# GPU-box: the measurements a round's profiles/ entries come from, in one call.  usage: tools/round_artifacts.sh r03
+# Writes gpurun_out/<R>_*: full default bench line (+ wall time), rocprofv3 kernel stats of the headline leg, kernel_bench,
+# PMC summaries of the shift / roll-out / GEMM kernels and the per-call HBM traffic of as_cosine_shift.
+R=${1:-rXX}
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+t0=$(date +%s)
+timeout 600 python bench.py > gpurun_out/${R}_bench_final.log 2>&1
+echo "default bench.py wall: $(( $(date +%s) - t0 )) s" | tee gpurun_out/${R}_bench_wall.txt
+tail -1 gpurun_out/${R}_bench_final.log > gpurun_out/${R}_bench_final.json
+AS_BENCH_OTHER_RNG=0 AS_BENCH_MIL=0 PROF_LINES=8 tools/prof_cmd.sh ${R}_bench_kernel_stats_final python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --train-steps 0 --other-configs "" > /dev/null 2>&1
+timeout 300 python tools/kernel_bench.py --reps 20 > gpurun_out/${R}_kernel_bench.jsonl 2>&1
+bash tools/pmc_call_traffic.sh ${R}_shift_traffic > gpurun_out/${R}_shift_traffic.log 2>&1
+for k in shift_sim shift_assign shift_aggregate shift_final_sim; do
+  PMC_TAG=${R}_$k PMC_FILTER=${k}_kernel PMC_CMD="python $GRAFT_REPO_ROOT/tools/kernel_bench.py --reps 6 --only shift" bash tools/pmc_sdpa_impl.sh auto > /dev/null 2>&1
+done
+PMC_TAG=${R}_rollout_step4 PMC_FILTER=rollout_step4 PMC_CMD="python $GRAFT_REPO_ROOT/tools/kernel_bench.py --reps 8 --only rollout" bash tools/pmc_sdpa_impl.sh auto > /dev/null 2>&1
+PMC_TRAFFIC=1 PMC_TAG=${R}_gemm_fc1 PMC_FILTER=gemm_glds PMC_CMD="python $GRAFT_REPO_ROOT/tools/experiments/gemm_variant_bench.py _one --variants base --shapes 8394x3072x768" bash tools/pmc_sdpa_impl.sh auto > /dev/null 2>&1
+PMC_TRAFFIC=1 PMC_TAG=${R}_gemm_fc2 PMC_FILTER=gemm_glds PMC_CMD="python $GRAFT_REPO_ROOT/tools/experiments/gemm_variant_bench.py _one --variants base --shapes 8394x768x3072" bash tools/pmc_sdpa_impl.sh auto > /dev/null 2>&1
+ls gpurun_out | grep ${R}_
+cat gpurun_out/${R}_bench_wall.txt
