@@ -40,6 +40,42 @@ def attention(x, w_qkv, b_qkv, w_proj, b_proj, num_heads, sink=None):
     return AttentionFn.apply(x, w_qkv, b_qkv, w_proj, b_proj, num_heads, sink)
 
 
+class ParamCastFn(torch.autograd.Function):
+    """Compute-dtype copies of MANY parameters in one multi-tensor pass, differentiable: what `p.to(bf16)` per parameter
+    and per forward does under apex O1 / autocast (the reference trains that way, run_train.py), without its one cast
+    launch per parameter in the forward and one per gradient in the backward (ViT-B: 72 + 72 launches per step).
+    forward(dtype, *params) -> tuple of `dtype` copies (views of one flat buffer); backward: the copies' gradients are
+    converted back to the parameters' dtype by one multi-tensor copy."""
+
+    @staticmethod
+    def forward(ctx, dtype, *params):
+        ctx.meta = [(p.dtype, p.shape) for p in params]
+        flat = torch.empty(sum(p.numel() for p in params), device=params[0].device, dtype=dtype)
+        outs = [v.view(p.shape) for v, p in zip(flat.split([p.numel() for p in params]), params)]
+        torch._foreach_copy_(outs, [p.detach() for p in params])
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        idx = [i for i, g in enumerate(grads) if g is not None]
+        res = [None] * len(grads)
+        if idx:
+            outs = [torch.empty(ctx.meta[i][1], device=grads[i].device, dtype=ctx.meta[i][0]) for i in idx]
+            torch._foreach_copy_(outs, [grads[i] for i in idx])
+            for o, i in zip(outs, idx):
+                res[i] = o
+        return (None, *res)
+
+
+def cast_params(params, dtype):
+    """{id(p): copy of p in `dtype`} for a list of parameters (one fused cast; differentiable when grad is enabled)."""
+    params = list(params)
+    if not params:
+        return {}
+    outs = ParamCastFn.apply(dtype, *params)
+    return {id(p): o for p, o in zip(params, outs)}
+
+
 class AddLayerNormFn(torch.autograd.Function):
     """(x_out, y) = (x + delta, LayerNorm(x + delta) * gamma + beta) in one pass forward (as_add_layernorm) and one pass
     backward (as_add_layernorm_bwd): the residual glue of Block.forward (models/vision_transformer.py:109-124).

@@ -17,6 +17,7 @@ What is different underneath:
     deconvolutions (one GEMM over tokens each) go through the same GEMM kernel (ops.linear).
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -350,8 +351,10 @@ class VisionTransformerDet(nn.Module):
         if rate == 0.0 or not self.training:
             return x
         keep = 1.0 - rate
-        mask = torch.rand(x.shape[0], 1, 1, device=x.device, dtype=x.dtype).add_(keep).floor_()
-        return x / keep * mask
+        # x / keep * mask with mask in {0, 1} as ONE multiply by mask / keep (a [B,1,1] tensor): one launch forward and one
+        # backward instead of two each; differs from the reference's x.div(keep) * mask by the rounding of 1 / keep only
+        mask = torch.rand(x.shape[0], 1, 1, device=x.device, dtype=torch.float32).add_(keep).floor_().div_(keep)
+        return x * mask.to(x.dtype)
 
     def _prepare_tokens_train(self, img):
         B, C, w, h = img.shape
@@ -373,12 +376,14 @@ class VisionTransformerDet(nn.Module):
         8a/A4).  `delta` = the previous block's MLP output not yet added; returns (x, this block's pending MLP output)."""
         from . import autograd as AG
         cd = self.compute_dtype
+        sh = self._train_shadow                          # compute-dtype copies of the blocks' GEMM parameters (forward())
+        w = lambda p: sh[id(p)] if id(p) in sh else p.to(cd)                      # noqa: E731
         x, y = AG.add_layernorm(x, delta, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps, cd)
-        a = AG.attention(y, blk.attn.qkv.weight.to(cd), None if blk.attn.qkv.bias is None else blk.attn.qkv.bias.float(),
-                         blk.attn.proj.weight.to(cd), blk.attn.proj.bias.float(), self.num_heads, sink)
+        a = AG.attention(y, w(blk.attn.qkv.weight), None if blk.attn.qkv.bias is None else blk.attn.qkv.bias.float(),
+                         w(blk.attn.proj.weight), blk.attn.proj.bias.float(), self.num_heads, sink)
         x, z = AG.add_layernorm(x, self._drop_path(a, i), blk.norm2.weight, blk.norm2.bias, blk.norm2.eps, cd)
-        z = F.gelu(F.linear(z, blk.mlp.fc1.weight.to(cd), blk.mlp.fc1.bias.to(cd)))
-        z = F.linear(z, blk.mlp.fc2.weight.to(cd), blk.mlp.fc2.bias.to(cd))
+        z = F.gelu(F.linear(z, w(blk.mlp.fc1.weight), w(blk.mlp.fc1.bias)))
+        z = F.linear(z, w(blk.mlp.fc2.weight), w(blk.mlp.fc2.bias))
         return x, self._drop_path(z, i)
 
     def forward(self, x):
@@ -415,6 +420,15 @@ class VisionTransformerDet(nn.Module):
 
         tap_due = False                                    # the previous block is a tap whose MLP output is still pending
         nblk = len(self.blocks)
+        self._train_shadow = {}
+        if grad_path and self.compute_dtype != torch.float32 and not os.environ.get("AS_NO_PARAM_SHADOW"):
+            # every GEMM parameter of the blocks in the compute dtype by ONE fused, differentiable cast (autograd.ParamCastFn)
+            from .autograd import cast_params
+            ps = []
+            for blk in self.blocks:
+                ps += [blk.attn.qkv.weight, blk.attn.proj.weight, blk.mlp.fc1.weight, blk.mlp.fc1.bias, blk.mlp.fc2.weight,
+                       blk.mlp.fc2.bias]
+            self._train_shadow = cast_params([p for p in ps if p.dtype != self.compute_dtype], self.compute_dtype)
         for i, blk in enumerate(self.blocks):
             if grad_path:
                 sink = [] if self.return_attention else None
@@ -436,6 +450,7 @@ class VisionTransformerDet(nn.Module):
                 attns.append(st)
             if self.last_feat and not self.recompute_last_feat and i == nblk - 1:
                 last_feat = x[:, :-T]
+        self._train_shadow = {}                            # (the consumers' autograd nodes hold what backward needs)
         org_features = store[0].permute(1, 0, 4, 2, 3) if store else None
         if org_features is None:
             org_features = torch.stack(features, dim=1)

@@ -73,7 +73,8 @@ template <typename T> int colsum(const void* in, float* out, float* part, int R,
 
 struct BwdLayout {
   size_t es, M, Mpad, D;
-  size_t off_sdpa, off_do, off_dqkv, off_doutT, off_oT, off_dqkvT, off_xT, off_WprojT, off_WqkvT, off_part, total;
+  size_t off_sdpa, off_do, off_dqkv, off_doutT, off_oT, off_dqkvT, off_xT, off_WprojT, off_WqkvT, off_part, off_splitk,
+      splitk_bytes, total;
 };
 BwdLayout bwd_layout(int B, int N, int D, int h, int dtype) {
   BwdLayout L{};
@@ -93,6 +94,9 @@ BwdLayout bwd_layout(int B, int N, int D, int h, int dtype) {
   L.off_WprojT = take((size_t)D * D * L.es);
   L.off_WqkvT = take((size_t)3 * D * D * L.es);
   L.off_part = take((size_t)CS_SLICES * 3 * D * sizeof(float));
+  // fp32 partial products of the split-K weight-gradient GEMMs (bf16 only; the larger of the two: dWqkv)
+  L.splitk_bytes = dtype == AS_BF16 ? as_linear_splitk_workspace_bytes(3 * D, D, (int)L.Mpad) : 0;
+  L.off_splitk = take(L.splitk_bytes);
   L.total = off;
   return L;
 }
@@ -115,7 +119,12 @@ int attn_bwd(const void* x, const void* Wqkv, const void* Wproj, const void* dou
   STEP(as_linear_fwd(dout, ws + L.off_WprojT, nullptr, d_o, M, D, D, dtype, 0, s));           // d_o = dout . Wproj
   STEP(transpose_pad<T>(dout, ws + L.off_doutT, M, D, Mpad, s));
   STEP(transpose_pad<T>(o, ws + L.off_oT, M, D, Mpad, s));
-  STEP(as_linear_fwd(ws + L.off_doutT, ws + L.off_oT, nullptr, dWproj, D, D, Mpad, dtype, 0, s));   // dout^T . o
+  // weight gradients contract over the TOKENS (K = Mpad = 8448 at config 2) into a few dozen output tiles: split-K with
+  // fixed-order fp32 partials fills the chip (dWproj: 36 tiles -> 16 K ranges; dWqkv: 108 -> 7)
+  if (sizeof(T) == 2)
+    STEP(as_linear_splitk_fwd(ws + L.off_doutT, ws + L.off_oT, dWproj, D, D, Mpad, dtype, 0, ws + L.off_splitk, L.splitk_bytes, s));
+  else
+    STEP(as_linear_fwd(ws + L.off_doutT, ws + L.off_oT, nullptr, dWproj, D, D, Mpad, dtype, 0, s));   // dout^T . o
   if (dbproj) STEP(colsum<T>(dout, dbproj, (float*)(ws + L.off_part), M, D, s));
   // attention core
   STEP(as_sdpa_bwd(q, k, vt, o, d_o, lse, dqkv, ws + L.off_sdpa, as_sdpa_bwd_workspace_bytes(B, N, h, dtype), B, N, h,
@@ -125,7 +134,10 @@ int attn_bwd(const void* x, const void* Wqkv, const void* Wproj, const void* dou
   STEP(as_linear_fwd(dqkv, ws + L.off_WqkvT, nullptr, dx, M, D, 3 * D, dtype, 0, s));         // dx = dqkv . Wqkv
   STEP(transpose_pad<T>(dqkv, ws + L.off_dqkvT, M, 3 * D, Mpad, s));
   STEP(transpose_pad<T>(x, ws + L.off_xT, M, D, Mpad, s));
-  STEP(as_linear_fwd(ws + L.off_dqkvT, ws + L.off_xT, nullptr, dWqkv, 3 * D, D, Mpad, dtype, 0, s)); // dqkv^T . x
+  if (sizeof(T) == 2)
+    STEP(as_linear_splitk_fwd(ws + L.off_dqkvT, ws + L.off_xT, dWqkv, 3 * D, D, Mpad, dtype, 0, ws + L.off_splitk, L.splitk_bytes, s));
+  else
+    STEP(as_linear_fwd(ws + L.off_dqkvT, ws + L.off_xT, nullptr, dWqkv, 3 * D, D, Mpad, dtype, 0, s)); // dqkv^T . x
   if (dbqkv) STEP(colsum<T>(dqkv, dbqkv, (float*)(ws + L.off_part), M, 3 * D, s));
 #undef STEP
   return AS_OK;

@@ -295,18 +295,21 @@ __global__ __launch_bounds__(64 * WM * WN, (WN == 4 || KS == 4) ? 1 : (WM == 2 ?
   // loader: per K step wave w moves NAP one-KiB pieces of A (tile rows 16p .. 16p+15 of piece p = NAP*w + j) and NWP of
   // the BN/16 pieces of W (2 + 2 per wave at 4 waves, 2 + 1 at 8, 1 + 1 at 16)
   const int lr = lane / CPR, lc = lane % CPR;
+  // MODE 3 (split-K): workgroup row blockIdx.y contracts over [kbeg, kbeg + klen) only and writes an fp32 partial tile
+  const int kbeg = MODE == 3 ? (int)blockIdx.y * epi.N : 0;
+  const int klen = MODE == 3 ? min(epi.N, K - kbeg) : K;
   constexpr int NAP = GT::A_PIECES, NWP = GT::W_PIECES;
   const char* srcA[NAP];
   const char* srcW[NWP];
 #pragma unroll
   for (int j = 0; j < NAP; ++j) {
     const int r = (wave * NAP + j) * PROWS + lr;
-    srcA[j] = reinterpret_cast<const char*>(A + (size_t)min(m0 + r, M - 1) * K) + (lc ^ g_swz<KS>(r)) * 16;
+    srcA[j] = reinterpret_cast<const char*>(A + (size_t)min(m0 + r, M - 1) * K + kbeg) + (lc ^ g_swz<KS>(r)) * 16;
   }
 #pragma unroll
   for (int j = 0; j < NWP; ++j) {
     const int r = (wave * NWP + j) * PROWS + lr;
-    srcW[j] = reinterpret_cast<const char*>(W + (size_t)min(n0 + r, Nout - 1) * K) + (lc ^ g_swz<KS>(r)) * 16;
+    srcW[j] = reinterpret_cast<const char*>(W + (size_t)min(n0 + r, Nout - 1) * K + kbeg) + (lc ^ g_swz<KS>(r)) * 16;
   }
   auto stage = [&](int kt, int buf) {
     char* base = smem + buf * G_STAGE;
@@ -343,7 +346,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WN == 4 || KS == 4) ? 1 : (WM == 2 ?
     }
   }
 
-  const int nk = K / GK;
+  const int nk = klen / GK;
   {
   stage(0, 0);
 #pragma unroll
@@ -411,6 +414,29 @@ __global__ __launch_bounds__(64 * WM * WN, (WN == 4 || KS == 4) ? 1 : (WM == 2 ?
 
   // ---------------- epilogue ----------------
   // lane -> token row m = m0 + wm*64 + i*32 + li; register r of block (i,j) -> column n0 + wn*64 + j*32 + acc_row(r,half)
+  if constexpr (MODE == 3) {
+    // fp32 partial of this K range, straight from the accumulators: lane = row, registers 4g .. 4g+3 = 4 consecutive columns
+    float* part = reinterpret_cast<float*>(epi.q) + (size_t)blockIdx.y * M * Nout;
+#pragma unroll
+    for (int i = 0; i < RI; ++i) {
+      const int row = m0 + wm * (32 * RI) + i * 32 + li;
+      if (row >= M) continue;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int col = n0 + wn * 64 + j * 32 + 8 * g + 4 * half;
+          float* dst = part + (size_t)row * Nout + col;
+          if (col + 4 <= Nout) {
+            *reinterpret_cast<float4*>(dst) = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+          } else {
+            for (int x = 0; x < 4; ++x)
+              if (col + x < Nout) dst[x] = acc[i][j][4 * g + x];
+          }
+        }
+    }
+    return;
+  }
   const bool vtile = MODE == 1 && n0 >= 2 * epi.D;   // block-uniform: the whole 128-column tile is V
   if (vtile) {
     if (AS_GEMM_ABLATE == 5) return;
@@ -499,7 +525,7 @@ int launch_gemm_glds_wm(const void* A, const void* W, const float* bias, void* o
                         QkvEpi epi, hipStream_t s) {
   using GT = GTile<WM, WN, RI, KS>;
   const int tiles = as_ceil_div(M, GT::BM_) * as_ceil_div(Nout, GT::BN_);
-  dim3 grid(8 * as_ceil_div(tiles, 8));              // 1-D, padded to a multiple of the 8 XCDs (see the tile order)
+  dim3 grid(8 * as_ceil_div(tiles, 8), MODE == 3 ? as_ceil_div(K, epi.N) : 1);   // x padded to a multiple of the 8 XCDs (tile order)
   // ring 48 / 72 / 96 KiB; the epilogue restages the output tile in the same memory (35 / 70 / 133 KiB)
   const size_t lds = (size_t)GT::LDS;
   static bool attr_set = false;
@@ -563,7 +589,73 @@ int launch_gemm(const void* A, const void* W, const float* bias, void* out, int 
   return AS_OK;
 }
 
+// out[e] = sum over the S partials in split order (fixed order: deterministic), converted to T
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, T* __restrict__ out, size_t n4, int S,
+                                                            size_t stride) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    float4 a = *reinterpret_cast<const float4*>(part + i * 4);
+    for (int sp = 1; sp < S; ++sp) {
+      const float4 b = *reinterpret_cast<const float4*>(part + sp * stride + i * 4);
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    if constexpr (sizeof(T) == 2) {
+      bf16x4 v = {(__bf16)a.x, (__bf16)a.y, (__bf16)a.z, (__bf16)a.w};
+      *reinterpret_cast<bf16x4*>(out + i * 4) = v;
+    } else {
+      *reinterpret_cast<float4*>(out + i * 4) = a;
+    }
+  }
+}
+
+// K ranges of the split-K form: as many as fill the 768 resident slots of the 128 x 128 tile once (<= 16), each a multiple
+// of the K step and at least 256 long
+int splitk_chunk(int M, int Nout, int K, int* splits) {
+  const int tiles = as_ceil_div(M, 128) * as_ceil_div(Nout, 128);
+  int S = 768 / (tiles > 0 ? tiles : 1);
+  if (S > 16) S = 16;
+  if (S < 1) S = 1;
+  int chunk = as_round_up(as_ceil_div(K, S), GK);
+  if (chunk < 256) chunk = 256;
+  if (chunk > K) chunk = K;
+  *splits = as_ceil_div(K, chunk);
+  return chunk;
+}
+
 }  // namespace
+
+extern "C" size_t as_linear_splitk_workspace_bytes(int M, int Nout, int K) {
+  if (M <= 0 || Nout <= 0 || K <= 0) return 0;
+  int S = 1;
+  (void)splitk_chunk(M, Nout, K, &S);
+  return (size_t)S * M * Nout * sizeof(float);
+}
+
+extern "C" int as_linear_splitk_fwd(const void* x, const void* W, void* out, int M, int Nout, int K, int dtype, int out_f32,
+                                    void* workspace, size_t workspace_bytes, as_stream_t stream) {
+  AS_REQUIRE(x && W && out, AS_E_BADARG, "as_linear_splitk_fwd: null pointer");
+  AS_REQUIRE(M > 0 && Nout > 0 && K > 0 && K % GK == 0 && Nout % 4 == 0, AS_E_BADARG,
+             "as_linear_splitk_fwd: need M, N > 0, K %% 32 == 0, N %% 4 == 0 (N=%d K=%d)", Nout, K);
+  AS_REQUIRE(dtype == AS_BF16, AS_E_UNSUPPORTED, "as_linear_splitk_fwd: bf16 operands only (dtype %d)", dtype);
+  int S = 1;
+  const int chunk = splitk_chunk(M, Nout, K, &S);
+  AS_REQUIRE(workspace && workspace_bytes >= (size_t)S * M * Nout * sizeof(float), AS_E_BADARG,
+             "as_linear_splitk_fwd: workspace too small (%zu < %zu)", workspace_bytes, (size_t)S * M * Nout * sizeof(float));
+  hipStream_t s = (hipStream_t)stream;
+  QkvEpi epi{workspace, nullptr, nullptr, chunk, 0, 0, 0};
+  const int rc = launch_gemm_glds_wm<3, 2, 2, 2, 2>(x, W, nullptr, nullptr, M, Nout, K, 0, epi, s);
+  if (rc != AS_OK) return rc;
+  const size_t n4 = (size_t)M * Nout / 4;
+  const int grid = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+  if (out_f32)
+    hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)workspace, (float*)out, n4, S,
+                       (size_t)M * Nout);
+  else
+    hipLaunchKernelGGL(splitk_reduce_kernel<__bf16>, dim3(grid), dim3(256), 0, s, (const float*)workspace, (__bf16*)out, n4, S,
+                       (size_t)M * Nout);
+  AS_CHECK_LAUNCH("splitk_reduce");
+  return AS_OK;
+}
 
 extern "C" int as_npad(int N) { return as_round_up(N, 64); }
 

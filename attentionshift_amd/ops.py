@@ -119,6 +119,24 @@ def linear(x, weight, bias=None, act="none"):
     return out.reshape(*x.shape[:-1], weight.shape[0])
 
 
+def linear_splitk(x, weight, out_dtype=None):
+    """x @ weight.T for bf16 x [M,K], weight [Nout,K] with the contraction split over workgroups (fixed-order fp32
+    partials): the shape of a weight gradient, dW = dy^T x with the tokens as K.  out_dtype: bf16 (default) or fp32."""
+    lib = _lib.load()
+    _chk(x, weight, dtype=torch.bfloat16)
+    M, K = x.shape
+    Nout = weight.shape[0]
+    if weight.shape[1] != K:
+        raise AttnShiftError("linear_splitk: weight must be [Nout, K]")
+    out_dtype = out_dtype or torch.bfloat16
+    out = torch.empty(M, Nout, device=x.device, dtype=out_dtype)
+    nbytes = int(lib.as_linear_splitk_workspace_bytes(M, Nout, K))
+    ws = torch.empty(max(nbytes, 4) // 4, device=x.device, dtype=torch.float32)
+    _lib.check(lib.as_linear_splitk_fwd(_p(x), _p(weight), _p(out), M, Nout, K, AS_BF16, 1 if out_dtype == torch.float32 else 0,
+                                        _p(ws), nbytes, _stream()), "as_linear_splitk_fwd")
+    return out
+
+
 def deconv2x2(x_nhwc, w4, bias4=None, act="none"):
     """ConvTranspose2d(k=2, s=2) on a channels-last bf16 map [B,h,w,cin] -> [B,2h,2w,cout] (one GEMM, scattered epilogue).
     w4 [4*cout, cin] bf16 (row (di*2+dj)*cout + co), bias4 [4*cout] fp32 | None."""

@@ -243,7 +243,7 @@ def build(device, rng_mode="fast", train=False, ranks=None, mil=False):
         if grad_clip is not None:
             torch.nn.utils.clip_grad_norm_(params, **grad_clip)
         opt.step()
-        opt.zero_grad(set_to_none=False)
+        opt.zero_grad(set_to_none=True)                    # (torch's default, what the reference's optimizer hook calls)
         return log_vars
 
     train_step.head = head

@@ -132,6 +132,14 @@ int as_window_attn_fwd(const void* qkv, const float* bqkv, const float* table, v
 int as_add_layernorm(const float* x_in, const void* delta, const float* gamma, const float* beta, float eps,
                      float* x_out, void* y_out, int M, int D, int dtype, as_stream_t stream);
 
+/* out[M,Nout] = x[M,K] . W[Nout,K]^T (no bias, no activation) with the CONTRACTION split over workgroups: fp32 partial
+ * products of K ranges, summed in range order (deterministic), written as bf16 (out_f32 = 0) or fp32 (1).  The form of an
+ * nn.Linear WEIGHT gradient dW = dy^T . x (models/vision_transformer.py:75-77,84 under autograd): few output tiles, the
+ * tokens as K.  bf16 operands, K % 32 == 0, Nout % 4 == 0; workspace: as_linear_splitk_workspace_bytes(M, Nout, K). */
+size_t as_linear_splitk_workspace_bytes(int M, int Nout, int K);
+int as_linear_splitk_fwd(const void* x, const void* W, void* out, int M, int Nout, int K, int dtype, int out_f32,
+                         void* workspace, size_t workspace_bytes, as_stream_t stream);
+
 /* k x k / stride-k max pooling of a token-major (NHWC) fp32 map [B,H,W,C] -> [B,H/k,W/k,C] (contiguous): the FPN's
  * coarsest tap, nn.MaxPool2d(k, k) (mmdet/models/backbones/visual_transformer_det.py:120,129,133) on the layout the taps
  * live in here.  x_batch_stride = elements between consecutive images of x (>= H*W*C, multiple of 4): the tap is the

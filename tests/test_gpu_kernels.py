@@ -68,6 +68,22 @@ def test_linear_bf16_backbone_shapes(ops, M, N, K, act):
     assert mx < 1e-2 and mean < 2e-3, (mx, mean)      # output rounding to bf16 dominates
 
 
+@pytest.mark.parametrize("M,N,K", [(768, 768, 8448), (2304, 768, 8448), (3072, 768, 8448), (200, 132, 96), (130, 64, 4096)])
+@pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float32])
+def test_linear_splitk_matches_fp32_matmul(ops, M, N, K, out_dtype):
+    """as_linear_splitk_fwd (the weight-gradient GEMM form: tokens as K, contraction split over workgroups, fixed-order fp32
+    partials) vs an fp32 matmul of the same bf16 operands; run twice: bitwise equal (no atomics)."""
+    g = torch.Generator().manual_seed(M + N + K)
+    x = (torch.randn(M, K, generator=g) * 0.5).bfloat16()
+    w = (torch.randn(N, K, generator=g) * 0.5).bfloat16()
+    ref = x.double() @ w.double().t()
+    got = ops.linear_splitk(dev(x), dev(w), out_dtype)
+    assert got.dtype == out_dtype and got.shape == (M, N)
+    mx, mean = rel_to_range(ref, got.float())
+    assert mx < (1e-2 if out_dtype == torch.bfloat16 else 2e-5) and mean < 2e-3, (mx, mean)
+    assert torch.equal(got, ops.linear_splitk(dev(x), dev(w), out_dtype))
+
+
 def test_linear_bf16(ops):
     g = torch.Generator().manual_seed(1)
     x, w, b = torch.randn(513, 768, generator=g), torch.randn(384, 768, generator=g) * 0.05, torch.randn(384, generator=g)
