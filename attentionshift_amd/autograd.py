@@ -79,34 +79,37 @@ def cast_params(params, dtype):
 class AddLayerNormFn(torch.autograd.Function):
     """(x_out, y) = (x + delta, LayerNorm(x + delta) * gamma + beta) in one pass forward (as_add_layernorm) and one pass
     backward (as_add_layernorm_bwd): the residual glue of Block.forward (models/vision_transformer.py:109-124).
-    x fp32 [B,N,D] residual stream, delta `out_dtype` | None (the previous sub-layer's output), y in `out_dtype`."""
+    x fp32 [B,N,D] residual stream, delta `out_dtype` | None (the previous sub-layer's output), y in `out_dtype`.
+    delta_scale fp32 [B] | None: x_out = x + delta_scale[b] * delta -- the DropPath around the sub-layer
+    (models/vision_transformer.py:117,122) folded into the add, in fp32, at no extra pass; not differentiated."""
 
     @staticmethod
-    def forward(ctx, x, delta, gamma, beta, eps, out_dtype):
+    def forward(ctx, x, delta, gamma, beta, eps, out_dtype, delta_scale=None):
         x = x.contiguous()
         delta = None if delta is None else delta.contiguous()
         g, b = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
-        x_out, y = ops.add_layernorm(x, delta, g, b, eps, out_dtype)
+        sc = None if (delta_scale is None or delta is None) else delta_scale.detach().float().contiguous()
+        x_out, y = ops.add_layernorm(x, delta, g, b, eps, out_dtype, delta_scale=sc)
         ctx.set_materialize_grads(False)                 # an unused output arrives as None, not as a zero tensor
-        ctx.save_for_backward(x_out, g)
+        ctx.save_for_backward(x_out, g, sc)
         ctx.cfg = (float(eps), out_dtype, delta is not None, gamma.dtype)
         return x_out, y
 
     @staticmethod
     def backward(ctx, dx_out, dy):
-        x_out, g = ctx.saved_tensors
+        x_out, g, sc = ctx.saved_tensors
         eps, out_dtype, has_delta, pdt = ctx.cfg
         if dx_out is None and dy is None:
-            return None, None, None, None, None, None
+            return None, None, None, None, None, None, None
         dx_out = None if dx_out is None else dx_out.contiguous()
         dy = None if dy is None else dy.to(out_dtype).contiguous()
         dx, dd, dg, db = ops.add_layernorm_bwd(x_out, dy, dx_out, g, eps, out_dtype, want_dx=ctx.needs_input_grad[0],
                                                want_ddelta=has_delta and ctx.needs_input_grad[1],
-                                               want_affine=ctx.needs_input_grad[2] or ctx.needs_input_grad[3])
+                                               want_affine=ctx.needs_input_grad[2] or ctx.needs_input_grad[3], delta_scale=sc)
         dg = None if dg is None or not ctx.needs_input_grad[2] else dg.to(pdt)
         db = None if db is None or not ctx.needs_input_grad[3] else db.to(pdt)
-        return dx, dd, dg, db, None, None
+        return dx, dd, dg, db, None, None, None
 
 
-def add_layernorm(x, delta, gamma, beta, eps, out_dtype):
-    return AddLayerNormFn.apply(x, delta, gamma, beta, eps, out_dtype)
+def add_layernorm(x, delta, gamma, beta, eps, out_dtype, delta_scale=None):
+    return AddLayerNormFn.apply(x, delta, gamma, beta, eps, out_dtype, delta_scale)

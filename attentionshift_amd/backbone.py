@@ -351,10 +351,18 @@ class VisionTransformerDet(nn.Module):
         if rate == 0.0 or not self.training:
             return x
         keep = 1.0 - rate
-        # x / keep * mask with mask in {0, 1} as ONE multiply by mask / keep (a [B,1,1] tensor): one launch forward and one
-        # backward instead of two each; differs from the reference's x.div(keep) * mask by the rounding of 1 / keep only
-        mask = torch.rand(x.shape[0], 1, 1, device=x.device, dtype=torch.float32).add_(keep).floor_().div_(keep)
-        return x * mask.to(x.dtype)
+        mask = torch.rand(x.shape[0], 1, 1, device=x.device, dtype=x.dtype).add_(keep).floor_()
+        return x / keep * mask
+
+    def _drop_scale(self, batch, i, device):
+        """The per-sample factor mask_b / keep of block i's DropPath as an fp32 vector [B] (None when inactive): the fused
+        residual add applies it in fp32 (autograd.AddLayerNormFn delta_scale) -- no pass over the tokens, forward or
+        backward.  Same draw as `_drop_path` (rand + keep, floor)."""
+        rate = self.drop_path_rate * i / max(self.depth - 1, 1)
+        if rate == 0.0 or not self.training:
+            return None
+        keep = 1.0 - rate
+        return torch.rand(batch, device=device, dtype=torch.float32).add_(keep).floor_().div_(keep)
 
     def _prepare_tokens_train(self, img):
         B, C, w, h = img.shape
@@ -369,7 +377,7 @@ class VisionTransformerDet(nn.Module):
         pt = (self.point_token + self.point_pos_embed).expand(B, -1, -1)
         return torch.cat((x, pt), dim=1)
 
-    def _block_train(self, blk, x, delta, i, sink):
+    def _block_train(self, blk, x, delta, i, sink, delta_scale=None):
         """Block.forward under autograd with the residual stream in fp32 and the residual adds fused into the LayerNorms in
         BOTH directions (autograd.AddLayerNormFn: as_add_layernorm / as_add_layernorm_bwd).  Attention =
         autograd.AttentionFn (as_attn_fwd / as_attn_bwd); the MLP GEMMs + GELU are torch ops (library GEMMs, SURVEY
@@ -378,13 +386,15 @@ class VisionTransformerDet(nn.Module):
         cd = self.compute_dtype
         sh = self._train_shadow                          # compute-dtype copies of the blocks' GEMM parameters (forward())
         w = lambda p: sh[id(p)] if id(p) in sh else p.to(cd)                      # noqa: E731
-        x, y = AG.add_layernorm(x, delta, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps, cd)
+        # `delta_scale` belongs to `delta` (the PREVIOUS block's MLP output and its DropPath factor); this block's two
+        # DropPaths (vision_transformer.py:117, :122) draw their own factors: independent draws, as in the reference
+        x, y = AG.add_layernorm(x, delta, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps, cd, delta_scale)
         a = AG.attention(y, w(blk.attn.qkv.weight), None if blk.attn.qkv.bias is None else blk.attn.qkv.bias.float(),
                          w(blk.attn.proj.weight), blk.attn.proj.bias.float(), self.num_heads, sink)
-        x, z = AG.add_layernorm(x, self._drop_path(a, i), blk.norm2.weight, blk.norm2.bias, blk.norm2.eps, cd)
+        x, z = AG.add_layernorm(x, a, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps, cd, self._drop_scale(x.shape[0], i, x.device))
         z = F.gelu(F.linear(z, w(blk.mlp.fc1.weight), w(blk.mlp.fc1.bias)))
         z = F.linear(z, w(blk.mlp.fc2.weight), w(blk.mlp.fc2.bias))
-        return x, self._drop_path(z, i)
+        return x, z, self._drop_scale(x.shape[0], i, x.device)
 
     def forward(self, x):
         """visual_transformer_det.py:221-275.  Under no-grad / eval every GEMM and the attention run on the HIP
@@ -399,6 +409,7 @@ class VisionTransformerDet(nn.Module):
         features, taps, attns = [], [], []
         store = []                                         # no-grad: token-major storage behind org_feats
         delta = None                                       # inference path: MLP output not yet added to x
+        dscale = None                                      # training path: the DropPath factor [B] that goes with `delta`
         if not grad_path:
             x = x.contiguous()
 
@@ -432,9 +443,10 @@ class VisionTransformerDet(nn.Module):
         for i, blk in enumerate(self.blocks):
             if grad_path:
                 sink = [] if self.return_attention else None
-                x, delta = self._block_train(blk, x.float() if x.dtype != torch.float32 else x, delta, i, sink)
+                x, delta, dscale = self._block_train(blk, x.float() if x.dtype != torch.float32 else x, delta, i, sink, dscale)
                 if i in self.out_indices or i == nblk - 1:                  # taps / output need the block's full result
-                    x, delta = x + delta.float(), None
+                    x = x + (delta.float() if dscale is None else delta.float() * dscale[:, None, None])
+                    delta, dscale = None, None
                 st = sink[0] if sink else None
                 if i in self.out_indices:
                     take_tap(x)

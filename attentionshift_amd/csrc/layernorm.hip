@@ -12,10 +12,11 @@ template <typename T, int VPL>   // VPL = float4 groups per lane: D <= 64 * 4 * 
 __global__ __launch_bounds__(256) void add_layernorm_kernel(const float* __restrict__ x_in, const T* __restrict__ delta,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             float* __restrict__ x_out, T* __restrict__ y_out, int M, int D,
-                                                            float eps) {
+                                                            float eps, const float* __restrict__ dscale, int rps) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= M) return;
   const size_t base = (size_t)row * D;
+  const float ds = dscale != nullptr ? dscale[row / rps] : 1.0f;    // per-sample scale of delta (stochastic depth)
   float v[VPL][4];
   float s = 0.0f;
 #pragma unroll
@@ -26,7 +27,8 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const float* __restr
       v[i][0] = a.x; v[i][1] = a.y; v[i][2] = a.z; v[i][3] = a.w;
       if (delta != nullptr) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) v[i][t] += to_f32<T>(delta[base + c + t]);
+        for (int t = 0; t < 4; ++t) v[i][t] = dscale != nullptr ? fmaf(ds, to_f32<T>(delta[base + c + t]), v[i][t])
+                                                                     : v[i][t] + to_f32<T>(delta[base + c + t]);
       }
       s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
     } else {
@@ -66,12 +68,12 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const float* __restr
 
 template <typename T>
 int launch_add_ln(const float* x_in, const void* delta, const float* gamma, const float* beta, float* x_out, void* y_out,
-                  int M, int D, float eps, hipStream_t s) {
+                  int M, int D, float eps, const float* dscale, int rps, hipStream_t s) {
   const int vpl = as_ceil_div(D, 256);
   dim3 grid(as_ceil_div(M, 4));
 #define AS_LN(V)                                                                                                   \
   hipLaunchKernelGGL((add_layernorm_kernel<T, V>), grid, dim3(256), 0, s, x_in, (const T*)delta, gamma, beta, x_out, \
-                     (T*)y_out, M, D, eps)
+                     (T*)y_out, M, D, eps, dscale, rps)
   switch (vpl) {
     case 1: AS_LN(1); break;
     case 2: AS_LN(2); break;
@@ -108,7 +110,7 @@ __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(const float* __r
                                                                 const float* __restrict__ dx_res,
                                                                 const float* __restrict__ gamma, float* __restrict__ dx_out,
                                                                 T* __restrict__ ddelta_out, float* __restrict__ part, int M,
-                                                                int D, float eps) {
+                                                                int D, float eps, const float* __restrict__ dscale, int rps) {
   __shared__ float red[2][4][VPL * 256];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   float dg[VPL][4], db[VPL][4], gm[VPL][4];
@@ -178,8 +180,9 @@ __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(const float* __r
         }
         if (dx_out != nullptr) *reinterpret_cast<float4*>(dx_out + base + c) = make_float4(o[0], o[1], o[2], o[3]);
         if (ddelta_out != nullptr) {
+          const float ds = dscale != nullptr ? dscale[row / rps] : 1.0f;        // d(x + ds * delta) / d delta
 #pragma unroll
-          for (int t = 0; t < 4; ++t) ddelta_out[base + c + t] = from_f32<T>(o[t]);
+          for (int t = 0; t < 4; ++t) ddelta_out[base + c + t] = from_f32<T>(ds * o[t]);
         }
       }
     }
@@ -223,18 +226,23 @@ constexpr int LNB_BLOCKS = 256;
 
 template <typename T>
 int launch_add_ln_bwd(const float* x, const void* dy, const float* dx_res, const float* gamma, float* dx_out, void* ddelta,
-                      float* dgamma, float* dbeta, float* part, int M, int D, float eps, hipStream_t s) {
+                      float* dgamma, float* dbeta, float* part, int M, int D, float eps, const float* dscale, int rps,
+                      hipStream_t s) {
   const int vpl = as_ceil_div(D, 256);
   const int nblk = as_ceil_div(M, 4) < LNB_BLOCKS ? as_ceil_div(M, 4) : LNB_BLOCKS;
 #define AS_LNB(V)                                                                                                    \
   hipLaunchKernelGGL((add_layernorm_bwd_kernel<T, V>), dim3(nblk), dim3(256), 0, s, x, (const T*)dy, dx_res, gamma, dx_out, \
-                     (T*)ddelta, part, M, D, eps)
+                     (T*)ddelta, part, M, D, eps, dscale, rps)
   switch (vpl) {
     case 1: AS_LNB(1); break;
     case 2: AS_LNB(2); break;
     case 3: AS_LNB(3); break;
     case 4: AS_LNB(4); break;
-    default: AS_REQUIRE(false, AS_E_UNSUPPORTED, "as_add_layernorm_bwd: D=%d (max 1024)", D);
+    case 5: AS_LNB(5); break;                        // D = 1280 (ViT-H)
+    case 6: AS_LNB(6); break;
+    case 7: AS_LNB(7); break;
+    case 8: AS_LNB(8); break;
+    default: AS_REQUIRE(false, AS_E_UNSUPPORTED, "as_add_layernorm_bwd: D=%d (max 2048)", D);
   }
 #undef AS_LNB
   AS_CHECK_LAUNCH("add_layernorm_bwd");
@@ -256,26 +264,44 @@ extern "C" size_t as_add_layernorm_bwd_workspace_bytes(int M, int D) {
 extern "C" int as_add_layernorm_bwd(const float* x, const void* dy, const float* dx_res, const float* gamma, float eps,
                                     float* dx_out, void* ddelta_out, float* dgamma, float* dbeta, void* workspace,
                                     size_t workspace_bytes, int M, int D, int dtype, as_stream_t stream) {
+  return as_add_layernorm_bwd_scaled(x, dy, dx_res, gamma, eps, dx_out, ddelta_out, dgamma, dbeta, workspace, workspace_bytes,
+                                     M, D, dtype, nullptr, 1, stream);
+}
+
+extern "C" int as_add_layernorm_bwd_scaled(const float* x, const void* dy, const float* dx_res, const float* gamma, float eps,
+                                           float* dx_out, void* ddelta_out, float* dgamma, float* dbeta, void* workspace,
+                                           size_t workspace_bytes, int M, int D, int dtype, const float* delta_scale,
+                                           int rows_per_scale, as_stream_t stream) {
   AS_REQUIRE(x && (dy || dx_res) && (dx_out || ddelta_out) && workspace, AS_E_BADARG, "as_add_layernorm_bwd: null pointer");
+  AS_REQUIRE(rows_per_scale > 0, AS_E_BADARG, "as_add_layernorm_bwd: rows_per_scale must be positive");
   AS_REQUIRE(M > 0 && D > 0 && D % 4 == 0, AS_E_BADARG, "as_add_layernorm_bwd: need M > 0 and D %% 4 == 0 (D=%d)", D);
   AS_REQUIRE(workspace_bytes >= as_add_layernorm_bwd_workspace_bytes(M, D), AS_E_WORKSPACE,
              "as_add_layernorm_bwd: workspace too small");
   hipStream_t s = (hipStream_t)stream;
   if (dtype == AS_BF16)
-    return launch_add_ln_bwd<__bf16>(x, dy, dx_res, gamma, dx_out, ddelta_out, dgamma, dbeta, (float*)workspace, M, D, eps, s);
+    return launch_add_ln_bwd<__bf16>(x, dy, dx_res, gamma, dx_out, ddelta_out, dgamma, dbeta, (float*)workspace, M, D, eps,
+                                     delta_scale, rows_per_scale, s);
   if (dtype == AS_F32)
-    return launch_add_ln_bwd<float>(x, dy, dx_res, gamma, dx_out, ddelta_out, dgamma, dbeta, (float*)workspace, M, D, eps, s);
+    return launch_add_ln_bwd<float>(x, dy, dx_res, gamma, dx_out, ddelta_out, dgamma, dbeta, (float*)workspace, M, D, eps,
+                                    delta_scale, rows_per_scale, s);
   AS_REQUIRE(false, AS_E_UNSUPPORTED, "as_add_layernorm_bwd: dtype %d", dtype);
 }
 
 extern "C" int as_add_layernorm(const float* x_in, const void* delta, const float* gamma, const float* beta, float eps,
                                 float* x_out, void* y_out, int M, int D, int dtype, as_stream_t stream) {
+  return as_add_layernorm_scaled(x_in, delta, gamma, beta, eps, x_out, y_out, M, D, dtype, nullptr, 1, stream);
+}
+
+extern "C" int as_add_layernorm_scaled(const float* x_in, const void* delta, const float* gamma, const float* beta, float eps,
+                                       float* x_out, void* y_out, int M, int D, int dtype, const float* delta_scale,
+                                       int rows_per_scale, as_stream_t stream) {
   AS_REQUIRE(x_in && (x_out || y_out), AS_E_BADARG, "as_add_layernorm: null pointer");
+  AS_REQUIRE(rows_per_scale > 0 && (!delta_scale || delta), AS_E_BADARG, "as_add_layernorm: delta_scale needs delta, rows_per_scale > 0");
   AS_REQUIRE(!y_out || (gamma && beta), AS_E_BADARG, "as_add_layernorm: y_out needs gamma and beta");
   AS_REQUIRE(M > 0 && D > 0 && D % 4 == 0, AS_E_BADARG, "as_add_layernorm: need M > 0 and D %% 4 == 0 (D=%d)", D);
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == AS_BF16) return launch_add_ln<__bf16>(x_in, delta, gamma, beta, x_out, y_out, M, D, eps, s);
-  if (dtype == AS_F32) return launch_add_ln<float>(x_in, delta, gamma, beta, x_out, y_out, M, D, eps, s);
+  if (dtype == AS_BF16) return launch_add_ln<__bf16>(x_in, delta, gamma, beta, x_out, y_out, M, D, eps, delta_scale, rows_per_scale, s);
+  if (dtype == AS_F32) return launch_add_ln<float>(x_in, delta, gamma, beta, x_out, y_out, M, D, eps, delta_scale, rows_per_scale, s);
   AS_REQUIRE(false, AS_E_UNSUPPORTED, "as_add_layernorm: dtype %d", dtype);
 }
 

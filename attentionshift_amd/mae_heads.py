@@ -295,9 +295,13 @@ class MAEMaskHeadPointSup(nn.Module):
         # matrix products (ATen's bicubic BACKWARD kernel needs 0.74 s for 256 RoIs x 256 channels on this GPU), and the
         # 1x1 mask-logit convolution as a matmul over the channel axis (MIOpen falls back to a naive weight-gradient
         # kernel for it).  Same operations in the same order as mae_mask_head_pointSup.py:186-189.
-        Ah = _resize_matrix(x.shape[1], self.scale_factor, self.scale_mode, x.device, x.dtype)
-        Aw = _resize_matrix(x.shape[2], self.scale_factor, self.scale_mode, x.device, x.dtype)
-        x = torch.einsum("oh,bhwc,pw->bopc", Ah, x, Aw)
+        # F.interpolate is not an autocast op: the reference resizes in the dtype the (fp32) LayerNorm produced, also under
+        # apex O1 / autocast -- keep the resize out of the low-precision region
+        with torch.autocast(x.device.type, enabled=False):
+            xf = x.float()
+            Ah = _resize_matrix(xf.shape[1], self.scale_factor, self.scale_mode, xf.device, xf.dtype)
+            Aw = _resize_matrix(xf.shape[2], self.scale_factor, self.scale_mode, xf.device, xf.dtype)
+            x = torch.einsum("oh,bhwc,pw->bopc", Ah, xf, Aw)
         wl = self.conv_logits.weight.view(self.conv_logits.out_channels, -1)
         return F.linear(x, wl, self.conv_logits.bias).permute(0, 3, 1, 2)
 

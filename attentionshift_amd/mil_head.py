@@ -53,7 +53,11 @@ def roi_align(feat, rois, output_size=7, spatial_scale=1.0 / 16, sampling_ratio=
     R = rois.shape[0]
     if R == 0:
         return feat.new_zeros(0, C, out, out)
-    if feat.is_cuda and C % 4 == 0:
+    # the HIP backward keeps fixed pixels x 8 channels per thread and its 1-D tables in LDS (csrc/roi_align.hip): outside its
+    # limits a trainable map takes the tensor-op path below instead of failing in backward
+    bwd_ok = (not (feat.requires_grad and torch.is_grad_enabled())) or (
+        C % 8 == 0 and H * W <= 8192 and (8 * out * (H + W) + 8 * out * out * 8 + 36 + R) * 4 <= 150 * 1024)
+    if feat.is_cuda and C % 4 == 0 and bwd_ok:
         # the HIP kernel (csrc/roi_align.hip): token-major in, [R, out*out, C] out; the [R, C, out, out] the heads expect
         # is a permuted VIEW of it (they flatten straight back to tokens)
         y = _RoIAlignFn.apply(feat.float(), rois.float().contiguous(), out, float(spatial_scale), int(sampling_ratio), bool(aligned))

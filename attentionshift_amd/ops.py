@@ -5,6 +5,8 @@ function validates device/dtype/contiguity, passes raw pointers and raises on an
 """
 import ctypes
 
+import threading
+
 import torch
 
 from . import _lib
@@ -152,8 +154,19 @@ def deconv2x2(x_nhwc, w4, bias4=None, act="none"):
     return out
 
 
-def add_layernorm(x, delta, gamma, beta, eps, out_dtype, want_x=True, want_y=True):
+def _scale_arg(delta_scale, x, delta):
+    """(pointer holder, rows per scale) of a per-sample delta scale [B] for x [B, N, D] (DropPath); None -> (None, 1)."""
+    if delta_scale is None:
+        return None, 1
+    if delta is None or x.dim() != 3 or delta_scale.numel() != x.shape[0]:
+        raise AttnShiftError("add_layernorm: delta_scale needs delta and x [B, N, D] with one scale per image")
+    _chk(delta_scale, dtype=torch.float32)
+    return delta_scale, x.shape[1]
+
+
+def add_layernorm(x, delta, gamma, beta, eps, out_dtype, want_x=True, want_y=True, delta_scale=None):
     """x_new = x + delta (fp32; delta may be None), y = LayerNorm(x_new) in `out_dtype` -- one pass (csrc/layernorm.hip).
+    delta_scale fp32 [B] | None: x_new = x + delta_scale[b] * delta (per-sample stochastic depth).
     Returns (x_new | None, y | None)."""
     lib = _lib.load()
     D = x.shape[-1]
@@ -166,8 +179,9 @@ def add_layernorm(x, delta, gamma, beta, eps, out_dtype, want_x=True, want_y=Tru
     x_out = torch.empty_like(x2) if (want_x and delta is not None) else None
     y = torch.empty(x2.shape, device=x.device, dtype=out_dtype) if want_y else None
     dt = AS_BF16 if out_dtype == torch.bfloat16 else AS_F32
-    _lib.check(lib.as_add_layernorm(_p(x2), _p(delta), _p(gamma), _p(beta), float(eps), _p(x_out), _p(y), x2.shape[0], D,
-                                    dt, _stream()), "as_add_layernorm")
+    sc, rps = _scale_arg(delta_scale, x, delta)
+    _lib.check(lib.as_add_layernorm_scaled(_p(x2), _p(delta), _p(gamma), _p(beta), float(eps), _p(x_out), _p(y), x2.shape[0], D,
+                                           dt, _p(sc), rps, _stream()), "as_add_layernorm")
     xo = x if (delta is None or not want_x) else x_out.reshape(x.shape)
     return (xo if want_x else None), (None if y is None else y.reshape(x.shape))
 
@@ -187,7 +201,7 @@ def maxpool_nhwc(x_nhwc, k):
     return out
 
 
-def add_layernorm_bwd(x_out, dy, dx_res, gamma, eps, dtype, want_dx=True, want_ddelta=True, want_affine=True):
+def add_layernorm_bwd(x_out, dy, dx_res, gamma, eps, dtype, want_dx=True, want_ddelta=True, want_affine=True, delta_scale=None):
     """Backward of add_layernorm (csrc/layernorm.hip): x_out fp32 [.., D] saved by the forward, dy (`dtype`) | None,
     dx_res fp32 | None, gamma fp32 [D] | None -> (dx fp32 | None, ddelta `dtype` | None, dgamma, dbeta fp32 [D] | None)."""
     lib = _lib.load()
@@ -197,7 +211,8 @@ def add_layernorm_bwd(x_out, dy, dx_res, gamma, eps, dtype, want_dx=True, want_d
     _chk(dy, dtype=dtype)
     M = x2.shape[0]
     dev = x_out.device
-    dx = torch.empty_like(x2) if want_dx else None
+    scratch = not want_dx and not want_ddelta          # only the affine gradients are wanted: the kernel still writes ONE of them
+    dx = torch.empty_like(x2) if (want_dx or scratch) else None
     dd = torch.empty(x2.shape, device=dev, dtype=dtype) if want_ddelta else None
     affine = want_affine and dy is not None
     dg = torch.empty(D, device=dev, dtype=torch.float32) if affine else None
@@ -205,9 +220,12 @@ def add_layernorm_bwd(x_out, dy, dx_res, gamma, eps, dtype, want_dx=True, want_d
     nbytes = lib.as_add_layernorm_bwd_workspace_bytes(M, D)
     ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
     dt = AS_BF16 if dtype == torch.bfloat16 else AS_F32
-    _lib.check(lib.as_add_layernorm_bwd(_p(x2), _p(dy), _p(dx_res), _p(gamma), float(eps), _p(dx), _p(dd), _p(dg), _p(db), _p(ws),
-                                        nbytes, M, D, dt, _stream()), "as_add_layernorm_bwd")
-    return (None if dx is None else dx.reshape(x_out.shape), None if dd is None else dd.reshape(x_out.shape), dg, db)
+    sc, rps = (None, 1) if delta_scale is None else (delta_scale, x_out.shape[1] if x_out.dim() == 3 else 1)
+    if sc is not None and (x_out.dim() != 3 or sc.numel() != x_out.shape[0]):
+        raise AttnShiftError("add_layernorm_bwd: delta_scale needs x_out [B, N, D] with one scale per image")
+    _lib.check(lib.as_add_layernorm_bwd_scaled(_p(x2), _p(dy), _p(dx_res), _p(gamma), float(eps), _p(dx), _p(dd), _p(dg), _p(db),
+                                               _p(ws), nbytes, M, D, dt, _p(sc), rps, _stream()), "as_add_layernorm_bwd")
+    return (None if dx is None or scratch else dx.reshape(x_out.shape), None if dd is None else dd.reshape(x_out.shape), dg, db)
 
 
 class AttnLayerState:
@@ -510,7 +528,12 @@ def semantic_prestage(map_fg, thr, k=11, up=16):
     return fg_inter, mask, counts
 
 
-_shift_ws = {}          # (device, stream, shape) -> workspace, reused across calls (stream-ordered)
+# cosine-shift workspaces, reused across calls: (device, stream, shape) -> workspace.  Stream-ordered reuse is safe because the
+# key holds the stream; bounded by BYTES (a full-size workspace is tens of MB) and guarded by a lock (the RoI head's optional
+# per-image worker threads call in concurrently).
+_shift_ws = {}
+_shift_ws_lock = threading.Lock()
+_SHIFT_WS_MAX_BYTES = 256 << 20
 
 
 def cosine_shift(feat, box_patch, obj_img, prot, n_shift, hp, wp, tau0=0.1, temp=0.1, return_trace=False):
@@ -528,12 +551,14 @@ def cosine_shift(feat, box_patch, obj_img, prot, n_shift, hp, wp, tau0=0.1, temp
     assign = torch.empty(max(n_shift, 1), G, Np_, device=feat.device, dtype=torch.int32) if return_trace else None
     tau = torch.empty(max(n_shift, 1), G, P, device=feat.device, dtype=torch.float32) if return_trace else None
     key = (feat.device, torch.cuda.current_stream(feat.device).cuda_stream, B, C, hp, wp, G, P)
-    ws = _shift_ws.get(key)
-    if ws is None:
-        if len(_shift_ws) > 64:
-            _shift_ws.clear()
-        ws = torch.empty(lib.as_cosine_shift_workspace_bytes(B, C, hp, wp, G, P), device=feat.device, dtype=torch.uint8)
-        _shift_ws[key] = ws
+    with _shift_ws_lock:
+        ws = _shift_ws.get(key)
+        if ws is None:
+            nbytes = lib.as_cosine_shift_workspace_bytes(B, C, hp, wp, G, P)
+            if sum(t.numel() for t in _shift_ws.values()) + nbytes > _SHIFT_WS_MAX_BYTES:
+                _shift_ws.clear()                       # (tensors still in flight stay alive through the caching allocator's stream rules)
+            ws = torch.empty(nbytes, device=feat.device, dtype=torch.uint8)
+            _shift_ws[key] = ws
     with _timed("cosine_shift"):
         _lib.check(lib.as_cosine_shift(_p(feat), _p(box_patch), _p(obj_img), _p(prot), _p(prot_out), float(tau0), float(temp),
                                        int(n_shift), _p(sim), _p(assign), _p(tau), _p(ws), ws.numel(), B, C, hp, wp, G, P,

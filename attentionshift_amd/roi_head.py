@@ -77,6 +77,7 @@ def _gen():
 
 
 _COPY_STREAMS = {}
+_COPY_STREAMS_LOCK = __import__("threading").Lock()
 
 
 def _to_host_issue(t, side_stream=False):
@@ -86,9 +87,10 @@ def _to_host_issue(t, side_stream=False):
     host = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
     cur = torch.cuda.current_stream()
     if side_stream:
-        cs = _COPY_STREAMS.get(t.device)
-        if cs is None:
-            cs = _COPY_STREAMS[t.device] = torch.cuda.Stream(device=t.device)
+        with _COPY_STREAMS_LOCK:                          # (the per-image worker threads of parallel_images share it)
+            cs = _COPY_STREAMS.get(t.device)
+            if cs is None:
+                cs = _COPY_STREAMS[t.device] = torch.cuda.Stream(device=t.device)
         cs.wait_stream(cur)
         with torch.cuda.stream(cs):
             host.copy_(t, non_blocking=True)

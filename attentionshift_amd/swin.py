@@ -93,7 +93,16 @@ class SwinTransformerBlock(nn.Module):
         self.mlp = _Mlp(dim, int(dim * mlp_ratio))
         self.compute_dtype = compute_dtype
         self.return_attention = return_attention
+        self.drop_path = float(drop_path)                 # stochastic depth rate of this block (training path only)
         self._wcache = {}
+
+    def _drop_path(self, t):
+        """timm DropPath (models/swin_transformer.py:196, :302-304): per-sample, scaled by 1 / keep; train() + grad only."""
+        if self.drop_path == 0.0 or not self.training:
+            return t
+        keep = 1.0 - self.drop_path
+        mask = torch.rand(t.shape[0], *([1] * (t.dim() - 1)), device=t.device, dtype=torch.float32).add_(keep).floor_().div_(keep)
+        return t * mask
 
     def _forward_train(self, x, hw=None):
         """Autograd path (train() + grad enabled): the window attention core runs on the HIP forward / backward kernels
@@ -107,11 +116,11 @@ class SwinTransformerBlock(nn.Module):
         o = WindowAttnFn.apply(qkv, bq, self.attn.relative_position_bias_table.float(), self.num_heads, self.window_size,
                                self.shift_size)
         y = F.linear(o.reshape(B, L, C), self.attn.proj.weight.to(cd), self.attn.proj.bias.to(cd))
-        x = x + y.float()
+        x = x + self._drop_path(y.float())
         z = F.layer_norm(x, (C,), self.norm2.weight, self.norm2.bias, self.norm2.eps).to(cd)
         z = F.linear(F.gelu(F.linear(z, self.mlp.fc1.weight.to(cd), self.mlp.fc1.bias.to(cd))),
                      self.mlp.fc2.weight.to(cd), self.mlp.fc2.bias.to(cd))
-        return x + z.float(), None
+        return x + self._drop_path(z.float()), None
 
     def _w(self, prm, dtype=None):
         """`dtype` (default: compute dtype) copy of a parameter, cached while it does not change (no-grad path only)."""

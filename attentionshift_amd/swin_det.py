@@ -45,12 +45,13 @@ class BasicLayerDet(nn.Module):
     Returns (x_out, H, W, x_down, Wh, Ww) like the reference."""
 
     def __init__(self, dim, depth, num_heads, window_size=7, mlp_ratio=4., qkv_bias=True, downsample=False,
-                 use_checkpoint=False, compute_dtype=torch.bfloat16):
+                 use_checkpoint=False, compute_dtype=torch.bfloat16, drop_path=0.):
         super().__init__()
         self.window_size, self.shift_size, self.depth, self.use_checkpoint = window_size, window_size // 2, depth, use_checkpoint
+        dpr = list(drop_path) if isinstance(drop_path, (list, tuple)) else [drop_path] * depth        # :352
         self.blocks = nn.ModuleList([
             SwinTransformerBlock(dim, None, num_heads, window_size, 0 if i % 2 == 0 else window_size // 2, mlp_ratio,
-                                 qkv_bias, compute_dtype=compute_dtype, return_attention=False)
+                                 qkv_bias, drop_path=dpr[i], compute_dtype=compute_dtype, return_attention=False)
             for i in range(depth)])
         self.downsample = PatchMergingDet(dim, compute_dtype) if downsample else None
 
@@ -117,7 +118,9 @@ class SwinTransformerDet(nn.Module):
             raise NotImplementedError("norm_layer other than nn.LayerNorm")
         self.pretrain_img_size, self.num_layers, self.embed_dim = pretrain_img_size, len(depths), embed_dim
         self.ape, self.patch_norm, self.out_indices, self.frozen_stages = ape, patch_norm, tuple(out_indices), frozen_stages
-        self.drop_path_rate = drop_path_rate              # stochastic depth is a training-time regulariser: inactive here
+        self.drop_path_rate = drop_path_rate
+        # stochastic depth: the rate rises linearly over ALL blocks (:520); active on the training path only
+        dpr = [drop_path_rate * i / max(sum(depths) - 1, 1) for i in range(sum(depths))]
         self.patch_embed = PatchEmbedDet(patch_size, in_chans, embed_dim, patch_norm)
         if ape:
             ps = self.patch_embed.patch_size
@@ -126,7 +129,8 @@ class SwinTransformerDet(nn.Module):
             nn.init.trunc_normal_(self.absolute_pos_embed, std=.02)
         self.layers = nn.ModuleList([
             BasicLayerDet(int(embed_dim * 2 ** i), depths[i], num_heads[i], window_size, mlp_ratio, qkv_bias,
-                          downsample=i < self.num_layers - 1, use_checkpoint=use_checkpoint, compute_dtype=compute_dtype)
+                          downsample=i < self.num_layers - 1, use_checkpoint=use_checkpoint, compute_dtype=compute_dtype,
+                          drop_path=dpr[sum(depths[:i]):sum(depths[:i + 1])])
             for i in range(self.num_layers)])
         self.num_features = [int(embed_dim * 2 ** i) for i in range(self.num_layers)]
         for i in self.out_indices:

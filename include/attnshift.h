@@ -131,6 +131,12 @@ int as_window_attn_fwd(const void* qkv, const float* bqkv, const float* table, v
  * x_out may alias x_in; either output may be NULL (x_out NULL: LN only; y_out NULL: add only).  D % 4 == 0, D <= 3072. */
 int as_add_layernorm(const float* x_in, const void* delta, const float* gamma, const float* beta, float eps,
                      float* x_out, void* y_out, int M, int D, int dtype, as_stream_t stream);
+/* The same with the sub-layer output scaled per SAMPLE: x_out = x_in + delta_scale[row / rows_per_scale] * delta -- the
+ * DropPath of the training path (models/vision_transformer.py:24-36, applied at :117 / :122: x + drop_path(f(norm(x)))),
+ * with delta_scale[b] = mask_b / keep_prob drawn by the caller (fp32, one value per image; NULL = 1). */
+int as_add_layernorm_scaled(const float* x_in, const void* delta, const float* gamma, const float* beta, float eps,
+                            float* x_out, void* y_out, int M, int D, int dtype, const float* delta_scale,
+                            int rows_per_scale, as_stream_t stream);
 
 /* out[M,Nout] = x[M,K] . W[Nout,K]^T (no bias, no activation) with the CONTRACTION split over workgroups: fp32 partial
  * products of K ranges, summed in range order (deterministic), written as bf16 (out_f32 = 0) or fp32 (1).  The form of an
@@ -152,11 +158,16 @@ int as_maxpool_nhwc(const float* x, float* out, int B, int H, int W, int C, int 
  * [M,D] in `dtype` = gradient of y_out (NULL: the call was add-only); dx_res [M,D] fp32 = gradient of x_out from the
  * residual stream (NULL: none); gamma fp32 [D].  Writes dx_out [M,D] fp32 (gradient of x_in) and / or ddelta_out [M,D]
  * in `dtype` (gradient of delta: the same values), dgamma / dbeta fp32 [D] (either may be NULL).  Column sums go through
- * per-workgroup partials added in workgroup order (deterministic).  D % 4 == 0, D <= 1024. */
+ * per-workgroup partials added in workgroup order (deterministic).  D % 4 == 0, D <= 2048. */
 size_t as_add_layernorm_bwd_workspace_bytes(int M, int D);
 int as_add_layernorm_bwd(const float* x, const void* dy, const float* dx_res, const float* gamma, float eps, float* dx_out,
                          void* ddelta_out, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, int M, int D,
                          int dtype, as_stream_t stream);
+/* Backward of as_add_layernorm_scaled: ddelta_out = delta_scale[row / rows_per_scale] * (gradient of x_out). */
+int as_add_layernorm_bwd_scaled(const float* x, const void* dy, const float* dx_res, const float* gamma, float eps,
+                                float* dx_out, void* ddelta_out, float* dgamma, float* dbeta, void* workspace,
+                                size_t workspace_bytes, int M, int D, int dtype, const float* delta_scale,
+                                int rows_per_scale, as_stream_t stream);
 
 /* Backward of as_window_attn_fwd (autograd of WindowAttention's core + the index maps around it):
  *   d_out     : [B,H,W,C] gradient of the attention output        dqkv : [B,H,W,3C] gradient w.r.t. the bias-free qkv

@@ -839,6 +839,75 @@ def test_add_layernorm_autograd_matches_torch(ops, M, D, dtype, tol, with_delta)
         assert mx < tol, (name, mx, mean)
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
+def test_add_layernorm_autograd_with_per_sample_delta_scale(ops, dtype, tol):
+    """DropPath folded into the fused add (as_add_layernorm_scaled / _bwd_scaled): x_out = x + s[b] * delta with s = mask / keep
+    per image -- forward and every gradient vs torch autograd in fp64; a dropped image (s = 0) gets ddelta = 0 exactly."""
+    from attentionshift_amd import autograd as AG
+    B, N, D = 3, 77, 768
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(B, N, D, generator=g)
+    delta = torch.randn(B, N, D, generator=g).to(dtype)
+    s = torch.tensor([1.0 / 0.9, 0.0, 1.0 / 0.9])
+    gamma, beta = torch.randn(D, generator=g) * 0.3 + 1, torch.randn(D, generator=g) * 0.1
+    w1, w2 = torch.randn(B, N, D, generator=g), torch.randn(B, N, D, generator=g)
+    x64, d64 = x.double().requires_grad_(True), delta.double().requires_grad_(True)
+    g64, b64 = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    with torch.enable_grad():
+        xo = x64 + s.double()[:, None, None] * d64
+        y64 = torch.nn.functional.layer_norm(xo, (D,), g64, b64, 1e-6)
+        ((xo * w1.double()).sum() + (y64 * w2.double()).sum()).backward()
+    xd, dd = dev(x).requires_grad_(True), dev(delta).requires_grad_(True)
+    gd, bd = dev(gamma).requires_grad_(True), dev(beta).requires_grad_(True)
+    with torch.enable_grad():
+        xo_d, y_d = AG.add_layernorm(xd, dd, gd, bd, 1e-6, dtype, dev(s))
+        ((xo_d * dev(w1)).sum() + (y_d.float() * dev(w2)).sum()).backward()
+    for name, ref, got in (("x_out", xo.detach(), xo_d.detach()), ("y", y64.detach(), y_d.detach()), ("dx", x64.grad, xd.grad),
+                           ("ddelta", d64.grad, dd.grad), ("dgamma", g64.grad, gd.grad), ("dbeta", b64.grad, bd.grad)):
+        mx, mean = rel_to_range(ref.float(), got.float())
+        assert mx < tol, (name, mx, mean)
+    assert (dd.grad[1] == 0).all() and torch.equal(xo_d[1].detach(), xd[1].detach())
+
+
+@pytest.mark.parametrize("D", [768, 1280])
+def test_add_layernorm_autograd_affine_gradients_only(ops, D):
+    """A first block behind a frozen token preparation: x needs no gradient, there is no delta, gamma / beta do -- the
+    kernel is asked for the affine gradients alone (a scratch dx); D = 1280 (ViT-H) is beyond the 1024 of round 2."""
+    from attentionshift_amd import autograd as AG
+    g = torch.Generator().manual_seed(D)
+    M = 300
+    x = torch.randn(M, D, generator=g)
+    gamma, beta = torch.randn(D, generator=g) * 0.3 + 1, torch.randn(D, generator=g) * 0.1
+    w = torch.randn(M, D, generator=g)
+    g64, b64 = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    with torch.enable_grad():
+        (torch.nn.functional.layer_norm(x.double(), (D,), g64, b64, 1e-6) * w.double()).sum().backward()
+    gd, bd = dev(gamma).requires_grad_(True), dev(beta).requires_grad_(True)
+    with torch.enable_grad():
+        _, y = AG.add_layernorm(dev(x), None, gd, bd, 1e-6, torch.float32)
+        (y * dev(w)).sum().backward()
+    for name, ref, got in (("dgamma", g64.grad, gd.grad), ("dbeta", b64.grad, bd.grad)):
+        mx, _ = rel_to_range(ref.float(), got.float())
+        assert mx < 2e-5, (name, mx)
+
+
+def test_roi_align_trainable_map_outside_the_hip_backward_limits_takes_the_tensor_path(ops):
+    """mil_head.roi_align: a trainable map the HIP backward cannot take (C % 8 != 0) must not pass the forward and then
+    fail in backward -- it runs on the tensor-op path, and agrees with the HIP forward of the same (no-grad) input."""
+    from attentionshift_amd.mil_head import roi_align
+    g = torch.Generator().manual_seed(5)
+    feat = torch.randn(1, 12, 20, 24, generator=g)
+    rois = torch.tensor([[0, 16.0, 20.0, 200.0, 180.0], [0, 100.0, 40.0, 330.0, 300.0]])
+    fd = dev(feat).requires_grad_(True)
+    with torch.enable_grad():
+        y = roi_align(fd, dev(rois), 7, 1.0 / 16, 0, True)
+        y.square().sum().backward()
+    assert fd.grad is not None and torch.isfinite(fd.grad).all() and fd.grad.abs().sum() > 0
+    with torch.no_grad():
+        y_hip = roi_align(dev(feat), dev(rois), 7, 1.0 / 16, 0, True)          # C % 4 == 0, no grad: the HIP kernel
+    assert_close(y_hip.cpu(), y.detach().cpu(), 1e-5, 1e-5, "roi_align tensor path vs HIP forward")
+
+
 @pytest.mark.parametrize("N,h,T,dtype", [(457, 4, 40, torch.bfloat16), (1090, 12, 100, torch.bfloat16), (457, 3, 40, torch.float32)])
 def test_rollout_of_a_row_subset_equals_those_rows_of_the_full_rollout(ops, N, h, T, dtype):
     """ops.rollout_rows(states, T, rows=sel): only the selected point-token rows go through the layers below the top one

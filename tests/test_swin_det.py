@@ -33,6 +33,27 @@ def test_registered_with_the_reference_signature_and_state_dict_keys(golden):
         net.init_weights(pretrained=3)
 
 
+def test_drop_path_rates_rise_linearly_over_all_blocks_and_only_act_in_training():
+    """mmdet swin_transformer.py:520 + :352: dpr = linspace(0, drop_path_rate, sum(depths)) handed to the blocks in order;
+    DropPath scales kept samples by 1 / keep and is the identity in eval()."""
+    net = A.build_backbone(dict(type="SwinTransformer", pretrain_img_size=64, embed_dim=32, depths=[2, 2, 6, 2],
+                                num_heads=[1, 2, 4, 8], drop_path_rate=0.2))
+    rates = [blk.drop_path for layer in net.layers for blk in layer.blocks]
+    assert rates[0] == 0.0 and abs(rates[-1] - 0.2) < 1e-12 and all(b > a for a, b in zip(rates, rates[1:]))
+    assert abs(rates[5] - 0.2 * 5 / 11) < 1e-12
+    blk = net.layers[3].blocks[1]
+    x = torch.ones(64, 3, 5)
+    blk.eval()
+    assert blk._drop_path(x) is x
+    blk.train()
+    torch.manual_seed(0)
+    y = blk._drop_path(x)
+    kept = y[:, 0, 0] != 0
+    assert 0 < kept.sum() < 64                                            # some samples dropped, some kept
+    assert torch.allclose(y[kept], torch.full_like(y[kept], 1.0 / 0.8))   # kept samples are scaled by 1 / keep
+    assert (y[~kept] == 0).all()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 3e-4), (torch.bfloat16, 6e-2)])
 def test_swin_det_backbone_matches_reference(golden, dtype, tol):
