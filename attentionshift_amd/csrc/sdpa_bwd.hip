@@ -22,6 +22,10 @@
 // next MFMA without leaving the lane, and that MFMA's A operand is a plain contiguous fragment of the transposed tile.
 // Templated on the element type: bf16 (v_mfma_f32_32x32x16_bf16) and fp32 (exact v_mfma_f32_32x32x2_f32 chains; the
 // parity path).
+#include <stdlib.h>
+
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -78,7 +82,8 @@ __global__ __launch_bounds__(BW_NT) void bwd_prep_kernel(const T* __restrict__ q
                                                          const T* __restrict__ vt, const T* __restrict__ o,
                                                          const T* __restrict__ d_o, T* __restrict__ dof,
                                                          T* __restrict__ dot, T* __restrict__ qt, T* __restrict__ kt,
-                                                         T* __restrict__ vrow, float* __restrict__ delta, int B, int N,
+                                                         T* __restrict__ vrow, float* __restrict__ delta,
+                                                         const float* __restrict__ lse, float* __restrict__ lse2, int B, int N,
                                                          int Npad, int h) {
   __shared__ float tile[64][65];
   const int BH = B * h;
@@ -87,6 +92,8 @@ __global__ __launch_bounds__(BW_NT) void bwd_prep_kernel(const T* __restrict__ q
   const int tid = threadIdx.x;
   const int D = h * BW_HD;
   const int row0 = t * 64;
+  // lse in base-2 units for the LDS-DMA kernels (an LDS-DMA cannot convert on the way): +inf on the padded rows, so P = 0
+  if (tid < 64) lse2[(size_t)bh * Npad + row0 + tid] = row0 + tid < N ? lse[(size_t)bh * N + row0 + tid] * AS_LOG2E : INFINITY;
 
   // dO tile: rows -> dof (fragment-major), delta; transposed -> dot
   for (int e = tid; e < 64 * 64; e += BW_NT) {
@@ -211,6 +218,9 @@ __global__ __launch_bounds__(BW_NT, sizeof(T) == 2 ? 2 : 1) void sdpa_bwd_dq_ker
     const char* Vs = Ks + TILE_B;
     const char* Kts = Ks + 2 * TILE_B;
     Frag<T> fds[2][2];
+    const bool ragged = (t + 1) * BW_TILE > N;
+    auto scores = [&](auto ragged_c) {                 // (masking compiled into the last key tile's copy only)
+    constexpr bool RAGGED = decltype(ragged_c)::value;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
       f32x16 sacc, pacc;
@@ -228,15 +238,17 @@ __global__ __launch_bounds__(BW_NT, sizeof(T) == 2 ? 2 : 1) void sdpa_bwd_dq_ker
         lds_frag(fa, Vs + (kb * 32 + prow) * PITCH + (ks * 16 + half * 8) * ES);
         pacc = mma32(fa, fdo[ks], pacc);
       }
-      const bool ragged = (t + 1) * BW_TILE > N;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float p = __builtin_amdgcn_exp2f(sacc[r] - lse2);     // q pre-scaled (common.h): base-2 logits
         float ds = p * (pacc[r] - dl);                  // the softmax scale 1/8 is applied once, to the accumulators
-        if (ragged && t * BW_TILE + kb * 32 + pi_acc_row(r, half) >= N) ds = 0.0f;   // padded key rows hold garbage
+        if (RAGGED && t * BW_TILE + kb * 32 + pi_acc_row(r, half) >= N) ds = 0.0f;   // padded key rows hold garbage
         fds[kb][r >> 3].set(r & 7, ds);
       }
     }
+    };
+    if (ragged) scores(std::true_type{});
+    else scores(std::false_type{});
 #pragma unroll
     for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -420,9 +432,362 @@ __global__ __launch_bounds__(BW_NT, sizeof(T) == 2 ? 2 : 1) void sdpa_bwd_dkv_ke
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// dK, dV (bf16) on an LDS-DMA ring: the arithmetic of sdpa_bwd_dkv_kernel, with the query tile's four operand images
+// (Q and dO fragment-major: 8 one-KiB lane-linear pieces each; Q^T and dO^T: 64 rows of 128 B, 8 pieces of 8 rows, the
+// 16-byte chunks swizzled on the SOURCE side as in gemm.hip) and its 128 row statistics brought by `global_load_lds`
+// straight into the ring -- no staging registers (32 fewer VGPRs), no per-thread address arithmetic in the loop, the loads
+// of tile t+1 in flight under the MFMAs of tile t.  The DMA is issued from inline asm (scalar base + lane offset), so
+// hipcc schedules the fragment reads as ordinary LDS loads; one raw barrier per tile.
+// ---------------------------------------------------------------------------------------------------------
+#ifndef AS_BWD_EARLY_T
+#define AS_BWD_EARLY_T 0                     // 1 / 2: transposed fragments read ahead of the scores -- spills (42 / 67 registers)
+#endif
+#ifndef AS_BWD_NST
+#define AS_BWD_NST 2                         // ring stages (2: 66.6 KB, two workgroups per CU; 3: 99.8 KB, one)
+#endif
+constexpr int DK_QF = 0, DK_DOF = 8192, DK_QT = 16384, DK_DOT = 24576, DK_ST = 32768, DK_STAGE = 33280;
+
+__device__ __forceinline__ void bw_dma16(unsigned voff, const char* sbase, unsigned dst) {
+  unsigned keep;   // global_load_lds_dwordx4, saddr form: 64 lanes x 16 B from sbase + voff[lane] -> LDS [dst + 16 * lane]
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(dst) : "memory");
+}
+__device__ __forceinline__ void bw_dma4(unsigned voff, const char* sbase, unsigned dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(dst) : "memory");
+}
+__device__ __forceinline__ int bw_swz(int r) { return ((r >> 1) & 3) | (((r >> 4) & 1) << 2); }   // gemm.hip g_swz<4>
+
+__global__ __launch_bounds__(BW_NT, 2) void sdpa_bwd_dkv_dma_kernel(const __bf16* __restrict__ q, const __bf16* __restrict__ dof,
+                                                                    const __bf16* __restrict__ qt, const __bf16* __restrict__ dot,
+                                                                    const __bf16* __restrict__ k, const __bf16* __restrict__ vrow,
+                                                                    const float* __restrict__ lse2, const float* __restrict__ delta,
+                                                                    __bf16* __restrict__ dqkv, int B, int N, int Npad, int h) {
+  using T = __bf16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int BH = B * h;
+  const int bh = blockIdx.x % BH, ktile = blockIdx.x / BH;
+  const int b = bh / h, head = bh % h;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, half = lane >> 5;
+  const int key = ktile * 128 + wave * 32 + li;
+  const int kc = min(key, Npad - 1);
+
+  Frag<T> fk[4], fv[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    fk[ks].load16B(k + ((size_t)bh * Npad + kc) * BW_HD + ks * 16 + half * 8);
+    fv[ks].load16B(vrow + ((size_t)bh * Npad + kc) * BW_HD + ks * 16 + half * 8);
+  }
+  // the ordinary loads are complete before the first LDS-DMA is issued (hipcc does not count the asm DMAs in vmcnt)
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(fk[0].v), "+v"(fk[1].v), "+v"(fk[2].v), "+v"(fk[3].v), "+v"(fv[0].v), "+v"(fv[1].v),
+               "+v"(fv[2].v), "+v"(fv[3].v));
+
+  const unsigned smem_u = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)smem;
+  const char* qf_b = reinterpret_cast<const char*>(q + (size_t)bh * Npad * BW_HD);
+  const char* dof_b = reinterpret_cast<const char*>(dof + (size_t)bh * Npad * BW_HD);
+  const char* qt_b = reinterpret_cast<const char*>(qt + (size_t)bh * BW_HD * Npad);
+  const char* dot_b = reinterpret_cast<const char*>(dot + (size_t)bh * BW_HD * Npad);
+  const char* l2_b = reinterpret_cast<const char*>(lse2 + (size_t)bh * Npad);
+  const char* dl_b = reinterpret_cast<const char*>(delta + (size_t)bh * Npad);
+  const unsigned voff = lane * 16;
+  unsigned voff_t[2];                        // my two 8-row pieces of the transposed tiles: row stride Npad, swizzled chunk
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int r = (wave * 2 + j) * 8 + (lane >> 3);
+    voff_t[j] = (unsigned)r * (unsigned)Npad * 2u + (unsigned)(((lane & 7) ^ bw_swz(r)) << 4);
+  }
+  auto stage = [&](int t, int slot) {
+    const unsigned base = smem_u + slot * DK_STAGE;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int p = wave * 2 + j;
+      bw_dma16(voff, qf_b + (size_t)t * 8192 + p * 1024, base + DK_QF + p * 1024);
+      bw_dma16(voff, dof_b + (size_t)t * 8192 + p * 1024, base + DK_DOF + p * 1024);
+      bw_dma16(voff_t[j], qt_b + (size_t)t * 128, base + DK_QT + p * 1024);
+      bw_dma16(voff_t[j], dot_b + (size_t)t * 128, base + DK_DOT + p * 1024);
+    }
+    if (wave == 0) bw_dma4(lane * 4, l2_b + (size_t)t * 256, base + DK_ST);
+    if (wave == 1) bw_dma4(lane * 4, dl_b + (size_t)t * 256, base + DK_ST + 256);
+  };
+  auto ring_barrier = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+
+  f32x16 dkacc[2], dvacc[2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { dkacc[0][r] = 0.0f; dkacc[1][r] = 0.0f; dvacc[0][r] = 0.0f; dvacc[1][r] = 0.0f; }
+
+  const int nqt = Npad / BW_TILE;
+  const int prow = pi_row(li);
+  const int sw = bw_swz(li);
+  int off_t[4];                              // [qb * 2 + s2]: byte offset of this lane's chunk in row li of a transposed tile
+#pragma unroll
+  for (int c2 = 0; c2 < 4; ++c2) off_t[c2] = li * 128 + (((c2 * 2 + half) ^ sw) << 4);
+
+#pragma unroll
+  for (int p_ = 0; p_ < AS_BWD_NST - 1; ++p_)
+    if (p_ < nqt) stage(p_, p_);
+  for (int t = 0; t < nqt; ++t) {
+    // my pieces of tile t have landed: everything but the (AS_BWD_NST - 2) younger tiles (9 or 8 DMAs per wave and tile)
+    if (AS_BWD_NST == 2 || t + 1 >= nqt) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (wave < 2) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    ring_barrier();                          // tile t is complete for everyone; everyone is done reading tile t-1
+    if (t + AS_BWD_NST - 1 < nqt) stage(t + AS_BWD_NST - 1, (t + AS_BWD_NST - 1) % AS_BWD_NST);
+    const char* Qs = smem + (t % AS_BWD_NST) * DK_STAGE;
+    const char* dOs = Qs + DK_DOF;
+    const char* Qts = Qs + DK_QT;
+    const char* dOts = Qs + DK_DOT;
+    const float* st = reinterpret_cast<const float*>(Qs + DK_ST);
+    const bool ragged = (t + 1) * BW_TILE > N;
+
+    // the 16 transposed fragments of the dV / dK products do not depend on the scores: their LDS reads are issued first and
+    // land under the score MFMAs and the softmax VALU (AS_BWD_EARLY_T=0: read at their use, as the register-staged kernel)
+    Frag<T> ft_do[2][4], ft_q[2][4];
+    if (AS_BWD_EARLY_T) {
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int c2 = 0; c2 < 4; ++c2) {
+          lds_frag(ft_do[db][c2], dOts + db * 4096 + off_t[c2]);
+          if (AS_BWD_EARLY_T > 1) lds_frag(ft_q[db][c2], Qts + db * 4096 + off_t[c2]);
+        }
+    }
+    Frag<T> fp[2][2], fds[2][2];
+    // (the masking of the padded query rows is compiled into the LAST tile's copy of the block only: left as a run-time
+    // condition hipcc if-converts it into 128 v_cndmask + 32 v_cmp per tile, 44 % of the loop's VALU)
+    auto scores = [&](auto ragged_c) {
+    constexpr bool RAGGED = decltype(ragged_c)::value;
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      f32x16 sacc, pacc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { sacc[r] = 0.0f; pacc[r] = 0.0f; }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        Frag<T> fa;
+        lds_frag(fa, Qs + (size_t)(((qb * 4 + ks) * 64) + prow + 32 * half) * 16);
+        sacc = mma32(fa, fk[ks], sacc);
+      }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        Frag<T> fa;
+        lds_frag(fa, dOs + (size_t)(((qb * 4 + ks) * 64) + prow + 32 * half) * 16);
+        pacc = mma32(fa, fv[ks], pacc);
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const int q0 = qb * 32 + 16 * s2 + 8 * half;            // 8 consecutive queries of this lane's registers
+        const float4 l0 = *reinterpret_cast<const float4*>(st + q0), l1 = *reinterpret_cast<const float4*>(st + q0 + 4);
+        const float4 d0 = *reinterpret_cast<const float4*>(st + 64 + q0),
+                     d1 = *reinterpret_cast<const float4*>(st + 64 + q0 + 4);
+        const float lv[8] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
+        const float dv[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+#pragma unroll
+        for (int t8 = 0; t8 < 8; ++t8) {
+          const int r = s2 * 8 + t8;
+          float p = __builtin_amdgcn_exp2f(sacc[r] - lv[t8]);        // q pre-scaled (common.h): base-2 logits
+          float ds = p * (pacc[r] - dv[t8]);            // scale applied once to the dK accumulators
+          if (RAGGED && t * BW_TILE + q0 + t8 >= N) { p = 0.0f; ds = 0.0f; }   // padded query rows hold garbage
+          fp[qb][s2].set(t8, p);
+          fds[qb][s2].set(t8, ds);
+        }
+      }
+    }
+    };
+    if (ragged) scores(std::true_type{});
+    else scores(std::false_type{});
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          if (AS_BWD_EARLY_T > 1) {
+            dvacc[db] = mma32(ft_do[db][qb * 2 + s2], fp[qb][s2], dvacc[db]);
+            dkacc[db] = mma32(ft_q[db][qb * 2 + s2], fds[qb][s2], dkacc[db]);
+          } else if (AS_BWD_EARLY_T == 1) {
+            Frag<T> fa;
+            lds_frag(fa, Qts + db * 4096 + off_t[qb * 2 + s2]);
+            dvacc[db] = mma32(ft_do[db][qb * 2 + s2], fp[qb][s2], dvacc[db]);
+            dkacc[db] = mma32(fa, fds[qb][s2], dkacc[db]);
+          } else {
+            Frag<T> fa;
+            lds_frag(fa, dOts + db * 4096 + off_t[qb * 2 + s2]);
+            dvacc[db] = mma32(fa, fp[qb][s2], dvacc[db]);
+            lds_frag(fa, Qts + db * 4096 + off_t[qb * 2 + s2]);
+            dkacc[db] = mma32(fa, fds[qb][s2], dkacc[db]);
+          }
+        }
+  }
+
+  if (key < N) {
+    const int D = h * BW_HD;
+    T* row = dqkv + ((size_t)b * N + key) * (size_t)(3 * D) + head * BW_HD;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d = db * 32 + 8 * g + 4 * half;
+        st4(row + D + d, dkacc[db][4 * g] * AS_LN2, dkacc[db][4 * g + 1] * AS_LN2, dkacc[db][4 * g + 2] * AS_LN2,
+            dkacc[db][4 * g + 3] * AS_LN2);
+        st4(row + 2 * D + d, dvacc[db][4 * g], dvacc[db][4 * g + 1], dvacc[db][4 * g + 2], dvacc[db][4 * g + 3]);
+      }
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------
+// dQ (bf16) on an LDS-DMA ring: the arithmetic of sdpa_bwd_dq_kernel; per 64-key tile the K rows, the V rows (both 64 rows
+// of 128 B, contiguous in HBM) and the K^T tile (64 rows d of 128 B, row stride Npad) arrive as 8 + 8 + 8 one-KiB pieces
+// of 8 rows with the 16-byte chunks swizzled on the source side; two stages of 24 KiB.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int DQ_K = 0, DQ_V = 8192, DQ_KT = 16384, DQ_STAGE = 24576;
+
+#ifndef AS_BWD_DQ_OCC
+#define AS_BWD_DQ_OCC 2                    // waves per SIMD asked of hipcc: 3 caps at 170 registers (2 spills) and measures 2-4 % slower
+#endif
+__global__ __launch_bounds__(BW_NT, AS_BWD_DQ_OCC) void sdpa_bwd_dq_dma_kernel(const __bf16* __restrict__ q, const __bf16* __restrict__ dof,
+                                                                   const __bf16* __restrict__ k, const __bf16* __restrict__ vrow,
+                                                                   const __bf16* __restrict__ kt, const float* __restrict__ lse,
+                                                                   const float* __restrict__ delta, __bf16* __restrict__ dqkv,
+                                                                   int B, int N, int Npad, int h) {
+  using T = __bf16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int BH = B * h;
+  const int bh = blockIdx.x % BH, qtile = blockIdx.x / BH;
+  const int b = bh / h, head = bh % h;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, half = lane >> 5;
+  const int query = qtile * 128 + wave * 32 + li;
+  const int qc = min(query, N - 1);
+
+  Frag<T> fq[4], fdo[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    fq[ks].load16B(q + qf_frag((size_t)bh, Npad, qc, ks, half));
+    fdo[ks].load16B(dof + qf_frag((size_t)bh, Npad, qc, ks, half));
+  }
+  float lse2 = lse[(size_t)bh * N + qc] * AS_LOG2E;
+  float dl = delta[(size_t)bh * Npad + qc];
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(fq[0].v), "+v"(fq[1].v), "+v"(fq[2].v), "+v"(fq[3].v), "+v"(fdo[0].v), "+v"(fdo[1].v),
+               "+v"(fdo[2].v), "+v"(fdo[3].v), "+v"(lse2), "+v"(dl));
+
+  const unsigned smem_u = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)smem;
+  const char* k_b = reinterpret_cast<const char*>(k + (size_t)bh * Npad * BW_HD);
+  const char* v_b = reinterpret_cast<const char*>(vrow + (size_t)bh * Npad * BW_HD);
+  const char* kt_b = reinterpret_cast<const char*>(kt + (size_t)bh * BW_HD * Npad);
+  unsigned voff_r[2], voff_t[2];             // my two 8-row pieces: of the row-major tiles (row stride 128 B) / of K^T (stride Npad)
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int r = (wave * 2 + j) * 8 + (lane >> 3);
+    const unsigned ch = (unsigned)(((lane & 7) ^ bw_swz(r)) << 4);
+    voff_r[j] = (unsigned)r * 128u + ch;
+    voff_t[j] = (unsigned)r * (unsigned)Npad * 2u + ch;
+  }
+  auto stage = [&](int t, int slot) {
+    const unsigned base = smem_u + slot * DQ_STAGE;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int p = wave * 2 + j;
+      bw_dma16(voff_r[j], k_b + (size_t)t * 8192, base + DQ_K + p * 1024);
+      bw_dma16(voff_r[j], v_b + (size_t)t * 8192, base + DQ_V + p * 1024);
+      bw_dma16(voff_t[j], kt_b + (size_t)t * 128, base + DQ_KT + p * 1024);
+    }
+  };
+  auto ring_barrier = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+
+  f32x16 dqacc[2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { dqacc[0][r] = 0.0f; dqacc[1][r] = 0.0f; }
+
+  const int nkt = Npad / BW_TILE;
+  const int prow = pi_row(li);
+  int off_k[4], off_t[4];                    // [ks] in row prow of a row-major tile / [kb * 2 + s2] in row li of the K^T tile
+  {
+    const int swp = bw_swz(prow), swl = bw_swz(li);
+#pragma unroll
+    for (int c2 = 0; c2 < 4; ++c2) {
+      off_k[c2] = prow * 128 + (((c2 * 2 + half) ^ swp) << 4);
+      off_t[c2] = li * 128 + (((c2 * 2 + half) ^ swl) << 4);
+    }
+  }
+  stage(0, 0);
+  for (int t = 0; t < nkt; ++t) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // my pieces of tile t (the only DMA in flight)
+    ring_barrier();                                           // tile t complete; everyone is done reading tile t-1
+    if (t + 1 < nkt) stage(t + 1, (t + 1) & 1);
+    const char* Ks = smem + (t & 1) * DQ_STAGE;
+    const char* Vs = Ks + DQ_V;
+    const char* Kts = Ks + DQ_KT;
+    Frag<T> fds[2][2];
+    const bool ragged = (t + 1) * BW_TILE > N;
+    auto scores = [&](auto ragged_c) {
+      constexpr bool RAGGED = decltype(ragged_c)::value;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        f32x16 sacc, pacc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sacc[r] = 0.0f; pacc[r] = 0.0f; }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          Frag<T> fa;
+          lds_frag(fa, Ks + kb * 4096 + off_k[ks]);
+          sacc = mma32(fa, fq[ks], sacc);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          Frag<T> fa;
+          lds_frag(fa, Vs + kb * 4096 + off_k[ks]);
+          pacc = mma32(fa, fdo[ks], pacc);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float p = __builtin_amdgcn_exp2f(sacc[r] - lse2);
+          float ds = p * (pacc[r] - dl);
+          if (RAGGED && t * BW_TILE + kb * 32 + pi_acc_row(r, half) >= N) ds = 0.0f;   // padded key rows hold garbage
+          fds[kb][r >> 3].set(r & 7, ds);
+        }
+      }
+    };
+    if (ragged) scores(std::true_type{});
+    else scores(std::false_type{});
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          Frag<T> fa;
+          lds_frag(fa, Kts + db * 4096 + off_t[kb * 2 + s2]);
+          dqacc[db] = mma32(fa, fds[kb][s2], dqacc[db]);
+        }
+  }
+
+  if (query < N) {
+    T* row = dqkv + ((size_t)b * N + query) * (size_t)(3 * h * BW_HD) + head * BW_HD;       // q slot of [3,h,64]
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        st4(row + db * 32 + 8 * g + 4 * half, dqacc[db][4 * g] * 0.125f, dqacc[db][4 * g + 1] * 0.125f,
+            dqacc[db][4 * g + 2] * 0.125f, dqacc[db][4 * g + 3] * 0.125f);
+  }
+}
+
 template <typename T> size_t bwd_ws_bytes(int B, int N, int h) {
   const size_t Npad = as_round_up(N, 64);
-  return (size_t)B * h * Npad * (5 * BW_HD * sizeof(T) + sizeof(float));
+  return (size_t)B * h * Npad * (5 * BW_HD * sizeof(T) + 2 * sizeof(float));      // ... + delta + lse2
 }
 
 template <typename T>
@@ -437,9 +802,10 @@ int launch_bwd(const void* q, const void* k, const void* vt, const void* o, cons
   T* kt = qt + per;
   T* vrow = kt + per;
   float* delta = (float*)(vrow + per);
+  float* lse2 = delta + (size_t)B * h * Npad;
   const int BH = B * h;
   hipLaunchKernelGGL((bwd_prep_kernel<T>), dim3(BH * (Npad / 64)), dim3(BW_NT), 0, s, (const T*)q, (const T*)k,
-                     (const T*)vt, (const T*)o, (const T*)d_o, dof, dot, qt, kt, vrow, delta, B, N, Npad, h);
+                     (const T*)vt, (const T*)o, (const T*)d_o, dof, dot, qt, kt, vrow, delta, lse, lse2, B, N, Npad, h);
   AS_CHECK_LAUNCH("sdpa_bwd_prep");
   constexpr int PITCH = TS::ROWB + 16;
   const size_t lds_dq = 2 * (size_t)(3 * BW_TILE * PITCH);
@@ -451,11 +817,40 @@ int launch_bwd(const void* q, const void* k, const void* vt, const void* o, cons
     attr_set = true;
   }
   const int tiles = as_ceil_div(N, 128);
-  hipLaunchKernelGGL((sdpa_bwd_dkv_kernel<T>), dim3(BH * tiles), dim3(BW_NT), lds_dkv, s, (const T*)q, dof, qt, dot,
-                     (const T*)k, vrow, lse, delta, (T*)dqkv, B, N, Npad, h);
+  static const bool old_dkv = getenv("AS_BWD_OLD") != nullptr;       // (experiments: the register-staged kernel)
+  if constexpr (sizeof(T) == 2) {
+    if (!old_dkv) {
+      const size_t lds_dma = (size_t)AS_BWD_NST * DK_STAGE;
+      static bool attr2 = false;
+      if (!attr2) {
+        (void)hipFuncSetAttribute((const void*)sdpa_bwd_dkv_dma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dma);
+        attr2 = true;
+      }
+      hipLaunchKernelGGL(sdpa_bwd_dkv_dma_kernel, dim3(BH * tiles), dim3(BW_NT), lds_dma, s, (const __bf16*)q, (const __bf16*)dof,
+                         (const __bf16*)qt, (const __bf16*)dot, (const __bf16*)k, (const __bf16*)vrow, (const float*)lse2,
+                         (const float*)delta, (__bf16*)dqkv, B, N, Npad, h);
+    }
+  }
+  if (sizeof(T) != 2 || old_dkv)
+    hipLaunchKernelGGL((sdpa_bwd_dkv_kernel<T>), dim3(BH * tiles), dim3(BW_NT), lds_dkv, s, (const T*)q, dof, qt, dot,
+                       (const T*)k, vrow, lse, delta, (T*)dqkv, B, N, Npad, h);
   AS_CHECK_LAUNCH("sdpa_bwd_dkv");
-  hipLaunchKernelGGL((sdpa_bwd_dq_kernel<T>), dim3(BH * tiles), dim3(BW_NT), lds_dq, s, (const T*)q, dof,
-                     (const T*)k, vrow, kt, lse, delta, (T*)dqkv, B, N, Npad, h);
+  if constexpr (sizeof(T) == 2) {
+    if (!old_dkv) {
+      const size_t lds_dma = 2 * (size_t)DQ_STAGE;
+      static bool attr3 = false;
+      if (!attr3) {
+        (void)hipFuncSetAttribute((const void*)sdpa_bwd_dq_dma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dma);
+        attr3 = true;
+      }
+      hipLaunchKernelGGL(sdpa_bwd_dq_dma_kernel, dim3(BH * tiles), dim3(BW_NT), lds_dma, s, (const __bf16*)q, (const __bf16*)dof,
+                         (const __bf16*)k, (const __bf16*)vrow, (const __bf16*)kt, lse, (const float*)delta, (__bf16*)dqkv, B, N,
+                         Npad, h);
+    }
+  }
+  if (sizeof(T) != 2 || old_dkv)
+    hipLaunchKernelGGL((sdpa_bwd_dq_kernel<T>), dim3(BH * tiles), dim3(BW_NT), lds_dq, s, (const T*)q, dof,
+                       (const T*)k, vrow, kt, lse, delta, (T*)dqkv, B, N, Npad, h);
   AS_CHECK_LAUNCH("sdpa_bwd_dq");
   return AS_OK;
 }
