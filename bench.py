@@ -472,7 +472,7 @@ def main():
             "kernel": "as_cosine_shift (per iteration: similarity / assign / aggregate launches; packed final similarity)",
             "bound": "hbm", "achieved": round(gbps, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
             "frac": round(gbps / PEAK_HBM_GBPS, 4),
-            "traffic": _static_traffic("r02_shift_traffic.json", "per_call_bytes") if headline and imgs_per_call == 2 else None,
+            "traffic": _static_traffic("r03_shift_traffic.json", "per_call_bytes") if headline and imgs_per_call == 2 else None,
             "calls_timed": n_cs, "images_per_call": imgs_per_call, "ms_per_call": round(ms_cs, 4),
             "algorithmic_bytes_per_call": bytes_cs}
         # the same step with the trainable MIL head choosing the roll-out depth from RoI-aligned features (stdroi:2308-2312)
