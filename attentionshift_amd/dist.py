@@ -6,6 +6,11 @@ import torch
 
 
 class Ranks:
+    """WORLD_SIZE / RANK / LOCAL_RANK from the launcher.  On GPU boxes the process group carries TWO backends
+    ("cpu:gloo,cuda:nccl"): the timing barriers and the max / sum of host scalars go through gloo on CPU tensors, so the
+    forward / attention-shift throughput (which has no data-path collective) never depends on RCCL; RCCL communicators are
+    created lazily by the first collective on a device tensor -- the gradient all-reduce of the training step."""
+
     def __init__(self, backend=None, device=None):
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.rank = int(os.environ.get("RANK", "0"))
@@ -14,31 +19,29 @@ class Ranks:
         self.dist = None
         if self.world > 1:
             import torch.distributed as dist
-            backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
-            kw = {}
-            if backend == "nccl" and device is not None:
-                kw["device_id"] = device
-            dist.init_process_group(backend=backend, **kw)
+            backend = backend or ("cpu:gloo,cuda:nccl" if torch.cuda.is_available() else "gloo")
+            dist.init_process_group(backend=backend)
             self.dist = dist
+
+    def _host_reduce(self, value, op):
+        t = torch.tensor([value], dtype=torch.float64)                    # CPU tensor: gloo
+        self.dist.all_reduce(t, op=op)
+        return float(t.item())
 
     def barrier(self):
         if self.dist is not None:
-            self.dist.barrier()
+            self._host_reduce(0.0, self.dist.ReduceOp.SUM)                # an all-reduce every rank must enter
 
     def max_over_ranks(self, value):
         """max of a python float over all ranks (the slowest rank defines the step time)."""
         if self.dist is None:
             return float(value)
-        t = torch.tensor([value], dtype=torch.float64, device=self.device if self.device is not None else "cpu")
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
-        return float(t.item())
+        return self._host_reduce(value, self.dist.ReduceOp.MAX)
 
     def sum_over_ranks(self, value):
         if self.dist is None:
             return float(value)
-        t = torch.tensor([value], dtype=torch.float64, device=self.device if self.device is not None else "cpu")
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
-        return float(t.item())
+        return self._host_reduce(value, self.dist.ReduceOp.SUM)
 
     def shard(self, n_items):
         """contiguous shard [lo, hi) of n_items for this rank (image sharding of a global batch)."""

@@ -393,10 +393,12 @@ def main():
     CFG.update(CONFIGS[a.config])
 
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("AS_BENCH_SHARE_GPUS"):            # test hook: more ranks than GPUs (plumbing check on a 1-GPU box)
+        local %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     from attentionshift_amd.dist import Ranks
-    ranks = Ranks(backend="nccl", device=device)          # "nccl" is RCCL on ROCm
+    ranks = Ranks(device=device)       # gloo for host scalars + "nccl" (= RCCL on ROCm) for device tensors (dist.Ranks)
     world, rank = ranks.world, ranks.rank
 
     from attentionshift_amd import ops
