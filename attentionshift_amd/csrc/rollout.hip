@@ -454,7 +454,10 @@ constexpr int R4_HPG = 4;                                  // heads per workgrou
 constexpr int R4_QBYTES = R4_HPG * 4 * 1024;               // Q fragments of one contraction block: [head][k16 step][1 KiB]
 constexpr int R4_LSE = R4_QBYTES + 8 * 1024;               // + R fragments [ib][s2][1 KiB]
 constexpr int R4_STAGE = R4_LSE + 1024;                    // + lse rows [head][64 lanes] fp32 (lane l holds row l % 32)
-constexpr int R4_NSTAGE = 3;
+// ring depth / waves per SIMD asked of hipcc, per form: the 32-row form (NIB = 1, 168 registers) runs three workgroups per
+// CU on a two-stage ring (51 KB each); the 128-row form (NIB = 4) carries 64 more accumulator registers and keeps the
+// three-stage ring with two workgroups per CU (at three it spills 53 registers: 1.89 vs 0.94 ms for the 7-layer roll-out)
+template <int NIB> struct R4Cfg { static constexpr int NSTAGE = NIB == 1 ? 2 : 3, OCC = NIB == 1 ? 3 : 2; };
 
 typedef __attribute__((ext_vector_type(4))) unsigned r4_u32x4;
 template <int OFF> __device__ __forceinline__ void r4_lds_read128(r4_u32x4& dst, unsigned addr) {
@@ -494,11 +497,12 @@ __device__ __forceinline__ void r4_dma4(unsigned voff, const char* sbase, unsign
 }
 
 template <int NIB>                                       // 32-row blocks of R carried (1: Trows <= 32, else 4)
-__global__ __launch_bounds__(RO_NT, 2) void rollout_step4_kernel(const __bf16* __restrict__ q, const __bf16* __restrict__ k,
+__global__ __launch_bounds__(RO_NT, R4Cfg<NIB>::OCC) void rollout_step4_kernel(const __bf16* __restrict__ q, const __bf16* __restrict__ k,
                                                                  const float* __restrict__ lse, const __bf16* __restrict__ rf_in,
                                                                  float* __restrict__ part, int B, int N, int Npad, int h,
                                                                  int Trows, int ksplit) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int R4_NSTAGE = R4Cfg<NIB>::NSTAGE;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, half = lane >> 5;
   const int ngroups = h / R4_HPG;
@@ -551,13 +555,13 @@ __global__ __launch_bounds__(RO_NT, 2) void rollout_step4_kernel(const __bf16* _
   const unsigned lbase = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)smem + lane * 16;
 
   if (nblk > 0) stage(kb0, 0);
-  if (nblk > 1) stage(kb0 + 1, 1);
+  if (R4_NSTAGE > 2 && nblk > 1) stage(kb0 + 1, 1);
 
   for (int it = 0; it < nblk; ++it) {
     const int kb = kb0 + it, buf = it % R4_NSTAGE;
     if (AS_ROLLOUT_ABLATE != 11) {
       // my pieces of block `it` have landed: all but the 7 (5 for the waves that carry no R block) of block it+1
-      if (it + 1 >= nblk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (R4_NSTAGE == 2 || it + 1 >= nblk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       else if (NIB == 4 || wave == 0) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
     }
@@ -571,7 +575,7 @@ __global__ __launch_bounds__(RO_NT, 2) void rollout_step4_kernel(const __bf16* _
       asm volatile("ds_write_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" :: "v"(a_own), "v"(own) : "memory");
     }
     if (AS_ROLLOUT_ABLATE != 14) __builtin_amdgcn_s_barrier();   // block `it` is complete; everyone is done with block it-1
-    if (AS_ROLLOUT_ABLATE != 11 && it + 2 < nblk) stage(kb + 2, (it + 2) % R4_NSTAGE);
+    if (AS_ROLLOUT_ABLATE != 11 && it + R4_NSTAGE - 1 < nblk) stage(kb + R4_NSTAGE - 1, (it + R4_NSTAGE - 1) % R4_NSTAGE);
     const unsigned sb = lbase + buf * R4_STAGE;
     // -log2(e) * lse of the block's 32 rows in ACCUMULATOR layout: register r of a lane in half `half` is row
     // (r & 3) + 8 (r >> 2) + 4 half, i.e. four runs of 4 consecutive rows = four 16-byte (broadcast) reads per head
@@ -697,13 +701,15 @@ bool rollout_force_v3() {
 // partial products of rollout_step4: (contraction splits) x (head groups), at most R4_MAXPARTS; the split count is chosen
 // so that the grid fills whole rounds of 2 workgroups per CU (e.g. 33 x 2 x 3 = 198 units -> 5 splits = 990 of 1024)
 constexpr int R4_MAXPARTS = 16;
-int rollout4_ksplit(int B, int N, int h) {
+int rollout4_ksplit(int B, int N, int h, int slots) {
+  static const int forced = [] { const char* e = getenv("AS_R4_KS"); return e ? atoi(e) : 0; }();   // (experiments)
+  if (forced > 0 && forced * (h / R4_HPG) <= 16) return forced;
   const int units = as_ceil_div(N, 128) * B * (h / R4_HPG);
   int best = 1;
   float best_eff = 0.0f;
   for (int ks = 1; ks * (h / R4_HPG) <= R4_MAXPARTS && ks <= 8; ++ks) {
     const int wgs = units * ks;
-    const float eff = (float)wgs / (float)(as_ceil_div(wgs, 512) * 512);
+    const float eff = (float)wgs / (float)(as_ceil_div(wgs, slots) * slots);
     if (eff > best_eff + 0.02f) { best_eff = eff; best = ks; }
   }
   return best;
@@ -747,8 +753,11 @@ int launch_rollout_step2(const void* q, const void* k, const float* lse, const f
   if (sizeof(T) == 2 && h % R4_HPG == 0 && part != nullptr && nsplit == R4_MAXPARTS && !rollout_force_v3()) {
     // bf16, heads in groups of four: streamed-operand kernel; `nsplit` here only says that the workspace holds
     // R4_MAXPARTS partial products
-    const int ks = rollout4_ksplit(B, N, h), ng = h / R4_HPG;
-    const size_t lds4 = (size_t)R4_NSTAGE * R4_STAGE;
+    const int ng = h / R4_HPG;
+    // (512 slots for both forms: with three resident workgroups per CU the 32-row form still measures best at the split that
+    // fills 512 -- 990 workgroups at config 2: 0.650 ms for the 6 steps against 0.72 at the 594 a 768-slot model picks)
+    const int ks = rollout4_ksplit(B, N, h, 512);
+    const size_t lds4 = (size_t)(Trows <= 32 ? R4Cfg<1>::NSTAGE : R4Cfg<4>::NSTAGE) * R4_STAGE;
     if (Trows <= 32) {
       (void)hipFuncSetAttribute((const void*)rollout_step4_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
       hipLaunchKernelGGL(rollout_step4_kernel<1>, dim3(as_ceil_div(N, 128), B, ks * ng), dim3(RO_NT), lds4, s, (const __bf16*)q,
