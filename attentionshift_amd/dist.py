@@ -162,11 +162,34 @@ class GradAllReducer:
             h.remove()
 
 
-def parse_losses(losses, ranks=None):
+class PendingLogVars:
+    """The logged scalars of parse_losses(lazy=True): the stacked device tensor is on its way to pinned host memory;
+    `resolve()` waits for that copy (the step's only loss-related sync) and returns the OrderedDict of python floats."""
+
+    def __init__(self, keys, flat):
+        self.keys = keys
+        if flat.is_cuda:
+            self.host = torch.empty(flat.shape, dtype=flat.dtype, pin_memory=True)
+            self.host.copy_(flat, non_blocking=True)
+            self.event = torch.cuda.Event()
+            self.event.record()
+        else:
+            self.host, self.event = flat, None
+
+    def resolve(self):
+        from collections import OrderedDict
+        if self.event is not None:
+            self.event.synchronize()
+        return OrderedDict(zip(self.keys, self.host.tolist()))
+
+
+def parse_losses(losses, ranks=None, lazy=False):
     """mmdet/models/detectors/base.py:185-218 `_parse_losses`: per-key means, `loss` = sum of the keys containing 'loss',
     and the logged values averaged over ranks -- with ONE all-reduce of the stacked scalars instead of one blocking
     all-reduce per key (the reference issues len(losses)+1 of them per step).  Returns (loss tensor, log_vars dict of
-    python floats)."""
+    python floats).  lazy=True: the second element is a PendingLogVars -- the reference reads the scalars back (`.item()`)
+    BEFORE backward, which makes the host wait for the whole forward and only then start queueing the backward; resolving
+    them after the optimizer step has been queued keeps the host ahead of the device through the backward."""
     from collections import OrderedDict
     log_vars = OrderedDict()
     for name, value in losses.items():
@@ -183,6 +206,8 @@ def parse_losses(losses, ranks=None):
     if ranks is not None and ranks.dist is not None and ranks.world > 1:
         flat = flat / ranks.world
         ranks.dist.all_reduce(flat)
+    if lazy:
+        return loss, PendingLogVars(keys, flat)
     vals = flat.tolist()
     return loss, OrderedDict((k, v) for k, v in zip(keys, vals))
 

@@ -220,7 +220,7 @@ def build(device, rng_mode="fast", train=False, ranks=None, mil=False):
         with torch.autocast("cuda", dtype=torch.bfloat16):
             losses, labels = head.train_losses(fmap, metas, proposals, vit_feat, out["attns"], out["outputs_class"].float(),
                                                out["outputs_coord"].float(), gt_points, gt_labels, generator=gen, **train_kw)
-        loss, log_vars = parse_losses(losses, ranks)
+        loss, log_vars = parse_losses(losses, ranks, lazy=True)       # read back after the step has been queued
         (loss * scale if scale != 1.0 else loss).backward()
         return log_vars
 
@@ -244,7 +244,7 @@ def build(device, rng_mode="fast", train=False, ranks=None, mil=False):
             torch.nn.utils.clip_grad_norm_(params, **grad_clip)
         opt.step()
         opt.zero_grad(set_to_none=True)                    # (torch's default, what the reference's optimizer hook calls)
-        return log_vars
+        return log_vars.resolve()                          # the logged scalars: the step's last host sync
 
     train_step.head = head
     train_step.reducer = reducer
