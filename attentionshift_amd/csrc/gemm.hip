@@ -543,7 +543,7 @@ int launch_gemm_glds_wm(const void* A, const void* W, const float* bias, void* o
 //   short   128 x 128, 4 waves of 64 x 64, K step 32, 3-stage ring (48 KiB, 3 workgroups per CU)
 //   tall    256 x 128, 8 waves of 64 x 64, K step 32, 3-stage ring (72 KiB, 2 per CU)
 //   tall64  256 x 128, 8 waves of 64 x 64, K step 64, 2 stages     (96 KiB, 1 per CU)     K % 64 == 0
-//   wide64  256 x 256, 8 waves of 128 x 64, K step 64, 2 stages    (136 KiB with the staged epilogue, 1 per CU)  plain-linear mode
+//   wide64  256 x 256, 8 waves of 128 x 64, K step 64, 2 stages    (136 KiB with the staged epilogue, 1 per CU)  not the QKV mode
 // chosen by a per-CU round model in units of one short tile's work: a CU works through ceil(tiles / 256) tiles; a tall tile
 // is two short ones done 1.28x as fast (4096^3: 662 -> 846 TFLOP/s); when the tall tiles fit ONE round (<= 256) tall64 runs
 // them 4-8 % faster (whole 128-byte lines per LDS-DMA request, half the barriers; M = 8394: N = 768, K = 768: 18.4 -> 17.7 us,
@@ -555,7 +555,7 @@ int launch_gemm_glds_wm(const void* A, const void* W, const float* bias, void* o
 // rounds of 1.56: tall (measured 45-47 vs 49.5 us).  Measured and not kept (tools/experiments/gemm_variant_bench.py,
 // gemm_pingpong.hip.inc): the 256 x 256 tile on 16 waves of 64 x 64 (K step 32: 1000-1039 TFLOP/s at 4096^3, K step 64: 1059;
 // wide64: 1106-1143), ring depths 3 / 4 / 5 for it (equal), and a ping-pong schedule of wide64 (1062-1140).
-// AS_GEMM_TILE=short|tall|tall64|wide64 forces one (experiments; wide64 only in the plain-linear mode, *64 only if K % 64 == 0).
+// AS_GEMM_TILE=short|tall|tall64|wide64 forces one (experiments; wide64 not in the QKV mode, *64 only if K % 64 == 0).
 template <int MODE>
 int launch_gemm_glds(const void* A, const void* W, const float* bias, void* out, int M, int Nout, int K, int act,
                      QkvEpi epi, hipStream_t s) {
@@ -568,10 +568,10 @@ int launch_gemm_glds(const void* A, const void* W, const float* bias, void* out,
   const bool k64 = K % 64 == 0;
   const float short_cost = (float)as_ceil_div(as_ceil_div(M, 128) * nt_n, 256);
   const float tall_cost = (float)as_ceil_div(tall_tiles, 256) * (tall_tiles <= 256 && k64 ? 1.47f : 2.0f / 1.28f);
-  const float wide_cost = (MODE == 0 && k64) ? (float)as_ceil_div(as_ceil_div(M, 256) * as_ceil_div(Nout, 256), 256) * 2.8f : 1e30f;
+  const float wide_cost = (MODE != 1 && k64) ? (float)as_ceil_div(as_ceil_div(M, 256) * as_ceil_div(Nout, 256), 256) * 2.8f : 1e30f;
   int pick = wide_cost < tall_cost && wide_cost < short_cost ? 4 : tall_cost < short_cost ? (tall_tiles <= 256 && k64 ? 3 : 2) : 1;
-  if (forced && (forced < 3 || k64) && (forced != 4 || MODE == 0)) pick = forced;
-  if constexpr (MODE == 0)
+  if (forced && (forced < 3 || k64) && (forced != 4 || MODE != 1)) pick = forced;
+  if constexpr (MODE != 1)
     if (pick == 4) return launch_gemm_glds_wm<MODE, 2, 4, 4, 4>(A, W, bias, out, M, Nout, K, act, epi, s);
   if (pick == 3) return launch_gemm_glds_wm<MODE, 4, 2, 2, 4>(A, W, bias, out, M, Nout, K, act, epi, s);
   if (pick == 2) return launch_gemm_glds_wm<MODE, 4, 2, 2, 2>(A, W, bias, out, M, Nout, K, act, epi, s);
