@@ -63,7 +63,7 @@ def test_bad_arguments_return_error_codes_without_launching():
     assert lib.as_cam_sample_masks_workspace_bytes(12, 64, 64, 16) == 4 * 1024 * 1024
     assert lib.as_rollout_step(*([None] * 8), 0, 1, 64, 1, 8, 1, None) == -1
     # workspace size queries are pure host functions
-    assert lib.as_sdpa_bwd_workspace_bytes(2, 4197, 12, 1) == 2 * 12 * 4224 * (5 * 64 * 2 + 4)
+    assert lib.as_sdpa_bwd_workspace_bytes(2, 4197, 12, 1) == 2 * 12 * 4224 * (5 * 64 * 2 + 8)      # 5 operand copies + delta + lse2
     assert lib.as_attn_bwd_workspace_bytes(2, 4197, 768, 12, 1) > lib.as_sdpa_bwd_workspace_bytes(2, 4197, 12, 1)
     assert lib.as_rollout_step_workspace_bytes(2, 4197, 100) == 16 * 2 * 100 * 4197 * 4      # up to 16 partial products
     assert lib.as_sdpa_bwd_workspace_bytes(0, 4197, 12, 1) == 0
