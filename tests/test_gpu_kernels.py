@@ -84,6 +84,40 @@ def test_linear_splitk_matches_fp32_matmul(ops, M, N, K, out_dtype):
     assert torch.equal(got, ops.linear_splitk(dev(x), dev(w), out_dtype))
 
 
+_TILE_SCRIPT = """
+import sys, torch
+sys.path.insert(0, %r)
+from attentionshift_amd import ops
+torch.manual_seed(0)
+worst = 0.0
+for (M, N, K, act) in [(300, 520, 64, "none"), (300, 520, 128, "gelu"), (1000, 264, 192, "none"), (8394, 768, 768, "none"),
+                       (2049, 3072, 768, "gelu"), (257, 1000, 1024, "none")]:
+    x = torch.randn(M, K).bfloat16(); w = (torch.randn(N, K) * K ** -0.5).bfloat16(); b = torch.randn(N)
+    ref = torch.nn.functional.linear(x.float(), w.float(), b)
+    if act == "gelu":
+        ref = torch.nn.functional.gelu(ref)
+    got = ops.linear(x.cuda(), w.cuda(), b.cuda(), act=act).float().cpu()
+    worst = max(worst, float((ref - got).abs().max() / ref.abs().max()))
+print("WORST", worst)
+"""
+
+
+@pytest.mark.parametrize("tile", ["short", "tall", "tall64", "wide64"])
+def test_linear_bf16_every_tile_shape_forced(tile):
+    """Every instantiation of gemm_glds_kernel (csrc/gemm.hip launch_gemm_glds) on shapes that are ragged in M and N, with
+    one, two and many K stages, through the same C entry point: AS_GEMM_TILE is read once per process, so each tile runs
+    in its own interpreter.  (K = 64 / 128: single- and two-stage pipelines of the K-step-64 tiles.)"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, AS_GEMM_TILE=tile)
+    out = subprocess.run([sys.executable, "-c", _TILE_SCRIPT % root], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    worst = float(out.stdout.strip().split("WORST")[-1])
+    assert worst < 1e-2, (tile, worst)
+
+
 def test_linear_bf16(ops):
     g = torch.Generator().manual_seed(1)
     x, w, b = torch.randn(513, 768, generator=g), torch.randn(384, 768, generator=g) * 0.05, torch.randn(384, generator=g)
@@ -291,7 +325,7 @@ def test_attention_bf16_vit_large_token_count(ops):
     assert mx < 3e-2, mx
 
 
-@pytest.mark.parametrize("B,N,h", [(1, 297, 3), (2, 200, 2), (1, 1000, 2), (1, 64, 1)])
+@pytest.mark.parametrize("B,N,h", [(1, 297, 3), (2, 200, 2), (1, 1000, 2), (1, 64, 1), (1, 65, 2), (2, 129, 1)])
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-4), (torch.bfloat16, 3e-2)])
 def test_sdpa_bwd_matches_autograd(ops, dtype, tol, B, N, h):
     """Backward of A2 (autograd of vision_transformer.py:79-83): dq, dk, dv from the tile-recomputing HIP kernels vs
