@@ -572,7 +572,8 @@ __device__ __forceinline__ void lds_dma16(unsigned voff, const char* sbase, unsi
 template <int NQ, bool SPLIT, int MODE>
 __global__ __launch_bounds__(SD_NT, NQ == 1 ? 3 : 2) void sdpa_fwd_pipe_kernel(
     const __bf16* __restrict__ q, const __bf16* __restrict__ k, const __bf16* __restrict__ vt, __bf16* __restrict__ o,
-    float* __restrict__ lse, int B, int N, int Npad, int h, int qt_fixed, int nslices, float* __restrict__ part) {
+    float* __restrict__ lse, int B, int N, int Npad, int h, int qt_fixed, int nslices, float* __restrict__ part,
+    int mix_mode, int mix_a, int mix_r) {
   extern __shared__ __attribute__((aligned(16))) char smem[];     // [3][K tile | V^T tile]
   constexpr int QROWS = SD_QB * NQ;                               // query rows of a workgroup
   constexpr int UPT = 2 * NQ;                                     // units per tile
@@ -580,7 +581,23 @@ __global__ __launch_bounds__(SD_NT, NQ == 1 ? 3 : 2) void sdpa_fwd_pipe_kernel(
   constexpr int NBUF = NQ == 2 ? AS_SDPA_NBUF2 : 3;               // ring depth: NBUF - 2 tiles in flight beyond the next
   const int BH = B * h;
   const int bid = blockIdx.x;
-  const int bh = bid % BH, qt = SPLIT ? qt_fixed : bid / BH;
+  // Workgroup -> (image-head, first query row).  Plain grids: bid = tile * BH + bh.  MIXED launch (mix_mode 1 / 2, see
+  // launch_sdpa_glds): the full 128-row chunks of every head are covered by 256-row workgroups of the NQ = 2 instance
+  // (mode 1: head bh owns a_bh = mix_a + (bh < mix_r) of them, rows [0, 256 a_bh)) and by 128-row workgroups of the NQ = 1
+  // instance (mode 2: the chunks after them); head-major numbering, closed form.
+  int bh, row0;
+  if (SPLIT || mix_mode == 0) {
+    bh = bid % BH;
+    row0 = (SPLIT ? qt_fixed : bid / BH) * QROWS;
+  } else {
+    const int cf = N / SD_QB;                                     // full 128-row chunks of a head
+    const int per_hi = mix_mode == 1 ? mix_a + 1 : cf - 2 * (mix_a + 1);   // tiles of the heads < mix_r / of the others
+    const int per_lo = mix_mode == 1 ? mix_a : cf - 2 * mix_a;
+    int t;
+    if (bid < mix_r * per_hi) { bh = bid / per_hi; t = bid - bh * per_hi; }
+    else { const int b2 = bid - mix_r * per_hi; bh = mix_r + b2 / per_lo; t = b2 % per_lo; }
+    row0 = mix_mode == 1 ? t * (2 * SD_QB) : (mix_a + (bh < mix_r ? 1 : 0)) * (2 * SD_QB) + t * SD_QB;
+  }
   const int slice = SPLIT ? bid / BH : 0;
   const int b = bh / h, head = bh % h;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -596,7 +613,7 @@ __global__ __launch_bounds__(SD_NT, NQ == 1 ? 3 : 2) void sdpa_fwd_pipe_kernel(
   bf16x8 fq[NQ][4];
 #pragma unroll
   for (int qb = 0; qb < NQ; ++qb) {
-    query[qb] = qt * QROWS + (wave * NQ + qb) * 32 + li;
+    query[qb] = row0 + (wave * NQ + qb) * 32 + li;
     const int qc = min(query[qb], N - 1);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) fq[qb][ks] = *reinterpret_cast<const bf16x8*>(q + qf_frag((size_t)bh, Npad, qc, ks, half));
@@ -987,6 +1004,35 @@ int sdpa_slots() {                                    // resident workgroups of 
   return slots;
 }
 
+// key slices of a split q-tile: about one workgroup per CU, no empty slice
+int sdpa_tail_slices(int B, int N, int h) {
+  const int nkt = as_round_up(N, 64) / SD_KB;
+  int ns = as_ceil_div(sdpa_slots() / 3, B * h);
+  ns = ns < 2 ? 2 : (ns > nkt ? nkt : ns);
+  return as_ceil_div(nkt, as_ceil_div(nkt, ns));
+}
+
+// MIXED launch (AS_SDPA_IMPL=5; an experiment kept behind the switch -- built to get 3 query blocks per SIMD instead of 4,
+// measured SLOWER: 148 us against 122 at ViT-B / 1024^2 / B = 2, the dispatcher does not pair the two kernels' workgroups
+// one of each per CU; sdpa_pick() never chooses it):
+// X workgroups of 256 rows (NQ = 2) + Y of 128 rows (NQ = 1) that together cover the full 128-row chunks
+// of every head, X, Y <= #CUs, so that every CU hosts ONE of each (a SIMD holds one 229-register and one 164-register
+// wave; a second of either does not fit) = 3 query blocks per SIMD instead of the 4 of two 256-row workgroups; the
+// ragged rows after the last full chunk go through the key-split kernel.  At ViT-B / 1024^2 / B = 2: 24 heads x 32 chunks
+// = 768 = 2 * 256 + 256.  Returns false when the shape does not decompose that way.
+struct SdpaMix { int X, Y, a, r, cf; };
+bool sdpa_mix_plan(int B, int N, int h, SdpaMix* m) {
+  const int BH = B * h, cus = sdpa_slots() / 3, cf = N / SD_QB, C = BH * cf;
+  if (cf < 2) return false;
+  int X = (C + 1) / 3;
+  if (X > cus) X = cus;
+  const int Y = C - 2 * X;
+  const int a = X / BH, r = X % BH;
+  if (Y < 0 || Y > cus || 2 * (a + (r > 0 ? 1 : 0)) > cf) return false;
+  *m = SdpaMix{X, Y, a, r, cf};
+  return true;
+}
+
 int sdpa_split_slices(int B, int N, int h) {           // 0 = no split for this shape
   const int BH = B * h, qtiles = as_ceil_div(N, SD_QB), slots = sdpa_slots();
   bool tail = qtiles * BH > slots && ((qtiles - 1) * BH) % slots == 0;
@@ -1034,7 +1080,16 @@ int launch_sdpa_glds(const void* q, const void* k, const void* vt, void* o, floa
   int ns = sdpa_split_slices(B, N, h);
   if (ns > 0 && (ws == nullptr || ws_bytes < (size_t)BH * ns * SD_QB * SD_REC * sizeof(float))) ns = 0;
   const int forced = sdpa_impl_forced();
-  const int impl = forced >= 0 ? forced : sdpa_pick(B, N, h, ns > 0);
+  int impl = forced >= 0 ? forced : sdpa_pick(B, N, h, ns > 0);
+  SdpaMix mix{};
+  const int tail_rows = N % SD_QB;
+  int ns_t = 0;
+  bool mixed = impl == 5 && sdpa_mix_plan(B, N, h, &mix);
+  if (mixed && tail_rows > 0) {
+    ns_t = sdpa_tail_slices(B, N, h);
+    if (ws == nullptr || ws_bytes < (size_t)BH * ns_t * SD_QB * SD_REC * sizeof(float)) mixed = false;
+  }
+  if (impl == 5 && !mixed) impl = sdpa_pick(B, N, h, ns > 0) == 5 ? 4 : sdpa_pick(B, N, h, ns > 0);
   if (impl == 2 || impl == 4) ns = 0;                        // 256-row workgroups: no split tail
   if (ns > 0) --qtiles;
   const size_t lds = (size_t)GL_NBUF * 2 * GL_TILE;        // 48 KiB
@@ -1042,8 +1097,8 @@ int launch_sdpa_glds(const void* q, const void* k, const void* vt, void* o, floa
   // stream): its 264 short workgroups fill the slots the main grid's workgroups free up as they retire, instead of
   // running as a separate 13 us phase afterwards.  Helper stream and events are created once per host thread.
   struct Side {
-    hipStream_t st = nullptr;
-    hipEvent_t fork = nullptr, join = nullptr;
+    hipStream_t st = nullptr, st2 = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr, join2 = nullptr;
     bool ok = false;
     int dev = -1;
     void init() {                                        // (re)created when this thread first uses a device
@@ -1052,20 +1107,60 @@ int launch_sdpa_glds(const void* q, const void* k, const void* vt, void* o, floa
       if (d == dev) return;
       dev = d;
       ok = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess &&
+           hipStreamCreateWithFlags(&st2, hipStreamNonBlocking) == hipSuccess &&
            hipEventCreateWithFlags(&fork, hipEventDisableTiming) == hipSuccess &&
-           hipEventCreateWithFlags(&join, hipEventDisableTiming) == hipSuccess;
+           hipEventCreateWithFlags(&join, hipEventDisableTiming) == hipSuccess &&
+           hipEventCreateWithFlags(&join2, hipEventDisableTiming) == hipSuccess;
     }
   };
   static thread_local Side side;
-  if (ns > 0) side.init();
+  if (ns > 0 || mixed) side.init();
   const bool concurrent = ns > 0 && qtiles > 0 && side.ok && getenv("AS_SDPA_SERIAL") == nullptr;
   hipStream_t s2 = concurrent ? side.st : s;
   if (concurrent) {
     if (hipEventRecord(side.fork, s) != hipSuccess || hipStreamWaitEvent(side.st, side.fork, 0) != hipSuccess) s2 = s;
   }
-#define AS_PIPE_LAUNCH(NQ_, SPLIT_, MODE_, GRID_, STREAM_, QT_, NS_, WS_)                                                  \
+#define AS_PIPE_LAUNCH_MIX(NQ_, SPLIT_, MODE_, GRID_, STREAM_, QT_, NS_, WS_, MIX_, MIXA_, MIXR_)                                                  \
   hipLaunchKernelGGL((sdpa_fwd_pipe_kernel<NQ_, SPLIT_, MODE_>), dim3(GRID_), dim3(SD_NT), lds, STREAM_, (const __bf16*)q,  \
-                     (const __bf16*)k, (const __bf16*)vt, (__bf16*)o, lse, B, N, Npad, h, QT_, NS_, (float*)(WS_))
+                     (const __bf16*)k, (const __bf16*)vt, (__bf16*)o, lse, B, N, Npad, h, QT_, NS_, (float*)(WS_), MIX_, MIXA_, MIXR_)
+#define AS_PIPE_LAUNCH(NQ_, SPLIT_, MODE_, GRID_, STREAM_, QT_, NS_, WS_) \
+  AS_PIPE_LAUNCH_MIX(NQ_, SPLIT_, MODE_, GRID_, STREAM_, QT_, NS_, WS_, 0, 0, 0)
+  if (mixed) {
+    // three concurrent launches: 256-row workgroups on the caller's stream, 128-row workgroups and the key-split ragged
+    // rows on two helper streams (fork / join with events), so the dispatcher can place one of each kind on every CU
+    static bool attr_mix = false;
+    const size_t lds2 = (size_t)AS_SDPA_NBUF2 * 2 * GL_TILE;
+    if (!attr_mix && lds2 > 64 * 1024 - 1) {
+      (void)hipFuncSetAttribute((const void*)sdpa_fwd_pipe_kernel<2, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+      attr_mix = true;
+    }
+    bool forked = side.ok && getenv("AS_SDPA_SERIAL") == nullptr && hipEventRecord(side.fork, s) == hipSuccess && hipStreamWaitEvent(side.st, side.fork, 0) == hipSuccess &&
+                  hipStreamWaitEvent(side.st2, side.fork, 0) == hipSuccess;
+    hipStream_t sa = forked ? side.st : s, sb = forked ? side.st2 : s;
+    {
+      const size_t lds = lds2;
+      AS_PIPE_LAUNCH_MIX(2, false, 1, mix.X, s, 0, 1, nullptr, 1, mix.a, mix.r);
+    }
+    AS_CHECK_LAUNCH("sdpa_fwd_pipe<2> (mixed)");
+    if (mix.Y > 0) {
+      AS_PIPE_LAUNCH_MIX(1, false, 1, mix.Y, sa, 0, 1, nullptr, 2, mix.a, mix.r);
+      AS_CHECK_LAUNCH("sdpa_fwd_pipe<1> (mixed)");
+    }
+    if (tail_rows > 0) {
+      AS_PIPE_LAUNCH(1, true, 1, ns_t * BH, sb, mix.cf, ns_t, ws);
+      AS_CHECK_LAUNCH("sdpa_fwd<split> (mixed)");
+      hipLaunchKernelGGL(sdpa_combine_kernel, dim3(SD_QB / 16, BH), dim3(256), 0, sb, (const float*)ws, (__bf16*)o, lse, B, N,
+                         h, mix.cf, ns_t);
+      AS_CHECK_LAUNCH("sdpa_combine (mixed)");
+    }
+    if (forked) {
+      (void)hipEventRecord(side.join, side.st);
+      (void)hipEventRecord(side.join2, side.st2);
+      (void)hipStreamWaitEvent(s, side.join, 0);
+      (void)hipStreamWaitEvent(s, side.join2, 0);
+    }
+    return AS_OK;
+  }
   if (impl == 2 || impl == 4) {                              // 64 queries per wave, 256 per workgroup, no split tail
     const int grid2 = as_ceil_div(N, 2 * SD_QB) * BH;
     const size_t lds1 = lds;
@@ -1103,6 +1198,7 @@ int launch_sdpa_glds(const void* q, const void* k, const void* vt, void* o, floa
     AS_CHECK_LAUNCH("sdpa_fwd");
   }
 #undef AS_PIPE_LAUNCH
+#undef AS_PIPE_LAUNCH_MIX
   if (ns > 0 && s2 != s) (void)hipStreamWaitEvent(s, side.join, 0);     // join: later work on `s` sees the split rows
   return AS_OK;
 }
@@ -1128,7 +1224,9 @@ int launch_sdpa(const void* q, const void* k, const void* vt, void* o, float* ls
 
 extern "C" size_t as_sdpa_fwd_workspace_bytes(int B, int N, int h, int dtype) {
   if (B <= 0 || N <= 0 || h <= 0 || dtype != AS_BF16) return 0;
-  const int ns = sdpa_split_slices(B, N, h);
+  int ns = sdpa_split_slices(B, N, h);
+  SdpaMix mix;
+  if (sdpa_mix_plan(B, N, h, &mix) && N % SD_QB != 0) ns = ns > sdpa_tail_slices(B, N, h) ? ns : sdpa_tail_slices(B, N, h);
   return (size_t)B * h * ns * SD_QB * SD_REC * sizeof(float);
 }
 

@@ -232,7 +232,7 @@ def test_sdpa_bf16_deferred_max_and_spikes(ops, monkeypatch, tail, N):
     assert torch.isfinite(o.float()).all()
 
 
-@pytest.mark.parametrize("impl", ["0", "1", "2", "3", "4"])
+@pytest.mark.parametrize("impl", ["0", "1", "2", "3", "4", "5"])
 @pytest.mark.parametrize("tail,N", [("0", 1000), ("1", 1153), ("1", 100)])
 def test_sdpa_bf16_out_of_range_logits_take_the_exact_pass(ops, monkeypatch, impl, tail, N):
     """Rows the reference-free first pass (sdpa_fwd_pipe_kernel MODE 1: P = exp2 of the raw base-2 logit) cannot represent
