@@ -81,7 +81,7 @@ class AddLayerNormFn(torch.autograd.Function):
     backward (as_add_layernorm_bwd): the residual glue of Block.forward (models/vision_transformer.py:109-124).
     x fp32 [B,N,D] residual stream, delta `out_dtype` | None (the previous sub-layer's output), y in `out_dtype`.
     delta_scale fp32 [B] | None: x_out = x + delta_scale[b] * delta -- the DropPath around the sub-layer
-    (models/vision_transformer.py:117,122) folded into the add, in fp32, at no extra pass; not differentiated."""
+    (models/vision_transformer.py:114-118) folded into the add, in fp32, at no extra pass; not differentiated."""
 
     @staticmethod
     def forward(ctx, x, delta, gamma, beta, eps, out_dtype, delta_scale=None):

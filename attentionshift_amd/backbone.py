@@ -346,7 +346,7 @@ class VisionTransformerDet(nn.Module):
         return torch.is_grad_enabled() and self.training and any(p.requires_grad for p in self.blocks.parameters())
 
     def _drop_path(self, x, i):
-        """Stochastic depth per sample, rate rising linearly with depth (models/vision_transformer.py:24-36, :165)."""
+        """Stochastic depth per sample, rate rising linearly with depth (models/vision_transformer.py:21-40, :160-164)."""
         rate = self.drop_path_rate * i / max(self.depth - 1, 1)
         if rate == 0.0 or not self.training:
             return x
@@ -387,7 +387,7 @@ class VisionTransformerDet(nn.Module):
         sh = self._train_shadow                          # compute-dtype copies of the blocks' GEMM parameters (forward())
         w = lambda p: sh[id(p)] if id(p) in sh else p.to(cd)                      # noqa: E731
         # `delta_scale` belongs to `delta` (the PREVIOUS block's MLP output and its DropPath factor); this block's two
-        # DropPaths (vision_transformer.py:117, :122) draw their own factors: independent draws, as in the reference
+        # DropPaths (vision_transformer.py:114-118) draw their own factors: independent draws, as in the reference
         x, y = AG.add_layernorm(x, delta, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps, cd, delta_scale)
         a = AG.attention(y, w(blk.attn.qkv.weight), None if blk.attn.qkv.bias is None else blk.attn.qkv.bias.float(),
                          w(blk.attn.proj.weight), blk.attn.proj.bias.float(), self.num_heads, sink)

@@ -132,7 +132,7 @@ int as_window_attn_fwd(const void* qkv, const float* bqkv, const float* table, v
 int as_add_layernorm(const float* x_in, const void* delta, const float* gamma, const float* beta, float eps,
                      float* x_out, void* y_out, int M, int D, int dtype, as_stream_t stream);
 /* The same with the sub-layer output scaled per SAMPLE: x_out = x_in + delta_scale[row / rows_per_scale] * delta -- the
- * DropPath of the training path (models/vision_transformer.py:24-36, applied at :117 / :122: x + drop_path(f(norm(x)))),
+ * DropPath of the training path (models/vision_transformer.py:21-40, applied at :114-118: x + drop_path(f(norm(x)))),
  * with delta_scale[b] = mask_b / keep_prob drawn by the caller (fp32, one value per image; NULL = 1). */
 int as_add_layernorm_scaled(const float* x_in, const void* delta, const float* gamma, const float* beta, float eps,
                             float* x_out, void* y_out, int M, int D, int dtype, const float* delta_scale,

@@ -29,6 +29,12 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert loaded.as_version() == 100
 
 
+def test_every_entry_point_is_mapped_to_the_reference_in_integration_md():
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    missing = [n for n in declared_symbols() if n not in doc and not n.endswith("_bytes")]
+    assert not missing, f"entry points without a row in INTEGRATION.md: {missing}"
+
+
 def test_bad_arguments_return_error_codes_without_launching():
     from attentionshift_amd import _lib
     lib = _lib.load()
