@@ -5,9 +5,13 @@ Reference: models/vision_transformer.py:74-86 is an ordinary nn.Module different
 [B,h,N,N] softmax saved for backward (or recomputed per block under `use_checkpoint`,
 visual_transformer_det.py:232-236).  Here the saved tensors are q, k, v^T, o and the row log-sum-exp; the backward
 recomputes softmax tiles on chip (csrc/sdpa_bwd.hip)."""
+import os
+
 import torch
 
 from . import ops
+
+_LIBRARY_LINEAR = bool(os.environ.get("AS_LINEAR_LIBRARY"))     # A/B switch: leave every nn.Linear to the library GEMMs
 
 
 class AttentionFn(torch.autograd.Function):
@@ -38,6 +42,49 @@ class AttentionFn(torch.autograd.Function):
 
 def attention(x, w_qkv, b_qkv, w_proj, b_proj, num_heads, sink=None):
     return AttentionFn.apply(x, w_qkv, b_qkv, w_proj, b_proj, num_heads, sink)
+
+
+class LinearFn(torch.autograd.Function):
+    """y = x W^T + b on the HIP GEMM (as_linear_fwd) with the backward as_linear_bwd computes: dx on the same kernel, dW
+    as a split-K product over the rows (the library runs these few-tile, deep-contraction shapes on a handful of
+    workgroups), db by fixed-order column sums.  x bf16 [..., K]; W bf16 or fp32 master [Nout, K] (cast here, dW comes
+    back in W's dtype); b fp32 / bf16 / None.  models/vision_transformer.py:47-59 (Mlp) and the decoder blocks of the
+    MAE heads (mae_bbox_head_rec.py:148-168) under autograd."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x2 = x.reshape(-1, x.shape[-1]).contiguous()
+        wb = weight if weight.dtype == torch.bfloat16 else weight.to(torch.bfloat16)
+        wb = wb.contiguous()
+        out = ops.linear(x2, wb, None if bias is None else bias.float())
+        ctx.save_for_backward(x2, wb)
+        ctx.meta = (x.shape, weight.dtype, None if bias is None else bias.dtype)
+        return out.view(*x.shape[:-1], weight.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, wb = ctx.saved_tensors
+        shape, w_dtype, b_dtype = ctx.meta
+        dy2 = dy.reshape(-1, dy.shape[-1])
+        dy2 = (dy2 if dy2.dtype == torch.bfloat16 else dy2.to(torch.bfloat16)).contiguous()
+        need_db = b_dtype is not None and ctx.needs_input_grad[2]
+        dx, dw, db = ops.linear_bwd(x2, wb, dy2, ctx.needs_input_grad[0], ctx.needs_input_grad[1], need_db, dw_dtype=w_dtype)
+        return (None if dx is None else dx.view(shape), dw, None if db is None else db.to(b_dtype))
+
+
+def linear(x, weight, bias=None):
+    """nn.Linear under autograd on the HIP kernels, computing in bf16 (what autocast / apex O1 does to F.linear)."""
+    return LinearFn.apply(x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16), weight, bias)
+
+
+def linear_applies(x, weight):
+    """Whether `linear` can stand in for F.linear here: device tensors, a bf16 autocast region (or bf16 operands
+    already) and sizes the kernels take (rows of 32)."""
+    if _LIBRARY_LINEAR or not x.is_cuda or weight.shape[0] % 32 or weight.shape[1] % 32:
+        return False
+    if x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16:
+        return True
+    return torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16
 
 
 class ParamCastFn(torch.autograd.Function):

@@ -392,8 +392,12 @@ class VisionTransformerDet(nn.Module):
         a = AG.attention(y, w(blk.attn.qkv.weight), None if blk.attn.qkv.bias is None else blk.attn.qkv.bias.float(),
                          w(blk.attn.proj.weight), blk.attn.proj.bias.float(), self.num_heads, sink)
         x, z = AG.add_layernorm(x, a, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps, cd, self._drop_scale(x.shape[0], i, x.device))
-        z = F.gelu(F.linear(z, w(blk.mlp.fc1.weight), w(blk.mlp.fc1.bias)))
-        z = F.linear(z, w(blk.mlp.fc2.weight), w(blk.mlp.fc2.bias))
+        if AG.linear_applies(z, w(blk.mlp.fc1.weight)):
+            z = F.gelu(AG.linear(z, w(blk.mlp.fc1.weight), blk.mlp.fc1.bias))          # fp32 master biases: db stays fp32
+            z = AG.linear(z, w(blk.mlp.fc2.weight), blk.mlp.fc2.bias)
+        else:
+            z = F.gelu(F.linear(z, w(blk.mlp.fc1.weight), w(blk.mlp.fc1.bias)))
+            z = F.linear(z, w(blk.mlp.fc2.weight), w(blk.mlp.fc2.bias))
         return x, z, self._drop_scale(x.shape[0], i, x.device)
 
     def forward(self, x):

@@ -18,6 +18,19 @@ import torch
 import torch.nn.functional as F
 
 
+_CONSTS = {}
+
+
+def _const(values, like, repeat=1):
+    """A small constant vector on `like`'s device / dtype, uploaded once (a `new_tensor(list)` on a GPU is a pageable
+    host -> device copy that waits for the stream)."""
+    key = (tuple(float(v) for v in values), repeat, like.device, like.dtype)
+    t = _CONSTS.get(key)
+    if t is None:
+        t = _CONSTS[key] = torch.tensor(key[0] * repeat, dtype=like.dtype).to(like.device)
+    return t
+
+
 def bbox2delta(proposals, gt, means=(0., 0., 0., 0.), stds=(1., 1., 1., 1.)):
     proposals, gt = proposals.float(), gt.float()
     px, py = (proposals[..., 0] + proposals[..., 2]) * 0.5, (proposals[..., 1] + proposals[..., 3]) * 0.5
@@ -25,13 +38,13 @@ def bbox2delta(proposals, gt, means=(0., 0., 0., 0.), stds=(1., 1., 1., 1.)):
     gx, gy = (gt[..., 0] + gt[..., 2]) * 0.5, (gt[..., 1] + gt[..., 3]) * 0.5
     gw, gh = gt[..., 2] - gt[..., 0], gt[..., 3] - gt[..., 1]
     deltas = torch.stack([(gx - px) / pw, (gy - py) / ph, torch.log(gw / pw), torch.log(gh / ph)], dim=-1)
-    return (deltas - deltas.new_tensor(means)) / deltas.new_tensor(stds)
+    return (deltas - _const(means, deltas)) / _const(stds, deltas)
 
 
 def delta2bbox(rois, deltas, means=(0., 0., 0., 0.), stds=(1., 1., 1., 1.), max_shape=None, wh_ratio_clip=16 / 1000):
     """rois [N,4], deltas [N, 4 * k] -> boxes [N, 4 * k] (clipped to max_shape = (H, W[, C]) when given)."""
     k = deltas.size(-1) // 4
-    d = deltas * deltas.new_tensor(stds).repeat(k) + deltas.new_tensor(means).repeat(k)
+    d = deltas * _const(stds, deltas, k) + _const(means, deltas, k)
     dx, dy, dw, dh = d[..., 0::4], d[..., 1::4], d[..., 2::4], d[..., 3::4]
     max_ratio = abs(math.log(wh_ratio_clip))
     dw, dh = dw.clamp(-max_ratio, max_ratio), dh.clamp(-max_ratio, max_ratio)
@@ -82,27 +95,31 @@ def bbox_targets(pos_bboxes, neg_bboxes, pos_gt_bboxes, pos_gt_labels, num_class
 
 def bbox_head_loss(cls_score, bbox_pred, labels, label_weights, bbox_targets_, bbox_weights, num_classes,
                    reg_class_agnostic=False, loss_cls_weight=1.0, loss_bbox_weight=1.0, rois=None, loss_bbox_type="L1Loss",
-                   means=(0., 0., 0., 0.), stds=(0.1, 0.1, 0.2, 0.2)):
+                   means=(0., 0., 0., 0.), stds=(0.1, 0.1, 0.2, 0.2), pos_index=None, num_weighted=None):
     """cls_score [n, K+1] | None, bbox_pred [n, 4 or 4K] | None -> dict(loss_cls, acc, loss_bbox).  With `rois` [n,4]
-    the predictions are decoded against them first (reg_decoded_bbox) and `bbox_targets_` are absolute boxes."""
+    the predictions are decoded against them first (reg_decoded_bbox) and `bbox_targets_` are absolute boxes.
+    `pos_index` (long tensor: the rows with a foreground label, ascending) and `num_weighted` (the number of rows with
+    a positive label weight) are what a caller that built the targets from host-side sampling results already knows;
+    given, nothing here reads a count back from the device."""
     losses = {}
     if cls_score is not None and cls_score.numel() > 0:
-        avg = max(float((label_weights > 0).sum()), 1.0)
+        avg = max(float((label_weights > 0).sum()) if num_weighted is None else float(num_weighted), 1.0)
         ce = F.cross_entropy(cls_score, labels, reduction="none") * label_weights
         losses["loss_cls"] = loss_cls_weight * ce.sum() / avg
         losses["acc"] = (cls_score.argmax(1) == labels).float().mean() * 100.0
     if bbox_pred is not None:
-        pos = (labels >= 0) & (labels < num_classes)
-        if pos.any():
+        if pos_index is None:
+            pos_index = torch.nonzero((labels >= 0) & (labels < num_classes), as_tuple=False).flatten()
+        if pos_index.numel():
             if rois is not None:
                 bbox_pred = delta2bbox(rois, bbox_pred, means, stds)
-            pred = bbox_pred.view(bbox_pred.size(0), 4)[pos] if reg_class_agnostic else \
-                bbox_pred.view(bbox_pred.size(0), -1, 4)[pos, labels[pos]]
+            pred = bbox_pred.view(bbox_pred.size(0), 4)[pos_index] if reg_class_agnostic else \
+                bbox_pred.view(bbox_pred.size(0), -1, 4)[pos_index, labels[pos_index]]
             if loss_bbox_type == "GIoULoss":
-                per = giou_loss(pred, bbox_targets_[pos]) * bbox_weights[pos].mean(-1)
+                per = giou_loss(pred, bbox_targets_[pos_index]) * bbox_weights[pos_index].mean(-1)
             else:
-                per = (pred - bbox_targets_[pos]).abs() * bbox_weights[pos]
+                per = (pred - bbox_targets_[pos_index]).abs() * bbox_weights[pos_index]
             losses["loss_bbox"] = loss_bbox_weight * per.sum() / bbox_targets_.size(0)
         else:
-            losses["loss_bbox"] = bbox_pred[pos].sum()
+            losses["loss_bbox"] = bbox_pred[pos_index].sum()
     return losses

@@ -8,6 +8,8 @@
 // operands that are contracted over their ROW index are first transposed into the workspace (zero-padded to a
 // multiple of 64 rows, the GEMM's K granularity): four activation transposes and two weight transposes per layer,
 // about 0.1 GB of HBM traffic against 0.18 TFLOP of GEMM work at ViT-B / 1024^2 / B=2.
+#include <algorithm>
+
 #include "common.h"
 
 namespace {
@@ -28,6 +30,61 @@ __global__ __launch_bounds__(256) void transpose_pad_kernel(const T* __restrict_
     const int c = c0 + i, r = r0 + tx;
     if (c < C && r < Rpad) out[(size_t)c * Rpad + r] = tile[tx][i];
   }
+}
+
+// The same for bf16 with C % 8 == 0, moving 16 bytes per lane on both sides: the tile is staged in LDS as packed pairs
+// [r][c/2] (pitch 33 words); a lane of the store phase gathers the 8 rows of its output vector from one word column
+// (8 row groups x 4 word columns per wave: 32 banks, the two halves of a word share a broadcast).
+__global__ __launch_bounds__(256) void transpose_pad_vec_kernel(const __bf16* __restrict__ in, __bf16* __restrict__ out, int R,
+                                                                int C, int Rpad) {
+  __shared__ uint32_t tile[64][33];
+  const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64, t = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int v = t + 256 * i, row = v >> 3, cv = v & 7;
+    const int r = r0 + row, c = c0 + cv * 8;
+    uint4 d = make_uint4(0u, 0u, 0u, 0u);
+    if (r < R && c < C) d = *reinterpret_cast<const uint4*>(in + (size_t)r * C + c);
+    tile[row][cv * 4 + 0] = d.x;
+    tile[row][cv * 4 + 1] = d.y;
+    tile[row][cv * 4 + 2] = d.z;
+    tile[row][cv * 4 + 3] = d.w;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int v = t + 256 * i, cl = v >> 3, ch = v & 7;
+    const int c = c0 + cl;
+    if (c >= C) continue;
+    const int w = cl >> 1, sh = (cl & 1) * 16;
+    uint32_t e[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) e[j] = (tile[ch * 8 + j][w] >> sh) & 0xffffu;
+    const uint4 o = make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
+    *reinterpret_cast<uint4*>(out + (size_t)c * Rpad + r0 + ch * 8) = o;
+  }
+}
+
+// out[r] = fp32 sum of row r of a bf16 matrix [R, P] (P % 8 == 0): the bias gradient read from the TRANSPOSED, zero-padded
+// upstream gradient the weight-gradient product needs anyway -- contiguous 16-byte loads, one workgroup per row, a fixed
+// summation order (lane-strided partials, then a tree): bit-reproducible.
+__global__ __launch_bounds__(256) void rowsum_bf16_kernel(const __bf16* __restrict__ in, float* __restrict__ out, int P) {
+  __shared__ float sm[256];
+  const __bf16* row = in + (size_t)blockIdx.x * P;
+  float s = 0.0f;
+  for (int i = threadIdx.x * 8; i < P; i += 256 * 8) {
+    const uint4 d = *reinterpret_cast<const uint4*>(row + i);
+    const uint32_t w[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s += __uint_as_float(w[j] << 16) + __uint_as_float(w[j] & 0xffff0000u);
+  }
+  sm[threadIdx.x] = s;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) {
+    if ((int)threadIdx.x < k) sm[threadIdx.x] += sm[threadIdx.x + k];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[blockIdx.x] = sm[0];
 }
 
 // fp32 column sums of in [R, C] in two fixed-order stages: CS_SLICES row slices -> partials [CS_SLICES, C] (in the
@@ -58,6 +115,13 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restri
 
 template <typename T> int transpose_pad(const void* in, void* out, int R, int C, int Rpad, hipStream_t s) {
   dim3 grid(as_ceil_div(Rpad, 64), as_ceil_div(C, 64));
+  if constexpr (sizeof(T) == 2) {
+    if (C % 8 == 0 && Rpad % 64 == 0) {
+      hipLaunchKernelGGL(transpose_pad_vec_kernel, grid, dim3(256), 0, s, (const __bf16*)in, (__bf16*)out, R, C, Rpad);
+      AS_CHECK_LAUNCH("transpose_pad_vec");
+      return AS_OK;
+    }
+  }
   hipLaunchKernelGGL((transpose_pad_kernel<T>), grid, dim3(256), 0, s, (const T*)in, (T*)out, R, C, Rpad);
   AS_CHECK_LAUNCH("transpose_pad");
   return AS_OK;
@@ -69,6 +133,18 @@ template <typename T> int colsum(const void* in, float* out, float* part, int R,
   hipLaunchKernelGGL(colsum_final_kernel, dim3(as_ceil_div(C, 256)), dim3(256), 0, s, (const float*)part, out, C);
   AS_CHECK_LAUNCH("colsum_final");
   return AS_OK;
+}
+
+// db from the transposed gradient [C, Rpad] (bf16) when the caller has it, else the two-stage column sums
+template <typename T> int bias_grad(const void* g, const void* gT, float* out, float* part, int R, int C, int Rpad, hipStream_t s) {
+  if constexpr (sizeof(T) == 2) {
+    if (gT) {
+      hipLaunchKernelGGL(rowsum_bf16_kernel, dim3(C), dim3(256), 0, s, (const __bf16*)gT, out, Rpad);
+      AS_CHECK_LAUNCH("rowsum_bf16");
+      return AS_OK;
+    }
+  }
+  return colsum<T>(g, out, part, R, C, s);
 }
 
 struct BwdLayout {
@@ -94,8 +170,10 @@ BwdLayout bwd_layout(int B, int N, int D, int h, int dtype) {
   L.off_WprojT = take((size_t)D * D * L.es);
   L.off_WqkvT = take((size_t)3 * D * D * L.es);
   L.off_part = take((size_t)CS_SLICES * 3 * D * sizeof(float));
-  // fp32 partial products of the split-K weight-gradient GEMMs (bf16 only; the larger of the two: dWqkv)
-  L.splitk_bytes = dtype == AS_BF16 ? as_linear_splitk_workspace_bytes(3 * D, D, (int)L.Mpad) : 0;
+  // fp32 partial products of the split-K weight-gradient GEMMs (bf16 only; the larger of the two)
+  L.splitk_bytes = dtype == AS_BF16 ? std::max(as_linear_splitk_workspace_bytes(3 * D, D, (int)L.Mpad),
+                                               as_linear_splitk_workspace_bytes(D, D, (int)L.Mpad))
+                                    : 0;
   L.off_splitk = take(L.splitk_bytes);
   L.total = off;
   return L;
@@ -125,7 +203,7 @@ int attn_bwd(const void* x, const void* Wqkv, const void* Wproj, const void* dou
     STEP(as_linear_splitk_fwd(ws + L.off_doutT, ws + L.off_oT, dWproj, D, D, Mpad, dtype, 0, ws + L.off_splitk, L.splitk_bytes, s));
   else
     STEP(as_linear_fwd(ws + L.off_doutT, ws + L.off_oT, nullptr, dWproj, D, D, Mpad, dtype, 0, s));   // dout^T . o
-  if (dbproj) STEP(colsum<T>(dout, dbproj, (float*)(ws + L.off_part), M, D, s));
+  if (dbproj) STEP(bias_grad<T>(dout, ws + L.off_doutT, dbproj, (float*)(ws + L.off_part), M, D, Mpad, s));
   // attention core
   STEP(as_sdpa_bwd(q, k, vt, o, d_o, lse, dqkv, ws + L.off_sdpa, as_sdpa_bwd_workspace_bytes(B, N, h, dtype), B, N, h,
                    dtype, s));
@@ -138,12 +216,68 @@ int attn_bwd(const void* x, const void* Wqkv, const void* Wproj, const void* dou
     STEP(as_linear_splitk_fwd(ws + L.off_dqkvT, ws + L.off_xT, dWqkv, 3 * D, D, Mpad, dtype, 0, ws + L.off_splitk, L.splitk_bytes, s));
   else
     STEP(as_linear_fwd(ws + L.off_dqkvT, ws + L.off_xT, nullptr, dWqkv, 3 * D, D, Mpad, dtype, 0, s)); // dqkv^T . x
-  if (dbqkv) STEP(colsum<T>(dqkv, dbqkv, (float*)(ws + L.off_part), M, 3 * D, s));
+  if (dbqkv) STEP(bias_grad<T>(dqkv, ws + L.off_dqkvT, dbqkv, (float*)(ws + L.off_part), M, 3 * D, Mpad, s));
 #undef STEP
   return AS_OK;
 }
 
+// Backward of one nn.Linear (y = x W^T + b) with the same three pieces: dx = dy . W on the forward kernel against a
+// transposed copy of W, dW = dy^T . x as a split-K product of the transposed activations, db = colsum(dy).
+struct LinBwdLayout {
+  size_t Mpad, off_WT, off_dyT, off_xT, off_part, off_splitk, splitk_bytes, total;
+};
+LinBwdLayout lin_bwd_layout(int M, int Nout, int K) {
+  LinBwdLayout L{};
+  L.Mpad = as_round_up(M, 64);
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+  L.off_WT = take((size_t)K * Nout * 2);
+  L.off_dyT = take((size_t)Nout * L.Mpad * 2);
+  L.off_xT = take((size_t)K * L.Mpad * 2);
+  L.off_part = take((size_t)CS_SLICES * Nout * sizeof(float));
+  L.splitk_bytes = as_linear_splitk_workspace_bytes(Nout, K, (int)L.Mpad);
+  L.off_splitk = take(L.splitk_bytes);
+  L.total = off;
+  return L;
+}
+
 }  // namespace
+
+extern "C" size_t as_linear_bwd_workspace_bytes(int M, int Nout, int K) {
+  if (M <= 0 || Nout <= 0 || K <= 0) return 0;
+  return lin_bwd_layout(M, Nout, K).total;
+}
+
+extern "C" int as_linear_bwd(const void* x, const void* W, const void* dy, void* dx, void* dW, float* db, int M, int Nout,
+                             int K, int dtype, int dw_f32, void* workspace, size_t workspace_bytes, as_stream_t stream) {
+  AS_REQUIRE(dy && workspace && (dx || dW || db), AS_E_BADARG, "as_linear_bwd: null pointer");
+  AS_REQUIRE(!dx || W, AS_E_BADARG, "as_linear_bwd: dx needs W");
+  AS_REQUIRE(!dW || x, AS_E_BADARG, "as_linear_bwd: dW needs x");
+  AS_REQUIRE(dtype == AS_BF16, AS_E_UNSUPPORTED, "as_linear_bwd: bf16 operands only (dtype %d)", dtype);
+  AS_REQUIRE(M > 0 && Nout > 0 && K > 0 && Nout % 32 == 0 && K % 4 == 0, AS_E_BADARG,
+             "as_linear_bwd: need M > 0, Nout %% 32 == 0, K %% 4 == 0 (M=%d Nout=%d K=%d)", M, Nout, K);
+  const LinBwdLayout L = lin_bwd_layout(M, Nout, K);
+  AS_REQUIRE(workspace_bytes >= L.total, AS_E_BADARG, "as_linear_bwd: workspace too small (%zu < %zu)", workspace_bytes,
+             L.total);
+  hipStream_t s = (hipStream_t)stream;
+  char* ws = (char*)workspace;
+  const int Mpad = (int)L.Mpad;
+  int rc;
+  if (dx) {
+    if ((rc = transpose_pad<__bf16>(W, ws + L.off_WT, Nout, K, Nout, s)) != AS_OK) return rc;        // [Nout,K] -> [K,Nout]
+    if ((rc = as_linear_fwd(dy, ws + L.off_WT, nullptr, dx, M, K, Nout, dtype, 0, s)) != AS_OK) return rc;
+  }
+  if (dW) {
+    if ((rc = transpose_pad<__bf16>(dy, ws + L.off_dyT, M, Nout, Mpad, s)) != AS_OK) return rc;
+    if ((rc = transpose_pad<__bf16>(x, ws + L.off_xT, M, K, Mpad, s)) != AS_OK) return rc;
+    if ((rc = as_linear_splitk_fwd(ws + L.off_dyT, ws + L.off_xT, dW, Nout, K, Mpad, dtype, dw_f32, ws + L.off_splitk,
+                                   L.splitk_bytes, s)) != AS_OK)
+      return rc;
+  }
+  if (db && (rc = bias_grad<__bf16>(dy, dW ? ws + L.off_dyT : nullptr, db, (float*)(ws + L.off_part), M, Nout, Mpad, s)) != AS_OK)
+    return rc;
+  return AS_OK;
+}
 
 extern "C" size_t as_attn_bwd_workspace_bytes(int B, int N, int D, int h, int dtype) {
   if (B <= 0 || N <= 0 || D <= 0 || h <= 0) return 0;

@@ -608,12 +608,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   }
 }
 
-// K ranges of the split-K form: as many as fill the 768 resident slots of the 128 x 128 tile once (<= 16), each a multiple
+// K ranges of the split-K form: as many as fill the 768 resident slots of the 128 x 128 tile once (<= 64), each a multiple
 // of the K step and at least 256 long
 int splitk_chunk(int M, int Nout, int K, int* splits) {
   const int tiles = as_ceil_div(M, 128) * as_ceil_div(Nout, 128);
   int S = 768 / (tiles > 0 ? tiles : 1);
-  if (S > 16) S = 16;
+  if (S > 64) S = 64;
   if (S < 1) S = 1;
   int chunk = as_round_up(as_ceil_div(K, S), GK);
   if (chunk < 256) chunk = 256;

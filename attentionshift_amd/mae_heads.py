@@ -69,6 +69,15 @@ def load_mae_decoder_weights(module, pretrained, logger=None):
     load_state_dict(module, sd, strict=False, logger=logger)
 
 
+def _lin(mod, x):
+    """nn.Linear `mod` on x: the HIP GEMM with the split-K weight gradient when training in a bf16 region on a GPU
+    (autograd.LinearFn), the module itself otherwise (fp32 / CPU / no-grad: as the reference)."""
+    from . import autograd as AG
+    if torch.is_grad_enabled() and AG.linear_applies(x, mod.weight) and (mod.weight.requires_grad or x.requires_grad):
+        return AG.linear(x, mod.weight, mod.bias)
+    return mod(x)
+
+
 class SmallAttnFn(torch.autograd.Function):
     """qkv [Bp,N,3,h,32] -> out [Bp,N,h*32]."""
 
@@ -94,8 +103,8 @@ class _Attention(nn.Module):
 
     def forward(self, x):
         B, N, C = x.shape
-        qkv = self.qkv(x).reshape(B, N, 3, self.num_heads, C // self.num_heads)       # the reference's packed layout
-        return self.proj(SmallAttnFn.apply(qkv))
+        qkv = _lin(self.qkv, x).reshape(B, N, 3, self.num_heads, C // self.num_heads)   # the reference's packed layout
+        return _lin(self.proj, SmallAttnFn.apply(qkv))
 
 
 class _Mlp(nn.Module):
@@ -105,7 +114,7 @@ class _Mlp(nn.Module):
         self.fc2 = nn.Linear(hidden, dim)
 
     def forward(self, x):
-        return self.fc2(F.gelu(self.fc1(x)))
+        return _lin(self.fc2, F.gelu(_lin(self.fc1, x)))
 
 
 class DecoderBlock(nn.Module):
@@ -201,7 +210,7 @@ class MAEBoxHeadRec(nn.Module):
         B, C, W, H = x.shape
         x = x.flatten(2).transpose(1, 2)
         if self.with_decoder_embed:
-            x = self.decoder_embed(self.norm(x))
+            x = _lin(self.decoder_embed, self.norm(x))
         x = torch.cat([self.det_token.expand(B, -1, -1), x], dim=1)
         x = x + self.interpolate_pos_encoding(x, W * self.patch_size, H * self.patch_size)
         for blk in self.decoder_blocks:
@@ -219,15 +228,17 @@ class MAEBoxHeadRec(nn.Module):
                             [r.pos_gt_bboxes for r in sampling_results], [r.pos_gt_labels for r in sampling_results],
                             self.num_classes, self.target_means, self.target_stds, pos_weight, self.reg_decoded_bbox)
 
-    def loss(self, cls_score, bbox_pred, rois, labels, label_weights, bbox_targets, bbox_weights):
-        """mae_bbox_head_rec.py:170-221 (the reconstruction term needs with_reconstruct, off in the shipped config)."""
+    def loss(self, cls_score, bbox_pred, rois, labels, label_weights, bbox_targets, bbox_weights, pos_index=None,
+             num_weighted=None):
+        """mae_bbox_head_rec.py:170-221 (the reconstruction term needs with_reconstruct, off in the shipped config).
+        `pos_index` / `num_weighted`: see bbox_loss.bbox_head_loss (known to a caller holding the sampling results)."""
         from .bbox_loss import bbox_head_loss
         out = bbox_head_loss(cls_score, bbox_pred, labels, label_weights, bbox_targets, bbox_weights, self.num_classes,
                              self.reg_class_agnostic, self.loss_cls_cfg.get("loss_weight", 1.0),
                              self.loss_bbox_cfg.get("loss_weight", 1.0),
                              rois=rois[:, 1:] if self.reg_decoded_bbox else None,
                              loss_bbox_type=self.loss_bbox_cfg.get("type", "L1Loss"), means=self.target_means,
-                             stds=self.target_stds)
+                             stds=self.target_stds, pos_index=pos_index, num_weighted=num_weighted)
         return {k: (v * self.loss_weight_bbox_start if k != "acc" else v) for k, v in out.items()}
 
 
@@ -283,7 +294,7 @@ class MAEMaskHeadPointSup(nn.Module):
         B, _, W, H = x.shape
         x = x.flatten(2).transpose(1, 2)
         if self.with_decoder_embed:
-            x = self.decoder_embed(self.norm(x))
+            x = _lin(self.decoder_embed, self.norm(x))
         C = x.shape[-1]
         # as the reference: x carries no class token here, so `npatch = x.shape[1] - 1` never equals the table size and
         # the patch part always goes through the bicubic resize (scale (W + 0.1) / sqrt(N)), even at the native size

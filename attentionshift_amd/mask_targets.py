@@ -12,24 +12,39 @@ import torch.nn.functional as F
 from torch.nn.utils.rnn import pad_sequence
 
 
-def update_coords_with_semantic_centers(points_coords, points_labels, semantic_centers):
+def update_coords_with_semantic_centers(points_coords, points_labels, semantic_centers, labels_host=None):
     """Per image: keep the NEGATIVE mask points of every object and replace its positive ones by the object's
     semantic centres.  points_coords[i] [G,P,2], points_labels[i] [G,P] bool, semantic_centers[i] = list of [k_g,2]
-    (empty list: the image is left as it is).  Ragged rows are padded with (-1,-1) / False, images to a common length."""
+    (empty list: the image is left as it is).  Ragged rows are padded with (-1,-1) / False, images to a common length.
+
+    The row lengths depend on the labels, so a HOST copy of them decides the shapes (`labels_host`: per image a bool
+    array / CPU tensor [G,P] or None; read back here, all images in one transfer, when not given); the device side is
+    one gather per image."""
+    from .roi_head import read_back, to_device
+    todo = [i for i, c in enumerate(semantic_centers) if len(c)]
+    if labels_host is None:
+        labels_host = [None] * len(points_labels)
+        for i, h in zip(todo, read_back([points_labels[i] for i in todo])):
+            labels_host[i] = h
     new_coords, new_labels = [], []
-    for coords, labels, centers in zip(points_coords, points_labels, semantic_centers):
+    for i, (coords, labels, centers) in enumerate(zip(points_coords, points_labels, semantic_centers)):
         if len(centers) == 0:
             new_coords.append(coords)
             new_labels.append(labels)
             continue
-        neg = ~labels
-        sizes = neg.sum(dim=1).tolist()
-        neg_coords = pad_sequence(coords[neg].split(sizes, dim=0), padding_value=-1.0)          # [maxneg, G, 2]
-        neg_labels = pad_sequence(labels[neg].split(sizes, dim=0), padding_value=False)         # all False
-        ctr_coords = pad_sequence(list(centers), padding_value=-1.0)                             # [maxk, G, 2]
+        neg = ~torch.as_tensor(labels_host[i]).bool()                                            # host [G,P]
+        G, maxneg = neg.shape[0], int(neg.sum(dim=1).max()) if neg.numel() else 0
+        # row g of `order` lists the positions of object g's negatives first, in order (stable sort of the flags)
+        order = torch.sort((~neg).to(torch.uint8), dim=1, stable=True)[1][:, :maxneg]
+        valid = torch.gather(neg, 1, order)                                                      # [G, maxneg]
+        order_d, valid_d = to_device(order, coords.device), to_device(valid, coords.device)
+        rows = torch.arange(G, device=coords.device)[:, None]
+        neg_coords = torch.where(valid_d[..., None], coords[rows, order_d], coords.new_full((), -1.0))   # [G, maxneg, 2]
+        neg_labels = torch.zeros(G, maxneg, dtype=labels.dtype, device=labels.device)
+        ctr_coords = pad_sequence(list(centers), padding_value=-1.0).transpose(0, 1)             # [G, maxk, 2]
         ctr_labels = torch.ones(ctr_coords.shape[:-1], dtype=neg_labels.dtype, device=neg_labels.device)
-        new_coords.append(torch.cat((neg_coords, ctr_coords), dim=0).transpose(0, 1))
-        new_labels.append(torch.cat((neg_labels, ctr_labels), dim=0).transpose(0, 1))
+        new_coords.append(torch.cat((neg_coords, ctr_coords), dim=1))
+        new_labels.append(torch.cat((neg_labels, ctr_labels), dim=1))
     width = max(c.shape[1] for c in new_coords)
     new_coords = [F.pad(c, (0, 0, 0, width - c.shape[1]), value=-1) for c in new_coords]
     new_labels = [F.pad(l, (0, width - l.shape[1]), value=False) for l in new_labels]
@@ -53,7 +68,8 @@ def point_sample(inp, points, align_corners=False):
     return F.grid_sample(inp, grid, align_corners=align_corners).squeeze(3)
 
 
-def mask_point_targets(pos_bboxes, assigned_gt_inds, points_coords, points_labels, semantic_centers, literal=True):
+def mask_point_targets(pos_bboxes, assigned_gt_inds, points_coords, points_labels, semantic_centers, literal=True,
+                       labels_host=None):
     """Target half of _mask_forward_train (:3106, :3134-3152): per image i, `pos_bboxes[i]` [R_i,4] are the positive
     proposals and `assigned_gt_inds[i]` [R_i] their object; returns (sites [R,P,2] box-normalised, targets [R,P]).
 
@@ -61,7 +77,7 @@ def mask_point_targets(pos_bboxes, assigned_gt_inds, points_coords, points_label
     stores True, so its loss (`mask_targets == 2`) never ignores anything and those points count as foreground.
     `literal=True` reproduces that (targets stay bool); `literal=False` gives the evident intent: long targets with
     1 = foreground, 0 = background, 2 = ignored."""
-    coords, labels = update_coords_with_semantic_centers(points_coords, points_labels, semantic_centers)
+    coords, labels = update_coords_with_semantic_centers(points_coords, points_labels, semantic_centers, labels_host)
     boxes = torch.cat(list(pos_bboxes))
     sites = torch.cat([c[idx] for c, idx in zip(coords, assigned_gt_inds)])
     targets = torch.cat([l[idx] for l, idx in zip(labels, assigned_gt_inds)])

@@ -184,8 +184,7 @@ class MAEBoxHeadMIL(nn.Module):
         bag = cls * prop
         picked = torch.gather(bag, -1, gt_labels.reshape(-1, 1, 1).repeat(1, Lq, 1))[..., 0]
         gt_index = picked.max(-1)[1]
-        onehot = torch.zeros(len(gt_labels), K, dtype=bag.dtype, device=bag.device)
-        onehot[torch.arange(len(gt_labels), device=bag.device), gt_labels] = 1
+        onehot = torch.zeros(len(gt_labels), K, dtype=bag.dtype, device=bag.device).scatter_(1, gt_labels.reshape(-1, 1), 1.0)
         return gt_index, self.loss_mil_factor * self.mil_losses(bag.sum(1), onehot)
 
 

@@ -139,6 +139,32 @@ def linear_splitk(x, weight, out_dtype=None):
     return out
 
 
+_LINEAR_BWD_WS = {}
+
+
+def linear_bwd(x, weight, dy, need_dx=True, need_dw=True, need_db=True, dw_dtype=None):
+    """Backward of y = x @ weight.T + b for bf16 x [M,K], weight [Nout,K], dy [M,Nout] -> (dx bf16 | None, dW | None,
+    db fp32 | None); dW in `dw_dtype` (bf16 default, fp32 for fp32 master weights).  as_linear_bwd."""
+    lib = _lib.load()
+    _chk(x, weight, dy, dtype=torch.bfloat16)
+    M, K = x.shape
+    Nout = weight.shape[0]
+    if weight.shape[1] != K or tuple(dy.shape) != (M, Nout):
+        raise AttnShiftError("linear_bwd: shapes must be x [M,K], weight [Nout,K], dy [M,Nout]")
+    dw_dtype = dw_dtype or torch.bfloat16
+    dx = torch.empty(M, K, device=x.device, dtype=torch.bfloat16) if need_dx else None
+    dW = torch.empty(Nout, K, device=x.device, dtype=dw_dtype) if need_dw else None
+    db = torch.empty(Nout, device=x.device, dtype=torch.float32) if need_db else None
+    nbytes = int(lib.as_linear_bwd_workspace_bytes(M, Nout, K))
+    key = (x.device, torch.cuda.current_stream(x.device).cuda_stream)
+    ws = _LINEAR_BWD_WS.get(key)                    # one growing scratch buffer per (device, stream): the calls of a
+    if ws is None or ws.numel() * 4 < nbytes:       # backward pass are serial on their stream
+        ws = _LINEAR_BWD_WS[key] = torch.empty((nbytes + 3) // 4, device=x.device, dtype=torch.float32)
+    _lib.check(lib.as_linear_bwd(_p(x), _p(weight), _p(dy), _p(dx), _p(dW), _p(db), M, Nout, K, AS_BF16,
+                                 1 if dw_dtype == torch.float32 else 0, _p(ws), nbytes, _stream()), "as_linear_bwd")
+    return dx, dW, db
+
+
 def deconv2x2(x_nhwc, w4, bias4=None, act="none"):
     """ConvTranspose2d(k=2, s=2) on a channels-last bf16 map [B,h,w,cin] -> [B,2h,2w,cout] (one GEMM, scattered epilogue).
     w4 [4*cout, cin] bf16 (row (di*2+dj)*cout + co), bias4 [4*cout] fp32 | None."""

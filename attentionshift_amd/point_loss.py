@@ -11,8 +11,6 @@ are supervised by the GT points.  Host-side tensor logic on a [B, 100, K] / [B, 
 import torch
 import torch.nn.functional as F
 
-from .roi_head import hungarian_point_match
-
 
 def sigmoid_focal_loss(pred, target, weight=None, gamma=2.0, alpha=0.25, avg_factor=None):
     """mmdet's py_sigmoid_focal_loss: pred [n,K] logits, target [n] class index (K = background), weight [n] | None."""
@@ -26,45 +24,78 @@ def sigmoid_focal_loss(pred, target, weight=None, gamma=2.0, alpha=0.25, avg_fac
     return loss.sum() / avg_factor if avg_factor is not None else loss.mean()
 
 
+def point_matches(point_cls, point_reg, gt_points, gt_labels, img_shapes, cls_cost=1.0, reg_cost=10.0, costs_host=None):
+    """Hungarian match of every image's tokens to its GT points -> list of (token indices ascending, GT index of each),
+    numpy int64 on the HOST.  All images' cost matrices are built on the device and read back together (one host sync);
+    `costs_host` (list of host [T, G_i] matrices, None for an image without points) skips that readback."""
+    import numpy as np
+    from .roi_head import hungarian_rows_cols, point_match_cost, read_back
+    B = point_reg.shape[0]
+    live = [i for i in range(B) if gt_points[i].shape[0] and point_reg.shape[1]]
+    if costs_host is None:
+        costs = [point_match_cost(point_reg[i].detach(), point_cls[i].detach(), gt_points[i], gt_labels[i], img_shapes[i],
+                                  cls_weight=cls_cost, reg_weight=reg_cost) for i in live]
+        costs_host = [None] * B
+        for i, c in zip(live, read_back(costs)):
+            costs_host[i] = c
+    empty = np.zeros(0, dtype=np.int64)
+    return [hungarian_rows_cols(np.asarray(costs_host[i])) if i in live else (empty, empty) for i in range(B)]
+
+
 def point_targets(point_cls, point_reg, gt_points, gt_labels, img_shapes, num_classes, point_pos_weight=1,
-                  cls_cost=1.0, reg_cost=10.0):
+                  cls_cost=1.0, reg_cost=10.0, matches=None):
     """Per image Hungarian match of the tokens to the GT points; returns flattened (labels [B*T] long, label_weights
-    [B*T], point_targets [B*T,2], point_weights [B*T,2]) as get_targets(concat=True) does."""
+    [B*T], point_targets [B*T,2], point_weights [B*T,2]) as get_targets(concat=True) does.  `matches`: the result of
+    `point_matches` when the caller already has it."""
+    from .roi_head import to_device
     B, T = point_reg.shape[:2]
     dev = point_reg.device
+    if matches is None:
+        matches = point_matches(point_cls, point_reg, gt_points, gt_labels, img_shapes, cls_cost, reg_cost)
     labels = torch.full((B, T), num_classes, dtype=torch.long, device=dev)
     label_w = torch.ones(B, T, device=dev)
     tgt = torch.zeros(B, T, 2, device=dev)
     tgt_w = torch.zeros(B, T, 2, device=dev)
-    for i in range(B):
-        pos, matched = hungarian_point_match(point_reg[i].detach(), point_cls[i].detach(), gt_points[i], gt_labels[i],
-                                             img_shapes[i], cls_weight=cls_cost, reg_weight=reg_cost)
-        if pos.numel():
+    for i, (pos_h, matched_h) in enumerate(matches):
+        if len(pos_h):
+            pos, matched = to_device(pos_h, dev, torch.long), to_device(matched_h, dev, torch.long)
             labels[i, pos] = gt_labels[i][matched]
-            label_w[i, pos] = 1.0 if point_pos_weight <= 0 else float(point_pos_weight)
+            # (index_fill_: a scalar on the right of an indexed assignment is uploaded as a tensor, which waits)
+            label_w[i].index_fill_(0, pos, 1.0 if point_pos_weight <= 0 else float(point_pos_weight))
             tgt[i, pos] = gt_points[i][matched].to(tgt.dtype)
-            tgt_w[i, pos] = 1.0
+            tgt_w[i].index_fill_(0, pos, 1.0)
     return labels.flatten(), label_w.flatten(), tgt.flatten(0, 1), tgt_w.flatten(0, 1)
 
 
 def point_token_loss(point_cls, point_reg, gt_points, gt_labels, img_shapes, num_classes=20, loss_point_weight=10.0,
-                     loss_cls_weight=1.0, gamma=2.0, alpha=0.25, ranks=None, **assign_kw):
-    """point_cls [B,T,K] logits, point_reg [B,T,2] in (0,1) -> dict(loss_point_cls, loss_point, pos_point_acc)."""
+                     loss_cls_weight=1.0, gamma=2.0, alpha=0.25, ranks=None, matches=None, point_pos_weight=1,
+                     cls_cost=1.0, reg_cost=10.0):
+    """point_cls [B,T,K] logits, point_reg [B,T,2] in (0,1) -> dict(loss_point_cls, loss_point, pos_point_acc).
+    The matched tokens are known on the host after the Hungarian match, so everything after it is index arithmetic on
+    host arrays + gathers on the device: the match's cost readback is the only host sync."""
+    import numpy as np
+    from .roi_head import to_device
     B, T, K = point_cls.shape
-    labels, label_w, tgt, tgt_w = point_targets(point_cls, point_reg, gt_points, gt_labels, img_shapes, num_classes, **assign_kw)
+    if matches is None:
+        matches = point_matches(point_cls, point_reg, gt_points, gt_labels, img_shapes, cls_cost, reg_cost)
+    labels, label_w, tgt, tgt_w = point_targets(point_cls, point_reg, gt_points, gt_labels, img_shapes, num_classes,
+                                                point_pos_weight, cls_cost, reg_cost, matches=matches)
     cls_score, pred = point_cls.reshape(-1, K).float(), point_reg.reshape(-1, 2)
-    pos = (labels >= 0) & (labels < num_classes)
-    num_pos = pos.sum().float()
+    # the positives (0 <= label < num_classes) are the matched tokens: flat indices in ascending order, as a mask gives
+    pos_h = np.concatenate([i * T + m[0] for i, m in enumerate(matches)]) if B else np.zeros(0, dtype=np.int64)
+    n_pos = float(len(pos_h))
     if ranks is not None and getattr(ranks, "world", 1) > 1:           # mmdet reduce_mean
-        num_pos = torch.as_tensor(ranks.sum_over_ranks(float(num_pos)) / ranks.world, device=pred.device)
-    avg = num_pos.clamp(min=1e-6) if float(num_pos) == 0 else num_pos
+        n_pos = ranks.sum_over_ranks(n_pos) / ranks.world
+    avg = max(n_pos, 1e-6) if n_pos == 0 else n_pos
     out = dict(loss_point_cls=loss_cls_weight * sigmoid_focal_loss(cls_score, labels, label_w, gamma, alpha, avg_factor=avg))
-    out["pos_point_acc"] = ((cls_score[pos].argmax(1) == labels[pos]).float().mean() * 100.0 if pos.any()
-                            else cls_score.new_zeros(()))
-    if pos.any():
-        whwh = torch.cat([pred.new_tensor([s[1], s[0]]).expand(T, 2) for s in img_shapes])      # (W, H) per token
-        l1 = (pred[pos] - tgt[pos] / whwh[pos]).abs() * tgt_w[pos]
+    if len(pos_h):
+        pos = to_device(pos_h, pred.device, torch.long)
+        out["pos_point_acc"] = (cls_score[pos].argmax(1) == labels[pos]).float().mean() * 100.0
+        wh = np.concatenate([np.tile(np.asarray([[img_shapes[i][1], img_shapes[i][0]]], dtype=np.float32), (len(m[0]), 1))
+                             for i, m in enumerate(matches)])                       # (W, H) of each matched token's image
+        l1 = (pred[pos] - tgt[pos] / to_device(wh, pred.device, pred.dtype)).abs() * tgt_w[pos]
         out["loss_point"] = loss_point_weight * l1.sum() / avg
     else:
+        out["pos_point_acc"] = cls_score.new_zeros(())
         out["loss_point"] = pred.sum() * 0
     return out

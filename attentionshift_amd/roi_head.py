@@ -121,6 +121,30 @@ def _to_host_numpy(t):
     return host.numpy()
 
 
+def to_device(values, device, dtype=None):
+    """Host values (numpy array / CPU tensor / list) -> tensor on `device` WITHOUT a host sync: through a pinned staging
+    tensor and a non-blocking copy (a pageable `torch.as_tensor(..., device=cuda)` waits for the stream to drain)."""
+    t = torch.as_tensor(values, dtype=dtype)
+    if torch.device(device).type != "cuda" or t.numel() == 0:
+        return t.to(device)
+    return t.pin_memory().to(device, non_blocking=True)
+
+
+def read_back(pieces):
+    """Device tensors -> list of fp32 CPU tensors of the same shapes with ONE transfer and one host sync (values must be
+    exact in fp32: small integers, bools, fp32 numbers)."""
+    if not pieces:
+        return []
+    if not pieces[0].is_cuda:
+        return [p_.detach().float().cpu() for p_ in pieces]
+    flat = torch.from_numpy(_to_host_numpy(torch.cat([p_.detach().reshape(-1).float() for p_ in pieces])))
+    out, off = [], 0
+    for p_ in pieces:
+        out.append(flat[off:off + p_.numel()].view(p_.shape))
+        off += p_.numel()
+    return out
+
+
 
 # --------------------------------------------------------------------------------------------------
 # host-side matching (stdroi:2237-2257; HungarianPointAssigner mmdet/core/bbox/assigners/
@@ -129,20 +153,34 @@ def _to_host_numpy(t):
 def hungarian_point_match(point_pred, cls_pred, gt_points, gt_labels, img_shape, cls_weight=1.0, reg_weight=10.0,
                           alpha=0.25, gamma=2.0, eps=1e-12):
     """Returns (pos_inds ascending [G'], matched gt index per pos_ind [G'])."""
-    from scipy.optimize import linear_sum_assignment
     if gt_points.shape[0] == 0 or point_pred.shape[0] == 0:
         z = torch.zeros(0, dtype=torch.long, device=point_pred.device)
         return z, z
+    cost = point_match_cost(point_pred, cls_pred, gt_points, gt_labels, img_shape, cls_weight, reg_weight, alpha, gamma, eps)
+    rows, cols = hungarian_rows_cols(cost.detach().cpu().numpy())
+    dev = point_pred.device
+    return to_device(rows, dev, torch.long), to_device(cols, dev, torch.long)
+
+
+def point_match_cost(point_pred, cls_pred, gt_points, gt_labels, img_shape, cls_weight=1.0, reg_weight=10.0, alpha=0.25,
+                     gamma=2.0, eps=1e-12):
+    """[T, G] matching cost (FocalLossCost + PointL1Cost, match_cost.py:52-104) on the inputs' device; no host sync."""
     img_h, img_w = img_shape[:2]
-    factor = gt_points.new_tensor([img_w, img_h]).unsqueeze(0)
     p = cls_pred.sigmoid()
     neg = -(1 - p + eps).log() * (1 - alpha) * p.pow(gamma)
     pos = -(p + eps).log() * alpha * (1 - p).pow(gamma)
-    cost = (pos[:, gt_labels] - neg[:, gt_labels]) * cls_weight + torch.cdist(point_pred, gt_points / factor, p=1) * reg_weight
-    rows, cols = linear_sum_assignment(cost.detach().cpu().numpy())
+    # torch.cdist(p=1) of 2-d points, written out (two terms: the same fp32 sum) with the scale applied per axis
+    gx, gy = gt_points[:, 0] / img_w, gt_points[:, 1] / img_h
+    l1 = (point_pred[:, None, 0] - gx[None, :]).abs() + (point_pred[:, None, 1] - gy[None, :]).abs()
+    return (pos[:, gt_labels] - neg[:, gt_labels]) * cls_weight + l1 * reg_weight
+
+
+def hungarian_rows_cols(cost_np):
+    """scipy's assignment on a host cost matrix -> (token indices ascending, their GT index), numpy int64."""
+    from scipy.optimize import linear_sum_assignment
+    rows, cols = linear_sum_assignment(cost_np)
     order = np.argsort(rows)
-    dev = point_pred.device
-    return torch.as_tensor(rows[order], device=dev, dtype=torch.long), torch.as_tensor(cols[order], device=dev, dtype=torch.long)
+    return rows[order].astype(np.int64), cols[order].astype(np.int64)
 
 
 # --------------------------------------------------------------------------------------------------
@@ -706,49 +744,75 @@ class AttnShiftRoIHead(nn.Module):
         `mask_point_*` / `semantic_centers_split` are what seed_pseudo_gt returned (two_stage_point_align.py:95-135)."""
         from . import assign as A
         from .mask_targets import mask_point_targets, point_sample
-        from .point_loss import point_token_loss
+        from .point_loss import point_matches, point_token_loss
         if not isinstance(self.bbox_head, nn.Module):
             raise RuntimeError("forward_train needs the box head built from its config (bbox_head with in_channels)")
         num_imgs = len(img_metas)
         rcnn = self.train_cfg
         losses = {}
         pa = _get(rcnn, "point_assigner", None)
+        asg = dict(_get(rcnn, "assigner", None) or {})
+        smp = dict(_get(rcnn, "sampler", None) or {})
+        with_mask = self.mask_head is not None and mask_point_coords is not None
+        shapes = [m["img_shape"] for m in img_metas]
+        # Everything whose SHAPE depends on data is decided on the host from ONE readback: the Hungarian cost matrices of
+        # the point tokens, the proposals' IoU assignment (the sampler permutes `randperm(count)`) and the mask points'
+        # labels (the negatives of an object are ragged).  The device work in between is queued without a sync.
+        pieces, what = [], []
+        if pa:
+            cls_cost, reg_cost = _get(pa, "cls_cost", {}).get("weight", 1.0), _get(pa, "reg_cost", {}).get("weight", 1.0)
+            for i in range(num_imgs):
+                if gt_points[i].shape[0] and point_reg.shape[1]:
+                    pieces.append(point_match_cost(point_reg[i].detach(), point_cls[i].detach(), gt_points[i],
+                                                   gt_points_labels[i], shapes[i], cls_weight=cls_cost, reg_weight=reg_cost))
+                    what.append(("cost", i))
+        assigned = []
+        for i in range(num_imgs):                                              # :2624-2636
+            assigned.append(A.max_iou_assign(proposal_list[i][:, :4], gt_bboxes[i], asg.get("pos_iou_thr", 0.5),
+                                             asg.get("neg_iou_thr", 0.5), asg.get("min_pos_iou", 0.5),
+                                             asg.get("match_low_quality", False))[0])
+            pieces.append(assigned[i])
+            what.append(("assigned", i))
+        if with_mask:
+            for i in range(num_imgs):
+                if len(semantic_centers_split[i]):
+                    pieces.append(mask_point_labels[i])
+                    what.append(("mask_labels", i))
+        host = {k: v for k, v in zip(what, read_back(pieces))}
         if pa:                                                                 # :2568-2602
             bh = self.bbox_head
+            matches = point_matches(point_cls, point_reg, gt_points, gt_points_labels, shapes, cls_cost, reg_cost,
+                                    costs_host=[host.get(("cost", i)) for i in range(num_imgs)])
             losses.update(point_token_loss(
-                point_cls, point_reg, gt_points, gt_points_labels, [m["img_shape"] for m in img_metas],
+                point_cls, point_reg, gt_points, gt_points_labels, shapes,
                 num_classes=bh.num_classes, loss_point_weight=bh.loss_point_cfg.get("loss_weight", 10.0),
                 loss_cls_weight=bh.loss_point_cls_cfg.get("loss_weight", 1.0),
                 gamma=bh.loss_point_cls_cfg.get("gamma", 2.0), alpha=bh.loss_point_cls_cfg.get("alpha", 0.25),
-                point_pos_weight=_get(rcnn, "point_pos_weight", 1),
-                cls_cost=_get(pa, "cls_cost", {}).get("weight", 1.0), reg_cost=_get(pa, "reg_cost", {}).get("weight", 1.0),
+                point_pos_weight=_get(rcnn, "point_pos_weight", 1), cls_cost=cls_cost, reg_cost=reg_cost, matches=matches,
                 ranks=getattr(self, "ranks", None)))        # reduce_mean of the matched-token count (stdroi:3430-3514)
-        asg = dict(_get(rcnn, "assigner", None) or {})
-        smp = dict(_get(rcnn, "sampler", None) or {})
-        sampling_results = []
-        for i in range(num_imgs):                                              # :2624-2636
-            props = proposal_list[i][:, :4]
-            assigned, _ = A.max_iou_assign(props, gt_bboxes[i], asg.get("pos_iou_thr", 0.5), asg.get("neg_iou_thr", 0.5),
-                                           asg.get("min_pos_iou", 0.5), asg.get("match_low_quality", False))
-            sampling_results.append(A.random_sample(props, gt_bboxes[i], gt_labels[i], assigned, smp.get("num", 512),
-                                                    smp.get("pos_fraction", 0.25), smp.get("add_gt_as_proposals", True),
-                                                    generator))
+        sampling_results = [A.random_sample(proposal_list[i][:, :4], gt_bboxes[i], gt_labels[i], assigned[i],
+                                            smp.get("num", 512), smp.get("pos_fraction", 0.25),
+                                            smp.get("add_gt_as_proposals", True), generator,
+                                            assigned_host=host[("assigned", i)]) for i in range(num_imgs)]
         # ---- box branch (:2974-3020) ----
         rois = torch.cat([torch.cat((r.bboxes.new_full((r.bboxes.shape[0], 1), float(i)), r.bboxes), dim=1)
                           for i, r in enumerate(sampling_results)])
         bbox_feats = self._roi_extract(x, rois)
         cls_score, bbox_pred, _rec = self.bbox_head(bbox_feats)
         targets = self.bbox_head.get_targets(sampling_results, _get(rcnn, "pos_weight", -1))
-        losses.update(self.bbox_head.loss(cls_score, bbox_pred, rois, *targets))
+        # the rows of the positives: each image's block of `rois` starts with them
+        offs = np.cumsum([0] + [r.bboxes.shape[0] for r in sampling_results])
+        pos_rows = np.concatenate([offs[i] + np.arange(r.pos_bboxes.shape[0]) for i, r in enumerate(sampling_results)])
+        pos_index = to_device(pos_rows.astype(np.int64), rois.device)
+        losses.update(self.bbox_head.loss(cls_score, bbox_pred, rois, *targets, pos_index=pos_index,
+                                          num_weighted=int(rois.shape[0])))
         # ---- mask branch (:3094-3160): the positives' BOX features through the mask head, BCE at the mask points ----
-        if self.mask_head is not None and mask_point_coords is not None:
-            pos = torch.cat([torch.cat((torch.ones(r.pos_bboxes.shape[0], dtype=torch.bool, device=rois.device),
-                                        torch.zeros(r.neg_bboxes.shape[0], dtype=torch.bool, device=rois.device)))
-                             for r in sampling_results])
-            mask_pred = self.mask_head(bbox_feats[pos])
+        if with_mask:
+            mask_pred = self.mask_head(bbox_feats[pos_index])
             sites, mask_t = mask_point_targets([r.pos_bboxes for r in sampling_results],
                                                [r.pos_assigned_gt_inds for r in sampling_results],
-                                               mask_point_coords, mask_point_labels, semantic_centers_split)
+                                               mask_point_coords, mask_point_labels, semantic_centers_split,
+                                               labels_host=[host.get(("mask_labels", i)) for i in range(num_imgs)])
             pos_labels = torch.cat([r.pos_gt_labels for r in sampling_results])
             if mask_pred.shape[0]:
                 losses.update(self.mask_head.loss(point_sample(mask_pred, sites, align_corners=False), mask_t, pos_labels))

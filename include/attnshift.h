@@ -146,6 +146,16 @@ size_t as_linear_splitk_workspace_bytes(int M, int Nout, int K);
 int as_linear_splitk_fwd(const void* x, const void* W, void* out, int M, int Nout, int K, int dtype, int out_f32,
                          void* workspace, size_t workspace_bytes, as_stream_t stream);
 
+/* Backward of one nn.Linear y = x W^T + b under autograd (models/vision_transformer.py:47-59 the MLP, :75-77,84 and the
+ * MAE-decoder heads' layers, mae_bbox_head_rec.py:148-168), x [M,K], W [Nout,K], dy [M,Nout] bf16:
+ *   dx [M,K] bf16   = dy . W           (NULL: skipped)   on the forward kernel against a transposed copy of W
+ *   dW [Nout,K]     = dy^T . x         (NULL: skipped)   split-K over the rows (as_linear_splitk_fwd), bf16 or fp32 (dw_f32)
+ *   db [Nout] fp32  = column sums of dy (NULL: skipped)  two fixed-order stages, no atomics
+ * Nout % 32 == 0, K % 4 == 0; workspace: as_linear_bwd_workspace_bytes(M, Nout, K). */
+size_t as_linear_bwd_workspace_bytes(int M, int Nout, int K);
+int as_linear_bwd(const void* x, const void* W, const void* dy, void* dx, void* dW, float* db, int M, int Nout, int K,
+                  int dtype, int dw_f32, void* workspace, size_t workspace_bytes, as_stream_t stream);
+
 /* k x k / stride-k max pooling of a token-major (NHWC) fp32 map [B,H,W,C] -> [B,H/k,W/k,C] (contiguous): the FPN's
  * coarsest tap, nn.MaxPool2d(k, k) (mmdet/models/backbones/visual_transformer_det.py:120,129,133) on the layout the taps
  * live in here.  x_batch_stride = elements between consecutive images of x (>= H*W*C, multiple of 4): the tap is the

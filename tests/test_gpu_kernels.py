@@ -84,6 +84,45 @@ def test_linear_splitk_matches_fp32_matmul(ops, M, N, K, out_dtype):
     assert torch.equal(got, ops.linear_splitk(dev(x), dev(w), out_dtype))
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K,w_dtype", [(8394, 3072, 768, torch.bfloat16), (8394, 768, 3072, torch.bfloat16),
+                                           (51200, 1024, 256, torch.float32), (50176, 256, 768, torch.float32),
+                                           (1000, 96, 36, torch.float32)])
+def test_linear_autograd_fn_matches_fp64_autograd(ops, M, N, K, w_dtype):
+    """autograd.LinearFn (as_linear_fwd forward, as_linear_bwd backward: dx on the forward kernel, split-K dW, column-sum
+    db) vs fp64 autograd of the same bf16-rounded operands; shapes: the backbone MLP and the MAE heads' layers (rows of
+    50 k tokens, fp32 master weights) and a small ragged one.  Run twice: bitwise equal gradients (no atomics)."""
+    from attentionshift_amd import autograd as AG
+    g = torch.Generator().manual_seed(M + N + K)
+    x = (torch.randn(M, K, generator=g) * 0.5).bfloat16()
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).to(w_dtype)
+    b = torch.randn(N, generator=g)
+    dy = (torch.randn(M, N, generator=g) * 0.1).bfloat16()
+    if K % 32:                                              # sizes the kernels do not take are refused by the predicate
+        assert not AG.linear_applies(dev(x), dev(w))
+        return
+    with torch.enable_grad():
+        xr, wr, br = x.double().requires_grad_(True), w.bfloat16().double().requires_grad_(True), b.double().requires_grad_(True)
+        ref = torch.nn.functional.linear(xr, wr, br)
+        ref.backward(dy.double())
+
+        def run():
+            xd, wd, bd = dev(x).requires_grad_(True), dev(w).requires_grad_(True), dev(b).requires_grad_(True)
+            out = AG.linear(xd, wd, bd)
+            out.backward(dev(dy))
+            return out.detach(), xd.grad, wd.grad, bd.grad
+
+        out, dx, dw, db = run()
+    assert out.dtype == torch.bfloat16 and dx.dtype == torch.bfloat16 and dw.dtype == w_dtype and db.dtype == torch.float32
+    for name, got, want, tol in (("out", out, ref.detach(), 1e-2), ("dx", dx, xr.grad, 1e-2),
+                                 ("dw", dw, wr.grad, 1e-2 if w_dtype == torch.bfloat16 else 1e-4), ("db", db, br.grad, 1e-4)):
+        mx, mean = rel_to_range(want, got.float())
+        assert mx < tol and mean < tol / 5, (name, mx, mean)
+    with torch.enable_grad():
+        again = run()
+    assert all(torch.equal(a, b_) for a, b_ in zip((out, dx, dw, db), again))
+
+
 _TILE_SCRIPT = """
 import sys, torch
 sys.path.insert(0, %r)

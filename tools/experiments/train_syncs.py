@@ -25,9 +25,13 @@ def hook(message, category, filename, lineno, file=None, line=None):
     if "synchroniz" not in str(message):
         return
     site = "?"
-    for fr in reversed(traceback.extract_stack(limit=30)):
+    stack = traceback.extract_stack(limit=40)
+    for k in range(len(stack) - 1, -1, -1):
+        fr = stack[k]
         if ROOT in fr.filename and "train_syncs" not in fr.filename:
             site = f"{os.path.relpath(fr.filename, ROOT)}:{fr.lineno} ({fr.name})"
+            if k + 1 < len(stack) - 2:                       # what the repo line called (torch internals)
+                site += " -> " + stack[k + 1].name
             break
     sites[site] += 1
 
