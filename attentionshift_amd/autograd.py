@@ -84,7 +84,7 @@ def linear_applies(x, weight):
         return False
     if x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16:
         return True
-    return torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16
+    return torch.is_autocast_enabled('cuda') and torch.get_autocast_dtype('cuda') == torch.bfloat16
 
 
 class ParamCastFn(torch.autograd.Function):

@@ -97,7 +97,10 @@ __global__ __launch_bounds__(RB_NT) void roi_align_bwd_kernel(const float* __res
   float* Ax = Ay + RB_BATCH * out * H;              // [RB_BATCH][out][W]
   float* Dd = Ax + RB_BATCH * out * W;              // [RB_BATCH][nb][RB_CH]
   int* span = reinterpret_cast<int*>(Dd + RB_BATCH * nb * RB_CH);      // [RB_BATCH][4] = ylo, yhi, xlo, xhi (inclusive)
-  int* cnt_s = span + RB_BATCH * 4;                 // [4] counters (all LDS lives in the dynamic region)
+  // per (RoI, pixel row / column): the first and last bin with a non-zero weight there, packed lo | hi << 16 -- a pixel
+  // touches 1-3 bins per axis, not all `out` of them (filled from the finished tables, one thread per position)
+  int* brange = span + RB_BATCH * 4;                // [RB_BATCH][H + W]
+  int* cnt_s = brange + RB_BATCH * (H + W);         // [4] counters (all LDS lives in the dynamic region)
   int& nlist_s = cnt_s[0];
   int* list_s = cnt_s + 4;                          // [R] RoIs of this image, RoI order
 
@@ -167,6 +170,18 @@ __global__ __launch_bounds__(RB_NT) void roi_align_bwd_kernel(const float* __res
           *reinterpret_cast<const float4*>(dout + ((size_t)list_s[l0 + j] * nb + bin) * C + c0 + q * 4);
     }
     __syncthreads();
+    // bin ranges: one thread per (RoI, pixel row or column) scans that position's column of the finished table
+    for (int i = tid; i < RB_BATCH * (H + W); i += RB_NT) {
+      const int j = i / (H + W), q = i - j * (H + W);
+      const float* col = q < H ? Ay + j * out * H + q : Ax + j * out * W + (q - H);
+      const int stride = q < H ? H : W;
+      int lo = 0x7fff, hi = 0;                                          // empty: lo > hi
+      if (j < nl)
+        for (int p = 0; p < out; ++p)
+          if (col[p * stride] != 0.0f) { lo = min(lo, p); hi = p; }
+      brange[i] = lo | (hi << 16);
+    }
+    __syncthreads();
 #pragma unroll
     for (int k = 0; k < RB_MAXPT; ++k) {
       const int pix = tid + k * RB_NT;
@@ -177,10 +192,12 @@ __global__ __launch_bounds__(RB_NT) void roi_align_bwd_kernel(const float* __res
         const float* ay = Ay + j * out * H + py;
         const float* ax = Ax + j * out * W + px;
         const float* d = Dd + j * nb * RB_CH;
-        for (int ph = 0; ph < out; ++ph) {
+        const int ry = brange[j * (H + W) + py], rx = brange[j * (H + W) + H + px];
+        const int ph1 = ry >> 16, pw0 = rx & 0xffff, pw1 = rx >> 16;
+        for (int ph = ry & 0xffff; ph <= ph1; ++ph) {
           const float wy = ay[ph * H];
           if (wy == 0.0f) continue;
-          for (int pw = 0; pw < out; ++pw) {
+          for (int pw = pw0; pw <= pw1; ++pw) {
             const float w = wy * ax[pw * W];
             if (w == 0.0f) continue;
             const float4 d0 = *reinterpret_cast<const float4*>(d + (ph * out + pw) * RB_CH);
@@ -230,7 +247,8 @@ extern "C" int as_roi_align_bwd(const float* dout, const float* rois, float* dfe
   AS_REQUIRE(C % RB_CH == 0, AS_E_UNSUPPORTED, "as_roi_align_bwd: C=%d must be a multiple of %d", C, RB_CH);
   AS_REQUIRE(H * W <= RB_NT * RB_MAXPT, AS_E_UNSUPPORTED, "as_roi_align_bwd: a %dx%d map exceeds %d pixels", H, W, RB_NT * RB_MAXPT);
   AS_REQUIRE(out_size * 2 * RB_BATCH <= RB_NT, AS_E_UNSUPPORTED, "as_roi_align_bwd: output size %d", out_size);
-  const size_t lds = ((size_t)RB_BATCH * out_size * (H + W) + (size_t)RB_BATCH * out_size * out_size * RB_CH + RB_BATCH * 4 + 4 + (size_t)R) * 4;
+  const size_t lds = ((size_t)RB_BATCH * out_size * (H + W) + (size_t)RB_BATCH * out_size * out_size * RB_CH + RB_BATCH * 4 +
+                      (size_t)RB_BATCH * (H + W) + 4 + (size_t)R) * 4;
   AS_REQUIRE(lds <= 150 * 1024, AS_E_UNSUPPORTED, "as_roi_align_bwd: tables of a %dx%d map / output %d exceed LDS", H, W, out_size);
   static bool attr = false;
   if (!attr) { (void)hipFuncSetAttribute((const void*)roi_align_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr = true; }

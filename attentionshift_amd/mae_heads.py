@@ -78,6 +78,25 @@ def _lin(mod, x):
     return mod(x)
 
 
+def _run_blocks(blocks, x):
+    """The decoder blocks on the token stream x [R, N, D].  Training in a bf16 region on a GPU: the residual stream stays
+    fp32 and every residual add is fused into the LayerNorm that follows it, forward and backward
+    (autograd.AddLayerNormFn, as in the backbone's blocks: models/vision_transformer.py:109-124 is the same Block);
+    otherwise the modules as they are."""
+    from . import autograd as AG
+    if not (len(blocks) and torch.is_grad_enabled() and x.dtype == torch.float32
+            and AG.linear_applies(x, blocks[0].attn.qkv.weight)):
+        for blk in blocks:
+            x = blk(x)
+        return x
+    bf, delta = torch.bfloat16, None
+    for blk in blocks:
+        x, y = AG.add_layernorm(x, delta, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps, bf)     # x += previous MLP output
+        x, z = AG.add_layernorm(x, blk.attn(y).contiguous(), blk.norm2.weight, blk.norm2.bias, blk.norm2.eps, bf)
+        delta = blk.mlp(z)
+    return torch.add(x, delta)
+
+
 class SmallAttnFn(torch.autograd.Function):
     """qkv [Bp,N,3,h,32] -> out [Bp,N,h*32]."""
 
@@ -213,8 +232,7 @@ class MAEBoxHeadRec(nn.Module):
             x = _lin(self.decoder_embed, self.norm(x))
         x = torch.cat([self.det_token.expand(B, -1, -1), x], dim=1)
         x = x + self.interpolate_pos_encoding(x, W * self.patch_size, H * self.patch_size)
-        for blk in self.decoder_blocks:
-            x = blk(x)
+        x = _run_blocks(self.decoder_blocks, x)
         x = self.decoder_box_norm(x)
         cls_score = self.fc_cls(x[:, 0]) if self.with_cls else None
         bbox_pred = self.fc_reg(x[:, 0]) if self.with_reg else None
@@ -299,8 +317,7 @@ class MAEMaskHeadPointSup(nn.Module):
         # as the reference: x carries no class token here, so `npatch = x.shape[1] - 1` never equals the table size and
         # the patch part always goes through the bicubic resize (scale (W + 0.1) / sqrt(N)), even at the native size
         x = x + self.interpolate_pos_encoding(x, W * self.patch_size, H * self.patch_size)[:, 1:]
-        for blk in self.decoder_blocks:
-            x = blk(x)
+        x = _run_blocks(self.decoder_blocks, x)
         x = self.decoder_box_norm(x).view(B, W, H, C)                      # [R, h, w, C] tokens on the RoI grid
         # F.interpolate(scale_factor, mode, align_corners=True) is a fixed separable linear map: applied as two small
         # matrix products (ATen's bicubic BACKWARD kernel needs 0.74 s for 256 RoIs x 256 channels on this GPU), and the

@@ -1250,6 +1250,53 @@ def test_mae_box_head_matches_tensor_op_decoder():
             assert_close(p.grad, got[n], 2e-3, 1e-5, f"grad {n}")
 
 
+@pytest.mark.parametrize("kind", ["box", "mask"])
+def test_mae_heads_bf16_training_path_matches_the_library_path(kind, monkeypatch):
+    """Under bf16 autocast the heads' layers run on autograd.LinearFn (as_linear_fwd / as_linear_bwd) and the blocks'
+    residual adds + LayerNorms on autograd.AddLayerNormFn; the same weights with every nn.Linear / LayerNorm left to the
+    library under the same autocast region must agree to bf16 rounding, outputs and parameter gradients."""
+    import attentionshift_amd as A
+    from attentionshift_amd import autograd as AG
+    torch.manual_seed(11)
+    common = dict(in_channels=96, img_size=224, patch_size=16, embed_dim=256, depth=2, num_heads=8, mlp_ratio=4., num_classes=20)
+    if kind == "box":
+        head = A.build_head(dict(type="MAEBoxHeadRec", with_reconstruct=False, **common)).cuda()
+        x = torch.randn(48, 96, 7, 7).cuda()
+    else:
+        head = A.build_head(dict(type="MAEMaskHeadPointSup", scale_factor=2, scale_mode="bicubic", **common)).cuda()
+        x = torch.randn(12, 96, 14, 14).cuda()
+    torch.nn.init.normal_(head.decoder_pos_embed, std=0.02)
+    head.train()
+
+    def run():
+        head.zero_grad()
+        xin = x.clone().requires_grad_(True)
+        with torch.enable_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            out = head(xin)
+            outs = [o for o in (out if isinstance(out, tuple) else (out,)) if o is not None]
+            sum(o.float().square().mean() for o in outs).backward()
+        return [o.detach().float() for o in outs], xin.grad, {n: p.grad.clone() for n, p in head.named_parameters() if p.grad is not None}
+
+    calls = []
+    orig = AG.LinearFn.forward
+    monkeypatch.setattr(AG.LinearFn, "forward", staticmethod(lambda ctx, *a: (calls.append(1), orig(ctx, *a))[1]))
+    outs, dx, grads = run()
+    assert len(calls) >= 9, "the HIP linear path did not run"       # decoder_embed + 4 layers per block
+    monkeypatch.setattr(AG, "_LIBRARY_LINEAR", True)
+    n_before = len(calls)
+    outs2, dx2, grads2 = run()
+    assert len(calls) == n_before, "the library path still went through LinearFn"
+    for a, b in zip(outs2, outs):
+        mx, mean = rel_to_range(a, b)
+        assert mx < 4e-2 and mean < 5e-3, ("output", mx, mean)
+    mx, mean = rel_to_range(dx2, dx)
+    assert mx < 6e-2 and mean < 6e-3, ("dx", mx, mean)
+    assert set(grads) == set(grads2)
+    for n in grads:
+        mx, mean = rel_to_range(grads2[n], grads[n])
+        assert mx < 8e-2 and mean < 1e-2, (n, mx, mean)
+
+
 def test_mae_mask_head_forward_loss_and_gradients():
     """MAEMaskHeadPointSup on the HIP small-N attention (196 tokens per RoI) vs the same weights through torch's
     scaled_dot_product_attention; point-sampled BCE loss with ignored points; gradients reach every parameter."""
