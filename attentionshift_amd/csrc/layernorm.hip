@@ -130,8 +130,17 @@ __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(const float* __r
       if (c < D) {
         const float4 a = *reinterpret_cast<const float4*>(x + base + c);
         v[i][0] = a.x; v[i][1] = a.y; v[i][2] = a.z; v[i][3] = a.w;
+        if (dy == nullptr) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) g[i][t] = dy != nullptr ? to_f32<T>(dy[base + c + t]) : 0.0f;
+          for (int t = 0; t < 4; ++t) g[i][t] = 0.0f;
+        } else if constexpr (sizeof(T) == 2) {             // one 8-byte load of the four bf16 values
+          const bf16x4 d4 = *reinterpret_cast<const bf16x4*>(dy + base + c);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) g[i][t] = (float)d4[t];
+        } else {
+          const float4 d4 = *reinterpret_cast<const float4*>(dy + base + c);
+          g[i][0] = d4.x; g[i][1] = d4.y; g[i][2] = d4.z; g[i][3] = d4.w;
+        }
         s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
       } else {
 #pragma unroll
@@ -173,16 +182,25 @@ __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(const float* __r
       const int c = (i * 64 + lane) * 4;
       if (c < D) {
         float o[4];
+        float4 r4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (dx_res != nullptr) r4 = *reinterpret_cast<const float4*>(dx_res + base + c);
+        const float r[4] = {r4.x, r4.y, r4.z, r4.w};
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           o[t] = rstd * (g[i][t] - mg - v[i][t] * mgx);
-          if (dx_res != nullptr) o[t] += dx_res[base + c + t];
+          if (dx_res != nullptr) o[t] += r[t];
         }
         if (dx_out != nullptr) *reinterpret_cast<float4*>(dx_out + base + c) = make_float4(o[0], o[1], o[2], o[3]);
         if (ddelta_out != nullptr) {
           const float ds = dscale != nullptr ? dscale[row / rps] : 1.0f;        // d(x + ds * delta) / d delta
+          if constexpr (sizeof(T) == 2) {
+            bf16x4 w4;
 #pragma unroll
-          for (int t = 0; t < 4; ++t) ddelta_out[base + c + t] = from_f32<T>(ds * o[t]);
+            for (int t = 0; t < 4; ++t) w4[t] = (__bf16)(ds * o[t]);
+            *reinterpret_cast<bf16x4*>(ddelta_out + base + c) = w4;
+          } else {
+            *reinterpret_cast<float4*>(ddelta_out + base + c) = make_float4(ds * o[0], ds * o[1], ds * o[2], ds * o[3]);
+          }
         }
       }
     }
@@ -203,16 +221,26 @@ __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(const float* __r
 }
 
 // dgamma / dbeta = the workgroup partials added in a FIXED order: 16 groups of a 64-column slab each add every 16th
-// partial in index order, then the 16 group sums are added in group order.  grid (ceil(D / 64), 2), 1024 threads.
+// partial (four interleaved running sums), then the 16 group sums are added in group order.  grid (ceil(D / 64), 2), 1024 threads.
 __global__ __launch_bounds__(1024) void add_layernorm_bwd_reduce_kernel(const float* __restrict__ part,
                                                                         float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                                         int nblk, int D) {
   __shared__ float red[16][64];
   const int cl = threadIdx.x & 63, grp = threadIdx.x >> 6, c = blockIdx.x * 64 + cl, which = blockIdx.y;
-  float a = 0.0f;
-  if (c < D)
-    for (int i = grp; i < nblk; i += 16) a += part[((size_t)i * 2 + which) * D + c];
-  red[grp][cl] = a;
+  // four independent running sums per group (partials grp, grp + 16, ... dealt round-robin), so four loads are in
+  // flight; combined in a fixed order
+  float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+  if (c < D) {
+    int i = grp;
+    for (; i + 48 < nblk; i += 64) {
+      a0 += part[((size_t)i * 2 + which) * D + c];
+      a1 += part[((size_t)(i + 16) * 2 + which) * D + c];
+      a2 += part[((size_t)(i + 32) * 2 + which) * D + c];
+      a3 += part[((size_t)(i + 48) * 2 + which) * D + c];
+    }
+    for (; i < nblk; i += 16) a0 += part[((size_t)i * 2 + which) * D + c];
+  }
+  red[grp][cl] = (a0 + a1) + (a2 + a3);
   __syncthreads();
   if (grp != 0 || c >= D) return;
   float t = 0.0f;
@@ -222,7 +250,7 @@ __global__ __launch_bounds__(1024) void add_layernorm_bwd_reduce_kernel(const fl
   if (dst != nullptr) dst[c] = t;
 }
 
-constexpr int LNB_BLOCKS = 256;
+constexpr int LNB_BLOCKS = 1024;      // 4 workgroups (16 waves) per CU: the pass is a stream, it needs the loads in flight
 
 template <typename T>
 int launch_add_ln_bwd(const float* x, const void* dy, const float* dx_res, const float* gamma, float* dx_out, void* ddelta,

@@ -1,7 +1,8 @@
 #!/bin/bash
 # GPU-box: the measurements a round's profiles/ entries come from, in one call.  usage: tools/round_artifacts.sh r03
 # Writes gpurun_out/<R>_*: full default bench line (+ wall time), rocprofv3 kernel stats of the headline leg, kernel_bench,
-# PMC summaries of the shift / roll-out / GEMM kernels and the per-call HBM traffic of as_cosine_shift.
+# PMC summaries of the shift / roll-out / GEMM kernels, the per-call HBM traffic of as_cosine_shift, and the training
+# step's kernel stats, phase timing and host-sync list.
 R=${1:-rXX}
 export TMPDIR=/tmp
 mkdir -p gpurun_out
@@ -18,5 +19,8 @@ done
 PMC_TAG=${R}_rollout_step4 PMC_FILTER=rollout_step4 PMC_CMD="python $GRAFT_REPO_ROOT/tools/kernel_bench.py --reps 8 --only rollout" bash tools/pmc_sdpa_impl.sh auto > /dev/null 2>&1
 PMC_TRAFFIC=1 PMC_TAG=${R}_gemm_fc1 PMC_FILTER=gemm_glds PMC_CMD="python $GRAFT_REPO_ROOT/tools/experiments/gemm_variant_bench.py _one --variants base --shapes 8394x3072x768" bash tools/pmc_sdpa_impl.sh auto > /dev/null 2>&1
 PMC_TRAFFIC=1 PMC_TAG=${R}_gemm_fc2 PMC_FILTER=gemm_glds PMC_CMD="python $GRAFT_REPO_ROOT/tools/experiments/gemm_variant_bench.py _one --variants base --shapes 8394x768x3072" bash tools/pmc_sdpa_impl.sh auto > /dev/null 2>&1
+PROF_LINES=8 tools/prof_cmd.sh ${R}_train_step_kernel_stats python $GRAFT_REPO_ROOT/tools/experiments/train_steps.py 6 > /dev/null 2>&1
+timeout 300 python tools/experiments/train_phases.py 8 2>&1 | tail -9 > gpurun_out/${R}_train_phases.txt
+timeout 300 python tools/experiments/train_syncs.py 2>&1 | tail -8 > gpurun_out/${R}_train_syncs.txt
 ls gpurun_out | grep ${R}_
 cat gpurun_out/${R}_bench_wall.txt
