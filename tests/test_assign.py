@@ -36,3 +36,33 @@ def test_assign_and_sample_equal_the_reference_sampler(golden):
         res = AS.random_sample(props, gts, labels, assigned, num=int(g[f"num{c}"]), pos_fraction=0.25, add_gt_as_proposals=True)
         assert torch.equal(res.pos_inds, t("pos_inds")) and torch.equal(res.neg_inds, t("neg_inds")), c
         assert torch.equal(res.pos_assigned_gt_inds, t("pos_assigned")) and torch.equal(res.pos_gt_labels, t("pos_gt_labels")), c
+
+
+def test_sampler_with_a_host_copy_of_the_assignment_draws_the_same_samples():
+    """forward_train hands random_sample the host copy of `assigned` it read back with the other shape-deciding tensors:
+    same draws, same index sets, and the namespace carries the host-side lists the target builders use."""
+    g = torch.Generator().manual_seed(3)
+    gts = torch.tensor([[10., 10., 120., 90.], [200., 150., 330., 300.]])
+    props = torch.cat((gts[torch.randint(2, (40,), generator=g)] + torch.randn(40, 4, generator=g) * 12,
+                       torch.rand(60, 4, generator=g) * 300))
+    props[:, 2:] = torch.maximum(props[:, 2:], props[:, :2] + 4)
+    labels = torch.tensor([4, 9])
+    assigned, _ = AS.max_iou_assign(props, gts, 0.5, 0.5, 0.5, False)
+    a = AS.random_sample(props, gts, labels, assigned, num=32, generator=torch.Generator().manual_seed(7))
+    b = AS.random_sample(props, gts, labels, assigned, num=32, generator=torch.Generator().manual_seed(7),
+                         assigned_host=assigned.float())               # read_back hands fp32 copies
+    for k in ("pos_inds", "neg_inds", "pos_assigned_gt_inds", "pos_gt_labels", "bboxes"):
+        assert torch.equal(getattr(a, k), getattr(b, k)), k
+    assert torch.equal(b.pos_inds_host, b.pos_inds) and torch.equal(b.pos_assigned_gt_inds_host, b.pos_assigned_gt_inds)
+    assert 0 < a.pos_inds.numel() <= 8 and a.pos_inds.numel() + a.neg_inds.numel() == 32
+
+
+def test_low_quality_matches_follow_the_reference_order():
+    """match_low_quality: every GT's best proposals are re-assigned to it in GT order (a later GT wins a tie), only
+    when that best IoU reaches min_pos_iou -- written with selects (no boolean-mask assignment)."""
+    gts = torch.tensor([[0., 0., 10., 10.], [0., 0., 10., 12.]])
+    props = torch.tensor([[0., 0., 10., 11.], [50., 50., 60., 60.], [0., 0., 5., 5.]])
+    assigned, best = AS.max_iou_assign(props, gts, pos_iou_thr=0.95, neg_iou_thr=0.3, min_pos_iou=0.3, match_low_quality=True)
+    assert assigned.tolist() == [2, 0, 0]                   # proposal 0 is both GTs' best (IoU 10/11, 11/12): GT 1 last
+    assigned, _ = AS.max_iou_assign(props, gts, pos_iou_thr=0.95, neg_iou_thr=0.3, min_pos_iou=0.99, match_low_quality=True)
+    assert assigned.tolist() == [-1, 0, 0]

@@ -27,6 +27,17 @@ def test_update_coords_with_semantic_centers_matches_reference(golden):
     assert out_l[1].sum(1).tolist() == [3, 3]
 
 
+def test_update_coords_with_a_host_copy_of_the_labels_is_the_same(golden):
+    """forward_train reads the labels back once with the other shape-deciding tensors (fp32 copies): same result, and an
+    image without centres needs no host copy."""
+    g, coords, labels, centers = _case(golden)
+    host = [None if len(c) == 0 else l.float() for l, c in zip(labels, centers)]
+    out_c, out_l = MT.update_coords_with_semantic_centers(coords, labels, centers, labels_host=host)
+    for i in range(3):
+        assert np.array_equal(g[f"out_coords{i}"], out_c[i].numpy()), i
+        assert np.array_equal(g[f"out_labels{i}"], out_l[i].numpy()), i
+
+
 def test_get_point_coords_wrt_box_matches_reference(golden):
     g = golden("consumers")
     got = MT.get_point_coords_wrt_box(t(g["boxes"]), t(g["pts"]))

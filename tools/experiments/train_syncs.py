@@ -1,5 +1,6 @@
-"""Which calls of a training step synchronise the host with the device (torch.cuda.set_sync_debug_mode("warn")), by source
-line inside this repo.    python tools/experiments/train_syncs.py     (GPU box)"""
+"""Which calls of a training step (or, with `infer`, of the headline forward + attention-shift step) synchronise the host
+with the device (torch.cuda.set_sync_debug_mode("warn")), by source line inside this repo.
+    python tools/experiments/train_syncs.py [infer [mil]]     (GPU box)"""
 import collections
 import os
 import sys
@@ -14,7 +15,13 @@ from attentionshift_amd.dist import Ranks  # noqa: E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 torch.cuda.set_device(0)
-step = bench.build(torch.device("cuda", 0), "fast", train=True, ranks=Ranks())
+INFER = len(sys.argv) > 1 and sys.argv[1] == "infer"
+if INFER:
+    step = bench.build(torch.device("cuda", 0), "fast", mil="mil" in sys.argv[2:])
+else:
+    step = bench.build(torch.device("cuda", 0), "fast", train=True, ranks=Ranks())
+if INFER:
+    torch.set_grad_enabled(False)                    # the headline step is a no-grad forward (as bench.py runs it)
 for _ in range(3):
     step()
 torch.cuda.synchronize()
@@ -41,6 +48,6 @@ warnings.simplefilter("always")
 torch.cuda.set_sync_debug_mode("warn")
 step()
 torch.cuda.set_sync_debug_mode("default")
-print("synchronising calls in one training step:", sum(sites.values()))
+print("synchronising calls in one %s step:" % ("headline" if INFER else "training"), sum(sites.values()))
 for s, n in sites.most_common():
     print(f"{n:4d}  {s}")
