@@ -608,11 +608,16 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   }
 }
 
-// K ranges of the split-K form: as many as fill the 768 resident slots of the 128 x 128 tile once (<= 64), each a multiple
-// of the K step and at least 256 long
-int splitk_chunk(int M, int Nout, int K, int* splits) {
-  const int tiles = as_ceil_div(M, 128) * as_ceil_div(Nout, 128);
-  int S = 768 / (tiles > 0 ? tiles : 1);
+// K ranges of the split-K form: as many as fill the resident slots of the tile once (<= 64), each a multiple of the K
+// step and at least 256 long.  Tile: 256 x 128 (two workgroups per CU, 512 slots) when the output has at least 48 of them
+// -- the backbone's weight gradients: a CU then holds 2 x 256 x 128 instead of 3 x 128 x 128 of output at 1.28x the rate
+// (launch_gemm_glds) -- else 128 x 128 (768 slots: the heads' [1024 x 256] gradients are 16 tiles).
+int splitk_chunk(int M, int Nout, int K, int* splits, bool* tall = nullptr) {
+  const int tall_tiles = as_ceil_div(M, 256) * as_ceil_div(Nout, 128);
+  const bool use_tall = tall_tiles >= 48;
+  if (tall) *tall = use_tall;
+  const int tiles = use_tall ? tall_tiles : as_ceil_div(M, 128) * as_ceil_div(Nout, 128);
+  int S = (use_tall ? 512 : 768) / (tiles > 0 ? tiles : 1);
   if (S > 64) S = 64;
   if (S < 1) S = 1;
   int chunk = as_round_up(as_ceil_div(K, S), GK);
@@ -638,12 +643,15 @@ extern "C" int as_linear_splitk_fwd(const void* x, const void* W, void* out, int
              "as_linear_splitk_fwd: need M, N > 0, K %% 32 == 0, N %% 4 == 0 (N=%d K=%d)", Nout, K);
   AS_REQUIRE(dtype == AS_BF16, AS_E_UNSUPPORTED, "as_linear_splitk_fwd: bf16 operands only (dtype %d)", dtype);
   int S = 1;
-  const int chunk = splitk_chunk(M, Nout, K, &S);
+  bool tall = false;
+  const int chunk = splitk_chunk(M, Nout, K, &S, &tall);
   AS_REQUIRE(workspace && workspace_bytes >= (size_t)S * M * Nout * sizeof(float), AS_E_BADARG,
              "as_linear_splitk_fwd: workspace too small (%zu < %zu)", workspace_bytes, (size_t)S * M * Nout * sizeof(float));
   hipStream_t s = (hipStream_t)stream;
   QkvEpi epi{workspace, nullptr, nullptr, chunk, 0, 0, 0};
-  const int rc = launch_gemm_glds_wm<3, 2, 2, 2, 2>(x, W, nullptr, nullptr, M, Nout, K, 0, epi, s);
+  static const bool no_tall = getenv("AS_SPLITK_SHORT") != nullptr;         // (experiments: always the 128 x 128 tile)
+  const int rc = tall && !no_tall ? launch_gemm_glds_wm<3, 4, 2, 2, 2>(x, W, nullptr, nullptr, M, Nout, K, 0, epi, s)
+                                  : launch_gemm_glds_wm<3, 2, 2, 2, 2>(x, W, nullptr, nullptr, M, Nout, K, 0, epi, s);
   if (rc != AS_OK) return rc;
   const size_t n4 = (size_t)M * Nout / 4;
   const int grid = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
