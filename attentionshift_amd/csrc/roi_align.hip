@@ -81,26 +81,26 @@ __global__ void roi_align_fwd_kernel(const float* __restrict__ feat, const float
 // Backward as a GATHER: grid (C / 8, B), 1024 threads.  Bin averaging + bilinear sampling is separable, so the gradient a
 // RoI sends to pixel (py, px) is  sum_{ph,pw} Ay[ph][py] * Ax[pw][px] * dout[r][ph][pw][c]  with the 1-D tables
 // Ay[ph][y] = (1/gh) * sum over the bin's samples of their bilinear weight on row y (Ax alike).  Every thread OWNS a fixed
-// set of pixels (t, t + 1024, ...) x 8 channels in registers and walks the image's RoIs in batches of RB_BATCH whose
+// set of pixels (t, t + 1024, ...) x 8 channels in registers and walks the image's RoIs in batches (`bsz`: as many as fit the LDS, <= 32) whose
 // tables and dout slices are staged in LDS: no atomics at all (a scatter with LDS float atomics took 5.7 ms for 1024
 // RoIs -- the proposals of an object overlap the same pixels; global float atomics ~1 s), fixed summation order,
 // deterministic.
-constexpr int RB_NT = 1024, RB_BATCH = 8, RB_CH = 8, RB_MAXPT = 8;        // pixels per thread <= 8: maps up to 8192 pixels
+constexpr int RB_NT = 1024, RB_BATCH_MAX = 32, RB_CH = 8, RB_MAXPT = 8;        // pixels per thread <= 8: maps up to 8192 pixels
 
 __global__ __launch_bounds__(RB_NT) void roi_align_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ rois,
                                                               float* __restrict__ dfeat, int B, int H, int W, int C, int R,
-                                                              int out, float scale, int sampling_ratio, int aligned) {
+                                                              int out, float scale, int sampling_ratio, int aligned, int bsz) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int c0 = blockIdx.x * RB_CH, b = blockIdx.y, tid = threadIdx.x;
   const int npix = H * W, nb = out * out;
-  float* Ay = sm;                                   // [RB_BATCH][out][H]
-  float* Ax = Ay + RB_BATCH * out * H;              // [RB_BATCH][out][W]
-  float* Dd = Ax + RB_BATCH * out * W;              // [RB_BATCH][nb][RB_CH]
-  int* span = reinterpret_cast<int*>(Dd + RB_BATCH * nb * RB_CH);      // [RB_BATCH][4] = ylo, yhi, xlo, xhi (inclusive)
+  float* Ay = sm;                                   // [bsz][out][H]
+  float* Ax = Ay + bsz * out * H;                   // [bsz][out][W]
+  float* Dd = Ax + bsz * out * W;                   // [bsz][nb][RB_CH]
+  int* span = reinterpret_cast<int*>(Dd + bsz * nb * RB_CH);           // [bsz][4] = ylo, yhi, xlo, xhi (inclusive)
   // per (RoI, pixel row / column): the first and last bin with a non-zero weight there, packed lo | hi << 16 -- a pixel
   // touches 1-3 bins per axis, not all `out` of them (filled from the finished tables, one thread per position)
-  int* brange = span + RB_BATCH * 4;                // [RB_BATCH][H + W]
-  int* cnt_s = brange + RB_BATCH * (H + W);         // [4] counters (all LDS lives in the dynamic region)
+  int* brange = span + bsz * 4;                     // [bsz][H + W]
+  int* cnt_s = brange + bsz * (H + W);              // [4] counters (all LDS lives in the dynamic region)
   int& nlist_s = cnt_s[0];
   int* list_s = cnt_s + 4;                          // [R] RoIs of this image, RoI order
 
@@ -134,11 +134,11 @@ __global__ __launch_bounds__(RB_NT) void roi_align_bwd_kernel(const float* __res
   }
   const int ntot = nlist_s;
 
-  for (int l0 = 0; l0 < ntot; l0 += RB_BATCH) {
-    const int nl = min(RB_BATCH, ntot - l0);
+  for (int l0 = 0; l0 < ntot; l0 += bsz) {
+    const int nl = min(bsz, ntot - l0);
     __syncthreads();                                // previous batch fully consumed
-    for (int i = tid; i < RB_BATCH * out * (H + W); i += RB_NT) sm[i] = 0.0f;      // Ay and Ax are contiguous
-    if (tid < RB_BATCH * 4) span[tid] = (tid & 1) ? -1 : (1 << 30);                  // lo = +inf, hi = -1
+    for (int i = tid; i < bsz * out * (H + W); i += RB_NT) sm[i] = 0.0f;      // Ay and Ax are contiguous
+    if (tid < bsz * 4) span[tid] = (tid & 1) ? -1 : (1 << 30);                  // lo = +inf, hi = -1
     __syncthreads();
     // 1-D tables: one thread per (RoI of the batch, bin, axis) walks that bin's samples sequentially and widens the
     // RoI's non-zero span on that axis
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(RB_NT) void roi_align_bwd_kernel(const float* __res
     }
     __syncthreads();
     // bin ranges: one thread per (RoI, pixel row or column) scans that position's column of the finished table
-    for (int i = tid; i < RB_BATCH * (H + W); i += RB_NT) {
+    for (int i = tid; i < bsz * (H + W); i += RB_NT) {
       const int j = i / (H + W), q = i - j * (H + W);
       const float* col = q < H ? Ay + j * out * H + q : Ax + j * out * W + (q - H);
       const int stride = q < H ? H : W;
@@ -246,14 +246,22 @@ extern "C" int as_roi_align_bwd(const float* dout, const float* rois, float* dfe
   AS_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && R >= 0 && out_size > 0, AS_E_BADARG, "as_roi_align_bwd: bad sizes");
   AS_REQUIRE(C % RB_CH == 0, AS_E_UNSUPPORTED, "as_roi_align_bwd: C=%d must be a multiple of %d", C, RB_CH);
   AS_REQUIRE(H * W <= RB_NT * RB_MAXPT, AS_E_UNSUPPORTED, "as_roi_align_bwd: a %dx%d map exceeds %d pixels", H, W, RB_NT * RB_MAXPT);
-  AS_REQUIRE(out_size * 2 * RB_BATCH <= RB_NT, AS_E_UNSUPPORTED, "as_roi_align_bwd: output size %d", out_size);
-  const size_t lds = ((size_t)RB_BATCH * out_size * (H + W) + (size_t)RB_BATCH * out_size * out_size * RB_CH + RB_BATCH * 4 +
-                      (size_t)RB_BATCH * (H + W) + 4 + (size_t)R) * 4;
+  // RoIs per batch: as many as the LDS takes (every batch costs a fixed round of barriers and a table build by
+  // 2 * out threads per RoI), at most RB_BATCH_MAX and RB_NT / (2 * out) (one table thread per RoI, bin and axis)
+  auto lds_of = [&](int bsz) {
+    return ((size_t)bsz * out_size * (H + W) + (size_t)bsz * out_size * out_size * RB_CH + (size_t)bsz * 4 + (size_t)bsz * (H + W) + 4 +
+            (size_t)R) * 4;
+  };
+  int bsz = RB_BATCH_MAX;
+  while (bsz > 1 && (lds_of(bsz) > 150 * 1024 || out_size * 2 * bsz > RB_NT)) --bsz;
+  if (bsz > 4) bsz &= ~3;                             // keeps the float4 staging of the dout slices 16-byte aligned
+  AS_REQUIRE(out_size * 2 * bsz <= RB_NT, AS_E_UNSUPPORTED, "as_roi_align_bwd: output size %d", out_size);
+  const size_t lds = lds_of(bsz);
   AS_REQUIRE(lds <= 150 * 1024, AS_E_UNSUPPORTED, "as_roi_align_bwd: tables of a %dx%d map / output %d exceed LDS", H, W, out_size);
   static bool attr = false;
   if (!attr) { (void)hipFuncSetAttribute((const void*)roi_align_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr = true; }
   hipLaunchKernelGGL(roi_align_bwd_kernel, dim3(C / RB_CH, B), dim3(RB_NT), lds, (hipStream_t)stream, dout, rois, dfeat, B, H, W,
-                     C, R, out_size, spatial_scale, sampling_ratio, aligned);
+                     C, R, out_size, spatial_scale, sampling_ratio, aligned, bsz);
   AS_CHECK_LAUNCH("roi_align_bwd");
   return AS_OK;
 }

@@ -75,7 +75,7 @@ template <typename T> __device__ __forceinline__ void lds_frag(Frag<T>& f, const
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// prep: one workgroup per (image*head, 64-row tile)
+// prep: one workgroup per (image*head, 64-row tile, layout job)
 // ---------------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(BW_NT) void bwd_prep_kernel(const T* __restrict__ q, const T* __restrict__ k,
@@ -92,6 +92,10 @@ __global__ __launch_bounds__(BW_NT) void bwd_prep_kernel(const T* __restrict__ q
   const int tid = threadIdx.x;
   const int D = h * BW_HD;
   const int row0 = t * 64;
+  // blockIdx.y picks ONE of the four independent layout jobs of the tile (the dO job also writes delta and lse2): four
+  // times the workgroups in flight instead of four LDS round trips in a row per workgroup
+  const int job = blockIdx.y;
+  if (job == 0) {
   // lse in base-2 units for the LDS-DMA kernels (an LDS-DMA cannot convert on the way): +inf on the padded rows, so P = 0
   if (tid < 64) lse2[(size_t)bh * Npad + row0 + tid] = row0 + tid < N ? lse[(size_t)bh * N + row0 + tid] * AS_LOG2E : INFINITY;
 
@@ -114,7 +118,7 @@ __global__ __launch_bounds__(BW_NT) void bwd_prep_kernel(const T* __restrict__ q
     const int d = e >> 6, r = e & 63;
     dot[((size_t)bh * BW_HD + d) * Npad + row0 + r] = from_f32<T>(tile[r][d]);
   }
-  __syncthreads();
+  } else if (job == 1) {
   // q (fragment-major) -> qt
   for (int e = tid; e < 64 * 64; e += BW_NT) {
     const int r = e >> 6, d = e & 63, n = row0 + r;
@@ -125,7 +129,7 @@ __global__ __launch_bounds__(BW_NT) void bwd_prep_kernel(const T* __restrict__ q
     const int d = e >> 6, r = e & 63;
     qt[((size_t)bh * BW_HD + d) * Npad + row0 + r] = from_f32<T>(tile[r][d]);
   }
-  __syncthreads();
+  } else if (job == 2) {
   // k (row-major) -> kt
   for (int e = tid; e < 64 * 64; e += BW_NT) {
     const int r = e >> 6, d = e & 63, n = row0 + r;
@@ -136,7 +140,7 @@ __global__ __launch_bounds__(BW_NT) void bwd_prep_kernel(const T* __restrict__ q
     const int d = e >> 6, r = e & 63;
     kt[((size_t)bh * BW_HD + d) * Npad + row0 + r] = from_f32<T>(tile[r][d]);
   }
-  __syncthreads();
+  } else {
   // vt (transposed) -> v row-major, zero padded
   for (int e = tid; e < 64 * 64; e += BW_NT) {
     const int d = e >> 6, r = e & 63, n = row0 + r;
@@ -146,6 +150,7 @@ __global__ __launch_bounds__(BW_NT) void bwd_prep_kernel(const T* __restrict__ q
   for (int e = tid; e < 64 * 64; e += BW_NT) {
     const int r = e >> 6, d = e & 63;
     vrow[((size_t)bh * Npad + row0 + r) * BW_HD + d] = from_f32<T>(tile[r][d]);
+  }
   }
 }
 
@@ -804,7 +809,7 @@ int launch_bwd(const void* q, const void* k, const void* vt, const void* o, cons
   float* delta = (float*)(vrow + per);
   float* lse2 = delta + (size_t)B * h * Npad;
   const int BH = B * h;
-  hipLaunchKernelGGL((bwd_prep_kernel<T>), dim3(BH * (Npad / 64)), dim3(BW_NT), 0, s, (const T*)q, (const T*)k,
+  hipLaunchKernelGGL((bwd_prep_kernel<T>), dim3(BH * (Npad / 64), 4), dim3(BW_NT), 0, s, (const T*)q, (const T*)k,
                      (const T*)vt, (const T*)o, (const T*)d_o, dof, dot, qt, kt, vrow, delta, lse, lse2, B, N, Npad, h);
   AS_CHECK_LAUNCH("sdpa_bwd_prep");
   constexpr int PITCH = TS::ROWB + 16;
