@@ -154,6 +154,114 @@ __global__ __launch_bounds__(BW_NT) void bwd_prep_kernel(const T* __restrict__ q
   }
 }
 
+// The same four jobs for bf16 with 16 bytes per lane on both sides of every transposition (the scalar template above
+// moves 2 bytes per lane: 130 MB in 53 us).  A 64 x 64 tile is loaded as 512 vectors of 8 elements (row a, chunk cv),
+// staged in LDS as packed pairs [a][b / 2] (pitch 33 words), and written as 512 vectors of 8 consecutive a for one b: a
+// lane of the store phase reads its 8 values from one word column (8 row groups x 4 word columns per wave: 32 banks).
+// Layout-only outputs (dof: the fragment-major copy of dO) are written straight from the load registers.
+__device__ __forceinline__ void prep_stage(uint32_t (*tile)[33], int v, uint4 d) {
+  const int row = v >> 3, cv = v & 7;
+  tile[row][cv * 4 + 0] = d.x; tile[row][cv * 4 + 1] = d.y; tile[row][cv * 4 + 2] = d.z; tile[row][cv * 4 + 3] = d.w;
+}
+__device__ __forceinline__ uint4 prep_gather(const uint32_t (*tile)[33], int v) {   // vector (b = v >> 3, a = 8 * (v & 7) ..)
+  const int bcol = v >> 3, ch = v & 7, w = bcol >> 1, sh = (bcol & 1) * 16;
+  uint32_t e[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) e[j] = (tile[ch * 8 + j][w] >> sh) & 0xffffu;
+  return make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
+}
+
+__global__ __launch_bounds__(BW_NT) void bwd_prep_vec_kernel(const __bf16* __restrict__ q, const __bf16* __restrict__ k,
+                                                             const __bf16* __restrict__ vt, const __bf16* __restrict__ o,
+                                                             const __bf16* __restrict__ d_o, __bf16* __restrict__ dof,
+                                                             __bf16* __restrict__ dot, __bf16* __restrict__ qt,
+                                                             __bf16* __restrict__ kt, __bf16* __restrict__ vrow,
+                                                             float* __restrict__ delta, const float* __restrict__ lse,
+                                                             float* __restrict__ lse2, int B, int N, int Npad, int h) {
+  __shared__ uint32_t tile[64][33];
+  const int BH = B * h;
+  const int bh = blockIdx.x % BH, t = blockIdx.x / BH;
+  const int b = bh / h, head = bh % h;
+  const int tid = threadIdx.x;
+  const int D = h * BW_HD;
+  const int row0 = t * 64;
+  const int job = blockIdx.y;
+  const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+  if (job == 0) {
+    if (tid < 64) lse2[(size_t)bh * Npad + row0 + tid] = row0 + tid < N ? lse[(size_t)bh * N + row0 + tid] * AS_LOG2E : INFINITY;
+    // dO rows: -> dof (fragment-major: the 8 elements of a (row, d-chunk) are one 16-byte run there too), delta, LDS
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int v = tid + BW_NT * i, r = v >> 3, cv = v & 7, n = row0 + r;
+      uint4 g = zero4, ov = zero4;
+      if (n < N) {
+        g = *reinterpret_cast<const uint4*>(d_o + ((size_t)b * N + n) * D + head * BW_HD + cv * 8);
+        ov = *reinterpret_cast<const uint4*>(o + ((size_t)b * N + n) * D + head * BW_HD + cv * 8);
+      }
+      *reinterpret_cast<uint4*>(dof + qf_elem((size_t)bh, Npad, n, cv * 8)) = g;
+      prep_stage(tile, v, g);
+      const uint32_t gw[4] = {g.x, g.y, g.z, g.w}, ow[4] = {ov.x, ov.y, ov.z, ov.w};
+      float s = 0.0f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        s += __uint_as_float(gw[j] << 16) * __uint_as_float(ow[j] << 16) +
+             __uint_as_float(gw[j] & 0xffff0000u) * __uint_as_float(ow[j] & 0xffff0000u);
+      // the 8 lanes of a row are consecutive: three xor steps inside the group of 8 (fixed order)
+      s += __shfl_xor(s, 1);
+      s += __shfl_xor(s, 2);
+      s += __shfl_xor(s, 4);
+      if (cv == 0) delta[(size_t)bh * Npad + n] = s;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int v = tid + BW_NT * i;
+      *reinterpret_cast<uint4*>(dot + ((size_t)bh * BW_HD + (v >> 3)) * Npad + row0 + (v & 7) * 8) = prep_gather(tile, v);
+    }
+  } else if (job == 1 || job == 2) {
+    // q (fragment-major) -> qt, k (row-major) -> kt: rows n, transposed to [d][n]
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int v = tid + BW_NT * i, r = v >> 3, cv = v & 7, n = row0 + r;
+      uint4 d = zero4;
+      if (n < N)
+        d = job == 1 ? *reinterpret_cast<const uint4*>(q + qf_elem((size_t)bh, Npad, n, cv * 8))
+                     : *reinterpret_cast<const uint4*>(k + ((size_t)bh * Npad + n) * BW_HD + cv * 8);
+      prep_stage(tile, v, d);
+    }
+    __syncthreads();
+    __bf16* dst = job == 1 ? qt : kt;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int v = tid + BW_NT * i;
+      *reinterpret_cast<uint4*>(dst + ((size_t)bh * BW_HD + (v >> 3)) * Npad + row0 + (v & 7) * 8) = prep_gather(tile, v);
+    }
+  } else {
+    // vt [d][n] -> v rows [n][d], zero beyond N: the tile's rows are d here, 8 consecutive n per vector
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int v = tid + BW_NT * i, d = v >> 3, cv = v & 7, n = row0 + cv * 8;
+      uint4 x = *reinterpret_cast<const uint4*>(vt + ((size_t)bh * BW_HD + d) * Npad + n);
+      if (n + 8 > N) {                                   // ragged end: keep the elements below N
+        uint32_t w[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (n + 2 * j >= N) w[j] = 0u;
+          else if (n + 2 * j + 1 >= N) w[j] &= 0xffffu;
+        }
+        x = make_uint4(w[0], w[1], w[2], w[3]);
+      }
+      prep_stage(tile, v, x);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int v = tid + BW_NT * i;                     // vector: n = row0 + (v >> 3), d = 8 * (v & 7) ..
+      *reinterpret_cast<uint4*>(vrow + ((size_t)bh * Npad + row0 + (v >> 3)) * BW_HD + (v & 7) * 8) = prep_gather(tile, v);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // dQ: workgroup = 128 queries of one (image, head); key tiles of 64
 //   S^T  = K . Q^T        A = K rows (pi order)     B = Q^T  (registers)
@@ -809,8 +917,14 @@ int launch_bwd(const void* q, const void* k, const void* vt, const void* o, cons
   float* delta = (float*)(vrow + per);
   float* lse2 = delta + (size_t)B * h * Npad;
   const int BH = B * h;
-  hipLaunchKernelGGL((bwd_prep_kernel<T>), dim3(BH * (Npad / 64), 4), dim3(BW_NT), 0, s, (const T*)q, (const T*)k,
-                     (const T*)vt, (const T*)o, (const T*)d_o, dof, dot, qt, kt, vrow, delta, lse, lse2, B, N, Npad, h);
+  static const bool prep_scalar = getenv("AS_BWD_PREP_SCALAR") != nullptr;      // (experiments: the 2-byte template)
+  if (sizeof(T) == 2 && !prep_scalar)
+    hipLaunchKernelGGL(bwd_prep_vec_kernel, dim3(BH * (Npad / 64), 4), dim3(BW_NT), 0, s, (const __bf16*)q, (const __bf16*)k,
+                       (const __bf16*)vt, (const __bf16*)o, (const __bf16*)d_o, (__bf16*)dof, (__bf16*)dot, (__bf16*)qt,
+                       (__bf16*)kt, (__bf16*)vrow, delta, lse, lse2, B, N, Npad, h);
+  else
+    hipLaunchKernelGGL((bwd_prep_kernel<T>), dim3(BH * (Npad / 64), 4), dim3(BW_NT), 0, s, (const T*)q, (const T*)k,
+                       (const T*)vt, (const T*)o, (const T*)d_o, dof, dot, qt, kt, vrow, delta, lse, lse2, B, N, Npad, h);
   AS_CHECK_LAUNCH("sdpa_bwd_prep");
   constexpr int PITCH = TS::ROWB + 16;
   const size_t lds_dq = 2 * (size_t)(3 * BW_TILE * PITCH);
