@@ -80,8 +80,8 @@ def linear(x, weight, bias=None):
 def linear_applies(x, weight):
     """Whether `linear` can stand in for F.linear here: device tensors, a bf16 autocast region (or bf16 operands
     already) and sizes the kernels take (rows of 32)."""
-    if _LIBRARY_LINEAR or not x.is_cuda or weight.shape[0] % 32 or weight.shape[1] % 32:
-        return False
+    if _LIBRARY_LINEAR or not x.is_cuda or x.numel() == 0 or weight.shape[0] % 32 or weight.shape[1] % 32:
+        return False                                 # (an empty batch -- no positive RoIs -- stays on the tensor ops)
     if x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16:
         return True
     return torch.is_autocast_enabled('cuda') and torch.get_autocast_dtype('cuda') == torch.bfloat16

@@ -122,6 +122,8 @@ class _Attention(nn.Module):
 
     def forward(self, x):
         B, N, C = x.shape
+        if B == 0:                                       # no RoIs (an image pair without positives): an empty result that
+            return self.proj(self.qkv(x)[..., :C])       # still hangs on both layers' parameters, as the reference's does
         qkv = _lin(self.qkv, x).reshape(B, N, 3, self.num_heads, C // self.num_heads)   # the reference's packed layout
         return _lin(self.proj, SmallAttnFn.apply(qkv))
 

@@ -108,3 +108,21 @@ def test_forward_train_without_positives_or_mask_head(monkeypatch):
     bare = A.build_head(dict(type="AttnShiftRoIHead", bbox_head=dict(type="MAEBoxHeadRec", cam_layer=3)))
     with pytest.raises(RuntimeError, match="box head"):
         bare.forward_train(d["fmap"], d["metas"], d["props"], d["gts"], d["labels"])
+
+
+def test_heads_take_an_empty_roi_batch_on_the_tensor_ops():
+    """No positive RoIs (images without objects): the heads run on [0, C, h, w] through the plain modules -- the attention
+    kernel is never asked for an empty problem -- the loss is 0 and the parameters still get (zero) gradients."""
+    common = dict(in_channels=96, img_size=224, patch_size=16, embed_dim=256, depth=1, num_heads=8, mlp_ratio=4., num_classes=20)
+    mask = A.build_head(dict(type="MAEMaskHeadPointSup", scale_factor=2, scale_mode="bicubic", **common)).train()
+    box = A.build_head(dict(type="MAEBoxHeadRec", with_reconstruct=False, **common)).train()
+    with torch.enable_grad():
+        pred = mask(torch.zeros(0, 96, 14, 14))
+        assert pred.shape == (0, 20, 28, 28)
+        loss = mask.loss(pred, torch.zeros(0, 5), torch.zeros(0, dtype=torch.long))["loss_mask"]
+        cls, reg, _ = box(torch.zeros(0, 96, 7, 7))
+        assert cls.shape == (0, 21) and reg.shape == (0, 80)
+        (loss + cls.sum() + reg.sum()).backward()
+    assert float(loss.detach()) == 0.0
+    for head in (mask, box):
+        assert not [n for n, p in head.named_parameters() if p.requires_grad and p.grad is None and "pos_embed" not in n]

@@ -1297,6 +1297,27 @@ def test_mae_heads_bf16_training_path_matches_the_library_path(kind, monkeypatch
         assert mx < 8e-2 and mean < 1e-2, (n, mx, mean)
 
 
+@pytest.mark.parametrize("autocast", [False, True])
+def test_mae_heads_take_an_empty_roi_batch(autocast):
+    """No positive RoIs in a batch (images without objects): the heads run on [0, C, h, w] as the reference's modules
+    do, the loss is 0 and every parameter still gets a (zero) gradient."""
+    import attentionshift_amd as A
+    common = dict(in_channels=96, img_size=224, patch_size=16, embed_dim=256, depth=1, num_heads=8, mlp_ratio=4., num_classes=20)
+    mask = A.build_head(dict(type="MAEMaskHeadPointSup", scale_factor=2, scale_mode="bicubic", **common)).cuda().train()
+    box = A.build_head(dict(type="MAEBoxHeadRec", with_reconstruct=False, **common)).cuda().train()
+    with torch.enable_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+        pred = mask(torch.zeros(0, 96, 14, 14).cuda())
+        assert pred.shape == (0, 20, 28, 28)
+        loss = mask.loss(pred, torch.zeros(0, 5, device="cuda"), torch.zeros(0, dtype=torch.long, device="cuda"))["loss_mask"]
+        cls, reg, _ = box(torch.zeros(0, 96, 7, 7).cuda())
+        assert cls.shape == (0, 21) and reg.shape == (0, 80)
+        (loss + cls.sum() + reg.sum()).backward()
+    assert float(loss) == 0.0
+    for head in (mask, box):
+        missing = [n for n, p in head.named_parameters() if p.requires_grad and p.grad is None and "pos_embed" not in n]
+        assert not missing, missing
+
+
 def test_mae_mask_head_forward_loss_and_gradients():
     """MAEMaskHeadPointSup on the HIP small-N attention (196 tokens per RoI) vs the same weights through torch's
     scaled_dot_product_attention; point-sampled BCE loss with ignored points; gradients reach every parameter."""
