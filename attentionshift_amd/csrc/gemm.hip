@@ -608,17 +608,22 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   }
 }
 
-// K ranges of the split-K form: as many as fill the resident slots of the tile once (<= 64), each a multiple of the K
-// step and at least 256 long.  Tile: 256 x 128 (two workgroups per CU, 512 slots) when the output has at least 48 of them
-// -- the backbone's weight gradients: a CU then holds 2 x 256 x 128 instead of 3 x 128 x 128 of output at 1.28x the rate
-// (launch_gemm_glds) -- else 128 x 128 (768 slots: the heads' [1024 x 256] gradients are 16 tiles).
+// K ranges of the split-K form: about ONE workgroup per CU (<= 256 in all, <= 32 ranges), each range a multiple of the K
+// step and at least 256 long.  Fewer, fatter ranges beat filling every resident slot: the fp32 partials cross HBM twice
+// (S x output x 4 bytes each way) and every workgroup pays its ring fill and a 64 KiB store -- measured on the shapes of
+// a training step (tools/experiments/splitk_bench.py, incl. the reduction): 512 / 768 slots -> 256: dW_fc1 72.5 -> 61.9 us,
+// dW_qkv 60.0 -> 50.5, dW_proj 45.6 -> 35.2, a head's [1024 x 256] over 51 200 rows 78.7 -> 55.4; 128 or 1024 are worse.
+// Tile: 256 x 128 when the output has at least 48 of them (the backbone's weight gradients: a CU then holds 256 x 128
+// instead of 128 x 128 of output at 1.28x the rate, launch_gemm_glds), else 128 x 128 (the heads' [1024 x 256] is 16 tiles).
 int splitk_chunk(int M, int Nout, int K, int* splits, bool* tall = nullptr) {
   const int tall_tiles = as_ceil_div(M, 256) * as_ceil_div(Nout, 128);
   const bool use_tall = tall_tiles >= 48;
   if (tall) *tall = use_tall;
   const int tiles = use_tall ? tall_tiles : as_ceil_div(M, 128) * as_ceil_div(Nout, 128);
-  int S = (use_tall ? 512 : 768) / (tiles > 0 ? tiles : 1);
-  if (S > 64) S = 64;
+  static const int slots_env = [] { const char* e = getenv("AS_SPLITK_SLOTS"); return e ? atoi(e) : 0; }();   // (experiments)
+  const int slots = slots_env > 0 ? slots_env : 256;
+  int S = slots / (tiles > 0 ? tiles : 1);
+  if (S > 32) S = 32;
   if (S < 1) S = 1;
   int chunk = as_round_up(as_ceil_div(K, S), GK);
   if (chunk < 256) chunk = 256;

@@ -87,6 +87,7 @@ __global__ void roi_align_fwd_kernel(const float* __restrict__ feat, const float
 // deterministic.
 constexpr int RB_NT = 1024, RB_BATCH_MAX = 32, RB_CH = 8, RB_MAXPT = 8;        // pixels per thread <= 8: maps up to 8192 pixels
 
+template <int MAXPT>   // pixels per thread (accumulators: MAXPT x 8 registers): 4 for maps up to 4096 pixels, else 8
 __global__ __launch_bounds__(RB_NT) void roi_align_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ rois,
                                                               float* __restrict__ dfeat, int B, int H, int W, int C, int R,
                                                               int out, float scale, int sampling_ratio, int aligned, int bsz) {
@@ -104,9 +105,9 @@ __global__ __launch_bounds__(RB_NT) void roi_align_bwd_kernel(const float* __res
   int& nlist_s = cnt_s[0];
   int* list_s = cnt_s + 4;                          // [R] RoIs of this image, RoI order
 
-  float acc[RB_MAXPT][RB_CH];
+  float acc[MAXPT][RB_CH];
 #pragma unroll
-  for (int k = 0; k < RB_MAXPT; ++k)
+  for (int k = 0; k < MAXPT; ++k)
 #pragma unroll
     for (int j = 0; j < RB_CH; ++j) acc[k][j] = 0.0f;
 
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(RB_NT) void roi_align_bwd_kernel(const float* __res
     }
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < RB_MAXPT; ++k) {
+    for (int k = 0; k < MAXPT; ++k) {
       const int pix = tid + k * RB_NT;
       if (pix >= npix) break;
       const int py = pix / W, px = pix - py * W;
@@ -213,7 +214,7 @@ __global__ __launch_bounds__(RB_NT) void roi_align_bwd_kernel(const float* __res
   }
   float* dst = dfeat + (size_t)b * npix * C + c0;
 #pragma unroll
-  for (int k = 0; k < RB_MAXPT; ++k) {
+  for (int k = 0; k < MAXPT; ++k) {
     const int pix = tid + k * RB_NT;
     if (pix >= npix) break;
     *reinterpret_cast<float4*>(dst + (size_t)pix * C) = make_float4(acc[k][0], acc[k][1], acc[k][2], acc[k][3]);
@@ -259,9 +260,17 @@ extern "C" int as_roi_align_bwd(const float* dout, const float* rois, float* dfe
   const size_t lds = lds_of(bsz);
   AS_REQUIRE(lds <= 150 * 1024, AS_E_UNSUPPORTED, "as_roi_align_bwd: tables of a %dx%d map / output %d exceed LDS", H, W, out_size);
   static bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute((const void*)roi_align_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr = true; }
-  hipLaunchKernelGGL(roi_align_bwd_kernel, dim3(C / RB_CH, B), dim3(RB_NT), lds, (hipStream_t)stream, dout, rois, dfeat, B, H, W,
-                     C, R, out_size, spatial_scale, sampling_ratio, aligned, bsz);
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)roi_align_bwd_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    (void)hipFuncSetAttribute((const void*)roi_align_bwd_kernel<RB_MAXPT>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    attr = true;
+  }
+  if (H * W <= RB_NT * 4)
+    hipLaunchKernelGGL(roi_align_bwd_kernel<4>, dim3(C / RB_CH, B), dim3(RB_NT), lds, (hipStream_t)stream, dout, rois, dfeat, B, H,
+                       W, C, R, out_size, spatial_scale, sampling_ratio, aligned, bsz);
+  else
+    hipLaunchKernelGGL(roi_align_bwd_kernel<RB_MAXPT>, dim3(C / RB_CH, B), dim3(RB_NT), lds, (hipStream_t)stream, dout, rois, dfeat,
+                       B, H, W, C, R, out_size, spatial_scale, sampling_ratio, aligned, bsz);
   AS_CHECK_LAUNCH("roi_align_bwd");
   return AS_OK;
 }
