@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/attnshift.h"
@@ -31,6 +32,49 @@ void as_set_error(const char* fmt, ...);
 
 static inline int as_ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline int as_round_up(int a, int b) { return as_ceil_div(a, b) * b; }
+
+// ---------------------------------------------------------------------------------------------
+// Fork / join onto a helper stream inside one C call: two independent launch chains of a backward pass run side by side
+// (a chain of one-workgroup-per-CU split-K products leaves most of every CU free; two half-empty last rounds fill each
+// other's slots).  The caller's stream forks with an event, the helper chain runs on the side stream, and the caller's
+// stream waits for the helper's last launch before the call returns -- so the caller sees ordinary stream order.
+// One set of stream + events per host thread, device and slot (nested users take different slots).  AS_BWD_SERIAL=1 (read
+// once) keeps everything on the caller's stream.
+// ---------------------------------------------------------------------------------------------
+struct AsSide {
+  hipStream_t st = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr, mid = nullptr;
+  bool ok = false;
+  int dev = -1;
+  void init() {
+    int d = -1;
+    if (hipGetDevice(&d) != hipSuccess) { ok = false; return; }
+    if (d == dev) return;
+    dev = d;
+    ok = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess &&
+         hipEventCreateWithFlags(&fork, hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&join, hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&mid, hipEventDisableTiming) == hipSuccess;
+  }
+};
+static inline bool as_side_serial() {
+  static const bool serial = getenv("AS_BWD_SERIAL") != nullptr;
+  return serial;
+}
+// -> the stream the helper chain should use: the side stream behind an event of `s`, or `s` itself (serial / no stream)
+static inline hipStream_t as_side_fork(AsSide& sd, hipStream_t s) {
+  if (as_side_serial()) return s;
+  sd.init();
+  if (sd.ok && hipEventRecord(sd.fork, s) == hipSuccess && hipStreamWaitEvent(sd.st, sd.fork, 0) == hipSuccess) return sd.st;
+  return s;
+}
+// `to` waits for everything queued on `from` so far (no-op when they are the same stream)
+static inline void as_side_wait(AsSide& sd, hipEvent_t ev, hipStream_t from, hipStream_t to) {
+  if (from == to) return;
+  if (hipEventRecord(ev, from) != hipSuccess || hipStreamWaitEvent(to, ev, 0) != hipSuccess)
+    (void)hipStreamSynchronize(from);                   // (a lost device; keeps the order safe)
+}
+static inline void as_side_join(AsSide& sd, hipStream_t sq, hipStream_t s) { as_side_wait(sd, sd.join, sq, s); }
 #ifdef __HIPCC__
 __device__ __forceinline__ int as_ceil_div_dev(int a, int b) { return (a + b - 1) / b; }
 #endif

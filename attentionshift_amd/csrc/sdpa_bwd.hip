@@ -940,31 +940,10 @@ int launch_bwd(const void* q, const void* k, const void* vt, const void* o, cons
   // dQ depends on the prep kernel only and writes its own third of dqkv: the bf16 kernels run it CONCURRENTLY with dK/dV
   // on a helper stream (fork after prep, join on the caller's stream).  Both grids are BH * tiles equal workgroups on 2
   // slots per CU -- 792 on 512 at config 2: two rounds each, the second 55 % full -- so dQ's workgroups take the slots
-  // dK/dV's second round leaves free (one of each kind fits a CU: 66.5 + 48 KiB of LDS).  Helper stream and events: one
-  // set per host thread and device.
-  struct Side {
-    hipStream_t st = nullptr;
-    hipEvent_t fork = nullptr, join = nullptr;
-    bool ok = false;
-    int dev = -1;
-    void init() {
-      int d = -1;
-      if (hipGetDevice(&d) != hipSuccess) { ok = false; return; }
-      if (d == dev) return;
-      dev = d;
-      ok = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess &&
-           hipEventCreateWithFlags(&fork, hipEventDisableTiming) == hipSuccess &&
-           hipEventCreateWithFlags(&join, hipEventDisableTiming) == hipSuccess;
-    }
-  };
-  static thread_local Side side;
-  static const bool serial = getenv("AS_BWD_SERIAL") != nullptr;     // (experiments / debugging: everything on one stream)
+  // dK/dV's second round leaves free (one of each kind fits a CU: 66.5 + 48 KiB of LDS).  (common.h AsSide.)
+  static thread_local AsSide side;
   hipStream_t sq = s;
-  if (sizeof(T) == 2 && !old_dkv && !serial) {
-    side.init();
-    if (side.ok && hipEventRecord(side.fork, s) == hipSuccess && hipStreamWaitEvent(side.st, side.fork, 0) == hipSuccess)
-      sq = side.st;
-  }
+  if (sizeof(T) == 2 && !old_dkv) sq = as_side_fork(side, s);
   if constexpr (sizeof(T) == 2) {
     if (!old_dkv) {
       const size_t lds_dma = (size_t)AS_BWD_NST * DK_STAGE;
@@ -993,10 +972,7 @@ int launch_bwd(const void* q, const void* k, const void* vt, const void* o, cons
       hipLaunchKernelGGL(sdpa_bwd_dq_dma_kernel, dim3(BH * tiles), dim3(BW_NT), lds_dma, sq, (const __bf16*)q, (const __bf16*)dof,
                          (const __bf16*)k, (const __bf16*)vrow, (const __bf16*)kt, lse, (const float*)delta, (__bf16*)dqkv, B, N,
                          Npad, h);
-      if (sq != s) {                                       // join: the caller's stream continues after dQ as well
-        if (hipEventRecord(side.join, sq) != hipSuccess || hipStreamWaitEvent(s, side.join, 0) != hipSuccess)
-          (void)hipStreamSynchronize(sq);                  // (cannot happen short of a lost device; keeps the order safe)
-      }
+      as_side_join(side, sq, s);                          // the caller's stream continues after dQ as well
     }
   }
   if (sizeof(T) != 2 || old_dkv)
