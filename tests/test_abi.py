@@ -53,6 +53,11 @@ def test_bad_arguments_return_error_codes_without_launching():
     assert lib.as_window_attn_fwd(None, None, None, None, None, 1, 14, 14, 64, 2, 7, 0, 1, None) == -1
     assert lib.as_add_layernorm(None, None, None, None, 1e-6, None, None, 4, 64, 1, None) == -1
     assert lib.as_mask_count(None, None, 1, 16, None) == -1
+    assert lib.as_linear_bwd(None, None, None, None, None, None, 8, 32, 32, 1, 0, None, 0, None) == -1
+    assert lib.as_linear_bwd_workspace_bytes(0, 32, 32) == 0
+    # W^T + dy^T + x^T (rows padded to 64) + the column-sum partials + one fp32 split-K partial of a 1-tile output
+    assert lib.as_linear_bwd_workspace_bytes(100, 64, 32) >= 2 * (32 * 64 + 64 * 128 + 32 * 128) + 64 * 64 * 4 + 64 * 32 * 4
+    assert lib.as_linear_splitk_workspace_bytes(768, 768, 8448) == 7 * 768 * 768 * 4       # 36 tiles -> 7 ranges on 256 CUs
     assert lib.as_merge_plan(None, None, None, None, 3, 20, None) == -1
     assert lib.as_small_attn_fwd(None, None, None, 4, 50, 8, 32, 1, None) == -1
     assert lib.as_small_attn_bwd(None, None, None, None, None, None, 0, 4, 50, 8, 32, 1, None) == -1
