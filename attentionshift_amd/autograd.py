@@ -97,6 +97,7 @@ class ParamCastFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, dtype, *params):
         ctx.meta = [(p.dtype, p.shape) for p in params]
+        ctx.set_materialize_grads(False)             # an unused copy costs nothing in backward (None is skipped below)
         flat = torch.empty(sum(p.numel() for p in params), device=params[0].device, dtype=dtype)
         outs = [v.view(p.shape) for v, p in zip(flat.split([p.numel() for p in params]), params)]
         torch._foreach_copy_(outs, [p.detach() for p in params])

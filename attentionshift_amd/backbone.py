@@ -439,10 +439,14 @@ class VisionTransformerDet(nn.Module):
         if grad_path and self.compute_dtype != torch.float32 and not os.environ.get("AS_NO_PARAM_SHADOW"):
             # every GEMM parameter of the blocks in the compute dtype by ONE fused, differentiable cast (autograd.ParamCastFn)
             from .autograd import cast_params
+            from . import autograd as _AG
+            # the HIP linear takes the fp32 master biases; only the F.linear fallback consumes compute-dtype bias copies
+            lib_mlp = _AG._LIBRARY_LINEAR or self.embed_dim % 32 != 0
             ps = []
             for blk in self.blocks:
-                ps += [blk.attn.qkv.weight, blk.attn.proj.weight, blk.mlp.fc1.weight, blk.mlp.fc1.bias, blk.mlp.fc2.weight,
-                       blk.mlp.fc2.bias]
+                ps += [blk.attn.qkv.weight, blk.attn.proj.weight, blk.mlp.fc1.weight, blk.mlp.fc2.weight]
+                if lib_mlp:
+                    ps += [blk.mlp.fc1.bias, blk.mlp.fc2.bias]
             self._train_shadow = cast_params([p for p in ps if p.dtype != self.compute_dtype], self.compute_dtype)
         for i, blk in enumerate(self.blocks):
             if grad_path:

@@ -1,6 +1,7 @@
 // Shared device/host helpers for libattnshift_hip.so (gfx950 / CDNA4 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -42,19 +43,41 @@ static inline int as_round_up(int a, int b) { return as_ceil_div(a, b) * b; }
 // once) keeps everything on the caller's stream.
 // ---------------------------------------------------------------------------------------------
 struct AsSide {
-  hipStream_t st = nullptr;
+  // one stream + three events PER DEVICE (a thread alternating between devices reuses each device's set instead of
+  // re-creating -- and leaking -- one on every switch); a set whose creation fails half-way is destroyed and stays off
+  static constexpr int kMaxDev = 16;
+  struct Slot {
+    hipStream_t st = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr, mid = nullptr;
+    int state = 0;                                      // 0 = not tried, 1 = ready, -1 = failed (do not retry)
+  };
+  Slot slots[kMaxDev];
+  hipStream_t st = nullptr;                             // the CURRENT device's set (valid while ok)
   hipEvent_t fork = nullptr, join = nullptr, mid = nullptr;
   bool ok = false;
-  int dev = -1;
   void init() {
     int d = -1;
-    if (hipGetDevice(&d) != hipSuccess) { ok = false; return; }
-    if (d == dev) return;
-    dev = d;
-    ok = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess &&
-         hipEventCreateWithFlags(&fork, hipEventDisableTiming) == hipSuccess &&
-         hipEventCreateWithFlags(&join, hipEventDisableTiming) == hipSuccess &&
-         hipEventCreateWithFlags(&mid, hipEventDisableTiming) == hipSuccess;
+    ok = false;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= kMaxDev) return;
+    Slot& sl = slots[d];
+    if (sl.state == 0) {
+      const bool made = hipStreamCreateWithFlags(&sl.st, hipStreamNonBlocking) == hipSuccess &&
+                        hipEventCreateWithFlags(&sl.fork, hipEventDisableTiming) == hipSuccess &&
+                        hipEventCreateWithFlags(&sl.join, hipEventDisableTiming) == hipSuccess &&
+                        hipEventCreateWithFlags(&sl.mid, hipEventDisableTiming) == hipSuccess;
+      if (!made) {
+        if (sl.mid) (void)hipEventDestroy(sl.mid);
+        if (sl.join) (void)hipEventDestroy(sl.join);
+        if (sl.fork) (void)hipEventDestroy(sl.fork);
+        if (sl.st) (void)hipStreamDestroy(sl.st);
+        sl = Slot();
+        (void)hipGetLastError();                        // the caller falls back to its own stream: not its error
+      }
+      sl.state = made ? 1 : -1;
+    }
+    if (sl.state != 1) return;
+    st = sl.st; fork = sl.fork; join = sl.join; mid = sl.mid;
+    ok = true;
   }
 };
 static inline bool as_side_serial() {

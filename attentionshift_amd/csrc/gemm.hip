@@ -528,7 +528,7 @@ int launch_gemm_glds_wm(const void* A, const void* W, const float* bias, void* o
   dim3 grid(8 * as_ceil_div(tiles, 8), MODE == 3 ? as_ceil_div(K, epi.N) : 1);   // x padded to a multiple of the 8 XCDs (tile order)
   // ring 48 / 72 / 96 KiB; the epilogue restages the output tile in the same memory (35 / 70 / 133 KiB)
   const size_t lds = (size_t)GT::LDS;
-  static bool attr_set = false;
+  static std::atomic<bool> attr_set{false};   // (idempotent attribute call: a race only repeats it)
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)gemm_glds_kernel<MODE, WM, WN, RI, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;

@@ -96,7 +96,7 @@ __global__ __launch_bounds__(RB_NT) void roi_align_bwd_kernel(const float* __res
   const int npix = H * W, nb = out * out;
   float* Ay = sm;                                   // [bsz][out][H]
   float* Ax = Ay + bsz * out * H;                   // [bsz][out][W]
-  float* Dd = Ax + bsz * out * W;                   // [bsz][nb][RB_CH]
+  float* Dd = sm + ((bsz * out * (H + W) + 3) & ~3);   // [bsz][nb][RB_CH], float4-staged: the tables are padded to 16 bytes
   int* span = reinterpret_cast<int*>(Dd + bsz * nb * RB_CH);           // [bsz][4] = ylo, yhi, xlo, xhi (inclusive)
   // per (RoI, pixel row / column): the first and last bin with a non-zero weight there, packed lo | hi << 16 -- a pixel
   // touches 1-3 bins per axis, not all `out` of them (filled from the finished tables, one thread per position)
@@ -250,16 +250,15 @@ extern "C" int as_roi_align_bwd(const float* dout, const float* rois, float* dfe
   // RoIs per batch: as many as the LDS takes (every batch costs a fixed round of barriers and a table build by
   // 2 * out threads per RoI), at most RB_BATCH_MAX and RB_NT / (2 * out) (one table thread per RoI, bin and axis)
   auto lds_of = [&](int bsz) {
-    return ((size_t)bsz * out_size * (H + W) + (size_t)bsz * out_size * out_size * RB_CH + (size_t)bsz * 4 + (size_t)bsz * (H + W) + 4 +
+    return ((((size_t)bsz * out_size * (H + W) + 3) & ~(size_t)3) + (size_t)bsz * out_size * out_size * RB_CH + (size_t)bsz * 4 + (size_t)bsz * (H + W) + 4 +
             (size_t)R) * 4;
   };
   int bsz = RB_BATCH_MAX;
   while (bsz > 1 && (lds_of(bsz) > 150 * 1024 || out_size * 2 * bsz > RB_NT)) --bsz;
-  if (bsz > 4) bsz &= ~3;                             // keeps the float4 staging of the dout slices 16-byte aligned
   AS_REQUIRE(out_size * 2 * bsz <= RB_NT, AS_E_UNSUPPORTED, "as_roi_align_bwd: output size %d", out_size);
   const size_t lds = lds_of(bsz);
   AS_REQUIRE(lds <= 150 * 1024, AS_E_UNSUPPORTED, "as_roi_align_bwd: tables of a %dx%d map / output %d exceed LDS", H, W, out_size);
-  static bool attr = false;
+  static std::atomic<bool> attr{false};
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)roi_align_bwd_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     (void)hipFuncSetAttribute((const void*)roi_align_bwd_kernel<RB_MAXPT>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);

@@ -1166,7 +1166,7 @@ int launch_sdpa_glds(const void* q, const void* k, const void* vt, void* o, floa
     const size_t lds1 = lds;
     const size_t lds = (size_t)AS_SDPA_NBUF2 * 2 * GL_TILE;
     (void)lds1;
-    static bool attr_set = false;
+    static std::atomic<bool> attr_set{false};   // (idempotent attribute call: a race only repeats it)
     if (!attr_set && lds > 64 * 1024 - 1) {
       (void)hipFuncSetAttribute((const void*)sdpa_fwd_pipe_kernel<2, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       (void)hipFuncSetAttribute((const void*)sdpa_fwd_pipe_kernel<2, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1209,7 +1209,7 @@ int launch_sdpa(const void* q, const void* k, const void* vt, void* o, float* ls
   const int Npad = as_round_up(N, 64);
   const int grid = as_ceil_div(N, SD_QB) * B * h;
   const size_t lds = 2 * ((size_t)SD_KB * SdpaCfg<T>::K_PITCH + (size_t)HD * SdpaCfg<T>::V_PITCH);
-  static bool attr_set = false;
+  static std::atomic<bool> attr_set{false};   // (idempotent attribute call: a race only repeats it)
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)sdpa_fwd_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;

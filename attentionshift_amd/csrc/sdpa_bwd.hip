@@ -929,7 +929,7 @@ int launch_bwd(const void* q, const void* k, const void* vt, const void* o, cons
   constexpr int PITCH = TS::ROWB + 16;
   const size_t lds_dq = 2 * (size_t)(3 * BW_TILE * PITCH);
   const size_t lds_dkv = 2 * (size_t)(2 * BW_TILE * TS::ROWB + 2 * BW_TILE * PITCH + 2 * BW_TILE * 4);
-  static bool attr_set = false;
+  static std::atomic<bool> attr_set{false};   // (idempotent attribute call: a race only repeats it)
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)sdpa_bwd_dq_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dq);
     (void)hipFuncSetAttribute((const void*)sdpa_bwd_dkv_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dkv);

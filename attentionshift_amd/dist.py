@@ -9,22 +9,62 @@ class Ranks:
     """WORLD_SIZE / RANK / LOCAL_RANK from the launcher.  On GPU boxes the process group carries TWO backends
     ("cpu:gloo,cuda:nccl"): the timing barriers and the max / sum of host scalars go through gloo on CPU tensors, so the
     forward / attention-shift throughput (which has no data-path collective) never depends on RCCL; RCCL communicators are
-    created lazily by the first collective on a device tensor -- the gradient all-reduce of the training step."""
+    created lazily by the first collective on a device tensor -- the gradient all-reduce of the training step.
 
-    def __init__(self, backend=None, device=None):
+    A process group that already exists (the reference's `mmcv.runner.init_dist` creates an nccl-only one before the model
+    is built, tools/train.py) is REUSED, not re-created; host scalars then travel on whatever the group offers: CPU
+    tensors when it has a CPU backend, tensors on `device` otherwise (so `Ranks(backend="nccl", device=...)` works too).
+
+    `force=True` (or AS_FORCE_DIST=1) creates a real ONE-rank group when the launcher gave none: `Ranks.dist` is live, the
+    reducer builds its buckets and every collective really runs (RCCL on a single GPU) -- the N > 1 code path made
+    executable on a one-GPU box."""
+
+    def __init__(self, backend=None, device=None, force=None):
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.rank = int(os.environ.get("RANK", "0"))
         self.local = int(os.environ.get("LOCAL_RANK", "0"))
         self.device = device
         self.dist = None
-        if self.world > 1:
-            import torch.distributed as dist
-            backend = backend or ("cpu:gloo,cuda:nccl" if torch.cuda.is_available() else "gloo")
-            dist.init_process_group(backend=backend)
+        self._own_group = False
+        self._tmp = None
+        if force is None:
+            force = os.environ.get("AS_FORCE_DIST", "0") == "1"
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
             self.dist = dist
+            self.world, self.rank = dist.get_world_size(), dist.get_rank()
+        elif self.world > 1 or force:
+            backend = backend or ("cpu:gloo,cuda:nccl" if torch.cuda.is_available() else "gloo")
+            if self.world > 1:
+                dist.init_process_group(backend=backend)
+            else:                      # forced one-rank group: no launcher, no port -- a file store in a private directory
+                import tempfile
+                self._tmp = tempfile.mkdtemp(prefix="as_dist_")
+                dist.init_process_group(backend=backend, init_method="file://" + os.path.join(self._tmp, "store"),
+                                        rank=0, world_size=1)
+            self.dist = dist
+            self._own_group = True
+        self._host_dev = torch.device("cpu")
+        if self.dist is not None and not self._has_cpu_backend():
+            if device is None:
+                raise RuntimeError("Ranks: the process group has no CPU backend (e.g. backend='nccl'); pass device= so that "
+                                   "barriers and host-scalar reductions can run on device tensors")
+            self._host_dev = torch.device(device)
+
+    def _has_cpu_backend(self):
+        try:
+            cfg = str(self.dist.get_backend_config())
+            return "cpu:" in cfg
+        except Exception:                     # noqa: BLE001 -- older torch: fall back to the backend's name
+            return "gloo" in str(self.dist.get_backend())
+
+    @property
+    def active(self):
+        """True when collectives are live (N > 1, or a forced one-rank group)."""
+        return self.dist is not None
 
     def _host_reduce(self, value, op):
-        t = torch.tensor([value], dtype=torch.float64)                    # CPU tensor: gloo
+        t = torch.tensor([value], dtype=torch.float64, device=self._host_dev)   # CPU tensor: gloo (when the group has it)
         self.dist.all_reduce(t, op=op)
         return float(t.item())
 
@@ -50,26 +90,78 @@ class Ranks:
         return lo, lo + per + (1 if self.rank < rem else 0)
 
     def close(self):
-        if self.dist is not None:
+        if self.dist is not None and self._own_group:     # a group the caller (mmcv's init_dist) made is the caller's
             self.dist.destroy_process_group()
+        self.dist = None
+        if self._tmp is not None:
+            import shutil
+            shutil.rmtree(self._tmp, ignore_errors=True)
+            self._tmp = None
+
+
+def broadcast_state(tensors, ranks, src=0, chunk_mb=256):
+    """Rank `src`'s values into every rank's `tensors` (parameters AND buffers), in place: what
+    MMDistributedDataParallel does at construction (mmdet/apis/train.py:96-100 -> torch DDP's `_sync_params_and_buffers`),
+    so that ranks which initialised unseeded, or of which only rank 0 loaded the checkpoint, start from identical
+    weights.  Tensors are packed by dtype into flat chunks (a few large broadcasts instead of one per tensor: the ViT-B
+    detector has ~420 tensors) and unpacked on arrival.  Returns the number of collectives issued."""
+    if ranks is None or ranks.dist is None:
+        return 0
+    groups = {}
+    for t in tensors:
+        groups.setdefault((t.dtype, t.device), []).append(t)
+    n_coll = 0
+    with torch.no_grad():
+        for (dtype, dev), ts in groups.items():
+            limit = max(1, int(chunk_mb * (1 << 20)) // max(torch.empty((), dtype=dtype).element_size(), 1))
+            i = 0
+            while i < len(ts):
+                j, n = i, 0
+                while j < len(ts) and (j == i or n + ts[j].numel() <= limit):
+                    n += ts[j].numel()
+                    j += 1
+                wire = torch.uint8 if dtype == torch.bool else dtype
+                flat = torch.cat([t.detach().reshape(-1).to(wire) for t in ts[i:j]]) if n else torch.empty(0, dtype=wire, device=dev)
+                ranks.dist.broadcast(flat, src=src)
+                n_coll += 1
+                off = 0
+                for t in ts[i:j]:
+                    t.detach().copy_(flat[off:off + t.numel()].reshape(t.shape).to(dtype))
+                    off += t.numel()
+                i = j
+    return n_coll
 
 
 class GradAllReducer:
     """Data-parallel gradient averaging for the trainable backbone (reference: mmdet's MMDistributedDataParallel around
     the detector, mmdet/apis/train.py:95-100; NCCL all-reduce of every parameter gradient once per optimizer step).
 
-    Gradients are packed into a few large flat buckets (default 64 MiB of bf16: xGMI is point-to-point, 7 links of
+    Construction broadcasts rank 0's parameters (and `buffers`, when given) to every rank, as the reference's DDP wrapper
+    does -- the ranks need not share a seed or a checkpoint load.
+
+    Gradients are packed into a few large flat buckets (default 64 MiB: xGMI is point-to-point, 7 links of
     ~153 GB/s per GPU, so a handful of big RCCL all-reduces beats hundreds of per-tensor ones) in REVERSE parameter order
     (the order backward produces them).  A bucket's all-reduce is launched asynchronously from the autograd hook of its
     last gradient, so communication of late layers overlaps the backward of early ones -- but always in BUCKET ORDER on
     every rank: bucket k is only launched once buckets < k are, and whatever is left (buckets holding a parameter that
     got no gradient on this rank, e.g. the mask head on a rank without positives) is launched in order by `finish()`,
-    which waits, averages and writes the result back into `p.grad`.  Ranks may therefore differ in which parameters
+    which waits and writes the rank-averaged result back into `p.grad`.  Ranks may therefore differ in which parameters
     receive gradients without mis-pairing collectives.  `no_sync()` skips the exchange for the micro-steps of a gradient
     accumulation (the reference's update_interval=2, mmdet/utils/optimizer.py:23-32): gradients accumulate in p.grad and
-    the step that leaves the context reduces the accumulated values.  With one rank everything is a no-op."""
+    the step that leaves the context reduces the accumulated values.
 
-    def __init__(self, params, ranks, bucket_mb=64, comm_dtype=torch.bfloat16):
+    Precision of the exchange: the default wire type is fp32 -- the sum over ranks is then the reference's (torch DDP
+    all-reduces fp32 gradients), and at 8 ranks the 0.36 GB of the detector's gradients are ~2.6 ms of ring time hidden
+    under a ~25 ms backward.  `comm_dtype=torch.bfloat16` halves the bytes; gradients are then
+    PRE-SCALED by 1/world while they are packed, so the running sum stays in the range of one rank's gradient instead of
+    growing by log2(world) binades before the scale (each partial sum still rounds to bf16's 8 bits -- use it only when
+    the exchange is exposed).
+
+    The reducer is live whenever the process group is (`ranks.dist is not None`): N > 1, or a forced one-rank group
+    (`Ranks(force=True)` / AS_FORCE_DIST=1), which runs the identical bucket / hook / RCCL / write-back path on one GPU.
+    Without a group everything is a no-op."""
+
+    def __init__(self, params, ranks, bucket_mb=64, comm_dtype=torch.float32, buffers=None, broadcast=True):
         self.ranks = ranks
         self.comm_dtype = comm_dtype
         self.params = [p for p in params if p.requires_grad]
@@ -77,8 +169,16 @@ class GradAllReducer:
         self._where = {}
         self._sync = True
         self._next = 0                       # first bucket whose all-reduce has not been launched yet
-        if ranks.world == 1:
+        self.active = ranks is not None and ranks.dist is not None
+        self.broadcasts = 0
+        if not self.active:
             return
+        self._inv = 1.0 / ranks.world
+        # fp32 wire: sum, then scale on write-back (exact w.r.t. the reference's order of operations);
+        # 16-bit wire: scale while packing so the running sum cannot leave the addends' range
+        self._prescale = comm_dtype != torch.float32
+        if broadcast:
+            self.broadcasts = broadcast_state(list(self.params) + list(buffers or []), ranks)
         limit = int(bucket_mb * (1 << 20)) // torch.empty((), dtype=comm_dtype).element_size()
         cur, cur_n = [], 0
         for p in reversed(self.params):
@@ -113,6 +213,14 @@ class GradAllReducer:
 
         return _NoSync()
 
+    def _pack(self, b, off, p):
+        dst = b["flat"][off:off + p.numel()]
+        if self._prescale:
+            torch.mul(p.grad.reshape(-1), self._inv, out=dst) if dst.dtype == p.grad.dtype else \
+                dst.copy_(p.grad.reshape(-1) * self._inv)
+        else:
+            dst.copy_(p.grad.reshape(-1))
+
     def _launch_ready(self):
         while self._next < len(self.buckets):
             b = self.buckets[self._next]
@@ -127,7 +235,7 @@ class GradAllReducer:
         b, off = self._where[id(p)]
         if b["work"] is not None:            # a second backward before finish(): this bucket is already in flight
             raise RuntimeError("GradAllReducer: backward ran again before finish(); use no_sync() for accumulation steps")
-        b["flat"][off:off + p.numel()].copy_(p.grad.reshape(-1))
+        self._pack(b, off, p)
         b["seen"].add(id(p))
         if b["index"] == self._next:
             self._launch_ready()
@@ -135,25 +243,27 @@ class GradAllReducer:
     def finish(self):
         """Call after the (last) loss.backward() of a step: completes every bucket in order and leaves the rank-averaged
         gradient in p.grad."""
-        if self.ranks.world == 1:
+        if not self.active:
             return
-        inv = 1.0 / self.ranks.world
+        post = 1.0 if self._prescale else self._inv
         for b in self.buckets[self._next:]:   # buckets with a parameter that got no gradient: zeros for it, in order
             for p, off in b["items"]:
                 if id(p) not in b["seen"]:
                     if p.grad is None:
                         b["flat"][off:off + p.numel()].zero_()
                     else:                      # accumulated earlier under no_sync() but untouched by the last backward
-                        b["flat"][off:off + p.numel()].copy_(p.grad.reshape(-1))
+                        self._pack(b, off, p)
             b["work"] = self.ranks.dist.all_reduce(b["flat"], op=self.ranks.dist.ReduceOp.SUM, async_op=True)
         for b in self.buckets:
             b["work"].wait()
             for p, off in b["items"]:
                 avg = b["flat"][off:off + p.numel()].reshape(p.shape)
                 if p.grad is None:
-                    p.grad = (avg * inv).to(p.dtype)
+                    p.grad = (avg * post).to(p.dtype) if post != 1.0 else avg.to(p.dtype, copy=True)
+                elif post != 1.0:
+                    torch.mul(avg, post, out=p.grad) if avg.dtype == p.grad.dtype else p.grad.copy_(avg).mul_(post)
                 else:
-                    p.grad.copy_(avg).mul_(inv)
+                    p.grad.copy_(avg)
             b["seen"], b["work"] = set(), None
         self._next = 0
 
@@ -203,7 +313,7 @@ def parse_losses(losses, ranks=None, lazy=False):
     log_vars["loss"] = loss
     keys = list(log_vars.keys())
     flat = torch.stack([log_vars[k].detach().float().reshape(()) for k in keys])
-    if ranks is not None and ranks.dist is not None and ranks.world > 1:
+    if ranks is not None and ranks.dist is not None:
         flat = flat / ranks.world
         ranks.dist.all_reduce(flat)
     if lazy:
@@ -262,7 +372,7 @@ class SyncBatchNorm2d(torch.nn.BatchNorm2d):
 
     def forward(self, x):
         r = self.ranks
-        if not self.training or r is None or r.dist is None or r.world == 1:
+        if not self.training or r is None or r.dist is None:
             return super().forward(x)
         y, mean, var, n = _SyncBNFn.apply(x, self.weight, self.bias, self.eps, r)
         if self.track_running_stats:

@@ -56,7 +56,9 @@ def roi_align(feat, rois, output_size=7, spatial_scale=1.0 / 16, sampling_ratio=
     # the HIP backward keeps fixed pixels x 8 channels per thread and its 1-D tables in LDS (csrc/roi_align.hip): outside its
     # limits a trainable map takes the tensor-op path below instead of failing in backward
     bwd_ok = (not (feat.requires_grad and torch.is_grad_enabled())) or (
-        C % 8 == 0 and H * W <= 8192 and (8 * out * (H + W) + 8 * out * out * 8 + 36 + R) * 4 <= 150 * 1024)
+        C % 8 == 0 and H * W <= 8192 and 2 * out <= 1024 and
+        # as_roi_align_bwd shrinks its RoI batch until the tables fit: the limit is ONE RoI's tables (padded to 16 bytes)
+        (((out * (H + W) + 3) & ~3) + out * out * 8 + 4 + (H + W) + 4 + R) * 4 <= 150 * 1024)
     if feat.is_cuda and C % 4 == 0 and bwd_ok:
         # the HIP kernel (csrc/roi_align.hip): token-major in, [R, out*out, C] out; the [R, C, out, out] the heads expect
         # is a permuted VIEW of it (they flatten straight back to tokens)

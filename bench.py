@@ -202,12 +202,14 @@ def build(device, rng_mode="fast", train=False, ranks=None, mil=False):
     # one fused all-reduce of the logged scalars, AdamW.  (The RPN / FPN neck that would produce the proposals is not part
     # of this build; the proposals are seeded jitters of the objects' boxes.)
     from attentionshift_amd.dist import GradAllReducer, convert_sync_batchnorm, parse_losses
-    if ranks is not None and ranks.world > 1:
+    if ranks is not None and ranks.dist is not None:
         convert_sync_batchnorm(bb, ranks)              # as mmdet/apis/train.py:95 does before wrapping the model in DDP
     head.train()
     params = [p for p in list(bb.parameters()) + list(head.parameters()) if p.requires_grad]
     opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=0.05, fused=True)
-    reducer = GradAllReducer(params, ranks)
+    # rank 0's parameters AND buffers are broadcast at construction (mmdet/apis/train.py:96-100); fp32 wire by default
+    comm = getattr(torch, os.environ.get("AS_COMM_DTYPE", "float32"))
+    reducer = GradAllReducer(params, ranks, comm_dtype=comm, buffers=list(bb.buffers()) + list(head.buffers()))
     proposals = synthetic_proposals(shift, device)
     gen = torch.Generator().manual_seed(99 + rank)
 
@@ -557,7 +559,23 @@ def main():
         dog.daemon = True
         dog.start()
         try:
-            tstep = build(device, rng_mode, train=True, ranks=ranks)
+            # N = 1: the leg runs through a REAL one-rank process group (dist.Ranks(force=True): RCCL on this GPU), so the
+            # bucket copies, the hook-launched all-reduces, finish() and the write-back are the code that N > 1 runs;
+            # AS_FORCE_DIST=0 (or an RCCL that does not come up) falls back to the group-less step, and says so
+            tranks, forced = ranks, None
+            if world == 1 and os.environ.get("AS_FORCE_DIST", "1") == "1":
+                try:
+                    tranks = Ranks(device=device, force=True)
+                    tstep = build(device, rng_mode, train=True, ranks=tranks)
+                    logs = tstep()
+                    forced = "one-rank process group (" + str(tranks.dist.get_backend_config()) + ")"
+                except Exception as e:                      # noqa: BLE001
+                    forced = f"one-rank group failed ({type(e).__name__}: {e})"[:200] + "; ran without a group"
+                    tranks.close() if tranks is not ranks else None
+                    tranks = ranks
+                    tstep = build(device, rng_mode, train=True, ranks=ranks)
+            else:
+                tstep = build(device, rng_mode, train=True, ranks=ranks)
             for _ in range(2):
                 logs = tstep()
             ops.enable_timing(["attn_bwd"])
@@ -570,7 +588,8 @@ def main():
             torch.cuda.synchronize()
             fin_ms = [e0.elapsed_time(e1) for e0, e1 in tstep.finish_events]
             red = tstep.reducer
-            comm = {"buckets": len(red.buckets), "bucket_bytes": [int(b["flat"].numel() * b["flat"].element_size()) for b in red.buckets],
+            comm = {"group": forced or (f"{world} ranks" if world > 1 else "none"), "state_broadcasts": red.broadcasts,
+                    "buckets": len(red.buckets), "bucket_bytes": [int(b["flat"].numel() * b["flat"].element_size()) for b in red.buckets],
                     "comm_dtype": str(red.comm_dtype).replace("torch.", ""),
                     # device time of reducer.finish() on the compute stream: what of the gradient all-reduce is NOT hidden
                     # under the backward (waits for the in-flight buckets + averaging / write-back), max over ranks
@@ -603,6 +622,11 @@ def main():
         except Exception as e:                              # noqa: BLE001 -- the headline must still be printed
             rec["train"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         dog.cancel()
+        try:
+            if tranks is not ranks:
+                tranks.close()
+        except Exception:                                   # noqa: BLE001
+            pass
 
     if rank == 0 and world == 1 and a.config == "vitb" and not a.no_cpu_baseline and not emitted.is_set():
         rec["cpu_baseline"] = cpu_baseline()

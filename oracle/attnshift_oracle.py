@@ -749,3 +749,167 @@ def swin_block(x, p, num_heads, ws, shift, ln_eps=1e-5):
     z = F.layer_norm(x, (C,), p["norm2.weight"], p["norm2.bias"], ln_eps)
     z = F.linear(F.gelu(F.linear(z, p["mlp.fc1.weight"], p["mlp.fc1.bias"])), p["mlp.fc2.weight"], p["mlp.fc2.bias"])
     return x + z, attn
+
+
+# ---------------------------------------------------------------------------------------------------------
+# mmcv-full 1.3.8 compiled ops used next to the path: RoIAlign and NMS.
+#
+# mmcv is a third-party dependency that is ABSENT from /root/reference (install.sh pins `mmcv-full==1.3.8`); its ops
+# cannot be executed here, so these are restatements of its PUBLISHED algorithm (mmcv/ops/csrc/pytorch/cpu/
+# roi_align.cpp `ROIAlignForward` / `ROIAlignBackward` + `pre_calc_for_bilinear_interpolate`, pool_mode 'avg';
+# mmcv/ops/csrc/pytorch/cpu/nms.cpp `nms_cpu`; mmcv/ops/nms.py `batched_nms`; mmdet/core/post_processing/bbox_nms.py
+# `multiclass_nms`), written as the scalar loops of that source -- deliberately NOT sharing a line of arithmetic with
+# attentionshift_amd/mil_head.roi_align (separable tensor ops) or attentionshift_amd/inference.nms (IoU matrix).
+# They are anchored on the reference's call sites: configs/mae/attnshift_voc12aug.py:64-68,123-127 (RoIAlign 7x7 /
+# 14x14, sampling_ratio=0, featmap stride 16; mmdet's SingleRoIExtractor builds the layer with aligned=True, its
+# default), stdroi:2958 (MIL RoI features), stdroi:3192-3221 + attnshift_voc12aug.py:200-204 (test-time NMS:
+# score_thr 0.05, IoU 0.5, 100 per image), and on closed-form cases in tests/test_oracle_roi_nms.py.  "parity
+# unpinned" in the sense of the task statement: no golden vector from mmcv itself exists in the reference tree.
+# ---------------------------------------------------------------------------------------------------------
+def _mmcv_bilinear_terms(height, width, y, x):
+    """One sample point -> ((y_low, x_low, y_high, x_high), (w1, w2, w3, w4)) or None when the point lies outside
+    [-1, size] (roi_align.cpp bilinear_interpolate / pre_calc_for_bilinear_interpolate: contributes 0)."""
+    if y < -1.0 or y > height or x < -1.0 or x > width:
+        return None
+    y = max(y, 0.0)
+    x = max(x, 0.0)
+    y_low, x_low = int(y), int(x)
+    if y_low >= height - 1:
+        y_high = y_low = height - 1
+        y = float(y_low)
+    else:
+        y_high = y_low + 1
+    if x_low >= width - 1:
+        x_high = x_low = width - 1
+        x = float(x_low)
+    else:
+        x_high = x_low + 1
+    ly, lx = y - y_low, x - x_low
+    hy, hx = 1.0 - ly, 1.0 - lx
+    return (y_low, x_low, y_high, x_high), (hy * hx, hy * lx, ly * hx, ly * lx)
+
+
+def _mmcv_roi_geometry(roi, spatial_scale, pooled, sampling_ratio, aligned):
+    offset = 0.5 if aligned else 0.0
+    x1, y1, x2, y2 = (float(v) * spatial_scale - offset for v in roi[1:5])
+    roi_w, roi_h = x2 - x1, y2 - y1
+    if not aligned:                                      # legacy: force a minimum size of one pixel
+        roi_w, roi_h = max(roi_w, 1.0), max(roi_h, 1.0)
+    bin_h, bin_w = roi_h / pooled, roi_w / pooled
+    grid_h = sampling_ratio if sampling_ratio > 0 else int(math.ceil(roi_h / pooled))
+    grid_w = sampling_ratio if sampling_ratio > 0 else int(math.ceil(roi_w / pooled))
+    count = max(grid_h * grid_w, 1)
+    return x1, y1, bin_h, bin_w, grid_h, grid_w, count
+
+
+def roi_align_mmcv(feat, rois, output_size, spatial_scale, sampling_ratio=0, aligned=True):
+    """mmcv.ops.roi_align (pool_mode='avg').  feat [B,C,H,W] float, rois [R,5] = (batch index, x1, y1, x2, y2) in image
+    coordinates -> [R,C,out,out] float64.  Scalar loops over RoIs, bins and sample points; vectorised over channels."""
+    f = np.asarray(feat, dtype=np.float64)
+    r = np.asarray(rois, dtype=np.float64)
+    B, C, H, W = f.shape
+    out = np.zeros((r.shape[0], C, output_size, output_size), dtype=np.float64)
+    for n in range(r.shape[0]):
+        b = int(r[n, 0])
+        x1, y1, bin_h, bin_w, grid_h, grid_w, count = _mmcv_roi_geometry(r[n], spatial_scale, output_size, sampling_ratio, aligned)
+        for ph in range(output_size):
+            for pw in range(output_size):
+                acc = np.zeros(C, dtype=np.float64)
+                for iy in range(grid_h):
+                    y = y1 + ph * bin_h + (iy + 0.5) * bin_h / grid_h
+                    for ix in range(grid_w):
+                        x = x1 + pw * bin_w + (ix + 0.5) * bin_w / grid_w
+                        terms = _mmcv_bilinear_terms(H, W, y, x)
+                        if terms is None:
+                            continue
+                        (yl, xl, yh, xh), (w1, w2, w3, w4) = terms
+                        acc += w1 * f[b, :, yl, xl] + w2 * f[b, :, yl, xh] + w3 * f[b, :, yh, xl] + w4 * f[b, :, yh, xh]
+                out[n, :, ph, pw] = acc / count
+    return out
+
+
+def roi_align_mmcv_backward(grad_out, rois, feat_shape, spatial_scale, sampling_ratio=0, aligned=True):
+    """ROIAlignBackward (avg): every sample point scatters grad / count with its four bilinear weights.
+    grad_out [R,C,out,out] -> grad_feat [B,C,H,W] float64."""
+    g = np.asarray(grad_out, dtype=np.float64)
+    r = np.asarray(rois, dtype=np.float64)
+    B, C, H, W = feat_shape
+    pooled = g.shape[-1]
+    df = np.zeros((B, C, H, W), dtype=np.float64)
+    for n in range(r.shape[0]):
+        b = int(r[n, 0])
+        x1, y1, bin_h, bin_w, grid_h, grid_w, count = _mmcv_roi_geometry(r[n], spatial_scale, pooled, sampling_ratio, aligned)
+        for ph in range(pooled):
+            for pw in range(pooled):
+                go = g[n, :, ph, pw] / count
+                for iy in range(grid_h):
+                    y = y1 + ph * bin_h + (iy + 0.5) * bin_h / grid_h
+                    for ix in range(grid_w):
+                        x = x1 + pw * bin_w + (ix + 0.5) * bin_w / grid_w
+                        terms = _mmcv_bilinear_terms(H, W, y, x)
+                        if terms is None:
+                            continue
+                        (yl, xl, yh, xh), (w1, w2, w3, w4) = terms
+                        df[b, :, yl, xl] += w1 * go
+                        df[b, :, yl, xh] += w2 * go
+                        df[b, :, yh, xl] += w3 * go
+                        df[b, :, yh, xh] += w4 * go
+    return df
+
+
+def nms_mmcv(boxes, scores, iou_threshold, offset=0):
+    """mmcv.ops.nms (nms_cpu): visit boxes by decreasing score (stable), keep a box unless suppressed, suppress every
+    later box whose IoU with it EXCEEDS the threshold (`ovr > iou_threshold`; areas and intersections with `offset`,
+    0 by default).  Returns the kept indices in decreasing-score order."""
+    bx = np.asarray(boxes, dtype=np.float64).reshape(-1, 4)
+    sc = np.asarray(scores, dtype=np.float64).reshape(-1)
+    order = np.argsort(-sc, kind="stable")
+    areas = (bx[:, 2] - bx[:, 0] + offset) * (bx[:, 3] - bx[:, 1] + offset)
+    suppressed = np.zeros(bx.shape[0], dtype=bool)
+    keep = []
+    for _i in range(order.size):
+        i = int(order[_i])
+        if suppressed[i]:
+            continue
+        keep.append(i)
+        for _j in range(_i + 1, order.size):
+            j = int(order[_j])
+            if suppressed[j]:
+                continue
+            w = max(0.0, min(bx[i, 2], bx[j, 2]) - max(bx[i, 0], bx[j, 0]) + offset)
+            h = max(0.0, min(bx[i, 3], bx[j, 3]) - max(bx[i, 1], bx[j, 1]) + offset)
+            inter = w * h
+            ovr = inter / (areas[i] + areas[j] - inter) if inter > 0 else 0.0
+            if ovr > iou_threshold:
+                suppressed[j] = True
+    return np.asarray(keep, dtype=np.int64)
+
+
+def multiclass_nms_mmdet(multi_bboxes, multi_scores, score_thr, iou_threshold, max_num=-1):
+    """mmdet/core/post_processing/bbox_nms.py `multiclass_nms` + mmcv.ops.batched_nms (class_agnostic=False): drop the
+    background column, keep (box, class) pairs with score > score_thr, shift the boxes of class c by c * (max coordinate
+    + 1) so that classes never overlap, one greedy NMS over all pairs, the best `max_num`.  Done here the direct way --
+    per class, then merged by score -- which is what the offset trick computes.  -> (dets [m,5], labels [m])."""
+    mb = np.asarray(multi_bboxes, dtype=np.float64)
+    ms = np.asarray(multi_scores, dtype=np.float64)
+    n, K = ms.shape[0], ms.shape[1] - 1
+    dets, labels, flat_pos = [], [], []
+    for c in range(K):
+        bc = mb[:, 4 * c:4 * c + 4] if mb.shape[1] > 4 else mb
+        idx = np.nonzero(ms[:, c] > score_thr)[0]
+        if idx.size == 0:
+            continue
+        keep = nms_mmcv(bc[idx], ms[idx, c], iou_threshold)
+        for k in keep:
+            i = int(idx[k])
+            dets.append(np.concatenate((bc[i], ms[i:i + 1, c])))
+            labels.append(c)
+            flat_pos.append(i * K + c)                   # position in mmdet's flattened (box-major) candidate list
+    if not dets:
+        return np.zeros((0, 5)), np.zeros(0, dtype=np.int64)
+    dets, labels, flat_pos = np.stack(dets), np.asarray(labels, dtype=np.int64), np.asarray(flat_pos)
+    # one global order by decreasing score; equal scores keep the candidate list's order (stable sort in nms)
+    order = np.lexsort((flat_pos, -dets[:, 4]))
+    if max_num > 0:
+        order = order[:max_num]
+    return dets[order], labels[order]

@@ -301,3 +301,121 @@ def test_two_rank_gradient_accumulation_with_no_sync():
     outs = _run_train_workers({"ACCUM": "2"})
     for o in outs:
         assert o["err"] < 1e-5, o
+
+
+BCAST_WORKER = textwrap.dedent("""
+    import os, sys, json
+    sys.path.insert(0, %r)
+    import torch
+    from attentionshift_amd.dist import Ranks, GradAllReducer
+    r = Ranks(backend="gloo")
+    torch.manual_seed(1000 + r.rank)                       # DIFFERENT replicas: only the broadcast can make them agree
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 1), torch.nn.BatchNorm2d(4), torch.nn.Flatten(), torch.nn.Linear(4 * 4, 3))
+    net[1].running_mean.add_(r.rank + 1.0)                 # buffers differ too (incl. the int64 num_batches_tracked)
+    net[1].num_batches_tracked.add_(3 * r.rank + 1)
+    flag = torch.nn.Parameter(torch.tensor([bool(r.rank)] * 3), requires_grad=False)     # bool buffer-like tensor
+    before = [p.detach().clone() for p in net.parameters()]
+    comm = os.environ.get("COMM", "float32")
+    red = GradAllReducer(net.parameters(), r, bucket_mb=0.0002, comm_dtype=getattr(torch, comm),
+                         buffers=list(net.buffers()) + [flag])
+    state = [t.detach().double().flatten().tolist() for t in list(net.parameters()) + list(net.buffers()) + [flag]]
+    changed = any(not torch.equal(a, p.detach()) for a, p in zip(before, net.parameters()))
+    # one step on rank-specific data: gradients averaged; with the 16-bit wire the values are pre-scaled by 1/world
+    x = torch.randn(5, 3, 2, 2, generator=torch.Generator().manual_seed(50 + r.rank))
+    net(x).square().sum().backward()
+    local = [p.grad.clone() for p in net.parameters()]
+    red.finish()
+    print(json.dumps(dict(rank=r.rank, state=state, changed=changed, ncoll=red.broadcasts, nb=len(red.buckets),
+                          avg=[p.grad.flatten().tolist() for p in net.parameters()],
+                          local=[g.flatten().tolist() for g in local])), flush=True)
+    red.close()
+    r.close()
+""") % ROOT
+
+
+def _spawn2(worker, extra_env=None, timeout=180):
+    import json
+    port = free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), **(extra_env or {}))
+        procs.append(subprocess.Popen([sys.executable, "-c", worker], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                                      text=True))
+    outs = []
+    for p in procs:
+        o, e = p.communicate(timeout=timeout)
+        assert p.returncode == 0, e[-3000:]
+        outs.append(json.loads(o.strip().splitlines()[-1]))
+    outs.sort(key=lambda d: d["rank"])
+    return outs
+
+
+def test_reducer_broadcasts_rank0_parameters_and_buffers_at_construction():
+    """mmdet/apis/train.py:96-100: MMDistributedDataParallel broadcasts rank 0's state when it wraps the model.  Ranks
+    seeded differently (or of which only rank 0 loaded a checkpoint) must start from identical weights and buffers."""
+    a, b = _spawn2(BCAST_WORKER)
+    assert a["state"] == b["state"]                      # bit-identical after construction (fp32, int64 and bool tensors)
+    assert not a["changed"] and b["changed"]             # rank 0 is the source, rank 1 was overwritten
+    assert 1 <= a["ncoll"] <= 4                          # packed by dtype: a few broadcasts, not one per tensor
+    for i in range(len(a["avg"])):
+        want = [(x + y) / 2 for x, y in zip(a["local"][i], b["local"][i])]
+        for got in (a["avg"][i], b["avg"][i]):
+            assert max(abs(g - w) for g, w in zip(got, want)) < 1e-5 * (1 + max(abs(w) for w in want))
+
+
+def test_bf16_wire_is_prescaled_by_the_world_size():
+    """comm_dtype=bfloat16: gradients are scaled by 1/world while they are packed (the running sum stays in one rank's
+    range), the result is the rank mean to bf16 precision and both ranks hold the same bits."""
+    a, b = _spawn2(BCAST_WORKER, {"COMM": "bfloat16"})
+    assert a["avg"] == b["avg"]
+    for i in range(len(a["avg"])):
+        want = [(x + y) / 2 for x, y in zip(a["local"][i], b["local"][i])]
+        scale = max(abs(w) for w in want) + 1e-12
+        assert max(abs(g - w) for g, w in zip(a["avg"][i], want)) < 1.2e-2 * scale
+
+
+def test_forced_one_rank_group_runs_the_real_reducer_path():
+    """Ranks(force=True) / AS_FORCE_DIST=1: a real one-rank process group, so the bucket copy, the hook-launched
+    all-reduce, finish() and the write-back all execute; gradients equal the plain step's."""
+    import torch
+    from attentionshift_amd.dist import GradAllReducer, Ranks, parse_losses
+    env = {k: os.environ.pop(k, None) for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    try:
+        r = Ranks(backend="gloo", force=True)
+        assert r.world == 1 and r.active and r.dist is not None
+        r.barrier()
+        assert r.max_over_ranks(2.5) == 2.5 and r.sum_over_ranks(3) == 3.0
+        torch.manual_seed(0)
+        net = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.GELU(), torch.nn.Linear(16, 4))
+        x = torch.randn(6, 8)
+        net(x).square().sum().backward()
+        want = [p.grad.clone() for p in net.parameters()]
+        for comm, tol in ((torch.float32, 0.0), (torch.bfloat16, 8e-3)):
+            for p in net.parameters():
+                p.grad = None
+            red = GradAllReducer(net.parameters(), r, bucket_mb=0.0003, comm_dtype=comm)
+            assert red.active and len(red.buckets) >= 2 and red.broadcasts >= 1
+            with red.no_sync():
+                (net(x).square().sum() * 0.5).backward()
+            (net(x).square().sum() * 0.5).backward()         # accumulates onto the no_sync micro-step
+            red.finish()
+            for p, w in zip(net.parameters(), want):
+                assert float((p.grad - w).abs().max()) <= tol * float(w.abs().max()) + (1e-6 if tol == 0 else 0)
+            red.close()
+        loss, logs = parse_losses({"loss_a": torch.tensor([1.0, 3.0]), "acc": torch.tensor(5.0)}, r)
+        assert float(loss) == 2.0 and logs == {"loss_a": 2.0, "acc": 5.0, "loss": 2.0}
+        # a second Ranks() finds the live group and REUSES it (mmcv's init_dist creates the group before the model is
+        # built); closing the borrower leaves the owner's group alive
+        r2 = Ranks()
+        assert r2.dist is not None and r2.world == 1 and not r2._own_group
+        r2.close()
+        assert torch.distributed.is_initialized()
+        r.close()
+        assert not torch.distributed.is_initialized()
+    finally:
+        if torch.distributed.is_initialized():
+            torch.distributed.destroy_process_group()
+        for k, v in env.items():
+            if v is not None:
+                os.environ[k] = v

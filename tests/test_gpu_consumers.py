@@ -10,6 +10,7 @@ import pytest
 import torch
 
 import attentionshift_amd as A
+import attnshift_oracle as O
 from attentionshift_amd import mae_heads, mask_targets as MT, point_loss as PL
 
 pytestmark = pytest.mark.gpu
@@ -102,3 +103,69 @@ def test_roi_align_hip_matches_the_tensor_op_restatement(out, C, hw):
     assert float((y_hip.cpu() - y_ref).abs().max()) <= 1e-5 * max(1.0, float(y_ref.abs().max()))
     gscale = float(f_ref.grad.abs().max())
     assert float((f_hip.grad.cpu() - f_ref.grad).abs().max()) <= 1e-4 * gscale
+
+
+@pytest.mark.parametrize("out,C,hw,n", [(7, 768, (64, 64), 48), (14, 768, (64, 64), 32), (7, 48, (14, 17), 40)])
+def test_roi_align_hip_matches_the_independent_mmcv_oracle(out, C, hw, n):
+    """as_roi_align_fwd / as_roi_align_bwd through the C ABI against oracle.roi_align_mmcv / roi_align_mmcv_backward --
+    the scalar-loop restatement of mmcv-full 1.3.8's published kernel that shares no arithmetic with the product
+    (tests/test_oracle_roi_nms.py holds it to closed-form cases).  Config-2 map (64x64x768) at 7x7 and 14x14
+    (configs/mae/attnshift_voc12aug.py:64-68,123-127), RoIs leaving the map, a degenerate RoI, two images."""
+    from attentionshift_amd import ops
+    gen = torch.Generator().manual_seed(11 + out)
+    H, W = hw
+    feat = torch.randn(2, C, H, W, generator=gen)
+    xy = torch.rand(n, 2, generator=gen) * torch.tensor([W * 16.0, H * 16.0]) - 24
+    rois = torch.cat((torch.randint(0, 2, (n, 1), generator=gen).float(), xy, xy + 8 + torch.rand(n, 2, generator=gen) * 380), 1)
+    rois[5, 3:] = rois[5, 1:3] - 3.0                        # empty sample grid -> zeros
+    rois[6] = torch.tensor([1.0, -40.0, 100.0, 90.0, 400.0])          # hangs off the left border
+    wgt = torch.randn(n, C, out, out, generator=gen)
+    nhwc = feat.permute(0, 2, 3, 1).contiguous().cuda()
+    y = ops.roi_align_fwd(nhwc, rois.cuda(), out, 1.0 / 16, 0, True)                       # [R, out*out, C]
+    d = ops.roi_align_bwd(wgt.permute(0, 2, 3, 1).reshape(n, out * out, C).contiguous().cuda(), rois.cuda(),
+                          tuple(nhwc.shape), out, 1.0 / 16, 0, True)                      # [B, H, W, C]
+    y_ref = O.roi_align_mmcv(feat.numpy(), rois.numpy(), out, 1.0 / 16, 0, True)
+    d_ref = O.roi_align_mmcv_backward(wgt.numpy(), rois.numpy(), tuple(feat.shape), 1.0 / 16, 0, True)
+    got = y.view(n, out, out, C).permute(0, 3, 1, 2).cpu().double().numpy()
+    assert (got[5] == 0).all()
+    assert np.abs(got - y_ref).max() <= 1e-5 * max(1.0, np.abs(y_ref).max())
+    gd = d.permute(0, 3, 1, 2).cpu().double().numpy()
+    assert np.abs(gd - d_ref).max() <= 1e-4 * np.abs(d_ref).max()
+
+
+def test_roi_align_hip_closed_forms():
+    """Constant map -> the constant; linear ramp -> the ramp at every bin centre (bilinear interpolation is exact on a
+    linear function); fully outside -> zeros.  fp32 kernel: 1e-5 of the range."""
+    from attentionshift_amd import ops
+    B, C, H, W = 1, 8, 64, 64
+    ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+    a = torch.arange(1, C + 1, dtype=torch.float32)
+    ramp = (0.5 * ys[..., None] - 0.25 * xs[..., None] + 1.0) * a                      # [H, W, C]
+    rois = torch.tensor([[0, 40., 56., 600., 480.], [0, 100.5, 33.25, 717.0, 890.75], [0, 2000., 2000., 2100., 2100.]])
+    for out in (7, 14):
+        y = ops.roi_align_fwd(ramp[None].contiguous().cuda(), rois.cuda(), out, 1.0 / 16, 0, True).cpu().view(3, out, out, C)
+        for n in range(2):
+            x1, y1, x2, y2 = (rois[n, 1:] / 16.0 - 0.5).tolist()
+            cy = y1 + (torch.arange(out) + 0.5) * (y2 - y1) / out
+            cx = x1 + (torch.arange(out) + 0.5) * (x2 - x1) / out
+            want = (0.5 * cy[:, None, None] - 0.25 * cx[None, :, None] + 1.0) * a
+            assert float((y[n] - want).abs().max()) <= 1e-5 * float(want.abs().max()), (out, n)
+        assert (y[2] == 0).all()
+        const = ops.roi_align_fwd(torch.full((1, H, W, C), 2.5).cuda(), rois[:2].cuda(), out, 1.0 / 16, 0, True)
+        assert float((const - 2.5).abs().max()) <= 1e-5
+
+
+def test_nms_on_device_tensors_matches_the_oracle():
+    """inference.multiclass_nms fed CUDA tensors (the test-time path of stdroi:3192-3221) against the oracle's per-class
+    greedy NMS."""
+    from attentionshift_amd import inference as I
+    gen = torch.Generator().manual_seed(2)
+    n, K = 300, 20
+    xy = torch.rand(n, 2, generator=gen) * 900
+    boxes = torch.cat((xy, xy + 10 + torch.rand(n, 2, generator=gen) * 200), 1)
+    per_class = (boxes[:, None, :] + torch.randn(n, K, 4, generator=gen) * 4).reshape(n, 4 * K)
+    scores = torch.softmax(torch.randn(n, K + 1, generator=gen) * 2.5, 1)
+    d, l = I.multiclass_nms(per_class.cuda(), scores.cuda(), 0.05, 0.5, 100)
+    dr, lr = O.multiclass_nms_mmdet(per_class.numpy(), scores.numpy(), 0.05, 0.5, 100)
+    assert l.cpu().tolist() == lr.tolist()
+    assert np.allclose(d.cpu().numpy(), dr, rtol=1e-6, atol=1e-5)

@@ -1,0 +1,102 @@
+"""The N > 1 code path on the ONE GPU of a test box: a real one-rank process group ("cpu:gloo,cuda:nccl", i.e. RCCL),
+so GradAllReducer builds its buckets, broadcasts the state, launches its all-reduces from the autograd hooks and writes
+the averages back -- and the result must equal the group-less training step.  Runs in a child process under a time limit
+(an RCCL that does not come up must not hang the suite).  Reference: mmdet/apis/train.py:95-100 (SyncBN conversion +
+MMDistributedDataParallel), mmdet/utils/optimizer.py:23-38 (update_interval)."""
+import json
+import os
+import subprocess
+import sys
+import textwrap
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = textwrap.dedent("""
+    import os, sys, json
+    sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests")); sys.path.insert(0, os.path.join(%r, "oracle"))
+    import numpy as np, torch
+    import attentionshift_amd as A
+    from attentionshift_amd import synthetic
+    from attentionshift_amd.dist import Ranks, GradAllReducer, convert_sync_batchnorm, parse_losses
+    from helpers import backbone_cfg, backbone_state_dict
+    torch.cuda.set_device(0)
+    g = dict(np.load(os.path.join(%r, "tests", "golden", "backbone_small.npz"), allow_pickle=False))
+    cfg = backbone_cfg(g)
+
+    def make():
+        bb = A.build_backbone(dict(type="VisionTransformerDet", img_size=cfg["img_size"], patch_size=16,
+                                   embed_dim=cfg["embed_dim"], depth=cfg["depth"], num_heads=cfg["num_heads"], mlp_ratio=4.,
+                                   qkv_bias=True, drop_path_rate=0., out_indices=cfg["out_indices"], last_feat=True,
+                                   point_tokens_num=cfg["point_tokens_num"], num_classes=cfg["num_classes"],
+                                   return_attention=True, compute_dtype=torch.bfloat16))
+        bb.load_state_dict(backbone_state_dict(g))
+        return bb.cuda().train()
+
+    img = synthetic.images(cfg["batch"], *cfg["img_hw"], seed=cfg["seed"]).cuda()
+
+    def loss_of(out, fpn):
+        gen = torch.Generator().manual_seed(3)
+        tot = 0.0
+        for k in ("last_feat", "point_tokens", "outputs_coord") + (("feature",) if fpn else ()):
+            for o in (out[k] if isinstance(out[k], (list, tuple)) else [out[k]]):
+                tot = tot + (o.float() * torch.randn(o.shape, generator=gen).cuda()).sum()
+        return {"loss_x": tot, "acc": tot.detach() * 0 + 7.0}
+
+    def step(bb, ranks, red, accum, fpn=False):
+        for p in bb.parameters():
+            p.grad = None
+        for micro in range(accum):
+            loss, logs = parse_losses(loss_of(bb(img), fpn), ranks)
+            if red is not None and micro < accum - 1:
+                with red.no_sync():
+                    (loss / accum).backward()
+            else:
+                (loss / accum).backward()
+        if red is not None:
+            red.finish()
+        return {n: p.grad.detach().clone() for n, p in bb.named_parameters() if p.grad is not None}, logs
+
+    plain = make()
+    want, logs0 = step(plain, None, None, 2)
+    want_fpn, _ = step(plain, None, None, 1, fpn=True)
+
+    r = Ranks(device=torch.device("cuda", 0), force=True)
+    assert r.active and r.world == 1
+    r.barrier()
+    out = dict(backend=str(r.dist.get_backend_config()))
+    for comm, tol in (("float32", 1e-6), ("bfloat16", 1.6e-2)):
+        bb = convert_sync_batchnorm(make(), r)
+        params = [p for p in bb.parameters() if p.requires_grad]
+        red = GradAllReducer(params, r, bucket_mb=1.0, comm_dtype=getattr(torch, comm), buffers=list(bb.buffers()))
+        got, logs = step(bb, r, red, 2)
+        torch.cuda.synchronize()
+        assert set(got) == set(want)
+        err = max(float((got[n] - want[n]).abs().max() / (want[n].abs().max() + 1e-20)) for n in want)
+        # with the FPN maps in the loss the stride-4 branch's BatchNorm runs as SyncBatchNorm2d: its statistics travel
+        # through a (one-rank) RCCL all-reduce and its arithmetic differs from ATen's fused batch norm in rounding only
+        got_f, _ = step(bb, r, red, 1, fpn=True)
+        assert set(got_f) == set(want_fpn)
+        err_f = max(float((got_f[n] - want_fpn[n]).abs().max() / (want_fpn[n].abs().max() + 1e-20)) for n in want_fpn)
+        out[comm] = dict(buckets=len(red.buckets), broadcasts=red.broadcasts, err=err, tol=tol, err_fpn=err_f,
+                         log_err=abs(logs["loss"] - logs0["loss"]) / (abs(logs0["loss"]) + 1e-12))
+        red.close()
+    r.close()
+    print(json.dumps(out), flush=True)
+""") % (ROOT, ROOT, ROOT, ROOT)
+
+
+def test_one_rank_rccl_group_runs_the_bucketed_reducer_and_matches_the_plain_step():
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cp = subprocess.run([sys.executable, "-c", WORKER], env=env, capture_output=True, text=True, timeout=420)
+    assert cp.returncode == 0, cp.stderr[-3000:]
+    rec = json.loads(cp.stdout.strip().splitlines()[-1])
+    assert "nccl" in rec["backend"], rec
+    for comm in ("float32", "bfloat16"):
+        o = rec[comm]
+        assert o["buckets"] >= 2 and o["broadcasts"] >= 1, rec
+        assert o["err"] <= o["tol"] and o["log_err"] < 1e-5, rec
+        assert o["err_fpn"] <= max(o["tol"], 5e-3), rec

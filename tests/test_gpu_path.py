@@ -119,6 +119,8 @@ def test_backbone_train_step_grads_match_oracle_autograd(golden, dtype, tol):
     names = ["blocks.0.attn.qkv.weight", "blocks.0.attn.qkv.bias", "blocks.0.attn.proj.weight", "blocks.0.norm1.weight",
              "blocks.1.mlp.fc1.weight", f"blocks.{cfg['depth'] - 1}.attn.proj.bias", "pos_embed", "point_token",
              "patch_embed.proj.weight", "bbox_embed.layers.2.weight"]
+    if dtype == torch.float32:         # fp32 has no gate flips: the lower point-head layers are held to the same bar
+        names += ["bbox_embed.layers.0.weight", "bbox_embed.layers.1.weight"]
     # (the LAST layer of the point head: its weight gradient is dY^T relu(h), continuous in the activations.  The first
     # layers' gradients are gated by relu'(h) of the layers above: in bf16 a pre-activation near 0 flips its gate against
     # the fp64 reference and moves a whole row of the gradient -- 0.05 .. 0.15 of the range depending on which rounding
