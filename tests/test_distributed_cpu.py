@@ -381,6 +381,8 @@ def test_forced_one_rank_group_runs_the_real_reducer_path():
     import torch
     from attentionshift_amd.dist import GradAllReducer, Ranks, parse_losses
     env = {k: os.environ.pop(k, None) for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    grad_was = torch.is_grad_enabled()
+    torch.set_grad_enabled(True)           # (the GPU test modules switch autograd off at import time)
     try:
         r = Ranks(backend="gloo", force=True)
         assert r.world == 1 and r.active and r.dist is not None
@@ -414,6 +416,7 @@ def test_forced_one_rank_group_runs_the_real_reducer_path():
         r.close()
         assert not torch.distributed.is_initialized()
     finally:
+        torch.set_grad_enabled(grad_was)
         if torch.distributed.is_initialized():
             torch.distributed.destroy_process_group()
         for k, v in env.items():
