@@ -569,12 +569,24 @@ __device__ __forceinline__ void lds_dma16(unsigned voff, const char* sbase, unsi
 //         long as nothing leaves the fp32 range; a row whose sum ends outside [1e-30, 1e30] (logits beyond +-87 in
 //         natural units: not something LayerNorm-ed ViT tokens produce, but legal input) makes the WORKGROUP run the
 //         MODE 0 pass over its keys again.  Tested with spiked rows (tests/test_gpu_kernels.py).
-template <int NQ, bool SPLIT, int MODE>
+// SPLIT 0: one workgroup per (q-tile, image-head), whole key range.  SPLIT 1: the key-split last q-tile (partials merged by
+// sdpa_combine_kernel).  SPLIT 2 = STREAM-K (round 4): a persistent grid of G = 2 x #CU workgroups; the flattened
+// (unit = 256-row q-tile of an image-head, key tile) space is cut into G equal contiguous ranges, so every resident slot
+// carries the same number of tile steps -- at ViT-B / 1024^2 / B = 2 the plain grid is 408 workgroups on 512 slots (104 CUs
+// host one workgroup and idle early), here 512 workgroups x 52.6 steps.  A unit cut by a range boundary is finished by
+// the LAST of its pieces to arrive, inside the kernel: every other piece leaves (O unnormalised in bf16, m, l) in the
+// workspace and the last arriver merges them in PIECE order with its own piece rounded to bf16 the same way, so the
+// result does not depend on who arrives last (cdna_hip_programming.md: in-launch split-K reduction, counter form:
+// agent-scope release by the writers, agent-scope acquire by the reducer, counters zeroed by a memset node per call).
+constexpr int SK_REC_BYTES = 2 * SD_QB * HD * 2 + 2 * SD_QB * 8;  // one 256-row piece: bf16 O + float2 (m, l) per row
+template <int NQ, int SPLIT, int MODE>
 __global__ __launch_bounds__(SD_NT, NQ == 1 ? 3 : 2) void sdpa_fwd_pipe_kernel(
     const __bf16* __restrict__ q, const __bf16* __restrict__ k, const __bf16* __restrict__ vt, __bf16* __restrict__ o,
     float* __restrict__ lse, int B, int N, int Npad, int h, int qt_fixed, int nslices, float* __restrict__ part,
     int mix_mode, int mix_a, int mix_r) {
   extern __shared__ __attribute__((aligned(16))) char smem[];     // [3][K tile | V^T tile]
+  constexpr bool KSPLIT = SPLIT == 1, SK = SPLIT == 2;
+  static_assert(!SK || NQ == 2, "stream-K is built on the 256-row workgroup");
   constexpr int QROWS = SD_QB * NQ;                               // query rows of a workgroup
   constexpr int UPT = 2 * NQ;                                     // units per tile
   constexpr int SLOTB = 2 * GL_TILE;                              // bytes of a ring slot
@@ -586,9 +598,9 @@ __global__ __launch_bounds__(SD_NT, NQ == 1 ? 3 : 2) void sdpa_fwd_pipe_kernel(
   // (mode 1: head bh owns a_bh = mix_a + (bh < mix_r) of them, rows [0, 256 a_bh)) and by 128-row workgroups of the NQ = 1
   // instance (mode 2: the chunks after them); head-major numbering, closed form.
   int bh, row0;
-  if (SPLIT || mix_mode == 0) {
+  if (SPLIT != 0 || mix_mode == 0) {
     bh = bid % BH;
-    row0 = (SPLIT ? qt_fixed : bid / BH) * QROWS;
+    row0 = (KSPLIT ? qt_fixed : bid / BH) * QROWS;              // (stream-K: set per segment below)
   } else {
     const int cf = N / SD_QB;                                     // full 128-row chunks of a head
     const int per_hi = mix_mode == 1 ? mix_a + 1 : cf - 2 * (mix_a + 1);   // tiles of the heads < mix_r / of the others
@@ -598,26 +610,28 @@ __global__ __launch_bounds__(SD_NT, NQ == 1 ? 3 : 2) void sdpa_fwd_pipe_kernel(
     else { const int b2 = bid - mix_r * per_hi; bh = mix_r + b2 / per_lo; t = b2 % per_lo; }
     row0 = mix_mode == 1 ? t * (2 * SD_QB) : (mix_a + (bh < mix_r ? 1 : 0)) * (2 * SD_QB) + t * SD_QB;
   }
-  const int slice = SPLIT ? bid / BH : 0;
-  const int b = bh / h, head = bh % h;
+  const int slice = KSPLIT ? bid / BH : 0;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, half = lane >> 5;
   const int nkt_all = Npad / SD_KB;
-  const int per = SPLIT ? (nkt_all + nslices - 1) / nslices : nkt_all;
-  const int kt_off = slice * per;
-  const int nkt = min(nkt_all, kt_off + per) - kt_off;            // >= 1 by construction
+  const int per = KSPLIT ? (nkt_all + nslices - 1) / nslices : nkt_all;
+  int kt_off = slice * per;                                       // (stream-K: the segment's key range, set below)
+  int nkt = min(nkt_all, kt_off + per) - kt_off;                  // >= 1 by construction
   const bool has_ragged = (N % SD_KB) != 0;
 
   int query[NQ];
   bf16x8 fq[NQ][4];
+  auto load_q = [&]() {
 #pragma unroll
-  for (int qb = 0; qb < NQ; ++qb) {
-    query[qb] = row0 + (wave * NQ + qb) * 32 + li;
-    const int qc = min(query[qb], N - 1);
+    for (int qb = 0; qb < NQ; ++qb) {
+      query[qb] = row0 + (wave * NQ + qb) * 32 + li;
+      const int qc = min(query[qb], N - 1);
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) fq[qb][ks] = *reinterpret_cast<const bf16x8*>(q + qf_frag((size_t)bh, Npad, qc, ks, half));
-  }
+      for (int ks = 0; ks < 4; ++ks) fq[qb][ks] = *reinterpret_cast<const bf16x8*>(q + qf_frag((size_t)bh, Npad, qc, ks, half));
+    }
+  };
+  if (!SK) load_q();
 
   // loader: per tile each wave moves 2 one-KiB pieces of K and 2 of V^T (8 rows x 128 B each); the bank swizzle sits on
   // the source address.  Per-lane 32-bit offsets + a scalar tile base (advanced by one tile per stage() call).
@@ -631,8 +645,8 @@ __global__ __launch_bounds__(SD_NT, NQ == 1 ? 3 : 2) void sdpa_fwd_pipe_kernel(
     offV[0] = r * (Npad * 2) + ((lc ^ key) << 4);
     offV[1] = offV[0] + 32 * Npad * 2;
   }
-  const char* const k_first = reinterpret_cast<const char*>(k + ((size_t)bh * Npad + (size_t)kt_off * SD_KB) * HD);
-  const char* const v_first = reinterpret_cast<const char*>(vt + (size_t)bh * HD * Npad + (size_t)kt_off * SD_KB);
+  const char* k_first = reinterpret_cast<const char*>(k + ((size_t)bh * Npad + (size_t)kt_off * SD_KB) * HD);
+  const char* v_first = reinterpret_cast<const char*>(vt + (size_t)bh * HD * Npad + (size_t)kt_off * SD_KB);
   const unsigned smem_base = lds_addr(smem);
 
   // per-lane fragment addresses (loop invariant): slot, key half and d block are immediates of the reads
@@ -646,8 +660,11 @@ __global__ __launch_bounds__(SD_NT, NQ == 1 ? 3 : 2) void sdpa_fwd_pipe_kernel(
     for (int c = 0; c < 4; ++c) vptr[c] = smem + GL_TILE + li * 128 + ((((c << 1) | half) ^ ((li >> 1) & 7)) << 4);
   }
   // make hipcc wait for the Q fragments HERE (ordinary loads), not inside the loop
+  auto pin_q = [&]() {
 #pragma unroll
-  for (int qb = 0; qb < NQ; ++qb) asm volatile("; Q fragments landed" : "+v"(fq[qb][0]), "+v"(fq[qb][1]), "+v"(fq[qb][2]), "+v"(fq[qb][3]));
+    for (int qb = 0; qb < NQ; ++qb) asm volatile("; Q fragments landed" : "+v"(fq[qb][0]), "+v"(fq[qb][1]), "+v"(fq[qb][2]), "+v"(fq[qb][3]));
+  };
+  if (!SK) pin_q();
 
   auto ring_barrier = [&]() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -905,50 +922,209 @@ __global__ __launch_bounds__(SD_NT, NQ == 1 ? 3 : 2) void sdpa_fwd_pipe_kernel(
     }
   };
 
-  if (MODE == 1) {
-    run_pass(std::true_type{});
-    bool bad = false;
+  // the key range of the current (bh, row0, kt_off, nkt): reference-free pass, exact pass when a row sum left the range
+  auto run_unit = [&]() {
+    if (MODE == 1) {
+      run_pass(std::true_type{});
+      bool bad = false;
 #pragma unroll
-    for (int qb = 0; qb < NQ; ++qb) bad = bad || !(l_row[qb] > 1e-30f && l_row[qb] < 1e30f);
-    // workgroup vote through the (now idle) ring; no static __shared__ object (it would shift the dynamic base)
-    const int wave_bad = __any(bad) ? 1 : 0;              // (all lanes vote: not inside the lane-0 branch)
-    ring_barrier();
-    int* flags = reinterpret_cast<int*>(smem);
-    if (lane == 0) flags[wave] = wave_bad;
-    ring_barrier();
-    const bool redo = (flags[0] | flags[1] | flags[2] | flags[3]) != 0;
-    ring_barrier();
-    if (redo) run_pass(std::false_type{});
-  } else {
-    run_pass(std::false_type{});
-  }
-
-#pragma unroll
-  for (int qb = 0; qb < NQ; ++qb) {
-    const float l = l_row[qb];
-    if (SPLIT) {
-      float* rec = part + (((size_t)bh * nslices + slice) * QROWS + (wave * NQ + qb) * 32 + li) * SD_REC;
-#pragma unroll
-      for (int db = 0; db < 2; ++db)
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-          *reinterpret_cast<float4*>(rec + db * 32 + 8 * g + 4 * half) =
-              make_float4(oacc[qb][db][4 * g], oacc[qb][db][4 * g + 1], oacc[qb][db][4 * g + 2], oacc[qb][db][4 * g + 3]);
-      if (half == 0) { rec[64] = m_run[qb]; rec[65] = l; }
-      continue;
+      for (int qb = 0; qb < NQ; ++qb) bad = bad || !(l_row[qb] > 1e-30f && l_row[qb] < 1e30f);
+      // workgroup vote through the (now idle) ring; no static __shared__ object (it would shift the dynamic base)
+      const int wave_bad = __any(bad) ? 1 : 0;              // (all lanes vote: not inside the lane-0 branch)
+      ring_barrier();
+      int* flags = reinterpret_cast<int*>(smem);
+      if (lane == 0) flags[wave] = wave_bad;
+      ring_barrier();
+      const bool redo = (flags[0] | flags[1] | flags[2] | flags[3]) != 0;
+      ring_barrier();
+      if (redo) run_pass(std::false_type{});
+    } else {
+      run_pass(std::false_type{});
     }
-    const float inv = 1.0f / l;
-    if (query[qb] < N) {
-      __bf16* orow = o + ((size_t)b * N + query[qb]) * ((size_t)h * HD) + head * HD;
+  };
+  // o / lse of this workgroup's rows from (oacc, m_run, l_row)
+  auto store_rows = [&]() {
+    const int b = bh / h, head = bh % h;
 #pragma unroll
-      for (int db = 0; db < 2; ++db)
+    for (int qb = 0; qb < NQ; ++qb) {
+      const float l = l_row[qb];
+      const float inv = 1.0f / l;
+      if (query[qb] < N) {
+        __bf16* orow = o + ((size_t)b * N + query[qb]) * ((size_t)h * HD) + head * HD;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int d = db * 32 + 8 * g + 4 * half;
-          store4(orow + d, oacc[qb][db][4 * g] * inv, oacc[qb][db][4 * g + 1] * inv, oacc[qb][db][4 * g + 2] * inv,
-                 oacc[qb][db][4 * g + 3] * inv);
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int d = db * 32 + 8 * g + 4 * half;
+            store4(orow + d, oacc[qb][db][4 * g] * inv, oacc[qb][db][4 * g + 1] * inv, oacc[qb][db][4 * g + 2] * inv,
+                   oacc[qb][db][4 * g + 3] * inv);
+          }
+        if (half == 0) lse[(size_t)bh * N + query[qb]] = m_run[qb] * AS_LN2 + logf(l);
+      }
+    }
+  };
+
+  if constexpr (SK) {
+    // ---- stream-K: this workgroup's range of the flattened (unit, key tile) space ----
+    const int G = (int)gridDim.x;
+    const int nx = ((G & 7) == 0 && !(mix_mode & 1)) ? 8 : 1;      // block b runs on XCD b % 8 (observed): consecutive RANKS
+    const int rank = (bid % nx) * (G / nx) + bid / nx;            // share an XCD, i.e. the K / V^T of a few heads per L2
+    const int QT = (N + QROWS - 1) / QROWS;
+    const int units = BH * QT;
+    const long long T = (long long)units * nkt_all;
+    long long st = T * rank / G;
+    const long long st_end = T * (rank + 1) / G;
+    int* const arrive = reinterpret_cast<int*>(part);
+    int* const done = arrive + units;
+    char* const recs = reinterpret_cast<char*>(part) + (((size_t)units * 8 + 255) & ~(size_t)255);
+    bool first_seg = true;
+    while (st < st_end) {
+      const int u = (int)(st / nkt_all);
+      const int kt0 = (int)(st - (long long)u * nkt_all);
+      const int n_t = (int)((st_end - st) < (long long)(nkt_all - kt0) ? (st_end - st) : (long long)(nkt_all - kt0));
+      // the pieces of unit u: rank r covers steps [T r / G, T (r + 1) / G); rank_of(x) = ((x + 1) G - 1) / T
+      const long long ub = (long long)u * nkt_all;
+      const int r_first = (int)(((ub + 1) * G - 1) / T);
+      const int r_last = (int)(((ub + nkt_all) * G - 1) / T);
+      const int np = r_last - r_first + 1, pidx = rank - r_first;
+      if (!first_seg) ring_barrier();                             // every wave has left the previous segment's ring
+      first_seg = false;
+      bh = u / QT;
+      row0 = (u - bh * QT) * QROWS;
+      kt_off = kt0;
+      nkt = n_t;
+      k_first = reinterpret_cast<const char*>(k + ((size_t)bh * Npad + (size_t)kt_off * SD_KB) * HD);
+      v_first = reinterpret_cast<const char*>(vt + (size_t)bh * HD * Npad + (size_t)kt_off * SD_KB);
+      load_q();
+      pin_q();
+      run_unit();
+      st += n_t;
+      if (np == 1 || (mix_mode & 2)) {                            // (bit 1: timing experiment without the exchange -- wrong rows)
+        store_rows();
+        continue;
+      }
+      // ---- ticket: who finishes unit u ----
+      ring_barrier();
+      int* const box = reinterpret_cast<int*>(smem);
+      if (tid == 0) box[0] = __hip_atomic_fetch_add(&arrive[u], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      ring_barrier();
+      const int ticket = __builtin_amdgcn_readfirstlane(box[0]);
+      // piece p of unit u is rank r_first + p: its FIRST segment when p > 0 (slot 0), its last when p == 0 (slot 1)
+      auto rec_of = [&](int p) { return recs + ((size_t)(r_first + p) * 2 + (p > 0 ? 0 : 1)) * SK_REC_BYTES; };
+      if (ticket < np - 1) {
+        char* rec = rec_of(pidx);
+#pragma unroll
+        for (int qb = 0; qb < NQ; ++qb) {
+#pragma unroll
+          for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int gp = 0; gp < 2; ++gp) {
+              bf16x8 v;
+#pragma unroll
+              for (int t = 0; t < 8; ++t) v[t] = (__bf16)oacc[qb][db][8 * gp + t];
+              *reinterpret_cast<bf16x8*>(rec + ((((wave * NQ + qb) * 2 + db) * 2 + gp) * 64 + lane) * 16) = v;
+            }
+          if (half == 0)
+            *reinterpret_cast<float2*>(rec + QROWS * HD * 2 + ((wave * NQ + qb) * 32 + li) * 8) = make_float2(m_run[qb], l_row[qb]);
         }
-      if (half == 0) lse[(size_t)bh * N + query[qb]] = m_run[qb] * AS_LN2 + logf(l);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the compiler may drop the fence's own wait here)
+          __hip_atomic_fetch_add(&done[u], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        continue;
+      }
+      // ---- last arriver: the other pieces have all drawn their tickets, i.e. they are running: a bounded wait ----
+      if (tid == 0) {
+        while (__hip_atomic_load(&done[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < np - 1) __builtin_amdgcn_s_sleep(2);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      }
+      __syncthreads();
+      float mx[NQ];
+#pragma unroll
+      for (int qb = 0; qb < NQ; ++qb) mx[qb] = m_run[qb];
+      for (int p = 0; p < np; ++p) {
+        if (p == pidx) continue;
+        const char* rec = rec_of(p);
+#pragma unroll
+        for (int qb = 0; qb < NQ; ++qb)
+          mx[qb] = fmaxf(mx[qb], reinterpret_cast<const float2*>(rec + QROWS * HD * 2 + ((wave * NQ + qb) * 32 + li) * 8)->x);
+      }
+      f32x16 res[NQ][2];
+      float lsum[NQ];
+#pragma unroll
+      for (int qb = 0; qb < NQ; ++qb) {
+        lsum[qb] = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { res[qb][0][r] = 0.0f; res[qb][1][r] = 0.0f; }
+      }
+      for (int p = 0; p < np; ++p) {                              // PIECE order, whoever holds which piece
+        if (p == pidx) {
+#pragma unroll
+          for (int qb = 0; qb < NQ; ++qb) {
+            const float w = __builtin_amdgcn_exp2f(m_run[qb] - mx[qb]);
+            lsum[qb] += w * l_row[qb];
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) res[qb][db][r] += w * (float)(__bf16)oacc[qb][db][r];
+          }
+        } else {
+          const char* rec = rec_of(p);
+          bf16x8 v[NQ][2][2];
+          float2 ml[NQ];
+#pragma unroll
+          for (int qb = 0; qb < NQ; ++qb) {
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+              for (int gp = 0; gp < 2; ++gp)
+                v[qb][db][gp] = *reinterpret_cast<const bf16x8*>(rec + ((((wave * NQ + qb) * 2 + db) * 2 + gp) * 64 + lane) * 16);
+            ml[qb] = *reinterpret_cast<const float2*>(rec + QROWS * HD * 2 + ((wave * NQ + qb) * 32 + li) * 8);
+          }
+#pragma unroll
+          for (int qb = 0; qb < NQ; ++qb) {
+            const float w = __builtin_amdgcn_exp2f(ml[qb].x - mx[qb]);
+            lsum[qb] += w * ml[qb].y;
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) res[qb][db][r] += w * (float)v[qb][db][r >> 3][r & 7];
+          }
+        }
+      }
+#pragma unroll
+      for (int qb = 0; qb < NQ; ++qb) {
+        m_run[qb] = mx[qb];
+        l_row[qb] = lsum[qb];
+        oacc[qb][0] = res[qb][0];
+        oacc[qb][1] = res[qb][1];
+      }
+      store_rows();
+      if (tid == 0) {                                             // leave the counters as the next call needs them
+        __hip_atomic_store(&arrive[u], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&done[u], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    return;
+  } else {
+    run_unit();
+    if (KSPLIT) {
+#pragma unroll
+      for (int qb = 0; qb < NQ; ++qb) {
+        float* rec = part + (((size_t)bh * nslices + slice) * QROWS + (wave * NQ + qb) * 32 + li) * SD_REC;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<float4*>(rec + db * 32 + 8 * g + 4 * half) =
+                make_float4(oacc[qb][db][4 * g], oacc[qb][db][4 * g + 1], oacc[qb][db][4 * g + 2], oacc[qb][db][4 * g + 3]);
+        if (half == 0) { rec[64] = m_run[qb]; rec[65] = l_row[qb]; }
+      }
+    } else {
+      store_rows();
     }
   }
 }
@@ -1050,7 +1226,32 @@ int sdpa_split_slices(int B, int N, int h) {           // 0 = no split for this 
 //   NQ = 1:  0.60 / 1.28 / 1.64 us for w = 1 / 2 / 3        NQ = 2:  1.15 us for w = 1, 1.75 .. 2.0 us for w = 2
 // and the key-split tail of NQ = 1 costs ~20 us per 66 tiles.  At ViT-B / 1024^2 / B = 2 (24 x 4197 rows): NQ = 1 is 768
 // workgroups + tail = 130 us, NQ = 2 is 408 workgroups on 512 slots = 121 us; at N = 4096 (no tail) NQ = 1 wins, 105 us.
-int sdpa_pick(int B, int N, int h, bool tail_ok) {
+// ---- stream-K (impl 6, sdpa_fwd_pipe_kernel<2, 2, 1>) ----
+int sdpa_sk_grid_forced() {                                       // test hook: AS_SDPA_SK_GRID=<workgroups> (small shapes)
+  const char* e = getenv("AS_SDPA_SK_GRID");
+  const int g = e ? atoi(e) : 0;
+  return g > 0 && g <= 4096 ? g : 0;
+}
+int sdpa_sk_grid() {                                              // one workgroup per resident slot (2 per CU)
+  const int f = sdpa_sk_grid_forced();
+  return f > 0 ? f : 2 * (sdpa_slots() / 3);
+}
+size_t sdpa_sk_counter_bytes(int B, int N, int h) {
+  const size_t units = (size_t)B * h * as_ceil_div(N, 2 * SD_QB);
+  return (units * 8 + 255) & ~(size_t)255;                        // arrive[units], done[units]
+}
+size_t sdpa_sk_ws_bytes(int B, int N, int h) {
+  return sdpa_sk_counter_bytes(B, N, h) + (size_t)sdpa_sk_grid() * 2 * SK_REC_BYTES;
+}
+// worth it when the plain 256-row grid leaves a fractional round and every workgroup still gets a long range
+bool sdpa_sk_ok(int B, int N, int h) {
+  const long long units = (long long)B * h * as_ceil_div(N, 2 * SD_QB), tiles = as_round_up(N, 64) / SD_KB;
+  const int G = sdpa_sk_grid();
+  if (sdpa_sk_grid_forced() > 0) return units * tiles / G >= 2;   // (the kernel itself takes any number of pieces per unit)
+  return G > 0 && units * tiles / G >= 16 && units * 2 >= G;      // >= 16 tile steps per workgroup, <= 3 pieces per unit
+}
+
+int sdpa_pick(int B, int N, int h, bool tail_ok, bool sk_ok = false) {
   const int BH = B * h, cus = sdpa_slots() / 3;
   const double tiles = (double)as_ceil_div(N, SD_KB);
   auto layers = [&](int wgs, int per_cu, const double* cost, double partial_hi) {   // us per key tile
@@ -1069,6 +1270,17 @@ int sdpa_pick(int B, int N, int h, bool tail_ok) {
   const bool tail = tail_ok && sdpa_split_slices(B, N, h) > 0;
   const double t1 = tiles * layers((tail ? q1 - 1 : q1) * BH, 3, c1, 0.0) + (tail ? 0.30 * tiles : 0.0);
   const double t2 = tiles * layers(as_ceil_div(N, 2 * SD_QB) * BH, 2, c2, 1.75);
+  // Stream-K is NOT picked by default: measured on MI355X (profiles/r04_sdpa_streamk.md) the balanced grid does not beat
+  // the plain one -- 119.7 us with the exchange switched off against 117.3 us, 143.8 us with it -- because the chip delivers
+  // the same ~228 tile steps per us whether 152 or all 256 CUs carry two workgroups: the idle CUs of the plain grid are
+  // not lost time, the busy ones clock higher.  AS_SDPA_SK=1 puts it back into the model (it is kept tested through
+  // AS_SDPA_IMPL=6).
+  static const bool sk_model = getenv("AS_SDPA_SK") != nullptr;
+  if (sk_model && sk_ok && sdpa_sk_ok(B, N, h)) {
+    // every slot runs units * tiles / G steps at the two-per-CU rate, + the measured ~24 us of exchange and ~5 of memset
+    const double tsk = (double)as_ceil_div(N, 2 * SD_QB) * BH * tiles / sdpa_sk_grid() * c2[1] + 29.0;
+    if (tsk < t1 && tsk < t2) return 6;
+  }
   return t2 < t1 ? 4 : 3;
 }
 
@@ -1080,7 +1292,9 @@ int launch_sdpa_glds(const void* q, const void* k, const void* vt, void* o, floa
   int ns = sdpa_split_slices(B, N, h);
   if (ns > 0 && (ws == nullptr || ws_bytes < (size_t)BH * ns * SD_QB * SD_REC * sizeof(float))) ns = 0;
   const int forced = sdpa_impl_forced();
-  int impl = forced >= 0 ? forced : sdpa_pick(B, N, h, ns > 0);
+  const bool sk_ws = ws != nullptr && ws_bytes >= sdpa_sk_ws_bytes(B, N, h) && getenv("AS_SDPA_NO_SK") == nullptr;
+  int impl = forced >= 0 ? forced : sdpa_pick(B, N, h, ns > 0, sk_ws);
+  if (impl == 6 && !(sk_ws && sdpa_sk_ok(B, N, h))) impl = sdpa_pick(B, N, h, ns > 0);
   SdpaMix mix{};
   const int tail_rows = N % SD_QB;
   int ns_t = 0;
@@ -1161,6 +1375,23 @@ int launch_sdpa_glds(const void* q, const void* k, const void* vt, void* o, floa
     }
     return AS_OK;
   }
+  if (impl == 6) {                                           // stream-K: persistent, balanced, merged in the kernel
+    const size_t lds = (size_t)AS_SDPA_NBUF2 * 2 * GL_TILE;
+    static std::atomic<bool> attr_sk{false};
+    if (!attr_sk && lds > 64 * 1024 - 1) {
+      (void)hipFuncSetAttribute((const void*)sdpa_fwd_pipe_kernel<2, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr_sk = true;
+    }
+    const char* dbg_e = getenv("AS_SDPA_SK_DEBUG");               // experiments: 1 identity ranks, 2 no exchange, 4 no memset
+    const int dbg = dbg_e ? atoi(dbg_e) : 0;
+    if (!(dbg & 4) && hipMemsetAsync(ws, 0, sdpa_sk_counter_bytes(B, N, h), s) != hipSuccess) {
+      as_set_error("as_sdpa_fwd: clearing the stream-K counters failed");
+      return AS_E_LAUNCH;
+    }
+    AS_PIPE_LAUNCH_MIX(2, 2, 1, sdpa_sk_grid(), s, 0, 1, ws, dbg & 3, 0, 0);
+    AS_CHECK_LAUNCH("sdpa_fwd_pipe<stream-K>");
+    return AS_OK;
+  }
   if (impl == 2 || impl == 4) {                              // 64 queries per wave, 256 per workgroup, no split tail
     const int grid2 = as_ceil_div(N, 2 * SD_QB) * BH;
     const size_t lds1 = lds;
@@ -1227,7 +1458,9 @@ extern "C" size_t as_sdpa_fwd_workspace_bytes(int B, int N, int h, int dtype) {
   int ns = sdpa_split_slices(B, N, h);
   SdpaMix mix;
   if (sdpa_mix_plan(B, N, h, &mix) && N % SD_QB != 0) ns = ns > sdpa_tail_slices(B, N, h) ? ns : sdpa_tail_slices(B, N, h);
-  return (size_t)B * h * ns * SD_QB * SD_REC * sizeof(float);
+  size_t bytes = (size_t)B * h * ns * SD_QB * SD_REC * sizeof(float);
+  if (sdpa_sk_ok(B, N, h) && sdpa_sk_ws_bytes(B, N, h) > bytes) bytes = sdpa_sk_ws_bytes(B, N, h);
+  return bytes;
 }
 
 extern "C" int as_sdpa_fwd(const void* q, const void* k, const void* vt, void* o, float* lse, void* workspace,

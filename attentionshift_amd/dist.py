@@ -213,19 +213,28 @@ class GradAllReducer:
 
         return _NoSync()
 
-    def _pack(self, b, off, p):
-        dst = b["flat"][off:off + p.numel()]
+    def _pack_many(self, b, items):
+        """p.grad -> the bucket slices of `items`, ONE multi-tensor launch (a bucket holds ~40 tensors: per-tensor copies
+        from the hooks were ~3 ms of host time per step)."""
+        if not items:
+            return
+        dst = [b["flat"][off:off + p.numel()].view(p.shape) for p, off in items]
+        src = [p.grad for p, _ in items]
+        keep = [i for i, (d, g) in enumerate(zip(dst, src)) if d.data_ptr() != g.data_ptr()]   # already a bucket view
+        if len(keep) < len(dst):
+            dst, src = [dst[i] for i in keep], [src[i] for i in keep]
+            if not dst:
+                return
+        torch._foreach_copy_(dst, src)
         if self._prescale:
-            torch.mul(p.grad.reshape(-1), self._inv, out=dst) if dst.dtype == p.grad.dtype else \
-                dst.copy_(p.grad.reshape(-1) * self._inv)
-        else:
-            dst.copy_(p.grad.reshape(-1))
+            torch._foreach_mul_(dst, self._inv)
 
     def _launch_ready(self):
         while self._next < len(self.buckets):
             b = self.buckets[self._next]
             if len(b["seen"]) < len(b["items"]):
                 return
+            self._pack_many(b, b["items"])
             b["work"] = self.ranks.dist.all_reduce(b["flat"], op=self.ranks.dist.ReduceOp.SUM, async_op=True)
             self._next += 1
 
@@ -235,35 +244,40 @@ class GradAllReducer:
         b, off = self._where[id(p)]
         if b["work"] is not None:            # a second backward before finish(): this bucket is already in flight
             raise RuntimeError("GradAllReducer: backward ran again before finish(); use no_sync() for accumulation steps")
-        self._pack(b, off, p)
-        b["seen"].add(id(p))
+        b["seen"].add(id(p))                 # (the copy happens once per BUCKET, when its last gradient has arrived)
         if b["index"] == self._next:
             self._launch_ready()
 
     def finish(self):
         """Call after the (last) loss.backward() of a step: completes every bucket in order and leaves the rank-averaged
-        gradient in p.grad."""
+        gradient in p.grad.  fp32 wire: p.grad becomes a VIEW of the reduced bucket (no copy back; the bucket is scaled
+        by 1/world in one pass) -- `zero_grad(set_to_none=True)` drops the views, an in-place zero_grad clears the
+        bucket, both are fine.  16-bit wire: one multi-tensor conversion per bucket."""
         if not self.active:
             return
-        post = 1.0 if self._prescale else self._inv
         for b in self.buckets[self._next:]:   # buckets with a parameter that got no gradient: zeros for it, in order
+            have = [(p, off) for p, off in b["items"] if p.grad is not None]   # incl. grads accumulated under no_sync()
             for p, off in b["items"]:
-                if id(p) not in b["seen"]:
-                    if p.grad is None:
-                        b["flat"][off:off + p.numel()].zero_()
-                    else:                      # accumulated earlier under no_sync() but untouched by the last backward
-                        self._pack(b, off, p)
+                if p.grad is None:
+                    b["flat"][off:off + p.numel()].zero_()
+            self._pack_many(b, have)
             b["work"] = self.ranks.dist.all_reduce(b["flat"], op=self.ranks.dist.ReduceOp.SUM, async_op=True)
         for b in self.buckets:
             b["work"].wait()
-            for p, off in b["items"]:
-                avg = b["flat"][off:off + p.numel()].reshape(p.shape)
-                if p.grad is None:
-                    p.grad = (avg * post).to(p.dtype) if post != 1.0 else avg.to(p.dtype, copy=True)
-                elif post != 1.0:
-                    torch.mul(avg, post, out=p.grad) if avg.dtype == p.grad.dtype else p.grad.copy_(avg).mul_(post)
-                else:
-                    p.grad.copy_(avg)
+            views = [b["flat"][off:off + p.numel()].view(p.shape) for p, off in b["items"]]
+            if not self._prescale and all(p.dtype == self.comm_dtype for p, _ in b["items"]):
+                if self._inv != 1.0:
+                    b["flat"].mul_(self._inv)
+                for (p, _), v in zip(b["items"], views):
+                    p.grad = v
+            else:
+                post = 1.0 if self._prescale else self._inv
+                missing = [p for p, _ in b["items"] if p.grad is None]
+                for p in missing:
+                    p.grad = torch.empty_like(p)
+                torch._foreach_copy_([p.grad for p, _ in b["items"]], views)
+                if post != 1.0:
+                    torch._foreach_mul_([p.grad for p, _ in b["items"]], post)
             b["seen"], b["work"] = set(), None
         self._next = 0
 

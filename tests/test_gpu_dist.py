@@ -73,12 +73,13 @@ WORKER = textwrap.dedent("""
         red = GradAllReducer(params, r, bucket_mb=1.0, comm_dtype=getattr(torch, comm), buffers=list(bb.buffers()))
         got, logs = step(bb, r, red, 2)
         torch.cuda.synchronize()
-        assert set(got) == set(want)
+        # (the reducer leaves ZERO gradients on parameters this step did not reach -- every rank joins every bucket)
+        assert set(want) <= set(got) and all(float(got[n].abs().max()) == 0.0 for n in set(got) - set(want))
         err = max(float((got[n] - want[n]).abs().max() / (want[n].abs().max() + 1e-20)) for n in want)
         # with the FPN maps in the loss the stride-4 branch's BatchNorm runs as SyncBatchNorm2d: its statistics travel
         # through a (one-rank) RCCL all-reduce and its arithmetic differs from ATen's fused batch norm in rounding only
         got_f, _ = step(bb, r, red, 1, fpn=True)
-        assert set(got_f) == set(want_fpn)
+        assert set(want_fpn) <= set(got_f)
         err_f = max(float((got_f[n] - want_fpn[n]).abs().max() / (want_fpn[n].abs().max() + 1e-20)) for n in want_fpn)
         out[comm] = dict(buckets=len(red.buckets), broadcasts=red.broadcasts, err=err, tol=tol, err_fpn=err_f,
                          log_err=abs(logs["loss"] - logs0["loss"]) / (abs(logs0["loss"]) + 1e-12))
@@ -93,7 +94,7 @@ def test_one_rank_rccl_group_runs_the_bucketed_reducer_and_matches_the_plain_ste
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     cp = subprocess.run([sys.executable, "-c", WORKER], env=env, capture_output=True, text=True, timeout=420)
     assert cp.returncode == 0, cp.stderr[-3000:]
-    rec = json.loads(cp.stdout.strip().splitlines()[-1])
+    rec = json.loads([ln for ln in cp.stdout.splitlines() if ln.startswith("{")][-1])     # (RCCL prints a banner at exit)
     assert "nccl" in rec["backend"], rec
     for comm in ("float32", "bfloat16"):
         o = rec[comm]

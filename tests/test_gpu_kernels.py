@@ -271,7 +271,7 @@ def test_sdpa_bf16_deferred_max_and_spikes(ops, monkeypatch, tail, N):
     assert torch.isfinite(o.float()).all()
 
 
-@pytest.mark.parametrize("impl", ["0", "1", "2", "3", "4", "5"])
+@pytest.mark.parametrize("impl", ["0", "1", "2", "3", "4", "5", "6"])
 @pytest.mark.parametrize("tail,N", [("0", 1000), ("1", 1153), ("1", 100)])
 def test_sdpa_bf16_out_of_range_logits_take_the_exact_pass(ops, monkeypatch, impl, tail, N):
     """Rows the reference-free first pass (sdpa_fwd_pipe_kernel MODE 1: P = exp2 of the raw base-2 logit) cannot represent
@@ -280,6 +280,8 @@ def test_sdpa_bf16_out_of_range_logits_take_the_exact_pass(ops, monkeypatch, imp
     variant behind as_sdpa_fwd is held to the same fp32 oracle on the same bf16 operands, the key-split tail included."""
     monkeypatch.setenv("AS_SDPA_TAIL", tail)
     monkeypatch.setenv("AS_SDPA_IMPL", impl)
+    if impl == "6":                        # stream-K on a small shape: 5 workgroups cut the 8 units (2 heads x 4 q-tiles at
+        monkeypatch.setenv("AS_SDPA_SK_GRID", "5")   # N = 1000) into uneven pieces; the exact pass then runs per PIECE
     B, h = 1, 2
     g = torch.Generator().manual_seed(131)
     q, k, v = (torch.randn(B, h, N, 64, generator=g) for _ in range(3))
@@ -304,6 +306,56 @@ def test_sdpa_bf16_out_of_range_logits_take_the_exact_pass(ops, monkeypatch, imp
     mx, mean = rel_to_range(ref, o.float())
     assert mx < 2e-2 and mean < 3e-3, (mx, mean)
     assert_close(torch.logsumexp(s_, dim=-1).float(), lse, 1e-4, 2e-3, "lse")
+
+
+def _sdpa_case(ops, B, h, N, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    q, k, v = (torch.randn(B, h, N, 64, generator=g) * scale for _ in range(3))
+    qb, kb, vb = (q * ops.QSCALE).bfloat16(), k.bfloat16(), v.bfloat16()
+    Np_ = ops.npad(N)
+    qp = torch.zeros(B, h, Np_, 64, dtype=torch.bfloat16); kp = torch.zeros_like(qp)
+    vtp = torch.full((B, h, 64, Np_), float("nan"), dtype=torch.bfloat16)        # padded keys hold garbage on purpose
+    qp[:, :, :N], kp[:, :, :N], vtp[:, :, :, :N] = qb, kb, vb.transpose(-1, -2)
+    kp[:, :, N:] = float("nan")
+    s_ = (qb.float() @ kb.float().transpose(-1, -2)) * ops.LN2
+    ref = (s_.softmax(-1) @ vb.float()).transpose(1, 2).reshape(B, N, h * 64)
+    return ops.q_to_fragment_major(dev(qp)), dev(kp), dev(vtp), ref, torch.logsumexp(s_, dim=-1)
+
+
+@pytest.mark.parametrize("B,h,N,grid", [(1, 2, 1000, "5"), (1, 2, 1000, "24"), (2, 3, 1153, "7"), (1, 1, 2049, "16"),
+                                        (1, 3, 700, "3"), (2, 12, 4197, "")])
+def test_sdpa_stream_k_matches_oracle_and_the_plain_grid(ops, monkeypatch, B, h, N, grid):
+    """Stream-K forward (sdpa_fwd_pipe_kernel<2, 2, 1>, AS_SDPA_IMPL=6): the flattened (q-tile, key-tile) space cut into
+    equal ranges, units finished by their last-arriving piece.  Small shapes with forced grids give 1, 2, 3 and many pieces
+    per unit (grid 24 on 8 units: every unit in three or more pieces; grid 3 on 9 units: workgroups spanning whole units in
+    the middle of their range); the last case is BASELINE config 2 at the grid the library picks by itself.  Held to the fp32
+    oracle like every other variant, to the plain 256-row grid (impl 4) within the bf16 rounding of the exchanged
+    partials, bitwise reproducible call after call, and immune to what the previous call left in workspace and caches."""
+    if grid:
+        monkeypatch.setenv("AS_SDPA_SK_GRID", grid)
+    qf, kp, vtp, ref, lse_ref = _sdpa_case(ops, B, h, N, 77 + N)
+    monkeypatch.setenv("AS_SDPA_IMPL", "4")
+    o4, lse4 = ops.sdpa_fwd(qf, kp, vtp, N)
+    monkeypatch.setenv("AS_SDPA_IMPL", "6")
+    o6, lse6 = ops.sdpa_fwd(qf, kp, vtp, N)
+    assert torch.isfinite(o6.float()).all()
+    mx, mean = rel_to_range(ref, o6.float())
+    assert mx < 2e-2 and mean < 3e-3, (mx, mean)
+    assert_close(lse_ref, lse6, 1e-4, 1e-3, "lse (stream-K)")
+    rng = float(o4.float().abs().max())
+    assert float((o6.float() - o4.float()).abs().max()) <= 1.2e-2 * rng       # two bf16 roundings apart at most
+    assert float((lse6 - lse4).abs().max()) <= 2e-3
+    # the merge happened somewhere (otherwise this test is not testing stream-K) unless the cut falls on unit boundaries
+    again, lse_again = ops.sdpa_fwd(qf, kp, vtp, N)
+    assert torch.equal(again, o6) and torch.equal(lse_again, lse6)            # piece-ordered merge: bitwise reproducible
+    # new operands in the SAME buffers (same workspace block from the caching allocator, caches warm with the old partials)
+    qf2, kp2, vtp2, ref2, lse_ref2 = _sdpa_case(ops, B, h, N, 1077 + N, scale=1.5)
+    qf.copy_(qf2); kp.copy_(kp2); vtp.copy_(vtp2)
+    for _ in range(3):
+        o6b, lse6b = ops.sdpa_fwd(qf, kp, vtp, N)
+        mx, mean = rel_to_range(ref2, o6b.float())
+        assert mx < 2e-2 and mean < 3e-3, (mx, mean)
+        assert_close(lse_ref2, lse6b, 1e-4, 1e-3, "lse (stream-K, second operand set)")
 
 
 @pytest.mark.parametrize("B,H,W,C,k", [(2, 64, 64, 768, 2), (1, 12, 20, 192, 4), (2, 6, 10, 128, 2)])

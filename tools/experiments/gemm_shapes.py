@@ -10,7 +10,13 @@ SHAPES = [(7168, 2304, 768), (5376, 3072, 768), (3584, 2304, 768), (8394, 768, 1
 
 def main():
     dev = torch.device("cuda")
-    for (M, N, K) in SHAPES:
+    shapes = SHAPES
+    if sys.argv[1:2] == ["sweep"]:
+        # time vs M at fixed (N, K): a staircase in rounds of 256 one-per-CU tiles = tile quantisation is the cost;
+        # a straight line = the chip runs at a fixed total rate (power / clock cap) and idle CUs are not lost time
+        N, K = int(sys.argv[2]), int(sys.argv[3])
+        shapes = [(256 * m, N, K) for m in range(int(sys.argv[4]), int(sys.argv[5]) + 1)]
+    for (M, N, K) in shapes:
         x = (torch.rand(M, K, device=dev) * 2 - 1).bfloat16()
         w = (torch.rand(N, K, device=dev) * 2 - 1).bfloat16()
         b = torch.zeros(N, device=dev)

@@ -45,6 +45,8 @@ class Variant:
     def __init__(self, spec, ops):
         self.spec = spec
         impl, _, bld = spec.partition("@")
+        impl, *envs = impl.split(":")                  # "6:AS_SDPA_SK_DEBUG=1": extra environment for this variant's calls
+        self.env = dict(e.split("=", 1) for e in envs)
         self.impl = impl
         from attentionshift_amd import _lib
         path = os.path.join(OUT, f"libsdpa_{bld}.so") if bld else _lib.LIB_PATH
@@ -60,12 +62,18 @@ class Variant:
         self.o = torch.empty(B, N, h * 64, device="cuda", dtype=torch.bfloat16)
         self.lse = torch.empty(B, h, N, device="cuda", dtype=torch.float32)
         nws = self.lib.as_sdpa_fwd_workspace_bytes(B, N, h, 1)
+        nws = max(nws, 96 << 20)                        # room for every AS_SDPA_SK_GRID a variant may force
         self.ws = torch.empty(max(nws, 1), device="cuda", dtype=torch.uint8)
         st = torch.cuda.current_stream().cuda_stream
         args = (q.data_ptr(), k.data_ptr(), vt.data_ptr(), self.o.data_ptr(), self.lse.data_ptr(), self.ws.data_ptr(), nws, B, N, h, 1, st)
 
+        self.ws.zero_()
+
         def call():
             os.environ["AS_SDPA_IMPL"] = self.impl
+            for k_ in ("AS_SDPA_SK_DEBUG", "AS_SDPA_SK_GRID"):
+                os.environ.pop(k_, None)
+            os.environ.update(self.env)
             rc = self.lib.as_sdpa_fwd(*args)
             assert rc == 0, rc
         self.call = call
@@ -116,6 +124,19 @@ def main():
                 e1.record()
                 torch.cuda.synchronize()
                 times[v.spec].append(e0.elapsed_time(e1) / a.reps)
+        # stale-data check AFTER the timing loop (caches warm, workspace full of the previous inputs' partials): new operands
+        # written into the SAME tensors, one call per variant, against a fresh reference
+        g2 = torch.Generator().manual_seed(1)
+        x2 = torch.randn(B, N, D, generator=g2).cuda().bfloat16()
+        q2, k2, vt2 = ops.qkv_fwd(x2, w, bias, h)
+        q.copy_(q2); k.copy_(k2); vt.copy_(vt2)
+        ref_o, ref_lse = reference(ops, ops.q_from_fragment_major(q), k, vt, N)
+        for v in variants:
+            for _ in range(3):
+                v.call()
+            torch.cuda.synchronize()
+            err = (v.o.float() - ref_o).abs().max().item() / max(ref_o.abs().max().item(), 1e-30)
+            print(f"[{shp}] {v.spec:10s}: after new operands: max err / range {err:.3e}  lse err {(v.lse - ref_lse).abs().max().item():.3e}", flush=True)
         for v in variants:
             t = sorted(times[v.spec])
             med, mn = t[len(t) // 2], t[0]
