@@ -61,6 +61,8 @@ SIGNATURES = {
     "as_part_stats": (_c_int, [_c_void_p] * 3 + [_c_float] + [_c_void_p] * 4 + [_c_int] * 3 + [_c_void_p]),
     "as_filter_parts": (_c_int, [_c_void_p] * 2 + [_c_float] * 2 + [_c_void_p] + [_c_int] * 3 + [_c_void_p]),
     "as_draw_distinct": (_c_int, [_c_void_p] * 6 + [_c_int] * 3 + [_c_void_p]),
+    "as_mt_sample_ranks": (_c_int, [_c_void_p] * 4 + [_c_int] * 2 + [_c_void_p]),
+    "as_mt_perm_ranks": (_c_int, [_c_void_p] * 4 + [_c_int] * 2 + [_c_void_p]),
     "as_small_attn_fwd": (_c_int, [_c_void_p] * 3 + [_c_int] * 5 + [_c_void_p]),
     "as_small_attn_bwd_workspace_bytes": (_c_size_t, [_c_int] * 3),
     "as_small_attn_bwd": (_c_int, [_c_void_p] * 6 + [_c_size_t] + [_c_int] * 5 + [_c_void_p]),

@@ -784,7 +784,7 @@ __global__ __launch_bounds__(SD_NT, NQ == 1 ? 3 : 2) void sdpa_fwd_pipe_kernel(
       const bool ragged = has_ragged && ktg == nkt_all - 1;
       static_for<UPT>([&](auto i_c) {
         constexpr int I = decltype(i_c)::value;
-        constexpr int KB = I / NQ, QB = I % NQ;
+        constexpr int QB = I % NQ;
         constexpr int IN = (I + 1) % UPT, QBN = IN % NQ;                                        // next unit
         constexpr int IP = (I + UPT - 1) % UPT, KBP = IP / NQ, QBP = IP % NQ;                    // previous unit
         constexpr int P_SLOT = I >= 1 ? SLOT : (SLOT + NBUF - 1) % NBUF;

@@ -817,6 +817,30 @@ def mask_count(mask):
     return out
 
 
+def mt_sample_ranks(state, counts, k):
+    """Device draws of sample_point_grid in the reference's stream (as_mt_sample_ranks): state int32[626] on the device
+    (advanced in place), counts int32 [S] -> (ranks int32 [S,k], flag int32 [1])."""
+    lib = _lib.load()
+    _chk(state, counts, dtype=torch.int32)
+    S = counts.numel()
+    ranks = torch.zeros(S, k, device=counts.device, dtype=torch.int32)
+    flag = torch.empty(1, device=counts.device, dtype=torch.int32)
+    _lib.check(lib.as_mt_sample_ranks(_p(state), _p(counts), _p(ranks), _p(flag), S, int(k), _stream()), "as_mt_sample_ranks")
+    return ranks, flag
+
+
+def mt_perm_ranks(state, counts2, k):
+    """Device draws of torch.randperm(n)[:k] per object in the reference's stream (as_mt_perm_ranks): counts2 int32 [G,2]
+    -> (ranks int32 [G,k], flag int32 [1])."""
+    lib = _lib.load()
+    _chk(state, counts2, dtype=torch.int32)
+    G = counts2.shape[0]
+    ranks = torch.zeros(G, k, device=counts2.device, dtype=torch.int32)
+    flag = torch.empty(1, device=counts2.device, dtype=torch.int32)
+    _lib.check(lib.as_mt_perm_ranks(_p(state), _p(counts2), _p(ranks), _p(flag), G, int(k), _stream()), "as_mt_perm_ranks")
+    return ranks, flag
+
+
 def rank_select(mask, ranks):
     """mask uint8 [M,HW] (0/1), ranks int [M,K] -> int64 [M,K] flat index of the ranks[m,k]-th set byte of row m in
     raster order (= mask[m].nonzero()[rank]), -1 if out of range."""

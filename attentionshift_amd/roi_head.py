@@ -25,6 +25,8 @@ whose CAM box has the median area).
 import types
 
 import numpy as np
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -64,6 +66,10 @@ class _StageClock:
 
 
 CLOCK = _StageClock()
+
+
+class _HostDrawsNeeded(Exception):
+    """reference-RNG mode, device draws: an image needs one of the reference's host-side refill branches."""
 
 # Per-thread CPU generator for the sampling draws: None = torch's global generator (the reference's stream).  When the
 # images of a batch are processed concurrently (seed_pseudo_gt, rng_mode "fast") every image gets its own generator,
@@ -338,6 +344,36 @@ def sample_points_from_cams_nosync(cams_lr, map_idx, minmax, num_points, gen, th
     ranks = torch.minimum((u * n).to(torch.int32), (counts[:, None] - 1).clamp(min=0))
     pts = rank_select_xy(masks.flatten(1), ranks, W)                           # (x, y) of every drawn candidate
     return pts[:G], pts[G:2 * G], pts[2 * G:], (counts < num_points).any()
+
+
+def sample_points_from_cams_mt(cams_lr, map_idx, minmax, num_points, mt_state, thr_bg=0.1, thr_fg=0.2):
+    """sample_points_from_cams in the REFERENCE's generator stream without the count readback: the candidate counts stay
+    on the device and ops.mt_sample_ranks advances torch's own mt19937 engine (`mt_state`, attentionshift_amd/mt19937.py)
+    by exactly the words the reference's `torch.randint(n, (n_draw,))` calls consume, spec by spec, object by object.
+    Returns (pts_bg, pts_fg, pts_supp, flag); flag: a candidate set smaller than num_points (host path)."""
+    G = map_idx.shape[0]
+    masks, counts = ops.cam_sample_masks(cams_lr, map_idx, minmax, thr_bg, thr_fg, STRIDE)
+    W = masks.shape[-1]
+    ranks, flag = ops.mt_sample_ranks(mt_state, counts.to(torch.int32).contiguous(), num_points)
+    pts = rank_select_xy(masks.flatten(1), ranks, W)
+    return pts[:G], pts[G:2 * G], pts[2 * G:], flag[0] != 0
+
+
+def mask_points_mt(pend, num_gt, mt_state):
+    """mask_points_finish in the reference's generator stream without the count readback: ranks = torch.randperm(n)[:num_gt]
+    per object from the device copy of torch's engine (ops.mt_perm_ranks).  flag: an object with fewer than num_gt
+    candidates (the reference's fill-in / empty branches, stdroi:449-455: host path)."""
+    pos, neg = pend["pos"], pend["neg"]
+    G, H, W = pend["shape"]
+    counts2 = pend["counts"].to(torch.int32).contiguous()
+    ranks, flag = ops.mt_perm_ranks(mt_state, counts2, num_gt)
+    n_pos = counts2[:, :1]
+    is_pos = ranks < n_pos
+    zero = torch.zeros_like(ranks)
+    xy_pos = rank_select_xy(pos.flatten(1), torch.where(is_pos, ranks, zero), W)
+    xy_neg = rank_select_xy(neg.flatten(1), torch.where(is_pos, zero, ranks - n_pos), W)
+    coords = torch.where(is_pos[..., None], xy_pos, xy_neg).float()
+    return coords, is_pos, flag[0] != 0
 
 
 def mask_points_nosync(pend, num_gt, gen):
@@ -899,13 +935,17 @@ class AttnShiftRoIHead(nn.Module):
         return ops.rollout_rows(states, num_proposals, rows=sel.to(states[0].q.device).long())
 
     def refine_maps(self, attn_sel, feat_chw, rois, gt_points, refine_times, obj_tau, minmax=None, cam_src=None,
-                    draw_gen=None, flags_out=None, last_level_only=False):
+                    draw_gen=None, flags_out=None, last_level_only=False, mt_state=None):
         """B2 (stdroi:1000-1019).  attn_sel [G,H,W], feat [C,hp,wp]; minmax [G,2] = per-map (min,max) if the
         caller already has them (as_cam_boxes does).  cam_src = (cams_lr [M,hp,wp], map_idx [G] int32, minmax [M,2])
         replaces attn_sel: the seed sampling then reads the low-resolution CAMs and the upsampled maps are never
         materialised.  Returns map_fg, map_bg [R+1,G,H,W], points_fg, points_bg, fg_feat, bg_feat."""
         C, hp, wp = feat_chw.shape
-        if cam_src is not None and draw_gen is not None:          # fast-RNG mode: no readback, flag instead
+        if cam_src is not None and mt_state is not None:          # reference stream, drawn on the device: no readback
+            G = cam_src[1].shape[0]
+            pts_bg, pts_fg, pts_supp, short = sample_points_from_cams_mt(cam_src[0], cam_src[1], cam_src[2], 20, mt_state)
+            flags_out.append(short)
+        elif cam_src is not None and draw_gen is not None:        # fast-RNG mode: no readback, flag instead
             G = cam_src[1].shape[0]
             pts_bg, pts_fg, pts_supp, short = sample_points_from_cams_nosync(cam_src[0], cam_src[1], cam_src[2], 20, draw_gen)
             flags_out.append(short)
@@ -1168,11 +1208,21 @@ class AttnShiftRoIHead(nn.Module):
             main.wait_stream(st)                                            # results are consumed on the caller's stream
         return res
 
-    def seed_pseudo_gt(self, x, img_metas, proposal_list, gt_bboxes, gt_labels, gt_bboxes_ignore=None, gt_masks=None,
-                       vit_feat=None, img=None, point_init=None, point_cls=None, point_reg=None, imgs_whwh=None,
-                       attns=None, gt_points=None, gt_points_labels=None, roi_feature_map=None, return_mask=False,
-                       pos_mask_thr=0.6, neg_mask_thr=0.1, num_mask_point_gt=10, corr_size=21, point_adjuster=None,
-                       edges=None, obj_tau=0.85, pos_inds=None, matched_gt=None):
+    def seed_pseudo_gt(self, *args, **kw):
+        """stdroi:2209-2415 (signature: _seed_pseudo_gt).  In the reference-RNG mode the draws are first attempted on the
+        device from torch's own engine state (no host round trip, same stream); if an image takes one of the reference's
+        rare refill branches, the call is repeated on the host path -- the global generator has not been touched by the
+        first attempt, so the repetition draws exactly what the reference draws."""
+        try:
+            return self._seed_pseudo_gt(*args, **kw)
+        except _HostDrawsNeeded:
+            return self._seed_pseudo_gt(*args, _mt_ok=False, **kw)
+
+    def _seed_pseudo_gt(self, x, img_metas, proposal_list, gt_bboxes, gt_labels, gt_bboxes_ignore=None, gt_masks=None,
+                        vit_feat=None, img=None, point_init=None, point_cls=None, point_reg=None, imgs_whwh=None,
+                        attns=None, gt_points=None, gt_points_labels=None, roi_feature_map=None, return_mask=False,
+                        pos_mask_thr=0.6, neg_mask_thr=0.1, num_mask_point_gt=10, corr_size=21, point_adjuster=None,
+                        edges=None, obj_tau=0.85, pos_inds=None, matched_gt=None, _mt_ok=True):
         """stdroi:2209-2415.  Extra optional inputs `pos_inds` / `matched_gt` (per-image lists) bypass the
         Hungarian matching when the caller already has it (fixtures, benchmarks)."""
         num_imgs = point_reg.size(0)
@@ -1271,20 +1321,26 @@ class AttnShiftRoIHead(nn.Module):
                 self.capture.append(dict(image=i, seeds=seeds, fg_inter=fg_inter))
             return coord_point, labels_point, map_fg, map_bg, feats_fg, feats_bg, (fg_inter, seeds), pm
 
-        def phase_a_nosync(i):
-            """phase_a + phase_a_finish with every draw made on the device (fast RNG mode): nothing is read back.  The
-            last element is the list of device flags that ask for the synchronous path (rare refill branches)."""
+        def phase_a_nosync(i, mt_state=None):
+            """phase_a + phase_a_finish with every draw made on the device: nothing is read back.  Fast RNG mode: uniform
+            numbers from the device generator; reference mode (`mt_state`): torch's own engine advanced on the device, the
+            images strictly in order on one stream.  The last element is the list of device flags that ask for the
+            synchronous path (rare refill branches)."""
             flags = []
             ar = torch.arange(counts[i], device=boxes.device)
             map_idx = (cam_off[i] + gt_box_index[i] * counts[i] + ar).to(torch.int32)
             map_fg, map_bg, _pa, _pb, feats_fg, feats_bg = self.refine_maps(
                 None, feats[i], pseudo_boxes[i], gt_points[i], 2, obj_tau, cam_src=(cams_lr, map_idx, cam_minmax),
-                draw_gen=self._device_gen(boxes.device), flags_out=flags, last_level_only=True)
+                draw_gen=None if mt_state is not None else self._device_gen(boxes.device), flags_out=flags,
+                last_level_only=True, mt_state=mt_state)
             mp, mask_u8 = mask_points_and_pseudo_issue(map_fg[-1], map_bg[-1], pseudo_boxes[i], pos_mask_thr, neg_mask_thr,
                                                        corr_size, pos_mask_thr)
             fg_inter, _map_fg_patch, gs = self._semantic_pre(map_fg[-1], map_bg[-1], pos_mask_thr)
             pm = _to_host_issue(mask_u8, side_stream=True)
-            coord_point, labels_point, f1 = mask_points_nosync(mp, num_mask_point_gt, self._device_gen(boxes.device))
+            if mt_state is not None:
+                coord_point, labels_point, f1 = mask_points_mt(mp, num_mask_point_gt, mt_state)
+            else:
+                coord_point, labels_point, f1 = mask_points_nosync(mp, num_mask_point_gt, self._device_gen(boxes.device))
             seeds, f2 = grid_seed_nosync(gs[0], gs[1], 20)
             if self.capture is not None:
                 self.capture.append(dict(image=i, seeds=seeds, fg_inter=fg_inter))
@@ -1295,7 +1351,16 @@ class AttnShiftRoIHead(nn.Module):
                   and self.batch_mean_shift and torch.cuda.is_available() and not CLOCK.on and not self.visualize)
         multi = (self.rng_mode == "fast" and num_imgs > 1 and not self.parallel_images and self.image_streams
                  and torch.cuda.is_available() and not CLOCK.on)
-        if nosync:
+        # reference RNG mode with the draws on the device (csrc/mt19937.hip): the same queue-everything-first structure
+        mtdev = (_mt_ok and self.rng_mode == "reference" and self.device_draws and _gen() is None and self.image_streams
+                 and self.batch_mean_shift and boxes.is_cuda and not CLOCK.on and not self.visualize
+                 and os.environ.get("AS_REF_RNG_HOST") is None)
+        mt_state = mt_blob = mt_final = None
+        if mtdev:
+            from . import mt19937 as _MT
+            mt_blob = torch.get_rng_state()
+            mt_state = to_device(_MT.unpack_state(mt_blob).copy(), boxes.device, torch.int32)
+        if nosync or mtdev:
             # Fast RNG mode, device-side draws: the host queues the WHOLE chain of every image (refinement, candidate
             # masks, draws, seeds), the batched mean shift and the merge inputs without reading anything back, i.e. while
             # the device is still in the backbone; the first readback is the merge plan of stdroi:278-294, which also
@@ -1303,17 +1368,23 @@ class AttnShiftRoIHead(nn.Module):
             if len(self._streams) < num_imgs:
                 self._streams = [torch.cuda.Stream() for _ in range(num_imgs)]
             main = torch.cuda.current_stream()
-            self._device_gen(boxes.device, reseed=True)
 
             def on_stream(i, fn, *args):
                 with torch.cuda.stream(self._streams[i]):
                     return fn(i, *args)
 
-            for st in self._streams[:num_imgs]:
-                st.wait_stream(main)
-            ra = [on_stream(i, phase_a_nosync) for i in range(num_imgs)]
-            for st in self._streams[:num_imgs]:
-                main.wait_stream(st)
+            if mtdev:
+                # the engine state threads through the images IN ORDER (image i + 1's first draw follows image i's last):
+                # one stream, no host decision in between
+                ra = [phase_a_nosync(i, mt_state) for i in range(num_imgs)]
+                mt_final = _to_host_issue(mt_state)
+            else:
+                self._device_gen(boxes.device, reseed=True)
+                for st in self._streams[:num_imgs]:
+                    st.wait_stream(main)
+                ra = [on_stream(i, phase_a_nosync) for i in range(num_imgs)]
+                for st in self._streams[:num_imgs]:
+                    main.wait_stream(st)
             shifted = self.mean_shift_batch([r[6][1] for r in ra], feats, pseudo_boxes, self.mean_shift_times_local,
                                             feat_tok=feat_tok)
 
@@ -1328,6 +1399,8 @@ class AttnShiftRoIHead(nn.Module):
                 if sc is None:
                     if st["extra"][0]:
                         raise RuntimeError("seed_pseudo_gt: a CAM has no foreground component (constant attention map)")
+                    if mtdev:                                    # the WHOLE call again on the host path, in stream order
+                        raise _HostDrawsNeeded()
                     r = phase_a_finish(i, phase_a(i))            # a rare branch needs host logic: synchronous path
                     prot, sim = self.mean_shift_batch([r[6][1]], [feats[i]], [pseudo_boxes[i]],
                                                       self.mean_shift_times_local)[0]
@@ -1345,6 +1418,8 @@ class AttnShiftRoIHead(nn.Module):
             for st in self._streams[:num_imgs]:
                 main.wait_stream(st)
             ra = None
+            if mtdev:                                            # hand the advanced engine back to torch's global generator
+                torch.set_rng_state(_MT.pack_state(mt_blob, _to_host_finish(mt_final)))
         elif multi:
             # One HIP stream per image, one host thread.  Every image's device work is queued first and only then are
             # the counts read back: a host sync waits for ITS image's stream only, so image i+1's refinement runs on

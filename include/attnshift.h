@@ -287,6 +287,18 @@ int as_filter_parts(const float* sim /*[G,P,Np]*/, const float* fg_inter /*[G,Np
 int as_draw_distinct(const int32_t* counts /*[G,2]*/, const float* u /*[G,M]*/, int32_t* rank_pos /*[G,K]*/,
                      int32_t* rank_neg, uint8_t* is_pos, int32_t* flag, int G, int M, int K, as_stream_t stream);
 
+/* The reference-RNG mode's draws made on the device (csrc/mt19937.hip): `state` = torch's CPU mt19937 engine as int32[626]
+ * (624 state words, left, next: attentionshift_amd/mt19937.py), advanced in place exactly as the reference's host calls
+ * advance the global generator.  as_mt_sample_ranks: for S candidate sets with counts[s] members,
+ * ranks[s, 0:K] = (torch.randint(n, (len(range(0, n, n // K)),)) % n)[:K]  (sample_point_grid, stdroi:343-371).
+ * as_mt_perm_ranks: for G objects with n = counts2[g,0] + counts2[g,1] candidates, ranks[g, 0:K] = torch.randperm(n)[:K]
+ * (get_mask_points_single_instance, stdroi:447).  flag (int32, written) != 0: a set the host path must handle (fewer
+ * than K candidates -- the reference's refill / fill-in / empty branches -- or a range beyond the one-word draws). */
+int as_mt_sample_ranks(int32_t* state /*[626]*/, const int32_t* counts /*[S]*/, int32_t* ranks /*[S,K]*/, int32_t* flag,
+                       int S, int K, as_stream_t stream);
+int as_mt_perm_ranks(int32_t* state /*[626]*/, const int32_t* counts2 /*[G,2]*/, int32_t* ranks /*[G,K]*/, int32_t* flag,
+                     int G, int K, as_stream_t stream);
+
 /* Greedy grouping of merge_maps (stdroi:278-294) for G objects: keep [G,P] uint8, link [G,P,P] uint8 (cos >= thr)
  * -> groups [G,P] int32 bit sets over the prototype ids, in the reference's emission order (0 = unused), ngroups [G]. */
 int as_merge_plan(const uint8_t* keep, const uint8_t* link, int32_t* groups, int32_t* ngroups, int G, int P,

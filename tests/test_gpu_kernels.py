@@ -1414,3 +1414,34 @@ def test_mae_mask_head_forward_loss_and_gradients():
     for n, p in head.named_parameters():
         if p.grad is not None:
             assert_close(p.grad, got[n], 2e-3, 1e-6, f"grad {n}")
+
+
+def test_mt19937_device_draws_equal_torchs_cpu_generator(ops):
+    """as_mt_sample_ranks / as_mt_perm_ranks (csrc/mt19937.hip) against torch's own global CPU generator: the ranks the
+    reference's `torch.randint(n, (n_draw,))` / `torch.randperm(n)[:k]` calls give (stdroi:343-371, 447), call after call
+    on ONE engine state, across many refills (a 600 000-candidate permutation skips ~960 blocks), and the generator state
+    torch is left in afterwards -- bit for bit."""
+    from attentionshift_amd import mt19937 as MT
+    rng = np.random.default_rng(4)
+    torch.manual_seed(2024)
+    torch.rand(333)                                         # start somewhere inside a block
+    start = torch.get_rng_state()
+    state = torch.from_numpy(MT.unpack_state(start).copy()).cuda()
+    for rep in range(3):
+        S, K, G, KP = 7, 20, 4, 10
+        counts = rng.integers(20, 60000, S).astype(np.int32)
+        counts[rep] = 20 + rep                               # n // k == 1: the longest draw lists
+        counts2 = np.stack((rng.integers(0, 30000, G), rng.integers(5, 40000, G)), 1).astype(np.int32)
+        counts2[0] = (10, 0) if rep == 0 else (300000, 300000)
+        want_s = [(torch.randint(int(n), (len(range(0, int(n), int(n) // K)),)) % int(n))[:K].tolist() for n in counts]
+        want_p = [torch.randperm(int(a + b))[:KP].tolist() for a, b in counts2]
+        ranks, flag = ops.mt_sample_ranks(state, torch.from_numpy(counts).cuda(), K)
+        perm, flag2 = ops.mt_perm_ranks(state, torch.from_numpy(counts2).cuda(), KP)
+        assert int(flag) == 0 and int(flag2) == 0
+        assert ranks.cpu().tolist() == want_s, rep
+        assert perm.cpu().tolist() == want_p, rep
+    assert torch.equal(MT.pack_state(start, state.cpu().numpy()), torch.get_rng_state())
+    # sets the host must handle are flagged
+    _, f = ops.mt_sample_ranks(state, torch.tensor([500, 19, 40], dtype=torch.int32).cuda(), 20)
+    _, f2 = ops.mt_perm_ranks(state, torch.tensor([[4, 5], [100, 100]], dtype=torch.int32).cuda(), 10)
+    assert int(f) != 0 and int(f2) != 0

@@ -194,6 +194,65 @@ def test_seed_pseudo_gt_two_images_equals_per_image(golden, monkeypatch):
     assert two["pseudo_gt_masks"][1].shape == two["pseudo_gt_masks"][0].shape
 
 
+def test_reference_rng_device_draws_equal_host_draws(golden, monkeypatch):
+    """Reference-RNG mode: the draws made on the device from torch's own engine state (csrc/mt19937.hip, the default) and
+    the draws made on the host from the global generator (AS_REF_RNG_HOST=1: the three count readbacks per image) give the
+    same sampled points, mask points, centres and masks bit for bit, for two images in one call -- and leave torch's
+    global generator in the same state (the next torch.rand agrees)."""
+    import attentionshift_amd as A
+    g = golden("shift_tiny224")
+    inp = shift_case_inputs(g)
+    hp, wp, G, Lc = int(g["hp"]), int(g["wp"]), int(g["G"]), int(g["Lc"])
+    T, N, nimg = 10, 1 + hp * wp + 10, 2
+
+    def run(host):
+        if host:
+            monkeypatch.setenv("AS_REF_RNG_HOST", "1")
+        else:
+            monkeypatch.delenv("AS_REF_RNG_HOST", raising=False)
+        head = A.build_head(dict(type="AttnShiftRoIHead", num_semantic_points=int(g["num_semantic_points"]),
+                                 mean_shift_times_local=int(g["n_shift"]),
+                                 bbox_head=dict(type="MAEBoxHeadRec", seed_thr=float(g["cam_thr"]),
+                                                seed_multiple=float(g["area_ratio"]), cam_layer=Lc, num_classes=20)))
+        assert head.rng_mode == "reference"
+        rows = torch.zeros(nimg, Lc, T, N)
+        rows[:, :, :G, 1:-T] = inp["cams"].flatten(2)
+        monkeypatch.setattr(head, "rollout_cams", lambda attns, n, pos_inds=None: rows.cuda())
+        best = t(g["best_idx"]).cuda()
+        head.layer_selector = lambda boxes, labels, fmap: [best] * nimg
+        head.capture = []
+        torch.manual_seed(int(g["seed"]) + 1)
+        out = head.seed_pseudo_gt(None, [dict(img_shape=(hp * 16, wp * 16, 3))] * nimg, None, None, None,
+                                  vit_feat=inp["vit_feat"][None].repeat(nimg, 1, 1, 1).cuda(),
+                                  point_cls=torch.zeros(nimg, T, 20).cuda(), point_reg=torch.zeros(nimg, T, 2).cuda(),
+                                  attns=None, gt_points=[inp["points"].cuda()] * nimg,
+                                  gt_points_labels=[inp["labels"].cuda()] * nimg, return_mask=True,
+                                  pos_mask_thr=float(g["pos_thr"]), neg_mask_thr=float(g["neg_thr"]),
+                                  num_mask_point_gt=int(g["num_gt"]), corr_size=int(g["corr_size"]),
+                                  obj_tau=float(g["obj_tau"]),
+                                  pos_inds=[torch.arange(G).cuda()] * nimg, matched_gt=[torch.arange(G).cuda()] * nimg)
+        return out, head.capture, torch.rand(4)
+
+    host, cap_h, next_h = run(True)
+    dev, cap_d, next_d = run(False)
+    assert torch.equal(next_h, next_d)                                # the generator ends where the host path leaves it
+    pts_h = [c for c in cap_h if "points_fg" in c]
+    pts_d = [c for c in cap_d if "points_fg" in c]
+    assert len(pts_h) == len(pts_d) == nimg
+    for a, b in zip(pts_h, pts_d):
+        assert_equal(a["points_fg"], b["points_fg"], "sampled foreground seeds")
+        assert_equal(a["points_bg"], b["points_bg"], "sampled background seeds")
+    for i in range(nimg):
+        assert_equal(host["mask_points_coords"][i], dev["mask_points_coords"][i], "mask points")
+        assert_equal(host["mask_points_labels"][i], dev["mask_points_labels"][i], "mask point labels")
+        assert (host["pseudo_gt_masks"][i] == dev["pseudo_gt_masks"][i]).all()
+        assert host["num_parts"][i] == dev["num_parts"][i]
+        assert_equal(host["semantic_centers_org"][0][i], dev["semantic_centers_org"][0][i], "part centres")
+        assert_close(host["map_cos_fg"][i], dev["map_cos_fg"][i], 0, 0, "instance maps")
+    # image 0 against the reference's own fixture (single-image run, same seed: the first image's stream prefix)
+    assert_equal(t(g["mask_coords"]), dev["mask_points_coords"][0], "mask points vs the reference fixture")
+
+
 def test_seed_pseudo_gt_ragged_batch(golden, monkeypatch):
     """Ragged batch: image 0 carries all 3 objects of the fixture scene, image 1 only the first 2.  Image 0 of the batch
     must equal the single-image run bitwise (same RNG prefix); image 1 must have 2 objects everywhere and the boxes /
