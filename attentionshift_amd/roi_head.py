@@ -739,7 +739,9 @@ class AttnShiftRoIHead(nn.Module):
         self.batch_mean_shift = True              # one as_cosine_shift call for all images of a batch
         self.rollout_matched_only = True          # roll out only the matched point tokens' rows (the only ones consumed)
         self.image_streams = True                 # one HIP stream per image in the single-threaded fast-RNG path
-        self.device_draws = True                  # fast-RNG mode: draws on the device, no readback before the merge plan
+        self.device_draws = True                  # draws on the device, no readback before the merge plan: fast mode from a
+        #                                           device generator, reference mode from torch's own engine (csrc/mt19937.hip)
+        self.rng_stats = dict(device_calls=0, host_redos=0)   # reference mode: calls drawn on the device / repeated on the host
         self.part_slots = 8                       # merged-part slots per object carried by the one-readback merge stage
         self._dev_gens = {}
         self._pool, self._streams = None, []
@@ -1213,9 +1215,13 @@ class AttnShiftRoIHead(nn.Module):
         device from torch's own engine state (no host round trip, same stream); if an image takes one of the reference's
         rare refill branches, the call is repeated on the host path -- the global generator has not been touched by the
         first attempt, so the repetition draws exactly what the reference draws."""
+        ncap = len(self.capture) if self.capture is not None else 0
         try:
             return self._seed_pseudo_gt(*args, **kw)
         except _HostDrawsNeeded:
+            self.rng_stats["host_redos"] += 1
+            if self.capture is not None:
+                del self.capture[ncap:]                     # what the abandoned attempt recorded
             return self._seed_pseudo_gt(*args, _mt_ok=False, **kw)
 
     def _seed_pseudo_gt(self, x, img_metas, proposal_list, gt_bboxes, gt_labels, gt_bboxes_ignore=None, gt_masks=None,
@@ -1420,6 +1426,7 @@ class AttnShiftRoIHead(nn.Module):
             ra = None
             if mtdev:                                            # hand the advanced engine back to torch's global generator
                 torch.set_rng_state(_MT.pack_state(mt_blob, _to_host_finish(mt_final)))
+                self.rng_stats["device_calls"] += 1
         elif multi:
             # One HIP stream per image, one host thread.  Every image's device work is queued first and only then are
             # the counts read back: a host sync waits for ITS image's stream only, so image i+1's refinement runs on

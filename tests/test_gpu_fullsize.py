@@ -141,6 +141,8 @@ def test_seed_pseudo_gt_chain_full_size_reference_rng(golden, cfg2, monkeypatch)
     head = _build_head(g, "reference")
     head.capture = []
     out = _run_head(head, g, inp, monkeypatch)
+    # the draws were made ON THE DEVICE from torch's engine state (csrc/mt19937.hip), not on the host path
+    assert head.rng_stats == dict(device_calls=1, host_redos=0), head.rng_stats
     assert_equal(t(g["rois"]), out["pseudo_gt_bboxes"][0], "pseudo boxes (B1)")
     cap = {k: v for d in head.capture for k, v in d.items()}
     assert_equal(t(g["points_fg"]), cap["points_fg"], "sampled fg points (B2)")
@@ -227,3 +229,39 @@ def test_seed_pseudo_gt_chain_full_size_fast_rng(golden, cfg2, monkeypatch):
         assert_equal(res["corres_gt"], out["corres_gts"][i], "corres_gts")
     # two identical images in one call give identical deterministic stages
     assert_equal(out["pseudo_gt_bboxes"][0], out["pseudo_gt_bboxes"][1], "image 0 == image 1 boxes")
+
+
+def test_reference_rng_device_draws_equal_host_draws_full_size(golden, cfg2, monkeypatch):
+    """Reference-RNG mode at config-2 size, two images in one call: the draws made on the device from torch's own engine
+    state (the default) and the draws made on the host from the global generator (AS_REF_RNG_HOST=1: three count readbacks
+    per image) give the same sampled seeds, mask points, centres and masks bit for bit -- and leave torch's global
+    generator in the same state (the next torch.rand agrees)."""
+    g, inp = cfg2
+
+    def run(host):
+        if host:
+            monkeypatch.setenv("AS_REF_RNG_HOST", "1")
+        else:
+            monkeypatch.delenv("AS_REF_RNG_HOST", raising=False)
+        head = _build_head(g, "reference")
+        head.capture = []
+        out = _run_head(head, g, inp, monkeypatch, images=2)
+        return out, head.capture, torch.rand(4), head.rng_stats
+
+    host, cap_h, next_h, st_h = run(True)
+    dev, cap_d, next_d, st_d = run(False)
+    assert st_h == dict(device_calls=0, host_redos=0) and st_d == dict(device_calls=1, host_redos=0), (st_h, st_d)
+    assert torch.equal(next_h, next_d)                                # the generator ends where the host path leaves it
+    pts_h = [c for c in cap_h if "points_fg" in c]
+    pts_d = [c for c in cap_d if "points_fg" in c]
+    assert len(pts_h) == len(pts_d) == 2
+    for a, b in zip(pts_h, pts_d):
+        assert_equal(a["points_fg"], b["points_fg"], "sampled foreground seeds")
+        assert_equal(a["points_bg"], b["points_bg"], "sampled background seeds")
+    for i in range(2):
+        assert_equal(host["mask_points_coords"][i], dev["mask_points_coords"][i], "mask points")
+        assert_equal(host["mask_points_labels"][i], dev["mask_points_labels"][i], "mask point labels")
+        assert (host["pseudo_gt_masks"][i] == dev["pseudo_gt_masks"][i]).all()
+        assert host["num_parts"][i] == dev["num_parts"][i]
+        assert_equal(host["semantic_centers_org"][0][i], dev["semantic_centers_org"][0][i], "part centres")
+    assert_equal(t(g["mask_coords"]), dev["mask_points_coords"][0], "image 0's mask points vs the reference fixture")
