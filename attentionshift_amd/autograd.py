@@ -77,6 +77,22 @@ def linear(x, weight, bias=None):
     return LinearFn.apply(x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16), weight, bias)
 
 
+def linear_shapes_ok(x, weight):
+    """The HIP linear takes these operands (device tensors, non-empty, feature sizes in rows of 32) -- for callers that
+    have already decided to compute in bf16 (the backbones' compute_dtype)."""
+    return not (_LIBRARY_LINEAR or not x.is_cuda or x.numel() == 0 or weight.shape[0] % 32 or weight.shape[1] % 32)
+
+
+def linear_in(x, weight, bias, compute_dtype):
+    """nn.Linear of a trainable path whose compute dtype is `compute_dtype`: the HIP forward / backward kernels (LinearFn:
+    dW as a split-K product, db as fixed-order column sums, fp32 master weights cast inside) when the dtype is bf16 and the
+    sizes fit, the library GEMM otherwise."""
+    if compute_dtype == torch.bfloat16 and linear_shapes_ok(x, weight):
+        return linear(x, weight, bias)
+    return torch.nn.functional.linear(x.to(compute_dtype), weight.to(compute_dtype),
+                                      None if bias is None else bias.to(compute_dtype))
+
+
 def linear_applies(x, weight):
     """Whether `linear` can stand in for F.linear here: device tensors, a bf16 autocast region (or bf16 operands
     already) and sizes the kernels take (rows of 32)."""

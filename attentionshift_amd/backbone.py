@@ -239,14 +239,16 @@ class VisionTransformerDet(nn.Module):
         return y.reshape(B, h, w, 2, 2, cout).permute(0, 1, 3, 2, 4, 5).reshape(B, 2 * h, 2 * w, cout)
 
     def _deconv2x2_train(self, x_nhwc, conv):
-        """_deconv2x2 under autograd: the same token GEMM through F.linear (library GEMM, differentiable) instead of
-        MIOpen's fp32 transposed convolution (whose backward dominated the training step: 17 ms of 55)."""
+        """_deconv2x2 under autograd: the same token GEMM through autograd.LinearFn (HIP GEMM forward, split-K dW backward;
+        the library GEMM when the sizes do not fit) instead of MIOpen's fp32 transposed convolution (whose backward
+        dominated the training step: 17 ms of 55)."""
         B, h, w, cin = x_nhwc.shape
         cout = conv.weight.shape[1]
         cd = self.compute_dtype
-        wmat = conv.weight.permute(2, 3, 1, 0).reshape(4 * cout, cin).to(cd)
-        bias = None if conv.bias is None else conv.bias.repeat(4).to(cd)
-        y = F.linear(x_nhwc.reshape(B * h * w, cin), wmat, bias)
+        from .autograd import linear_in
+        wmat = conv.weight.permute(2, 3, 1, 0).reshape(4 * cout, cin)
+        bias = None if conv.bias is None else conv.bias.repeat(4)
+        y = linear_in(x_nhwc.reshape(B * h * w, cin), wmat, bias, cd)         # HIP GEMM fwd / bwd (autograd.LinearFn)
         return y.reshape(B, h, w, 2, 2, cout).permute(0, 1, 3, 2, 4, 5).reshape(B, 2 * h, 2 * w, cout)
 
     def _fpn_train(self, i, feat_nchw, tok):
@@ -370,8 +372,9 @@ class VisionTransformerDet(nn.Module):
         hp, wp = w // ps, h // ps
         cd = self.compute_dtype
         patches = img.reshape(B, C, hp, ps, wp, ps).permute(0, 2, 4, 1, 3, 5).reshape(B, hp * wp, C * ps * ps)
-        x = F.linear(patches.to(cd), self.patch_embed.proj.weight.reshape(self.embed_dim, -1).to(cd),
-                     self.patch_embed.proj.bias.to(cd)).float()
+        from .autograd import linear_in
+        x = linear_in(patches.to(cd), self.patch_embed.proj.weight.reshape(self.embed_dim, -1), self.patch_embed.proj.bias,
+                      cd).float()
         x = torch.cat((self.cls_token.expand(B, -1, -1), x), dim=1)
         x = x + self.interpolate_pos_encoding(x.shape[1] - 1, w, h)
         pt = (self.point_token + self.point_pos_embed).expand(B, -1, -1)

@@ -106,20 +106,22 @@ class SwinTransformerBlock(nn.Module):
 
     def _forward_train(self, x, hw=None):
         """Autograd path (train() + grad enabled): the window attention core runs on the HIP forward / backward kernels
-        (WindowAttnFn); LayerNorm, the Linear layers and GELU are torch ops (library GEMMs)."""
+        (WindowAttnFn), the Linear layers on the HIP GEMMs forward and backward (autograd.LinearFn, bf16 compute dtype;
+        library GEMMs otherwise); LayerNorm and GELU are torch ops."""
         B, L, C = x.shape
         H, W = hw if hw is not None else (int(math.sqrt(L)),) * 2
         cd = self.compute_dtype
+        from .autograd import linear_in
         y = F.layer_norm(x, (C,), self.norm1.weight, self.norm1.bias, self.norm1.eps).to(cd)
-        qkv = F.linear(y, self.attn.qkv.weight.to(cd)).reshape(B, H, W, 3 * C)
+        qkv = linear_in(y, self.attn.qkv.weight, None, cd).reshape(B, H, W, 3 * C)
         bq = None if self.attn.qkv.bias is None else self.attn.qkv.bias.float()
         o = WindowAttnFn.apply(qkv, bq, self.attn.relative_position_bias_table.float(), self.num_heads, self.window_size,
                                self.shift_size)
-        y = F.linear(o.reshape(B, L, C), self.attn.proj.weight.to(cd), self.attn.proj.bias.to(cd))
+        y = linear_in(o.reshape(B, L, C), self.attn.proj.weight, self.attn.proj.bias, cd)
         x = x + self._drop_path(y.float())
         z = F.layer_norm(x, (C,), self.norm2.weight, self.norm2.bias, self.norm2.eps).to(cd)
-        z = F.linear(F.gelu(F.linear(z, self.mlp.fc1.weight.to(cd), self.mlp.fc1.bias.to(cd))),
-                     self.mlp.fc2.weight.to(cd), self.mlp.fc2.bias.to(cd))
+        z = linear_in(F.gelu(linear_in(z, self.mlp.fc1.weight, self.mlp.fc1.bias, cd)), self.mlp.fc2.weight,
+                      self.mlp.fc2.bias, cd)
         return x + self._drop_path(z.float()), None
 
     def _w(self, prm, dtype=None):

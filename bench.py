@@ -541,6 +541,22 @@ def main():
             "traffic": _static_traffic(("r04_shift_traffic.json", "r03_shift_traffic.json"), "per_call_bytes") if headline and imgs_per_call == 2 else None,
             "calls_timed": n_cs, "images_per_call": imgs_per_call, "ms_per_call": round(ms_cs, 4),
             "algorithmic_bytes_per_call": bytes_cs}
+        ra = rec["roofline_affinity"]
+        if ra["traffic"] is not None:
+            # the same call priced by the bytes the counters saw (the kernels skip out-of-box patches, which the SURVEY 8d
+            # formula counts): the honest HBM fraction, next to the algorithmic one
+            cb = ra["traffic"]["bytes"]
+            ra["frac_counter_bytes"] = round(cb / (ms_cs * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4)
+            ra["counter_over_algorithmic"] = round(cb / bytes_cs, 3)
+        try:      # the dependent-chain floor of 16 launches of this grid size (tools/experiments/chain_floor.hip, this round)
+            with open(os.path.join(ROOT, "profiles", "r04_chain_floor.json")) as f:
+                cf = json.load(f)
+            ra["dependent_chain_floor"] = {
+                "us_16_launches_3_hops": cf["us_per_chain_by_hops"]["3"], "us_16_empty_launches": cf["us_per_chain_by_hops"]["0"],
+                "us_per_dependent_hop": cf["us_per_dependent_hop"], "source": "profiles/r04_chain_floor.json (micro-benchmark: 16 "
+                "dependent launches of 126 workgroups, each thread walking 3 dependent L2-resident loads)"}
+        except (OSError, KeyError, ValueError):
+            pass
         # the same step with the trainable MIL head choosing the roll-out depth from RoI-aligned features (stdroi:2308-2312)
         if os.environ.get("AS_BENCH_MIL", "1") == "1":
             del step
