@@ -1342,7 +1342,7 @@ int launch_sdpa_glds(const void* q, const void* k, const void* vt, void* o, floa
   if (mixed) {
     // three concurrent launches: 256-row workgroups on the caller's stream, 128-row workgroups and the key-split ragged
     // rows on two helper streams (fork / join with events), so the dispatcher can place one of each kind on every CU
-    static bool attr_mix = false;
+    static std::atomic<bool> attr_mix{false};
     const size_t lds2 = (size_t)AS_SDPA_NBUF2 * 2 * GL_TILE;
     if (!attr_mix && lds2 > 64 * 1024 - 1) {
       (void)hipFuncSetAttribute((const void*)sdpa_fwd_pipe_kernel<2, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);

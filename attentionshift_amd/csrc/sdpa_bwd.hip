@@ -947,7 +947,7 @@ int launch_bwd(const void* q, const void* k, const void* vt, const void* o, cons
   if constexpr (sizeof(T) == 2) {
     if (!old_dkv) {
       const size_t lds_dma = (size_t)AS_BWD_NST * DK_STAGE;
-      static bool attr2 = false;
+      static std::atomic<bool> attr2{false};
       if (!attr2) {
         (void)hipFuncSetAttribute((const void*)sdpa_bwd_dkv_dma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dma);
         attr2 = true;
@@ -964,7 +964,7 @@ int launch_bwd(const void* q, const void* k, const void* vt, const void* o, cons
   if constexpr (sizeof(T) == 2) {
     if (!old_dkv) {
       const size_t lds_dma = 2 * (size_t)DQ_STAGE;
-      static bool attr3 = false;
+      static std::atomic<bool> attr3{false};
       if (!attr3) {
         (void)hipFuncSetAttribute((const void*)sdpa_bwd_dq_dma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dma);
         attr3 = true;

@@ -22,5 +22,10 @@ PMC_TRAFFIC=1 PMC_TAG=${R}_gemm_fc2 PMC_FILTER=gemm_glds PMC_CMD="python $GRAFT_
 PROF_LINES=8 tools/prof_cmd.sh ${R}_train_step_kernel_stats python $GRAFT_REPO_ROOT/tools/experiments/train_steps.py 6 > /dev/null 2>&1
 timeout 300 python tools/experiments/train_phases.py 8 2>&1 | tail -9 > gpurun_out/${R}_train_phases.txt
 timeout 300 python tools/experiments/train_syncs.py 2>&1 | tail -8 > gpurun_out/${R}_train_syncs.txt
+# round 4: SDPA counters incl. HBM traffic of the shipped kernel, the dependent-chain floor, the power / clock probe
+PMC_TRAFFIC=1 PMC_TAG=${R}_sdpa bash tools/pmc_sdpa_impl.sh auto > gpurun_out/${R}_sdpa_pmc.log 2>&1
+cp gpurun_out/pmc_sdpa_${R}_sdpa.md gpurun_out/${R}_sdpa_pmc.md 2>/dev/null
+( hipcc --offload-arch=gfx950 -O3 -o /tmp/chain_floor tools/experiments/chain_floor.hip > /dev/null 2>&1 && /tmp/chain_floor ) > gpurun_out/${R}_chain_floor.json 2>&1
+timeout 120 python tools/experiments/power_probe.py 2>&1 | grep kernel > gpurun_out/${R}_power_probe.jsonl
 ls gpurun_out | grep ${R}_
 cat gpurun_out/${R}_bench_wall.txt
