@@ -553,8 +553,10 @@ def main():
                 cf = json.load(f)
             ra["dependent_chain_floor"] = {
                 "us_16_launches_3_hops": cf["us_per_chain_by_hops"]["3"], "us_16_empty_launches": cf["us_per_chain_by_hops"]["0"],
-                "us_per_dependent_hop": cf["us_per_dependent_hop"], "source": "profiles/r04_chain_floor.json (micro-benchmark: 16 "
-                "dependent launches of 126 workgroups, each thread walking 3 dependent L2-resident loads)"}
+                "us_per_dependent_hop": cf["us_per_dependent_hop"], "source": "profiles/r04_chain_floor.json (micro-benchmark, chain queued behind a blocker so "
+                "the host's launch rate does not enter: 16 dependent launches of 126 workgroups, each thread walking 3 dependent "
+                "cache-resident loads) -- the launch boundaries explain ~1/6 of the call; the rest is the latency chains INSIDE "
+                "the 16 kernels (operands -> MFMA -> reductions, ~8-12 us each on a quarter-full chip)"}
         except (OSError, KeyError, ValueError):
             pass
         # the same step with the trainable MIL head choosing the roll-out depth from RoI-aligned features (stdroi:2308-2312)

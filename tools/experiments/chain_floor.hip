@@ -6,7 +6,8 @@
 //   hipcc --offload-arch=gfx950 -O3 -o /tmp/chain_floor tools/experiments/chain_floor.hip && /tmp/chain_floor
 //
 // Prints one JSON line: microseconds per chain of 16 launches for H = 0 .. 4 hops, grid = 126 workgroups of 256 threads
-// (21 tiles x 6 objects, config 2), median of 200 chains.
+// (21 tiles x 6 objects, config 2), median of 200 chains; every chain is queued behind a ~300 us blocker kernel so that
+// the host's launch rate does not enter.
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdio>
@@ -22,7 +23,15 @@ __global__ void hop_kernel(const int* __restrict__ idx, const float* __restrict_
     i = idx[i];                                          // dependent: the address comes from the previous load
     v += (float)(i & 1);
   }
-  out[t % n] = v * 0.0f;                                 // (keeps the values bounded; still a true dependence)
+  out[t % n] = v;                                        // 0 .. H: the next launch's first index moves by a few slots
+}
+
+// keeps the stream busy while the host queues a whole chain behind it, so the chain then runs at the DEVICE's pace (an
+// eager host loop tops out at ~2.8 us per launch, which would hide the device-side boundary)
+__global__ void blocker_kernel(long long cycles, int* sink) {
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < cycles) {}
+  if (sink != nullptr && threadIdx.x == 12345) sink[0] = 1;
 }
 
 template <int H> float chain_us(int launches, int grid, int* idx, float* a, float* b, int n, hipStream_t s) {
@@ -31,6 +40,7 @@ template <int H> float chain_us(int launches, int grid, int* idx, float* a, floa
   hipEventCreate(&e1);
   std::vector<float> t;
   for (int rep = 0; rep < 220; ++rep) {
+    hipLaunchKernelGGL(blocker_kernel, dim3(1), dim3(64), 0, s, (long long)30000, (int*)nullptr);   // ~300 us at 100 MHz
     hipEventRecord(e0, s);
     for (int l = 0; l < launches; ++l) hipLaunchKernelGGL(hop_kernel<H>, dim3(grid), dim3(256), 0, s, idx, (l & 1) ? b : a, (l & 1) ? a : b, n);
     hipEventRecord(e1, s);
