@@ -30,7 +30,7 @@ def smi():
 
 
 def main():
-    names = sys.argv[1:] or ["idle", "sdpa", "sdpa_zeros", "gemm"]
+    names = sys.argv[1:] or ["idle", "sdpa", "sdpa_zeros", "sdpa_bwd", "sdpa_bwd_zeros", "fc2", "gemm"]
     B, h, N, D = 2, 12, 4197, 768
     g = torch.Generator().manual_seed(0)
     x = torch.randn(B, N, D, generator=g).cuda().bfloat16()
@@ -41,7 +41,16 @@ def main():
     a = (torch.rand(8192, 4096, device="cuda") * 2 - 1).bfloat16()
     wb = (torch.rand(4096, 4096, device="cuda") * 2 - 1).bfloat16()
     bz = torch.zeros(4096, device="cuda")
+    o, lse = ops.sdpa_fwd(q, k, vt, N)
+    d_o = torch.randn(B, N, D, generator=g).cuda().bfloat16()
+    oz, lz, dz = torch.zeros_like(o), torch.zeros_like(lse), torch.zeros_like(d_o)
+    xf = torch.randn(8394, 3072, generator=g).cuda().bfloat16()
+    w2 = (torch.randn(768, 3072, generator=g) * 0.03).cuda().bfloat16()
+    b2 = torch.zeros(768, device="cuda")
     work = {"sdpa": lambda: ops.sdpa_fwd(q, k, vt, N), "sdpa_zeros": lambda: ops.sdpa_fwd(qz, kz, vz, N),
+            "sdpa_bwd": lambda: ops.sdpa_bwd(q, k, vt, o, d_o, lse, N),
+            "sdpa_bwd_zeros": lambda: ops.sdpa_bwd(qz, kz, vz, oz, dz, lz, N),
+            "fc2": lambda: ops.linear(xf, w2, b2),
             "gemm": lambda: ops.linear(a, wb, bz), "idle": None}
     for name in names:
         fn = work[name]
