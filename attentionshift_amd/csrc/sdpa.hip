@@ -275,9 +275,14 @@ __device__ __forceinline__ void lds_wait8(u32x2 (&v)[8]) {
 #ifndef AS_SDPA_SGB
 #define AS_SDPA_SGB 1             // sched_group_barrier interleave of sdpa_fwd_pipe_kernel's reference-free step
 #endif
+#ifndef AS_SDPA_NO_DEAD_SKIP
+#define AS_SDPA_NO_DEAD_SKIP 0    // 1: waves without a valid query row run the full pass (A/B of the round-4 skip)
+#endif
 #ifndef AS_SDPA_ABLATE
 #define AS_SDPA_ABLATE 0          // timing experiments only (tools/experiments/sdpa_ablate.py): 1 no exp2, 2 no softmax
-#endif                            // VALU, 3 no P.V MFMAs, 4 no Q.K MFMAs, 5 no LDS-DMA in the loop, 6 no barrier
+#endif                            // VALU, 3 no P.V MFMAs, 4 no Q.K MFMAs, 5 no LDS-DMA in the loop, 6 no barrier (old
+                                  // kernel); 11 .. 17: the same for sdpa_fwd_pipe_kernel's reference-free pass (17: no LDS
+                                  // fragment reads in the loop)
 constexpr int GL_TILE = SD_KB * HD * 2;          // 8 KiB per K (or V^T) tile
 constexpr int GL_NBUF = 3;                       // LDS ring: tiles kt, kt+1, kt+2 (48 KiB per workgroup)
 
@@ -800,30 +805,43 @@ __global__ __launch_bounds__(SD_NT, NQ == 1 ? 3 : 2) void sdpa_fwd_pipe_kernel(
         }
 
         // ---- first half: V^T fragments of the previous unit; S(next) = K . Q^T; exp2 of this unit under the MFMAs ----
-        if (QBP == 0) {
+        if (QBP == 0 && AS_SDPA_ABLATE != 17) {
 #pragma unroll
           for (int c = 0; c < 4; ++c)            // (d block c >> 1, 16-key step c & 1) of key half KBP
             vf[c] = *reinterpret_cast<const bf16x8*>(vptr[2 * KBP + (c & 1)] + P_SLOT * SLOTB + (c >> 1) * 32 * 128);
         }
-        f32x16 s_next = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], fq[QBN][0], zero, 0, 0, 0);
+        f32x16 s_next;
+        if (AS_SDPA_ABLATE == 14) {                                // (timing experiment: no Q.K MFMAs)
+          s_next = s_cur;
+          asm volatile("" : "+v"(s_next) : "v"(kf[0]), "v"(kf[1]), "v"(kf[2]), "v"(kf[3]));
+        } else {
+          s_next = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], fq[QBN][0], zero, 0, 0, 0);
 #pragma unroll
-        for (int ks = 1; ks < 4; ++ks) s_next = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], fq[QBN][ks], s_next, 0, 0, 0);
+          for (int ks = 1; ks < 4; ++ks) s_next = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], fq[QBN][ks], s_next, 0, 0, 0);
+        }
 
         float p[16];
         float ps[4];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           if (FASTP) {
-            p[r] = __builtin_amdgcn_exp2f(s_cur[r]);
-            lp4[QB][r & 3] += p[r];
+            if (AS_SDPA_ABLATE == 11) p[r] = s_cur[r] * 0.5f;       // (timing experiments: 11 no exp2, 12 no softmax VALU)
+            else if (AS_SDPA_ABLATE == 12) p[r] = s_cur[r];
+            else p[r] = __builtin_amdgcn_exp2f(s_cur[r]);
+            if (AS_SDPA_ABLATE != 12) lp4[QB][r & 3] += p[r];
           } else {
             p[r] = __builtin_amdgcn_exp2f(s_cur[r] - mc[QB]);
             ps[r & 3] = r < 4 ? p[r] : ps[r & 3] + p[r];
           }
         }
         bf16x8 p_cur[2];
+        if (AS_SDPA_ABLATE == 12 && FASTP) {                       // raw accumulator bits as "P": no VALU at all
+          p_cur[0] = *reinterpret_cast<bf16x8*>(&p[0]);
+          p_cur[1] = *reinterpret_cast<bf16x8*>(&p[8]);
+        } else {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) p_cur[r >> 3][r & 7] = (__bf16)p[r];
+          for (int r = 0; r < 16; ++r) p_cur[r >> 3][r & 7] = (__bf16)p[r];
+        }
 
         if (I == 0) {
           // ---- ring hand-over (one barrier per tile) ----
@@ -832,18 +850,22 @@ __global__ __launch_bounds__(SD_NT, NQ == 1 ? 3 : 2) void sdpa_fwd_pipe_kernel(
             // my pieces of tile kt+1 have landed (NBUF = 4: tile kt+2 may still be in flight)
             if (NBUF == 4 && kt + 2 < nkt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
+            if (AS_SDPA_ABLATE != 16) __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            if (kt + NBUF - 1 < nkt) stage((SLOT + NBUF - 1) % NBUF);          // into the slot of tile kt-1
+            if (kt + NBUF - 1 < nkt && AS_SDPA_ABLATE != 15) stage((SLOT + NBUF - 1) % NBUF);          // into the slot of tile kt-1
             if (has_ragged && ktg + 1 == nkt_all - 1) zero_pad_cols((SLOT + 1) % NBUF);
           }
         }
 
         // ---- second half: K fragments two units ahead; O += V^T . P of the previous unit ----
-        if (QBNN == 0) load_k(kf, std::integral_constant<int, NN_SLOT * SLOTB + KBNN * 32 * 128>{});
+        if (QBNN == 0 && AS_SDPA_ABLATE != 17) load_k(kf, std::integral_constant<int, NN_SLOT * SLOTB + KBNN * 32 * 128>{});
+        if (AS_SDPA_ABLATE == 13) {                                // (timing experiment: no P.V MFMAs)
+          asm volatile("" : "+v"(oacc[QBP][0]), "+v"(oacc[QBP][1]) : "v"(vf[0]), "v"(vf[1]), "v"(vf[2]), "v"(vf[3]), "v"(p_prev[0]), "v"(p_prev[1]));
+        } else {
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
-          oacc[QBP][c >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[c], p_prev[c & 1], oacc[QBP][c >> 1], 0, 0, 0);
+          for (int c = 0; c < 4; ++c)
+            oacc[QBP][c >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[c], p_prev[c & 1], oacc[QBP][c >> 1], 0, 0, 0);
+        }
 
         if (!FASTP) {
           float psum = (ps[0] + ps[1]) + (ps[2] + ps[3]);
@@ -922,8 +944,72 @@ __global__ __launch_bounds__(SD_NT, NQ == 1 ? 3 : 2) void sdpa_fwd_pipe_kernel(
     }
   };
 
+  // A wave whose 64 query rows all lie beyond N (the last q-tile of an image-head: 101 valid rows of 256 at N = 4197 leave
+  // waves 2 and 3 without a query) still owes the workgroup its share of the LDS-DMA and every barrier, but none of the
+  // MFMA / softmax work: this is run_pass's ring protocol alone -- same staging order, same waits, same barriers.  Under
+  // the chip's power limit (profiles/r04_power_probe.md) the work not done is clock for the waves that have rows.
+  auto run_pass_dead = [&]() {
+    const char* k_tile = k_first;
+    const char* v_tile = v_first;
+    auto stage = [&](int slot) {
+      const unsigned base = smem_base + slot * SLOTB;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const unsigned piece = (wave + 4 * j) * 1024;
+        lds_dma16(offK[j], k_tile, base + piece);
+        lds_dma16(offV[j], v_tile, base + GL_TILE + piece);
+      }
+      k_tile += SD_KB * HD * 2;
+      v_tile += SD_KB * 2;
+    };
+    stage(0);
+    if (nkt > 1) stage(1);
+    if (NBUF == 4 && nkt > 2) stage(2);
+    {
+      const uint4 z = make_uint4(0, 0, 0, 0);
+      *reinterpret_cast<uint4*>(smem + (NBUF - 1) * SLOTB + GL_TILE + tid * 16) = z;
+      *reinterpret_cast<uint4*>(smem + (NBUF - 1) * SLOTB + GL_TILE + 4096 + tid * 16) = z;
+    }
+    if (NBUF == 4 && nkt > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (nkt > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ring_barrier();
+    if (has_ragged && kt_off == nkt_all - 1) zero_pad_cols(0);
+    for (int kt = 0; kt < nkt; ++kt) {
+      const int slot = kt % NBUF, ktg = kt_off + kt;
+      if (kt + 1 < nkt) {
+        if (NBUF == 4 && kt + 2 < nkt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (kt + NBUF - 1 < nkt) stage((slot + NBUF - 1) % NBUF);
+        if (has_ragged && ktg + 1 == nkt_all - 1) zero_pad_cols((slot + 1) % NBUF);
+      }
+    }
+#pragma unroll
+    for (int qb = 0; qb < NQ; ++qb) {
+      m_run[qb] = 0.0f;
+      l_row[qb] = 1.0f;                                            // (never stored: every row of this wave is >= N)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { oacc[qb][0][r] = 0.0f; oacc[qb][1][r] = 0.0f; }
+    }
+  };
+  constexpr bool dead_skip_ok = NQ == 2 && !KSPLIT && AS_SDPA_ABLATE == 0;
   // the key range of the current (bh, row0, kt_off, nkt): reference-free pass, exact pass when a row sum left the range
   auto run_unit = [&]() {
+    if (dead_skip_ok && row0 + wave * (NQ * 32) >= N && !AS_SDPA_NO_DEAD_SKIP) {
+      run_pass_dead();
+      if (MODE == 1) {                                             // the workgroup's vote on the exact pass: this wave abstains
+        ring_barrier();
+        int* flags = reinterpret_cast<int*>(smem);
+        if (lane == 0) flags[wave] = 0;
+        ring_barrier();
+        const bool redo = (flags[0] | flags[1] | flags[2] | flags[3]) != 0;
+        ring_barrier();
+        if (redo) run_pass_dead();
+      }
+      return;
+    }
     if (MODE == 1) {
       run_pass(std::true_type{});
       bool bad = false;
@@ -937,7 +1023,7 @@ __global__ __launch_bounds__(SD_NT, NQ == 1 ? 3 : 2) void sdpa_fwd_pipe_kernel(
       ring_barrier();
       const bool redo = (flags[0] | flags[1] | flags[2] | flags[3]) != 0;
       ring_barrier();
-      if (redo) run_pass(std::false_type{});
+      if (redo && AS_SDPA_ABLATE == 0) run_pass(std::false_type{});     // (ablated builds produce garbage sums: no redo)
     } else {
       run_pass(std::false_type{});
     }

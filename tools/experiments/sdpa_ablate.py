@@ -15,6 +15,9 @@ CS = os.path.join(ROOT, "attentionshift_amd", "csrc")
 OUT = os.path.join(ROOT, "tools", "experiments", "_build")
 VARIANTS = {0: "baseline", 1: "exp2 -> multiply", 2: "no softmax VALU", 3: "no P.V MFMAs", 4: "no Q.K MFMAs",
             5: "no LDS-DMA in the loop", 6: "no per-tile barrier"}
+if os.environ.get("SDPA_ABLATE_PIPE"):        # the shipped kernel (sdpa_fwd_pipe_kernel<2, 0, 1>): hooks 11 .. 17
+    VARIANTS = {0: "baseline", 11: "exp2 -> multiply", 12: "no softmax VALU", 13: "no P.V MFMAs", 14: "no Q.K MFMAs",
+                15: "no LDS-DMA in the loop", 16: "no per-tile barrier", 17: "no LDS fragment reads"}
 
 
 def build():
