@@ -438,6 +438,13 @@ def main():
     CFG.clear()
     CFG.update(CONFIGS[a.config])
 
+    # stdout carries the ONE JSON line and nothing else: gloo and RCCL print banners to the C-level stdout (RCCL's version
+    # block is flushed at process exit, i.e. AFTER the record), so file descriptor 1 is pointed at stderr for the whole
+    # run and the record is written to the saved descriptor
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if os.environ.get("AS_BENCH_SHARE_GPUS"):            # test hook: more ranks than GPUs (plumbing check on a 1-GPU box)
         local %= max(torch.cuda.device_count(), 1)
@@ -626,7 +633,7 @@ def main():
             return
         emitted.set()
         if rank == 0:
-            print(json.dumps(rec), flush=True)
+            os.write(real_stdout, (json.dumps(rec) + "\n").encode())
 
     # ---- the DDP training step: default at N > 1 (that is where RCCL over xGMI runs), optional at N = 1 ----
     if vit and a.train_steps > 0:
