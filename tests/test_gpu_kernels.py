@@ -1231,6 +1231,14 @@ def test_chamfer_2d_forward_backward(ops):
         r2 = ((y2 - torch.gather(y1, 1, j2.long()[..., None].expand(-1, -1, 2))) ** 2).sum(-1)
         ((r1 * w1.double()).sum() + (r2 * w2.double()).sum()).backward()
     assert_close(y1.grad, x1.grad, 1e-4, 1e-4, "grad xyz1"); assert_close(y2.grad, x2.grad, 1e-4, 1e-4, "grad xyz2")
+    # the backward is a fixed-order gather (no atomics): bitwise reproducible, also with many points sharing a neighbour
+    b_few = dev(b[:, :7].contiguous())                          # 1300 points compete for 7 neighbours
+    d1f, d2f, i1f, i2f = ops.chamfer_2d_fwd(dev(a), b_few)
+    g1, g2 = dev(torch.rand(B, n, generator=gen)), dev(torch.rand(B, 7, generator=gen))
+    first = ops.chamfer_2d_bwd(dev(a), b_few, g1, g2, i1f, i2f)
+    for _ in range(3):
+        again = ops.chamfer_2d_bwd(dev(a), b_few, g1, g2, i1f, i2f)
+        assert torch.equal(first[0], again[0]) and torch.equal(first[1], again[1])
 
 
 def _ref_small_attn(qkv):
