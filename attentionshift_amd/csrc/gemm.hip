@@ -477,8 +477,14 @@ __global__ __launch_bounds__(64 * WM * WN, (WN == 4 || KS == 4) ? 1 : (WM == 2 ?
   float* bias_s = reinterpret_cast<float*>(smem + BM * G_EPI_PITCH);
   if (tid < BN) bias_s[tid] = (bias != nullptr && n0 + tid < Nout) ? bias[n0 + tid] : 0.0f;
   __syncthreads();
+  if (AS_GEMM_ABLATE == 8) {                         // timing experiment: no conversion / staging writes (garbage is stored)
+    float keep = 0.0f;
 #pragma unroll
-  for (int i = 0; i < RI; ++i) {
+    for (int i = 0; i < RI; ++i) keep += acc[i][0][0] + acc[i][1][15];
+    if (keep == 12345.678f) smem[0] = 1;
+  }
+#pragma unroll
+  for (int i = 0; i < (AS_GEMM_ABLATE == 8 ? 0 : RI); ++i) {
     char* srow = smem + (wm * (32 * RI) + i * 32 + li) * G_EPI_PITCH;
 #pragma unroll
     for (int j = 0; j < 2; ++j)
@@ -497,6 +503,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WN == 4 || KS == 4) ? 1 : (WM == 2 ?
       }
   }
   __syncthreads();
+  if (AS_GEMM_ABLATE == 9) return;                   // timing experiment: staging only, no copy-out
 #pragma unroll
   for (int t = 0; t < BM * (BN / 8) / NT; ++t) {
     const int c = tid + t * NT;

@@ -13,7 +13,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 CS = os.path.join(ROOT, "attentionshift_amd", "csrc")
 OUT = os.path.join(ROOT, "tools", "experiments", "_build")
 VARIANTS = {0: "baseline", 1: "no LDS-DMA / vmcnt in the loop", 2: "no MFMAs", 3: "no fragment reads", 4: "no barrier",
-            5: "QKV only: no V^T tile stores", 6: "staged epilogue without the global stores", 7: "no epilogue"}
+            5: "QKV only: no V^T tile stores", 6: "staged epilogue without the global stores", 7: "no epilogue",
+            8: "epilogue without conversion + staging writes", 9: "epilogue without copy-out + stores"}
 SHAPES = [(4096, 4096, 4096), (8394, 3072, 768), (8394, 3072, 1536), (8394, 3072, 3072), (8394, 768, 3072)]
 if os.environ.get("GEMM_ABLATE_SHAPES"):
     SHAPES = [tuple(int(v) for v in t.split("x")) for t in os.environ["GEMM_ABLATE_SHAPES"].split(",")]
