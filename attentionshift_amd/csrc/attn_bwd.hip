@@ -174,6 +174,8 @@ BwdLayout bwd_layout(int B, int N, int D, int h, int dtype) {
   L.splitk_bytes = dtype == AS_BF16 ? std::max(as_linear_splitk_workspace_bytes(3 * D, D, (int)L.Mpad),
                                                as_linear_splitk_workspace_bytes(D, D, (int)L.Mpad))
                                     : 0;
+  if (dtype == AS_BF16 && as_tn_applies((int)L.M, 3 * D, D) && as_tn_applies((int)L.M, D, D))
+    L.splitk_bytes = std::max(L.splitk_bytes, std::max(as_tn_workspace_bytes((int)L.M, 3 * D, D), as_tn_workspace_bytes((int)L.M, D, D)));
   L.off_splitk = take(L.splitk_bytes);
   L.total = off;
   return L;
@@ -195,28 +197,41 @@ int attn_bwd(const void* x, const void* Wqkv, const void* Wproj, const void* dou
   // proj backward
   STEP(transpose_pad<T>(Wproj, ws + L.off_WprojT, D, D, D, s));                               // [Dout,Din] -> [Din,Dout]
   STEP(as_linear_fwd(dout, ws + L.off_WprojT, nullptr, d_o, M, D, D, dtype, 0, s));           // d_o = dout . Wproj
-  STEP(transpose_pad<T>(dout, ws + L.off_doutT, M, D, Mpad, s));
-  STEP(transpose_pad<T>(o, ws + L.off_oT, M, D, Mpad, s));
-  // weight gradients contract over the TOKENS (K = Mpad = 8448 at config 2) into a few dozen output tiles: split-K with
-  // fixed-order fp32 partials fills the chip (dWproj: 36 tiles -> 16 K ranges; dWqkv: 108 -> 7)
-  if (sizeof(T) == 2)
-    STEP(as_linear_splitk_fwd(ws + L.off_doutT, ws + L.off_oT, dWproj, D, D, Mpad, dtype, 0, ws + L.off_splitk, L.splitk_bytes, s));
-  else
-    STEP(as_linear_fwd(ws + L.off_doutT, ws + L.off_oT, nullptr, dWproj, D, D, Mpad, dtype, 0, s));   // dout^T . o
-  if (dbproj) STEP(bias_grad<T>(dout, ws + L.off_doutT, dbproj, (float*)(ws + L.off_part), M, D, Mpad, s));
+  // weight gradients contract over the TOKENS (K = Mpad = 8448 at config 2) into a few dozen output tiles: split over the
+  // token range with fixed-order fp32 partials (dWproj: 36 tiles -> 7 ranges; dWqkv: 108 -> 2).  bf16 with 128-aligned
+  // widths: straight from the row-major activations (csrc/gemm_tn.hip); else through transposed, zero-padded copies
+  const bool tn = sizeof(T) == 2 && as_tn_applies(M, D, D) && as_tn_applies(M, 3 * D, D) &&
+                  L.splitk_bytes >= as_tn_workspace_bytes(M, 3 * D, D) && L.splitk_bytes >= as_tn_workspace_bytes(M, D, D);
+  if (tn) {
+    STEP(as_tn_dw(dout, o, dWproj, M, D, D, 0, ws + L.off_splitk, L.splitk_bytes, s));
+    if (dbproj) STEP(as_tn_colsum(dout, dbproj, (float*)(ws + L.off_part), M, D, s));
+  } else {
+    STEP(transpose_pad<T>(dout, ws + L.off_doutT, M, D, Mpad, s));
+    STEP(transpose_pad<T>(o, ws + L.off_oT, M, D, Mpad, s));
+    if (sizeof(T) == 2)
+      STEP(as_linear_splitk_fwd(ws + L.off_doutT, ws + L.off_oT, dWproj, D, D, Mpad, dtype, 0, ws + L.off_splitk, L.splitk_bytes, s));
+    else
+      STEP(as_linear_fwd(ws + L.off_doutT, ws + L.off_oT, nullptr, dWproj, D, D, Mpad, dtype, 0, s));   // dout^T . o
+    if (dbproj) STEP(bias_grad<T>(dout, ws + L.off_doutT, dbproj, (float*)(ws + L.off_part), M, D, Mpad, s));
+  }
   // attention core
   STEP(as_sdpa_bwd(q, k, vt, o, d_o, lse, dqkv, ws + L.off_sdpa, as_sdpa_bwd_workspace_bytes(B, N, h, dtype), B, N, h,
                    dtype, s));
   // qkv backward
   STEP(transpose_pad<T>(Wqkv, ws + L.off_WqkvT, 3 * D, D, 3 * D, s));                         // [3D,D] -> [D,3D]
   STEP(as_linear_fwd(dqkv, ws + L.off_WqkvT, nullptr, dx, M, D, 3 * D, dtype, 0, s));         // dx = dqkv . Wqkv
-  STEP(transpose_pad<T>(dqkv, ws + L.off_dqkvT, M, 3 * D, Mpad, s));
-  STEP(transpose_pad<T>(x, ws + L.off_xT, M, D, Mpad, s));
-  if (sizeof(T) == 2)
-    STEP(as_linear_splitk_fwd(ws + L.off_dqkvT, ws + L.off_xT, dWqkv, 3 * D, D, Mpad, dtype, 0, ws + L.off_splitk, L.splitk_bytes, s));
-  else
-    STEP(as_linear_fwd(ws + L.off_dqkvT, ws + L.off_xT, nullptr, dWqkv, 3 * D, D, Mpad, dtype, 0, s)); // dqkv^T . x
-  if (dbqkv) STEP(bias_grad<T>(dqkv, ws + L.off_dqkvT, dbqkv, (float*)(ws + L.off_part), M, 3 * D, Mpad, s));
+  if (tn) {
+    STEP(as_tn_dw(dqkv, x, dWqkv, M, 3 * D, D, 0, ws + L.off_splitk, L.splitk_bytes, s));
+    if (dbqkv) STEP(as_tn_colsum(dqkv, dbqkv, (float*)(ws + L.off_part), M, 3 * D, s));
+  } else {
+    STEP(transpose_pad<T>(dqkv, ws + L.off_dqkvT, M, 3 * D, Mpad, s));
+    STEP(transpose_pad<T>(x, ws + L.off_xT, M, D, Mpad, s));
+    if (sizeof(T) == 2)
+      STEP(as_linear_splitk_fwd(ws + L.off_dqkvT, ws + L.off_xT, dWqkv, 3 * D, D, Mpad, dtype, 0, ws + L.off_splitk, L.splitk_bytes, s));
+    else
+      STEP(as_linear_fwd(ws + L.off_dqkvT, ws + L.off_xT, nullptr, dWqkv, 3 * D, D, Mpad, dtype, 0, s)); // dqkv^T . x
+    if (dbqkv) STEP(bias_grad<T>(dqkv, ws + L.off_dqkvT, dbqkv, (float*)(ws + L.off_part), M, 3 * D, Mpad, s));
+  }
 #undef STEP
   return AS_OK;
 }
@@ -236,6 +251,7 @@ LinBwdLayout lin_bwd_layout(int M, int Nout, int K) {
   L.off_xT = take((size_t)K * L.Mpad * 2);
   L.off_part = take((size_t)CS_SLICES * Nout * sizeof(float));
   L.splitk_bytes = as_linear_splitk_workspace_bytes(Nout, K, (int)L.Mpad);
+  if (as_tn_applies(M, Nout, K) && as_tn_workspace_bytes(M, Nout, K) > L.splitk_bytes) L.splitk_bytes = as_tn_workspace_bytes(M, Nout, K);
   L.off_splitk = take(L.splitk_bytes);
   L.total = off;
   return L;
@@ -267,15 +283,23 @@ extern "C" int as_linear_bwd(const void* x, const void* W, const void* dy, void*
     if ((rc = transpose_pad<__bf16>(W, ws + L.off_WT, Nout, K, Nout, s)) != AS_OK) return rc;        // [Nout,K] -> [K,Nout]
     if ((rc = as_linear_fwd(dy, ws + L.off_WT, nullptr, dx, M, K, Nout, dtype, 0, s)) != AS_OK) return rc;
   }
-  if (dW) {
+  // dW = dy^T . x straight from the row-major activations (csrc/gemm_tn.hip: transposing LDS reads) when the feature counts
+  // are 128-aligned; otherwise (and with AS_BWD_TRANSPOSED=1) through transposed, zero-padded copies as in round 3
+  const bool tn = as_tn_applies(M, Nout, K);
+  if (dW && tn) {
+    if ((rc = as_tn_dw(dy, x, dW, M, Nout, K, dw_f32, ws + L.off_splitk, L.splitk_bytes, s)) != AS_OK) return rc;
+  } else if (dW) {
     if ((rc = transpose_pad<__bf16>(dy, ws + L.off_dyT, M, Nout, Mpad, s)) != AS_OK) return rc;
     if ((rc = transpose_pad<__bf16>(x, ws + L.off_xT, M, K, Mpad, s)) != AS_OK) return rc;
     if ((rc = as_linear_splitk_fwd(ws + L.off_dyT, ws + L.off_xT, dW, Nout, K, Mpad, dtype, dw_f32, ws + L.off_splitk,
                                    L.splitk_bytes, s)) != AS_OK)
       return rc;
   }
-  if (db && (rc = bias_grad<__bf16>(dy, dW ? ws + L.off_dyT : nullptr, db, (float*)(ws + L.off_part), M, Nout, Mpad, s)) != AS_OK)
+  if (db && tn) {
+    if ((rc = as_tn_colsum(dy, db, (float*)(ws + L.off_part), M, Nout, s)) != AS_OK) return rc;
+  } else if (db && (rc = bias_grad<__bf16>(dy, dW ? ws + L.off_dyT : nullptr, db, (float*)(ws + L.off_part), M, Nout, Mpad, s)) != AS_OK) {
     return rc;
+  }
   return AS_OK;
 }
 

@@ -102,6 +102,13 @@ static inline void as_side_join(AsSide& sd, hipStream_t sq, hipStream_t s) { as_
 __device__ __forceinline__ int as_ceil_div_dev(int a, int b) { return (a + b - 1) / b; }
 #endif
 
+// ---- internal (not part of the C ABI): weight gradients without transposed activation copies, csrc/gemm_tn.hip ----
+bool as_tn_applies(int M, int Nout, int K);                          // 128-aligned feature counts, 32-bit row offsets
+size_t as_tn_workspace_bytes(int M, int Nout, int K);                // fp32 partials [S][Nout][K]
+size_t as_tn_colsum_workspace_bytes(int C);
+int as_tn_dw(const void* dy, const void* x, void* dW, int M, int Nout, int K, int dw_f32, void* ws, size_t ws_bytes, hipStream_t s);
+int as_tn_colsum(const void* g, float* out, float* part, int R, int C, hipStream_t s);   // bf16 [R, C] -> fp32 [C]
+
 // ---------------------------------------------------------------------------------------------
 // MFMA fragments.  One "k16 step" of a 32x32 tile: lane l = (i = l & 31, half = l >> 5) holds the 8
 // consecutive k elements k0 + 8*half .. +7 of row i (A) / column i (B).  C/D: col = l & 31,

@@ -1453,3 +1453,37 @@ def test_mt19937_device_draws_equal_torchs_cpu_generator(ops):
     _, f = ops.mt_sample_ranks(state, torch.tensor([500, 19, 40], dtype=torch.int32).cuda(), 20)
     _, f2 = ops.mt_perm_ranks(state, torch.tensor([[4, 5], [100, 100]], dtype=torch.int32).cuda(), 10)
     assert int(f) != 0 and int(f2) != 0
+
+
+@pytest.mark.parametrize("M,K,Nout", [(8394, 768, 3072), (8394, 3072, 768), (2051, 256, 1024), (4197, 128, 256)])
+def test_weight_gradient_without_transposes_equals_the_transposed_path(ops, M, K, Nout):
+    """as_linear_bwd's two weight-gradient routes -- row-major activations through the transposing LDS read (default) and
+    the round-3 route through transposed, zero-padded copies (AS_BWD_TRANSPOSED=1, read once per process: a child process)
+    -- against each other and against fp64: the same products, summed in different orders (fp32 partial tiles: 1e-3 of the
+    range apart at most), bias gradients included; the transpose-free route twice: bitwise reproducible."""
+    import subprocess, sys, os, json
+    g = torch.Generator().manual_seed(M + K)
+    x = torch.randn(M, K, generator=g).bfloat16()
+    w = (torch.randn(Nout, K, generator=g) / K ** 0.5).bfloat16()
+    dy = torch.randn(M, Nout, generator=g).bfloat16()
+    dx, dw, db = ops.linear_bwd(dev(x), dev(w), dev(dy), True, True, True, dw_dtype=torch.float32)
+    dx2, dw2, db2 = ops.linear_bwd(dev(x), dev(w), dev(dy), True, True, True, dw_dtype=torch.float32)
+    assert torch.equal(dw, dw2) and torch.equal(db, db2)
+    ref_dw = dy.double().t() @ x.double()
+    ref_db = dy.double().sum(0)
+    assert float((dw.cpu().double() - ref_dw).abs().max()) <= 2e-5 * float(ref_dw.abs().max()) + 1e-6 * M ** 0.5
+    assert float((db.cpu().double() - ref_db).abs().max()) <= 2e-5 * float(ref_db.abs().max()) + 1e-6 * M ** 0.5
+    code = (
+        "import sys, json, torch; sys.path.insert(0, %r)\n"
+        "from attentionshift_amd import ops\n"
+        "g = torch.Generator().manual_seed(%d)\n"
+        "x = torch.randn(%d, %d, generator=g).bfloat16(); w = (torch.randn(%d, %d, generator=g) / %d ** 0.5).bfloat16()\n"
+        "dy = torch.randn(%d, %d, generator=g).bfloat16()\n"
+        "dx, dw, db = ops.linear_bwd(x.cuda(), w.cuda(), dy.cuda(), True, True, True, dw_dtype=torch.float32)\n"
+        "torch.save((dw.cpu(), db.cpu()), %r)\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), M + K, M, K, Nout, K, K, M, Nout, "/tmp/as_tn_ref_%d_%d.pt" % (M, K))
+    cp = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, AS_BWD_TRANSPOSED="1"), capture_output=True, text=True, timeout=300)
+    assert cp.returncode == 0, cp.stderr[-2000:]
+    dw_t, db_t = torch.load("/tmp/as_tn_ref_%d_%d.pt" % (M, K))
+    assert float((dw.cpu() - dw_t).abs().max()) <= 1e-3 * float(dw_t.abs().max())
+    assert float((db.cpu() - db_t).abs().max()) <= 1e-3 * float(db_t.abs().max()) + 1e-4
