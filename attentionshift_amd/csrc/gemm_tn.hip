@@ -21,7 +21,6 @@ namespace {
 constexpr int TN_T = 128;                 // features per tile side
 constexpr int TN_GM = 32;                 // token rows per stage (two k16 steps)
 constexpr int TN_NT = 256;
-constexpr int TN_NSTAGE = 4;
 constexpr int TN_TILE_B = TN_GM * TN_T * 2;        // 8 KiB: one operand tile of a stage
 constexpr int TN_STAGE_B = 2 * TN_TILE_B;          // dY tile | X tile
 
@@ -47,7 +46,8 @@ template <int OFF> __device__ __forceinline__ void tn_read_tr(tn_u32x2& dst, uns
 }
 
 // grid (tiles, S).  part: fp32 [S][Nout][K].  chunk: token rows per split (multiple of TN_GM).
-__global__ __launch_bounds__(TN_NT, 2) void gemm_tn_splitk_kernel(const __bf16* __restrict__ dy, const __bf16* __restrict__ x,
+template <int TN_NSTAGE>
+__global__ __launch_bounds__(TN_NT, TN_NSTAGE == 4 ? 2 : 3) void gemm_tn_splitk_kernel(const __bf16* __restrict__ dy, const __bf16* __restrict__ x,
                                                                   float* __restrict__ part, int M, int Nout, int K, int chunk) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -106,43 +106,51 @@ __global__ __launch_bounds__(TN_NT, 2) void gemm_tn_splitk_kernel(const __bf16* 
 
   stage(0, 0);
   if (nst > 1) stage(1, 1);
-  if (nst > 2) stage(2, 2);
+  if (TN_NSTAGE == 4 && nst > 2) stage(2, 2);
   for (int st0 = 0; st0 < nst; st0 += TN_NSTAGE) {
     static_for_tn<TN_NSTAGE>([&](auto slot_c) {
       constexpr int SLOT = decltype(slot_c)::value;
       const int st = st0 + SLOT;
       if (st >= nst) return;
-      // my pieces of stage st have landed when at most the (up to 2) newer stages are in flight: 4 LDS-DMA per stage
-      const int newer = min(2, nst - 1 - st);
+      // my pieces of stage st have landed when at most the (up to NSTAGE - 2) newer stages are in flight: 4 LDS-DMA per stage
+      const int newer = min(TN_NSTAGE - 2, nst - 1 - st);
       if (newer == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       else if (newer == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();                                  // publishes stage st; everyone is done reading stage st-1
       asm volatile("" ::: "memory");
-      if (st + 3 < nst) stage(st + 3, (SLOT + 3) % TN_NSTAGE);
-      // fragments of the stage: [operand][block][k16 step][read]
+      if (st + TN_NSTAGE - 1 < nst) stage(st + TN_NSTAGE - 1, (SLOT + TN_NSTAGE - 1) % TN_NSTAGE);
+      // fragments of the stage: [operand][block][k16 step][read]; the first k16 step's eight reads are waited for alone
+      // (LDS returns in order), so its MFMAs run while the second step's reads are still in flight
       tn_u32x2 ra[2][2][2], rb[2][2][2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         tn_read_tr<SLOT * TN_STAGE_B + 0 * 4096 + 0 * 1024>(ra[i][0][0], fA[i]);
         tn_read_tr<SLOT * TN_STAGE_B + 0 * 4096 + 1 * 1024>(ra[i][0][1], fA[i]);
-        tn_read_tr<SLOT * TN_STAGE_B + 1 * 4096 + 0 * 1024>(ra[i][1][0], fA[i]);
-        tn_read_tr<SLOT * TN_STAGE_B + 1 * 4096 + 1 * 1024>(ra[i][1][1], fA[i]);
         tn_read_tr<SLOT * TN_STAGE_B + 0 * 4096 + 0 * 1024>(rb[i][0][0], fB[i]);
         tn_read_tr<SLOT * TN_STAGE_B + 0 * 4096 + 1 * 1024>(rb[i][0][1], fB[i]);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        tn_read_tr<SLOT * TN_STAGE_B + 1 * 4096 + 0 * 1024>(ra[i][1][0], fA[i]);
+        tn_read_tr<SLOT * TN_STAGE_B + 1 * 4096 + 1 * 1024>(ra[i][1][1], fA[i]);
         tn_read_tr<SLOT * TN_STAGE_B + 1 * 4096 + 0 * 1024>(rb[i][1][0], fB[i]);
         tn_read_tr<SLOT * TN_STAGE_B + 1 * 4096 + 1 * 1024>(rb[i][1][1], fB[i]);
       }
-      asm volatile("s_waitcnt lgkmcnt(0)"
-                   : "+v"(ra[0][0][0]), "+v"(ra[0][0][1]), "+v"(ra[0][1][0]), "+v"(ra[0][1][1]), "+v"(ra[1][0][0]), "+v"(ra[1][0][1]),
-                     "+v"(ra[1][1][0]), "+v"(ra[1][1][1]));
-      asm volatile("" : "+v"(rb[0][0][0]), "+v"(rb[0][0][1]), "+v"(rb[0][1][0]), "+v"(rb[0][1][1]), "+v"(rb[1][0][0]), "+v"(rb[1][0][1]),
-                   "+v"(rb[1][1][0]), "+v"(rb[1][1][1]));
-      __builtin_amdgcn_sched_barrier(0);
+      auto wait_step = [&](auto s_c, auto left_c) {
+        constexpr int S_ = decltype(s_c)::value;
+        asm volatile("s_waitcnt lgkmcnt(%8)"
+                     : "+v"(ra[0][S_][0]), "+v"(ra[0][S_][1]), "+v"(ra[1][S_][0]), "+v"(ra[1][S_][1]), "+v"(rb[0][S_][0]),
+                       "+v"(rb[0][S_][1]), "+v"(rb[1][S_][0]), "+v"(rb[1][S_][1])
+                     : "n"(decltype(left_c)::value));
+        __builtin_amdgcn_sched_barrier(0);
+      };
       const int mrow = m_lo + st * TN_GM;                            // first token row of the stage
       const bool ragged = mrow + TN_GM > M;                          // only the last stage of the last split
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
+        if (s == 0) wait_step(std::integral_constant<int, 0>{}, std::integral_constant<int, 8>{});
+        else wait_step(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
         Frag<__bf16> fa[2], fb[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -244,10 +252,14 @@ bool as_tn_applies(int M, int Nout, int K) {
   return !off && M >= TN_GM && Nout % TN_T == 0 && K % TN_T == 0 && (size_t)M * Nout * 2 < (1ull << 32) &&
          (size_t)M * K * 2 < (1ull << 32);
 }
-// token ranges: about one workgroup per CU (<= 256 in all, <= 32 ranges), a multiple of the stage, >= 256 rows
+// token ranges: one or two workgroups per CU in all (<= 32 ranges), a multiple of the stage, >= 256 rows
 static int tn_plan(int M, int Nout, int K, int* splits) {
   const int tiles = (Nout / TN_T) * (K / TN_T);
-  int S = 256 / (tiles > 0 ? tiles : 1);
+  static const int slots_env = [] { const char* e = getenv("AS_TN_SLOTS"); return e ? atoi(e) : 0; }();   // (experiments)
+  // measured (tools/experiments/dw_tn_bench.py, stages x slots sweep): the MLP's 144 output tiles want two workgroups per CU
+  // (fc1 / fc2 dW + db: 123 -> 74 us), a few dozen tiles one (proj 768 x 768: 51 -> 44 us; the heads' 16 tiles: 134 -> 124)
+  const int slots = slots_env > 0 ? slots_env : (tiles >= 96 ? 512 : 256);
+  int S = slots / (tiles > 0 ? tiles : 1);
   if (S > 32) S = 32;
   if (S < 1) S = 1;
   int chunk = as_round_up(as_ceil_div(M, S), TN_GM);
@@ -268,14 +280,20 @@ int as_tn_dw(const void* dy, const void* x, void* dW, int M, int Nout, int K, in
   const int chunk = tn_plan(M, Nout, K, &S);
   AS_REQUIRE(ws && ws_bytes >= (size_t)S * Nout * K * sizeof(float), AS_E_BADARG, "tn dW: workspace too small");
   const int tiles = (Nout / TN_T) * (K / TN_T);
-  const size_t lds = (size_t)TN_NSTAGE * TN_STAGE_B;
+  static const int stages = [] { const char* e = getenv("AS_TN_STAGES"); return e && atoi(e) == 4 ? 4 : 3; }();   // (experiments: 4-deep ring, 2 workgroups per CU)
+  const size_t lds = (size_t)stages * TN_STAGE_B;
   static std::atomic<bool> attr{false};
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)gemm_tn_splitk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)gemm_tn_splitk_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TN_STAGE_B);
+    (void)hipFuncSetAttribute((const void*)gemm_tn_splitk_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * TN_STAGE_B);
     attr = true;
   }
-  hipLaunchKernelGGL(gemm_tn_splitk_kernel, dim3(8 * as_ceil_div(tiles, 8), S), dim3(TN_NT), lds, s, (const __bf16*)dy,
-                     (const __bf16*)x, (float*)ws, M, Nout, K, chunk);
+  if (stages == 3)
+    hipLaunchKernelGGL(gemm_tn_splitk_kernel<3>, dim3(8 * as_ceil_div(tiles, 8), S), dim3(TN_NT), lds, s, (const __bf16*)dy,
+                       (const __bf16*)x, (float*)ws, M, Nout, K, chunk);
+  else
+    hipLaunchKernelGGL(gemm_tn_splitk_kernel<4>, dim3(8 * as_ceil_div(tiles, 8), S), dim3(TN_NT), lds, s, (const __bf16*)dy,
+                       (const __bf16*)x, (float*)ws, M, Nout, K, chunk);
   AS_CHECK_LAUNCH("gemm_tn_splitk");
   const size_t n4 = (size_t)Nout * K / 4;
   const int grid = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
