@@ -203,8 +203,7 @@ int attn_bwd(const void* x, const void* Wqkv, const void* Wproj, const void* dou
   const bool tn = sizeof(T) == 2 && as_tn_applies(M, D, D) && as_tn_applies(M, 3 * D, D) &&
                   L.splitk_bytes >= as_tn_workspace_bytes(M, 3 * D, D) && L.splitk_bytes >= as_tn_workspace_bytes(M, D, D);
   if (tn) {
-    STEP(as_tn_dw(dout, o, dWproj, M, D, D, 0, ws + L.off_splitk, L.splitk_bytes, s));
-    if (dbproj) STEP(as_tn_colsum(dout, dbproj, (float*)(ws + L.off_part), M, D, s));
+    STEP(as_tn_dw(dout, o, dWproj, dbproj, (float*)(ws + L.off_part), M, D, D, 0, ws + L.off_splitk, L.splitk_bytes, s));
   } else {
     STEP(transpose_pad<T>(dout, ws + L.off_doutT, M, D, Mpad, s));
     STEP(transpose_pad<T>(o, ws + L.off_oT, M, D, Mpad, s));
@@ -221,8 +220,7 @@ int attn_bwd(const void* x, const void* Wqkv, const void* Wproj, const void* dou
   STEP(transpose_pad<T>(Wqkv, ws + L.off_WqkvT, 3 * D, D, 3 * D, s));                         // [3D,D] -> [D,3D]
   STEP(as_linear_fwd(dqkv, ws + L.off_WqkvT, nullptr, dx, M, D, 3 * D, dtype, 0, s));         // dx = dqkv . Wqkv
   if (tn) {
-    STEP(as_tn_dw(dqkv, x, dWqkv, M, 3 * D, D, 0, ws + L.off_splitk, L.splitk_bytes, s));
-    if (dbqkv) STEP(as_tn_colsum(dqkv, dbqkv, (float*)(ws + L.off_part), M, 3 * D, s));
+    STEP(as_tn_dw(dqkv, x, dWqkv, dbqkv, (float*)(ws + L.off_part), M, 3 * D, D, 0, ws + L.off_splitk, L.splitk_bytes, s));
   } else {
     STEP(transpose_pad<T>(dqkv, ws + L.off_dqkvT, M, 3 * D, Mpad, s));
     STEP(transpose_pad<T>(x, ws + L.off_xT, M, D, Mpad, s));
@@ -286,8 +284,8 @@ extern "C" int as_linear_bwd(const void* x, const void* W, const void* dy, void*
   // dW = dy^T . x straight from the row-major activations (csrc/gemm_tn.hip: transposing LDS reads) when the feature counts
   // are 128-aligned; otherwise (and with AS_BWD_TRANSPOSED=1) through transposed, zero-padded copies as in round 3
   const bool tn = as_tn_applies(M, Nout, K);
-  if (dW && tn) {
-    if ((rc = as_tn_dw(dy, x, dW, M, Nout, K, dw_f32, ws + L.off_splitk, L.splitk_bytes, s)) != AS_OK) return rc;
+  if (dW && tn) {                       // (db rides in the same pass)
+    if ((rc = as_tn_dw(dy, x, dW, db, (float*)(ws + L.off_part), M, Nout, K, dw_f32, ws + L.off_splitk, L.splitk_bytes, s)) != AS_OK) return rc;
   } else if (dW) {
     if ((rc = transpose_pad<__bf16>(dy, ws + L.off_dyT, M, Nout, Mpad, s)) != AS_OK) return rc;
     if ((rc = transpose_pad<__bf16>(x, ws + L.off_xT, M, K, Mpad, s)) != AS_OK) return rc;
@@ -295,7 +293,9 @@ extern "C" int as_linear_bwd(const void* x, const void* W, const void* dy, void*
                                    L.splitk_bytes, s)) != AS_OK)
       return rc;
   }
-  if (db && tn) {
+  if (db && tn && dW) {
+    // (done above)
+  } else if (db && tn) {
     if ((rc = as_tn_colsum(dy, db, (float*)(ws + L.off_part), M, Nout, s)) != AS_OK) return rc;
   } else if (db && (rc = bias_grad<__bf16>(dy, dW ? ws + L.off_dyT : nullptr, db, (float*)(ws + L.off_part), M, Nout, Mpad, s)) != AS_OK) {
     return rc;

@@ -106,7 +106,9 @@ __device__ __forceinline__ int as_ceil_div_dev(int a, int b) { return (a + b - 1
 bool as_tn_applies(int M, int Nout, int K);                          // 128-aligned feature counts, 32-bit row offsets
 size_t as_tn_workspace_bytes(int M, int Nout, int K);                // fp32 partials [S][Nout][K]
 size_t as_tn_colsum_workspace_bytes(int C);
-int as_tn_dw(const void* dy, const void* x, void* dW, int M, int Nout, int K, int dw_f32, void* ws, size_t ws_bytes, hipStream_t s);
+// db (nullable): the bias gradient falls out of the same pass; db_part = [<= 32][Nout] floats of scratch
+int as_tn_dw(const void* dy, const void* x, void* dW, float* db, float* db_part, int M, int Nout, int K, int dw_f32, void* ws,
+             size_t ws_bytes, hipStream_t s);
 int as_tn_colsum(const void* g, float* out, float* part, int R, int C, hipStream_t s);   // bf16 [R, C] -> fp32 [C]
 
 // ---------------------------------------------------------------------------------------------

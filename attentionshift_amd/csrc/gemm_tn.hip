@@ -48,7 +48,8 @@ template <int OFF> __device__ __forceinline__ void tn_read_tr(tn_u32x2& dst, uns
 // grid (tiles, S).  part: fp32 [S][Nout][K].  chunk: token rows per split (multiple of TN_GM).
 template <int TN_NSTAGE>
 __global__ __launch_bounds__(TN_NT, TN_NSTAGE == 4 ? 2 : 3) void gemm_tn_splitk_kernel(const __bf16* __restrict__ dy, const __bf16* __restrict__ x,
-                                                                  float* __restrict__ part, int M, int Nout, int K, int chunk) {
+                                                                  float* __restrict__ part, float* __restrict__ db_part, int M, int Nout,
+                                                                  int K, int chunk) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -104,6 +105,10 @@ __global__ __launch_bounds__(TN_NT, TN_NSTAGE == 4 ? 2 : 3) void gemm_tn_splitk_
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
+  // bias gradient: db[n] = sum_m dY[m][n] falls out of the dY fragments -- the workgroups of the first k tile (wave column 0)
+  // add up the eight token values every fragment holds; partial per token range, summed in range order by tn_db_reduce
+  const bool want_db = db_part != nullptr && (tile % nt_k) == 0 && wn == 0;
+  float dbacc[2] = {0.0f, 0.0f};
   stage(0, 0);
   if (nst > 1) stage(1, 1);
   if (TN_NSTAGE == 4 && nst > 2) stage(2, 2);
@@ -164,6 +169,15 @@ __global__ __launch_bounds__(TN_NT, TN_NSTAGE == 4 ? 2 : 3) void gemm_tn_splitk_
               if (mrow + 16 * s + 8 * half + e >= M) { fa[i].v[e] = (__bf16)0.0f; fb[i].v[e] = (__bf16)0.0f; }
           }
         }
+        if (want_db) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            float t = 0.0f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t += (float)fa[i].v[e];
+            dbacc[i] += t;
+          }
+        }
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -172,6 +186,13 @@ __global__ __launch_bounds__(TN_NT, TN_NSTAGE == 4 ? 2 : 3) void gemm_tn_splitk_
     });
   }
 
+  if (want_db) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const float v = dbacc[i] + __shfl_xor(dbacc[i], 32);          // the two halves hold the two 8-token runs of every k16 step
+      if (half == 0) db_part[(size_t)blockIdx.y * Nout + n0 + wm * 64 + i * 32 + li] = v;
+    }
+  }
   // ---- fp32 partial of this token range: lane = row n of dW, registers 4g .. 4g+3 = 4 consecutive columns k
   float* out = part + (size_t)blockIdx.y * Nout * K;
 #pragma unroll
@@ -204,6 +225,14 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict_
       *reinterpret_cast<float4*>(out + i * 4) = a;
     }
   }
+}
+
+__global__ __launch_bounds__(256) void tn_db_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int C, int S) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.0f;
+  for (int i = 0; i < S; ++i) s += part[(size_t)i * C + c];
+  out[c] = s;
 }
 
 // fp32 column sums of a bf16 matrix [R, C] (C % 8 == 0) with 16-byte loads: thread = 8 columns x every 8th row of a slice,
@@ -275,10 +304,12 @@ size_t as_tn_workspace_bytes(int M, int Nout, int K) {
 }
 size_t as_tn_colsum_workspace_bytes(int C) { return (size_t)TN_CS_SLICES * C * sizeof(float); }
 
-int as_tn_dw(const void* dy, const void* x, void* dW, int M, int Nout, int K, int dw_f32, void* ws, size_t ws_bytes, hipStream_t s) {
+int as_tn_dw(const void* dy, const void* x, void* dW, float* db, float* db_part, int M, int Nout, int K, int dw_f32, void* ws,
+             size_t ws_bytes, hipStream_t s) {
   int S = 1;
   const int chunk = tn_plan(M, Nout, K, &S);
   AS_REQUIRE(ws && ws_bytes >= (size_t)S * Nout * K * sizeof(float), AS_E_BADARG, "tn dW: workspace too small");
+  AS_REQUIRE(!db || db_part, AS_E_BADARG, "tn dW: db needs its partial buffer ([<= 32][Nout] floats)");
   const int tiles = (Nout / TN_T) * (K / TN_T);
   static const int stages = [] { const char* e = getenv("AS_TN_STAGES"); return e && atoi(e) == 4 ? 4 : 3; }();   // (experiments: 4-deep ring, 2 workgroups per CU)
   const size_t lds = (size_t)stages * TN_STAGE_B;
@@ -290,10 +321,10 @@ int as_tn_dw(const void* dy, const void* x, void* dW, int M, int Nout, int K, in
   }
   if (stages == 3)
     hipLaunchKernelGGL(gemm_tn_splitk_kernel<3>, dim3(8 * as_ceil_div(tiles, 8), S), dim3(TN_NT), lds, s, (const __bf16*)dy,
-                       (const __bf16*)x, (float*)ws, M, Nout, K, chunk);
+                       (const __bf16*)x, (float*)ws, db ? db_part : nullptr, M, Nout, K, chunk);
   else
     hipLaunchKernelGGL(gemm_tn_splitk_kernel<4>, dim3(8 * as_ceil_div(tiles, 8), S), dim3(TN_NT), lds, s, (const __bf16*)dy,
-                       (const __bf16*)x, (float*)ws, M, Nout, K, chunk);
+                       (const __bf16*)x, (float*)ws, db ? db_part : nullptr, M, Nout, K, chunk);
   AS_CHECK_LAUNCH("gemm_tn_splitk");
   const size_t n4 = (size_t)Nout * K / 4;
   const int grid = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
@@ -302,6 +333,10 @@ int as_tn_dw(const void* dy, const void* x, void* dW, int M, int Nout, int K, in
   else
     hipLaunchKernelGGL(tn_reduce_kernel<__bf16>, dim3(grid), dim3(256), 0, s, (const float*)ws, (__bf16*)dW, n4, S, (size_t)Nout * K);
   AS_CHECK_LAUNCH("tn_reduce");
+  if (db) {
+    hipLaunchKernelGGL(tn_db_reduce_kernel, dim3(as_ceil_div(Nout, 256)), dim3(256), 0, s, (const float*)db_part, db, Nout, S);
+    AS_CHECK_LAUNCH("tn_db_reduce");
+  }
   return AS_OK;
 }
 

@@ -7,9 +7,8 @@ R=${1:-rXX}
 export TMPDIR=/tmp
 mkdir -p gpurun_out
 t0=$(date +%s)
-timeout 600 python bench.py > gpurun_out/${R}_bench_final.log 2>&1
+timeout 600 python bench.py > gpurun_out/${R}_bench_final.json 2> gpurun_out/${R}_bench_final.log
 echo "default bench.py wall: $(( $(date +%s) - t0 )) s" | tee gpurun_out/${R}_bench_wall.txt
-tail -1 gpurun_out/${R}_bench_final.log > gpurun_out/${R}_bench_final.json
 AS_BENCH_OTHER_RNG=0 AS_BENCH_MIL=0 PROF_LINES=8 tools/prof_cmd.sh ${R}_bench_kernel_stats_final python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --train-steps 0 --other-configs "" > /dev/null 2>&1
 timeout 300 python tools/kernel_bench.py --reps 20 > gpurun_out/${R}_kernel_bench.jsonl 2>&1
 bash tools/pmc_call_traffic.sh ${R}_shift_traffic > gpurun_out/${R}_shift_traffic.log 2>&1
