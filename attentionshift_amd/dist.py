@@ -193,8 +193,10 @@ class GradAllReducer:
 
     def _seal(self, items, numel):
         dev = items[0][0].device
-        b = dict(items=items, flat=torch.zeros(numel, dtype=self.comm_dtype, device=dev), seen=set(), work=None,
-                 index=len(self.buckets))
+        flat = torch.zeros(numel, dtype=self.comm_dtype, device=dev)
+        # the parameters' windows into the bucket, made ONCE (300 slice + view calls per step were ~2.5 ms of host time)
+        views = [flat[off:off + p.numel()].view(p.shape) for p, off in items]
+        b = dict(items=items, flat=flat, views=views, seen=set(), work=None, index=len(self.buckets))
         for p, off in items:
             self._where[id(p)] = (b, off)
         self.buckets.append(b)
@@ -218,7 +220,11 @@ class GradAllReducer:
         from the hooks were ~3 ms of host time per step)."""
         if not items:
             return
-        dst = [b["flat"][off:off + p.numel()].view(p.shape) for p, off in items]
+        if items is b["items"]:
+            dst = b["views"]
+        else:
+            where = {id(p): v for (p, _), v in zip(b["items"], b["views"])}
+            dst = [where[id(p)] for p, _ in items]
         src = [p.grad for p, _ in items]
         keep = [i for i, (d, g) in enumerate(zip(dst, src)) if d.data_ptr() != g.data_ptr()]   # already a bucket view
         if len(keep) < len(dst):
@@ -257,14 +263,14 @@ class GradAllReducer:
             return
         for b in self.buckets[self._next:]:   # buckets with a parameter that got no gradient: zeros for it, in order
             have = [(p, off) for p, off in b["items"] if p.grad is not None]   # incl. grads accumulated under no_sync()
-            for p, off in b["items"]:
+            for (p, _), v in zip(b["items"], b["views"]):
                 if p.grad is None:
-                    b["flat"][off:off + p.numel()].zero_()
+                    v.zero_()
             self._pack_many(b, have)
             b["work"] = self.ranks.dist.all_reduce(b["flat"], op=self.ranks.dist.ReduceOp.SUM, async_op=True)
         for b in self.buckets:
             b["work"].wait()
-            views = [b["flat"][off:off + p.numel()].view(p.shape) for p, off in b["items"]]
+            views = b["views"]
             if not self._prescale and all(p.dtype == self.comm_dtype for p, _ in b["items"]):
                 if self._inv != 1.0:
                     b["flat"].mul_(self._inv)
@@ -346,7 +352,9 @@ class _SyncBNFn(torch.autograd.Function):
         C = x.shape[1]
         dims = [0] + list(range(2, x.dim()))
         xf = x.float()
-        stat = torch.cat((xf.sum(dims), (xf * xf).sum(dims), xf.new_tensor([xf.numel() / C])))
+        # (the element count as a device FILL, not `new_tensor([...])`: a pageable host -> device copy waits for the whole
+        # stream and left the host in lock-step with the device for the rest of the step -- found with the one-rank group)
+        stat = torch.cat((xf.sum(dims), (xf * xf).sum(dims), torch.full((1,), xf.numel() / C, device=xf.device, dtype=xf.dtype)))
         ranks.dist.all_reduce(stat, op=ranks.dist.ReduceOp.SUM)
         n = stat[-1]
         mean = stat[:C] / n
