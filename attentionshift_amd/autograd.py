@@ -177,3 +177,76 @@ class AddLayerNormFn(torch.autograd.Function):
 
 def add_layernorm(x, delta, gamma, beta, eps, out_dtype, delta_scale=None):
     return AddLayerNormFn.apply(x, delta, gamma, beta, eps, out_dtype, delta_scale)
+
+
+class DecoderBlockFn(torch.autograd.Function):
+    """One pre-LN transformer block of the MAE-decoder heads (mae_bbox_head_rec.py:148-168 = the Block of
+    models/vision_transformer.py:109-124 at embed 256 / 8 heads of 32) as ONE autograd node:
+
+        x1 = x + delta;  y = LN1(x1);  a = proj(attn(qkv(y)));  x2 = x1 + a;  z = LN2(x2);  out_delta = fc2(gelu(fc1(z)))
+
+    forward(x fp32 [R,N,C], delta bf16 | None, 12 parameters, eps1, eps2, num_heads) -> (x2 fp32, out_delta bf16).  The same
+    kernels as the per-op bridges (AddLayerNormFn, LinearFn, SmallAttnFn) in the same order, so values and gradients are
+    theirs bit for bit; what goes away is seven `Function.apply` calls and autograd nodes per block and direction -- the RoI
+    head's loss phase was host-bound on them (6.2 ms of host for ~3 ms of device work per training step)."""
+
+    @staticmethod
+    def forward(ctx, x, delta, g1, b1, wq, bq, wp, bp, g2, b2, w1, bf1, w2, bf2, eps1, eps2, heads):
+        bf = torch.bfloat16
+        R, N, C = x.shape
+        f = lambda t: None if t is None else t.detach().float().contiguous()        # noqa: E731
+        c = lambda t: t.detach().to(bf).contiguous()                              # noqa: E731
+        g1f, g2f = f(g1), f(g2)
+        wqb, wpb, w1b, w2b = c(wq), c(wp), c(w1), c(w2)
+        x1, y = ops.add_layernorm(x.contiguous(), None if delta is None else delta.contiguous(), g1f, f(b1), eps1, bf)
+        qkv = ops.linear(y.reshape(R * N, C), wqb, f(bq)).reshape(R, N, 3, heads, C // heads)
+        o, lse = ops.small_attention_fwd(qkv)
+        a = ops.linear(o.reshape(R * N, C), wpb, f(bp)).reshape(R, N, C)
+        x2, z = ops.add_layernorm(x1, a, g2f, f(b2), eps2, bf)
+        h = ops.linear(z.reshape(R * N, C), w1b, f(bf1))
+        hg = torch.nn.functional.gelu(h)
+        d = ops.linear(hg, w2b, f(bf2)).reshape(R, N, C)
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(x1, y, qkv, o, lse, x2, z, h, hg, wqb, wpb, w1b, w2b, g1f, g2f)
+        ctx.cfg = (float(eps1), float(eps2), delta is not None, [None if t is None else t.dtype for t in
+                                                                  (g1, b1, wq, bq, wp, bp, g2, b2, w1, bf1, w2, bf2)])
+        return x2, d
+
+    @staticmethod
+    def backward(ctx, dx2, dd):
+        x1, y, qkv, o, lse, x2, z, h, hg, wqb, wpb, w1b, w2b, g1f, g2f = ctx.saved_tensors
+        eps1, eps2, has_delta, dts = ctx.cfg
+        bf = torch.bfloat16
+        R, N, C = x1.shape
+        M = R * N
+        need = ctx.needs_input_grad
+        dz = dw2 = db2 = dw1 = db1 = None
+        if dd is not None:
+            dd2 = dd.to(bf).reshape(M, C).contiguous()
+            dhg, dw2, db2 = ops.linear_bwd(hg, w2b, dd2, True, need[12], need[13] and dts[11] is not None, dw_dtype=dts[10])
+            dh = torch.ops.aten.gelu_backward(dhg, h)
+            dz, dw1, db1 = ops.linear_bwd(z.reshape(M, C), w1b, dh, True, need[10], need[11] and dts[9] is not None, dw_dtype=dts[8])
+            dz = dz.reshape(R, N, C)
+        if dz is None and dx2 is None:
+            return (None,) * 17
+        dx1, da, dg2, dbt2 = ops.add_layernorm_bwd(x2, dz, None if dx2 is None else dx2.contiguous(), g2f, eps2, bf,
+                                                   want_dx=True, want_ddelta=True, want_affine=need[8] or need[9])
+        do, dwp, dbp = ops.linear_bwd(o.reshape(M, C), wpb, da.reshape(M, C), True, need[6], need[7] and dts[5] is not None,
+                                      dw_dtype=dts[4])
+        dqkv = ops.small_attention_bwd(qkv, o, do.reshape(R, N, C), lse)
+        dy, dwq, dbq = ops.linear_bwd(y.reshape(M, C), wqb, dqkv.reshape(M, 3 * C), True, need[4], need[5] and dts[3] is not None,
+                                      dw_dtype=dts[2])
+        dx, ddelta, dg1, dbt1 = ops.add_layernorm_bwd(x1, dy.reshape(R, N, C), dx1, g1f, eps1, bf, want_dx=need[0],
+                                                      want_ddelta=has_delta and need[1], want_affine=need[2] or need[3])
+        cast = lambda t, i: None if (t is None or not need[i + 2]) else t.to(dts[i])     # noqa: E731
+        return (dx, ddelta, cast(dg1, 0), cast(dbt1, 1), dwq if need[4] else None, cast(dbq, 3), dwp if need[6] else None,
+                cast(dbp, 5), cast(dg2, 6), cast(dbt2, 7), dw1 if need[10] else None, cast(db1, 9), dw2 if need[12] else None,
+                cast(db2, 11), None, None, None)
+
+
+def decoder_block(x, delta, blk):
+    """DecoderBlockFn on a block module with .norm1 / .attn.qkv / .attn.proj / .norm2 / .mlp.fc1 / .mlp.fc2 (mae_heads.DecoderBlock)."""
+    a, m = blk.attn, blk.mlp
+    return DecoderBlockFn.apply(x, delta, blk.norm1.weight, blk.norm1.bias, a.qkv.weight, a.qkv.bias, a.proj.weight, a.proj.bias,
+                                blk.norm2.weight, blk.norm2.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias,
+                                blk.norm1.eps, blk.norm2.eps, a.num_heads)

@@ -11,6 +11,8 @@
 import math
 from functools import partial
 
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -90,7 +92,12 @@ def _run_blocks(blocks, x):
             x = blk(x)
         return x
     bf, delta = torch.bfloat16, None
+    fused = x.shape[0] > 0 and os.environ.get("AS_HEAD_BLOCKS_UNFUSED") is None and \
+        all(AG.linear_shapes_ok(x, w) for w in (blocks[0].attn.proj.weight, blocks[0].mlp.fc1.weight, blocks[0].mlp.fc2.weight))
     for blk in blocks:
+        if fused:                                           # ONE autograd node per block (autograd.DecoderBlockFn)
+            x, delta = AG.decoder_block(x, delta, blk)
+            continue
         x, y = AG.add_layernorm(x, delta, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps, bf)     # x += previous MLP output
         x, z = AG.add_layernorm(x, blk.attn(y).contiguous(), blk.norm2.weight, blk.norm2.bias, blk.norm2.eps, bf)
         delta = blk.mlp(z)

@@ -169,3 +169,36 @@ def test_nms_on_device_tensors_matches_the_oracle():
     dr, lr = O.multiclass_nms_mmdet(per_class.numpy(), scores.numpy(), 0.05, 0.5, 100)
     assert l.cpu().tolist() == lr.tolist()
     assert np.allclose(d.cpu().numpy(), dr, rtol=1e-6, atol=1e-5)
+
+
+def test_fused_decoder_block_node_equals_the_per_op_bridges(monkeypatch):
+    """autograd.DecoderBlockFn (one autograd node per MAE-decoder block) against the per-op bridges it replaces
+    (AddLayerNormFn + LinearFn + SmallAttnFn, AS_HEAD_BLOCKS_UNFUSED=1): same kernels in the same order, so the output and
+    every gradient -- input, LayerNorm affine, the four Linear weights and biases of each of the 3 blocks -- are bitwise
+    equal, in a bf16 autocast region as the training step runs the heads."""
+    from attentionshift_amd.mae_heads import DecoderBlock, _run_blocks
+    torch.manual_seed(5)
+    blocks = torch.nn.ModuleList([DecoderBlock(256, 8) for _ in range(3)]).cuda()
+    for p in blocks.parameters():
+        torch.nn.init.normal_(p, std=0.05)
+    x0 = torch.randn(37, 50, 256, device="cuda")
+    w = torch.randn(37, 50, 256, device="cuda")
+
+    def run(unfused):
+        if unfused:
+            monkeypatch.setenv("AS_HEAD_BLOCKS_UNFUSED", "1")
+        else:
+            monkeypatch.delenv("AS_HEAD_BLOCKS_UNFUSED", raising=False)
+        for p in blocks.parameters():
+            p.grad = None
+        x = x0.clone().requires_grad_(True)
+        with torch.enable_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            y = _run_blocks(blocks, x)
+            (y.float() * w).sum().backward()
+        return y.detach(), x.grad, [p.grad.clone() for p in blocks.parameters()]
+
+    y_u, dx_u, g_u = run(True)
+    y_f, dx_f, g_f = run(False)
+    assert torch.equal(y_u, y_f) and torch.equal(dx_u, dx_f)
+    for (n, _), a, b in zip(blocks.named_parameters(), g_u, g_f):
+        assert a.dtype == b.dtype and torch.equal(a, b), n
