@@ -1337,15 +1337,18 @@ def test_mae_heads_bf16_training_path_matches_the_library_path(kind, monkeypatch
             sum(o.float().square().mean() for o in outs).backward()
         return [o.detach().float() for o in outs], xin.grad, {n: p.grad.clone() for n, p in head.named_parameters() if p.grad is not None}
 
-    calls = []
-    orig = AG.LinearFn.forward
+    calls, blocks = [], []
+    orig, orig_blk = AG.LinearFn.forward, AG.DecoderBlockFn.forward
     monkeypatch.setattr(AG.LinearFn, "forward", staticmethod(lambda ctx, *a: (calls.append(1), orig(ctx, *a))[1]))
+    monkeypatch.setattr(AG.DecoderBlockFn, "forward", staticmethod(lambda ctx, *a: (blocks.append(1), orig_blk(ctx, *a))[1]))
     outs, dx, grads = run()
-    assert len(calls) >= 9, "the HIP linear path did not run"       # decoder_embed + 4 layers per block
+    # decoder_embed (+ the box head's output layers) through LinearFn, the two decoder blocks as one fused node each
+    # (DecoderBlockFn: the same as_linear_fwd / as_linear_bwd kernels for their four layers)
+    assert len(calls) >= 1 and len(blocks) == 2, ("the HIP linear path did not run", len(calls), len(blocks))
     monkeypatch.setattr(AG, "_LIBRARY_LINEAR", True)
-    n_before = len(calls)
+    n_before, b_before = len(calls), len(blocks)
     outs2, dx2, grads2 = run()
-    assert len(calls) == n_before, "the library path still went through LinearFn"
+    assert len(calls) == n_before and len(blocks) == b_before, "the library path still went through the HIP bridges"
     for a, b in zip(outs2, outs):
         mx, mean = rel_to_range(a, b)
         assert mx < 4e-2 and mean < 5e-3, ("output", mx, mean)
