@@ -584,15 +584,20 @@ __device__ __forceinline__ void lds_dma16(unsigned voff, const char* sbase, unsi
 // result does not depend on who arrives last (cdna_hip_programming.md: in-launch split-K reduction, counter form:
 // agent-scope release by the writers, agent-scope acquire by the reducer, counters zeroed by a memset node per call).
 constexpr int SK_REC_BYTES = 2 * SD_QB * HD * 2 + 2 * SD_QB * 8;  // one 256-row piece: bf16 O + float2 (m, l) per row
-template <int NQ, int SPLIT, int MODE>
-__global__ __launch_bounds__(SD_NT, NQ == 1 ? 3 : 2) void sdpa_fwd_pipe_kernel(
+// NW = waves per workgroup (4; 8 = round-4 experiment AS_SDPA_IMPL=7: 512-row workgroups, one per CU, every K / V^T tile
+// staged once for twice the queries -- the LDS-DMA is 14 % of the loop, profiles/r04_sdpa_streamk.md).
+template <int NQ, int SPLIT, int MODE, int NW = 4>
+__global__ __launch_bounds__(64 * NW, NQ == 1 ? 3 : 2) void sdpa_fwd_pipe_kernel(
     const __bf16* __restrict__ q, const __bf16* __restrict__ k, const __bf16* __restrict__ vt, __bf16* __restrict__ o,
     float* __restrict__ lse, int B, int N, int Npad, int h, int qt_fixed, int nslices, float* __restrict__ part,
     int mix_mode, int mix_a, int mix_r) {
   extern __shared__ __attribute__((aligned(16))) char smem[];     // [3][K tile | V^T tile]
   constexpr bool KSPLIT = SPLIT == 1, SK = SPLIT == 2;
-  static_assert(!SK || NQ == 2, "stream-K is built on the 256-row workgroup");
-  constexpr int QROWS = SD_QB * NQ;                               // query rows of a workgroup
+  static_assert(!SK || (NQ == 2 && NW == 4), "stream-K is built on the 256-row workgroup");
+  static_assert(NW == 4 || NW == 8, "4 or 8 waves");
+  constexpr int NT = 64 * NW;                                     // threads of a workgroup
+  constexpr int PPW = 8 / NW;                                     // one-KiB pieces of K (and of V^T) a wave moves per tile
+  constexpr int QROWS = 32 * NQ * NW;                             // query rows of a workgroup
   constexpr int UPT = 2 * NQ;                                     // units per tile
   constexpr int SLOTB = 2 * GL_TILE;                              // bytes of a ring slot
   constexpr int NBUF = NQ == 2 ? AS_SDPA_NBUF2 : 3;               // ring depth: NBUF - 2 tiles in flight beyond the next
@@ -646,7 +651,7 @@ __global__ __launch_bounds__(SD_NT, NQ == 1 ? 3 : 2) void sdpa_fwd_pipe_kernel(
     const int r = wave * 8 + lr;
     const int key = (r >> 1) & 7;
     offK[0] = r * (HD * 2) + ((lc ^ key) << 4);
-    offK[1] = offK[0] + 32 * HD * 2;
+    offK[1] = offK[0] + 32 * HD * 2;                               // (second piece: NW = 4 only)
     offV[0] = r * (Npad * 2) + ((lc ^ key) << 4);
     offV[1] = offV[0] + 32 * Npad * 2;
   }
@@ -681,10 +686,11 @@ __global__ __launch_bounds__(SD_NT, NQ == 1 ? 3 : 2) void sdpa_fwd_pipe_kernel(
   auto zero_pad_cols = [&](int slot) {
     const int nv = N - (nkt_all - 1) * SD_KB;                     // valid keys of the last tile, 1 .. 63
     char* Vs = smem + slot * SLOTB + GL_TILE;
-    const int d = tid >> 2;
+    constexpr int TPR = NT / 64, CPT = 8 / TPR;                  // threads per d row, 16-byte chunks per thread
+    const int d = tid / TPR;
 #pragma unroll
-    for (int cc = 0; cc < 2; ++cc) {
-      const int c = (tid & 3) * 2 + cc;
+    for (int cc = 0; cc < CPT; ++cc) {
+      const int c = (tid % TPR) * CPT + cc;
       if (8 * c + 8 > nv) {
         bf16x8* pch = reinterpret_cast<bf16x8*>(Vs + d * 128 + ((c ^ ((d >> 1) & 7)) << 4));
         bf16x8 v = *pch;
@@ -730,8 +736,8 @@ __global__ __launch_bounds__(SD_NT, NQ == 1 ? 3 : 2) void sdpa_fwd_pipe_kernel(
     auto stage = [&](int slot) {                                   // tiles are staged strictly in order
       const unsigned base = smem_base + slot * SLOTB;
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const unsigned piece = (wave + 4 * j) * 1024;
+      for (int j = 0; j < PPW; ++j) {
+        const unsigned piece = (wave + NW * j) * 1024;
         lds_dma16(offK[j], k_tile, base + piece);
         lds_dma16(offV[j], v_tile, base + GL_TILE + piece);
       }
@@ -744,12 +750,12 @@ __global__ __launch_bounds__(SD_NT, NQ == 1 ? 3 : 2) void sdpa_fwd_pipe_kernel(
     // the slot "before tile 0" feeds the first step's (all-zero) P.V product: its V^T half must hold finite numbers
     {
       const uint4 z = make_uint4(0, 0, 0, 0);
-      *reinterpret_cast<uint4*>(smem + (NBUF - 1) * SLOTB + GL_TILE + tid * 16) = z;
-      *reinterpret_cast<uint4*>(smem + (NBUF - 1) * SLOTB + GL_TILE + 4096 + tid * 16) = z;
+#pragma unroll
+      for (int o_ = 0; o_ < GL_TILE; o_ += NT * 16) *reinterpret_cast<uint4*>(smem + (NBUF - 1) * SLOTB + GL_TILE + o_ + tid * 16) = z;
     }
     // wait for tile 0 only: the later tiles' pieces (4 LDS-DMA per wave and tile) may stay in flight
-    if (NBUF == 4 && nkt > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (nkt > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    if (NBUF == 4 && nkt > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * PPW) : "memory");
+    else if (nkt > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     ring_barrier();
     if (has_ragged && kt_off == nkt_all - 1) zero_pad_cols(0);     // tile 0 of this workgroup is the ragged one
@@ -848,7 +854,7 @@ __global__ __launch_bounds__(SD_NT, NQ == 1 ? 3 : 2) void sdpa_fwd_pipe_kernel(
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // my reads of tile kt-1 are done
           if (kt + 1 < nkt) {
             // my pieces of tile kt+1 have landed (NBUF = 4: tile kt+2 may still be in flight)
-            if (NBUF == 4 && kt + 2 < nkt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            if (NBUF == 4 && kt + 2 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (AS_SDPA_ABLATE != 16) __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
@@ -954,8 +960,8 @@ __global__ __launch_bounds__(SD_NT, NQ == 1 ? 3 : 2) void sdpa_fwd_pipe_kernel(
     auto stage = [&](int slot) {
       const unsigned base = smem_base + slot * SLOTB;
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const unsigned piece = (wave + 4 * j) * 1024;
+      for (int j = 0; j < PPW; ++j) {
+        const unsigned piece = (wave + NW * j) * 1024;
         lds_dma16(offK[j], k_tile, base + piece);
         lds_dma16(offV[j], v_tile, base + GL_TILE + piece);
       }
@@ -967,18 +973,18 @@ __global__ __launch_bounds__(SD_NT, NQ == 1 ? 3 : 2) void sdpa_fwd_pipe_kernel(
     if (NBUF == 4 && nkt > 2) stage(2);
     {
       const uint4 z = make_uint4(0, 0, 0, 0);
-      *reinterpret_cast<uint4*>(smem + (NBUF - 1) * SLOTB + GL_TILE + tid * 16) = z;
-      *reinterpret_cast<uint4*>(smem + (NBUF - 1) * SLOTB + GL_TILE + 4096 + tid * 16) = z;
+#pragma unroll
+      for (int o_ = 0; o_ < GL_TILE; o_ += NT * 16) *reinterpret_cast<uint4*>(smem + (NBUF - 1) * SLOTB + GL_TILE + o_ + tid * 16) = z;
     }
-    if (NBUF == 4 && nkt > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (nkt > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    if (NBUF == 4 && nkt > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * PPW) : "memory");
+    else if (nkt > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     ring_barrier();
     if (has_ragged && kt_off == nkt_all - 1) zero_pad_cols(0);
     for (int kt = 0; kt < nkt; ++kt) {
       const int slot = kt % NBUF, ktg = kt_off + kt;
       if (kt + 1 < nkt) {
-        if (NBUF == 4 && kt + 2 < nkt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if (NBUF == 4 && kt + 2 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -1004,7 +1010,10 @@ __global__ __launch_bounds__(SD_NT, NQ == 1 ? 3 : 2) void sdpa_fwd_pipe_kernel(
         int* flags = reinterpret_cast<int*>(smem);
         if (lane == 0) flags[wave] = 0;
         ring_barrier();
-        const bool redo = (flags[0] | flags[1] | flags[2] | flags[3]) != 0;
+        int any_bad = 0;
+#pragma unroll
+        for (int w_ = 0; w_ < NW; ++w_) any_bad |= flags[w_];
+        const bool redo = any_bad != 0;
         ring_barrier();
         if (redo) run_pass_dead();
       }
@@ -1021,7 +1030,10 @@ __global__ __launch_bounds__(SD_NT, NQ == 1 ? 3 : 2) void sdpa_fwd_pipe_kernel(
       int* flags = reinterpret_cast<int*>(smem);
       if (lane == 0) flags[wave] = wave_bad;
       ring_barrier();
-      const bool redo = (flags[0] | flags[1] | flags[2] | flags[3]) != 0;
+      int any_bad = 0;
+#pragma unroll
+      for (int w_ = 0; w_ < NW; ++w_) any_bad |= flags[w_];
+      const bool redo = any_bad != 0;
       ring_barrier();
       if (redo && AS_SDPA_ABLATE == 0) run_pass(std::false_type{});     // (ablated builds produce garbage sums: no redo)
     } else {
@@ -1249,7 +1261,8 @@ __global__ __launch_bounds__(256) void sdpa_combine_kernel(const float* __restri
 // the LDS ring -- followed by a tiny merge of the 11 partial (max, sum, O) records per row (fixed order).
 // ---------------------------------------------------------------------------------------------------------
 // Which forward kernel.  AS_SDPA_IMPL (read per call; tests and tools/experiments/sdpa_impl_bench.py) forces one:
-// 0 = sdpa_fwd_glds_kernel; sdpa_fwd_pipe_kernel: 1 = <NQ 1, MODE 0>, 2 = <2, 0>, 3 = <1, 1>, 4 = <2, 1>.  Unset: the
+// 0 = sdpa_fwd_glds_kernel; sdpa_fwd_pipe_kernel: 1 = <NQ 1, MODE 0>, 2 = <2, 0>, 3 = <1, 1>, 4 = <2, 1>, 6 = stream-K,
+// 7 = <2, 1> on 8-wave / 512-row workgroups.  Unset: the
 // reference-free pipelined kernel with the query blocking (3 or 4) that sdpa_pick() prices cheaper for the shape.
 int sdpa_impl_forced() {
   const char* e = getenv("AS_SDPA_IMPL");
@@ -1367,7 +1380,15 @@ int sdpa_pick(int B, int N, int h, bool tail_ok, bool sk_ok = false) {
     const double tsk = (double)as_ceil_div(N, 2 * SD_QB) * BH * tiles / sdpa_sk_grid() * c2[1] + 29.0;
     if (tsk < t1 && tsk < t2) return 6;
   }
-  return t2 < t1 ? 4 : 3;
+  if (t2 < t1) {
+    // 64 queries per wave: on 512-row workgroups of EIGHT waves (impl 7) when they still cover at least half the CUs -- each
+    // K / V^T tile is then staged once for twice the queries (the LDS-DMA is 14 % of the loop); measured in one call
+    // (tools/experiments/sdpa_impl_bench.py): config 2 117.4 -> 114.4 us, ViT-L 1 x 16 x 6501 176.3 -> 166.8 us (1038 TFLOP/s),
+    // 2 x 16 x 4096 128.9 -> 126.8 us; bitwise the same rows as the 256-row grid.  AS_SDPA_NO_W8=1 keeps four waves.
+    static const bool no_w8 = getenv("AS_SDPA_NO_W8") != nullptr;
+    return (!no_w8 && as_ceil_div(N, 512) * BH >= cus / 2) ? 7 : 4;
+  }
+  return 3;
 }
 
 int launch_sdpa_glds(const void* q, const void* k, const void* vt, void* o, float* lse, void* ws, size_t ws_bytes, int B,
@@ -1390,7 +1411,7 @@ int launch_sdpa_glds(const void* q, const void* k, const void* vt, void* o, floa
     if (ws == nullptr || ws_bytes < (size_t)BH * ns_t * SD_QB * SD_REC * sizeof(float)) mixed = false;
   }
   if (impl == 5 && !mixed) impl = sdpa_pick(B, N, h, ns > 0) == 5 ? 4 : sdpa_pick(B, N, h, ns > 0);
-  if (impl == 2 || impl == 4) ns = 0;                        // 256-row workgroups: no split tail
+  if (impl == 2 || impl == 4 || impl == 6 || impl == 7) ns = 0;   // 64 queries per wave: no split tail
   if (ns > 0) --qtiles;
   const size_t lds = (size_t)GL_NBUF * 2 * GL_TILE;        // 48 KiB
   // The split q-tile runs CONCURRENTLY with the main grid on a helper stream (fork / join with events on the caller's
@@ -1459,6 +1480,18 @@ int launch_sdpa_glds(const void* q, const void* k, const void* vt, void* o, floa
       (void)hipStreamWaitEvent(s, side.join, 0);
       (void)hipStreamWaitEvent(s, side.join2, 0);
     }
+    return AS_OK;
+  }
+  if (impl == 7) {                                           // 512-row workgroups of 8 waves (64 queries per wave), one per CU
+    const size_t lds = (size_t)AS_SDPA_NBUF2 * 2 * GL_TILE;
+    static std::atomic<bool> attr_w8{false};
+    if (!attr_w8 && lds > 64 * 1024 - 1) {
+      (void)hipFuncSetAttribute((const void*)sdpa_fwd_pipe_kernel<2, 0, 1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr_w8 = true;
+    }
+    hipLaunchKernelGGL((sdpa_fwd_pipe_kernel<2, 0, 1, 8>), dim3(as_ceil_div(N, 512) * BH), dim3(512), lds, s, (const __bf16*)q,
+                       (const __bf16*)k, (const __bf16*)vt, (__bf16*)o, lse, B, N, Npad, h, 0, 1, (float*)nullptr, 0, 0, 0);
+    AS_CHECK_LAUNCH("sdpa_fwd_pipe<8 waves>");
     return AS_OK;
   }
   if (impl == 6) {                                           // stream-K: persistent, balanced, merged in the kernel

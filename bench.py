@@ -521,8 +521,9 @@ def main():
         headline = a.config == "vitb"
         rec["roofline"] = {
             "kernel": "as_sdpa_fwd (bf16): sdpa_fwd_pipe_kernel (software-pipelined units of 32x32 scores, reference-free "
-                      "first pass); 256-row workgroups (64 queries per wave) or 128-row workgroups + key-split last q-tile, "
-                      "whichever csrc/sdpa.hip sdpa_pick() prices cheaper for the shape; one timed 'launch' = the whole call",
+                      "first pass); 512-row workgroups of 8 waves / 256-row of 4 (64 queries per wave) or 128-row workgroups + "
+                      "key-split last q-tile, whichever csrc/sdpa.hip sdpa_pick() prices cheaper for the shape; one timed "
+                      "'launch' = the whole call",
             "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ach / PEAK_BF16_TFLOPS, 4),
             "traffic": _static_traffic(("r04_sdpa_traffic.json", "r03_sdpa_traffic.json"), "per_as_sdpa_fwd_call_bytes") if headline else None,

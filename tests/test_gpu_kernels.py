@@ -271,7 +271,7 @@ def test_sdpa_bf16_deferred_max_and_spikes(ops, monkeypatch, tail, N):
     assert torch.isfinite(o.float()).all()
 
 
-@pytest.mark.parametrize("impl", ["0", "1", "2", "3", "4", "5", "6"])
+@pytest.mark.parametrize("impl", ["0", "1", "2", "3", "4", "5", "6", "7"])
 @pytest.mark.parametrize("tail,N", [("0", 1000), ("1", 1153), ("1", 100)])
 def test_sdpa_bf16_out_of_range_logits_take_the_exact_pass(ops, monkeypatch, impl, tail, N):
     """Rows the reference-free first pass (sdpa_fwd_pipe_kernel MODE 1: P = exp2 of the raw base-2 logit) cannot represent
@@ -356,6 +356,23 @@ def test_sdpa_stream_k_matches_oracle_and_the_plain_grid(ops, monkeypatch, B, h,
         mx, mean = rel_to_range(ref2, o6b.float())
         assert mx < 2e-2 and mean < 3e-3, (mx, mean)
         assert_close(lse_ref2, lse6b, 1e-4, 1e-3, "lse (stream-K, second operand set)")
+
+
+@pytest.mark.parametrize("B,h,N", [(1, 2, 1000), (2, 3, 1153), (1, 1, 513), (1, 2, 100), (2, 12, 4197)])
+def test_sdpa_eight_wave_workgroups_match_oracle_and_the_plain_grid(ops, monkeypatch, B, h, N):
+    """AS_SDPA_IMPL=7: the pipelined kernel on 512-row workgroups of eight waves (each K / V^T tile staged once for twice the
+    queries): against the fp32 oracle and, row for row, against the 256-row grid -- the same arithmetic per wave, so bitwise
+    equal outputs are expected; ragged last tiles with 1 .. 7 waves that own no query (N = 513: seven of eight)."""
+    qf, kp, vtp, ref, lse_ref = _sdpa_case(ops, B, h, N, 99 + N)
+    monkeypatch.setenv("AS_SDPA_IMPL", "4")
+    o4, lse4 = ops.sdpa_fwd(qf, kp, vtp, N)
+    monkeypatch.setenv("AS_SDPA_IMPL", "7")
+    o7, lse7 = ops.sdpa_fwd(qf, kp, vtp, N)
+    assert torch.isfinite(o7.float()).all()
+    mx, mean = rel_to_range(ref, o7.float())
+    assert mx < 2e-2 and mean < 3e-3, (mx, mean)
+    assert_close(lse_ref, lse7, 1e-4, 1e-3, "lse (8 waves)")
+    assert torch.equal(o7, o4) and torch.equal(lse7, lse4)
 
 
 @pytest.mark.parametrize("B,H,W,C,k", [(2, 64, 64, 768, 2), (1, 12, 20, 192, 4), (2, 6, 10, 128, 2)])
