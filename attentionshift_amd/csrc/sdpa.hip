@@ -278,6 +278,9 @@ __device__ __forceinline__ void lds_wait8(u32x2 (&v)[8]) {
 #ifndef AS_SDPA_NO_DEAD_SKIP
 #define AS_SDPA_NO_DEAD_SKIP 0    // 1: waves without a valid query row run the full pass (A/B of the round-4 skip)
 #endif
+#ifndef AS_SDPA_DOT2SUM
+#define AS_SDPA_DOT2SUM 0         // experiment: softmax row sums by v_dot2_f32_bf16 on the packed weights (8 per unit) instead of 16 adds
+#endif
 #ifndef AS_SDPA_ABLATE
 #define AS_SDPA_ABLATE 0          // timing experiments only (tools/experiments/sdpa_ablate.py): 1 no exp2, 2 no softmax
 #endif                            // VALU, 3 no P.V MFMAs, 4 no Q.K MFMAs, 5 no LDS-DMA in the loop, 6 no barrier (old
@@ -834,7 +837,7 @@ __global__ __launch_bounds__(64 * NW, NQ == 1 ? 3 : 2) void sdpa_fwd_pipe_kernel
             if (AS_SDPA_ABLATE == 11) p[r] = s_cur[r] * 0.5f;       // (timing experiments: 11 no exp2, 12 no softmax VALU)
             else if (AS_SDPA_ABLATE == 12) p[r] = s_cur[r];
             else p[r] = __builtin_amdgcn_exp2f(s_cur[r]);
-            if (AS_SDPA_ABLATE != 12) lp4[QB][r & 3] += p[r];
+            if (AS_SDPA_ABLATE != 12 && !AS_SDPA_DOT2SUM) lp4[QB][r & 3] += p[r];
           } else {
             p[r] = __builtin_amdgcn_exp2f(s_cur[r] - mc[QB]);
             ps[r & 3] = r < 4 ? p[r] : ps[r & 3] + p[r];
@@ -847,6 +850,15 @@ __global__ __launch_bounds__(64 * NW, NQ == 1 ? 3 : 2) void sdpa_fwd_pipe_kernel
         } else {
 #pragma unroll
           for (int r = 0; r < 16; ++r) p_cur[r >> 3][r & 7] = (__bf16)p[r];
+          if (AS_SDPA_DOT2SUM && FASTP) {                          // experiment: row sums of the bf16-ROUNDED weights, 8 v_dot2 per unit
+            typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+            const bf16x2_t ones = {(__bf16)1.0f, (__bf16)1.0f};
+#pragma unroll
+            for (int w_ = 0; w_ < 8; ++w_) {
+              const bf16x2_t pr = {p_cur[w_ >> 2][2 * (w_ & 3)], p_cur[w_ >> 2][2 * (w_ & 3) + 1]};
+              lp4[QB][w_ & 3] = __builtin_amdgcn_fdot2_f32_bf16(pr, ones, lp4[QB][w_ & 3], false);
+            }
+          }
         }
 
         if (I == 0) {
