@@ -46,7 +46,7 @@ def run(variants, B=2, N=4197, h=12):
         lib.as_sdpa_bwd.argtypes = [ctypes.c_void_p] * 8 + [ctypes.c_size_t] + [ctypes.c_int] * 4 + [ctypes.c_void_p]
         nb = lib.as_sdpa_bwd_workspace_bytes(B, N, h, 1)
         ws = torch.empty(nb, device="cuda", dtype=torch.uint8)
-        dqkv = torch.empty(B, N, 3 * D, device="cuda", dtype=torch.bfloat16)
+        dqkv = torch.full((B, N, 3 * D), float("nan"), device="cuda", dtype=torch.bfloat16)   # unwritten rows show
         st = torch.cuda.current_stream().cuda_stream
         call = lambda: lib.as_sdpa_bwd(q.data_ptr(), k.data_ptr(), vt.data_ptr(), o.data_ptr(), d_o.data_ptr(), lse.data_ptr(),
                                        dqkv.data_ptr(), ws.data_ptr(), nb, B, N, h, 1, st)
@@ -76,5 +76,9 @@ if __name__ == "__main__":
         ap = argparse.ArgumentParser()
         ap.add_argument("cmd")
         ap.add_argument("--variants", default="base")
+        ap.add_argument("--shapes", default="2x4197x12", help="comma list of BxNxh")
         a = ap.parse_args()
-        run(a.variants.split(","))
+        for shp in a.shapes.split(","):
+            B, N, h = (int(v) for v in shp.split("x"))
+            print(f"--- B={B} N={N} h={h}", flush=True)
+            run(a.variants.split(","), B, N, h)
