@@ -1018,7 +1018,7 @@ __device__ __forceinline__ void lds_frag_tr3(Frag<__bf16>& f, bw_lds_ptr p0, bw_
 constexpr int T3_A = 0, T3_B = 8192, T3_ST = 16384;
 constexpr int T3_DKV_STAGE = 16896, T3_DQ_STAGE = 16384;
 #ifndef AS_BWD_ABLATE
-#define AS_BWD_ABLATE 0                      // (timing experiments only: 1 no DMA in the loop, 2 no barrier)
+#define AS_BWD_ABLATE 0                      // (timing experiments only: 1 no DMA in the loop, 2 no barrier, 3 packs only, 4 no VALU in E)
 #endif
 constexpr int T3_ABL = AS_BWD_ABLATE;
 
@@ -1168,6 +1168,8 @@ __global__ __launch_bounds__(BW_NT, 2) void sdpa_bwd_dkv_tr_kernel(const __bf16*
         unsigned wp[8], wd[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
+          if (T3_ABL == 3) { wp[j] = t3_pack(sacc[2 * j], sacc[2 * j + 1]); wd[j] = t3_pack(pacc[2 * j], pacc[2 * j + 1]); continue; }
+          if (T3_ABL == 4) { wp[j] = __float_as_uint(sacc[2 * j]); wd[j] = __float_as_uint(pacc[2 * j + 1]); continue; }
           const float p0 = __builtin_amdgcn_exp2f(sacc[2 * j]), p1 = __builtin_amdgcn_exp2f(sacc[2 * j + 1]);
           wp[j] = t3_pack(p0, p1);
           wd[j] = t3_pack(p0 * pacc[2 * j], p1 * pacc[2 * j + 1]);
@@ -1313,6 +1315,8 @@ __global__ __launch_bounds__(BW_NT, 2) void sdpa_bwd_dq_tr_kernel(const __bf16* 
           unsigned wd[8];
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
+            if (T3_ABL == 3) { wd[j] = t3_pack(sacc[2 * j] + pacc[2 * j], sacc[2 * j + 1] + pacc[2 * j + 1]); continue; }
+            if (T3_ABL == 4) { wd[j] = __float_as_uint(sacc[2 * j]) ^ __float_as_uint(pacc[2 * j + 1]); continue; }
             float d0 = __builtin_amdgcn_exp2f(sacc[2 * j]) * pacc[2 * j], d1 = __builtin_amdgcn_exp2f(sacc[2 * j + 1]) * pacc[2 * j + 1];
             if (RAGGED) {                      // padded key rows
               if (t * BW_TILE + kb * 32 + pi_acc_row(2 * j, half) >= N) d0 = 0.0f;
@@ -1438,12 +1442,12 @@ int launch_bwd(const void* q, const void* k, const void* vt, const void* o, cons
           attr = true;
         }
         // (workspace slots under ROWM: dof = dO rows, qt = q rows, kt = k rows)
-        static const int only = getenv("AS_BWD_ONLY") ? atoi(getenv("AS_BWD_ONLY")) : 0;      // (timing experiments: 1 dK/dV, 2 dQ)
-        if (only != 2)
+        static const int only = getenv("AS_BWD_ONLY") ? atoi(getenv("AS_BWD_ONLY")) : 0;      // (timing experiments: 1 dK/dV, 2 dQ, 3 the prep kernel alone)
+        if (only != 2 && only != 3)
         hipLaunchKernelGGL((sdpa_bwd_dkv_tr_kernel<NSTK>), dim3(BH * tiles), dim3(BW_NT), lds_k, s, (const __bf16*)qt, (const __bf16*)dof,
                            (const __bf16*)k, (const __bf16*)vrow, (const float*)lse2, (const float*)delta, (__bf16*)dqkv, B, N, Npad, h);
         AS_CHECK_LAUNCH("sdpa_bwd_dkv_tr");
-        if (only != 1)
+        if (only != 1 && only != 3)
         hipLaunchKernelGGL((sdpa_bwd_dq_tr_kernel<NSTQ>), dim3(BH * tiles), dim3(BW_NT), lds_q, sq, (const __bf16*)qt, (const __bf16*)dof,
                            (const __bf16*)kt, (const __bf16*)vrow, lse, (const float*)delta, (__bf16*)dqkv, B, N, Npad, h);
         AS_CHECK_LAUNCH("sdpa_bwd_dq_tr");

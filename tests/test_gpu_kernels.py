@@ -500,6 +500,44 @@ def test_sdpa_bwd_full_size_properties(ops):
     assert ((lhs - rhs).abs().max().item() / scale) < 3e-2, (lhs, rhs)
 
 
+@pytest.mark.parametrize("B,N,h", [(2, 4197, 12), (1, 6501, 16), (2, 197, 3), (1, 64, 2), (3, 65, 1)])
+def test_sdpa_bwd_transposing_reads_equal_the_transposed_copy_kernels(ops, B, N, h):
+    """as_sdpa_bwd's two bf16 routes against each other: round 4's kernels (one row-major tile image per operand, column
+    fragments through ds_read_b64_tr_b16, row statistics as MFMA C operands) and round 3's (q^T / k^T / dO^T copies;
+    AS_BWD_TR=0, read once per process: a child process).  Same tiles, same order of the sums; the only arithmetic
+    difference is where -lse2 / -delta enter (C operand instead of a subtraction after the MFMA), so a P or dS may round to
+    the neighbouring bf16: 5e-3 of each gradient's range (measured 2.6e-3 / 3.3e-3 at the ViT-B / ViT-L sizes).  NaN in
+    the padded rows of the workspaces must not leak on either route."""
+    import subprocess, sys, os
+    g = torch.Generator().manual_seed(5 * N + h)
+    x, wqkv, bqkv, _, _ = _attn_inputs(B, N, h, 5 * N + h, scale=2.0)
+    d_o = torch.randn(B, N, 64 * h, generator=g)
+    path = "/tmp/as_bwd_route_%d_%d_%d.pt" % (B, N, h)
+    torch.save((x, wqkv, bqkv, d_o), path + ".in")
+    code = """
+import sys, torch
+sys.path.insert(0, {root!r})
+from attentionshift_amd import ops
+x, wqkv, bqkv, d_o = torch.load({inp!r})
+q, k, vt = ops.qkv_fwd(x.bfloat16().cuda(), wqkv.bfloat16().cuda(), bqkv.cuda(), {h})
+k[:, :, {N}:] = float('nan'); vt[:, :, :, {N}:] = float('nan')
+o, lse = ops.sdpa_fwd(q, k, vt, {N})
+out = ops.sdpa_bwd(q, k, vt, o, d_o.bfloat16().cuda(), lse, {N})
+torch.save(out.cpu(), {outp!r})
+""".format(root=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), inp=path + ".in", h=h, N=N, outp=path)
+    outs = []
+    for env in ({"AS_BWD_TR": "0"}, {}):
+        cp = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert cp.returncode == 0, cp.stderr[-2000:]
+        outs.append(torch.load(path).float())
+    old, new = outs
+    assert torch.isfinite(old).all() and torch.isfinite(new).all()
+    o3, n3 = old.reshape(B, N, 3, h * 64), new.reshape(B, N, 3, h * 64)
+    for i, name in enumerate(("dq", "dk", "dv")):
+        rng = float(o3[:, :, i].abs().max())
+        assert float((o3[:, :, i] - n3[:, :, i]).abs().max()) <= 5e-3 * rng, (name, float((o3[:, :, i] - n3[:, :, i]).abs().max()) / rng)
+
+
 @pytest.mark.parametrize("B,N,h", [(2, 297, 3), (1, 130, 2)])
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-4), (torch.bfloat16, 4e-2)])
 def test_attention_module_bwd_matches_autograd(ops, dtype, tol, B, N, h):
