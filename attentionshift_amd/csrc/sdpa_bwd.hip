@@ -12,8 +12,9 @@
 //   dQ = dS K            dK = dS^T Q
 //
 // Three kernels, no atomics, fixed summation order (bit-reproducible run to run):
-//   bwd_prep      : delta, a fragment-major copy of dO, and the transposed copies (q^T, k^T, dO^T) / row-major v that
-//                   the MFMAs below need as k-contiguous A operands.
+//   bwd_prep      : delta, lse in base-2 units, row-major v; for the bf16 kernels of round 4 (sdpa_bwd_*_tr_kernel, the
+//                   default) zero-padded row-major q / k / dO, for the fp32 parity path and AS_BWD_TR=0 a fragment-major
+//                   copy of dO and the transposed copies (q^T, k^T, dO^T) those kernels need as k-contiguous A operands.
 //   bwd_dq        : one workgroup = 128 queries (a lane owns ONE query), loops over 64-key tiles.
 //   bwd_dkv       : one workgroup = 128 keys    (a lane owns ONE key),   loops over 64-query tiles.
 // As in the forward every MFMA is "swapped" so the lane that owns a query (key) keeps its column through the whole
