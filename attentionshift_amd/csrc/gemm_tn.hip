@@ -106,7 +106,7 @@ __global__ __launch_bounds__(TN_NT, TN_NSTAGE == 4 ? 2 : 3) void gemm_tn_splitk_
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
   // bias gradient: db[n] = sum_m dY[m][n] falls out of the dY fragments -- the workgroups of the first k tile (wave column 0)
-  // add up the eight token values every fragment holds; partial per token range, summed in range order by tn_db_reduce
+  // add up the eight token values every fragment holds; partial per token range, summed in range order by the bias blocks of tn_reduce_kernel
   const bool want_db = db_part != nullptr && (tile % nt_k) == 0 && wn == 0;
   float dbacc[2] = {0.0f, 0.0f};
   stage(0, 0);
@@ -209,10 +209,22 @@ __global__ __launch_bounds__(TN_NT, TN_NSTAGE == 4 ? 2 : 3) void gemm_tn_splitk_
   }
 }
 
+// The last `db_blocks` workgroups of the grid sum the bias-gradient partials instead ([S][C] -> [C]; same fixed order): one
+// launch for both reductions (the separate 5 us bias launch was 83 launches = 0.47 ms of the training step).
 template <typename T>
 __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ part, T* __restrict__ out, size_t n4, int S,
-                                                        size_t stride) {
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+                                                        size_t stride, const float* __restrict__ db_part, float* __restrict__ db,
+                                                        int C, int db_blocks) {
+  const int main_blocks = (int)gridDim.x - db_blocks;
+  if ((int)blockIdx.x >= main_blocks) {
+    const int c = ((int)blockIdx.x - main_blocks) * 256 + threadIdx.x;
+    if (c >= C) return;
+    float sum = 0.0f;
+    for (int i = 0; i < S; ++i) sum += db_part[(size_t)i * C + c];
+    db[c] = sum;
+    return;
+  }
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)main_blocks * blockDim.x) {
     float4 a = *reinterpret_cast<const float4*>(part + i * 4);
     for (int sp = 1; sp < S; ++sp) {
       const float4 b = *reinterpret_cast<const float4*>(part + sp * stride + i * 4);
@@ -225,14 +237,6 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict_
       *reinterpret_cast<float4*>(out + i * 4) = a;
     }
   }
-}
-
-__global__ __launch_bounds__(256) void tn_db_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int C, int S) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
-  float s = 0.0f;
-  for (int i = 0; i < S; ++i) s += part[(size_t)i * C + c];
-  out[c] = s;
 }
 
 // fp32 column sums of a bf16 matrix [R, C] (C % 8 == 0) with 16-byte loads: thread = 8 columns x every 8th row of a slice,
@@ -328,15 +332,14 @@ int as_tn_dw(const void* dy, const void* x, void* dW, float* db, float* db_part,
   AS_CHECK_LAUNCH("gemm_tn_splitk");
   const size_t n4 = (size_t)Nout * K / 4;
   const int grid = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+  const int db_blocks = db ? as_ceil_div(Nout, 256) : 0;
   if (dw_f32)
-    hipLaunchKernelGGL(tn_reduce_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)ws, (float*)dW, n4, S, (size_t)Nout * K);
+    hipLaunchKernelGGL(tn_reduce_kernel<float>, dim3(grid + db_blocks), dim3(256), 0, s, (const float*)ws, (float*)dW, n4, S,
+                       (size_t)Nout * K, (const float*)db_part, db, Nout, db_blocks);
   else
-    hipLaunchKernelGGL(tn_reduce_kernel<__bf16>, dim3(grid), dim3(256), 0, s, (const float*)ws, (__bf16*)dW, n4, S, (size_t)Nout * K);
+    hipLaunchKernelGGL(tn_reduce_kernel<__bf16>, dim3(grid + db_blocks), dim3(256), 0, s, (const float*)ws, (__bf16*)dW, n4, S,
+                       (size_t)Nout * K, (const float*)db_part, db, Nout, db_blocks);
   AS_CHECK_LAUNCH("tn_reduce");
-  if (db) {
-    hipLaunchKernelGGL(tn_db_reduce_kernel, dim3(as_ceil_div(Nout, 256)), dim3(256), 0, s, (const float*)db_part, db, Nout, S);
-    AS_CHECK_LAUNCH("tn_db_reduce");
-  }
   return AS_OK;
 }
 
