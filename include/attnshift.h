@@ -13,7 +13,11 @@
  *   - no ownership transfer: inputs, outputs and workspaces are caller-allocated
  *     (sizes through as_*_workspace_bytes); workspaces need no initialisation.
  *   - asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream); re-entrant;
- *     no global mutable state.
+ *     no global mutable state.  as_sdpa_bwd (bf16) runs one of its kernels on a library-owned helper stream
+ *     (per host thread and device, created on first use and freed at thread exit) that is forked from and joined
+ *     back to `stream` with events: to the caller everything is ordered on `stream`, but the first call on a thread
+ *     creates a stream (not legal inside a stream capture -- warm up before capturing), and a per-stream allocator
+ *     must treat the workspace and dqkv as in use until work queued on `stream` after the call has run.
  *   - dtype: AS_F32 = exact fp32 MFMA path (parity), AS_BF16 = bf16 operands with fp32 accumulate.
  *     Biases, log-sum-exp, roll-out matrices and all of Part B are always fp32; indices int32.
  */
@@ -91,7 +95,8 @@ int as_sdpa_fwd(const void* q, const void* k, const void* vt, void* o, float* ls
  * recomputed from q, k and lse; no [h,N,N] buffer, no atomics, fixed summation order.
  *   q,k,vt,lse : as written by as_qkv_fwd / as_sdpa_fwd           o, d_o : [B,N,h*64] (forward output, its gradient)
  *   dqkv       : [B,N,3,h,64] = gradient of the QKV projection output in the reference's reshape order (:76)
- *   workspace  : as_sdpa_bwd_workspace_bytes(B,N,h,dtype) bytes, caller-owned */
+ *   workspace  : as_sdpa_bwd_workspace_bytes(B,N,h,dtype) bytes, caller-owned
+ * Rows [N, Npad) of q / k / vt may hold anything (NaN included): nothing outside [0, N) reaches a gradient. */
 size_t as_sdpa_bwd_workspace_bytes(int B, int N, int h, int dtype);
 int as_sdpa_bwd(const void* q, const void* k, const void* vt, const void* o, const void* d_o, const float* lse,
                 void* dqkv, void* workspace, size_t workspace_bytes, int B, int N, int h, int dtype,
