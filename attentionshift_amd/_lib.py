@@ -19,6 +19,8 @@ SIGNATURES = {
     "as_last_error": (ctypes.c_char_p, []),
     "as_npad": (_c_int, [_c_int]),
     "as_linear_fwd": (_c_int, [_c_void_p] * 4 + [_c_int] * 5 + [_c_void_p]),
+    "as_linear_gelu_fwd": (_c_int, [_c_void_p] * 5 + [_c_int] * 4 + [_c_void_p]),
+    "as_linear_dgelu_fwd": (_c_int, [_c_void_p] * 4 + [_c_int] * 4 + [_c_void_p]),
     "as_deconv2x2_fwd": (_c_int, [_c_void_p] * 4 + [_c_int] * 6 + [_c_void_p]),
     "as_qkv_fwd": (_c_int, [_c_void_p] * 6 + [_c_int] * 5 + [_c_void_p]),
     "as_sdpa_fwd_workspace_bytes": (_c_size_t, [_c_int] * 4),
@@ -38,6 +40,7 @@ SIGNATURES = {
     "as_linear_splitk_fwd": (_c_int, [_c_void_p] * 3 + [_c_int] * 5 + [_c_void_p, ctypes.c_size_t, _c_void_p]),
     "as_linear_bwd_workspace_bytes": (ctypes.c_size_t, [_c_int] * 3),
     "as_linear_bwd": (_c_int, [_c_void_p] * 6 + [_c_int] * 5 + [_c_void_p, ctypes.c_size_t, _c_void_p]),
+    "as_linear_bwd_dgelu": (_c_int, [_c_void_p] * 7 + [_c_int] * 5 + [_c_void_p, ctypes.c_size_t, _c_void_p]),
     "as_maxpool_nhwc": (_c_int, [_c_void_p] * 2 + [_c_int] * 5 + [ctypes.c_longlong, _c_void_p]),
     "as_mask_count": (_c_int, [_c_void_p] * 2 + [_c_int] * 2 + [_c_void_p]),
     "as_window_attn_bwd_workspace_bytes": (_c_size_t, [_c_int] * 5),

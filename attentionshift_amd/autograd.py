@@ -11,6 +11,7 @@ import torch
 
 from . import ops
 
+_UNFUSED_MLP = bool(os.environ.get("AS_MLP_UNFUSED"))           # A/B switch: fc1 -> F.gelu -> fc2 as three autograd nodes
 _LIBRARY_LINEAR = bool(os.environ.get("AS_LINEAR_LIBRARY"))     # A/B switch: leave every nn.Linear to the library GEMMs
 
 
@@ -70,6 +71,46 @@ class LinearFn(torch.autograd.Function):
         need_db = b_dtype is not None and ctx.needs_input_grad[2]
         dx, dw, db = ops.linear_bwd(x2, wb, dy2, ctx.needs_input_grad[0], ctx.needs_input_grad[1], need_db, dw_dtype=w_dtype)
         return (None if dx is None else dx.view(shape), dw, None if db is None else db.to(b_dtype))
+
+
+class MlpFn(torch.autograd.Function):
+    """fc2(GELU(fc1(x))) as ONE autograd node (models/vision_transformer.py:47-59): the GELU runs in fc1's epilogue
+    (as_linear_gelu_fwd writes the bf16 pre-activation and its GELU), its derivative in the epilogue of fc2's input-gradient
+    GEMM (as_linear_bwd_dgelu) -- no activation pass in either direction (ATen's GeluBackward alone moved 155 MB per
+    ViT-B layer).  Same rounding points as LinearFn -> F.gelu -> LinearFn: h, GELU(h) and every gradient are bf16 tensors."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        x2 = x.reshape(-1, x.shape[-1]).contiguous()
+        cast = lambda w: (w if w.dtype == torch.bfloat16 else w.to(torch.bfloat16)).contiguous()    # noqa: E731
+        w1b, w2b = cast(w1), cast(w2)
+        a, pre = ops.linear_gelu(x2, w1b, None if b1 is None else b1.float())
+        y = ops.linear(a, w2b, None if b2 is None else b2.float())
+        ctx.save_for_backward(x2, w1b, w2b, pre, a)
+        ctx.meta = (x.shape, w1.dtype, None if b1 is None else b1.dtype, w2.dtype, None if b2 is None else b2.dtype)
+        return y.view(*x.shape[:-1], w2.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w1b, w2b, pre, a = ctx.saved_tensors
+        shape, w1_dtype, b1_dtype, w2_dtype, b2_dtype = ctx.meta
+        dy2 = dy.reshape(-1, dy.shape[-1])
+        dy2 = (dy2 if dy2.dtype == torch.bfloat16 else dy2.to(torch.bfloat16)).contiguous()
+        need = ctx.needs_input_grad
+        dpre, dw2, db2 = ops.linear_bwd(a, w2b, dy2, True, need[3], b2_dtype is not None and need[4], dw_dtype=w2_dtype,
+                                        gelu_pre=pre)
+        dx, dw1, db1 = ops.linear_bwd(x2, w1b, dpre, need[0], need[1], b1_dtype is not None and need[2], dw_dtype=w1_dtype)
+        return (None if dx is None else dx.view(shape), dw1, None if db1 is None else db1.to(b1_dtype), dw2,
+                None if db2 is None else db2.to(b2_dtype))
+
+
+def mlp(x, w1, b1, w2, b2):
+    """The transformer MLP under autograd on the HIP kernels in bf16 (MlpFn)."""
+    return MlpFn.apply(x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16), w1, b1, w2, b2)
+
+
+def mlp_applies(x, w1, w2):
+    return linear_applies(x, w1) and w2.shape[0] % 32 == 0 and not _UNFUSED_MLP
 
 
 def linear(x, weight, bias=None):
@@ -186,7 +227,7 @@ class DecoderBlockFn(torch.autograd.Function):
         x1 = x + delta;  y = LN1(x1);  a = proj(attn(qkv(y)));  x2 = x1 + a;  z = LN2(x2);  out_delta = fc2(gelu(fc1(z)))
 
     forward(x fp32 [R,N,C], delta bf16 | None, 12 parameters, eps1, eps2, num_heads) -> (x2 fp32, out_delta bf16).  The same
-    kernels as the per-op bridges (AddLayerNormFn, LinearFn, SmallAttnFn) in the same order, so values and gradients are
+    kernels as the per-op bridges (AddLayerNormFn, LinearFn, MlpFn, SmallAttnFn) in the same order, so values and gradients are
     theirs bit for bit; what goes away is seven `Function.apply` calls and autograd nodes per block and direction -- the RoI
     head's loss phase was host-bound on them (6.2 ms of host for ~3 ms of device work per training step)."""
 
@@ -203,8 +244,11 @@ class DecoderBlockFn(torch.autograd.Function):
         o, lse = ops.small_attention_fwd(qkv)
         a = ops.linear(o.reshape(R * N, C), wpb, f(bp)).reshape(R, N, C)
         x2, z = ops.add_layernorm(x1, a, g2f, f(b2), eps2, bf)
-        h = ops.linear(z.reshape(R * N, C), w1b, f(bf1))
-        hg = torch.nn.functional.gelu(h)
+        if _UNFUSED_MLP:
+            h = ops.linear(z.reshape(R * N, C), w1b, f(bf1))
+            hg = torch.nn.functional.gelu(h)
+        else:
+            hg, h = ops.linear_gelu(z.reshape(R * N, C), w1b, f(bf1))        # GELU in fc1's epilogue (MlpFn's kernels)
         d = ops.linear(hg, w2b, f(bf2)).reshape(R, N, C)
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(x1, y, qkv, o, lse, x2, z, h, hg, wqb, wpb, w1b, w2b, g1f, g2f)
@@ -223,8 +267,12 @@ class DecoderBlockFn(torch.autograd.Function):
         dz = dw2 = db2 = dw1 = db1 = None
         if dd is not None:
             dd2 = dd.to(bf).reshape(M, C).contiguous()
-            dhg, dw2, db2 = ops.linear_bwd(hg, w2b, dd2, True, need[12], need[13] and dts[11] is not None, dw_dtype=dts[10])
-            dh = torch.ops.aten.gelu_backward(dhg, h)
+            if _UNFUSED_MLP:
+                dhg, dw2, db2 = ops.linear_bwd(hg, w2b, dd2, True, need[12], need[13] and dts[11] is not None, dw_dtype=dts[10])
+                dh = torch.ops.aten.gelu_backward(dhg, h)
+            else:                                       # GELU' in the epilogue of fc2's input-gradient GEMM
+                dh, dw2, db2 = ops.linear_bwd(hg, w2b, dd2, True, need[12], need[13] and dts[11] is not None, dw_dtype=dts[10],
+                                              gelu_pre=h)
             dz, dw1, db1 = ops.linear_bwd(z.reshape(M, C), w1b, dh, True, need[10], need[11] and dts[9] is not None, dw_dtype=dts[8])
             dz = dz.reshape(R, N, C)
         if dz is None and dx2 is None:

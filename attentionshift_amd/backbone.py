@@ -383,8 +383,8 @@ class VisionTransformerDet(nn.Module):
     def _block_train(self, blk, x, delta, i, sink, delta_scale=None):
         """Block.forward under autograd with the residual stream in fp32 and the residual adds fused into the LayerNorms in
         BOTH directions (autograd.AddLayerNormFn: as_add_layernorm / as_add_layernorm_bwd).  Attention =
-        autograd.AttentionFn (as_attn_fwd / as_attn_bwd); the MLP GEMMs + GELU are torch ops (library GEMMs, SURVEY
-        8a/A4).  `delta` = the previous block's MLP output not yet added; returns (x, this block's pending MLP output)."""
+        autograd.AttentionFn (as_attn_fwd / as_attn_bwd); the MLP = autograd.MlpFn (GELU and its derivative in the GEMM
+        epilogues; library GEMMs + F.gelu only outside a bf16 region).  `delta` = the previous block's MLP output not yet added; returns (x, this block's pending MLP output)."""
         from . import autograd as AG
         cd = self.compute_dtype
         sh = self._train_shadow                          # compute-dtype copies of the blocks' GEMM parameters (forward())
@@ -395,8 +395,11 @@ class VisionTransformerDet(nn.Module):
         a = AG.attention(y, w(blk.attn.qkv.weight), None if blk.attn.qkv.bias is None else blk.attn.qkv.bias.float(),
                          w(blk.attn.proj.weight), blk.attn.proj.bias.float(), self.num_heads, sink)
         x, z = AG.add_layernorm(x, a, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps, cd, self._drop_scale(x.shape[0], i, x.device))
-        if AG.linear_applies(z, w(blk.mlp.fc1.weight)):
-            z = F.gelu(AG.linear(z, w(blk.mlp.fc1.weight), blk.mlp.fc1.bias))          # fp32 master biases: db stays fp32
+        if AG.mlp_applies(z, w(blk.mlp.fc1.weight), w(blk.mlp.fc2.weight)):
+            # one autograd node, GELU / GELU' in the GEMM epilogues (autograd.MlpFn); fp32 master biases: db stays fp32
+            z = AG.mlp(z, w(blk.mlp.fc1.weight), blk.mlp.fc1.bias, w(blk.mlp.fc2.weight), blk.mlp.fc2.bias)
+        elif AG.linear_applies(z, w(blk.mlp.fc1.weight)):
+            z = F.gelu(AG.linear(z, w(blk.mlp.fc1.weight), blk.mlp.fc1.bias))
             z = AG.linear(z, w(blk.mlp.fc2.weight), blk.mlp.fc2.bias)
         else:
             z = F.gelu(F.linear(z, w(blk.mlp.fc1.weight), w(blk.mlp.fc1.bias)))

@@ -264,7 +264,16 @@ extern "C" size_t as_linear_bwd_workspace_bytes(int M, int Nout, int K) {
 
 extern "C" int as_linear_bwd(const void* x, const void* W, const void* dy, void* dx, void* dW, float* db, int M, int Nout,
                              int K, int dtype, int dw_f32, void* workspace, size_t workspace_bytes, as_stream_t stream) {
+  return as_linear_bwd_dgelu(x, W, dy, nullptr, dx, dW, db, M, Nout, K, dtype, dw_f32, workspace, workspace_bytes, stream);
+}
+
+// as_linear_bwd whose input gradient is multiplied by gelu'(pre) in the GEMM's epilogue (pre [M,K] = the pre-activation the
+// linear's input was the GELU of; NULL = plain as_linear_bwd): dx is then the gradient of the PRE-activation
+extern "C" int as_linear_bwd_dgelu(const void* x, const void* W, const void* dy, const void* pre, void* dx, void* dW, float* db,
+                                   int M, int Nout, int K, int dtype, int dw_f32, void* workspace, size_t workspace_bytes,
+                                   as_stream_t stream) {
   AS_REQUIRE(dy && workspace && (dx || dW || db), AS_E_BADARG, "as_linear_bwd: null pointer");
+  AS_REQUIRE(!pre || (dx && K % 8 == 0 && Nout % 32 == 0), AS_E_BADARG, "as_linear_bwd_dgelu: pre needs dx, K %% 8 == 0");
   AS_REQUIRE(!dx || W, AS_E_BADARG, "as_linear_bwd: dx needs W");
   AS_REQUIRE(!dW || x, AS_E_BADARG, "as_linear_bwd: dW needs x");
   AS_REQUIRE(dtype == AS_BF16, AS_E_UNSUPPORTED, "as_linear_bwd: bf16 operands only (dtype %d)", dtype);
@@ -279,7 +288,9 @@ extern "C" int as_linear_bwd(const void* x, const void* W, const void* dy, void*
   int rc;
   if (dx) {
     if ((rc = transpose_pad<__bf16>(W, ws + L.off_WT, Nout, K, Nout, s)) != AS_OK) return rc;        // [Nout,K] -> [K,Nout]
-    if ((rc = as_linear_fwd(dy, ws + L.off_WT, nullptr, dx, M, K, Nout, dtype, 0, s)) != AS_OK) return rc;
+    if (pre) rc = as_linear_dgelu_fwd(dy, ws + L.off_WT, pre, dx, M, K, Nout, dtype, s);
+    else rc = as_linear_fwd(dy, ws + L.off_WT, nullptr, dx, M, K, Nout, dtype, 0, s);
+    if (rc != AS_OK) return rc;
   }
   // dW = dy^T . x straight from the row-major activations (csrc/gemm_tn.hip: transposing LDS reads) when the feature counts
   // are 128-aligned; otherwise (and with AS_BWD_TRANSPOSED=1) through transposed, zero-padded copies as in round 3

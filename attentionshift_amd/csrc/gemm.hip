@@ -42,6 +42,46 @@ __device__ __forceinline__ float gelu_bf16(float x) {
   return 0.5f * x + 0.5f * fabsf(x) * e;
 }
 
+// d/dx of the erf-GELU with the same erf: 0.5 (1 + erf(x / sqrt 2)) + x exp(-x^2 / 2) / sqrt(2 pi)
+__device__ __forceinline__ float gelu_grad_bf16(float x) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float g = __builtin_amdgcn_exp2f(-z * z * 1.44269504088896340736f);                   // exp(-x^2 / 2)
+  const float e = 1.0f - p * t * g;                                                            // erf(|x| / sqrt 2)
+  return 0.5f + copysignf(0.5f * e, x) + x * g * 0.39894228040143267794f;
+}
+// the two training-path epilogues of the bf16 LDS-DMA kernel, applied to a staged 16-byte chunk (8 bf16) at copy-out:
+//   act 2: the chunk is the PRE-activation h: write it to `pre` and gelu(h) to out     (fc1 under autograd)
+//   act 3: the chunk is dA; out = dA * gelu'(h) with h read from `pre`                 (fc2's input gradient)
+typedef __attribute__((ext_vector_type(2))) __bf16 g_bf16x2;
+__device__ __forceinline__ uint4 gelu_chunk(uint4 hv) {
+  const uint32_t w[4] = {hv.x, hv.y, hv.z, hv.w};
+  uint32_t r[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float a = gelu_bf16(__uint_as_float(w[j] << 16)), b = gelu_bf16(__uint_as_float(w[j] & 0xffff0000u));
+    const g_bf16x2 pk = {(__bf16)a, (__bf16)b};
+    r[j] = __builtin_bit_cast(uint32_t, pk);
+  }
+  return make_uint4(r[0], r[1], r[2], r[3]);
+}
+__device__ __forceinline__ uint4 dgelu_chunk(uint4 dv, uint4 hv) {
+  const uint32_t d[4] = {dv.x, dv.y, dv.z, dv.w}, w[4] = {hv.x, hv.y, hv.z, hv.w};
+  uint32_t r[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float a = __uint_as_float(d[j] << 16) * gelu_grad_bf16(__uint_as_float(w[j] << 16));
+    const float b = __uint_as_float(d[j] & 0xffff0000u) * gelu_grad_bf16(__uint_as_float(w[j] & 0xffff0000u));
+    const g_bf16x2 pk = {(__bf16)a, (__bf16)b};
+    r[j] = __builtin_bit_cast(uint32_t, pk);
+  }
+  return make_uint4(r[0], r[1], r[2], r[3]);
+}
+
 // accumulators -> memory.  MODE 0: row-major out (+bias, +GELU).  MODE 1: q,k [B,h,Npad,64] and V^T [B,h,64,Npad].
 template <typename T, int MODE>
 __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[2][2], const bool (&swapped)[2], const float* __restrict__ bias,
@@ -522,7 +562,13 @@ __global__ __launch_bounds__(64 * WM * WN, (WN == 4 || KS == 4) ? 1 : (WM == 2 ?
       const int tap = col / epi.D, co = col - tap * epi.D;
       *reinterpret_cast<uint4*>(out + ((size_t)(2 * bi + (tap >> 1)) * (2 * epi.N) + 2 * j + (tap & 1)) * epi.D + co) = v;
     } else if (MODE == 0) {
-      if (col + 8 <= Nout) {
+      if (act == 2) {                                  // (Nout % 8 == 0 on this path: as_linear_gelu_fwd)
+        *reinterpret_cast<uint4*>(reinterpret_cast<__bf16*>(epi.q) + (size_t)row * Nout + col) = v;
+        *reinterpret_cast<uint4*>(out + (size_t)row * Nout + col) = gelu_chunk(v);
+      } else if (act == 3) {
+        const uint4 hv = *reinterpret_cast<const uint4*>(reinterpret_cast<const __bf16*>(epi.q) + (size_t)row * Nout + col);
+        *reinterpret_cast<uint4*>(out + (size_t)row * Nout + col) = dgelu_chunk(v, hv);
+      } else if (col + 8 <= Nout) {
         *reinterpret_cast<uint4*>(out + (size_t)row * Nout + col) = v;
       } else {
         const __bf16* e = reinterpret_cast<const __bf16*>(smem + rr * G_EPI_PITCH + ch * 16);
@@ -708,6 +754,26 @@ extern "C" int as_linear_fwd(const void* x, const void* W, const float* bias, vo
   if (dtype == AS_BF16) return launch_gemm<__bf16, 0>(x, W, bias, out, M, Nout, K, act, epi, s);
   if (dtype == AS_F32) return launch_gemm<float, 0>(x, W, bias, out, M, Nout, K, act, epi, s);
   AS_REQUIRE(false, AS_E_UNSUPPORTED, "as_linear_fwd: dtype %d", dtype);
+}
+
+extern "C" int as_linear_gelu_fwd(const void* x, const void* W, const float* bias, void* out, void* pre, int M, int Nout, int K,
+                                  int dtype, as_stream_t stream) {
+  AS_REQUIRE(x && W && out && pre, AS_E_BADARG, "as_linear_gelu_fwd: null pointer");
+  AS_REQUIRE(M > 0 && Nout > 0 && K > 0 && K % GK == 0 && Nout % 8 == 0, AS_E_BADARG,
+             "as_linear_gelu_fwd: need M > 0, K %% 32 == 0, Nout %% 8 == 0 (Nout=%d K=%d)", Nout, K);
+  AS_REQUIRE(dtype == AS_BF16, AS_E_UNSUPPORTED, "as_linear_gelu_fwd: bf16 only (dtype %d)", dtype);
+  QkvEpi epi{pre, nullptr, nullptr, 0, 0, 0, 0};
+  return launch_gemm_glds<0>(x, W, bias, out, M, Nout, K, 2, epi, (hipStream_t)stream);
+}
+
+extern "C" int as_linear_dgelu_fwd(const void* x, const void* W, const void* pre, void* out, int M, int Nout, int K, int dtype,
+                                   as_stream_t stream) {
+  AS_REQUIRE(x && W && out && pre, AS_E_BADARG, "as_linear_dgelu_fwd: null pointer");
+  AS_REQUIRE(M > 0 && Nout > 0 && K > 0 && K % GK == 0 && Nout % 8 == 0, AS_E_BADARG,
+             "as_linear_dgelu_fwd: need M > 0, K %% 32 == 0, Nout %% 8 == 0 (Nout=%d K=%d)", Nout, K);
+  AS_REQUIRE(dtype == AS_BF16, AS_E_UNSUPPORTED, "as_linear_dgelu_fwd: bf16 only (dtype %d)", dtype);
+  QkvEpi epi{const_cast<void*>(pre), nullptr, nullptr, 0, 0, 0, 0};
+  return launch_gemm_glds<0>(x, W, nullptr, out, M, Nout, K, 3, epi, (hipStream_t)stream);
 }
 
 extern "C" int as_deconv2x2_fwd(const void* x, const void* W4, const float* bias4, void* out, int M, int w, int cin, int cout,

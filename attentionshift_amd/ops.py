@@ -121,6 +121,29 @@ def linear(x, weight, bias=None, act="none"):
     return out.reshape(*x.shape[:-1], weight.shape[0])
 
 
+def linear_gelu(x, weight, bias=None):
+    """The Mlp's fc1 under autograd: (GELU(h), h) with h = x @ weight.T + bias rounded to bf16, both written by the GEMM's
+    epilogue (as_linear_gelu_fwd).  x [M,K] bf16, weight [Nout,K] bf16, bias fp32 | None."""
+    lib = _lib.load()
+    _chk(x, weight, dtype=torch.bfloat16)
+    if bias is not None:
+        _chk(bias, dtype=torch.float32)
+    M, K = x.shape
+    Nout = weight.shape[0]
+    if weight.shape[1] != K:
+        raise AttnShiftError("linear_gelu: weight must be [Nout, K]")
+    out = torch.empty(M, Nout, device=x.device, dtype=torch.bfloat16)
+    pre = torch.empty_like(out)
+    _lib.check(lib.as_linear_gelu_fwd(_p(x), _p(weight), _p(bias), _p(out), _p(pre), M, Nout, K, AS_BF16, _stream()),
+               "as_linear_gelu_fwd")
+    return out, pre
+
+
+def linear_gelu_applies(x, weight):
+    """Sizes as_linear_gelu_fwd / as_linear_bwd_dgelu take (rows of 32 on both feature axes)."""
+    return x.is_cuda and x.numel() > 0 and weight.shape[0] % 32 == 0 and weight.shape[1] % 32 == 0
+
+
 def linear_splitk(x, weight, out_dtype=None):
     """x @ weight.T for bf16 x [M,K], weight [Nout,K] with the contraction split over workgroups (fixed-order fp32
     partials): the shape of a weight gradient, dW = dy^T x with the tokens as K.  out_dtype: bf16 (default) or fp32."""
@@ -142,9 +165,11 @@ def linear_splitk(x, weight, out_dtype=None):
 _LINEAR_BWD_WS = {}
 
 
-def linear_bwd(x, weight, dy, need_dx=True, need_dw=True, need_db=True, dw_dtype=None):
+def linear_bwd(x, weight, dy, need_dx=True, need_dw=True, need_db=True, dw_dtype=None, gelu_pre=None):
     """Backward of y = x @ weight.T + b for bf16 x [M,K], weight [Nout,K], dy [M,Nout] -> (dx bf16 | None, dW | None,
-    db fp32 | None); dW in `dw_dtype` (bf16 default, fp32 for fp32 master weights).  as_linear_bwd."""
+    db fp32 | None); dW in `dw_dtype` (bf16 default, fp32 for fp32 master weights).  as_linear_bwd.
+    gelu_pre [M,K] bf16: x was GELU(gelu_pre); dx then comes back multiplied by GELU'(gelu_pre) -- the gradient of the
+    pre-activation (as_linear_bwd_dgelu)."""
     lib = _lib.load()
     _chk(x, weight, dy, dtype=torch.bfloat16)
     M, K = x.shape
@@ -160,6 +185,13 @@ def linear_bwd(x, weight, dy, need_dx=True, need_dw=True, need_db=True, dw_dtype
     ws = _LINEAR_BWD_WS.get(key)                    # one growing scratch buffer per (device, stream): the calls of a
     if ws is None or ws.numel() * 4 < nbytes:       # backward pass are serial on their stream
         ws = _LINEAR_BWD_WS[key] = torch.empty((nbytes + 3) // 4, device=x.device, dtype=torch.float32)
+    if gelu_pre is not None:
+        _chk(gelu_pre, dtype=torch.bfloat16)
+        if tuple(gelu_pre.shape) != (M, K) or not need_dx:
+            raise AttnShiftError("linear_bwd: gelu_pre must be [M,K] and needs dx")
+        _lib.check(lib.as_linear_bwd_dgelu(_p(x), _p(weight), _p(dy), _p(gelu_pre), _p(dx), _p(dW), _p(db), M, Nout, K, AS_BF16,
+                                           1 if dw_dtype == torch.float32 else 0, _p(ws), nbytes, _stream()), "as_linear_bwd_dgelu")
+        return dx, dW, db
     _lib.check(lib.as_linear_bwd(_p(x), _p(weight), _p(dy), _p(dx), _p(dW), _p(db), M, Nout, K, AS_BF16,
                                  1 if dw_dtype == torch.float32 else 0, _p(ws), nbytes, _stream()), "as_linear_bwd")
     return dx, dW, db

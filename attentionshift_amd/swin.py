@@ -120,8 +120,13 @@ class SwinTransformerBlock(nn.Module):
         y = linear_in(o.reshape(B, L, C), self.attn.proj.weight, self.attn.proj.bias, cd)
         x = x + self._drop_path(y.float())
         z = F.layer_norm(x, (C,), self.norm2.weight, self.norm2.bias, self.norm2.eps).to(cd)
-        z = linear_in(F.gelu(linear_in(z, self.mlp.fc1.weight, self.mlp.fc1.bias, cd)), self.mlp.fc2.weight,
-                      self.mlp.fc2.bias, cd)
+        from . import autograd as AG
+        if cd == torch.bfloat16 and AG.linear_shapes_ok(z, self.mlp.fc1.weight) and self.mlp.fc2.weight.shape[0] % 32 == 0 \
+                and not AG._UNFUSED_MLP:
+            z = AG.mlp(z, self.mlp.fc1.weight, self.mlp.fc1.bias, self.mlp.fc2.weight, self.mlp.fc2.bias)
+        else:
+            z = linear_in(F.gelu(linear_in(z, self.mlp.fc1.weight, self.mlp.fc1.bias, cd)), self.mlp.fc2.weight,
+                          self.mlp.fc2.bias, cd)
         return x + self._drop_path(z.float()), None
 
     def _w(self, prm, dtype=None):

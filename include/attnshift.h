@@ -147,6 +147,16 @@ int as_add_layernorm_scaled(const float* x_in, const void* delta, const float* g
  * products of K ranges, summed in range order (deterministic), written as bf16 (out_f32 = 0) or fp32 (1).  The form of an
  * nn.Linear WEIGHT gradient dW = dy^T . x (models/vision_transformer.py:75-77,84 under autograd): few output tiles, the
  * tokens as K.  bf16 operands, K % 32 == 0, Nout % 4 == 0; workspace: as_linear_splitk_workspace_bytes(M, Nout, K). */
+/* The MLP's first linear under autograd (vision_transformer.py:47-59: fc1 -> GELU): pre[M,Nout] = x . W^T + bias rounded
+ * to bf16, out = GELU(pre) -- both written by the GEMM's epilogue (no separate activation pass; `pre` is what the
+ * backward needs).  bf16 only, K % 32 == 0, Nout % 8 == 0. */
+int as_linear_gelu_fwd(const void* x, const void* W, const float* bias, void* out, void* pre, int M, int Nout, int K,
+                       int dtype, as_stream_t stream);
+/* out[M,Nout] = (x[M,K] . W[Nout,K]^T) * GELU'(pre[M,Nout]): a linear's input gradient times the derivative of the GELU that
+ * produced that input, in the epilogue (the GeluBackward pass of autograd).  bf16 only, K % 32 == 0, Nout % 8 == 0. */
+int as_linear_dgelu_fwd(const void* x, const void* W, const void* pre, void* out, int M, int Nout, int K, int dtype,
+                        as_stream_t stream);
+
 size_t as_linear_splitk_workspace_bytes(int M, int Nout, int K);
 int as_linear_splitk_fwd(const void* x, const void* W, void* out, int M, int Nout, int K, int dtype, int out_f32,
                          void* workspace, size_t workspace_bytes, as_stream_t stream);
@@ -160,6 +170,10 @@ int as_linear_splitk_fwd(const void* x, const void* W, void* out, int M, int Nou
 size_t as_linear_bwd_workspace_bytes(int M, int Nout, int K);
 int as_linear_bwd(const void* x, const void* W, const void* dy, void* dx, void* dW, float* db, int M, int Nout, int K,
                   int dtype, int dw_f32, void* workspace, size_t workspace_bytes, as_stream_t stream);
+/* as_linear_bwd for the linear that FOLLOWS a GELU (fc2 of the Mlp): x = GELU(pre); dx [M,K] comes out already multiplied
+ * by GELU'(pre[M,K]) (as_linear_dgelu_fwd), i.e. it is the gradient of the pre-activation.  pre NULL = as_linear_bwd. */
+int as_linear_bwd_dgelu(const void* x, const void* W, const void* dy, const void* pre, void* dx, void* dW, float* db, int M,
+                        int Nout, int K, int dtype, int dw_f32, void* workspace, size_t workspace_bytes, as_stream_t stream);
 
 /* k x k / stride-k max pooling of a token-major (NHWC) fp32 map [B,H,W,C] -> [B,H/k,W/k,C] (contiguous): the FPN's
  * coarsest tap, nn.MaxPool2d(k, k) (mmdet/models/backbones/visual_transformer_det.py:120,129,133) on the layout the taps

@@ -1513,6 +1513,51 @@ def test_mt19937_device_draws_equal_torchs_cpu_generator(ops):
     assert int(f) != 0 and int(f2) != 0
 
 
+@pytest.mark.parametrize("M,D,H", [(8394, 768, 3072), (197, 256, 1024), (50, 64, 128), (1, 32, 32), (2051, 1024, 4096)])
+def test_mlp_with_the_gelu_in_the_gemm_epilogues(ops, M, D, H):
+    """autograd.MlpFn's kernels (models/vision_transformer.py:47-59 under autograd).
+    as_linear_gelu_fwd: the pre-activation it writes is as_linear_fwd's output bit for bit, and the activation is the erf-GELU
+    of that bf16 tensor (fp64 reference, half a bf16 ulp + the 1.5e-7 of the erf polynomial);
+    as_linear_bwd_dgelu: dx equals GeluBackward(as_linear_bwd's dx, pre) computed in fp64 from the SAME bf16 tensors to a
+    bf16 ulp, dW / db are as_linear_bwd's bit for bit;
+    MlpFn end to end against fp64 autograd of fc2(gelu(fc1(x))) on the rounded operands (3e-2 of each gradient's range)."""
+    from attentionshift_amd import autograd as AG
+    g = torch.Generator().manual_seed(M + D)
+    x = torch.randn(M, D, generator=g).bfloat16()
+    w1 = (torch.randn(H, D, generator=g) / D ** 0.5).bfloat16()
+    b1 = torch.randn(H, generator=g) * 0.5
+    w2 = (torch.randn(D, H, generator=g) / H ** 0.5).bfloat16()
+    b2 = torch.randn(D, generator=g) * 0.1
+    dy = torch.randn(M, D, generator=g).bfloat16()
+    a, pre = ops.linear_gelu(dev(x), dev(w1), dev(b1))
+    assert torch.equal(pre, ops.linear(dev(x), dev(w1), dev(b1)))
+    ref_a = torch.nn.functional.gelu(pre.cpu().double())
+    assert float((a.cpu().double() - ref_a).abs().max()) <= 2 ** -8 * float(ref_a.abs().max()) + 1e-6
+    # backward of fc2 with the GELU derivative in the epilogue
+    dpre, dw2, db2 = ops.linear_bwd(a, dev(w2), dev(dy), True, True, True, dw_dtype=torch.float32, gelu_pre=pre)
+    da, dw2u, db2u = ops.linear_bwd(a, dev(w2), dev(dy), True, True, True, dw_dtype=torch.float32)
+    assert torch.equal(dw2, dw2u) and torch.equal(db2, db2u)
+    h64 = pre.cpu().double()
+    dgelu = 0.5 * (1 + torch.erf(h64 / 2 ** 0.5)) + h64 * torch.exp(-h64 * h64 / 2) / (2 * torch.pi) ** 0.5
+    ref_dpre = da.cpu().double() * dgelu
+    assert float((dpre.cpu().double() - ref_dpre).abs().max()) <= 2 ** -8 * float(ref_dpre.abs().max()) + 1e-6
+    # the autograd node end to end
+    with torch.enable_grad():
+        xs, w1s, b1s, w2s, b2s = (dev(t).requires_grad_(True) for t in (x, w1.float(), b1, w2.float(), b2))
+        y = AG.mlp(xs, w1s, b1s, w2s, b2s)
+        y.backward(dev(dy))
+        x64, w164, b164, w264, b264 = (t.double().requires_grad_(True) for t in (x, w1, b1, w2, b2))
+        y64 = torch.nn.functional.linear(torch.nn.functional.gelu(torch.nn.functional.linear(x64, w164, b164)), w264, b264)
+        y64.backward(dy.double())
+    mx, _ = rel_to_range(y64.detach().float(), y.float())
+    assert mx < 3e-2, mx
+    for name, got, ref in (("dx", xs.grad, x64.grad), ("dw1", w1s.grad, w164.grad), ("db1", b1s.grad, b164.grad),
+                           ("dw2", w2s.grad, w264.grad), ("db2", b2s.grad, b264.grad)):
+        mx, _ = rel_to_range(ref.float(), got.float())
+        assert mx < 3e-2, (name, mx)
+    assert w1s.grad.dtype == torch.float32 and b1s.grad.dtype == torch.float32
+
+
 @pytest.mark.parametrize("M,K,Nout", [(8394, 768, 3072), (8394, 3072, 768), (2051, 256, 1024), (4197, 128, 256)])
 def test_weight_gradient_without_transposes_equals_the_transposed_path(ops, M, K, Nout):
     """as_linear_bwd's two weight-gradient routes -- row-major activations through the transposing LDS read (default) and
