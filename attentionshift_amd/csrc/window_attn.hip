@@ -512,21 +512,375 @@ __global__ __launch_bounds__(64) void window_attn_bwd_kernel(const T* __restrict
   }
 }
 
-// dtable[r][head] = sum over windows (in window order) of part_tab;  dpad[which*C + head*32 + c] likewise
-__global__ void window_attn_bwd_reduce_kernel(const float* __restrict__ part_tab, const float* __restrict__ part_pad,
-                                              float* __restrict__ dtable, float* __restrict__ dpad, int nwin, int h, int TB,
-                                              int HD3) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+// ---- bf16 backward on the matrix cores ------------------------------------------------------------------------
+// One wave per (window, head), four per workgroup, the decomposition of window_attn_mfma_kernel: a lane owns one query
+// column of S^T = K Q^T, so the softmax, delta_i = sum_j P_ij dP_ij and dS = P (dP - delta) are in-lane on the
+// accumulators of two product pairs (S^T, dP^T = V dO^T), and dQ^T = K^T dS^T takes dS^T from them in place.  dV^T = dO^T P
+// and dK^T = Q^T dS contract over the QUERIES: P^T and dS^T go through an LDS image [query][key] (bf16, 8-byte stores of
+// four consecutive keys, 16-byte chunks swizzled) and come back as B fragments through the transposing read
+// ds_read_b64_tr_b16; the A fragments of all three gradient products (K^T, dO^T, Q^T: channel rows, token columns) are
+// transposing reads of row-major [token][32 channels] images -- no transposed copy is ever written.  40 MFMAs per (window,
+// head) instead of ~31 000 fp32 FMA issue cycles per lane.  Relative-position-bias gradient: each of the 169 offsets sums its
+// (i, j) pairs from the dS image in a fixed order; padded tokens' gradients (their qkv IS the bias) are added up in token
+// order; both reduced over windows by window_attn_bwd_reduce_kernel.  No atomics: bit-reproducible.
+#ifndef AS_WA_ABLATE
+#define AS_WA_ABLATE 0                       // (timing experiments: 1 no table-gradient loop, 2 no dqkv stores, 3 no table loads)
+#endif
+typedef short wa_i16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) const char* wa_lds_ptr;
+__device__ __forceinline__ int wa_swz(int r) { return (((r >> 1) & 1) << 2) | ((r >> 2) & 3); }      // sdpa_bwd.hip t3_swz
+__device__ __forceinline__ void wa_frag_tr(Frag<__bf16>& f, wa_lds_ptr p0, wa_lds_ptr p1) {
+  const wa_i16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) wa_i16x4*)p0);
+  const wa_i16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) wa_i16x4*)p1);
+  typedef short i16x8 __attribute__((ext_vector_type(8)));
+  const i16x8 w = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  f.v = __builtin_bit_cast(bf16x8, w);
+}
+
+template <int WS, int HD>
+__global__ __launch_bounds__(256, 3) void window_attn_bwd_mfma_kernel(const __bf16* __restrict__ qkv, const float* __restrict__ bqkv,
+                                                                      const float* __restrict__ table, const __bf16* __restrict__ d_out,
+                                                                      __bf16* __restrict__ dqkv, float* __restrict__ part_tab,
+                                                                      float* __restrict__ part_pad, int B, int H, int W, int h,
+                                                                      int shift, int nitems) {
+  static_assert(WS == 7 && HD == 32, "tiling is written for 7x7 windows of head dim 32");
+  constexpr int N = WS * WS, TB = (2 * WS - 1) * (2 * WS - 1);
+  // per wave: three row-major [64 tokens][32 channels] bf16 images (64-byte rows) and two [64 queries][64 keys] images
+  // (ONE of each, reused phase by phase: K rows for dQ, then dO rows + P for dV, then q rows + dS for dK and the table
+  //  gradient -- 13 KiB per wave, three workgroups per CU)
+  __shared__ __attribute__((aligned(16))) char Rm_s[4][64 * 64];
+  __shared__ __attribute__((aligned(16))) char Im_s[4][64 * 128];
+  __shared__ float tab_s[4][TB + 7];
+  __shared__ int info_s[4][64];
+  __shared__ float pad_s[4][3 * HD];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, hf = lane >> 5;
+  const int raw_item = blockIdx.x * 4 + wave;
+  const bool live = raw_item < nitems;
+  const int item = min(raw_item, nitems - 1);
+  const int win = item / h, head = item - win * h;
+  const int C = h * HD;
+  const int nWh = as_ceil_div_dev(H, WS), nWw = as_ceil_div_dev(W, WS);
+  const int Hp = nWh * WS, Wp = nWw * WS;
+  const int b = win / (nWh * nWw), wrem = win - b * (nWh * nWw), wi = wrem / nWw, wj = wrem - wi * nWw;
+
+  bool valid[2], real[2];
+  size_t tokidx[2];
+  int lin[2], rid[2];
+#pragma unroll
+  for (int x = 0; x < 2; ++x) {
+    const int t = li + 32 * x;
+    valid[x] = t < N;
+    const int tc = min(t, N - 1);
+    const int a = tc / WS, c_ = tc - a * WS;
+    const int hs = wi * WS + a, ws_ = wj * WS + c_;
+    int ho = hs + shift, wo = ws_ + shift;
+    ho -= ho >= Hp ? Hp : 0;
+    wo -= wo >= Wp ? Wp : 0;
+    real[x] = valid[x] && ho < H && wo < W;
+    tokidx[x] = ((size_t)b * H + (real[x] ? ho : 0)) * W + (real[x] ? wo : 0);
+    lin[x] = a * (2 * WS - 1) + c_;
+    const int rh = hs < Hp - WS ? 0 : (hs < Hp - shift ? 1 : 2), rw = ws_ < Wp - WS ? 0 : (ws_ < Wp - shift ? 1 : 2);
+    rid[x] = shift > 0 ? 3 * rh + rw : 0;
+  }
+  info_s[wave][lane] = (valid[hf] ? 0 : 0x10000) | ((valid[hf] && !real[hf]) ? 0x20000 : 0) | (rid[hf] << 8) | lin[hf];
+  for (int t = lane; t < TB; t += 64) tab_s[wave][t] = AS_WA_ABLATE == 3 ? 0.0f : table[(size_t)t * h + head];
+  for (int t = lane; t < 3 * HD; t += 64) pad_s[wave][t] = 0.0f;
+
+  // operand fragments: channels ks*16 + hf*8 + 0..7 of q / k / v / dO of both tokens; the row-major images of k, q, dO
+  Frag<__bf16> fq[2][2], fk[2][2], fv[2][2], fg[2][2];
+  char* Rm = Rm_s[wave];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const int ch = head * HD + ks * 16 + hf * 8;
+    float bq[8], bk[8], bv[8];
+#pragma unroll
+    for (int e = 0; e < 8; e += 4) {
+      const float4 q4 = bqkv ? *reinterpret_cast<const float4*>(bqkv + ch + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 k4 = bqkv ? *reinterpret_cast<const float4*>(bqkv + C + ch + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 v4 = bqkv ? *reinterpret_cast<const float4*>(bqkv + 2 * C + ch + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+      bq[e] = q4.x; bq[e + 1] = q4.y; bq[e + 2] = q4.z; bq[e + 3] = q4.w;
+      bk[e] = k4.x; bk[e + 1] = k4.y; bk[e + 2] = k4.z; bk[e + 3] = k4.w;
+      bv[e] = v4.x; bv[e + 1] = v4.y; bv[e + 2] = v4.z; bv[e + 3] = v4.w;
+    }
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+      const __bf16* tok = qkv + tokidx[x] * (size_t)(3 * C) + ch;
+      const bf16x8 rq = *reinterpret_cast<const bf16x8*>(tok);
+      const bf16x8 rk = *reinterpret_cast<const bf16x8*>(tok + C);
+      const bf16x8 rv = *reinterpret_cast<const bf16x8*>(tok + 2 * C);
+      const bf16x8 rg = *reinterpret_cast<const bf16x8*>(d_out + tokidx[x] * (size_t)C + ch);
+      const float keep = real[x] ? 1.0f : 0.0f, exist = valid[x] ? 1.0f : 0.0f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        fq[x][ks].v[e] = (__bf16)(exist * fmaf(keep, (float)rq[e], bq[e]));
+        fk[x][ks].v[e] = (__bf16)(exist * fmaf(keep, (float)rk[e], bk[e]));
+        fv[x][ks].v[e] = (__bf16)(exist * fmaf(keep, (float)rv[e], bv[e]));
+        fg[x][ks].v[e] = (__bf16)(keep * (float)rg[e]);             // padded rows produce no output: dO = 0
+      }
+      *reinterpret_cast<bf16x8*>(Rm + (li + 32 * x) * 64 + (ks * 2 + hf) * 16) = fk[x][ks].v;      // K rows first (dQ)
+    }
+  }
+  __syncthreads();
+
+  // S^T and dP^T tiles: [jb][ib], key = jb*32 + acc_row(r, hf), query = ib*32 + li
+  f32x16 acc[2][2], dpa[2][2];
+#pragma unroll
+  for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc[jb][ib][r] = 0.0f; dpa[jb][ib][r] = 0.0f; }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        acc[jb][ib] = mma32(fk[jb][ks], fq[ib][ks], acc[jb][ib]);
+        dpa[jb][ib] = mma32(fv[jb][ks], fg[ib][ks], dpa[jb][ib]);
+      }
+    }
+  const float scale = rsqrtf((float)HD);
+  const float* tab = tab_s[wave];
+  float mx[2] = {-INFINITY, -INFINITY};
+#pragma unroll
+  for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int inf = info_s[wave][jb * 32 + acc_row(r, hf)];
+      const int lj = inf & 0xff, rj = (inf >> 8) & 0xff;
+      const bool gone = (inf & 0x10000) != 0;
+#pragma unroll
+      for (int ib = 0; ib < 2; ++ib) {
+        float sc = fmaf(acc[jb][ib][r], scale, tab[lin[ib] - lj + (WS - 1) * (2 * WS - 1) + (WS - 1)]);
+        sc += rj != rid[ib] ? -100.0f : 0.0f;
+        sc = gone ? -INFINITY : sc;
+        acc[jb][ib][r] = sc;
+        mx[ib] = fmaxf(mx[ib], sc);
+      }
+    }
+  // P = softmax, delta = sum_j P dP, dS = P (dP - delta): acc <- P, dpa <- dS
+#pragma unroll
+  for (int ib = 0; ib < 2; ++ib) {
+    mx[ib] = fmaxf(mx[ib], __shfl_xor(mx[ib], 32));
+    float sum = 0.0f;
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float e = __expf(acc[jb][ib][r] - mx[ib]);
+        acc[jb][ib][r] = e;
+        sum += e;
+      }
+    sum += __shfl_xor(sum, 32);
+    const float inv = 1.0f / sum;
+    float delta = 0.0f;
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = acc[jb][ib][r] * inv;
+        acc[jb][ib][r] = p;
+        delta = fmaf(p, dpa[jb][ib][r], delta);
+      }
+    delta += __shfl_xor(delta, 32);
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dpa[jb][ib][r] = acc[jb][ib][r] * (dpa[jb][ib][r] - delta);
+  }
+  // image [query][key] of P, later of dS: registers 4g .. 4g+3 of (jb, ib) are keys jb*32 + 8g + 4hf .. +3 of query ib*32 + li
+  char* Im = Im_s[wave];
+  auto put_image = [&](f32x16 (&src)[2][2]) {
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib) {
+      const int qrow = ib * 32 + li, sw = wa_swz(qrow);
+#pragma unroll
+      for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const bf16x4 pv = {(__bf16)src[jb][ib][4 * g], (__bf16)src[jb][ib][4 * g + 1], (__bf16)src[jb][ib][4 * g + 2],
+                             (__bf16)src[jb][ib][4 * g + 3]};
+          *reinterpret_cast<bf16x4*>(Im + qrow * 128 + (((jb * 4 + g) ^ sw) << 4) + 8 * hf) = pv;
+        }
+    }
+  };
+  auto put_rows = [&](Frag<__bf16> (&f)[2][2]) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int x = 0; x < 2; ++x) *reinterpret_cast<bf16x8*>(Rm + (li + 32 * x) * 64 + (ks * 2 + hf) * 16) = f[x][ks].v;
+  };
+  // per-lane pieces of the transposing reads (16-lane group g_ = lane >> 4, t_ = lane & 15): row t_ >> 2 of the 4-row group,
+  // columns 16 (g_ & 1) + 4 (t_ & 3) .. +3
+  const int g_ = lane >> 4, t_ = lane & 15;
+  const wa_lds_ptr Rm3 = (wa_lds_ptr)Rm, Im3 = (wa_lds_ptr)Im;
+  const int rm_lane = (t_ >> 2) * 64 + (16 * (g_ & 1) + 4 * (t_ & 3)) * 2;      // inside a row-major [token][32] image
+
+  // dQ^T[c][query] = K^T . dS^T: A = K^T (rows c, keys in acc_row's order: key0 .. +3 and key0 + 8 .. +11), B = dS^T in place
+  f32x16 dqa[2];
+#pragma unroll
+  for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dqa[ib][r] = 0.0f;
+#pragma unroll
+  for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int key0 = jb * 32 + 16 * s + 4 * hf;
+      Frag<__bf16> fa;
+      wa_frag_tr(fa, Rm3 + (key0 * 64 + rm_lane), Rm3 + ((key0 + 8) * 64 + rm_lane));
+#pragma unroll
+      for (int ib = 0; ib < 2; ++ib) {
+        Frag<__bf16> fb;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) fb.v[t] = (__bf16)dpa[jb][ib][8 * s + t];
+        dqa[ib] = mma32(fa, fb, dqa[ib]);
+      }
+    }
+  // dV^T[c][key] = dO^T . P, then dK^T[c][key] = Q^T . dS: contraction over the queries in natural order (16 kq + 8 hf + 0..7)
+  f32x16 dva[2], dka[2];
+#pragma unroll
+  for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dva[jb][r] = 0.0f; dka[jb][r] = 0.0f; }
+  auto contract_queries = [&](f32x16 (&out)[2]) {
+#pragma unroll
+    for (int kq = 0; kq < 4; ++kq) {
+      const int q0 = 16 * kq + 8 * hf;                                // + 4 q' + (t_ >> 2): the row this lane addresses
+      Frag<__bf16> fa;
+      wa_frag_tr(fa, Rm3 + (q0 * 64 + rm_lane), Rm3 + ((q0 + 4) * 64 + rm_lane));
+#pragma unroll
+      for (int jb = 0; jb < 2; ++jb) {
+        // B fragments from the [query][key] image: rows q0 + 4 q' + (t_ >> 2), key columns 32 jb + 16 (g_ & 1) + 4 (t_ & 3) .. +3
+        const int chunk = 4 * jb + 2 * (g_ & 1) + ((t_ & 3) >> 1), sub = 8 * (t_ & 1);
+        const int r0 = q0 + (t_ >> 2), r1 = r0 + 4;
+        Frag<__bf16> fb;
+        wa_frag_tr(fb, Im3 + (r0 * 128 + ((chunk ^ wa_swz(r0)) << 4) + sub), Im3 + (r1 * 128 + ((chunk ^ wa_swz(r1)) << 4) + sub));
+        out[jb] = mma32(fa, fb, out[jb]);
+      }
+    }
+  };
+  __syncthreads();                                                   // dQ's reads of the K rows are done
+  put_rows(fg);
+  put_image(acc);
+  __syncthreads();
+  contract_queries(dva);
+  __syncthreads();
+  put_rows(fq);
+  put_image(dpa);
+  __syncthreads();
+  contract_queries(dka);
+  const char* Di = Im;                                               // (the dS image stays for the table gradient)
+  // ---- relative-position-bias table gradient of this (window, head): offset r = (da, db) sums dS[i][j] over its pairs
+  // (a_i - a_j, b_i - b_j) = (da, db) in ascending i.  Rows a_i of the 7 x 7 window in a loop, the seven b_i unrolled with
+  // the out-of-window ones masked, so that seven independent LDS reads are in flight (a div / mod / branch per pair with one
+  // dependent read each made this loop the longest phase of the kernel)
+  if (live) {
+    for (int r = lane; r < TB; r += 64) {
+      const int da = r / (2 * WS - 1) - (WS - 1), db = r % (2 * WS - 1) - (WS - 1);     // a_i - a_j, b_i - b_j
+      float sum = 0.0f;
+      if (AS_WA_ABLATE != 1)
+      for (int ai = max(0, da); ai <= min(WS - 1, WS - 1 + da); ++ai) {
+        float v[WS];
+#pragma unroll
+        for (int bi = 0; bi < WS; ++bi) {
+          const int bj = min(max(bi - db, 0), WS - 1);
+          const int i = ai * WS + bi, j = (ai - da) * WS + bj;
+          v[bi] = (float)*reinterpret_cast<const __bf16*>(Di + i * 128 + (((j >> 3) ^ wa_swz(i)) << 4) + (j & 7) * 2);
+        }
+#pragma unroll
+        for (int bi = 0; bi < WS; ++bi) sum += (bi - db >= 0 && bi - db < WS) ? v[bi] : 0.0f;
+      }
+      part_tab[((size_t)win * h + head) * TB + r] = sum;
+    }
+  }
+  // ---- scatter real tokens (registers 4g .. 4g+3 = channels 8g + 4hf .. +3); padded tokens feed the bias gradient ----
+  bool any_pad = false;
+#pragma unroll
+  for (int x = 0; x < 2; ++x) {
+    any_pad |= valid[x] && !real[x];
+    if (live && real[x] && AS_WA_ABLATE != 2) {
+      __bf16* dst = dqkv + tokidx[x] * (size_t)(3 * C) + head * HD + 4 * hf;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const bf16x4 q4 = {(__bf16)(dqa[x][4 * g] * scale), (__bf16)(dqa[x][4 * g + 1] * scale), (__bf16)(dqa[x][4 * g + 2] * scale),
+                           (__bf16)(dqa[x][4 * g + 3] * scale)};
+        const bf16x4 k4 = {(__bf16)(dka[x][4 * g] * scale), (__bf16)(dka[x][4 * g + 1] * scale), (__bf16)(dka[x][4 * g + 2] * scale),
+                           (__bf16)(dka[x][4 * g + 3] * scale)};
+        const bf16x4 v4 = {(__bf16)dva[x][4 * g], (__bf16)dva[x][4 * g + 1], (__bf16)dva[x][4 * g + 2], (__bf16)dva[x][4 * g + 3]};
+        *reinterpret_cast<bf16x4*>(dst + 8 * g) = q4;
+        *reinterpret_cast<bf16x4*>(dst + C + 8 * g) = k4;
+        *reinterpret_cast<bf16x4*>(dst + 2 * C + 8 * g) = v4;
+      }
+    }
+  }
+  if (__any(any_pad)) {                                              // (edge windows of a padded grid only)
+    float* pad = pad_s[wave];
+    for (int t = 0; t < N; ++t) {                                    // token order: one owner lane pair per token, fixed order
+      if (!(info_s[wave][t] & 0x20000)) continue;
+      const int x = t >> 5;
+      if (li == (t & 31)) {
+#pragma unroll
+        for (int xx = 0; xx < 2; ++xx)
+          if (xx == x) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int c = acc_row(r, hf);
+              pad[c] += dqa[xx][r] * scale;
+              pad[HD + c] += dka[xx][r] * scale;
+              pad[2 * HD + c] += dva[xx][r];
+            }
+          }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  if (live)
+    for (int x = lane; x < 3 * HD; x += 64) part_pad[((size_t)win * h + head) * (3 * HD) + x] = pad_s[wave][x];
+}
+
+// First level of the reduction over windows: workgroup (chunk, head) adds up its chunk's windows in window order, thread = one of
+// the 169 + 96 outputs (coalesced along the outputs).  A single-level loop over all windows per thread took 1.36 ms at Swin-B's
+// first stage (2738 windows of 2.7-KiB-strided partials per thread) -- 70 % of the whole call.
+__global__ __launch_bounds__(320) void window_attn_bwd_reduce1_kernel(const float* __restrict__ part_tab, const float* __restrict__ part_pad,
+                                                                    float* __restrict__ red_tab, float* __restrict__ red_pad, int nwin,
+                                                                    int h, int TB, int HD3, int per) {
+  const int chunk = blockIdx.x, head = blockIdx.y, t = threadIdx.x;
+  if (t >= TB + HD3) return;
+  const int w0 = chunk * per, w1 = min(nwin, w0 + per);
+  float s = 0.0f;
+  if (t < TB)
+    for (int w = w0; w < w1; ++w) s += part_tab[((size_t)w * h + head) * TB + t];
+  else
+    for (int w = w0; w < w1; ++w) s += part_pad[((size_t)w * h + head) * HD3 + (t - TB)];
+  if (t < TB) red_tab[((size_t)chunk * h + head) * TB + t] = s;
+  else red_pad[((size_t)chunk * h + head) * HD3 + (t - TB)] = s;
+}
+
+// Second level: dtable[r][head] = sum over the (<= 64) chunks of red_tab, dpad[which*C + head*32 + c] likewise.  One output per
+// 16 lanes: lane l adds chunks l, l + 16, l + 32, l + 48 in that order, then a fixed xor tree over the 16 lanes.
+__global__ __launch_bounds__(256) void window_attn_bwd_reduce_kernel(const float* __restrict__ part_tab, const float* __restrict__ part_pad,
+                                                                   float* __restrict__ dtable, float* __restrict__ dpad, int nwin, int h,
+                                                                   int TB, int HD3) {
+  const int t = blockIdx.x * 16 + (threadIdx.x >> 4), l = threadIdx.x & 15;
   const int C = h * (HD3 / 3);
-  if (t < TB * h) {
+  const bool is_tab = t < TB * h, is_pad = !is_tab && t < TB * h + h * HD3;
+  float s = 0.0f;
+  int u = 0;
+  if (is_tab) {
     const int r = t / h, head = t % h;
-    float s = 0.0f;
-    for (int w = 0; w < nwin; ++w) s += part_tab[((size_t)w * h + head) * TB + r];
-    dtable[t] = s;
-  } else if (t < TB * h + h * HD3) {
-    const int u = t - TB * h, head = u / HD3, x = u % HD3, which = x / (HD3 / 3), c = x % (HD3 / 3);
-    float s = 0.0f;
-    for (int w = 0; w < nwin; ++w) s += part_pad[((size_t)w * h + head) * HD3 + x];
+    for (int w = l; w < nwin; w += 16) s += part_tab[((size_t)w * h + head) * TB + r];
+  } else if (is_pad) {
+    u = t - TB * h;
+    const int head = u / HD3, x = u % HD3;
+    for (int w = l; w < nwin; w += 16) s += part_pad[((size_t)w * h + head) * HD3 + x];
+  }
+  s += __shfl_xor(s, 8);
+  s += __shfl_xor(s, 4);
+  s += __shfl_xor(s, 2);
+  s += __shfl_xor(s, 1);
+  if (l != 0) return;
+  if (is_tab) dtable[t] = s;
+  else if (is_pad) {
+    const int head = u / HD3, x = u % HD3, which = x / (HD3 / 3), c = x % (HD3 / 3);
     dpad[which * C + head * (HD3 / 3) + c] = s;
   }
 }
@@ -537,7 +891,7 @@ extern "C" size_t as_window_attn_bwd_workspace_bytes(int B, int H, int W, int h,
   if (B <= 0 || H <= 0 || W <= 0 || h <= 0 || ws <= 0) return 0;
   const size_t nwin = (size_t)B * as_ceil_div(H, ws) * as_ceil_div(W, ws);
   const size_t TB = (size_t)(2 * ws - 1) * (2 * ws - 1);
-  return nwin * h * (TB + 96) * sizeof(float);
+  return (nwin + 64) * h * (TB + 96) * sizeof(float);          // per-window partials + <= 64 first-level sums
 }
 
 extern "C" int as_window_attn_bwd(const void* qkv, const float* bqkv, const float* table, const void* d_out, void* dqkv,
@@ -556,7 +910,11 @@ extern "C" int as_window_attn_bwd(const void* qkv, const float* bqkv, const floa
   float* part_tab = (float*)workspace;
   float* part_pad = part_tab + (size_t)nwin * h * 169;
   // padded-grid positions have no row in dqkv: rows of real tokens are all written (every real token is in exactly one window)
-  if (dtype == AS_BF16)
+  static const bool valu = getenv("AS_WINDOW_BWD_VALU") != nullptr;   // (A/B: the fp32-arithmetic kernel on bf16 tensors)
+  if (dtype == AS_BF16 && !valu)
+    hipLaunchKernelGGL((window_attn_bwd_mfma_kernel<7, 32>), dim3(as_ceil_div(nwin * h, 4)), dim3(256), 0, s, (const __bf16*)qkv,
+                       bqkv, table, (const __bf16*)d_out, (__bf16*)dqkv, part_tab, part_pad, B, H, W, h, shift, nwin * h);
+  else if (dtype == AS_BF16)
     hipLaunchKernelGGL((window_attn_bwd_kernel<__bf16, 7, 32>), dim3(nwin, h), dim3(64), 0, s, (const __bf16*)qkv, bqkv, table,
                        (const __bf16*)d_out, (__bf16*)dqkv, part_tab, part_pad, B, H, W, h, shift);
   else if (dtype == AS_F32)
@@ -566,8 +924,15 @@ extern "C" int as_window_attn_bwd(const void* qkv, const float* bqkv, const floa
     AS_REQUIRE(false, AS_E_UNSUPPORTED, "as_window_attn_bwd: dtype %d", dtype);
   AS_CHECK_LAUNCH("window_attn_bwd");
   const int total = 169 * h + h * 96;
-  hipLaunchKernelGGL(window_attn_bwd_reduce_kernel, dim3(as_ceil_div(total, 256)), dim3(256), 0, s, (const float*)part_tab,
-                     (const float*)part_pad, dtable, dbqkv_pad, nwin, h, 169, 96);
+  // two fixed-order levels: <= 64 chunks of consecutive windows, then the chunks
+  const int per = as_ceil_div(nwin, 64), nchunk = as_ceil_div(nwin, per);
+  float* red_tab = part_pad + (size_t)nwin * h * 96;
+  float* red_pad = red_tab + (size_t)nchunk * h * 169;
+  hipLaunchKernelGGL(window_attn_bwd_reduce1_kernel, dim3(nchunk, h), dim3(320), 0, s, (const float*)part_tab, (const float*)part_pad,
+                     red_tab, red_pad, nwin, h, 169, 96, per);
+  AS_CHECK_LAUNCH("window_attn_bwd_reduce1");
+  hipLaunchKernelGGL(window_attn_bwd_reduce_kernel, dim3(as_ceil_div(total, 16)), dim3(256), 0, s, (const float*)red_tab,
+                     (const float*)red_pad, dtable, dbqkv_pad, nchunk, h, 169, 96);
   AS_CHECK_LAUNCH("window_attn_bwd_reduce");
   return AS_OK;
 }

@@ -1226,6 +1226,31 @@ def test_swin_block_backward_matches_autograd(ops, golden, tag, dtype, tol):
         assert mx < tol, (n, mx, mean)
 
 
+@pytest.mark.parametrize("B,H,W,h,shift", [(2, 14, 14, 4, 0), (1, 14, 14, 2, 3), (1, 16, 18, 3, 3), (2, 9, 23, 1, 0),
+                                            (1, 64, 64, 4, 3)])
+def test_window_attention_backward_on_the_matrix_cores_matches_the_fp32_kernel(ops, B, H, W, h, shift):
+    """as_window_attn_bwd on bf16 tensors (window_attn_bwd_mfma_kernel: S^T / dP^T / dQ^T, dV^T and dK^T on
+    v_mfma_f32_32x32x16_bf16, P and dS through a transposing LDS read) against the fp32-arithmetic kernel fed the SAME
+    bf16-rounded tensors: dqkv, the relative-position-bias-table gradient and the padded tokens' bias gradient
+    (models/swin_transformer.py:131-153 under autograd; grids that need window padding and the cyclic shift included).
+    Differences: P / dS rounded to bf16 before the gradient products -- 2e-2 of each output's range; twice: bitwise equal."""
+    g = torch.Generator().manual_seed(H * 100 + W + shift)
+    C = 32 * h
+    qkv = torch.randn(B, H, W, 3 * C, generator=g).bfloat16()
+    bq = torch.randn(3 * C, generator=g) * 0.2
+    table = torch.randn(169, h, generator=g) * 0.5
+    d_out = torch.randn(B, H, W, C, generator=g).bfloat16()
+    got = ops.window_attention_bwd(dev(qkv), dev(bq), dev(table), dev(d_out), h, 7, shift)
+    again = ops.window_attention_bwd(dev(qkv), dev(bq), dev(table), dev(d_out), h, 7, shift)
+    ref = ops.window_attention_bwd(dev(qkv.float()), dev(bq), dev(table), dev(d_out.float()), h, 7, shift)
+    for name, a, b, r in zip(("dqkv", "dtable", "dbqkv_pad"), got, again, ref):
+        assert torch.equal(a, b), name
+        assert torch.isfinite(a.float()).all(), name
+        rng = float(r.float().abs().max())
+        err = float((a.float() - r.float()).abs().max())
+        assert err <= 2e-2 * rng + 1e-6, (name, err, rng)
+
+
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-4), (torch.bfloat16, 6e-2)])
 def test_swin_backbone_matches_reference(golden, dtype, tol):
     """The whole Swin backbone (patch embed, two stages of (shifted-)window blocks on as_window_attn_fwd, patch merging,
