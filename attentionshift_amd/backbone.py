@@ -428,7 +428,9 @@ class VisionTransformerDet(nn.Module):
             taps.append(xf[:, 1:-T])                                     # token-major view [B, Np, D]
             tap = xf[:, 1:, :][:, :-T].permute(0, 2, 1).unflatten(2, (hp, wp))
             if grad_path:
-                features.append(tap.contiguous())
+                # an NCHW-shaped VIEW of the token-major residual stream (no transposing clone: the consumers -- the FPN's token
+                # GEMMs, RoIAlign -- read channels-last, and the gradient comes back in the same layout)
+                features.append(tap if os.environ.get("AS_TAP_VIEW", "1") != "0" else tap.contiguous())
                 return
             # no-grad: org_feats [B, L, D, hp, wp] is a VIEW of token-major storage [L, B, hp, wp, D] (every tap a
             # channels-last map): filling a slot is a straight copy of the tokens, not a transpose, and the
@@ -459,7 +461,8 @@ class VisionTransformerDet(nn.Module):
                 sink = [] if self.return_attention else None
                 x, delta, dscale = self._block_train(blk, x.float() if x.dtype != torch.float32 else x, delta, i, sink, dscale)
                 if i in self.out_indices or i == nblk - 1:                  # taps / output need the block's full result
-                    x = x + (delta.float() if dscale is None else delta.float() * dscale[:, None, None])
+                    # (mixed-dtype operands are promoted inside the element-wise kernels: no separate fp32 copy of delta)
+                    x = x + (delta if dscale is None else delta * dscale[:, None, None])
                     delta, dscale = None, None
                 st = sink[0] if sink else None
                 if i in self.out_indices:

@@ -846,7 +846,11 @@ class AttnShiftRoIHead(nn.Module):
                                           num_weighted=int(rois.shape[0])))
         # ---- mask branch (:3094-3160): the positives' BOX features through the mask head, BCE at the mask points ----
         if with_mask:
-            mask_pred = self.mask_head(bbox_feats[pos_index])
+            # the positives' rows gathered in the layout RoIAlign wrote them in ([R, 7, 7, C]; bbox_feats is its NCHW-shaped
+            # view): the gather, its backward scatter and the sum of the two branches' gradients stay token-major
+            tok = bbox_feats.permute(0, 2, 3, 1)
+            mask_in = tok[pos_index].permute(0, 3, 1, 2) if tok.is_contiguous() else bbox_feats[pos_index]
+            mask_pred = self.mask_head(mask_in)
             sites, mask_t = mask_point_targets([r.pos_bboxes for r in sampling_results],
                                                [r.pos_assigned_gt_inds for r in sampling_results],
                                                mask_point_coords, mask_point_labels, semantic_centers_split,
