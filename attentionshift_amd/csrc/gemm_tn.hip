@@ -209,6 +209,166 @@ __global__ __launch_bounds__(TN_NT, TN_NSTAGE == 4 ? 2 : 3) void gemm_tn_splitk_
   }
 }
 
+// ---- 256 (n) x 128 (k) tiles: four waves of 128 x 64 -------------------------------------------------------------
+// The 128 x 128 kernel above issues two transposing LDS reads per MFMA and stages 16 KiB per 64 MFMAs: with three workgroups
+// per CU its LDS pipe is asked for more cycles than its matrix pipe (reads 4 waves x 16 x 2 cycles + ~200 cycles of LDS-DMA
+// writes against 256 MFMA cycles per stage and SIMD) -- it waits half of its wave cycles.  Here a wave owns 128 rows of dW x
+// 64 columns: 24 reads per 16 MFMAs and 24 KiB staged per 128, the same kernel otherwise (32-token stages, 3-deep LDS-DMA
+// ring, fixed-order fp32 partials per token range, bias gradient from the dY fragments).  The fragment reads go through the
+// compiler's transposing-read builtin (hipcc tracks their lgkmcnt), issued for the whole stage before its first MFMA.
+// dY tile: 32 token rows x 512 B, X tile: 32 x 256 B; 16-byte chunk c of token row r at position c ^ ((r & 3) << 2).
+constexpr int TW_N = 256, TW_K = 128;
+constexpr int TW_A_B = TN_GM * TW_N * 2, TW_B_B = TN_GM * TW_K * 2, TW_STAGE_B = TW_A_B + TW_B_B;   // 16 + 8 KiB
+constexpr int TW_NSTAGE = 3;
+typedef short tw_i16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) const char* tw_lds_ptr;
+__device__ __forceinline__ void tw_frag(Frag<__bf16>& f, tw_lds_ptr p0, tw_lds_ptr p1) {
+  const tw_i16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tw_i16x4*)p0);
+  const tw_i16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tw_i16x4*)p1);
+  typedef short i16x8 __attribute__((ext_vector_type(8)));
+  const i16x8 w = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  f.v = __builtin_bit_cast(bf16x8, w);
+}
+
+__global__ __launch_bounds__(TN_NT, 2) void gemm_tn_wide_kernel(const __bf16* __restrict__ dy, const __bf16* __restrict__ x,
+                                                              float* __restrict__ part, float* __restrict__ db_part, int M, int Nout,
+                                                              int K, int chunk) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 31, half = lane >> 5;
+  const int nt_k = K / TW_K, tiles = (Nout / TW_N) * nt_k;
+  const int per = (tiles + 7) >> 3;                                  // XCD-aware tile order, k fastest (a dY tile stays in one L2)
+  const int tile = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if (tile >= tiles) return;
+  const int n0 = (tile / nt_k) * TW_N, k0 = (tile % nt_k) * TW_K;
+  const int m_lo = blockIdx.y * chunk, m_hi = min(M, m_lo + chunk);
+  const int nst = (m_hi - m_lo + TN_GM - 1) / TN_GM;
+
+  // ---- loader: a stage is 16 one-KiB pieces of dY (2 token rows x 512 B) and 8 of X (4 rows x 256 B); wave w moves dY pieces
+  // 4w .. 4w+3 and X pieces 2w, 2w+1.  LDS is written lane-linear, so the swizzle is applied to the SOURCE chunk.
+  const int a_row = lane >> 5, b_row = lane >> 4;                    // row inside a piece
+  const char* const dy_b = reinterpret_cast<const char*>(dy) + (size_t)n0 * 2;
+  const char* const x_b = reinterpret_cast<const char*>(x) + (size_t)k0 * 2;
+  const unsigned smem_base = tn_lds_addr(smem);
+  auto stage = [&](int st, int buf) {
+    const unsigned base = smem_base + buf * TW_STAGE_B;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = (wave * 4 + j) * 2 + a_row;                      // token row of the stage
+      const int m = min(m_lo + st * TN_GM + r, M - 1);               // rows past the end re-read the last row (zeroed below)
+      tn_dma16((unsigned)m * (unsigned)(Nout * 2) + (unsigned)(((lane & 31) ^ ((r & 3) << 2)) * 16), dy_b, base + (wave * 4 + j) * 1024);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int r = (wave * 2 + j) * 4 + b_row;
+      const int m = min(m_lo + st * TN_GM + r, M - 1);
+      tn_dma16((unsigned)m * (unsigned)(K * 2) + (unsigned)(((lane & 15) ^ ((r & 3) << 2)) * 16), x_b, base + TW_A_B + (wave * 2 + j) * 1024);
+    }
+  };
+
+  // ---- fragment pointers (slot 0, k16 step 0, read 0): the 16-lane group g = lane >> 4 reads rows 8 (g >> 1) + (t >> 2) [+ 16 s
+  // + 4 q as immediates], columns 32 blk + 16 (g & 1) + 4 (t & 3) .. +3 of the block; chunk = 4 blk' + 2 (g & 1) + ((t & 3) >> 1)
+  tw_lds_ptr pa[4], pb[2];
+  {
+    const int g = lane >> 4, t = lane & 15;
+    const int rowl = 8 * (g >> 1) + (t >> 2), lowc = 2 * (g & 1) + ((t & 3) >> 1), sw = (t >> 2) << 2, sub = (t & 1) * 8;
+    const tw_lds_ptr base = (tw_lds_ptr)smem;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pa[i] = base + (rowl * 512 + ((((wm * 4 + i) * 4 + lowc) ^ sw) << 4) + sub);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) pb[j] = base + (TW_A_B + rowl * 256 + ((((wn * 2 + j) * 4 + lowc) ^ sw) << 4) + sub);
+  }
+
+  f32x16 acc[4][2];                                                  // [i: n block][j: k block], D[k][n]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+  const bool want_db = db_part != nullptr && (tile % nt_k) == 0 && wn == 0;
+  float dbacc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+
+  stage(0, 0);
+  if (nst > 1) stage(1, 1);
+  for (int st0 = 0; st0 < nst; st0 += TW_NSTAGE) {
+    static_for_tn<TW_NSTAGE>([&](auto slot_c) {
+      constexpr int SLOT = decltype(slot_c)::value;
+      const int st = st0 + SLOT;
+      if (st >= nst) return;
+      // my pieces of stage st have landed when at most the one newer stage is in flight: 6 LDS-DMA per wave and stage
+      if (st + 1 < nst) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                                  // publishes stage st; everyone is done reading stage st-1
+      asm volatile("" ::: "memory");
+      if (st + TW_NSTAGE - 1 < nst) stage(st + TW_NSTAGE - 1, (SLOT + TW_NSTAGE - 1) % TW_NSTAGE);
+      const int mrow = m_lo + st * TN_GM;
+      const bool ragged = mrow + TN_GM > M;                          // only the last stage of the last split
+      Frag<__bf16> fa[2][4], fb[2][2];                               // [k16 step][block]
+#pragma unroll
+      for (int sk = 0; sk < 2; ++sk) {
+        constexpr int O = SLOT * TW_STAGE_B;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) tw_frag(fa[sk][i], pa[i] + (O + (16 * sk) * 512), pa[i] + (O + (16 * sk + 4) * 512));
+#pragma unroll
+        for (int j = 0; j < 2; ++j) tw_frag(fb[sk][j], pb[j] + (O + (16 * sk) * 256), pb[j] + (O + (16 * sk + 4) * 256));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int sk = 0; sk < 2; ++sk) {
+        if (ragged) {                                                // token rows >= M were clamped re-reads: contribute zero
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if (mrow + 16 * sk + 8 * half + e >= M) {
+#pragma unroll
+              for (int i = 0; i < 4; ++i) fa[sk][i].v[e] = (__bf16)0.0f;
+#pragma unroll
+              for (int j = 0; j < 2; ++j) fb[sk][j].v[e] = (__bf16)0.0f;
+            }
+        }
+        if (want_db) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            float t = 0.0f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t += (float)fa[sk][i].v[e];
+            dbacc[i] += t;
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = mma32(fb[sk][j], fa[sk][i], acc[i][j]);          // D[k][n]
+      }
+    });
+  }
+
+  if (want_db) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float v = dbacc[i] + __shfl_xor(dbacc[i], 32);          // the two halves hold the two 8-token runs of every k16 step
+      if (half == 0) db_part[(size_t)blockIdx.y * Nout + n0 + wm * 128 + i * 32 + li] = v;
+    }
+  }
+  // ---- fp32 partial of this token range: lane = row n of dW, registers 4g .. 4g+3 = 4 consecutive columns k
+  float* out = part + (size_t)blockIdx.y * Nout * K;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int n = n0 + wm * 128 + i * 32 + li;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int k = k0 + wn * 64 + j * 32 + 8 * g + 4 * half;
+        *reinterpret_cast<float4*>(out + (size_t)n * K + k) =
+            make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+      }
+  }
+}
+
 // The last `db_blocks` workgroups of the grid sum the bias-gradient partials instead ([S][C] -> [C]; same fixed order): one
 // launch for both reductions (the separate 5 us bias launch was 83 launches = 0.47 ms of the training step).
 template <typename T>
@@ -286,7 +446,29 @@ bool as_tn_applies(int M, int Nout, int K) {
          (size_t)M * K * 2 < (1ull << 32);
 }
 // token ranges: one or two workgroups per CU in all (<= 32 ranges), a multiple of the stage, >= 256 rows
+// 256 x 128 tiles (gemm_tn_wide_kernel) when the output has rows for them and at least 64 such tiles -- the MLP's weight
+// gradients (72 tiles at ViT-B: fc1 / fc2 dW + db 69.5 / 73.2 -> 61-62 / 66-68 us with two workgroups per CU = 7 token ranges;
+// with one per CU it LOSES, 88-90 us: four waves per CU do not hide the per-stage barrier).  The 54 / 18 tiles of the QKV / proj
+// gradients and the heads' 8 need more token ranges than their fp32 partials are worth (module backward 627 us either way).
+// AS_TN_WIDE=0: always the 128 x 128 kernel
+static bool tn_wide(int Nout, int K) {
+  static const bool off = getenv("AS_TN_WIDE") != nullptr && atoi(getenv("AS_TN_WIDE")) == 0;
+  static const int min_tiles = getenv("AS_TN_WIDE_MIN") ? atoi(getenv("AS_TN_WIDE_MIN")) : 64;
+  return !off && Nout % TW_N == 0 && K % TW_K == 0 && (Nout / TW_N) * (K / TW_K) >= min_tiles;
+}
 static int tn_plan(int M, int Nout, int K, int* splits) {
+  if (tn_wide(Nout, K)) {                            // two workgroups per CU: tiles x ranges ~ 512, <= 8 ranges
+    const int tiles = (Nout / TW_N) * (K / TW_K);
+    static const int slots_env = [] { const char* e = getenv("AS_TN_WIDE_SLOTS"); return e ? atoi(e) : 0; }();   // (experiments)
+    int S = (slots_env > 0 ? slots_env : 512) / tiles;
+    if (S > 8) S = 8;
+    if (S < 1) S = 1;
+    int chunk = as_round_up(as_ceil_div(M, S), TN_GM);
+    if (chunk < 256) chunk = 256;
+    if (chunk > as_round_up(M, TN_GM)) chunk = as_round_up(M, TN_GM);
+    *splits = as_ceil_div(M, chunk);
+    return chunk;
+  }
   const int tiles = (Nout / TN_T) * (K / TN_T);
   static const int slots_env = [] { const char* e = getenv("AS_TN_SLOTS"); return e ? atoi(e) : 0; }();   // (experiments)
   // measured (tools/experiments/dw_tn_bench.py, stages x slots sweep): the MLP's 144 output tiles want two workgroups per CU
@@ -314,6 +496,17 @@ int as_tn_dw(const void* dy, const void* x, void* dW, float* db, float* db_part,
   const int chunk = tn_plan(M, Nout, K, &S);
   AS_REQUIRE(ws && ws_bytes >= (size_t)S * Nout * K * sizeof(float), AS_E_BADARG, "tn dW: workspace too small");
   AS_REQUIRE(!db || db_part, AS_E_BADARG, "tn dW: db needs its partial buffer ([<= 32][Nout] floats)");
+  if (tn_wide(Nout, K)) {
+    const int tiles = (Nout / TW_N) * (K / TW_K);
+    static std::atomic<bool> attr_w{false};
+    if (!attr_w) {
+      (void)hipFuncSetAttribute((const void*)gemm_tn_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TW_NSTAGE * TW_STAGE_B);
+      attr_w = true;
+    }
+    hipLaunchKernelGGL(gemm_tn_wide_kernel, dim3(8 * as_ceil_div(tiles, 8), S), dim3(TN_NT), (size_t)TW_NSTAGE * TW_STAGE_B, s,
+                       (const __bf16*)dy, (const __bf16*)x, (float*)ws, db ? db_part : nullptr, M, Nout, K, chunk);
+    AS_CHECK_LAUNCH("gemm_tn_wide");
+  } else {
   const int tiles = (Nout / TN_T) * (K / TN_T);
   static const int stages = [] { const char* e = getenv("AS_TN_STAGES"); return e && atoi(e) == 4 ? 4 : 3; }();   // (experiments: 4-deep ring, 2 workgroups per CU)
   const size_t lds = (size_t)stages * TN_STAGE_B;
@@ -330,6 +523,7 @@ int as_tn_dw(const void* dy, const void* x, void* dW, float* db, float* db_part,
     hipLaunchKernelGGL(gemm_tn_splitk_kernel<4>, dim3(8 * as_ceil_div(tiles, 8), S), dim3(TN_NT), lds, s, (const __bf16*)dy,
                        (const __bf16*)x, (float*)ws, db ? db_part : nullptr, M, Nout, K, chunk);
   AS_CHECK_LAUNCH("gemm_tn_splitk");
+  }
   const size_t n4 = (size_t)Nout * K / 4;
   const int grid = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
   const int db_blocks = db ? as_ceil_div(Nout, 256) : 0;
