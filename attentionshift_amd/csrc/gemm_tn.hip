@@ -18,6 +18,9 @@
 
 namespace {
 
+#ifndef AS_TN_ABLATE
+#define AS_TN_ABLATE 0                    // (timing experiments on the 128 x 128 kernel: 1 no LDS-DMA in the loop, 2 no barrier, 3 no MFMAs)
+#endif
 constexpr int TN_T = 128;                 // features per tile side
 constexpr int TN_GM = 32;                 // token rows per stage (two k16 steps)
 constexpr int TN_NT = 256;
@@ -122,9 +125,9 @@ __global__ __launch_bounds__(TN_NT, TN_NSTAGE == 4 ? 2 : 3) void gemm_tn_splitk_
       if (newer == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       else if (newer == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();                                  // publishes stage st; everyone is done reading stage st-1
+      if (AS_TN_ABLATE != 2) __builtin_amdgcn_s_barrier();           // publishes stage st; everyone is done reading stage st-1
       asm volatile("" ::: "memory");
-      if (st + TN_NSTAGE - 1 < nst) stage(st + TN_NSTAGE - 1, (SLOT + TN_NSTAGE - 1) % TN_NSTAGE);
+      if (AS_TN_ABLATE != 1 && st + TN_NSTAGE - 1 < nst) stage(st + TN_NSTAGE - 1, (SLOT + TN_NSTAGE - 1) % TN_NSTAGE);
       // fragments of the stage: [operand][block][k16 step][read]; the first k16 step's eight reads are waited for alone
       // (LDS returns in order), so its MFMAs run while the second step's reads are still in flight
       tn_u32x2 ra[2][2][2], rb[2][2][2];
@@ -181,7 +184,10 @@ __global__ __launch_bounds__(TN_NT, TN_NSTAGE == 4 ? 2 : 3) void gemm_tn_splitk_
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) acc[i][j] = mma32(fb[j], fa[i], acc[i][j]);          // D[k][n]
+          for (int j = 0; j < 2; ++j) {
+            if (AS_TN_ABLATE == 3) { acc[i][j][0] += (float)fa[i].v[0] + (float)fb[j].v[1]; continue; }
+            acc[i][j] = mma32(fb[j], fa[i], acc[i][j]);          // D[k][n]
+          }
       }
     });
   }
