@@ -538,7 +538,7 @@ __device__ __forceinline__ void wa_frag_tr(Frag<__bf16>& f, wa_lds_ptr p0, wa_ld
 }
 
 template <int WS, int HD>
-__global__ __launch_bounds__(256, 3) void window_attn_bwd_mfma_kernel(const __bf16* __restrict__ qkv, const float* __restrict__ bqkv,
+__global__ __launch_bounds__(256, 2) void window_attn_bwd_mfma_kernel(const __bf16* __restrict__ qkv, const float* __restrict__ bqkv,
                                                                       const float* __restrict__ table, const __bf16* __restrict__ d_out,
                                                                       __bf16* __restrict__ dqkv, float* __restrict__ part_tab,
                                                                       float* __restrict__ part_pad, int B, int H, int W, int h,
@@ -547,7 +547,7 @@ __global__ __launch_bounds__(256, 3) void window_attn_bwd_mfma_kernel(const __bf
   constexpr int N = WS * WS, TB = (2 * WS - 1) * (2 * WS - 1);
   // per wave: three row-major [64 tokens][32 channels] bf16 images (64-byte rows) and two [64 queries][64 keys] images
   // (ONE of each, reused phase by phase: K rows for dQ, then dO rows + P for dV, then q rows + dS for dK and the table
-  //  gradient -- 13 KiB per wave, three workgroups per CU)
+  //  gradient -- 13 KiB per wave, two workgroups per CU)
   __shared__ __attribute__((aligned(16))) char Rm_s[4][64 * 64];
   __shared__ __attribute__((aligned(16))) char Im_s[4][64 * 128];
   __shared__ float tab_s[4][TB + 7];
