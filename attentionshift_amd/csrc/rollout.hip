@@ -457,7 +457,10 @@ constexpr int R4_STAGE = R4_LSE + 1024;                    // + lse rows [head][
 // ring depth / waves per SIMD asked of hipcc, per form: the 32-row form (NIB = 1, 168 registers) runs three workgroups per
 // CU on a two-stage ring (51 KB each); the 128-row form (NIB = 4) carries 64 more accumulator registers and keeps the
 // three-stage ring with two workgroups per CU (at three it spills 53 registers: 1.89 vs 0.94 ms for the 7-layer roll-out)
-template <int NIB> struct R4Cfg { static constexpr int NSTAGE = NIB == 1 ? 2 : 3, OCC = NIB == 1 ? 3 : 2; };
+#ifndef AS_R4_OCC1
+#define AS_R4_OCC1 3                          // (experiments: waves per SIMD asked for the 32-row form)
+#endif
+template <int NIB> struct R4Cfg { static constexpr int NSTAGE = NIB == 1 ? 2 : 3, OCC = NIB == 1 ? AS_R4_OCC1 : 2; };
 
 typedef __attribute__((ext_vector_type(4))) unsigned r4_u32x4;
 template <int OFF> __device__ __forceinline__ void r4_lds_read128(r4_u32x4& dst, unsigned addr) {
