@@ -83,6 +83,55 @@ class MLP(nn.Module):
         return x
 
 
+class DeferredFPN:
+    """The FPN maps of a no-grad forward whose kernels have not been queued yet (`VisionTransformerDet.defer_fpn`).
+
+    launch()  queues the FPN of every tap on a side stream that first waits for the caller's stream (the taps);
+    result()  makes the caller's stream wait for that side stream and returns the tuple of maps;
+    len / iteration / indexing go through result(), so a consumer that does not know about the deferral reads correct maps
+    (without the overlap).  The visual_transformer_det.py:246-256 arithmetic is `_fpn`, unchanged."""
+
+    def __init__(self, backbone, features, taps):
+        self._bb, self._features, self._taps = backbone, list(features), list(taps)
+        self._out, self._event, self._joined = None, None, False
+
+    def launch(self):
+        if self._out is not None:
+            return self
+        bb = self._bb
+        main = torch.cuda.current_stream()
+        if bb._fpn_stream is None:
+            bb._fpn_stream = torch.cuda.Stream()
+        side = bb._fpn_stream
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            for t in self._features + self._taps:
+                t.record_stream(side)                       # the taps were allocated on the caller's stream
+            self._out = tuple(bb._fpn(i, self._features[i], self._taps[i]) for i in range(len(self._features)))
+            self._event = side.record_event()
+        return self
+
+    def result(self):
+        self.launch()
+        if not self._joined:
+            main = torch.cuda.current_stream()
+            main.wait_event(self._event)
+            for t in self._out:
+                t.record_stream(main)
+            self._joined = True
+            self._features, self._taps = [], []
+        return self._out
+
+    def __len__(self):
+        return len(self._features) if self._out is None else len(self._out)
+
+    def __iter__(self):
+        return iter(self.result())
+
+    def __getitem__(self, i):
+        return self.result()[i]
+
+
 @BACKBONES.register_module()
 class VisionTransformerDet(nn.Module):
     def __init__(self, img_size, patch_size, embed_dim, in_chans=3, with_fpn=True, frozen_stages=-1,
@@ -109,6 +158,10 @@ class VisionTransformerDet(nn.Module):
         self.point_tokens_num = point_tokens_num
         self.with_point_head = with_point_head
         self.compute_dtype = compute_dtype
+        # no-grad forward: hand the FPN to the caller as a DeferredFPN (a schedule switch, same arithmetic; opt-in because
+        # the maps of such a forward become valid on the caller's stream only through DeferredFPN.result())
+        self.defer_fpn = bool(unused.pop("defer_fpn", False))
+        self._fpn_stream = None
 
         self.patch_embed = PatchEmbed(img_size, patch_size, in_chans, embed_dim)
         n_patches = self.patch_embed.num_patches
@@ -485,11 +538,17 @@ class VisionTransformerDet(nn.Module):
             org_features = torch.stack(features, dim=1)
         if self.with_fpn and grad_path:
             features = [self._fpn_train(i, features[i], taps[i]) for i in range(len(features))]
+        elif self.with_fpn and self.defer_fpn and x.is_cuda:
+            # nothing between here and the RoI head's feature extraction reads the FPN maps (two_stage_point_align.py:75-88:
+            # seed_pseudo_gt works on attns / last_feat), so their GEMMs are handed to the caller as a DeferredFPN: the RoI
+            # head launches them on a side stream when its own latency-bound chain of small launches starts
+            features = DeferredFPN(self, features, taps)
         elif self.with_fpn:
             # the taps are token-major already: run the 2x2/2 deconvolutions as GEMMs over tokens (channels-last)
             features = [self._fpn(i, features[i], taps[i]) for i in range(len(features))]
         point_tokens = x[:, -T:]
-        out = dict(org_feats=org_features, feature=tuple(features), point_tokens=point_tokens)
+        out = dict(org_feats=org_features, feature=features if isinstance(features, DeferredFPN) else tuple(features),
+                   point_tokens=point_tokens)
         if self.with_point_head:
             out.update(outputs_class=self.class_embed(point_tokens), outputs_coord=self.bbox_embed(point_tokens).sigmoid())
         if self.return_attention and self.last_feat:

@@ -32,6 +32,25 @@ constexpr float COS_EPS = 1e-8f;
 
 struct Box { int x0, y0, x1, y1; };
 
+// -DAS_SHIFT_STAMPS (tools/experiments/shift_timeline.py): thread 0 of every workgroup writes s_memrealtime (100 MHz, one
+// counter for the whole chip) at the phase boundaries of the three iteration kernels; `drain` first waits for the
+// workgroup's outstanding loads so that the stamp is "operands landed", not "operands requested".
+#ifdef AS_SHIFT_STAMPS
+constexpr int ST_SLOTS = 8, ST_BLOCKS = 1024, ST_LAUNCH = 16;
+__device__ unsigned long long g_stamps[ST_LAUNCH][ST_BLOCKS][ST_SLOTS];
+#define AS_STAMP_ARG , int stamp_id
+#define AS_STAMP_VAL(x) , x
+#define AS_STAMP(slot, drain)                                                                                      \
+  do {                                                                                                             \
+    if (drain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                    \
+    if (threadIdx.x == 0) g_stamps[stamp_id][blockIdx.y * gridDim.x + blockIdx.x][slot] = wall_clock64();           \
+  } while (0)
+#else
+#define AS_STAMP_ARG
+#define AS_STAMP_VAL(x)
+#define AS_STAMP(slot, drain)
+#endif
+
 __device__ __forceinline__ Box load_box(const int32_t* bp, int g, int Hp, int Wp) {
   Box b;
   b.x0 = max(bp[g * 4 + 0], 0); b.y0 = max(bp[g * 4 + 1], 0);
@@ -134,15 +153,17 @@ __global__ __launch_bounds__(S1_NT) void shift_sim_kernel(const float* __restric
                                                           const int32_t* __restrict__ obj_img,
                                                           const int2* __restrict__ aw_prev,   // [G][Np] compact or null
                                                           float* __restrict__ sim, float* __restrict__ part_stats,
-                                                          int C, int Hp, int Wp, int P, int nt1) {
+                                                          int C, int Hp, int Wp, int P, int nt1 AS_STAMP_ARG) {
   __shared__ float red[8][32][33];
   __shared__ float nrm[2][16][32];
   __shared__ float invnp_s[PMAX];
   const int Np = Hp * Wp;
   const int g = blockIdx.y, tile = blockIdx.x;
+  AS_STAMP(0, false);
   const Box ob = load_box(box_patch_, g, Hp, Wp);
   const int nb = box_count(ob);
   if (tile * CS_TILE1 >= nb) return;
+  AS_STAMP(1, false);                            // box known
   const int b = obj_img[g];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, half = lane >> 5;
@@ -189,6 +210,7 @@ __global__ __launch_bounds__(S1_NT) void shift_sim_kernel(const float* __restric
     // keep all 4*SU operand loads in flight: without the fence the scheduler sinks each load to its MFMA to save
     // registers and the loop degenerates into SU dependent memory round trips
     __builtin_amdgcn_sched_barrier(0);
+    AS_STAMP(2, true);                           // operand fragments landed
 #pragma unroll
     for (int u = 0; u < SU; ++u) {
 #pragma unroll
@@ -201,11 +223,13 @@ __global__ __launch_bounds__(S1_NT) void shift_sim_kernel(const float* __restric
       acc = mma32(fa[u], fb[u], acc);          // D[p][n]
     }
   }
+  AS_STAMP(3, false);                            // MFMA chain issued
 #pragma unroll
   for (int r = 0; r < 16; ++r) red[wave][acc_row(r, half)][li] = acc[r];
   nrm[0][wave * 2 + half][li] = qa;
   nrm[1][wave * 2 + half][li] = qb;
   __syncthreads();
+  AS_STAMP(4, false);                            // partials exchanged
 
   float fn = 0.0f;
 #pragma unroll
@@ -240,6 +264,7 @@ __global__ __launch_bounds__(S1_NT) void shift_sim_kernel(const float* __restric
       ps[1] = ds;
     }
   }
+  AS_STAMP(5, false);                            // results stored (issued)
 }
 
 // ---- shift iteration, pass 2: per-prototype softmax statistics + assignment of this tile ------------------
@@ -252,14 +277,16 @@ __global__ __launch_bounds__(CS_NT) void shift_assign_kernel(const float* __rest
                                                              const int32_t* __restrict__ box_patch_,
                                                              float* __restrict__ stats, float* __restrict__ tau_out,
                                                              int2* __restrict__ aw, int32_t* __restrict__ assign_out,
+                                                             int32_t* __restrict__ oc_out,
                                                              float tau0, float temp, float tt0, int it, int Hp, int Wp,
-                                                             int P, int G, int nt1) {
+                                                             int P, int G, int nt1 AS_STAMP_ARG) {
   __shared__ float sh_mx[8][32], sh_ds[8][32];
   __shared__ float st_s[PMAX * 4], zs_s[PMAX * 2];
   const int Np = Hp * Wp;
   const int g = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
   const int t0 = tile * CS_TILE1;
+  AS_STAMP(0, false);
   // Every dependent global-memory hop of these small kernels costs ~2 us, so ALL operands are requested before
   // anything is known about the box: addresses are clamped to the array, masks are applied when the box arrives.
   constexpr int PSU = 8;                       // part_stats tiles per thread per trip (8 slots x PSU = 64 tiles)
@@ -289,8 +316,10 @@ __global__ __launch_bounds__(CS_NT) void shift_assign_kernel(const float* __rest
   const Box ob = load_box(box_patch_, g, Hp, Wp);
   const int nb = box_count(ob);
   __builtin_amdgcn_sched_barrier(0);
-  if (t0 >= nb && assign_out == nullptr) return;
+  if (t0 >= nb && assign_out == nullptr && tile != 0) return;   // (tile 0 always publishes the object's statistics)
+  AS_STAMP(1, false);                            // box known
   const int ntiles = (nb + CS_TILE1 - 1) / CS_TILE1;
+  AS_STAMP(2, true);                             // blind operand loads landed
 
   {                                             // maximum / previous-assignment density sums over the tiles
     float mx = -INFINITY, ds = 0.0f;
@@ -325,6 +354,7 @@ __global__ __launch_bounds__(CS_NT) void shift_assign_kernel(const float* __rest
     zs_s[p * 2 + 0] = maxsim; zs_s[p * 2 + 1] = 1.4426950408889634f / tt;
   }
   __syncthreads();
+  AS_STAMP(3, false);                            // tau / max per prototype
   // Z_p: wave w owns prototypes w, w+4, ... (<= 8 of them).  Every tile workgroup of the object repeats this sum,
   // so it uses the hardware exp2 on (sim - max) * log2(e)/(temp*tau): the difference is exact for the terms that
   // matter (close to the maximum), one rounding + v_exp_f32 instead of an IEEE division and a full expf per term.
@@ -364,6 +394,7 @@ __global__ __launch_bounds__(CS_NT) void shift_assign_kernel(const float* __rest
     }
   }
   __syncthreads();
+  AS_STAMP(4, false);                            // Z per prototype
   if (tile == 0 && tid < P * 4) stats[(size_t)g * PMAX * 4 + tid] = st_s[tid];
 
   // user-visible assignment of out-of-box patches (never read back by the iteration itself)
@@ -389,6 +420,21 @@ __global__ __launch_bounds__(CS_NT) void shift_assign_kernel(const float* __rest
     sh_ds[slot][sp] = __int_as_float(bp);
   }
   __syncthreads();
+  // the cluster every out-of-box patch falls into (the aggregation's member counts need it): one lane per prototype and a
+  // shuffle argmax with the sequential scan's rule (strict >, so ties go to the lowest index) -- here the statistics are in
+  // LDS; in the aggregation kernel the same scan was a dependent global round trip + 20 expf on the launch's critical path
+  if (tile == 0 && wave == 1) {              // wave 0 merges the tile's assignment below; wave 1 is idle here
+    const int p = lane & 31;
+    float w = (lane < 32 && p < P) ? expf(0.0f / st_s[p * 4 + 0] - st_s[p * 4 + 1]) / st_s[p * 4 + 2] : -INFINITY;
+    int bp = (lane < 32 && p < P) ? p : PMAX;
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) {
+      const float w2 = __shfl_xor(w, o);
+      const int p2 = __shfl_xor(bp, o);
+      if (w2 > w || (w2 == w && p2 < bp)) { w = w2; bp = p2; }
+    }
+    if (lane == 0) oc_out[g] = bp < P ? bp : 0;
+  }
   if (tid < CS_TILE1 && t0 + tid < nb) {
     const int t = t0 + tid;
     int best = 0;
@@ -402,6 +448,7 @@ __global__ __launch_bounds__(CS_NT) void shift_assign_kernel(const float* __rest
     aw[(size_t)g * Np + t] = make_int2(best, __float_as_int(bw));
     if (assign_out != nullptr) assign_out[(size_t)g * Np + box_patch(ob, t, Wp)] = best;
   }
+  AS_STAMP(5, false);                            // assignment stored (issued)
 }
 
 // ---- shift iteration, pass 3: cluster-wise aggregation, channel-major ---------------------------------------
@@ -412,23 +459,26 @@ __global__ __launch_bounds__(CS_NT) void shift_assign_kernel(const float* __rest
 // and, from channel block 0, the member counts (for the density).
 __global__ __launch_bounds__(CS_NT) void shift_aggregate_kernel(const float* __restrict__ feat,
                                                                 const int2* __restrict__ aw,
-                                                                const float* __restrict__ stats,
+                                                                const int32_t* __restrict__ oc_in,
                                                                 const int32_t* __restrict__ box_patch_,
                                                                 const int32_t* __restrict__ obj_img,
                                                                 float* __restrict__ prot, float* __restrict__ pn2,
                                                                 int32_t* __restrict__ cnt, int C, int Hp, int Wp,
-                                                                int P) {
+                                                                int P AS_STAMP_ARG) {
   __shared__ float4 acc_s[PMAX * CS_NT];
   __shared__ int cnt_s[PMAX];
   const int Np = Hp * Wp;
   const int chunk = blockIdx.x, nchunk = gridDim.x, g = blockIdx.y, tid = threadIdx.x;
+  AS_STAMP(0, false);
   const Box ob = load_box(box_patch_, g, Hp, Wp);
   const int nb = box_count(ob), bw = max(box_w(ob), 1);
   const int b = obj_img[g];
+  const int oc = oc_in[g];                      // cluster of the out-of-box patches (shift_assign), requested early
   const int cq = tid & 7, ms = tid >> 3;
   const bool count_here = chunk == 0 && cq == 0;
   if (tid < PMAX) cnt_s[tid] = 0;
   __syncthreads();
+  AS_STAMP(1, false);                            // box known
 
   const float* fb = feat + (size_t)b * Np * C + chunk * SH_CH + cq * 4;
   const int2* awg = aw + (size_t)g * Np;
@@ -446,6 +496,7 @@ __global__ __launch_bounds__(CS_NT) void shift_aggregate_kernel(const float* __r
       m[u] = awg[j];
     }
     __builtin_amdgcn_sched_barrier(0);          // all 2*U loads issued before the first use
+    if (j0 == ms) AS_STAMP(2, true);            // first batch of (feature, assignment) loads landed
     if (!zeroed) {                              // a thread only ever touches its own accumulator slots: no barrier
       for (int p = 0; p < P; ++p) acc_s[p * CS_NT + tid] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
       zeroed = true;
@@ -463,6 +514,7 @@ __global__ __launch_bounds__(CS_NT) void shift_aggregate_kernel(const float* __r
     }
   }
   __syncthreads();
+  AS_STAMP(3, false);                            // member-slot accumulation done
 
   const float* accf = reinterpret_cast<const float*>(acc_s);
   for (int o = tid; o < PMAX * SH_CH; o += CS_NT) {       // uniform trip count: the shuffles below need whole waves
@@ -486,13 +538,14 @@ __global__ __launch_bounds__(CS_NT) void shift_aggregate_kernel(const float* __r
   }
   if (chunk == 0 && tid < P) {
     int c = cnt_s[tid];
-    if (nb < Np && outside_cluster(stats + (size_t)g * PMAX * 4, P) == tid) c += Np - nb;
+    if (nb < Np && oc == tid) c += Np - nb;
     cnt[g * PMAX + tid] = c;
   }
+  AS_STAMP(4, false);                            // prototypes / norms / counts stored (issued)
 }
 
 struct WsLayout {
-  size_t pn2, cnt, stats, part_stats, sim_c, aw, total;
+  size_t pn2, cnt, oc, stats, part_stats, sim_c, aw, total;
   int nt1, nchunk;
 };
 WsLayout ws_layout(int B, int C, int Np, int G, int P) {
@@ -503,6 +556,7 @@ WsLayout ws_layout(int B, int C, int Np, int G, int P) {
   size_t o = 0;
   w.pn2 = o; o = al(o + (size_t)G * w.nchunk * PMAX * 4);
   w.cnt = o; o = al(o + (size_t)G * PMAX * 4);
+  w.oc = o; o = al(o + (size_t)G * 4);
   w.stats = o; o = al(o + (size_t)G * PMAX * 16);
   w.part_stats = o; o = al(o + (size_t)G * w.nt1 * PMAX * 8);
   w.sim_c = o; o = al(o + (size_t)G * P * Np * 4);
@@ -516,6 +570,18 @@ WsLayout ws_layout(int B, int C, int Np, int G, int P) {
 void as_shift_final_sim_launch(const float* feat, const float* prot, const int32_t* box_patch, const int32_t* obj_img,
                                const int2* aw, float* sim_out, float* part_stats, int B, int C, int Hp, int Wp, int P, int G,
                                int nt1, hipStream_t s);                       // shift_final.hip
+
+#ifdef AS_SHIFT_STAMPS
+extern "C" int as_shift_stamps_read(void* dst, size_t bytes, int clear) {
+  if (bytes > sizeof(g_stamps)) bytes = sizeof(g_stamps);
+  if (hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_stamps), bytes, 0, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  if (clear) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_stamps)) != hipSuccess || hipMemset(p, 0, sizeof(g_stamps)) != hipSuccess) return -2;
+  }
+  return 0;
+}
+#endif
 
 extern "C" size_t as_cosine_shift_workspace_bytes(int B, int C, int Hp, int Wp, int G, int P) {
   if (B <= 0 || C <= 0 || Hp <= 0 || Wp <= 0 || G <= 0 || P <= 0) return 0;
@@ -541,6 +607,7 @@ extern "C" int as_cosine_shift(const float* feat, const int32_t* box_patch, cons
   char* w = (char*)ws;
   float* pn2 = (float*)(w + L.pn2);
   int32_t* cnt = (int32_t*)(w + L.cnt);
+  int32_t* oc = (int32_t*)(w + L.oc);
   float* stats = (float*)(w + L.stats);
   float* part_stats = (float*)(w + L.part_stats);
   float* sim_c = (float*)(w + L.sim_c);
@@ -554,12 +621,12 @@ extern "C" int as_cosine_shift(const float* feat, const int32_t* box_patch, cons
   for (int it = 0; it < n_shift; ++it) {
     hipLaunchKernelGGL(shift_sim_kernel, dim3(L.nt1, G), dim3(S1_NT), 0, s, feat, it == 0 ? prot_in : prot_out,
                        it == 0 ? nullptr : pn2, L.nchunk, box_patch, obj_img, it > 0 ? aw : nullptr, sim_c, part_stats,
-                       C, Hp, Wp, P, L.nt1);
+                       C, Hp, Wp, P, L.nt1 AS_STAMP_VAL(it < 5 ? it * 3 : 15));
     int32_t* aout = assign_out ? assign_out + (size_t)it * G * Np : nullptr;
     hipLaunchKernelGGL(shift_assign_kernel, dim3(L.nt1, G), dim3(CS_NT), 0, s, sim_c, part_stats, cnt, box_patch,
-                       stats, tau_out, aw, aout, tau0, temp, tt0, it, Hp, Wp, P, G, L.nt1);
-    hipLaunchKernelGGL(shift_aggregate_kernel, dim3(L.nchunk, G), dim3(CS_NT), 0, s, feat, aw, stats, box_patch,
-                       obj_img, prot_out, pn2, cnt, C, Hp, Wp, P);
+                       stats, tau_out, aw, aout, oc, tau0, temp, tt0, it, Hp, Wp, P, G, L.nt1 AS_STAMP_VAL(it < 5 ? it * 3 + 1 : 15));
+    hipLaunchKernelGGL(shift_aggregate_kernel, dim3(L.nchunk, G), dim3(CS_NT), 0, s, feat, aw, oc, box_patch,
+                       obj_img, prot_out, pn2, cnt, C, Hp, Wp, P AS_STAMP_VAL(it < 5 ? it * 3 + 2 : 15));
   }
   // final similarity on the UNMASKED map (+ the density of the last assignment for tau_out)
   as_shift_final_sim_launch(feat, n_shift > 0 ? prot_out : prot_in, box_patch, obj_img, (n_shift > 0 && tau_out) ? aw : nullptr,

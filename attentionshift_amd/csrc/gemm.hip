@@ -26,6 +26,7 @@ template <typename T> struct GemmCfg {
 struct QkvEpi {
   void* q; void* k; void* vt;
   int N, Npad, D, h;
+  int stagger;     // two-workgroups-per-CU tiles: the second wave of workgroups starts this many s_sleep(127) late (0 = off)
 };
 
 __device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
@@ -266,8 +267,8 @@ constexpr int G_NSTAGE = AS_GEMM_K32_STAGES;
 #ifndef AS_GEMM_K64_STAGES
 #define AS_GEMM_K64_STAGES 2
 #endif
-template <int WM, int WN = 2, int RI = 2, int KS = 2> struct GTile {
-  static constexpr int BM_ = 32 * RI * WM, BN_ = 64 * WN, NT_ = 64 * WM * WN;
+template <int WM, int WN = 2, int RI = 2, int KS = 2, int NJ = 2> struct GTile {
+  static constexpr int BM_ = 32 * RI * WM, BN_ = 32 * NJ * WN, NT_ = 64 * WM * WN;   // NJ: 32-column blocks per wave
   static constexpr int GK_ = 16 * KS, ROWB = 2 * GK_;        // K elements / bytes of one tile row per stage
   static constexpr int PROWS = 1024 / ROWB;                  // tile rows per 1-KiB LDS-DMA piece: 16 / 8
   static constexpr int A_BYTES = BM_ * ROWB, W_BYTES = BN_ * ROWB;
@@ -294,8 +295,11 @@ template <int LEFT> __device__ __forceinline__ void g_lds_wait4(g_u32x4& a, g_u3
   __builtin_amdgcn_sched_barrier(0);
 }
 template <int LEFT, int N> __device__ __forceinline__ void g_lds_waitn(g_u32x4* f) {
-  static_assert(N == 6, "128 x 64 wave tile: 4 + 2 fragments per k16 step");
-  asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]) : "n"(LEFT));
+  static_assert(N == 6 || N == 8, "128 x 64 wave tile: 4 + 2 fragments per k16 step; 128 x 128: 4 + 4");
+  if constexpr (N == 6)
+    asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]) : "n"(LEFT));
+  else
+    asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7]) : "n"(LEFT));
   __builtin_amdgcn_sched_barrier(0);
 }
 template <int... I, typename F> __device__ __forceinline__ void g_static_for_impl(std::integer_sequence<int, I...>, F&& f) {
@@ -312,11 +316,11 @@ template <int KS> __device__ __forceinline__ int g_swz(int r) {
   return KS == 2 ? ((r >> 2) & 3) : (((r >> 1) & 3) | (((r >> 4) & 1) << 2));
 }
 
-template <int MODE, int WM, int WN, int RI, int KS>
-__global__ __launch_bounds__(64 * WM * WN, (WN == 4 || KS == 4) ? 1 : (WM == 2 ? 3 : 2)) void gemm_glds_kernel(
+template <int MODE, int WM, int WN, int RI, int KS, int NJ = 2>
+__global__ __launch_bounds__(64 * WM * WN, (WN == 4 || KS == 4) ? 1 : (WM == 2 && RI == 2 ? 3 : 2)) void gemm_glds_kernel(
     const __bf16* __restrict__ A, const __bf16* __restrict__ W, const float* __restrict__ bias, __bf16* __restrict__ out,
     int M, int Nout, int K, int act, QkvEpi epi) {
-  using GT = GTile<WM, WN, RI, KS>;
+  using GT = GTile<WM, WN, RI, KS, NJ>;
   constexpr int GK = GT::GK_, ROWB = GT::ROWB, PROWS = GT::PROWS, CPR = ROWB / 16;   // CPR: 16-byte chunks per tile row
   constexpr int BM = GT::BM_, BN = GT::BN_, NT = GT::NT_, G_TILE_BYTES = GT::A_BYTES, G_STAGE = GT::STAGE;
   constexpr int G_EPI_PITCH = GT::EPI_PITCH, NSTAGE = GT::NSTAGE;
@@ -333,6 +337,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WN == 4 || KS == 4) ? 1 : (WM == 2 ?
   const int per = (tiles + 7) >> 3;
   const int tile = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
   if (tile >= tiles) return;
+  // phase offset between the two workgroups that share a CU (see launch_gemm_glds): without it both run their main loops
+  // and then their epilogues at the same time; with it one's prologue / epilogue runs under the other's MFMAs
+  if (epi.stagger > 0 && blockIdx.x >= 256 && blockIdx.x < 512)
+    for (int i = 0; i < epi.stagger; ++i) __builtin_amdgcn_s_sleep(127);
   const int m0 = (tile / nt_n) * BM, n0 = (tile % nt_n) * BN;
 
   // loader: per K step wave w moves NAP one-KiB pieces of A (tile rows 16p .. 16p+15 of piece p = NAP*w + j) and NWP of
@@ -367,11 +375,11 @@ __global__ __launch_bounds__(64 * WM * WN, (WN == 4 || KS == 4) ? 1 : (WM == 2 ?
                                        16, 0, 0);
   };
 
-  f32x16 acc[RI][2];                                 // [i: 32-row block of m][j: 32-col block of n], D[n][m] orientation
+  f32x16 acc[RI][NJ];                                // [i: 32-row block of m][j: 32-col block of n], D[n][m] orientation
 #pragma unroll
   for (int i = 0; i < RI; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
@@ -380,7 +388,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WN == 4 || KS == 4) ? 1 : (WM == 2 ?
   const unsigned smem_base = g_lds_addr(smem);
   unsigned offA[KS], offW[KS];
   {
-    const int ra = wm * (32 * RI) + li, rb = wn * 64 + li;
+    const int ra = wm * (32 * RI) + li, rb = wn * (32 * NJ) + li;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       const int g = ks * 2 + half;
@@ -410,7 +418,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WN == 4 || KS == 4) ? 1 : (WM == 2 ?
       }
       if (AS_GEMM_ABLATE != 4) __builtin_amdgcn_s_barrier();   // publishes stage kt; everyone is done reading stage kt-1
       if (AS_GEMM_ABLATE != 1 && kt + NSTAGE - 1 < nk) stage(kt + NSTAGE - 1, (slot + NSTAGE - 1) % NSTAGE);
-      constexpr int NF = RI + 2;                     // fragments per k16 step: RI of A, 2 of W
+      constexpr int NF = RI + NJ;                    // fragments per k16 step: RI of A, NJ of W
       g_static_for<KS / 2>([&](auto kp_c) {          // pairs of k16 steps
       constexpr int k0 = 2 * decltype(kp_c)::value;
       g_u32x4 f[2 * NF];                             // [ks][A0 .. A(RI-1), W0, W1]
@@ -424,14 +432,16 @@ __global__ __launch_bounds__(64 * WM * WN, (WN == 4 || KS == 4) ? 1 : (WM == 2 ?
           constexpr int i = decltype(i_c)::value;
           g_lds_read128<slot * G_STAGE + i * 32 * ROWB>(f[ks * NF + i], offA[k0 + ks]);
         });
-        g_lds_read128<slot * G_STAGE>(f[ks * NF + RI], offW[k0 + ks]);
-        g_lds_read128<slot * G_STAGE + 32 * ROWB>(f[ks * NF + RI + 1], offW[k0 + ks]);
+        g_static_for<NJ>([&](auto j_c) {
+          constexpr int j = decltype(j_c)::value;
+          g_lds_read128<slot * G_STAGE + j * 32 * ROWB>(f[ks * NF + RI + j], offW[k0 + ks]);
+        });
       });
       // the first half's MFMAs start as soon as ITS fragments are back; the second half's reads finish under them
       g_static_for<2>([&](auto ks_c) {
         constexpr int ks = decltype(ks_c)::value;
         if (AS_GEMM_ABLATE != 3) {
-          if constexpr (RI == 2) {
+          if constexpr (RI == 2 && NJ == 2) {
             if (ks == 0) g_lds_wait4<4>(f[0], f[1], f[2], f[3]);
             else g_lds_wait4<0>(f[4], f[5], f[6], f[7]);
           } else {
@@ -443,7 +453,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WN == 4 || KS == 4) ? 1 : (WM == 2 ?
 #pragma unroll
         for (int i = 0; i < RI; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) {
+          for (int j = 0; j < NJ; ++j) {
             Frag<__bf16> fa, fb;
             fa.v = *reinterpret_cast<bf16x8*>(&f[ks * NF + i]);
             fb.v = *reinterpret_cast<bf16x8*>(&f[ks * NF + RI + j]);
@@ -465,10 +475,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WN == 4 || KS == 4) ? 1 : (WM == 2 ?
       const int row = m0 + wm * (32 * RI) + i * 32 + li;
       if (row >= M) continue;
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const int col = n0 + wn * 64 + j * 32 + 8 * g + 4 * half;
+          const int col = n0 + wn * (32 * NJ) + j * 32 + 8 * g + 4 * half;
           float* dst = part + (size_t)row * Nout + col;
           if (col + 4 <= Nout) {
             *reinterpret_cast<float4*>(dst) = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
@@ -489,8 +499,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WN == 4 || KS == 4) ? 1 : (WM == 2 ?
       if (row < M) {
         const int b = row / epi.N, n = row - b * epi.N;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int cbase = n0 + wn * 64 + j * 32;
+        for (int j = 0; j < NJ; ++j) {
+          const int cbase = n0 + wn * (32 * NJ) + j * 32;
           const int head = (cbase % epi.D) / 64, dd0 = cbase % 64;
           __bf16* dst = reinterpret_cast<__bf16*>(epi.vt) + ((size_t)(b * epi.h + head) * 64 + dd0) * epi.Npad + n;
 #pragma unroll
@@ -509,7 +519,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WN == 4 || KS == 4) ? 1 : (WM == 2 ?
   if (AS_GEMM_ABLATE == 7) {                         // timing experiment: no epilogue at all (accumulators kept alive)
     float keep = 0.0f;
 #pragma unroll
-    for (int i = 0; i < RI; ++i) keep += acc[i][0][0] + acc[i][1][15];
+    for (int i = 0; i < RI; ++i) keep += acc[i][0][0] + acc[i][NJ - 1][15];
     if (keep == 12345.678f) out[0] = (__bf16)keep;
     return;
   }
@@ -520,17 +530,17 @@ __global__ __launch_bounds__(64 * WM * WN, (WN == 4 || KS == 4) ? 1 : (WM == 2 ?
   if (AS_GEMM_ABLATE == 8) {                         // timing experiment: no conversion / staging writes (garbage is stored)
     float keep = 0.0f;
 #pragma unroll
-    for (int i = 0; i < RI; ++i) keep += acc[i][0][0] + acc[i][1][15];
+    for (int i = 0; i < RI; ++i) keep += acc[i][0][0] + acc[i][NJ - 1][15];
     if (keep == 12345.678f) smem[0] = 1;
   }
 #pragma unroll
   for (int i = 0; i < (AS_GEMM_ABLATE == 8 ? 0 : RI); ++i) {
     char* srow = smem + (wm * (32 * RI) + i * 32 + li) * G_EPI_PITCH;
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int c0 = wn * 64 + j * 32 + 8 * g + 4 * half;     // 4 consecutive columns: registers 4g .. 4g+3
+        const int c0 = wn * (32 * NJ) + j * 32 + 8 * g + 4 * half;   // 4 consecutive columns: registers 4g .. 4g+3
         const float4 bv = *reinterpret_cast<const float4*>(bias_s + c0);
         float v0 = acc[i][j][4 * g] + bv.x, v1 = acc[i][j][4 * g + 1] + bv.y, v2 = acc[i][j][4 * g + 2] + bv.z,
               v3 = acc[i][j][4 * g + 3] + bv.w;
@@ -587,20 +597,20 @@ __global__ __launch_bounds__(64 * WM * WN, (WN == 4 || KS == 4) ? 1 : (WM == 2 ?
   }
 }
 
-template <int MODE, int WM, int WN, int RI = 2, int KS = 2>
+template <int MODE, int WM, int WN, int RI = 2, int KS = 2, int NJ = 2>
 int launch_gemm_glds_wm(const void* A, const void* W, const float* bias, void* out, int M, int Nout, int K, int act,
                         QkvEpi epi, hipStream_t s) {
-  using GT = GTile<WM, WN, RI, KS>;
+  using GT = GTile<WM, WN, RI, KS, NJ>;
   const int tiles = as_ceil_div(M, GT::BM_) * as_ceil_div(Nout, GT::BN_);
   dim3 grid(8 * as_ceil_div(tiles, 8), MODE == 3 ? as_ceil_div(K, epi.N) : 1);   // x padded to a multiple of the 8 XCDs (tile order)
   // ring 48 / 72 / 96 KiB; the epilogue restages the output tile in the same memory (35 / 70 / 133 KiB)
   const size_t lds = (size_t)GT::LDS;
   static std::atomic<bool> attr_set{false};   // (idempotent attribute call: a race only repeats it)
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_glds_kernel<MODE, WM, WN, RI, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)gemm_glds_kernel<MODE, WM, WN, RI, KS, NJ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_glds_kernel<MODE, WM, WN, RI, KS>), grid, dim3(GT::NT_), lds, s, (const __bf16*)A, (const __bf16*)W, bias,
+  hipLaunchKernelGGL((gemm_glds_kernel<MODE, WM, WN, RI, KS, NJ>), grid, dim3(GT::NT_), lds, s, (const __bf16*)A, (const __bf16*)W, bias,
                      (__bf16*)out, M, Nout, K, act, epi);
   AS_CHECK_LAUNCH("gemm_glds");
   return AS_OK;
@@ -630,19 +640,24 @@ int launch_gemm_glds(const void* A, const void* W, const float* bias, void* out,
     const char* e = getenv("AS_GEMM_TILE");
     if (e == nullptr) return 0;
     return !strcmp(e, "short") ? 1 : !strcmp(e, "tall") ? 2 : !strcmp(e, "tall64") ? 3 : !strcmp(e, "wide64") ? 4 :
-           !strcmp(e, "wide32") ? 5 : 0;
+           !strcmp(e, "wide32") ? 5 : !strcmp(e, "tall4") ? 6 : !strcmp(e, "wide4") ? 7 : 0;
   }();
+  static const int stagger = [] { const char* e = getenv("AS_GEMM_STAGGER"); return e ? atoi(e) : 0; }();
+  epi.stagger = stagger;
   const int nt_n = as_ceil_div(Nout, BN), tall_tiles = as_ceil_div(M, 256) * nt_n;
   const bool k64 = K % 64 == 0;
   const float short_cost = (float)as_ceil_div(as_ceil_div(M, 128) * nt_n, 256);
   const float tall_cost = (float)as_ceil_div(tall_tiles, 256) * (tall_tiles <= 256 && k64 ? 1.47f : 2.0f / 1.28f);
   const float wide_cost = (MODE != 1 && k64) ? (float)as_ceil_div(as_ceil_div(M, 256) * as_ceil_div(Nout, 256), 256) * 2.8f : 1e30f;
   int pick = wide_cost < tall_cost && wide_cost < short_cost ? 4 : tall_cost < short_cost ? (tall_tiles <= 256 && k64 ? 3 : 2) : 1;
-  if (forced && (forced < 3 || forced == 5 || k64) && ((forced != 4 && forced != 5) || MODE != 1)) pick = forced;
+  if (forced && (forced < 3 || forced == 5 || forced == 6 || k64) && ((forced != 4 && forced != 5 && forced != 7) || MODE != 1)) pick = forced;
+  if (pick == 6) return launch_gemm_glds_wm<MODE, 2, 2, 4, 2>(A, W, bias, out, M, Nout, K, act, epi, s);
   if constexpr (MODE != 1) {
     if (pick == 4) return launch_gemm_glds_wm<MODE, 2, 4, 4, 4>(A, W, bias, out, M, Nout, K, act, epi, s);
     // experiment (AS_GEMM_TILE=wide32): the 256 x 256 tile on K-step-32 stages, AS_GEMM_K32_STAGES deep (32 KiB each)
     if (pick == 5) return launch_gemm_glds_wm<MODE, 2, 4, 4, 2>(A, W, bias, out, M, Nout, K, act, epi, s);
+    // experiment (AS_GEMM_TILE=wide4): the 256 x 256 tile on FOUR waves of 128 x 128 (one wave per SIMD, 256 accumulator registers)
+    if (pick == 7) return launch_gemm_glds_wm<MODE, 2, 2, 4, 4, 4>(A, W, bias, out, M, Nout, K, act, epi, s);
   }
   if (pick == 3) return launch_gemm_glds_wm<MODE, 4, 2, 2, 4>(A, W, bias, out, M, Nout, K, act, epi, s);
   if (pick == 2) return launch_gemm_glds_wm<MODE, 4, 2, 2, 2>(A, W, bias, out, M, Nout, K, act, epi, s);

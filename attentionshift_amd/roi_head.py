@@ -1275,6 +1275,10 @@ class AttnShiftRoIHead(nn.Module):
             boxes, status, cam_minmax = ops.cam_boxes(cams_lr, pts, self.bbox_head.seed_thr,
                                                       self.bbox_head.seed_multiple, STRIDE, return_minmax=True)
         CLOCK.mark("cam_boxes")
+        if hasattr(x, "launch"):
+            # backbone.DeferredFPN: from here to the RoI feature extraction this path is a dependent chain of small launches
+            # that leaves the device idle -- the FPN's GEMMs run under it on their own stream
+            x.launch()
         # the reference raises here when a CAM has no foreground component (torch.stack of an empty list, stdroi:80).
         # The flag stays on the device and is checked at the first host sync the chain needs anyway (the seed counts):
         # reading it here would stall the host for the whole roll-out + CAM-box phase with nothing queued behind it.

@@ -131,7 +131,7 @@ def build(device, rng_mode="fast", train=False, ranks=None, mil=False):
                                qkv_bias=True, drop_path_rate=0.05, out_indices=(3, 5, 7, 11) if CFG["depth"] == 12 else (5, 11, 17, 23),
                                learnable_pos_embed=True, use_checkpoint=True, last_feat=True,
                                point_tokens_num=CFG["point_tokens"], num_classes=CFG["num_classes"], return_attention=True,
-                               compute_dtype=torch.bfloat16))
+                               compute_dtype=torch.bfloat16, defer_fpn=not train and os.environ.get("AS_DEFER_FPN", "1") != "0"))
     bb = bb.to(device)
     bb = bb.train() if train else bb.eval()
 
@@ -190,7 +190,11 @@ def build(device, rng_mode="fast", train=False, ranks=None, mil=False):
 
     if not train:
         def step():
-            return pseudo_labels(bb(img))
+            out = bb(img)
+            res = pseudo_labels(out)
+            if hasattr(out["feature"], "result"):
+                out["feature"].result()                # the step ends with the FPN maps valid on the caller's stream
+            return res
 
         step.head = head
         return step

@@ -70,6 +70,32 @@ def test_backbone_bf16_close_to_reference(golden, tag):
     assert rel(t(g["rollout_rows"]), rows) < 3e-2
 
 
+def test_deferred_fpn_is_the_same_maps(golden):
+    """VisionTransformerDet.defer_fpn: the FPN maps queued later on a side stream (backbone.DeferredFPN) are bit-identical
+    to the ones the forward computes itself, a consumer that just indexes `feature` gets valid maps on its own stream, and
+    launch() before result() (the RoI head's order) gives the same again."""
+    from attentionshift_amd.backbone import DeferredFPN
+    g = golden("backbone_tiny224")
+    bb, img, cfg = build_backbone(g, torch.bfloat16)
+    ref = [f.clone() for f in bb(img)["feature"]]
+    bb.defer_fpn = True
+    out = bb(img)
+    assert isinstance(out["feature"], DeferredFPN) and len(out["feature"]) == len(ref)
+    busy = torch.randn(2048, 2048, device="cuda")
+    for _ in range(8):                                     # keep the caller's stream busy: the join must still order the reads
+        busy = busy @ busy * 1e-3
+    for i, f in enumerate(out["feature"]):                 # iteration = launch + join
+        assert torch.equal(f, ref[i]), f"feature{i} (auto-join)"
+    out2 = bb(img)
+    out2["feature"].launch()
+    got = out2["feature"].result()
+    assert out2["feature"].result() is got
+    for i in range(len(ref)):
+        assert torch.equal(out2["feature"][i], ref[i]) and got[i].shape == ref[i].shape, f"feature{i} (launch, then result)"
+    bb.defer_fpn = False
+    assert isinstance(bb(img)["feature"], tuple)
+
+
 @pytest.mark.parametrize("tag", ["tiny224", "mid320"])
 def test_seed_pseudo_gt_chain_matches_reference(golden, tag, monkeypatch):
     import attentionshift_amd as A

@@ -73,7 +73,7 @@ def run_one(name, shapes, act):
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 50
-        print(json.dumps(dict(variant=name + "@" + os.environ.get("AS_GEMM_TILE", "auto"), M=M, N=N, K=K,
+        print(json.dumps(dict(variant=name + "@" + os.environ.get("AS_GEMM_TILE", "auto") + "+" + os.environ.get("AS_GEMM_STAGGER", "0"), M=M, N=N, K=K,
                               us=round(ms * 1e3, 1), tflops=round(2.0 * M * N * K / ms / 1e9), err=round(err, 5), lib_tflops=lib_tf)), flush=True)
         assert err < 2e-2, err
 
@@ -94,8 +94,12 @@ def main():
     else:
         for v in a.variants.split(","):
             name, _, mode = v.partition("@")
+            mode, _, stag = mode.partition("+")              # name@tile+N: AS_GEMM_STAGGER=N (phase offset of the second workgroup per CU)
             env = dict(os.environ)
             env.pop("AS_GEMM_TILE", None)
+            env.pop("AS_GEMM_STAGGER", None)
+            if stag:
+                env["AS_GEMM_STAGGER"] = stag
             if mode:
                 env["AS_GEMM_TILE"] = mode
             subprocess.call([sys.executable, os.path.abspath(__file__), "_one", "--variants", name, "--act", str(a.act)]
