@@ -89,7 +89,12 @@ class DeferredFPN:
     launch()  queues the FPN of every tap on a side stream that first waits for the caller's stream (the taps);
     result()  makes the caller's stream wait for that side stream and returns the tuple of maps;
     len / iteration / indexing go through result(), so a consumer that does not know about the deferral reads correct maps
-    (without the overlap).  The visual_transformer_det.py:246-256 arithmetic is `_fpn`, unchanged."""
+    (without the overlap).  The visual_transformer_det.py:246-256 arithmetic is `_fpn`, unchanged.
+
+    Measured on the headline step (round 5): NOT a win on MI355X -- the 256 x 256 GEMM workgroups fill every CU's
+    register file, so each small launch of the RoI head's chain waits for a GEMM workgroup to retire (7.43 -> 7.79 ms per
+    step; with a fifth stream the four default hardware queues are over-subscribed and the two image chains serialise;
+    a CU-masked stream is slower still).  It stays opt-in for callers whose head has real work to hide it under."""
 
     def __init__(self, backbone, features, taps):
         self._bb, self._features, self._taps = backbone, list(features), list(taps)

@@ -43,6 +43,30 @@ __device__ __forceinline__ float gelu_bf16(float x) {
   return 0.5f * x + 0.5f * fabsf(x) * e;
 }
 
+// The same function on two values at once: the polynomial, the scalings and the final blend go through the packed fp32 VALU
+// ops (v_pk_mul / v_pk_fma_f32: two IEEE results per instruction), the reciprocal and the exponential stay scalar (no packed
+// transcendental) -- 17 instructions per PAIR instead of ~16 per value.  Used by the inference epilogue (act == 1), where a
+// 256 x 256 tile spends 64 k of these per workgroup with the matrix pipe idle.
+typedef __attribute__((ext_vector_type(2))) float g_f32x2;
+__device__ __forceinline__ g_f32x2 gelu_bf16_x2(g_f32x2 x) {
+  const g_f32x2 hx = x * 0.5f;
+  g_f32x2 ahx;
+  ahx.x = fabsf(hx.x); ahx.y = fabsf(hx.y);                             // |x| / 2
+  const g_f32x2 z = ahx * 1.41421356237309504880f;                      // |x| / sqrt 2
+  const g_f32x2 den = z * 0.3275911f + 1.0f;
+  g_f32x2 t;
+  t.x = __builtin_amdgcn_rcpf(den.x); t.y = __builtin_amdgcn_rcpf(den.y);
+  g_f32x2 p = t * 1.061405429f + (-1.453152027f);
+  p = p * t + 1.421413741f;
+  p = p * t + (-0.284496736f);
+  p = p * t + 0.254829592f;
+  const g_f32x2 a = (z * z) * (-1.44269504088896340736f);
+  g_f32x2 g;
+  g.x = __builtin_amdgcn_exp2f(a.x); g.y = __builtin_amdgcn_exp2f(a.y);
+  const g_f32x2 e = 1.0f - (p * t) * g;                                 // erf(|x| / sqrt 2)
+  return hx + ahx * e;
+}
+
 // d/dx of the erf-GELU with the same erf: 0.5 (1 + erf(x / sqrt 2)) + x exp(-x^2 / 2) / sqrt(2 pi)
 __device__ __forceinline__ float gelu_grad_bf16(float x) {
   const float z = fabsf(x) * 0.70710678118654752440f;
@@ -547,7 +571,14 @@ __global__ __launch_bounds__(64 * WM * WN, (WN == 4 || KS == 4) ? 1 : (WM == 2 &
         if (MODE == 1 && n0 + c0 < epi.D) {              // q columns: stored pre-scaled by log2(e)/8 (common.h)
           v0 *= AS_QSCALE; v1 *= AS_QSCALE; v2 *= AS_QSCALE; v3 *= AS_QSCALE;
         }
-        if (act == 1) { v0 = gelu_bf16(v0); v1 = gelu_bf16(v1); v2 = gelu_bf16(v2); v3 = gelu_bf16(v3); }
+        if (act == 1) {
+#ifdef AS_GEMM_GELU_SCALAR                               // (A/B switch: the one-value-per-instruction form)
+          v0 = gelu_bf16(v0); v1 = gelu_bf16(v1); v2 = gelu_bf16(v2); v3 = gelu_bf16(v3);
+#else
+          const g_f32x2 ga = gelu_bf16_x2(g_f32x2{v0, v1}), gb = gelu_bf16_x2(g_f32x2{v2, v3});
+          v0 = ga.x; v1 = ga.y; v2 = gb.x; v3 = gb.y;
+#endif
+        }
         bf16x4 pk = {(__bf16)v0, (__bf16)v1, (__bf16)v2, (__bf16)v3};
         *reinterpret_cast<bf16x4*>(srow + c0 * 2) = pk;
       }

@@ -669,12 +669,19 @@ __device__ __forceinline__ void rank_select_store(int32_t* out, long long* out_x
   }
 }
 
+// MODE 0: the rank comes from `ranks`.  MODE 1 / 2 (as_rank_draw_xy): the rank is derived from the row's population n, which
+// the chunk counts already give -- 1: a uniform draw, min(int(u[m][k] * float(n)), max(n - 1, 0)), the fast-RNG form of the
+// reference's `torch.randint(n, ...)` (stdroi:366); 2: the k-th of K grid-strided positives, k * max(n / K, 1) (stdroi:1790-
+// 1792).  Both raise *flag when n < K (the reference's refill branches, which the caller redoes on the host path).
+template <int MODE>
 __global__ __launch_bounds__(64) void rank_select_kernel(const uint8_t* __restrict__ mask, const int32_t* __restrict__ cc,
-                                                         const int32_t* __restrict__ ranks, int32_t* __restrict__ out,
+                                                         const int32_t* __restrict__ ranks, const float* __restrict__ u,
+                                                         int32_t* __restrict__ flag, int32_t* __restrict__ out,
                                                          long long* __restrict__ out_xy, int W, int yx, int HW, int nchunk,
                                                          int K) {
   const int k = blockIdx.x, m = blockIdx.y, lane = threadIdx.x;
-  int r = ranks[(size_t)m * K + k];
+  int r = MODE == 0 ? ranks[(size_t)m * K + k] : 0;
+  const float uk = MODE == 1 ? u[(size_t)m * K + k] : 0.0f;
   const int32_t* c = cc + (size_t)m * nchunk;
   // level 1: which chunk
   const int cpl = (nchunk + 63) / 64;
@@ -689,6 +696,12 @@ __global__ __launch_bounds__(64) void rank_select_kernel(const uint8_t* __restri
     for (int i = lane * cpl; i < min((lane + 1) * cpl, nchunk); ++i) mine += c[i];
   }
   const int before = wave_excl_scan(mine, lane);
+  if (MODE != 0) {
+    const int n = __shfl(before + mine, 63);       // the row's population
+    if (MODE == 1) r = min((int)(uk * (float)n), max(n - 1, 0));
+    else r = k * max(n / K, 1);
+    if (k == 0 && lane == 0 && n < K && flag != nullptr) atomicOr(flag, 1);
+  }
   const unsigned long long hit = __ballot(r >= before && r < before + mine);
   if (hit == 0ull || r < 0) {                    // rank beyond the population
     if (lane == 0) rank_select_store(out, out_xy, (size_t)m * K + k, -1, W, yx);
@@ -920,15 +933,21 @@ extern "C" size_t as_rank_select_workspace_bytes(int M, int HW) {
 }
 
 static int rank_select_launch(const uint8_t* mask, const int32_t* ranks, int32_t* out, long long* out_xy, int W, int yx, void* ws,
-                              size_t ws_bytes, int M, int HW, int K, as_stream_t stream, const char* who) {
-  AS_REQUIRE(mask && ranks && (out || out_xy) && ws, AS_E_BADARG, "%s: null pointer", who);
+                              size_t ws_bytes, int M, int HW, int K, as_stream_t stream, const char* who, int mode = 0,
+                              const float* u = nullptr, int32_t* flag = nullptr) {
+  AS_REQUIRE(mask && (ranks || mode != 0) && (out || out_xy) && ws, AS_E_BADARG, "%s: null pointer", who);
   AS_REQUIRE(M > 0 && HW > 0 && K > 0 && HW % 16 == 0 && W > 0, AS_E_BADARG, "%s: bad sizes (HW %% 16 == 0)", who);
   AS_REQUIRE(ws_bytes >= as_rank_select_workspace_bytes(M, HW), AS_E_WORKSPACE, "%s: workspace too small", who);
   hipStream_t s = (hipStream_t)stream;
   const int nchunk = as_ceil_div(HW, RS_CHUNK);
   int32_t* cc = (int32_t*)ws;
   hipLaunchKernelGGL(rank_counts_kernel, dim3(nchunk, M), dim3(RF_NT), 0, s, mask, cc, HW, nchunk);
-  hipLaunchKernelGGL(rank_select_kernel, dim3(K, M), dim3(64), 0, s, mask, cc, ranks, out, out_xy, W, yx, HW, nchunk, K);
+  if (mode == 1)
+    hipLaunchKernelGGL(rank_select_kernel<1>, dim3(K, M), dim3(64), 0, s, mask, cc, ranks, u, flag, out, out_xy, W, yx, HW, nchunk, K);
+  else if (mode == 2)
+    hipLaunchKernelGGL(rank_select_kernel<2>, dim3(K, M), dim3(64), 0, s, mask, cc, ranks, u, flag, out, out_xy, W, yx, HW, nchunk, K);
+  else
+    hipLaunchKernelGGL(rank_select_kernel<0>, dim3(K, M), dim3(64), 0, s, mask, cc, ranks, u, flag, out, out_xy, W, yx, HW, nchunk, K);
   AS_CHECK_LAUNCH(who);
   return AS_OK;
 }
@@ -942,6 +961,15 @@ extern "C" int as_rank_select_xy(const uint8_t* mask, const int32_t* ranks, int6
                                  int HW, int K, int W, int yx_order, as_stream_t stream) {
   return rank_select_launch(mask, ranks, nullptr, (long long*)out_xy, W, yx_order ? 1 : 0, ws, ws_bytes, M, HW, K, stream,
                             "as_rank_select_xy");
+}
+
+extern "C" int as_rank_draw_xy(const uint8_t* mask, int mode, const float* u, int32_t* flag, int64_t* out_xy, void* ws,
+                               size_t ws_bytes, int M, int HW, int K, int W, int yx_order, as_stream_t stream) {
+  AS_REQUIRE(mode == 1 || mode == 2, AS_E_BADARG, "as_rank_draw_xy: mode %d (1 = uniform draws, 2 = grid stride)", mode);
+  AS_REQUIRE(mode != 1 || u, AS_E_BADARG, "as_rank_draw_xy: mode 1 needs the uniform numbers");
+  AS_REQUIRE(out_xy, AS_E_BADARG, "as_rank_draw_xy: null pointer");
+  return rank_select_launch(mask, nullptr, nullptr, (long long*)out_xy, W, yx_order ? 1 : 0, ws, ws_bytes, M, HW, K, stream,
+                            "as_rank_draw_xy", mode, u, flag);
 }
 
 extern "C" int as_mask_count(const uint8_t* mask, int32_t* counts, int M, int HW, as_stream_t stream) {

@@ -906,6 +906,27 @@ def rank_select_xy(mask, ranks, W, yx=False):
     return out
 
 
+def rank_draw_xy(mask, K, W, u=None, flag=None, yx=False):
+    """rank_select_xy whose ranks come from each row's population n on the device (as_rank_draw_xy): with `u` [M,K] uniform
+    numbers rank = min(int(u * n), max(n - 1, 0)) (the fast-RNG seed draws); without, the K grid-strided positives
+    k * max(n // K, 1).  `flag` (int32 [1] or 0-dim view, OR-ed with 1 when some row has fewer than K set bytes)."""
+    lib = _lib.load()
+    _chk(mask, dtype=torch.uint8)
+    M, HW = mask.shape
+    if u is not None:
+        _chk(u, dtype=torch.float32)
+        if tuple(u.shape) != (M, K):
+            raise AttnShiftError("rank_draw_xy: u must be [M, K]")
+    if flag is not None and (flag.dtype != torch.int32 or flag.numel() != 1 or not flag.is_cuda):
+        raise AttnShiftError("rank_draw_xy: flag must be one int32 on the device")
+    out = torch.empty(M, K, 2, device=mask.device, dtype=torch.int64)
+    nbytes = lib.as_rank_select_workspace_bytes(M, HW)
+    ws = torch.empty(nbytes, device=mask.device, dtype=torch.uint8)
+    _lib.check(lib.as_rank_draw_xy(_p(mask), 1 if u is not None else 2, _p(u), _p(flag), _p(out), _p(ws), nbytes, M, HW, int(K),
+                                   int(W), 1 if yx else 0, _stream()), "as_rank_draw_xy")
+    return out
+
+
 def roi_align_fwd(feat_nhwc, rois, out_size, spatial_scale, sampling_ratio=0, aligned=True):
     """feat [B,H,W,C] fp32 token-major, rois [R,5] fp32 -> [R, out*out, C] (csrc/roi_align.hip)."""
     lib = _lib.load()

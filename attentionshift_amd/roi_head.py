@@ -333,12 +333,18 @@ def sample_points_from_cams(cams_lr, map_idx, minmax, gt_points, num_points, thr
 # raise a device FLAG; the caller reads it with a readback it needs anyway and redoes that image on the synchronous
 # path (same distributions, different draws).
 
-def sample_points_from_cams_nosync(cams_lr, map_idx, minmax, num_points, gen, thr_bg=0.1, thr_fg=0.2):
+def sample_points_from_cams_nosync(cams_lr, map_idx, minmax, num_points, gen, thr_bg=0.1, thr_fg=0.2, flag=None):
     """sample_points_from_cams without the count readback.  Returns (pts_bg, pts_fg, pts_supp, flag) with flag a
-    device bool: some candidate set is smaller than num_points (the reference's refill branches, stdroi:354-364)."""
+    device flag: some candidate set is smaller than num_points (the reference's refill branches, stdroi:354-364).
+    `flag` (a zeroed int32 [1] slot of the caller): the ranks are then derived inside the selection kernel from the
+    populations it counts anyway (ops.rank_draw_xy: one launch pair instead of the eight tensor ops below)."""
     G = map_idx.shape[0]
     masks, counts = ops.cam_sample_masks(cams_lr, map_idx, minmax, thr_bg, thr_fg, STRIDE)
     W = masks.shape[-1]
+    if flag is not None and (masks.shape[-1] * masks.shape[-2]) % 16 == 0:
+        u = torch.rand(2 * G + 1, num_points, device=masks.device, generator=gen)
+        pts = ops.rank_draw_xy(masks.flatten(1), num_points, W, u=u, flag=flag)
+        return pts[:G], pts[G:2 * G], pts[2 * G:], flag.reshape(())
     n = counts.float()[:, None]
     u = torch.rand(2 * G + 1, num_points, device=masks.device, generator=gen)
     ranks = torch.minimum((u * n).to(torch.int32), (counts[:, None] - 1).clamp(min=0))
@@ -376,7 +382,7 @@ def mask_points_mt(pend, num_gt, mt_state):
     return coords, is_pos, flag[0] != 0
 
 
-def mask_points_nosync(pend, num_gt, gen):
+def mask_points_nosync(pend, num_gt, gen, int_flag=False):
     """mask_points_finish without the count readback: num_gt DISTINCT uniform ranks among the n = n_pos + n_neg
     candidates of each object (the first num_gt entries of a random permutation, stdroi:447) = the first num_gt
     distinct values of 32 uniform draws.  flag: an object with fewer than 4*num_gt candidates (the host path's
@@ -388,13 +394,16 @@ def mask_points_nosync(pend, num_gt, gen):
     xy_pos = rank_select_xy(pos.flatten(1), rank_pos, W)
     xy_neg = rank_select_xy(neg.flatten(1), rank_neg, W)
     coords = torch.where(is_pos[..., None], xy_pos, xy_neg).float()
-    return coords, is_pos, flag[0] != 0
+    return coords, is_pos, (flag[0] if int_flag else flag[0] != 0)
 
 
-def grid_seed_nosync(mask, count_dev, n_points=20):
+def grid_seed_nosync(mask, count_dev, n_points=20, flag=None):
     """grid_seed_finish without the count readback, for objects with at least n_points positives (stdroi:1790-1792:
-    every (n // n_points)-th positive in raster order).  flag: an object with fewer (refill / box-centre branches)."""
+    every (n // n_points)-th positive in raster order).  flag: an object with fewer (refill / box-centre branches).
+    With `flag` (a zeroed int32 [1] slot) ranks and flag come out of the selection kernel itself (ops.rank_draw_xy)."""
     G, hp, wp = mask.shape
+    if flag is not None and (hp * wp) % 16 == 0 and mask.dtype == torch.uint8:
+        return ops.rank_draw_xy(mask.flatten(1), n_points, wp, flag=flag, yx=True), flag.reshape(())
     step = (count_dev // n_points).clamp(min=1)
     ranks = torch.arange(n_points, device=mask.device, dtype=torch.int32)[None, :] * step[:, None].int()
     return rank_select_xy(mask.flatten(1), ranks, wp, yx=True), (count_dev < n_points).any()
@@ -941,7 +950,7 @@ class AttnShiftRoIHead(nn.Module):
         return ops.rollout_rows(states, num_proposals, rows=sel.to(states[0].q.device).long())
 
     def refine_maps(self, attn_sel, feat_chw, rois, gt_points, refine_times, obj_tau, minmax=None, cam_src=None,
-                    draw_gen=None, flags_out=None, last_level_only=False, mt_state=None):
+                    draw_gen=None, flags_out=None, last_level_only=False, mt_state=None, flag_slot=None):
         """B2 (stdroi:1000-1019).  attn_sel [G,H,W], feat [C,hp,wp]; minmax [G,2] = per-map (min,max) if the
         caller already has them (as_cam_boxes does).  cam_src = (cams_lr [M,hp,wp], map_idx [G] int32, minmax [M,2])
         replaces attn_sel: the seed sampling then reads the low-resolution CAMs and the upsampled maps are never
@@ -953,7 +962,8 @@ class AttnShiftRoIHead(nn.Module):
             flags_out.append(short)
         elif cam_src is not None and draw_gen is not None:        # fast-RNG mode: no readback, flag instead
             G = cam_src[1].shape[0]
-            pts_bg, pts_fg, pts_supp, short = sample_points_from_cams_nosync(cam_src[0], cam_src[1], cam_src[2], 20, draw_gen)
+            pts_bg, pts_fg, pts_supp, short = sample_points_from_cams_nosync(cam_src[0], cam_src[1], cam_src[2], 20, draw_gen,
+                                                                             flag=flag_slot)
             flags_out.append(short)
         elif cam_src is not None:
             G = cam_src[1].shape[0]
@@ -1335,7 +1345,7 @@ class AttnShiftRoIHead(nn.Module):
                 self.capture.append(dict(image=i, seeds=seeds, fg_inter=fg_inter))
             return coord_point, labels_point, map_fg, map_bg, feats_fg, feats_bg, (fg_inter, seeds), pm
 
-        def phase_a_nosync(i, mt_state=None):
+        def phase_a_nosync(i, mt_state=None, flag_slots=None):
             """phase_a + phase_a_finish with every draw made on the device: nothing is read back.  Fast RNG mode: uniform
             numbers from the device generator; reference mode (`mt_state`): torch's own engine advanced on the device, the
             images strictly in order on one stream.  The last element is the list of device flags that ask for the
@@ -1346,7 +1356,7 @@ class AttnShiftRoIHead(nn.Module):
             map_fg, map_bg, _pa, _pb, feats_fg, feats_bg = self.refine_maps(
                 None, feats[i], pseudo_boxes[i], gt_points[i], 2, obj_tau, cam_src=(cams_lr, map_idx, cam_minmax),
                 draw_gen=None if mt_state is not None else self._device_gen(boxes.device), flags_out=flags,
-                last_level_only=True, mt_state=mt_state)
+                last_level_only=True, mt_state=mt_state, flag_slot=None if flag_slots is None else flag_slots[i, 0:1])
             mp, mask_u8 = mask_points_and_pseudo_issue(map_fg[-1], map_bg[-1], pseudo_boxes[i], pos_mask_thr, neg_mask_thr,
                                                        corr_size, pos_mask_thr)
             fg_inter, _map_fg_patch, gs = self._semantic_pre(map_fg[-1], map_bg[-1], pos_mask_thr)
@@ -1354,8 +1364,9 @@ class AttnShiftRoIHead(nn.Module):
             if mt_state is not None:
                 coord_point, labels_point, f1 = mask_points_mt(mp, num_mask_point_gt, mt_state)
             else:
-                coord_point, labels_point, f1 = mask_points_nosync(mp, num_mask_point_gt, self._device_gen(boxes.device))
-            seeds, f2 = grid_seed_nosync(gs[0], gs[1], 20)
+                coord_point, labels_point, f1 = mask_points_nosync(mp, num_mask_point_gt, self._device_gen(boxes.device),
+                                                                   int_flag=flag_slots is not None)
+            seeds, f2 = grid_seed_nosync(gs[0], gs[1], 20, flag=None if flag_slots is None else flag_slots[i, 1:2])
             if self.capture is not None:
                 self.capture.append(dict(image=i, seeds=seeds, fg_inter=fg_inter))
             flags += [f1, f2]
@@ -1394,9 +1405,11 @@ class AttnShiftRoIHead(nn.Module):
                 mt_final = _to_host_issue(mt_state)
             else:
                 self._device_gen(boxes.device, reseed=True)
+                # device flags raised by the selection kernels themselves (too few candidates): one zero fill for the batch
+                flag_slots = torch.zeros(num_imgs, 2, dtype=torch.int32, device=boxes.device)
                 for st in self._streams[:num_imgs]:
                     st.wait_stream(main)
-                ra = [on_stream(i, phase_a_nosync) for i in range(num_imgs)]
+                ra = [on_stream(i, phase_a_nosync, None, flag_slots) for i in range(num_imgs)]
                 for st in self._streams[:num_imgs]:
                     main.wait_stream(st)
             shifted = self.mean_shift_batch([r[6][1] for r in ra], feats, pseudo_boxes, self.mean_shift_times_local,

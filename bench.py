@@ -131,7 +131,7 @@ def build(device, rng_mode="fast", train=False, ranks=None, mil=False):
                                qkv_bias=True, drop_path_rate=0.05, out_indices=(3, 5, 7, 11) if CFG["depth"] == 12 else (5, 11, 17, 23),
                                learnable_pos_embed=True, use_checkpoint=True, last_feat=True,
                                point_tokens_num=CFG["point_tokens"], num_classes=CFG["num_classes"], return_attention=True,
-                               compute_dtype=torch.bfloat16, defer_fpn=not train and os.environ.get("AS_DEFER_FPN", "1") != "0"))
+                               compute_dtype=torch.bfloat16, defer_fpn=not train and os.environ.get("AS_DEFER_FPN", "0") == "1"))
     bb = bb.to(device)
     bb = bb.train() if train else bb.eval()
 
@@ -477,6 +477,18 @@ def main():
         elapsed = timed(step, ranks, a.steps)
     timing = ops.collect_timing()
     ops.disable_timing()
+    block_timing = {}
+    if vit and os.environ.get("AS_BENCH_EVENTS", "1") == "1":
+        # the attention BLOCK (A1 + A2 = QKV projection + SDPA + output projection) against the MFMA peak.  Its
+        # three launches are timed in a few extra steps AFTER the headline's timed region (six event records per layer would
+        # otherwise sit inside it)
+        with torch.no_grad():
+            ops.enable_timing(["qkv_gemm", "sdpa_fwd", "proj_gemm"])
+            for _ in range(5):
+                step()
+            torch.cuda.synchronize()
+        block_timing = ops.collect_timing()
+        ops.disable_timing()
     B = CFG["batch"]
     rec = {
         "metric": "images/sec (1024^2, ViT-B) hot path: backbone attention fwd + attention-shift pseudo-labels",
@@ -532,6 +544,23 @@ def main():
             "frac": round(ach / PEAK_BF16_TFLOPS, 4),
             "traffic": _static_traffic(("r04_sdpa_traffic.json", "r03_sdpa_traffic.json"), "per_as_sdpa_fwd_call_bytes") if headline else None,
             "launches_timed": n_sdpa, "ms_per_launch": round(ms_sdpa, 4), "flops_per_launch": flops_sdpa}
+        if all(k in block_timing for k in ("qkv_gemm", "sdpa_fwd", "proj_gemm")):
+            D_ = CFG["embed_dim"]
+            ms_q, ms_s, ms_p = (block_timing[k][1] for k in ("qkv_gemm", "sdpa_fwd", "proj_gemm"))
+            fl_q, fl_p = 2.0 * B * N * D_ * 3 * D_, 2.0 * B * N * D_ * D_
+            blk = (fl_q + flops_sdpa + fl_p) / ((ms_q + ms_s + ms_p) * 1e-3) / 1e12
+            rec["roofline_attention_block"] = {
+                "what": "A1 + A2 of SURVEY 8d(ii): as_qkv_fwd + as_sdpa_fwd + output projection of one layer, one batch "
+                        f"({(fl_q + flops_sdpa + fl_p) * CFG['depth'] / B / 1e9:.1f} GFLOP per image forward over the "
+                        f"{CFG['depth']} layers); HIP events around the three launches in 5 steps after the timed region",
+                "bound": "mfma", "achieved": round(blk, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(blk / PEAK_BF16_TFLOPS, 4), "launches_timed": block_timing["sdpa_fwd"][0],
+                "ms_per_layer": {"qkv": round(ms_q, 4), "sdpa": round(ms_s, 4), "proj": round(ms_p, 4),
+                                 "sum": round(ms_q + ms_s + ms_p, 4)},
+                "frac_by_kernel": {"qkv": round(fl_q / (ms_q * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
+                                   "sdpa": round(flops_sdpa / (ms_s * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
+                                   "proj": round(fl_p / (ms_p * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4)},
+                "flops_per_layer": fl_q + flops_sdpa + fl_p}
         # the step as a whole against the MFMA peak: the backbone's matrix FLOPs (QKV / proj / MLP GEMMs + QK^T and PV of the
         # attention; the roll-out's recomputed QK^T tiles counted too) over the measured step time
         D, L, Ntok = CFG["embed_dim"], CFG["depth"], N

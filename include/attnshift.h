@@ -393,6 +393,17 @@ int as_rank_select(const uint8_t* mask /*[M,HW] 0/1*/, const int32_t* ranks /*[M
 int as_rank_select_xy(const uint8_t* mask /*[M,HW] 0/1*/, const int32_t* ranks /*[M,K]*/, int64_t* out_xy /*[M,K,2]*/, void* ws,
                       size_t ws_bytes, int M, int HW, int K, int W, int yx_order, as_stream_t stream);
 
+/* Rank selection whose ranks are derived on the device from each row's population n (known from the same counting pass), so
+ * that the sampling chains need no tensor-op glue and no readback (fast-RNG mode of the seed sampling, stdroi:346-369, and the
+ * grid seeds of mean_shift_grid_prototype, stdroi:1790-1792):
+ *   mode 1  rank[m][k] = min(int(u[m][k] * float(n_m)), max(n_m - 1, 0))     u [M,K] uniform in [0, 1)
+ *   mode 2  rank[m][k] = k * max(n_m / K, 1)                                 every (n / K)-th positive
+ * out_xy as as_rank_select_xy; *flag (int32, may be NULL) is OR-ed with 1 when some n_m < K (the reference's refill
+ * branches: the caller repeats that image on the host path). */
+int as_rank_draw_xy(const uint8_t* mask /*[M,HW] 0/1*/, int mode, const float* u /*[M,K] or NULL*/, int32_t* flag,
+                    int64_t* out_xy /*[M,K,2]*/, void* ws, size_t ws_bytes, int M, int HW, int K, int W, int yx_order,
+                    as_stream_t stream);
+
 /* Small-N batched multi-head self-attention (the MAE-decoder box / mask heads: thousands of 50- / 197-token problems of
  * head dim 32 per step; models/vision_transformer.py:62-86 as used by mae_bbox_head_rec.py:148-168):
  *   qkv  [Bp, N, 3, h, d]  the packed output of the reference's qkv Linear (fp32 or bf16), d = 32

@@ -358,6 +358,51 @@ def test_sdpa_stream_k_matches_oracle_and_the_plain_grid(ops, monkeypatch, B, h,
         assert_close(lse_ref2, lse6b, 1e-4, 1e-3, "lse (stream-K, second operand set)")
 
 
+def _sdpa_matched_reference(qb, kb, vb):
+    """Precision-matched restatement of the shipped bf16 forward (models/vision_transformer.py:79-83 at the kernel's own
+    rounding points): q' = q * log2(e)/8, k, v are the bf16 VALUES the kernel reads; the base-2 logits S = q'.k and the
+    weights P = 2^S are fp32; the row sum adds the fp32 weights; the P.V product takes P ROUNDED TO bf16 (the MFMA B
+    operand); the output is rounded to bf16 once.  (A running-max variant scales P by a power of two that is not an
+    integer power, which moves individual roundings of P by one bf16 ulp -- an O(1e-4) effect on a 4197-key average.)"""
+    s2 = qb.double() @ kb.double().transpose(-1, -2)                    # exact products, fp64 sums: the fp32 MFMA sum to ~1e-7
+    p = torch.exp2(s2.float())                                          # fp32 weights, no reference subtracted (MODE 1)
+    l = p.double().sum(-1, keepdim=True)
+    o = (p.bfloat16().double() @ vb.double()) / l
+    B, h, N, _ = qb.shape
+    return o.transpose(1, 2).reshape(B, N, h * 64).float().bfloat16().float()
+
+
+@pytest.mark.parametrize("impl", ["", "0", "1", "2", "3", "4", "5", "6", "7"])
+@pytest.mark.parametrize("N,h", [(4197, 2), (6501, 1)])
+def test_sdpa_bf16_against_the_precision_matched_oracle(ops, monkeypatch, impl, N, h):
+    """The bf16 kernels that the benchmark times (and every variant behind AS_SDPA_IMPL) at the ViT-B / ViT-L token counts
+    against an oracle that rounds where they round: max error <= 5e-3 of the output range, mean <= 5e-4 (the fp32-softmax
+    oracle of the other bf16 tests leaves the rounding of P in the error and needs 2e-2 / 3e-3)."""
+    if impl:
+        monkeypatch.setenv("AS_SDPA_IMPL", impl)
+    else:
+        monkeypatch.delenv("AS_SDPA_IMPL", raising=False)
+    B = 1
+    g = torch.Generator().manual_seed(4000 + N)
+    # logits of standard deviation ~4 (q, k at scale 2): peaked rows, outputs of order 1 -- with unit-scale operands every
+    # output is a 4197-key average of order 0.05 and ONE bf16 ulp of it is already 4e-3 of the output range
+    q, k = (torch.randn(B, h, N, 64, generator=g) * 2.0 for _ in range(2))
+    v = torch.randn(B, h, N, 64, generator=g)
+    qb, kb, vb = (q * ops.QSCALE).bfloat16(), k.bfloat16(), v.bfloat16()
+    Np_ = ops.npad(N)
+    qp = torch.zeros(B, h, Np_, 64, dtype=torch.bfloat16); kp = torch.zeros_like(qp)
+    vtp = torch.full((B, h, 64, Np_), float("nan"), dtype=torch.bfloat16)
+    qp[:, :, :N], kp[:, :, :N], vtp[:, :, :, :N] = qb, kb, vb.transpose(-1, -2)
+    kp[:, :, N:] = float("nan")
+    o, lse = ops.sdpa_fwd(ops.q_to_fragment_major(dev(qp)), dev(kp), dev(vtp), N)
+    ref = _sdpa_matched_reference(qb, kb, vb)
+    assert ref.abs().max() > 1.0
+    mx, mean = rel_to_range(ref, o.float())
+    assert mx <= 5e-3 and mean <= 5e-4, (impl, N, mx, mean)
+    s_ = (qb.double() @ kb.double().transpose(-1, -2)) * ops.LN2
+    assert_close(torch.logsumexp(s_, dim=-1).float(), lse, 1e-4, 1e-3, "lse")
+
+
 @pytest.mark.parametrize("B,h,N", [(1, 2, 1000), (2, 3, 1153), (1, 1, 513), (1, 2, 100), (2, 12, 4197)])
 def test_sdpa_eight_wave_workgroups_match_oracle_and_the_plain_grid(ops, monkeypatch, B, h, N):
     """AS_SDPA_IMPL=7: the pipelined kernel on 512-row workgroups of eight waves (each K / V^T tile staged once for twice the
@@ -963,6 +1008,36 @@ def test_rank_select_matches_nonzero(ops):
         assert_equal(ref, got, f"rank select M={M} HW={HW}")
         beyond = ops.rank_select(dev(mask), dev(cnt[:, None] + torch.zeros(M, 1, dtype=torch.long)))
         assert (beyond.cpu() == -1).all()
+
+
+def test_rank_draw_xy_equals_the_tensor_op_chain(ops):
+    """as_rank_draw_xy (ranks derived in the selection kernel from the populations it counts) against the chain of tensor
+    ops it replaces in the fast-RNG sampling paths (roi_head.sample_points_from_cams_nosync / grid_seed_nosync), bit for
+    bit, incl. rows with fewer candidates than draws (flag) and empty rows (pixel 0)."""
+    g = torch.Generator().manual_seed(29)
+    for M, H, W, dens, K in ((7, 64, 64, 0.2, 20), (3, 128, 96, 0.6, 20), (4, 16, 16, 0.02, 20), (2, 1024, 1024, 0.3, 20)):
+        mask = (torch.rand(M, H * W, generator=g) < dens).to(torch.uint8)
+        if M == 4:
+            mask[1] = 0                                    # an empty row
+            mask[2] = 0; mask[2, 37] = 1                   # a single candidate
+        counts = mask.sum(1).int()
+        u = torch.rand(M, K, generator=g)
+        u[0, 0] = 0.0; u[0, 1] = 0.99999994                # the ends of [0, 1)
+        # mode 1: min(int(u * n), max(n - 1, 0)) -> (x, y)
+        ranks = torch.minimum((u * counts.float()[:, None]).to(torch.int32), (counts[:, None] - 1).clamp(min=0))
+        ref = ops.rank_select_xy(dev(mask), dev(ranks), W)
+        flag = torch.zeros(1, dtype=torch.int32).cuda()
+        got = ops.rank_draw_xy(dev(mask), K, W, u=dev(u), flag=flag)
+        assert_equal(ref, got, f"uniform draws M={M} {H}x{W}")
+        assert bool(flag.item()) == bool((counts < K).any()), "flag of the uniform draws"
+        # mode 2: the k-th of K grid-strided positives -> (y, x)
+        step = (counts // K).clamp(min=1)
+        ranks = torch.arange(K, dtype=torch.int32)[None, :] * step[:, None].int()
+        ref = ops.rank_select_xy(dev(mask), dev(ranks), W, yx=True)
+        flag = torch.zeros(2, dtype=torch.int32).cuda()
+        got = ops.rank_draw_xy(dev(mask), K, W, flag=flag[1:2], yx=True)
+        assert_equal(ref, got, f"grid-strided seeds M={M} {H}x{W}")
+        assert int(flag[0]) == 0 and bool(flag[1].item()) == bool((counts < K).any()), "flag slot of the grid seeds"
 
 
 # ------------------------------------------------------------------------------------------------
