@@ -514,6 +514,96 @@ extern "C" int as_merge_plan(const uint8_t* keep, const uint8_t* link, int32_t* 
 }
 
 // =====================================================================================================
+// merge_maps of stdroi:278-294 for every object in ONE launch: the cosine links between the kept prototypes, the greedy
+// grouping above, and the merged prototypes  matmul(weight, prot) / (weight.sum(-1) + 1e-8)  of the first `slots` groups
+// (unused slots are zero rows).  One workgroup per object; the object's prototypes are normalised into LDS
+// (x / max(|x|, 1e-8), the reference's form), every (i, j >= i) cosine is one thread's dot product, thread 0 runs the
+// grouping on the bit rows, and the members of a group are summed in index order.  *flag is OR-ed with 1 when an object
+// has more than `slots` groups (the caller then takes its synchronous path).
+// =====================================================================================================
+namespace {
+constexpr int MG_NT = 256, MG_PMAX = 32;
+__global__ __launch_bounds__(MG_NT) void merge_parts_kernel(const float* __restrict__ prot, const uint8_t* __restrict__ keep,
+                                                            float thr, float* __restrict__ merged, int32_t* __restrict__ ngroups,
+                                                            int32_t* __restrict__ flag, int P, int C, int slots) {
+  extern __shared__ float mg_u[];                            // [P][C + 1] normalised prototypes (row pitch C + 1: no conflicts)
+  __shared__ float nrm_s[MG_PMAX];
+  __shared__ unsigned link_s[MG_PMAX], group_s[MG_PMAX];
+  __shared__ int n_s;
+  const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* pg = prot + (size_t)g * P * C;
+  const int pitch = C + 1;
+  for (int p = wave; p < P; p += MG_NT / 64) {                // |prot_p|: one wave per row, fixed shuffle tree
+    float s = 0.0f;
+    for (int c = lane; c < C; c += 64) { const float v = pg[(size_t)p * C + c]; s = fmaf(v, v, s); }
+    s = wave_sum(s);
+    if (lane == 0) nrm_s[p] = fmaxf(sqrtf(s), 1e-8f);
+  }
+  if (tid < MG_PMAX) link_s[tid] = 0u;
+  __syncthreads();
+  for (int i = tid; i < P * C; i += MG_NT) {
+    const int p = i / C, c = i - p * C;
+    mg_u[p * pitch + c] = pg[i] / nrm_s[p];
+  }
+  __syncthreads();
+  for (int pr = tid; pr < P * P; pr += MG_NT) {               // cos(u_i, u_j) >= thr for j >= i (the upper triangle is all
+    const int i = pr / P, j = pr - i * P;                     // the grouping reads)
+    if (j < i) continue;
+    const float* a = mg_u + i * pitch;
+    const float* b = mg_u + j * pitch;
+    float d0 = 0.0f, d1 = 0.0f, d2 = 0.0f, d3 = 0.0f;
+    int c = 0;
+    for (; c + 4 <= C; c += 4) {
+      d0 = fmaf(a[c], b[c], d0); d1 = fmaf(a[c + 1], b[c + 1], d1);
+      d2 = fmaf(a[c + 2], b[c + 2], d2); d3 = fmaf(a[c + 3], b[c + 3], d3);
+    }
+    for (; c < C; ++c) d0 = fmaf(a[c], b[c], d0);
+    if ((d0 + d1) + (d2 + d3) >= thr) atomicOr(&link_s[i], 1u << j);
+  }
+  __syncthreads();
+  if (tid == 0) {                                             // the greedy grouping of merge_plan_kernel
+    unsigned kept = 0u;
+    for (int p = 0; p < P; ++p) kept |= (keep[g * P + p] != 0 ? 1u : 0u) << p;
+    unsigned cleared = 0u;
+    int n = 0;
+    for (int i = 0; i < P; ++i) {
+      group_s[i] = 0u;
+      if (!((kept >> i) & 1u) || ((cleared >> i) & 1u)) continue;
+      const unsigned row = link_s[i] & kept;
+      if (row) { group_s[n] = row; ++n; cleared |= row; }
+    }
+    n_s = n;
+    ngroups[g] = n < slots ? n : slots;
+    if (n > slots && flag != nullptr) atomicOr(flag, 1);
+  }
+  __syncthreads();
+  for (int o = tid; o < slots * C; o += MG_NT) {
+    const int sl = o / C, c = o - sl * C;
+    const unsigned row = sl < P ? group_s[sl] : 0u;
+    float acc = 0.0f, cnt = 0.0f;
+    for (int p = 0; p < P; ++p)
+      if ((row >> p) & 1u) { acc += pg[(size_t)p * C + c]; cnt += 1.0f; }
+    merged[((size_t)g * slots + sl) * C + c] = acc / (cnt + 1e-8f);
+  }
+}
+}  // namespace
+
+extern "C" int as_merge_parts(const float* prot, const uint8_t* keep, float thr, float* merged, int32_t* ngroups, int32_t* flag,
+                              int G, int P, int C, int slots, as_stream_t stream) {
+  AS_REQUIRE(prot && keep && merged && ngroups, AS_E_BADARG, "as_merge_parts: null pointer");
+  AS_REQUIRE(G > 0 && P > 0 && P <= MG_PMAX && C > 0 && slots > 0 && slots <= P, AS_E_UNSUPPORTED,
+             "as_merge_parts: P=%d prototypes per object (max %d), %d slots", P, MG_PMAX, slots);
+  const size_t lds = (size_t)P * (C + 1) * sizeof(float);
+  AS_REQUIRE(lds <= 140 * 1024, AS_E_UNSUPPORTED, "as_merge_parts: %d x %d prototypes exceed the LDS image", P, C);
+  if (lds > 48 * 1024)
+    (void)hipFuncSetAttribute((const void*)merge_parts_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(merge_parts_kernel, dim3(G), dim3(MG_NT), lds, (hipStream_t)stream, prot, keep, thr, merged, ngroups, flag,
+                     P, C, slots);
+  AS_CHECK_LAUNCH("merge_parts");
+  return AS_OK;
+}
+
+// =====================================================================================================
 // Patch-grid foreground of get_semantic_centers (stdroi:2011-2012, 2020): erode(map_fg > thr, k) at full resolution,
 // bilinear DOWN to the patch grid.  For an exact integer factor `up` the down-sampled value is the mean of the 2x2
 // pixels (up/2-1, up/2) of the patch with weights 0.5/0.5, so only those four erosions are evaluated: a 16-lane group
@@ -660,13 +750,20 @@ __device__ __forceinline__ int wave_excl_scan(int v, int lane) {
 
 // result of one (row, rank): the flat index, and / or its (x, y) [or (y, x)] coordinates on a W-wide grid as int64 with an
 // out-of-range rank (-1) clamped to pixel 0 -- what the callers' `clamp(min=0)`, `% W`, `// W`, `stack` chain produced
-__device__ __forceinline__ void rank_select_store(int32_t* out, long long* out_xy, size_t idx, int flat, int W, int yx) {
+// (as_rank_draw_xy only) patch: the index of the selected pixel's patch on a patch_w-wide grid of patch_div-pixel patches,
+// plus patch_base, written to row (m + M - row_rot) % M of patch_out -- what the callers' `// 16`, `clamp`, `cat` chain and
+// the gather index of the seed features were built from
+struct RankPatch { long long* out; int div, w, rot; long long base; };
+__device__ __forceinline__ void rank_select_store(int32_t* out, long long* out_xy, size_t idx, int flat, int W, int yx,
+                                                  const RankPatch* rp = nullptr, int m = 0, int M = 1, int k = 0, int K = 1) {
   if (out != nullptr) out[idx] = flat;
+  const int f = flat < 0 ? 0 : flat, y = f / W, x = f - y * W;
   if (out_xy != nullptr) {
-    const int f = flat < 0 ? 0 : flat, y = f / W, x = f - y * W;
     out_xy[2 * idx + 0] = yx ? y : x;
     out_xy[2 * idx + 1] = yx ? x : y;
   }
+  if (rp != nullptr && rp->out != nullptr)
+    rp->out[(size_t)((m + M - rp->rot) % M) * K + k] = rp->base + (long long)(y / rp->div) * rp->w + x / rp->div;
 }
 
 // MODE 0: the rank comes from `ranks`.  MODE 1 / 2 (as_rank_draw_xy): the rank is derived from the row's population n, which
@@ -678,8 +775,10 @@ __global__ __launch_bounds__(64) void rank_select_kernel(const uint8_t* __restri
                                                          const int32_t* __restrict__ ranks, const float* __restrict__ u,
                                                          int32_t* __restrict__ flag, int32_t* __restrict__ out,
                                                          long long* __restrict__ out_xy, int W, int yx, int HW, int nchunk,
-                                                         int K) {
+                                                         int K, RankPatch rpv) {
   const int k = blockIdx.x, m = blockIdx.y, lane = threadIdx.x;
+  const RankPatch* rp = MODE == 0 ? nullptr : &rpv;
+  const int M = gridDim.y;
   int r = MODE == 0 ? ranks[(size_t)m * K + k] : 0;
   const float uk = MODE == 1 ? u[(size_t)m * K + k] : 0.0f;
   const int32_t* c = cc + (size_t)m * nchunk;
@@ -704,7 +803,7 @@ __global__ __launch_bounds__(64) void rank_select_kernel(const uint8_t* __restri
   }
   const unsigned long long hit = __ballot(r >= before && r < before + mine);
   if (hit == 0ull || r < 0) {                    // rank beyond the population
-    if (lane == 0) rank_select_store(out, out_xy, (size_t)m * K + k, -1, W, yx);
+    if (lane == 0) rank_select_store(out, out_xy, (size_t)m * K + k, -1, W, yx, rp, m, M, k, K);
     return;
   }
   const int owner = __ffsll((long long)hit) - 1;
@@ -758,7 +857,7 @@ __global__ __launch_bounds__(64) void rank_select_kernel(const uint8_t* __restri
       const int c = __popcll(occ & ((1ull << sft) - 1ull));
       if (left >= c) { occ >>= sft; left -= c; pos += sft; }
     }
-    rank_select_store(out, out_xy, (size_t)m * K + k, chunk * RS_CHUNK + off + pos, W, yx);
+    rank_select_store(out, out_xy, (size_t)m * K + k, chunk * RS_CHUNK + off + pos, W, yx, rp, m, M, k, K);
   }
 }
 
@@ -934,8 +1033,8 @@ extern "C" size_t as_rank_select_workspace_bytes(int M, int HW) {
 
 static int rank_select_launch(const uint8_t* mask, const int32_t* ranks, int32_t* out, long long* out_xy, int W, int yx, void* ws,
                               size_t ws_bytes, int M, int HW, int K, as_stream_t stream, const char* who, int mode = 0,
-                              const float* u = nullptr, int32_t* flag = nullptr) {
-  AS_REQUIRE(mask && (ranks || mode != 0) && (out || out_xy) && ws, AS_E_BADARG, "%s: null pointer", who);
+                              const float* u = nullptr, int32_t* flag = nullptr, RankPatch rp = RankPatch{nullptr, 1, 1, 0, 0}) {
+  AS_REQUIRE(mask && (ranks || mode != 0) && (out || out_xy || rp.out) && ws, AS_E_BADARG, "%s: null pointer", who);
   AS_REQUIRE(M > 0 && HW > 0 && K > 0 && HW % 16 == 0 && W > 0, AS_E_BADARG, "%s: bad sizes (HW %% 16 == 0)", who);
   AS_REQUIRE(ws_bytes >= as_rank_select_workspace_bytes(M, HW), AS_E_WORKSPACE, "%s: workspace too small", who);
   hipStream_t s = (hipStream_t)stream;
@@ -943,11 +1042,11 @@ static int rank_select_launch(const uint8_t* mask, const int32_t* ranks, int32_t
   int32_t* cc = (int32_t*)ws;
   hipLaunchKernelGGL(rank_counts_kernel, dim3(nchunk, M), dim3(RF_NT), 0, s, mask, cc, HW, nchunk);
   if (mode == 1)
-    hipLaunchKernelGGL(rank_select_kernel<1>, dim3(K, M), dim3(64), 0, s, mask, cc, ranks, u, flag, out, out_xy, W, yx, HW, nchunk, K);
+    hipLaunchKernelGGL(rank_select_kernel<1>, dim3(K, M), dim3(64), 0, s, mask, cc, ranks, u, flag, out, out_xy, W, yx, HW, nchunk, K, rp);
   else if (mode == 2)
-    hipLaunchKernelGGL(rank_select_kernel<2>, dim3(K, M), dim3(64), 0, s, mask, cc, ranks, u, flag, out, out_xy, W, yx, HW, nchunk, K);
+    hipLaunchKernelGGL(rank_select_kernel<2>, dim3(K, M), dim3(64), 0, s, mask, cc, ranks, u, flag, out, out_xy, W, yx, HW, nchunk, K, rp);
   else
-    hipLaunchKernelGGL(rank_select_kernel<0>, dim3(K, M), dim3(64), 0, s, mask, cc, ranks, u, flag, out, out_xy, W, yx, HW, nchunk, K);
+    hipLaunchKernelGGL(rank_select_kernel<0>, dim3(K, M), dim3(64), 0, s, mask, cc, ranks, u, flag, out, out_xy, W, yx, HW, nchunk, K, rp);
   AS_CHECK_LAUNCH(who);
   return AS_OK;
 }
@@ -963,13 +1062,17 @@ extern "C" int as_rank_select_xy(const uint8_t* mask, const int32_t* ranks, int6
                             "as_rank_select_xy");
 }
 
-extern "C" int as_rank_draw_xy(const uint8_t* mask, int mode, const float* u, int32_t* flag, int64_t* out_xy, void* ws,
-                               size_t ws_bytes, int M, int HW, int K, int W, int yx_order, as_stream_t stream) {
+extern "C" int as_rank_draw_xy(const uint8_t* mask, int mode, const float* u, int32_t* flag, int64_t* out_xy, int64_t* patch_out,
+                               int patch_div, int patch_w, int64_t patch_base, int row_rot, void* ws, size_t ws_bytes, int M,
+                               int HW, int K, int W, int yx_order, as_stream_t stream) {
   AS_REQUIRE(mode == 1 || mode == 2, AS_E_BADARG, "as_rank_draw_xy: mode %d (1 = uniform draws, 2 = grid stride)", mode);
   AS_REQUIRE(mode != 1 || u, AS_E_BADARG, "as_rank_draw_xy: mode 1 needs the uniform numbers");
-  AS_REQUIRE(out_xy, AS_E_BADARG, "as_rank_draw_xy: null pointer");
+  AS_REQUIRE(out_xy || patch_out, AS_E_BADARG, "as_rank_draw_xy: null pointer");
+  AS_REQUIRE(!patch_out || (patch_div > 0 && patch_w > 0 && row_rot >= 0 && row_rot < M), AS_E_BADARG,
+             "as_rank_draw_xy: patch grid (div %d, width %d, row rotation %d of %d rows)", patch_div, patch_w, row_rot, M);
+  const RankPatch rp{(long long*)patch_out, patch_div > 0 ? patch_div : 1, patch_w > 0 ? patch_w : 1, row_rot, (long long)patch_base};
   return rank_select_launch(mask, nullptr, nullptr, (long long*)out_xy, W, yx_order ? 1 : 0, ws, ws_bytes, M, HW, K, stream,
-                            "as_rank_draw_xy", mode, u, flag);
+                            "as_rank_draw_xy", mode, u, flag, rp);
 }
 
 extern "C" int as_mask_count(const uint8_t* mask, int32_t* counts, int M, int HW, as_stream_t stream) {

@@ -751,7 +751,7 @@ def filter_parts(sim, fg_inter, sim_thr=0.8, pos_thr=0.85):
     keep = torch.empty(G, P, device=sim.device, dtype=torch.uint8)
     _lib.check(lib.as_filter_parts(_p(sim), _p(fg), float(sim_thr), float(pos_thr), _p(keep), G, P, sim[0, 0].numel(),
                                    _stream()), "as_filter_parts")
-    return keep.bool()
+    return keep.view(torch.bool)                      # 0/1 bytes: a view, not a conversion launch
 
 
 def draw_distinct(counts, u, k):
@@ -768,7 +768,7 @@ def draw_distinct(counts, u, k):
     flag = torch.empty(1, device=u.device, dtype=torch.int32)
     _lib.check(lib.as_draw_distinct(_p(counts), _p(u), _p(rp), _p(rn), _p(ip), _p(flag), G, M, int(k), _stream()),
                "as_draw_distinct")
-    return rp, rn, ip.bool(), flag
+    return rp, rn, ip.view(torch.bool), flag
 
 
 def small_attention_fwd(qkv):
@@ -836,6 +836,24 @@ def merge_plan(keep, link):
     ngroups = torch.empty(G, device=k8.device, dtype=torch.int32)
     _lib.check(lib.as_merge_plan(_p(k8), _p(l8), _p(groups), _p(ngroups), G, P, _stream()), "as_merge_plan")
     return groups, ngroups
+
+
+def merge_parts(prot, keep, thr, slots, flag=None):
+    """prot [G,P,C] fp32, keep [G,P] uint8/bool -> (merged [G,slots,C] fp32, ngroups [G] int32 clamped to slots): the
+    cosine links, the greedy grouping (merge_plan) and the merged prototypes of stdroi:278-294 in one launch
+    (as_merge_parts); `flag` (one int32 on the device) is OR-ed with 1 if an object has more than `slots` groups."""
+    lib = _lib.load()
+    prot = prot.contiguous()
+    _chk(prot, dtype=torch.float32)
+    k8 = keep.view(torch.uint8) if keep.dtype == torch.bool else keep
+    k8 = k8.contiguous()
+    _chk(k8, dtype=torch.uint8)
+    G, P, C = prot.shape
+    merged = torch.empty(G, slots, C, device=prot.device, dtype=torch.float32)
+    ngroups = torch.empty(G, device=prot.device, dtype=torch.int32)
+    _lib.check(lib.as_merge_parts(_p(prot), _p(k8), float(thr), _p(merged), _p(ngroups), _p(flag), G, P, C, int(slots),
+                                  _stream()), "as_merge_parts")
+    return merged, ngroups
 
 
 def mask_count(mask):
@@ -906,10 +924,13 @@ def rank_select_xy(mask, ranks, W, yx=False):
     return out
 
 
-def rank_draw_xy(mask, K, W, u=None, flag=None, yx=False):
+def rank_draw_xy(mask, K, W, u=None, flag=None, yx=False, patch=None, want_xy=True):
     """rank_select_xy whose ranks come from each row's population n on the device (as_rank_draw_xy): with `u` [M,K] uniform
     numbers rank = min(int(u * n), max(n - 1, 0)) (the fast-RNG seed draws); without, the K grid-strided positives
-    k * max(n // K, 1).  `flag` (int32 [1] or 0-dim view, OR-ed with 1 when some row has fewer than K set bytes)."""
+    k * max(n // K, 1).  `flag` (int32 [1] or 0-dim view, OR-ed with 1 when some row has fewer than K set bytes).
+    patch = (out [M,K] int64 or None, div, width, base, row_rot): also the token index base + (y // div) * width + x // div
+    of every selected pixel, row m stored at row (m - row_rot) mod M (the gather index of the seed features).
+    Returns xy [M,K,2] int64, or (xy | None, patch_out) with `patch`."""
     lib = _lib.load()
     _chk(mask, dtype=torch.uint8)
     M, HW = mask.shape
@@ -919,12 +940,20 @@ def rank_draw_xy(mask, K, W, u=None, flag=None, yx=False):
             raise AttnShiftError("rank_draw_xy: u must be [M, K]")
     if flag is not None and (flag.dtype != torch.int32 or flag.numel() != 1 or not flag.is_cuda):
         raise AttnShiftError("rank_draw_xy: flag must be one int32 on the device")
-    out = torch.empty(M, K, 2, device=mask.device, dtype=torch.int64)
+    out = torch.empty(M, K, 2, device=mask.device, dtype=torch.int64) if want_xy or patch is None else None
+    pout, pdiv, pw, pbase, prot = None, 1, 1, 0, 0
+    if patch is not None:
+        pout, pdiv, pw, pbase, prot = patch
+        if pout is None:
+            pout = torch.empty(M, K, device=mask.device, dtype=torch.int64)
+        if pout.dtype != torch.int64 or pout.numel() != M * K or not pout.is_contiguous():
+            raise AttnShiftError("rank_draw_xy: patch output must be a contiguous int64 [M, K]")
     nbytes = lib.as_rank_select_workspace_bytes(M, HW)
     ws = torch.empty(nbytes, device=mask.device, dtype=torch.uint8)
-    _lib.check(lib.as_rank_draw_xy(_p(mask), 1 if u is not None else 2, _p(u), _p(flag), _p(out), _p(ws), nbytes, M, HW, int(K),
-                                   int(W), 1 if yx else 0, _stream()), "as_rank_draw_xy")
-    return out
+    _lib.check(lib.as_rank_draw_xy(_p(mask), 1 if u is not None else 2, _p(u), _p(flag), _p(out), _p(pout), int(pdiv), int(pw),
+                                   int(pbase), int(prot), _p(ws), nbytes, M, HW, int(K), int(W), 1 if yx else 0, _stream()),
+               "as_rank_draw_xy")
+    return out if patch is None else (out, pout)
 
 
 def roi_align_fwd(feat_nhwc, rois, out_size, spatial_scale, sampling_ratio=0, aligned=True):

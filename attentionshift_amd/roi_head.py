@@ -343,8 +343,10 @@ def sample_points_from_cams_nosync(cams_lr, map_idx, minmax, num_points, gen, th
     W = masks.shape[-1]
     if flag is not None and (masks.shape[-1] * masks.shape[-2]) % 16 == 0:
         u = torch.rand(2 * G + 1, num_points, device=masks.device, generator=gen)
-        pts = ops.rank_draw_xy(masks.flatten(1), num_points, W, u=u, flag=flag)
-        return pts[:G], pts[G:2 * G], pts[2 * G:], flag.reshape(())
+        # also the token index of every drawn pixel, rows rotated to [fg objects, shared background, bg objects]: the
+        # gather index of the seed features (seed_features' `// 16`, clamp and cat chain)
+        pts, pidx = ops.rank_draw_xy(masks.flatten(1), num_points, W, u=u, flag=flag, patch=(None, STRIDE, W // STRIDE, 0, G))
+        return pts[:G], pts[G:], pidx, flag.reshape(())
     n = counts.float()[:, None]
     u = torch.rand(2 * G + 1, num_points, device=masks.device, generator=gen)
     ranks = torch.minimum((u * n).to(torch.int32), (counts[:, None] - 1).clamp(min=0))
@@ -397,12 +399,15 @@ def mask_points_nosync(pend, num_gt, gen, int_flag=False):
     return coords, is_pos, (flag[0] if int_flag else flag[0] != 0)
 
 
-def grid_seed_nosync(mask, count_dev, n_points=20, flag=None):
+def grid_seed_nosync(mask, count_dev, n_points=20, flag=None, patch=None):
     """grid_seed_finish without the count readback, for objects with at least n_points positives (stdroi:1790-1792:
     every (n // n_points)-th positive in raster order).  flag: an object with fewer (refill / box-centre branches).
     With `flag` (a zeroed int32 [1] slot) ranks and flag come out of the selection kernel itself (ops.rank_draw_xy)."""
     G, hp, wp = mask.shape
     if flag is not None and (hp * wp) % 16 == 0 and mask.dtype == torch.uint8:
+        if patch is not None:                              # (out rows, base): also the seeds' token ids, for ONE batched gather
+            return ops.rank_draw_xy(mask.flatten(1), n_points, wp, flag=flag, yx=True,
+                                    patch=(patch[0], 1, wp, patch[1], 0))[0], flag.reshape(())
         return ops.rank_draw_xy(mask.flatten(1), n_points, wp, flag=flag, yx=True), flag.reshape(())
     step = (count_dev // n_points).clamp(min=1)
     ranks = torch.arange(n_points, device=mask.device, dtype=torch.int32)[None, :] * step[:, None].int()
@@ -563,6 +568,22 @@ def grid_seed_finish(mask, count_dev, rois, n_points=20):
         if n == 0:
             coords[g] = ((rois[g][:2] + rois[g][2:]) // (2 * STRIDE)).long().view(1, 2).flip(1).repeat(n_points, 1)
     return coords
+
+
+_CONSTS = {}
+
+
+def _const_tensor(key, device, make):
+    """Small index tensors that depend only on sizes (arange, owners of padded slots): built once on the host, copied, and
+    reused by every later call and stream (the creating stream is drained once so that no other stream can read early)."""
+    k = (key, str(device))
+    t = _CONSTS.get(k)
+    if t is None:
+        t = make().to(device)
+        if t.is_cuda:
+            torch.cuda.current_stream(t.device).synchronize()
+        _CONSTS[k] = t
+    return t
 
 
 def _unit(x):
@@ -950,12 +971,13 @@ class AttnShiftRoIHead(nn.Module):
         return ops.rollout_rows(states, num_proposals, rows=sel.to(states[0].q.device).long())
 
     def refine_maps(self, attn_sel, feat_chw, rois, gt_points, refine_times, obj_tau, minmax=None, cam_src=None,
-                    draw_gen=None, flags_out=None, last_level_only=False, mt_state=None, flag_slot=None):
+                    draw_gen=None, flags_out=None, last_level_only=False, mt_state=None, flag_slot=None, box_patch=None):
         """B2 (stdroi:1000-1019).  attn_sel [G,H,W], feat [C,hp,wp]; minmax [G,2] = per-map (min,max) if the
         caller already has them (as_cam_boxes does).  cam_src = (cams_lr [M,hp,wp], map_idx [G] int32, minmax [M,2])
         replaces attn_sel: the seed sampling then reads the low-resolution CAMs and the upsampled maps are never
         materialised.  Returns map_fg, map_bg [R+1,G,H,W], points_fg, points_bg, fg_feat, bg_feat."""
         C, hp, wp = feat_chw.shape
+        seed_idx = None
         if cam_src is not None and mt_state is not None:          # reference stream, drawn on the device: no readback
             G = cam_src[1].shape[0]
             pts_bg, pts_fg, pts_supp, short = sample_points_from_cams_mt(cam_src[0], cam_src[1], cam_src[2], 20, mt_state)
@@ -965,6 +987,8 @@ class AttnShiftRoIHead(nn.Module):
             pts_bg, pts_fg, pts_supp, short = sample_points_from_cams_nosync(cam_src[0], cam_src[1], cam_src[2], 20, draw_gen,
                                                                              flag=flag_slot)
             flags_out.append(short)
+            if flag_slot is not None and pts_supp.dim() == 2:      # (pts_fg already holds the shared group; pts_supp = token ids)
+                seed_idx, pts_supp = pts_supp, None
         elif cam_src is not None:
             G = cam_src[1].shape[0]
             pts_bg, pts_fg, pts_supp = sample_points_from_cams(cam_src[0], cam_src[1], cam_src[2], gt_points, 20)
@@ -977,14 +1001,19 @@ class AttnShiftRoIHead(nn.Module):
                 nm = (attn_sel - lo) / (hi - lo)
             pts_bg, pts_fg, pts_supp = sample_point_grid_multi(
                 [(nm, 0.1, False, None), (nm, 0.2, True, gt_points), (nm.mean(0, keepdim=True), 0.1, False, None)], 20)
-        pts_fg = torch.cat((pts_fg, pts_supp), dim=0)
+        if pts_supp is not None:
+            pts_fg = torch.cat((pts_fg, pts_supp), dim=0)
         if self.capture is not None:
             self.capture.append(dict(points_fg=pts_fg, points_bg=pts_bg))
         CLOCK.mark("  sampling")
         feat_tok = feat_chw.flatten(1).t().contiguous()
-        box_patch = (rois // STRIDE).to(torch.int32).contiguous()
+        if box_patch is None:
+            box_patch = (rois // STRIDE).to(torch.int32).contiguous()
         # foreground (G + 1 seeds, selection group) and background (G seeds) sets refined by ONE call
-        seeds = seed_features(torch.cat((pts_fg, pts_bg), dim=0), feat_chw).contiguous()
+        if seed_idx is not None:                                  # token ids straight from the selection kernel
+            seeds = feat_tok[seed_idx].mean(dim=1)
+        else:
+            seeds = seed_features(torch.cat((pts_fg, pts_bg), dim=0), feat_chw).contiguous()
         n_fg = pts_fg.shape[0]
         sims, seeds_out = ops.refine_similarity(feat_tok, seeds, box_patch, G, refine_times, obj_tau, n_fg, hp, wp)
         sim_fg, sim_bg = sims[:, :n_fg], sims[:, n_fg:]
@@ -1024,26 +1053,34 @@ class AttnShiftRoIHead(nn.Module):
         pout, sim = ops.cosine_shift(feat_tok[None], box_patch, obj_img, prot, n_shift, hp, wp, tau, temp)
         return pout.flatten(0, 1), sim.reshape(-1, hp, wp).clamp(0)
 
-    def mean_shift_batch(self, coords_list, feats_list, rois_list, n_shift, tau=0.1, temp=0.1, feat_tok=None):
+    def mean_shift_batch(self, coords_list, feats_list, rois_list, n_shift, tau=0.1, temp=0.1, feat_tok=None,
+                         box_patch_list=None, seed_ids=None, clamp=True):
         """mean_shift_grid_prototype for every image of the batch in ONE as_cosine_shift call (coords_list[i] =
         grid_seed_coords of image i; the objects carry their
         image index; the kernels are batched over objects, and a call's latency does not depend on how many objects it
         holds).  Returns per-image (prototypes [G_i*P,C], sim [G_i*P,hp,wp] clamped at 0) exactly as the per-image
         method does (batched == per-image bitwise, tests/test_gpu_kernels.py)."""
         C, hp, wp = feats_list[0].shape
-        prots, boxes, owners = [], [], []
-        for i, (coords, feat, rois) in enumerate(zip(coords_list, feats_list, rois_list)):
-            prots.append(feat.permute(1, 2, 0)[coords[..., 0], coords[..., 1]])
-            boxes.append((rois // STRIDE).to(torch.int32))
-            owners.append(torch.full((coords.shape[0],), i, dtype=torch.int32, device=feat.device))
+        sizes = tuple(int(c.shape[0]) for c in coords_list)
+        dev = feats_list[0].device
         if feat_tok is None or not feat_tok.is_contiguous():
             feat_tok = torch.stack([f.flatten(1).t() for f in feats_list]).contiguous()
-        pout, sim = ops.cosine_shift(feat_tok, torch.cat(boxes).contiguous(), torch.cat(owners), torch.cat(prots).contiguous(),
-                                     n_shift, hp, wp, tau, temp)
+            seed_ids = None                                  # (the ids index the caller's token tensor)
+        if seed_ids is not None:                             # token ids of the seeds (as_rank_draw_xy): one gather
+            prot = feat_tok.flatten(0, 1)[seed_ids]
+        else:
+            prot = torch.cat([feat.permute(1, 2, 0)[coords[..., 0], coords[..., 1]]
+                              for coords, feat in zip(coords_list, feats_list)]).contiguous()
+        if box_patch_list is None:
+            box_patch_list = [(rois // STRIDE).to(torch.int32) for rois in rois_list]
+        boxes = torch.cat(box_patch_list).contiguous() if len(box_patch_list) > 1 else box_patch_list[0].contiguous()
+        owners = _const_tensor(("owners", sizes), dev,
+                               lambda: torch.cat([torch.full((n,), i, dtype=torch.int32) for i, n in enumerate(sizes)]))
+        pout, sim = ops.cosine_shift(feat_tok, boxes, owners, prot, n_shift, hp, wp, tau, temp)
         out, off = [], 0
-        for coords in coords_list:
-            g = coords.shape[0]
-            out.append((pout[off:off + g].flatten(0, 1), sim[off:off + g].reshape(-1, hp, wp).clamp(0)))
+        for g in sizes:
+            s_i = sim[off:off + g].reshape(-1, hp, wp)
+            out.append((pout[off:off + g].flatten(0, 1), s_i.clamp(0) if clamp else s_i))
             off += g
         return out
 
@@ -1102,7 +1139,7 @@ class AttnShiftRoIHead(nn.Module):
                                                                    merge_thr, num_semantic_points, extra), num_max_keep)
 
     def _semantic_post_issue(self, prot, sim, fg_inter, rois, vit_feat, gt_labels, merge_thr, num_semantic_points,
-                             extra=None):
+                             extra=None, flag_slot=None):
         """_semantic_post with ONE readback (fast-RNG path), first half: everything up to and including the START of
         that readback (a device -> pinned-host copy + event), so that a caller with several images can queue all of them
         before it waits for the first: the greedy merge plan (ops.merge_plan), the merged prototypes, their similarity
@@ -1116,31 +1153,27 @@ class AttnShiftRoIHead(nn.Module):
         dev = prot.device
         protg = prot.unflatten(0, (G, P))
         keep = ops.filter_parts(sim.unflatten(0, (G, P)), fg_inter)                  # one launch (stdroi:263-271)
-        u = _unit(protg)
-        groups, ngroups = ops.merge_plan(keep, (u @ u.transpose(1, 2)) >= merge_thr)
         # objects rarely keep more than a few merged parts: carry `slots` group slots per object through the
         # similarity / statistics passes; an object with more raises a flag (synchronous path), like the other rare cases
-        slots = min(P, self.part_slots)
+        slots = min(P, self.part_slots) if extra is not None else P
+        # cosine links, greedy grouping and the merged prototypes matmul(weight, prot) / (sum + 1e-8) in one launch
+        # (as_merge_parts: stdroi:278-294 for every object; it replaces a chain of seventeen tensor ops)
+        over = None
+        if extra is not None:                             # (`flag_slot`: a zeroed int32 [1] slot of the caller's flag vector)
+            over = flag_slot if flag_slot is not None else torch.zeros(1, dtype=torch.int32, device=dev)
+        merged, ng32 = ops.merge_parts(protg, keep, merge_thr, slots, over)
         if extra is not None:
-            extra.append((ngroups > slots).any())
-        else:
-            slots = P
-        groups = groups[:, :slots]
-        ar_p = torch.arange(P, device=dev)
-        wgt = ((groups[..., None] >> ar_p.int()) & 1).float()                         # [G, slot, member]
-        merged = torch.bmm(wgt, protg) / (wgt.sum(-1, keepdim=True) + 1e-8)            # matmul(weight, prot) / (sum + 1e-8)
+            extra.append(over.reshape(()))
         feat_tok = vit_feat.flatten(1).t().contiguous()
-        allp = merged.flatten(0, 1).contiguous()
+        allp = merged.flatten(0, 1)
         P = slots                                                                      # from here on: slots per object
-        ngroups = ngroups.clamp(max=P)
-        ar = torch.arange(P, device=dev)
         sims = torch.cat([ops.refine_similarity(feat_tok, allp[o:o + 32], None, 0, 0, 1.0, False, hp, wp)[0][0]
                           for o in range(0, G * P, 32)]).reshape(G, P, hp, wp)
         # per-slot statistics exactly as part_centers computes them per part (one launch), then the visiting order / cap
         # logic of stdroi:222-262 and the gathers behind it in as_part_select: nothing here waits for the host
-        slot_owner = torch.arange(G, device=dev).repeat_interleave(P)
+        slot_owner = _const_tensor(("slot_owner", G, P), dev,
+                                   lambda: torch.arange(G, dtype=torch.int32).repeat_interleave(P))
         c, yx, area, inside = ops.part_stats_raw(sims.flatten(0, 1), rois, slot_owner, STRIDE)
-        ng32 = ngroups.to(torch.int32).contiguous()
         coords, coords_org, labels, labels_org, corres, feats, split = ops.part_select(
             area, inside, ng32, c, yx, gt_labels.long().contiguous(), feat_tok, G, P, wp, num_semantic_points)
         pieces = [split, ng32]
@@ -1293,6 +1326,8 @@ class AttnShiftRoIHead(nn.Module):
         # The flag stays on the device and is checked at the first host sync the chain needs anyway (the seed counts):
         # reading it here would stall the host for the whole roll-out + CAM-box phase with nothing queued behind it.
         bad_cam = (status <= 0).any()                        # 0: no component; -1: run table overflow
+        if status.is_cuda:
+            bad_cam = bad_cam.to(torch.int32)                # the dtype of the other device flags it is read back with
         gt_scale_bboxes, attn_maps_dealed, cam_off, off = [], [], [], 0
         for i in range(num_imgs):
             n = Lc * counts[i]
@@ -1351,12 +1386,14 @@ class AttnShiftRoIHead(nn.Module):
             images strictly in order on one stream.  The last element is the list of device flags that ask for the
             synchronous path (rare refill branches)."""
             flags = []
-            ar = torch.arange(counts[i], device=boxes.device)
+            ar = _const_tensor(("arange", counts[i]), boxes.device, lambda: torch.arange(counts[i]))
             map_idx = (cam_off[i] + gt_box_index[i] * counts[i] + ar).to(torch.int32)
+            bp = (pseudo_boxes[i] // STRIDE).to(torch.int32)         # stdroi:1812 patch box, shared by B2 and B4
             map_fg, map_bg, _pa, _pb, feats_fg, feats_bg = self.refine_maps(
                 None, feats[i], pseudo_boxes[i], gt_points[i], 2, obj_tau, cam_src=(cams_lr, map_idx, cam_minmax),
                 draw_gen=None if mt_state is not None else self._device_gen(boxes.device), flags_out=flags,
-                last_level_only=True, mt_state=mt_state, flag_slot=None if flag_slots is None else flag_slots[i, 0:1])
+                last_level_only=True, mt_state=mt_state, flag_slot=None if flag_slots is None else flag_slots[i, 0:1],
+                box_patch=bp)
             mp, mask_u8 = mask_points_and_pseudo_issue(map_fg[-1], map_bg[-1], pseudo_boxes[i], pos_mask_thr, neg_mask_thr,
                                                        corr_size, pos_mask_thr)
             fg_inter, _map_fg_patch, gs = self._semantic_pre(map_fg[-1], map_bg[-1], pos_mask_thr)
@@ -1366,11 +1403,13 @@ class AttnShiftRoIHead(nn.Module):
             else:
                 coord_point, labels_point, f1 = mask_points_nosync(mp, num_mask_point_gt, self._device_gen(boxes.device),
                                                                    int_flag=flag_slots is not None)
-            seeds, f2 = grid_seed_nosync(gs[0], gs[1], 20, flag=None if flag_slots is None else flag_slots[i, 1:2])
+            seeds, f2 = grid_seed_nosync(gs[0], gs[1], 20, flag=None if flag_slots is None else flag_slots[i, 1:2],
+                                         patch=None if seed_ids is None else (seed_ids[obj_off[i]:obj_off[i] + counts[i]],
+                                                                              i * patch_h * patch_w))
             if self.capture is not None:
                 self.capture.append(dict(image=i, seeds=seeds, fg_inter=fg_inter))
             flags += [f1, f2]
-            return coord_point, labels_point, map_fg, map_bg, feats_fg, feats_bg, (fg_inter, seeds), pm, flags
+            return coord_point, labels_point, map_fg, map_bg, feats_fg, feats_bg, (fg_inter, seeds), pm, flags, bp
 
         nosync = (self.rng_mode == "fast" and self.device_draws and not self.parallel_images and self.image_streams
                   and self.batch_mean_shift and torch.cuda.is_available() and not CLOCK.on and not self.visualize)
@@ -1380,7 +1419,8 @@ class AttnShiftRoIHead(nn.Module):
         mtdev = (_mt_ok and self.rng_mode == "reference" and self.device_draws and _gen() is None and self.image_streams
                  and self.batch_mean_shift and boxes.is_cuda and not CLOCK.on and not self.visualize
                  and os.environ.get("AS_REF_RNG_HOST") is None)
-        mt_state = mt_blob = mt_final = None
+        mt_state = mt_blob = mt_final = flag_slots = seed_ids = None
+        obj_off = [sum(counts[:i]) for i in range(num_imgs)]
         if mtdev:
             from . import mt19937 as _MT
             mt_blob = torch.get_rng_state()
@@ -1406,20 +1446,27 @@ class AttnShiftRoIHead(nn.Module):
             else:
                 self._device_gen(boxes.device, reseed=True)
                 # device flags raised by the selection kernels themselves (too few candidates): one zero fill for the batch
-                flag_slots = torch.zeros(num_imgs, 2, dtype=torch.int32, device=boxes.device)
+                if os.environ.get("AS_HEAD_TENSOR_GLUE") != "1":     # (A/B switch: "1" = the tensor-op forms of the draws)
+                    flag_slots = torch.zeros(num_imgs, 3, dtype=torch.int32, device=boxes.device)
+                if flag_slots is not None and feat_tok.is_contiguous() and (patch_h * patch_w) % 16 == 0:
+                    # token ids (image offset included) of every object's grid seeds, written by the selection kernels: the
+                    # mean shift's initial prototypes are then ONE gather for the batch
+                    seed_ids = torch.empty(sum(counts), 20, dtype=torch.int64, device=boxes.device)
                 for st in self._streams[:num_imgs]:
                     st.wait_stream(main)
                 ra = [on_stream(i, phase_a_nosync, None, flag_slots) for i in range(num_imgs)]
                 for st in self._streams[:num_imgs]:
                     main.wait_stream(st)
             shifted = self.mean_shift_batch([r[6][1] for r in ra], feats, pseudo_boxes, self.mean_shift_times_local,
-                                            feat_tok=feat_tok)
+                                            feat_tok=feat_tok, box_patch_list=[r[9] for r in ra], seed_ids=seed_ids,
+                                            clamp=False)       # (the only consumer thresholds the maps at 0.8: no clamp(0))
 
             def chain_issue(i):
                 prot, sim = shifted[i]
                 extra = [bad_cam] + ra[i][8]
                 return self._semantic_post_issue(prot, sim, ra[i][6][0], pseudo_boxes[i], feats[i], gt_labels[i], 0.85,
-                                                 self.num_semantic_points, extra=extra)
+                                                 self.num_semantic_points, extra=extra,
+                                                 flag_slot=None if flag_slots is None else flag_slots[i, 2:3])
 
             def chain_finish(i, st):
                 sc = self._semantic_post_finish(st)

@@ -393,16 +393,26 @@ int as_rank_select(const uint8_t* mask /*[M,HW] 0/1*/, const int32_t* ranks /*[M
 int as_rank_select_xy(const uint8_t* mask /*[M,HW] 0/1*/, const int32_t* ranks /*[M,K]*/, int64_t* out_xy /*[M,K,2]*/, void* ws,
                       size_t ws_bytes, int M, int HW, int K, int W, int yx_order, as_stream_t stream);
 
+/* merge_maps (stdroi:278-294) of every object in one launch: cosine links between the kept prototypes (>= thr), the greedy
+ * upper-triangular grouping of as_merge_plan, and the merged prototypes matmul(weight, prot) / (weight.sum(-1) + 1e-8) of
+ * the first `slots` groups per object (unused slots are zero rows).  ngroups [G] = min(groups, slots); *flag (may be NULL)
+ * is OR-ed with 1 when an object has more than `slots` groups.  prot [G,P,C] fp32, keep [G,P] 0/1, P <= 32. */
+int as_merge_parts(const float* prot, const uint8_t* keep, float thr, float* merged /*[G,slots,C]*/, int32_t* ngroups /*[G]*/,
+                   int32_t* flag, int G, int P, int C, int slots, as_stream_t stream);
+
 /* Rank selection whose ranks are derived on the device from each row's population n (known from the same counting pass), so
  * that the sampling chains need no tensor-op glue and no readback (fast-RNG mode of the seed sampling, stdroi:346-369, and the
  * grid seeds of mean_shift_grid_prototype, stdroi:1790-1792):
  *   mode 1  rank[m][k] = min(int(u[m][k] * float(n_m)), max(n_m - 1, 0))     u [M,K] uniform in [0, 1)
  *   mode 2  rank[m][k] = k * max(n_m / K, 1)                                 every (n / K)-th positive
- * out_xy as as_rank_select_xy; *flag (int32, may be NULL) is OR-ed with 1 when some n_m < K (the reference's refill
- * branches: the caller repeats that image on the host path). */
+ * out_xy as as_rank_select_xy (may be NULL if patch_out is given); *flag (int32, may be NULL) is OR-ed with 1 when some
+ * n_m < K (the reference's refill branches: the caller repeats that image on the host path).
+ * patch_out (may be NULL) [M,K] int64: patch_base + (y / patch_div) * patch_w + x / patch_div of the selected pixel (x, y),
+ * i.e. its token index on a patch_w-wide grid of patch_div-pixel patches (`point // 16` of seed_features stdroi:335-338, or
+ * with patch_div = 1 the flat seed index of stdroi:1793), row m written to row (m + M - row_rot) % M. */
 int as_rank_draw_xy(const uint8_t* mask /*[M,HW] 0/1*/, int mode, const float* u /*[M,K] or NULL*/, int32_t* flag,
-                    int64_t* out_xy /*[M,K,2]*/, void* ws, size_t ws_bytes, int M, int HW, int K, int W, int yx_order,
-                    as_stream_t stream);
+                    int64_t* out_xy /*[M,K,2]*/, int64_t* patch_out /*[M,K]*/, int patch_div, int patch_w, int64_t patch_base,
+                    int row_rot, void* ws, size_t ws_bytes, int M, int HW, int K, int W, int yx_order, as_stream_t stream);
 
 /* Small-N batched multi-head self-attention (the MAE-decoder box / mask heads: thousands of 50- / 197-token problems of
  * head dim 32 per step; models/vision_transformer.py:62-86 as used by mae_bbox_head_rec.py:148-168):

@@ -1010,6 +1010,36 @@ def test_rank_select_matches_nonzero(ops):
         assert (beyond.cpu() == -1).all()
 
 
+def test_merge_parts_equals_the_tensor_op_chain(ops):
+    """as_merge_parts (links, greedy grouping, merged prototypes in one launch) against normalise / matmul / >= thr /
+    as_merge_plan / matmul(weight, prot) / (sum + 1e-8) (stdroi:278-294; oracle.merge_parts), incl. the slot cap flag."""
+    g = torch.Generator().manual_seed(31)
+    for G, P, C, slots in ((3, 20, 768, 20), (7, 20, 1024, 8), (2, 5, 64, 5), (4, 32, 192, 3)):
+        base = torch.randn(G, 4, C, generator=g)
+        prot = base[:, torch.randint(4, (P,), generator=g)] + 0.25 * torch.randn(G, P, C, generator=g)   # a few tight clusters
+        prot[0, 1] = prot[0, 0]                                # an exact duplicate (cos = 1)
+        keep = torch.rand(G, P, generator=g) < 0.7
+        keep[-1] = False                                       # an object that keeps nothing
+        u = prot / prot.norm(dim=-1, keepdim=True).clamp_min(1e-8)
+        link = (u @ u.transpose(1, 2)) >= 0.85
+        groups, ngroups = ops.merge_plan(dev(keep), dev(link))
+        groups, ngroups = groups.cpu(), ngroups.cpu()
+        wgt = ((groups[:, :slots, None] >> torch.arange(P, dtype=torch.int32)) & 1).float()
+        ref = torch.bmm(wgt, prot) / (wgt.sum(-1, keepdim=True) + 1e-8)
+        flag = torch.zeros(1, dtype=torch.int32).cuda()
+        merged, ng = ops.merge_parts(dev(prot), dev(keep), 0.85, slots, flag)
+        assert_equal(ngroups.clamp(max=slots), ng, f"group counts G={G} P={P}")
+        assert bool(flag.item()) == bool((ngroups > slots).any()), "slot-cap flag"
+        assert_close(ref, merged, 1e-6, 1e-6, f"merged prototypes G={G} P={P} C={C}")
+        ref_o = [O.merge_parts([prot[i][keep[i]]], 0.85)[0] if keep[i].any() else [] for i in range(G)] if hasattr(O, "merge_parts") else None
+        if ref_o is not None and slots == P:
+            for i in range(G):
+                n = int(ng[i])
+                assert n == (0 if isinstance(ref_o[i], list) else ref_o[i].shape[0]), f"object {i}: groups vs oracle"
+                if n:
+                    assert_close(ref_o[i], merged[i, :n], 1e-5, 1e-6, f"object {i}: merged prototypes vs oracle")
+
+
 def test_rank_draw_xy_equals_the_tensor_op_chain(ops):
     """as_rank_draw_xy (ranks derived in the selection kernel from the populations it counts) against the chain of tensor
     ops it replaces in the fast-RNG sampling paths (roi_head.sample_points_from_cams_nosync / grid_seed_nosync), bit for
@@ -1038,6 +1068,16 @@ def test_rank_draw_xy_equals_the_tensor_op_chain(ops):
         got = ops.rank_draw_xy(dev(mask), K, W, flag=flag[1:2], yx=True)
         assert_equal(ref, got, f"grid-strided seeds M={M} {H}x{W}")
         assert int(flag[0]) == 0 and bool(flag[1].item()) == bool((counts < K).any()), "flag slot of the grid seeds"
+        # token ids: base + (y // div) * width + x // div, rows rotated by `rot` (the seed-feature gather index)
+        if H % 16 == 0 and W % 16 == 0:
+            rot, base = M // 2, 1000
+            xy, pid = ops.rank_draw_xy(dev(mask), K, W, u=dev(u), patch=(None, 16, W // 16, base, rot))
+            want = base + (xy[..., 1] // 16) * (W // 16) + xy[..., 0] // 16
+            assert_equal(torch.roll(want.cpu(), -rot, 0), pid, f"token ids M={M} {H}x{W}")
+            buf = torch.full((M + 2, K), -7, dtype=torch.int64).cuda()
+            none_xy, pid2 = ops.rank_draw_xy(dev(mask), K, W, yx=True, patch=(buf[1:M + 1], 1, W, 0, 0), want_xy=False)
+            assert none_xy is None and (buf[0] == -7).all() and (buf[-1] == -7).all()
+            assert_equal(got[..., 0] * W + got[..., 1], buf[1:M + 1], "flat ids of the grid seeds, written into a caller's rows")
 
 
 # ------------------------------------------------------------------------------------------------
