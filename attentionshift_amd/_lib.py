@@ -78,6 +78,8 @@ SIGNATURES = {
     "as_cosine_shift_workspace_bytes": (_c_size_t, [_c_int] * 6),
     "as_cosine_shift": (_c_int, [_c_void_p] * 5 + [_c_double] * 2 + [_c_int] + [_c_void_p] * 4 + [_c_size_t]
                         + [_c_int] * 6 + [_c_void_p]),
+    "as_cosine_shift_strided": (_c_int, [_c_void_p, ctypes.c_longlong] + [_c_void_p] * 4 + [_c_double] * 2 + [_c_int] + [_c_void_p] * 4
+                                + [_c_size_t] + [_c_int] * 6 + [_c_void_p]),
     "as_refine_similarity_workspace_bytes": (_c_size_t, [_c_int] * 3),
     "as_refine_similarity": (_c_int, [_c_void_p] * 3 + [_c_int] * 3 + [_c_float, _c_int] + [_c_void_p] * 3
                              + [_c_size_t] + [_c_int] * 3 + [_c_void_p]),

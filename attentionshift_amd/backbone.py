@@ -167,6 +167,7 @@ class VisionTransformerDet(nn.Module):
         # the maps of such a forward become valid on the caller's stream only through DeferredFPN.result())
         self.defer_fpn = bool(unused.pop("defer_fpn", False))
         self._fpn_stream = None
+        self._point_pack = None
 
         self.patch_embed = PatchEmbed(img_size, patch_size, in_chans, embed_dim)
         n_patches = self.patch_embed.num_patches
@@ -347,6 +348,41 @@ class VisionTransformerDet(nn.Module):
                 # the tap is token-major: pool it there (NCHW-shaped view of channels-last storage, like the other taps)
                 return ops.maxpool_nhwc(tok.reshape(B, hp, wp, D), k).permute(0, 3, 1, 2)
         return op(feat_nchw)
+
+    # ---- point head (visual_transformer_det.py:26-38, 152-153, 268-269) on the inference path -------------------------
+    # class_embed and bbox_embed are two 3-layer FFNs over the SAME B*T point tokens: fourteen library launches for 200
+    # rows.  Their layers are packed once per weight version -- layer 1 side by side (shared input), layers 2 and 3
+    # block-diagonally -- so the head is three as_linear_fwd launches with bias + ReLU in the epilogue.
+    def _point_head_packable(self, x):
+        ls = list(self.class_embed.layers) + list(self.bbox_embed.layers)
+        return (x.dtype == torch.float32 and len(self.class_embed.layers) == 3 and len(self.bbox_embed.layers) == 3
+                and all(l.weight.dtype == torch.float32 and l.bias is not None and l.in_features % 32 == 0 for l in ls)
+                and self.class_embed.layers[0].in_features == self.bbox_embed.layers[0].in_features)
+
+    def _point_head_packed(self, x):
+        c, b = self.class_embed.layers, self.bbox_embed.layers
+        params = [t for l in list(c) + list(b) for t in (l.weight, l.bias)]
+        key = tuple((t.data_ptr(), t._version) for t in params)
+        pk = self._point_pack
+        if pk is None or pk["key"] != key:
+            with torch.no_grad():
+                h1, h2 = c[0].out_features, b[0].out_features
+                w2 = torch.zeros(c[1].out_features + b[1].out_features, h1 + h2, device=x.device)
+                w2[:c[1].out_features, :h1] = c[1].weight
+                w2[c[1].out_features:, h1:] = b[1].weight
+                k3 = c[1].out_features + b[1].out_features
+                w3 = torch.zeros(c[2].out_features + b[2].out_features, k3, device=x.device)
+                w3[:c[2].out_features, :c[1].out_features] = c[2].weight
+                w3[c[2].out_features:, c[1].out_features:] = b[2].weight
+                pk = dict(key=key, w1=torch.cat((c[0].weight, b[0].weight)).contiguous(), b1=torch.cat((c[0].bias, b[0].bias)),
+                          w2=w2, b2=torch.cat((c[1].bias, b[1].bias)), w3=w3, b3=torch.cat((c[2].bias, b[2].bias)),
+                          ncls=c[2].out_features)
+            self._point_pack = pk
+        B, T, D = x.shape
+        h = ops.linear(x.reshape(B * T, D).contiguous(), pk["w1"], pk["b1"], act="relu")
+        h = ops.linear(h, pk["w2"], pk["b2"], act="relu")
+        o = ops.linear(h, pk["w3"], pk["b3"]).reshape(B, T, -1)
+        return o[..., :pk["ncls"]], o[..., pk["ncls"]:].sigmoid()
 
     def interpolate_pos_encoding(self, n_patch_tokens, w, h):
         """models/vision_transformer.py:187-207 (bicubic, scale_factor with the +0.1 trick)."""
@@ -554,7 +590,10 @@ class VisionTransformerDet(nn.Module):
         point_tokens = x[:, -T:]
         out = dict(org_feats=org_features, feature=features if isinstance(features, DeferredFPN) else tuple(features),
                    point_tokens=point_tokens)
-        if self.with_point_head:
+        if self.with_point_head and not grad_path and point_tokens.is_cuda and self._point_head_packable(point_tokens):
+            cls, reg = self._point_head_packed(point_tokens)
+            out.update(outputs_class=cls, outputs_coord=reg)
+        elif self.with_point_head:
             out.update(outputs_class=self.class_embed(point_tokens), outputs_coord=self.bbox_embed(point_tokens).sigmoid())
         if self.return_attention and self.last_feat:
             out.update(attns=attns)

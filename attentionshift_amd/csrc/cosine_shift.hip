@@ -153,7 +153,7 @@ __global__ __launch_bounds__(S1_NT) void shift_sim_kernel(const float* __restric
                                                           const int32_t* __restrict__ obj_img,
                                                           const int2* __restrict__ aw_prev,   // [G][Np] compact or null
                                                           float* __restrict__ sim, float* __restrict__ part_stats,
-                                                          int C, int Hp, int Wp, int P, int nt1 AS_STAMP_ARG) {
+                                                          int C, int Hp, int Wp, int P, int nt1, size_t fbs AS_STAMP_ARG) {
   __shared__ float red[8][32][33];
   __shared__ float nrm[2][16][32];
   __shared__ float invnp_s[PMAX];
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(S1_NT) void shift_sim_kernel(const float* __restric
 
   auto patch_of = [&](int local) { return box_patch(ob, min(tile * CS_TILE1 + local, nb - 1), Wp); };
   const int n_mine = patch_of(li);
-  const float* frow = feat + ((size_t)b * Np + n_mine) * C;
+  const float* frow = feat + (size_t)b * fbs + (size_t)n_mine * C;      // fbs: floats between two images' token blocks
   const float* prow = prot + ((size_t)g * P + min(li, P - 1)) * C;
   const bool pvalid = li < P;
 
@@ -464,7 +464,7 @@ __global__ __launch_bounds__(CS_NT) void shift_aggregate_kernel(const float* __r
                                                                 const int32_t* __restrict__ obj_img,
                                                                 float* __restrict__ prot, float* __restrict__ pn2,
                                                                 int32_t* __restrict__ cnt, int C, int Hp, int Wp,
-                                                                int P AS_STAMP_ARG) {
+                                                                int P, size_t fbs AS_STAMP_ARG) {
   __shared__ float4 acc_s[PMAX * CS_NT];
   __shared__ int cnt_s[PMAX];
   const int Np = Hp * Wp;
@@ -480,7 +480,7 @@ __global__ __launch_bounds__(CS_NT) void shift_aggregate_kernel(const float* __r
   __syncthreads();
   AS_STAMP(1, false);                            // box known
 
-  const float* fb = feat + (size_t)b * Np * C + chunk * SH_CH + cq * 4;
+  const float* fb = feat + (size_t)b * fbs + chunk * SH_CH + cq * 4;
   const int2* awg = aw + (size_t)g * Np;
   constexpr int U = 16;
   bool zeroed = false;
@@ -569,7 +569,7 @@ WsLayout ws_layout(int B, int C, int Np, int G, int P) {
 
 void as_shift_final_sim_launch(const float* feat, const float* prot, const int32_t* box_patch, const int32_t* obj_img,
                                const int2* aw, float* sim_out, float* part_stats, int B, int C, int Hp, int Wp, int P, int G,
-                               int nt1, hipStream_t s);                       // shift_final.hip
+                               int nt1, size_t fbs, hipStream_t s);           // shift_final.hip
 
 #ifdef AS_SHIFT_STAMPS
 extern "C" int as_shift_stamps_read(void* dst, size_t bytes, int clear) {
@@ -588,11 +588,27 @@ extern "C" size_t as_cosine_shift_workspace_bytes(int B, int C, int Hp, int Wp, 
   return ws_layout(B, C, Hp * Wp, G, P).total;
 }
 
+extern "C" int as_cosine_shift_strided(const float* feat, long long feat_batch_stride, const int32_t* box_patch,
+                                       const int32_t* obj_img, const float* prot_in, float* prot_out, double tau0_d, double temp_d,
+                                       int n_shift, float* sim_out, int32_t* assign_out, float* tau_out, void* ws, size_t ws_bytes,
+                                       int B, int C, int Hp, int Wp, int G, int P, as_stream_t stream);
+
 extern "C" int as_cosine_shift(const float* feat, const int32_t* box_patch, const int32_t* obj_img, const float* prot_in,
                                float* prot_out, double tau0_d, double temp_d, int n_shift, float* sim_out,
                                int32_t* assign_out, float* tau_out, void* ws, size_t ws_bytes, int B, int C, int Hp, int Wp,
                                int G, int P, as_stream_t stream) {
+  return as_cosine_shift_strided(feat, (long long)Hp * Wp * C, box_patch, obj_img, prot_in, prot_out, tau0_d, temp_d, n_shift,
+                                 sim_out, assign_out, tau_out, ws, ws_bytes, B, C, Hp, Wp, G, P, stream);
+}
+
+extern "C" int as_cosine_shift_strided(const float* feat, long long feat_batch_stride, const int32_t* box_patch,
+                                       const int32_t* obj_img, const float* prot_in, float* prot_out, double tau0_d, double temp_d,
+                                       int n_shift, float* sim_out, int32_t* assign_out, float* tau_out, void* ws, size_t ws_bytes,
+                                       int B, int C, int Hp, int Wp, int G, int P, as_stream_t stream) {
   AS_REQUIRE(feat && box_patch && obj_img && prot_in && prot_out && sim_out && ws, AS_E_BADARG, "as_cosine_shift: null pointer");
+  AS_REQUIRE(feat_batch_stride >= (long long)Hp * Wp * C && feat_batch_stride % 4 == 0, AS_E_BADARG,
+             "as_cosine_shift: image stride %lld floats (>= Hp * Wp * C, multiple of 4: 16-byte rows)", feat_batch_stride);
+  const size_t fbs = (size_t)feat_batch_stride;
   AS_REQUIRE(B > 0 && Hp > 0 && Wp > 0 && G > 0 && n_shift >= 0, AS_E_BADARG, "as_cosine_shift: bad sizes");
   AS_REQUIRE(P > 0 && P <= PMAX, AS_E_UNSUPPORTED, "as_cosine_shift: P=%d prototypes per object (max %d)", P, PMAX);
   AS_REQUIRE(C % SH_CH == 0 && C <= 4 * CS_NT, AS_E_UNSUPPORTED,
@@ -621,16 +637,16 @@ extern "C" int as_cosine_shift(const float* feat, const int32_t* box_patch, cons
   for (int it = 0; it < n_shift; ++it) {
     hipLaunchKernelGGL(shift_sim_kernel, dim3(L.nt1, G), dim3(S1_NT), 0, s, feat, it == 0 ? prot_in : prot_out,
                        it == 0 ? nullptr : pn2, L.nchunk, box_patch, obj_img, it > 0 ? aw : nullptr, sim_c, part_stats,
-                       C, Hp, Wp, P, L.nt1 AS_STAMP_VAL(it < 5 ? it * 3 : 15));
+                       C, Hp, Wp, P, L.nt1, fbs AS_STAMP_VAL(it < 5 ? it * 3 : 15));
     int32_t* aout = assign_out ? assign_out + (size_t)it * G * Np : nullptr;
     hipLaunchKernelGGL(shift_assign_kernel, dim3(L.nt1, G), dim3(CS_NT), 0, s, sim_c, part_stats, cnt, box_patch,
                        stats, tau_out, aw, aout, oc, tau0, temp, tt0, it, Hp, Wp, P, G, L.nt1 AS_STAMP_VAL(it < 5 ? it * 3 + 1 : 15));
     hipLaunchKernelGGL(shift_aggregate_kernel, dim3(L.nchunk, G), dim3(CS_NT), 0, s, feat, aw, oc, box_patch,
-                       obj_img, prot_out, pn2, cnt, C, Hp, Wp, P AS_STAMP_VAL(it < 5 ? it * 3 + 2 : 15));
+                       obj_img, prot_out, pn2, cnt, C, Hp, Wp, P, fbs AS_STAMP_VAL(it < 5 ? it * 3 + 2 : 15));
   }
   // final similarity on the UNMASKED map (+ the density of the last assignment for tau_out)
   as_shift_final_sim_launch(feat, n_shift > 0 ? prot_out : prot_in, box_patch, obj_img, (n_shift > 0 && tau_out) ? aw : nullptr,
-                            sim_out, part_stats, B, C, Hp, Wp, P, G, L.nt1, s);
+                            sim_out, part_stats, B, C, Hp, Wp, P, G, L.nt1, fbs, s);
   if (n_shift > 0 && tau_out != nullptr)
     hipLaunchKernelGGL(stats_kernel, dim3(P, G), dim3(CS_NT), 0, s, sim_out, part_stats, cnt, box_patch, stats,
                        tau_out, tau0, temp, tt0, n_shift, Hp, Wp, P, G, L.nt1, 1);

@@ -126,6 +126,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[2][2], const bool (&
           if (row < M && col < Nout) {
             float v = acc[i][j][r] + bv;
             if (act == 1) v = gelu_exact(v);
+            else if (act == 4) v = fmaxf(v, 0.0f);       // ReLU (the point head's FFN, visual_transformer_det.py:36)
             out[(size_t)row * Nout + col] = from_f32<T>(v);
           }
         }
@@ -578,6 +579,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WN == 4 || KS == 4) ? 1 : (WM == 2 &
           const g_f32x2 ga = gelu_bf16_x2(g_f32x2{v0, v1}), gb = gelu_bf16_x2(g_f32x2{v2, v3});
           v0 = ga.x; v1 = ga.y; v2 = gb.x; v3 = gb.y;
 #endif
+        } else if (act == 4) {
+          v0 = fmaxf(v0, 0.0f); v1 = fmaxf(v1, 0.0f); v2 = fmaxf(v2, 0.0f); v3 = fmaxf(v3, 0.0f);
         }
         bf16x4 pk = {(__bf16)v0, (__bf16)v1, (__bf16)v2, (__bf16)v3};
         *reinterpret_cast<bf16x4*>(srow + c0 * 2) = pk;
@@ -793,7 +796,7 @@ extern "C" int as_linear_fwd(const void* x, const void* W, const float* bias, vo
                              int dtype, int act, as_stream_t stream) {
   AS_REQUIRE(x && W && out, AS_E_BADARG, "as_linear_fwd: null pointer");
   AS_REQUIRE(M > 0 && Nout > 0 && K > 0 && K % BK == 0, AS_E_BADARG, "as_linear_fwd: need M,N>0 and K %% 32 == 0 (K=%d)", K);
-  AS_REQUIRE(act == 0 || act == 1, AS_E_BADARG, "as_linear_fwd: act must be 0 or 1");
+  AS_REQUIRE(act == 0 || act == 1 || act == 4, AS_E_BADARG, "as_linear_fwd: act must be 0 (none), 1 (GELU) or 4 (ReLU)");
   QkvEpi epi{};
   hipStream_t s = (hipStream_t)stream;
   if (dtype == AS_BF16 && K % GK == 0) return launch_gemm_glds<0>(x, W, bias, out, M, Nout, K, act, epi, s);

@@ -34,7 +34,7 @@ __global__ __launch_bounds__(SC_NT) void shift_final_sim_kernel(const float* __r
                                                                 const int32_t* __restrict__ obj_img,
                                                                 const int2* __restrict__ aw, float* __restrict__ sim,
                                                                 float* __restrict__ part_stats, int C, int Hp, int Wp,
-                                                                int P, int G, int nt1) {
+                                                                int P, int G, int nt1, size_t fbs) {
   __shared__ float red[SC_NW][32][33];
   __shared__ float nrmA[2][2 * SC_NW][32], nrmB[2 * SC_NW][32];
   __shared__ int objs[256];
@@ -44,7 +44,7 @@ __global__ __launch_bounds__(SC_NT) void shift_final_sim_kernel(const float* __r
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, half = lane >> 5;
   const int n_mine = min(tile * 32 + li, Np - 1);
-  const float* frow = feat + ((size_t)b * Np + n_mine) * C;
+  const float* frow = feat + (size_t)b * fbs + (size_t)n_mine * C;
   const int nsteps = C / 16;
 
   float fb[SF2_SU][8];
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(SC_NT) void shift_final_sim_kernel(const float* __r
 // grid (tiles of 32 patches, B).  aw != null: also the density sums of the last assignment (tau trace).
 void as_shift_final_sim_launch(const float* feat, const float* prot, const int32_t* box_patch, const int32_t* obj_img,
                                const int2* aw, float* sim_out, float* part_stats, int B, int C, int Hp, int Wp, int P, int G,
-                               int nt1, hipStream_t s) {
+                               int nt1, size_t fbs, hipStream_t s) {
   hipLaunchKernelGGL(shift_final_sim_kernel, dim3(as_ceil_div(Hp * Wp, 32), B), dim3(SC_NT), 0, s, feat, prot, box_patch,
-                     obj_img, aw, sim_out, part_stats, C, Hp, Wp, P, G, nt1);
+                     obj_img, aw, sim_out, part_stats, C, Hp, Wp, P, G, nt1, fbs);
 }

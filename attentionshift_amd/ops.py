@@ -117,7 +117,7 @@ def linear(x, weight, bias=None, act="none"):
         raise AttnShiftError("linear: weight must be [Nout, K] in the dtype of x")
     out = torch.empty(x2.shape[0], weight.shape[0], device=x.device, dtype=x.dtype)
     _lib.check(lib.as_linear_fwd(_p(x2), _p(weight), _p(bias), _p(out), x2.shape[0], weight.shape[0], K, _dt(x),
-                                 1 if act == "gelu" else 0, _stream()), "as_linear_fwd")
+                                 {"none": 0, "gelu": 1, "relu": 4}[act], _stream()), "as_linear_fwd")
     return out.reshape(*x.shape[:-1], weight.shape[0])
 
 
@@ -598,12 +598,17 @@ def cosine_shift(feat, box_patch, obj_img, prot, n_shift, hp, wp, tau0=0.1, temp
     """feat [B,Np,C] fp32 token-major; box_patch [G,4] int32; obj_img [G] int32; prot [G,P,C] (seeds, not modified).
     Returns (prot_out [G,P,C], sim [G,P,Np]) and, with return_trace, (assign [S,G,Np], tau [S,G,P])."""
     lib = _lib.load()
-    _chk(feat, prot, dtype=torch.float32)
+    _chk(prot, dtype=torch.float32)
     _chk(box_patch, obj_img, dtype=torch.int32)
     B, Np_, C = feat.shape
     G, P, _ = prot.shape
     if Np_ != hp * wp:
         raise AttnShiftError("cosine_shift: Np != hp*wp")
+    # images may be apart by more than Np*C floats (a view of last_feat [B, 1 + Np, C] without its cls row): no copy
+    if not (feat.is_cuda and feat.dtype == torch.float32 and feat.stride(2) == 1 and feat.stride(1) == C
+            and (B == 1 or (feat.stride(0) >= Np_ * C and feat.stride(0) % 4 == 0)) and feat.data_ptr() % 16 == 0):
+        raise AttnShiftError("cosine_shift: feat must be fp32 [B,Np,C] on the device with contiguous, 16-byte aligned image blocks")
+    fbs = feat.stride(0) if B > 1 else Np_ * C
     prot_out = torch.empty_like(prot)
     sim = torch.empty(G, P, Np_, device=feat.device, dtype=torch.float32)
     assign = torch.empty(max(n_shift, 1), G, Np_, device=feat.device, dtype=torch.int32) if return_trace else None
@@ -618,9 +623,9 @@ def cosine_shift(feat, box_patch, obj_img, prot, n_shift, hp, wp, tau0=0.1, temp
             ws = torch.empty(nbytes, device=feat.device, dtype=torch.uint8)
             _shift_ws[key] = ws
     with _timed("cosine_shift"):
-        _lib.check(lib.as_cosine_shift(_p(feat), _p(box_patch), _p(obj_img), _p(prot), _p(prot_out), float(tau0), float(temp),
-                                       int(n_shift), _p(sim), _p(assign), _p(tau), _p(ws), ws.numel(), B, C, hp, wp, G, P,
-                                       _stream()), "as_cosine_shift")
+        _lib.check(lib.as_cosine_shift_strided(_p(feat), int(fbs), _p(box_patch), _p(obj_img), _p(prot), _p(prot_out), float(tau0),
+                                               float(temp), int(n_shift), _p(sim), _p(assign), _p(tau), _p(ws), ws.numel(), B, C,
+                                               hp, wp, G, P, _stream()), "as_cosine_shift")
     if return_trace:
         return prot_out, sim, assign[:n_shift], tau[:n_shift]
     return prot_out, sim

@@ -586,6 +586,27 @@ def _const_tensor(key, device, make):
     return t
 
 
+def _token_blocks_ok(t):
+    """[B,Np,C] fp32 whose per-image blocks are contiguous rows of C floats, images a whole number of rows apart (a
+    contiguous tensor, or the reference caller's view of last_feat without the cls row): what as_cosine_shift_strided reads
+    in place and what _token_rows can index as one 2-D row table."""
+    B, Np, C = t.shape
+    return (t.dtype == torch.float32 and t.stride(2) == 1 and t.stride(1) == C and t.data_ptr() % 16 == 0
+            and (B == 1 or (t.stride(0) >= Np * C and t.stride(0) % C == 0 and t.stride(0) % 4 == 0)))
+
+
+def _token_rows(t):
+    """Row table [(B - 1) * rows_per_image + Np, C] over the storage of a _token_blocks_ok tensor: token n of image i is row
+    i * _token_row_stride(t) + n."""
+    B, Np, C = t.shape
+    rpi = t.stride(0) // C if B > 1 else Np
+    return t.as_strided(((B - 1) * rpi + Np, C), (C, 1))
+
+
+def _token_row_stride(t):
+    return t.stride(0) // t.shape[2] if t.shape[0] > 1 else t.shape[1]
+
+
 def _unit(x):
     return x / x.norm(dim=-1, keepdim=True).clamp_min(1e-8)
 
@@ -1063,11 +1084,11 @@ class AttnShiftRoIHead(nn.Module):
         C, hp, wp = feats_list[0].shape
         sizes = tuple(int(c.shape[0]) for c in coords_list)
         dev = feats_list[0].device
-        if feat_tok is None or not feat_tok.is_contiguous():
+        if feat_tok is None or not _token_blocks_ok(feat_tok):
             feat_tok = torch.stack([f.flatten(1).t() for f in feats_list]).contiguous()
             seed_ids = None                                  # (the ids index the caller's token tensor)
         if seed_ids is not None:                             # token ids of the seeds (as_rank_draw_xy): one gather
-            prot = feat_tok.flatten(0, 1)[seed_ids]
+            prot = _token_rows(feat_tok)[seed_ids]
         else:
             prot = torch.cat([feat.permute(1, 2, 0)[coords[..., 0], coords[..., 1]]
                               for coords, feat in zip(coords_list, feats_list)]).contiguous()
@@ -1107,14 +1128,14 @@ class AttnShiftRoIHead(nn.Module):
             self._dev_gens[key].manual_seed(int(torch.randint(2 ** 62, (1,)).item()))
         return self._dev_gens[key]
 
-    def _semantic_pre(self, map_cos_fg, map_cos_bg, pos_thr):
+    def _semantic_pre(self, map_cos_fg, map_cos_bg, pos_thr, float_map=True):
         """First part of get_semantic_centers (stdroi:2011-2020): the patch-grid foreground maps, one fused launch
         (ops.semantic_prestage).  The reference also down-samples max_g(map_cos_bg) here (bg_inter, :2013), but its
         only consumer is commented out (filter_maps :267), so it is not computed.  Returns fg_inter, the binary
         patch map (float, as the reference), and (mask uint8, counts) of its positives for the grid seeds."""
         fg_inter, mask, counts = ops.semantic_prestage(map_cos_fg.contiguous(), pos_thr, 11, STRIDE)
         CLOCK.mark("  sc:prestage")
-        return fg_inter, mask.to(fg_inter.dtype), (mask, counts)
+        return fg_inter, (mask.to(fg_inter.dtype) if float_map else None), (mask, counts)
 
     def _semantic_post(self, prot, sim, fg_inter, rois, vit_feat, gt_labels, merge_thr, num_semantic_points, extra=None):
         """Last part of get_semantic_centers (stdroi:2022-2031): filter / merge the shifted prototypes, part centres.
@@ -1339,8 +1360,8 @@ class AttnShiftRoIHead(nn.Module):
 
         CLOCK.mark("box_split")
         gt_box_index = self.layer_selector(gt_scale_bboxes, gt_labels, roi_feature_map)
-        pseudo_boxes = [gt_scale_bboxes[i][torch.arange(counts[i], device=boxes.device), gt_box_index[i]]
-                        for i in range(num_imgs)]
+        pseudo_boxes = [gt_scale_bboxes[i][_const_tensor(("arange", counts[i]), boxes.device, lambda n=counts[i]: torch.arange(n)),
+                                           gt_box_index[i]] for i in range(num_imgs)]
         mil_losses = {}
         if self.mil_head is not None and roi_feature_map is not None and self._mil_selector.last_loss is not None:
             mil_losses["mil_loss"] = self._mil_selector.last_loss                # stdroi:2961
@@ -1396,7 +1417,7 @@ class AttnShiftRoIHead(nn.Module):
                 box_patch=bp)
             mp, mask_u8 = mask_points_and_pseudo_issue(map_fg[-1], map_bg[-1], pseudo_boxes[i], pos_mask_thr, neg_mask_thr,
                                                        corr_size, pos_mask_thr)
-            fg_inter, _map_fg_patch, gs = self._semantic_pre(map_fg[-1], map_bg[-1], pos_mask_thr)
+            fg_inter, _map_fg_patch, gs = self._semantic_pre(map_fg[-1], map_bg[-1], pos_mask_thr, float_map=False)
             pm = _to_host_issue(mask_u8, side_stream=True)
             if mt_state is not None:
                 coord_point, labels_point, f1 = mask_points_mt(mp, num_mask_point_gt, mt_state)
@@ -1405,7 +1426,7 @@ class AttnShiftRoIHead(nn.Module):
                                                                    int_flag=flag_slots is not None)
             seeds, f2 = grid_seed_nosync(gs[0], gs[1], 20, flag=None if flag_slots is None else flag_slots[i, 1:2],
                                          patch=None if seed_ids is None else (seed_ids[obj_off[i]:obj_off[i] + counts[i]],
-                                                                              i * patch_h * patch_w))
+                                                                              i * _token_row_stride(feat_tok)))
             if self.capture is not None:
                 self.capture.append(dict(image=i, seeds=seeds, fg_inter=fg_inter))
             flags += [f1, f2]
@@ -1448,7 +1469,7 @@ class AttnShiftRoIHead(nn.Module):
                 # device flags raised by the selection kernels themselves (too few candidates): one zero fill for the batch
                 if os.environ.get("AS_HEAD_TENSOR_GLUE") != "1":     # (A/B switch: "1" = the tensor-op forms of the draws)
                     flag_slots = torch.zeros(num_imgs, 3, dtype=torch.int32, device=boxes.device)
-                if flag_slots is not None and feat_tok.is_contiguous() and (patch_h * patch_w) % 16 == 0:
+                if flag_slots is not None and _token_blocks_ok(feat_tok) and (patch_h * patch_w) % 16 == 0:
                     # token ids (image offset included) of every object's grid seeds, written by the selection kernels: the
                     # mean shift's initial prototypes are then ONE gather for the batch
                     seed_ids = torch.empty(sum(counts), 20, dtype=torch.int64, device=boxes.device)

@@ -56,7 +56,8 @@ const char* as_last_error(void);
 int as_npad(int N);
 
 /* out[M,Nout] = act(x[M,K] . W[Nout,K]^T + bias[Nout])           nn.Linear (vision_transformer.py:47-59,
- * 84).  x,W,out in `dtype`; bias fp32 or NULL; act 0 = none, 1 = exact (erf) GELU.  K % 32 == 0. */
+ * 84).  x,W,out in `dtype`; bias fp32 or NULL; act 0 = none, 1 = exact (erf) GELU, 4 = ReLU (the point head's FFN,
+ * mmdet/models/backbones/visual_transformer_det.py:26-38).  K % 32 == 0. */
 int as_linear_fwd(const void* x, const void* W, const float* bias, void* out, int M, int Nout, int K,
                   int dtype, int act, as_stream_t stream);
 
@@ -346,6 +347,13 @@ int as_cosine_shift(const float* feat, const int32_t* box_patch, const int32_t* 
                     float* prot_out, double tau0, double temp, int n_shift, float* sim_out, int32_t* assign_out,
                     float* tau_out, void* ws, size_t ws_bytes, int B, int C, int Hp, int Wp, int G, int P,
                     as_stream_t stream);
+/* The same call on a feature tensor whose images are `feat_batch_stride` floats apart (>= Np*C, a multiple of 4): the
+ * reference's caller passes vit_feat as a VIEW of last_feat [B, 1 + Np, C] without its cls row
+ * (mmdet/models/detectors/two_stage_point_align.py:77), whose per-image token blocks are contiguous but not adjacent. */
+int as_cosine_shift_strided(const float* feat, long long feat_batch_stride, const int32_t* box_patch, const int32_t* obj_img,
+                            const float* prot_in, float* prot_out, double tau0, double temp, int n_shift, float* sim_out,
+                            int32_t* assign_out, float* tau_out, void* ws, size_t ws_bytes, int B, int C, int Hp, int Wp, int G,
+                            int P, as_stream_t stream);
 
 /* Cosine-affinity refinement on the patch grid (stdroi:668-707 get_refined_similarity):
  *   feat   [Np,C] one image, seeds [Gp,C] (mean feature of the sampled points, :335-338)

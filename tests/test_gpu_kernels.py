@@ -899,6 +899,37 @@ def test_cosine_shift_ties_and_batch(ops):
         assert_close(so, sim[gi], 1e-3, 1e-5, "sim vs oracle")
 
 
+def test_cosine_shift_reads_the_callers_view_of_last_feat_in_place(ops):
+    """as_cosine_shift_strided: vit_feat as the reference's caller builds it -- a view of last_feat [B, 1 + Np, C] without the
+    cls row (two_stage_point_align.py:77), images (1 + Np) * C floats apart -- gives bitwise the result of the contiguous copy."""
+    from attentionshift_amd import synthetic
+    hp, wp, C, B = 14, 18, 192, 3
+    feats, boxes, prots, obj = [], [], [], []
+    for b in range(B):
+        inp = synthetic.shift_inputs(300 + b, hp, wp, C, 2, 1)
+        f = inp["vit_feat"].flatten(1).t().contiguous()
+        feats.append(f)
+        pb = inp["patch_boxes"].int()
+        boxes.append(pb)
+        for gi in range(2):
+            x0, y0, x1, y1 = pb[gi].tolist()
+            idx = (torch.linspace(y0, y1, 5).long()[:, None] * wp + torch.linspace(x0, x1, 4).long()[None, :]).flatten()
+            prots.append(f[idx])
+            obj.append(b)
+    last = torch.randn(B, 1 + hp * wp, C)
+    last[:, 1:] = torch.stack(feats)
+    last = last.cuda()
+    view = last[:, 1:]                                             # [B, Np, C], stride(0) = (1 + Np) * C
+    assert not view.is_contiguous()
+    args = (dev(torch.cat(boxes)), dev(torch.tensor(obj, dtype=torch.int32)), dev(torch.stack(prots)), 4, hp, wp)
+    r_view = ops.cosine_shift(view, *args, return_trace=True)
+    r_copy = ops.cosine_shift(view.contiguous(), *args, return_trace=True)
+    for a, b_ in zip(r_view, r_copy):
+        assert_equal(b_, a, "strided view vs contiguous copy")
+    with pytest.raises(Exception):
+        ops.cosine_shift(last.transpose(1, 2)[:, :, 1:].transpose(1, 2)[:, :, ::2], *args)      # rows not contiguous
+
+
 def test_cosine_shift_full_size_properties(ops):
     """BASELINE config-2 shape (B=2, 64x64 patches, C=768, G=3/img, P=20, S=5): size-independent
     properties -- cosine range, assignment range, determinism (two runs bitwise equal), and that the

@@ -453,8 +453,8 @@ def test_fast_mode_flagged_image_falls_back_to_the_synchronous_path(monkeypatch)
     real = RH.grid_seed_nosync
     calls = []
 
-    def flagged(mask, count_dev, n_points=20):
-        coords, flag = real(mask, count_dev, n_points)
+    def flagged(mask, count_dev, n_points=20, **kw):
+        coords, flag = real(mask, count_dev, n_points, **kw)
         calls.append(1)
         return coords, torch.ones_like(flag) if len(calls) == 1 else flag      # flag image 0 only
 

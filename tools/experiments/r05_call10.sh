@@ -1,0 +1,7 @@
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+timeout 900 python -m pytest tests -q -x -m gpu --timeout 300 > gpurun_out/r05_t10.log 2>&1; tail -5 gpurun_out/r05_t10.log
+timeout 300 python tools/experiments/glue_sites.py --steps 3 --rows 200 > gpurun_out/r05_glue_sites2.log 2>&1
+grep "ATen ops on device\|ATen device time" gpurun_out/r05_glue_sites2.log
+AS_BENCH_OTHER_RNG=0 AS_BENCH_MIL=0 timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --train-steps 0 --other-configs "" > gpurun_out/r05_bench10.json 2> gpurun_out/r05_bench10.err
+echo "$(cut -c100-200 gpurun_out/r05_bench10.json)"
