@@ -350,39 +350,32 @@ class VisionTransformerDet(nn.Module):
         return op(feat_nchw)
 
     # ---- point head (visual_transformer_det.py:26-38, 152-153, 268-269) on the inference path -------------------------
-    # class_embed and bbox_embed are two 3-layer FFNs over the SAME B*T point tokens: fourteen library launches for 200
-    # rows.  Their layers are packed once per weight version -- layer 1 side by side (shared input), layers 2 and 3
-    # block-diagonally -- so the head is three as_linear_fwd launches with bias + ReLU in the epilogue.
+    # class_embed and bbox_embed are two 3-layer FFNs over the SAME B*T = 200 point tokens: fifteen launches as written.
+    # Their first layers are packed side by side (shared input) once per weight version and bias + ReLU ride in the GEMM
+    # epilogue: five library GEMMs + the sigmoid.  (fp32, 200 rows: a plain small-M library GEMM -- the hand-written fp32
+    # MFMA kernel's 128 x 128 tiles put this shape on 24 CUs, 170 us per layer; measured, round 5.)
     def _point_head_packable(self, x):
         ls = list(self.class_embed.layers) + list(self.bbox_embed.layers)
-        return (x.dtype == torch.float32 and len(self.class_embed.layers) == 3 and len(self.bbox_embed.layers) == 3
-                and all(l.weight.dtype == torch.float32 and l.bias is not None and l.in_features % 32 == 0 for l in ls)
+        return (len(self.class_embed.layers) == 3 and len(self.bbox_embed.layers) == 3 and hasattr(torch, "_addmm_activation")
+                and all(l.weight.dtype == x.dtype and l.bias is not None for l in ls)
                 and self.class_embed.layers[0].in_features == self.bbox_embed.layers[0].in_features)
 
     def _point_head_packed(self, x):
         c, b = self.class_embed.layers, self.bbox_embed.layers
-        params = [t for l in list(c) + list(b) for t in (l.weight, l.bias)]
-        key = tuple((t.data_ptr(), t._version) for t in params)
+        key = tuple((t.data_ptr(), t._version) for t in (c[0].weight, c[0].bias, b[0].weight, b[0].bias))
         pk = self._point_pack
         if pk is None or pk["key"] != key:
             with torch.no_grad():
-                h1, h2 = c[0].out_features, b[0].out_features
-                w2 = torch.zeros(c[1].out_features + b[1].out_features, h1 + h2, device=x.device)
-                w2[:c[1].out_features, :h1] = c[1].weight
-                w2[c[1].out_features:, h1:] = b[1].weight
-                k3 = c[1].out_features + b[1].out_features
-                w3 = torch.zeros(c[2].out_features + b[2].out_features, k3, device=x.device)
-                w3[:c[2].out_features, :c[1].out_features] = c[2].weight
-                w3[c[2].out_features:, c[1].out_features:] = b[2].weight
-                pk = dict(key=key, w1=torch.cat((c[0].weight, b[0].weight)).contiguous(), b1=torch.cat((c[0].bias, b[0].bias)),
-                          w2=w2, b2=torch.cat((c[1].bias, b[1].bias)), w3=w3, b3=torch.cat((c[2].bias, b[2].bias)),
-                          ncls=c[2].out_features)
+                pk = dict(key=key, w1t=torch.cat((c[0].weight, b[0].weight)).t().contiguous(), b1=torch.cat((c[0].bias, b[0].bias)))
             self._point_pack = pk
         B, T, D = x.shape
-        h = ops.linear(x.reshape(B * T, D).contiguous(), pk["w1"], pk["b1"], act="relu")
-        h = ops.linear(h, pk["w2"], pk["b2"], act="relu")
-        o = ops.linear(h, pk["w3"], pk["b3"]).reshape(B, T, -1)
-        return o[..., :pk["ncls"]], o[..., pk["ncls"]:].sigmoid()
+        hc = c[0].out_features
+        h1 = torch._addmm_activation(pk["b1"], x.reshape(B * T, D), pk["w1t"])              # ReLU epilogue, both heads
+        h2c = torch._addmm_activation(c[1].bias, h1[:, :hc], c[1].weight.t())
+        h2b = torch._addmm_activation(b[1].bias, h1[:, hc:], b[1].weight.t())
+        cls = torch.addmm(c[2].bias, h2c, c[2].weight.t()).reshape(B, T, -1)
+        reg = torch.addmm(b[2].bias, h2b, b[2].weight.t()).reshape(B, T, -1).sigmoid()
+        return cls, reg
 
     def interpolate_pos_encoding(self, n_patch_tokens, w, h):
         """models/vision_transformer.py:187-207 (bicubic, scale_factor with the +0.1 trick)."""

@@ -529,41 +529,59 @@ __global__ __launch_bounds__(MG_NT) void merge_parts_kernel(const float* __restr
   extern __shared__ float mg_u[];                            // [P][C + 1] normalised prototypes (row pitch C + 1: no conflicts)
   __shared__ float nrm_s[MG_PMAX];
   __shared__ unsigned link_s[MG_PMAX], group_s[MG_PMAX];
+  __shared__ uint8_t keep_s[MG_PMAX];
   __shared__ int n_s;
   const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* pg = prot + (size_t)g * P * C;
   const int pitch = C + 1;
+  // the object's prototypes -> LDS, eight independent loads per thread in flight (a load -> use loop of 60 trips per thread
+  // is 60 serialised L2 round trips: that alone was 60 of the kernel's first version's 70 us)
+  if (tid < MG_PMAX) link_s[tid] = 0u;
+  if (tid < MG_PMAX) keep_s[tid] = tid < P ? keep[g * P + tid] : 0;       // (one thread reading them one by one: 20 round trips)
+  {
+    constexpr int U = 8;
+    const int n = P * C;
+    for (int i0 = tid; i0 < n; i0 += MG_NT * U) {
+      float v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) v[u] = pg[min(i0 + u * MG_NT, n - 1)];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = i0 + u * MG_NT;
+        if (i < n) { const int p = i / C; mg_u[p * pitch + (i - p * C)] = v[u]; }
+      }
+    }
+  }
+  __syncthreads();
   for (int p = wave; p < P; p += MG_NT / 64) {                // |prot_p|: one wave per row, fixed shuffle tree
     float s = 0.0f;
-    for (int c = lane; c < C; c += 64) { const float v = pg[(size_t)p * C + c]; s = fmaf(v, v, s); }
+    for (int c = lane; c < C; c += 64) { const float v = mg_u[p * pitch + c]; s = fmaf(v, v, s); }
     s = wave_sum(s);
     if (lane == 0) nrm_s[p] = fmaxf(sqrtf(s), 1e-8f);
   }
-  if (tid < MG_PMAX) link_s[tid] = 0u;
   __syncthreads();
-  for (int i = tid; i < P * C; i += MG_NT) {
+  for (int i = tid; i < P * C; i += MG_NT) {                  // u = x / max(|x|, 1e-8), in place
     const int p = i / C, c = i - p * C;
-    mg_u[p * pitch + c] = pg[i] / nrm_s[p];
+    mg_u[p * pitch + c] = mg_u[p * pitch + c] / nrm_s[p];
   }
   __syncthreads();
-  for (int pr = tid; pr < P * P; pr += MG_NT) {               // cos(u_i, u_j) >= thr for j >= i (the upper triangle is all
-    const int i = pr / P, j = pr - i * P;                     // the grouping reads)
-    if (j < i) continue;
+  // cos(u_i, u_j) >= thr for j >= i (the upper triangle is all the grouping reads): one WAVE per pair, lanes along the
+  // channels (conflict-free LDS rows), fixed shuffle tree -- a thread per pair walked 2 x C LDS words alone (70 us per launch)
+  for (int pr = wave; pr < P * P; pr += MG_NT / 64) {
+    const int i = pr / P, j = pr - i * P;
+    if (j < i) continue;                                      // wave-uniform
     const float* a = mg_u + i * pitch;
     const float* b = mg_u + j * pitch;
-    float d0 = 0.0f, d1 = 0.0f, d2 = 0.0f, d3 = 0.0f;
-    int c = 0;
-    for (; c + 4 <= C; c += 4) {
-      d0 = fmaf(a[c], b[c], d0); d1 = fmaf(a[c + 1], b[c + 1], d1);
-      d2 = fmaf(a[c + 2], b[c + 2], d2); d3 = fmaf(a[c + 3], b[c + 3], d3);
-    }
-    for (; c < C; ++c) d0 = fmaf(a[c], b[c], d0);
-    if ((d0 + d1) + (d2 + d3) >= thr) atomicOr(&link_s[i], 1u << j);
+    float d = 0.0f;
+    for (int c = lane; c < C; c += 64) d = fmaf(a[c], b[c], d);
+    d = wave_sum(d);
+    if (lane == 0 && d >= thr) atomicOr(&link_s[i], 1u << j);
   }
   __syncthreads();
   if (tid == 0) {                                             // the greedy grouping of merge_plan_kernel
     unsigned kept = 0u;
-    for (int p = 0; p < P; ++p) kept |= (keep[g * P + p] != 0 ? 1u : 0u) << p;
+    for (int p = 0; p < P; ++p) kept |= (keep_s[p] != 0 ? 1u : 0u) << p;
     unsigned cleared = 0u;
     int n = 0;
     for (int i = 0; i < P; ++i) {
@@ -577,13 +595,24 @@ __global__ __launch_bounds__(MG_NT) void merge_parts_kernel(const float* __restr
     if (n > slots && flag != nullptr) atomicOr(flag, 1);
   }
   __syncthreads();
-  for (int o = tid; o < slots * C; o += MG_NT) {
-    const int sl = o / C, c = o - sl * C;
-    const unsigned row = sl < P ? group_s[sl] : 0u;
-    float acc = 0.0f, cnt = 0.0f;
-    for (int p = 0; p < P; ++p)
-      if ((row >> p) & 1u) { acc += pg[(size_t)p * C + c]; cnt += 1.0f; }
-    merged[((size_t)g * slots + sl) * C + c] = acc / (cnt + 1e-8f);
+  // thread = channel: the P values of a channel are loaded ONCE, unconditionally and together (a load inside the member test
+  // is a branch with its own s_waitcnt: ~100 dependent L2 round trips per thread, 90 us per launch), then every slot sums
+  // its members in index order (adding +0 for the others leaves every partial sum bit-identical)
+  for (int c = tid; c < C; c += MG_NT) {
+    float v[MG_PMAX];
+#pragma unroll
+    for (int p = 0; p < MG_PMAX; ++p) v[p] = pg[(size_t)min(p, P - 1) * C + c];
+    for (int sl = 0; sl < slots; ++sl) {
+      const unsigned row = sl < P ? group_s[sl] : 0u;
+      float acc = 0.0f, cnt = 0.0f;
+#pragma unroll
+      for (int p = 0; p < MG_PMAX; ++p) {
+        const bool in = p < P && ((row >> p) & 1u);
+        acc += in ? v[p] : 0.0f;
+        cnt += in ? 1.0f : 0.0f;
+      }
+      merged[((size_t)g * slots + sl) * C + c] = acc / (cnt + 1e-8f);
+    }
   }
 }
 }  // namespace

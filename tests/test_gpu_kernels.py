@@ -38,19 +38,21 @@ def rel_to_range(ref, got):
 # Part A
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("M,N,K", [(300, 192, 192), (129, 576, 64), (1000, 256, 768)])
-@pytest.mark.parametrize("act", ["none", "gelu"])
+@pytest.mark.parametrize("act", ["none", "gelu", "relu"])
 def test_linear_f32(ops, M, N, K, act):
     g = torch.Generator().manual_seed(M + N + K)
     x, w, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.1, torch.randn(N, generator=g)
     ref = torch.nn.functional.linear(x, w, b)
     if act == "gelu":
         ref = torch.nn.functional.gelu(ref)
+    if act == "relu":
+        ref = torch.relu(ref)
     got = ops.linear(dev(x), dev(w), dev(b), act=act)
     assert_close(ref, got, 1e-4, 1e-4, f"linear f32 {M}x{N}x{K} {act}")
 
 
 @pytest.mark.parametrize("M,N,K", [(8394, 3072, 768), (8394, 768, 3072), (4197, 768, 768), (8394, 3080, 768), (8394, 1000, 4096)])
-@pytest.mark.parametrize("act", ["none", "gelu"])
+@pytest.mark.parametrize("act", ["none", "gelu", "relu"])
 def test_linear_bf16_backbone_shapes(ops, M, N, K, act):
     """as_linear_fwd in plain-linear mode on the shapes the ViT-B blocks launch (fc1 / fc2 / proj at 2 x 4197 tokens):
     fc2 / proj pick the 256 x 128 tile, fc1 (N = 3072) the 256 x 256 one (csrc/gemm.hip launch_gemm_glds; M = 513 below
@@ -63,6 +65,8 @@ def test_linear_bf16_backbone_shapes(ops, M, N, K, act):
     ref = torch.nn.functional.linear(x.float(), w.float(), b)
     if act == "gelu":
         ref = torch.nn.functional.gelu(ref)
+    if act == "relu":
+        ref = torch.relu(ref)
     got = ops.linear(dev(x), dev(w), dev(b), act=act).float()
     mx, mean = rel_to_range(ref, got)
     assert mx < 1e-2 and mean < 2e-3, (mx, mean)      # output rounding to bf16 dominates

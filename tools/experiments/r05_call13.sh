@@ -1,0 +1,6 @@
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+timeout 600 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_path.py -q -x -m gpu --timeout 300 -k "merge_parts or linear_f32 or backbone_fp32 or backbone_bf16 or seed_pseudo or semantic_post or fast_mode" > gpurun_out/r05_t13.log 2>&1; tail -3 gpurun_out/r05_t13.log
+bash tools/experiments/r05_ab.sh 2>&1 | tee gpurun_out/r05_ab2.log
+AS_BENCH_EVENTS=0 AS_BENCH_OTHER_RNG=0 AS_BENCH_MIL=0 PROF_LINES=2 tools/prof_cmd.sh r05_bench_kernel_stats_mid2 python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --train-steps 0 --other-configs "" > /dev/null 2>&1
+grep "merge_parts\|Cijk\|total kernel" gpurun_out/r05_bench_kernel_stats_mid2.md | cut -c1-200
