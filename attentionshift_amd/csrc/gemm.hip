@@ -359,21 +359,20 @@ __global__ __launch_bounds__(64 * WM * WN, (WN == 4 || KS == 4) ? 1 : (WM == 2 &
   // an A tile (128 tokens x K) is fetched into one L2 once and reused by all Nout/128 column tiles, instead of being
   // pulled through the fabric by every XCD (measured: 192 MB fetched per QKV launch for 16 MB of operands).
   const int nt_n = (Nout + BN - 1) / BN, tiles = ((M + BM - 1) / BM) * nt_n;
-  const int per = (tiles + 7) >> 3;
-  const int tile = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-  if (tile >= tiles) return;
-  // phase offset between the two workgroups that share a CU (see launch_gemm_glds): without it both run their main loops
-  // and then their epilogues at the same time; with it one's prologue / epilogue runs under the other's MFMAs
-  if (epi.stagger > 0 && blockIdx.x >= 256 && blockIdx.x < 512)
-    for (int i = 0; i < epi.stagger; ++i) __builtin_amdgcn_s_sleep(127);
+  // MODE 4 / 5 = stream-K (plain / QKV epilogue): a workgroup contracts a contiguous range of the flattened (tile, K step)
+  // space -- at most the tail of one tile, whole tiles, the head of another -- so that every workgroup gets the same number
+  // of K steps whatever the tile count (launch_gemm_sk).  A tile cut into np > 1 pieces is finished by the piece that draws
+  // the LAST ticket: the others leave their fp32 accumulators in the workspace (the sdpa.hip stream-K hand-off: plain stores,
+  // one agent-scope release per workgroup, a relaxed counter), so nobody ever waits for a workgroup that is not running.
+  constexpr bool SK = MODE >= 4;
+  constexpr int EM = MODE == 4 ? 0 : MODE == 5 ? 1 : MODE;           // which epilogue
+  // one (tile, K range): kind 0 = the whole contraction; kind 1 = piece `pidx` of `np` (first piece held by rank r_first)
+  auto run_tile = [&](const int tile, const int kbeg, const int klen, const int np, const int pidx, const int r_first) {
   const int m0 = (tile / nt_n) * BM, n0 = (tile % nt_n) * BN;
 
   // loader: per K step wave w moves NAP one-KiB pieces of A (tile rows 16p .. 16p+15 of piece p = NAP*w + j) and NWP of
   // the BN/16 pieces of W (2 + 2 per wave at 4 waves, 2 + 1 at 8, 1 + 1 at 16)
   const int lr = lane / CPR, lc = lane % CPR;
-  // MODE 3 (split-K): workgroup row blockIdx.y contracts over [kbeg, kbeg + klen) only and writes an fp32 partial tile
-  const int kbeg = MODE == 3 ? (int)blockIdx.y * epi.N : 0;
-  const int klen = MODE == 3 ? min(epi.N, K - kbeg) : K;
   constexpr int NAP = GT::A_PIECES, NWP = GT::W_PIECES;
   const char* srcA[NAP];
   const char* srcW[NWP];
@@ -490,6 +489,82 @@ __global__ __launch_bounds__(64 * WM * WN, (WN == 4 || KS == 4) ? 1 : (WM == 2 &
   }
   }
 
+  if constexpr (SK) {
+    if (np > 1) {
+      // tile-local fp32 image of a piece: lane = row, registers 4g .. 4g+3 = 4 consecutive columns -> one float4
+      float* const parts = reinterpret_cast<float*>(epi.q);
+      int* const arrive = reinterpret_cast<int*>(epi.k);
+      int* const done = arrive + tiles;
+      // piece p of this tile is rank r_first + p: its FIRST segment when p > 0 (slot 0), its last when p == 0 (slot 1)
+      auto part_of = [&](int p) { return parts + ((size_t)(r_first + p) * 2 + (p > 0 ? 0 : 1)) * (size_t)(BM * BN); };
+      // this lane's first quad; quad (i, j, g) is the compile-time offset i * 32 * BN + j * 32 + 8 * g floats further on
+      const int lane_at = (wm * (32 * RI) + li) * BN + wn * (32 * NJ) + 4 * half;
+      __syncthreads();                                  // every wave is done with the ring: smem[0..3] is the ticket box
+      int* const box = reinterpret_cast<int*>(smem);
+      if (tid == 0) box[0] = __hip_atomic_fetch_add(&arrive[tile], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();
+      const int ticket = __builtin_amdgcn_readfirstlane(box[0]);
+      const bool last = ticket == np - 1;
+      if (!last || np > 2) {                            // (np == 2: the finisher adds the other piece -- a + b is commutative;
+        float* mine = part_of(pidx) + lane_at;          //  np >= 3: it re-reads ALL pieces in piece order, its own included,
+#pragma unroll                                          //  so that the sum does not depend on who arrived last)
+        for (int i = 0; i < RI; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+              *reinterpret_cast<float4*>(mine + i * 32 * BN + j * 32 + 8 * g) =
+                  make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+      }
+      if (!last) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // (the compiler may drop the fence's own wait here)
+          __hip_atomic_fetch_add(&done[tile], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return;
+      }
+      // last arriver: the other pieces have drawn their tickets, i.e. they are running -- a bounded wait
+      if (tid == 0) {
+        while (__hip_atomic_load(&done[tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < np - 1) __builtin_amdgcn_s_sleep(2);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      }
+      if (np > 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // my own piece is re-read below
+      __syncthreads();
+      if (np > 2) {
+#pragma unroll
+        for (int i = 0; i < RI; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+      }
+      for (int p = 0; p < np; ++p) {
+        if (np == 2 && p == pidx) continue;
+        const float* src = part_of(p) + lane_at;
+#pragma unroll
+        for (int i = 0; i < RI; ++i) {                  // one 32-row block at a time: 4 NJ loads in flight, not 4 NJ RI
+          float4 v[NJ * 4];
+#pragma unroll
+          for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+              v[j * 4 + g] = *reinterpret_cast<const float4*>(src + i * 32 * BN + j * 32 + 8 * g);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              acc[i][j][4 * g] += v[j * 4 + g].x; acc[i][j][4 * g + 1] += v[j * 4 + g].y;
+              acc[i][j][4 * g + 2] += v[j * 4 + g].z; acc[i][j][4 * g + 3] += v[j * 4 + g].w;
+            }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+  }
   // ---------------- epilogue ----------------
   // lane -> token row m = m0 + wm*64 + i*32 + li; register r of block (i,j) -> column n0 + wn*64 + j*32 + acc_row(r,half)
   if constexpr (MODE == 3) {
@@ -515,7 +590,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WN == 4 || KS == 4) ? 1 : (WM == 2 &
     }
     return;
   }
-  const bool vtile = MODE == 1 && n0 >= 2 * epi.D;   // block-uniform: the whole 128-column tile is V
+  const bool vtile = EM == 1 && n0 >= 2 * epi.D;     // block-uniform: the whole 128-column tile is V
   if (vtile) {
     if (AS_GEMM_ABLATE == 5) return;
 #pragma unroll
@@ -569,7 +644,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WN == 4 || KS == 4) ? 1 : (WM == 2 &
         const float4 bv = *reinterpret_cast<const float4*>(bias_s + c0);
         float v0 = acc[i][j][4 * g] + bv.x, v1 = acc[i][j][4 * g + 1] + bv.y, v2 = acc[i][j][4 * g + 2] + bv.z,
               v3 = acc[i][j][4 * g + 3] + bv.w;
-        if (MODE == 1 && n0 + c0 < epi.D) {              // q columns: stored pre-scaled by log2(e)/8 (common.h)
+        if (EM == 1 && n0 + c0 < epi.D) {                // q columns: stored pre-scaled by log2(e)/8 (common.h)
           v0 *= AS_QSCALE; v1 *= AS_QSCALE; v2 *= AS_QSCALE; v3 *= AS_QSCALE;
         }
         if (act == 1) {
@@ -599,13 +674,13 @@ __global__ __launch_bounds__(64 * WM * WN, (WN == 4 || KS == 4) ? 1 : (WM == 2 &
       if (v.x == 0x12345678u && v.w == 0x9abcdef0u) out[0] = (__bf16)1.0f;
       continue;
     }
-    if (MODE == 2) {
+    if (EM == 2) {
       // 2x2 / stride-2 transposed convolution: GEMM row = input pixel (b*h + i, j) of a grid epi.N wide, column =
       // (di, dj, co) with co < epi.D -> NHWC output pixel (2 (b*h + i) + di, 2 j + dj); a 16-byte chunk never straddles
       const int bi = row / epi.N, j = row - bi * epi.N;
       const int tap = col / epi.D, co = col - tap * epi.D;
       *reinterpret_cast<uint4*>(out + ((size_t)(2 * bi + (tap >> 1)) * (2 * epi.N) + 2 * j + (tap & 1)) * epi.D + co) = v;
-    } else if (MODE == 0) {
+    } else if (EM == 0) {
       if (act == 2) {                                  // (Nout % 8 == 0 on this path: as_linear_gelu_fwd)
         *reinterpret_cast<uint4*>(reinterpret_cast<__bf16*>(epi.q) + (size_t)row * Nout + col) = v;
         *reinterpret_cast<uint4*>(out + (size_t)row * Nout + col) = gelu_chunk(v);
@@ -627,6 +702,44 @@ __global__ __launch_bounds__(64 * WM * WN, (WN == 4 || KS == 4) ? 1 : (WM == 2 &
         *reinterpret_cast<uint4*>(reinterpret_cast<__bf16*>(epi.q) + qf_frag(bh, epi.Npad, n, d0 >> 4, (d0 >> 3) & 1)) = v;
       else
         *reinterpret_cast<uint4*>(reinterpret_cast<__bf16*>(epi.k) + (bh * epi.Npad + n) * 64 + d0) = v;
+    }
+  }
+  };   // run_tile
+
+  if constexpr (!SK) {
+    const int per = (tiles + 7) >> 3;
+    const int tile = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if (tile >= tiles) return;
+    // phase offset between the two workgroups that share a CU (see launch_gemm_glds): without it both run their main loops
+    // and then their epilogues at the same time; with it one's prologue / epilogue runs under the other's MFMAs
+    if (epi.stagger > 0 && blockIdx.x >= 256 && blockIdx.x < 512)
+      for (int i = 0; i < epi.stagger; ++i) __builtin_amdgcn_s_sleep(127);
+    // MODE 3 (split-K): workgroup row blockIdx.y contracts over [kbeg, kbeg + klen) only and writes an fp32 partial tile
+    const int kbeg = MODE == 3 ? (int)blockIdx.y * epi.N : 0;
+    run_tile(tile, kbeg, MODE == 3 ? min(epi.N, K - kbeg) : K, 1, 0, 0);
+  } else {
+    // rank = position of this workgroup in the flattened order.  Workgroup ids are dealt round-robin over the 8 XCDs, so
+    // the ranks of one XCD are made contiguous (id -> (id % 8) * (S / 8) + id / 8, S % 8 == 0): consecutive tiles -- which
+    // share their A rows -- stay in one L2, as in the plain grid
+    const int S = gridDim.x, nk = K / GK;
+    const int rank = (blockIdx.x & 7) * (S >> 3) + (blockIdx.x >> 3);
+    const long long total = (long long)tiles * nk;
+    const int base = (int)(total / S), rem = (int)(total % S);
+    auto start_of = [&](int r) { return (long long)r * base + (r < rem ? r : rem); };
+    auto rank_of = [&](long long st) {                  // the rank whose range holds step st
+      const long long cut = (long long)rem * (base + 1);
+      return st < cut ? (int)(st / (base + 1)) : rem + (int)((st - cut) / base);
+    };
+    long long st = start_of(rank);
+    const long long end = start_of(rank + 1);
+    while (st < end) {
+      const int tile = (int)(st / nk), k0 = (int)(st - (long long)tile * nk);
+      const int n_t = (int)((end - st) < (long long)(nk - k0) ? (end - st) : (long long)(nk - k0));
+      const long long t_begin = (long long)tile * nk;
+      const int r_first = rank_of(t_begin), r_last = rank_of(t_begin + nk - 1);
+      run_tile(tile, k0 * GK, n_t * GK, r_last - r_first + 1, rank - r_first, r_first);
+      st += n_t;
+      if (st < end) __syncthreads();                    // the next segment's first LDS-DMA lands in the ring / staging tile
     }
   }
 }
@@ -696,6 +809,75 @@ int launch_gemm_glds(const void* A, const void* W, const float* bias, void* out,
   if (pick == 3) return launch_gemm_glds_wm<MODE, 4, 2, 2, 4>(A, W, bias, out, M, Nout, K, act, epi, s);
   if (pick == 2) return launch_gemm_glds_wm<MODE, 4, 2, 2, 2>(A, W, bias, out, M, Nout, K, act, epi, s);
   return launch_gemm_glds_wm<MODE, 2, 2, 2, 2>(A, W, bias, out, M, Nout, K, act, epi, s);
+}
+
+// ---- stream-K launch (MODE 4 plain / 5 QKV) on the one-workgroup-per-CU tiles: S = CU count workgroups, each with the same
+// number of K steps.  Worth it when the plain grid's last round is far from full: fc1 at M = 8394 is 396 tiles of 256 x 256 =
+// 1.55 rounds run as 2, fc2 198 tiles of 256 x 128 on 256 CUs.  Workspace: two fp32 tile images per workgroup (a range
+// starts with at most one tail piece and ends with at most one head piece) + the arrive / done counters of every tile.
+struct SkPlan { int pick, tiles, S; size_t part_bytes, total; bool use; };
+SkPlan sk_plan(int M, int Nout, int K, bool qkv) {
+  SkPlan p{};
+  static const int cus = [] {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return n > 0 ? n : 256;
+  }();
+  p.S = cus - cus % 8;                                   // (ranks are dealt per XCD: a multiple of 8)
+  const bool wide = !qkv && Nout >= 1024 && K % 64 == 0; // the tile launch_gemm_glds would pick among the 1-per-CU ones
+  p.pick = wide ? 4 : 3;
+  const int bm = 256, bn = wide ? 256 : 128;
+  p.tiles = as_ceil_div(M, bm) * as_ceil_div(Nout, bn);
+  p.part_bytes = (size_t)p.S * 2 * bm * bn * sizeof(float);
+  p.total = p.part_bytes + (size_t)as_round_up(2 * p.tiles * (int)sizeof(int), 256);
+  const int rounds = as_ceil_div(p.tiles, p.S);
+  // MEASURED SLOWER, so OFF unless AS_GEMM_SK=1 (round 5, one MI355X, us, plain grid -> stream-K): fc1 8394 x 3072 x 768
+  // 60.1 -> 149.8, fc2 8394 x 768 x 3072 53.0 -> 94.5, proj 8394 x 768 x 768 18.6 -> 40.0.  Every workgroup publishes a
+  // 128 / 256 KiB fp32 tile image behind an agent-scope release (a write-back of its XCD's whole L2, in which the other
+  // workgroups' output tiles sit) and the finisher re-reads it; the second and third segment of a range restart the LDS-DMA
+  // pipeline.  hipBLASLt's stream-K kernels win 25 % on these shapes with the same idea, so the cost is in THIS hand-off,
+  // not in the schedule -- kept for the record and for a write-through (sc1) hand-off to be tried on it.
+  const char* e = getenv("AS_GEMM_SK");                  // (read per call: tests switch it)
+  const int force = e ? atoi(e) : 0;
+  (void)rounds;
+  p.use = force == 1 && K % 64 == 0 && p.S >= 8 && (long long)p.tiles * (K / 64) >= 8LL * p.S;
+  return p;
+}
+
+template <int MODE>
+int launch_gemm_sk(const void* A, const void* W, const float* bias, void* out, int M, int Nout, int K, int act, QkvEpi epi,
+                   void* ws, const SkPlan& p, hipStream_t s) {
+  char* w = (char*)ws;
+  int* counters = (int*)(w + p.part_bytes);
+  (void)hipMemsetAsync(counters, 0, (size_t)2 * p.tiles * sizeof(int), s);
+  float* parts = (float*)w;
+  auto go = [&](auto kern, size_t lds, int nt) {
+    static std::atomic<bool> attr_set{false};
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(p.S), dim3(nt), lds, s, (const __bf16*)A, (const __bf16*)W, bias, (__bf16*)out, M, Nout, K, act, epi);
+  };
+  // (the stream-K hand-off borrows the q / k pointer slots of the epilogue descriptor: MODE 4 has no QKV outputs; MODE 5
+  //  carries them in epi.vt's neighbours -- see SkQkv below)
+  if (p.pick == 4) {
+    if constexpr (MODE == 4) {
+      epi.q = parts; epi.k = counters;
+      go(gemm_glds_kernel<4, 2, 4, 4, 4, 2>, (size_t)GTile<2, 4, 4, 4, 2>::LDS, GTile<2, 4, 4, 4, 2>::NT_);
+    } else {
+      return AS_E_UNSUPPORTED;
+    }
+  } else {
+    if constexpr (MODE == 4) {
+      epi.q = parts; epi.k = counters;
+      go(gemm_glds_kernel<4, 4, 2, 2, 4, 2>, (size_t)GTile<4, 2, 2, 4, 2>::LDS, GTile<4, 2, 2, 4, 2>::NT_);
+    } else {
+      return AS_E_UNSUPPORTED;
+    }
+  }
+  AS_CHECK_LAUNCH("gemm_sk");
+  return AS_OK;
 }
 
 template <typename T, int MODE>
@@ -803,6 +985,23 @@ extern "C" int as_linear_fwd(const void* x, const void* W, const float* bias, vo
   if (dtype == AS_BF16) return launch_gemm<__bf16, 0>(x, W, bias, out, M, Nout, K, act, epi, s);
   if (dtype == AS_F32) return launch_gemm<float, 0>(x, W, bias, out, M, Nout, K, act, epi, s);
   AS_REQUIRE(false, AS_E_UNSUPPORTED, "as_linear_fwd: dtype %d", dtype);
+}
+
+extern "C" size_t as_linear_sk_workspace_bytes(int M, int Nout, int K) {
+  if (M <= 0 || Nout <= 0 || K <= 0) return 0;
+  const SkPlan p = sk_plan(M, Nout, K, false);
+  return p.use ? p.total : 0;
+}
+
+extern "C" int as_linear_sk_fwd(const void* x, const void* W, const float* bias, void* out, int M, int Nout, int K, int dtype,
+                                int act, void* ws, size_t ws_bytes, as_stream_t stream) {
+  AS_REQUIRE(x && W && out, AS_E_BADARG, "as_linear_sk_fwd: null pointer");
+  AS_REQUIRE(M > 0 && Nout > 0 && K > 0 && K % BK == 0, AS_E_BADARG, "as_linear_sk_fwd: need M,N>0 and K %% 32 == 0 (K=%d)", K);
+  AS_REQUIRE(act == 0 || act == 1 || act == 4, AS_E_BADARG, "as_linear_sk_fwd: act must be 0 (none), 1 (GELU) or 4 (ReLU)");
+  const SkPlan p = sk_plan(M, Nout, K, false);
+  if (dtype != AS_BF16 || !p.use) return as_linear_fwd(x, W, bias, out, M, Nout, K, dtype, act, stream);
+  AS_REQUIRE(ws && ws_bytes >= p.total, AS_E_WORKSPACE, "as_linear_sk_fwd: workspace %zu < %zu bytes", ws_bytes, p.total);
+  return launch_gemm_sk<4>(x, W, bias, out, M, Nout, K, act, QkvEpi{}, ws, p, (hipStream_t)stream);
 }
 
 extern "C" int as_linear_gelu_fwd(const void* x, const void* W, const float* bias, void* out, void* pre, int M, int Nout, int K,

@@ -522,7 +522,7 @@ extern "C" int as_merge_plan(const uint8_t* keep, const uint8_t* link, int32_t* 
 // has more than `slots` groups (the caller then takes its synchronous path).
 // =====================================================================================================
 namespace {
-constexpr int MG_NT = 256, MG_PMAX = 32;
+constexpr int MG_NT = 1024, MG_PMAX = 32;   // 16 waves: every phase is a short latency chain, so more waves = less time
 __global__ __launch_bounds__(MG_NT) void merge_parts_kernel(const float* __restrict__ prot, const uint8_t* __restrict__ keep,
                                                             float thr, float* __restrict__ merged, int32_t* __restrict__ ngroups,
                                                             int32_t* __restrict__ flag, int P, int C, int slots) {
@@ -573,9 +573,15 @@ __global__ __launch_bounds__(MG_NT) void merge_parts_kernel(const float* __restr
     if (j < i) continue;                                      // wave-uniform
     const float* a = mg_u + i * pitch;
     const float* b = mg_u + j * pitch;
-    float d = 0.0f;
-    for (int c = lane; c < C; c += 64) d = fmaf(a[c], b[c], d);
-    d = wave_sum(d);
+    float d0 = 0.0f, d1 = 0.0f, d2 = 0.0f, d3 = 0.0f;         // four reads in flight per operand (one LDS round trip per
+    int c = lane;                                             // 4 terms instead of per term)
+    for (; c + 192 < C; c += 256) {
+      const float a0 = a[c], a1 = a[c + 64], a2 = a[c + 128], a3 = a[c + 192];
+      const float b0 = b[c], b1 = b[c + 64], b2 = b[c + 128], b3 = b[c + 192];
+      d0 = fmaf(a0, b0, d0); d1 = fmaf(a1, b1, d1); d2 = fmaf(a2, b2, d2); d3 = fmaf(a3, b3, d3);
+    }
+    for (; c < C; c += 64) d0 = fmaf(a[c], b[c], d0);
+    const float d = wave_sum((d0 + d1) + (d2 + d3));
     if (lane == 0 && d >= thr) atomicOr(&link_s[i], 1u << j);
   }
   __syncthreads();

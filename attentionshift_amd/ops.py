@@ -105,6 +105,27 @@ def npad(n):
 # ------------------------------------------------------------------------------------------------
 # Part A
 # ------------------------------------------------------------------------------------------------
+_SK_BYTES = {}
+_SK_WS = {}
+
+
+def _sk_bytes(lib, M, Nout, K):
+    key = (M, Nout, K)
+    v = _SK_BYTES.get(key)
+    if v is None:
+        v = _SK_BYTES[key] = int(lib.as_linear_sk_workspace_bytes(M, Nout, K))
+    return v
+
+
+def _sk_workspace(device, nbytes):
+    """One stream-K workspace per (device, stream): calls on a stream are ordered, so consecutive GEMMs share it."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    ws = _SK_WS.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = _SK_WS[key] = torch.empty(nbytes, device=device, dtype=torch.uint8)
+    return ws
+
+
 def linear(x, weight, bias=None, act="none"):
     """act(x @ weight.T + bias); x [..., K] in fp32/bf16, bias fp32."""
     lib = _lib.load()
@@ -116,9 +137,16 @@ def linear(x, weight, bias=None, act="none"):
     if weight.dtype != x.dtype or weight.shape[1] != K:
         raise AttnShiftError("linear: weight must be [Nout, K] in the dtype of x")
     out = torch.empty(x2.shape[0], weight.shape[0], device=x.device, dtype=x.dtype)
-    _lib.check(lib.as_linear_fwd(_p(x2), _p(weight), _p(bias), _p(out), x2.shape[0], weight.shape[0], K, _dt(x),
-                                 {"none": 0, "gelu": 1, "relu": 4}[act], _stream()), "as_linear_fwd")
-    return out.reshape(*x.shape[:-1], weight.shape[0])
+    code = {"none": 0, "gelu": 1, "relu": 4}[act]
+    M, Nout = x2.shape[0], weight.shape[0]
+    need = _sk_bytes(lib, M, Nout, K) if x.dtype == torch.bfloat16 else 0
+    if need:                                               # stream-K schedule (as_linear_sk_fwd) with its fp32 partial tiles
+        ws = _sk_workspace(x.device, need)
+        _lib.check(lib.as_linear_sk_fwd(_p(x2), _p(weight), _p(bias), _p(out), M, Nout, K, _dt(x), code, _p(ws), ws.numel(),
+                                        _stream()), "as_linear_sk_fwd")
+    else:
+        _lib.check(lib.as_linear_fwd(_p(x2), _p(weight), _p(bias), _p(out), M, Nout, K, _dt(x), code, _stream()), "as_linear_fwd")
+    return out.reshape(*x.shape[:-1], Nout)
 
 
 def linear_gelu(x, weight, bias=None):

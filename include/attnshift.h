@@ -61,6 +61,17 @@ int as_npad(int N);
 int as_linear_fwd(const void* x, const void* W, const float* bias, void* out, int M, int Nout, int K,
                   int dtype, int act, as_stream_t stream);
 
+/* as_linear_fwd with a stream-K schedule for shapes whose tile count leaves the last round of the plain grid mostly empty
+ * (ViT-B at 2 x 4197 tokens: fc1 = 396 tiles of 256 x 256 on 256 CUs, fc2 = 198 of 256 x 128): every workgroup contracts
+ * the same number of K steps of the flattened (tile, K step) space; a tile cut into pieces is finished by its last-arriving
+ * piece from fp32 partials in `ws` (fixed summation order: bitwise reproducible).  as_linear_sk_workspace_bytes returns 0
+ * when the plain grid is the better schedule for (M, Nout, K) -- the call then IS as_linear_fwd and ws may be NULL.  bf16.
+ * Round-5 measurement: with the fence-based hand-off it is SLOWER than the plain grid on every ViT-B / ViT-L shape (fc1
+ * 60 -> 150 us), so the query returns 0 unless AS_GEMM_SK=1 is set in the environment (csrc/gemm.hip sk_plan). */
+size_t as_linear_sk_workspace_bytes(int M, int Nout, int K);
+int as_linear_sk_fwd(const void* x, const void* W, const float* bias, void* out, int M, int Nout, int K, int dtype, int act,
+                     void* ws, size_t ws_bytes, as_stream_t stream);
+
 /* nn.ConvTranspose2d(cin, cout, kernel 2, stride 2) on a channels-last map as one GEMM over its pixels
  * (mmdet/models/backbones/visual_transformer_det.py:107-117, the FPN taps): x [M = B*h*w, cin] (pixel-major, grid w wide),
  * W4 [4*cout, cin] with row (di*2 + dj)*cout + co = weight[ci, co, di, dj], bias4 [4*cout] fp32 or NULL ->

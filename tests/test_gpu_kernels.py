@@ -72,6 +72,54 @@ def test_linear_bf16_backbone_shapes(ops, M, N, K, act):
     assert mx < 1e-2 and mean < 2e-3, (mx, mean)      # output rounding to bf16 dominates
 
 
+@pytest.mark.parametrize("M,N,K", [(8394, 3072, 768), (8394, 768, 3072), (8394, 768, 768), (8192, 768, 768), (6501, 4096, 1024),
+                                   (6501, 1024, 4096), (5000, 1000, 1536), (8394, 3080, 768)])
+@pytest.mark.parametrize("act", ["none", "gelu"])
+def test_linear_stream_k_matches_the_plain_grid_and_fp32(ops, monkeypatch, M, N, K, act):
+    """as_linear_sk_fwd (every workgroup the same number of K steps, tiles finished by their last-arriving piece) against
+    fp32 F.linear on the same bf16 operands, against as_linear_fwd (one bf16 rounding apart at most: the pieces are summed in
+    fp32 before the single rounding), bitwise reproducible call after call, and unaffected by what the previous call -- other
+    operands, another shape -- left in the shared workspace."""
+    lib = ops._lib.load()
+    assert lib.as_linear_sk_workspace_bytes(M, N, K) == 0, "the schedule is off by default (measured slower, csrc/gemm.hip sk_plan)"
+    monkeypatch.setenv("AS_GEMM_SK", "1")
+    nb = lib.as_linear_sk_workspace_bytes(M, N, K)
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g).bfloat16()
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).bfloat16()
+    b = torch.randn(N, generator=g)
+    ref = torch.nn.functional.linear(x.float(), w.float(), b)
+    if act == "gelu":
+        ref = torch.nn.functional.gelu(ref)
+    xd, wd, bd = dev(x), dev(w), dev(b)
+    code = 1 if act == "gelu" else 0
+    st = torch.cuda.current_stream().cuda_stream
+    ws = torch.full((max(nb, 16),), 0xAB, dtype=torch.uint8).cuda()                 # garbage in the partial tiles
+    plain = torch.empty(M, N, dtype=torch.bfloat16).cuda()
+    assert lib.as_linear_fwd(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), plain.data_ptr(), M, N, K, 1, code, st) == 0
+    outs = []
+    for _ in range(3):
+        o = torch.empty(M, N, dtype=torch.bfloat16).cuda()
+        assert lib.as_linear_sk_fwd(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), o.data_ptr(), M, N, K, 1, code, ws.data_ptr(),
+                                    ws.numel(), st) == 0
+        outs.append(o)
+    mx, mean = rel_to_range(ref, outs[0].float())
+    assert mx < 1e-2 and mean < 2e-3, (mx, mean, nb)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), "stream-K must be bitwise reproducible"
+    rng = float(plain.float().abs().max())
+    assert float((outs[0].float() - plain.float()).abs().max()) <= 8e-3 * rng      # one bf16 ulp of the largest values
+    # different operands through the SAME workspace, then the first operands again
+    x2 = dev((torch.randn(M, K, generator=g) * 2).bfloat16())
+    o2 = torch.empty(M, N, dtype=torch.bfloat16).cuda()
+    assert lib.as_linear_sk_fwd(x2.data_ptr(), wd.data_ptr(), bd.data_ptr(), o2.data_ptr(), M, N, K, 1, code, ws.data_ptr(),
+                                ws.numel(), st) == 0
+    o3 = torch.empty(M, N, dtype=torch.bfloat16).cuda()
+    assert lib.as_linear_sk_fwd(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), o3.data_ptr(), M, N, K, 1, code, ws.data_ptr(),
+                                ws.numel(), st) == 0
+    assert torch.equal(o3, outs[0])
+    print(f"[stream-K] {M}x{N}x{K}: workspace {nb} bytes ({'stream-K' if nb else 'plain grid'})")
+
+
 @pytest.mark.parametrize("M,N,K", [(768, 768, 8448), (2304, 768, 8448), (3072, 768, 8448), (200, 132, 96), (130, 64, 4096)])
 @pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float32])
 def test_linear_splitk_matches_fp32_matmul(ops, M, N, K, out_dtype):

@@ -48,6 +48,15 @@ def run_one(name, shapes, act):
             x.zero_(); w.zero_()
         out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
         call = lambda: lib.as_linear_fwd(x.data_ptr(), w.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, K, 1, act, st)
+        if os.environ.get("GEMM_SK"):                         # the stream-K entry point (falls back to the plain grid by itself)
+            lib.as_linear_sk_workspace_bytes.restype = ctypes.c_size_t
+            lib.as_linear_sk_workspace_bytes.argtypes = [ctypes.c_int] * 3
+            lib.as_linear_sk_fwd.restype = ctypes.c_int
+            lib.as_linear_sk_fwd.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] * 5 + [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+            nb = lib.as_linear_sk_workspace_bytes(M, N, K)
+            wsb = torch.empty(max(nb, 16), device="cuda", dtype=torch.uint8)
+            call = lambda: lib.as_linear_sk_fwd(x.data_ptr(), w.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, K, 1, act,
+                                                wsb.data_ptr(), wsb.numel(), st)
         for _ in range(5):
             assert call() == 0
         torch.cuda.synchronize()
@@ -73,7 +82,7 @@ def run_one(name, shapes, act):
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 50
-        print(json.dumps(dict(variant=name + "@" + os.environ.get("AS_GEMM_TILE", "auto") + "+" + os.environ.get("AS_GEMM_STAGGER", "0"), M=M, N=N, K=K,
+        print(json.dumps(dict(variant=name + "@" + os.environ.get("AS_GEMM_TILE", "auto") + "+" + os.environ.get("AS_GEMM_STAGGER", "0") + ("/sk" if os.environ.get("GEMM_SK") else ""), M=M, N=N, K=K,
                               us=round(ms * 1e3, 1), tflops=round(2.0 * M * N * K / ms / 1e9), err=round(err, 5), lib_tflops=lib_tf)), flush=True)
         assert err < 2e-2, err
 
