@@ -97,9 +97,15 @@ class MlpFn(torch.autograd.Function):
         dy2 = dy.reshape(-1, dy.shape[-1])
         dy2 = (dy2 if dy2.dtype == torch.bfloat16 else dy2.to(torch.bfloat16)).contiguous()
         need = ctx.needs_input_grad
-        dpre, dw2, db2 = ops.linear_bwd(a, w2b, dy2, True, need[3], b2_dtype is not None and need[4], dw_dtype=w2_dtype,
-                                        gelu_pre=pre)
-        dx, dw1, db1 = ops.linear_bwd(x2, w1b, dpre, need[0], need[1], b1_dtype is not None and need[2], dw_dtype=w1_dtype)
+        need_b1, need_b2 = b1_dtype is not None and need[2], b2_dtype is not None and need[4]
+        first = need[0] or need[1] or need_b1               # does anything upstream of fc2's input want a gradient?
+        if not (first or need[3] or need_b2):
+            return None, None, None, None, None
+        # (a frozen fc1 under a frozen input -- head-only fine-tuning -- needs neither d(pre) nor the second call)
+        dpre, dw2, db2 = ops.linear_bwd(a, w2b, dy2, first, need[3], need_b2, dw_dtype=w2_dtype, gelu_pre=pre if first else None)
+        dx = dw1 = db1 = None
+        if first:
+            dx, dw1, db1 = ops.linear_bwd(x2, w1b, dpre, need[0], need[1], need_b1, dw_dtype=w1_dtype)
         return (None if dx is None else dx.view(shape), dw1, None if db1 is None else db1.to(b1_dtype), dw2,
                 None if db2 is None else db2.to(b2_dtype))
 

@@ -79,6 +79,19 @@ struct AsSide {
     st = sl.st; fork = sl.fork; join = sl.join; mid = sl.mid;
     ok = true;
   }
+  // thread exit (the instances are thread_local): give the streams and events back.  Errors are ignored -- at process exit
+  // the HIP runtime may already be gone.
+  ~AsSide() {
+    for (Slot& sl : slots) {
+      if (sl.state != 1) continue;
+      (void)hipEventDestroy(sl.mid);
+      (void)hipEventDestroy(sl.join);
+      (void)hipEventDestroy(sl.fork);
+      (void)hipStreamDestroy(sl.st);
+      sl = Slot();
+    }
+    (void)hipGetLastError();
+  }
 };
 static inline bool as_side_serial() {
   static const bool serial = getenv("AS_BWD_SERIAL") != nullptr;

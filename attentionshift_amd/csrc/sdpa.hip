@@ -1434,21 +1434,50 @@ int launch_sdpa_glds(const void* q, const void* k, const void* vt, void* o, floa
   // The split q-tile runs CONCURRENTLY with the main grid on a helper stream (fork / join with events on the caller's
   // stream): its 264 short workgroups fill the slots the main grid's workgroups free up as they retire, instead of
   // running as a separate 13 us phase afterwards.  Helper stream and events are created once per host thread.
-  struct Side {
+  struct Side {                                          // one set PER DEVICE (as AsSide in common.h): a thread that alternates
+    enum { kMaxDev = 16 };                               // between devices reuses each device's set instead of leaking one per
+    struct Slot {                                        // switch; a set whose creation fails half-way is destroyed and stays off
+      hipStream_t st = nullptr, st2 = nullptr;
+      hipEvent_t fork = nullptr, join = nullptr, join2 = nullptr;
+      int state = 0;                                     // 0 = not tried, 1 = ready, -1 = failed
+    };
+    Slot slots[kMaxDev];
     hipStream_t st = nullptr, st2 = nullptr;
     hipEvent_t fork = nullptr, join = nullptr, join2 = nullptr;
     bool ok = false;
-    int dev = -1;
-    void init() {                                        // (re)created when this thread first uses a device
+    static void drop(Slot& sl) {
+      if (sl.join2) (void)hipEventDestroy(sl.join2);
+      if (sl.join) (void)hipEventDestroy(sl.join);
+      if (sl.fork) (void)hipEventDestroy(sl.fork);
+      if (sl.st2) (void)hipStreamDestroy(sl.st2);
+      if (sl.st) (void)hipStreamDestroy(sl.st);
+      sl = Slot();
+    }
+    void init() {
       int d = -1;
-      if (hipGetDevice(&d) != hipSuccess) { ok = false; return; }
-      if (d == dev) return;
-      dev = d;
-      ok = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess &&
-           hipStreamCreateWithFlags(&st2, hipStreamNonBlocking) == hipSuccess &&
-           hipEventCreateWithFlags(&fork, hipEventDisableTiming) == hipSuccess &&
-           hipEventCreateWithFlags(&join, hipEventDisableTiming) == hipSuccess &&
-           hipEventCreateWithFlags(&join2, hipEventDisableTiming) == hipSuccess;
+      ok = false;
+      if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= kMaxDev) return;
+      Slot& sl = slots[d];
+      if (sl.state == 0) {
+        const bool made = hipStreamCreateWithFlags(&sl.st, hipStreamNonBlocking) == hipSuccess &&
+                          hipStreamCreateWithFlags(&sl.st2, hipStreamNonBlocking) == hipSuccess &&
+                          hipEventCreateWithFlags(&sl.fork, hipEventDisableTiming) == hipSuccess &&
+                          hipEventCreateWithFlags(&sl.join, hipEventDisableTiming) == hipSuccess &&
+                          hipEventCreateWithFlags(&sl.join2, hipEventDisableTiming) == hipSuccess;
+        if (!made) {
+          drop(sl);
+          (void)hipGetLastError();                       // the launch falls back to the caller's stream: not its error
+        }
+        sl.state = made ? 1 : -1;
+      }
+      if (sl.state != 1) return;
+      st = sl.st; st2 = sl.st2; fork = sl.fork; join = sl.join; join2 = sl.join2;
+      ok = true;
+    }
+    ~Side() {                                            // thread exit
+      for (Slot& sl : slots)
+        if (sl.state == 1) drop(sl);
+      (void)hipGetLastError();
     }
   };
   static thread_local Side side;

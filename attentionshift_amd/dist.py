@@ -161,9 +161,14 @@ class GradAllReducer:
     (`Ranks(force=True)` / AS_FORCE_DIST=1), which runs the identical bucket / hook / RCCL / write-back path on one GPU.
     Without a group everything is a no-op."""
 
-    def __init__(self, params, ranks, bucket_mb=64, comm_dtype=torch.float32, buffers=None, broadcast=True):
+    def __init__(self, params, ranks, bucket_mb=64, comm_dtype=torch.float32, buffers=None, broadcast=True,
+                 find_unused_parameters=False):
         self.ranks = ranks
         self.comm_dtype = comm_dtype
+        # A parameter that received no gradient on ANY rank keeps p.grad = None after finish() (torch DDP leaves such
+        # gradients undefined, so weight decay / momentum skip the parameter) -- known locally in a one-rank group; with
+        # more ranks it takes one extra small all-reduce per step, so it is opt-in there (off: zeros, as before)
+        self.find_unused_parameters = find_unused_parameters
         self.params = [p for p in params if p.requires_grad]
         self.buckets = []
         self._where = {}
@@ -261,6 +266,16 @@ class GradAllReducer:
         bucket, both are fine.  16-bit wire: one multi-tensor conversion per bucket."""
         if not self.active:
             return
+        unused = set()
+        missing = [i for i, p in enumerate(self.params) if p.grad is None]
+        if self.ranks.world == 1:
+            unused = {id(self.params[i]) for i in missing}
+        elif self.find_unused_parameters:
+            used = torch.ones(len(self.params), dtype=torch.float32)
+            used[missing] = 0.0
+            used = used.to(self.params[0].device)
+            self.ranks.dist.all_reduce(used, op=self.ranks.dist.ReduceOp.MAX)
+            unused = {id(p) for p, u in zip(self.params, used.tolist()) if u == 0.0}
         for b in self.buckets[self._next:]:   # buckets with a parameter that got no gradient: zeros for it, in order
             have = [(p, off) for p, off in b["items"] if p.grad is not None]   # incl. grads accumulated under no_sync()
             for (p, _), v in zip(b["items"], b["views"]):
@@ -275,15 +290,17 @@ class GradAllReducer:
                 if self._inv != 1.0:
                     b["flat"].mul_(self._inv)
                 for (p, _), v in zip(b["items"], views):
-                    p.grad = v
+                    p.grad = None if id(p) in unused else v
             else:
                 post = 1.0 if self._prescale else self._inv
-                missing = [p for p, _ in b["items"] if p.grad is None]
-                for p in missing:
-                    p.grad = torch.empty_like(p)
-                torch._foreach_copy_([p.grad for p, _ in b["items"]], views)
-                if post != 1.0:
-                    torch._foreach_mul_([p.grad for p, _ in b["items"]], post)
+                live = [(p, v) for (p, _), v in zip(b["items"], views) if id(p) not in unused]
+                for p, _ in live:
+                    if p.grad is None:
+                        p.grad = torch.empty_like(p)
+                if live:
+                    torch._foreach_copy_([p.grad for p, _ in live], [v for _, v in live])
+                    if post != 1.0:
+                        torch._foreach_mul_([p.grad for p, _ in live], post)
             b["seen"], b["work"] = set(), None
         self._next = 0
 

@@ -1287,6 +1287,12 @@ class AttnShiftRoIHead(nn.Module):
         try:
             return self._seed_pseudo_gt(*args, **kw)
         except _HostDrawsNeeded:
+            # the abandoned attempt may still have work queued on the per-image streams (the exception left the closing
+            # join out): order the redo -- and the release of the attempt's tensors -- behind it
+            if torch.cuda.is_available():
+                cur = torch.cuda.current_stream()
+                for st in self._streams:
+                    cur.wait_stream(st)
             self.rng_stats["host_redos"] += 1
             if self.capture is not None:
                 del self.capture[ncap:]                     # what the abandoned attempt recorded
