@@ -275,6 +275,12 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const T* __restrict__ A, const
 #define AS_GEMM_ABLATE 0                     // timing ablations (tools/experiments/gemm_ablate.py); results are wrong when != 0
 #endif
 constexpr int GK = 32;                       // K step (elements)
+#ifndef AS_GEMM_VT_STAGED
+#define AS_GEMM_VT_STAGED 0                  // QKV epilogue: 1 = V^T tiles transposed through LDS and stored 16 bytes at a time.  Measured
+                                             // round 5 (as_qkv_fwd, config 2, same box, bitwise equal): 56.0-60.8 us against 53.9-57.5 us
+                                             // for the two-byte stores straight from the accumulators (0): the stores are fire-and-forget,
+                                             // the staging adds two barriers and 64 ds_write_b16 per lane -- kept for the record
+#endif
 #ifndef AS_GEMM_K32_STAGES
 #define AS_GEMM_K32_STAGES 3                 // ring depth of the K-step-32 tiles: 2 K steps in flight + 1 consumed
 #endif
@@ -593,6 +599,51 @@ __global__ __launch_bounds__(64 * WM * WN, (WN == 4 || KS == 4) ? 1 : (WM == 2 &
   const bool vtile = EM == 1 && n0 >= 2 * epi.D;     // block-uniform: the whole 128-column tile is V
   if (vtile) {
     if (AS_GEMM_ABLATE == 5) return;
+    // V^T [B,h,64,Npad]: rows = features, tokens contiguous.  A tile whose tokens all belong to ONE image is transposed
+    // through LDS -- [feature][token + shift] with shift = (first token's index in its image) % 8, so that the 16-byte chunks
+    // of the image row and of the LDS row coincide -- and leaves as 16-byte stores along the tokens (8 store instructions per
+    // thread instead of 64 two-byte ones).  A tile that straddles two images (one per image boundary) takes the direct path.
+    constexpr int VT_PITCH = (BM + 8) * 2 + 16;          // bytes per staged feature row (odd multiple of 16: no bank pile-up)
+    const int b_first = m0 / epi.N, last_row = min(m0 + BM, M) - 1;
+    if (BN * VT_PITCH <= GT::LDS && last_row / epi.N == b_first && (AS_GEMM_VT_STAGED != 0)) {
+      const int n_first = m0 - b_first * epi.N, shift = n_first & 7;
+      __syncthreads();                                   // every wave is done with the ring
+#pragma unroll
+      for (int i = 0; i < RI; ++i) {
+        const int tl = wm * (32 * RI) + i * 32 + li + shift;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const int fb_ = wn * (32 * NJ) + j * 32;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int f_ = fb_ + acc_row(r, half);
+            const float bv = (bias != nullptr && n0 + f_ < Nout) ? bias[n0 + f_] : 0.0f;
+            *reinterpret_cast<__bf16*>(smem + f_ * VT_PITCH + tl * 2) = (__bf16)(acc[i][j][r] + bv);
+          }
+        }
+      }
+      __syncthreads();
+      constexpr int NCH = BM / 8 + 1;                    // 16-byte chunks per staged row (the shifted tile spans one more)
+      __bf16* const vt_b = reinterpret_cast<__bf16*>(epi.vt);
+      const int n_al = n_first - shift;                  // image-local token of staged column 0 (a multiple of 8)
+      const int t_hi = last_row - m0;                    // last valid token of the tile
+      for (int idx = tid; idx < BN * NCH; idx += NT) {
+        const int f_ = idx / NCH, c = idx - f_ * NCH;
+        const int col = n0 + f_;
+        if (col >= Nout) continue;
+        const int head = (col % epi.D) / 64, dd = col % 64;
+        __bf16* dst = vt_b + ((size_t)(b_first * epi.h + head) * 64 + dd) * epi.Npad + n_al + 8 * c;
+        const int t0 = 8 * c - shift;                    // tile-local token of the chunk's first element
+        const char* src = smem + f_ * VT_PITCH + 16 * c;
+        if (t0 >= 0 && t0 + 7 <= t_hi) {
+          *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(src);
+        } else {
+          for (int e_ = 0; e_ < 8; ++e_)
+            if (t0 + e_ >= 0 && t0 + e_ <= t_hi) dst[e_] = reinterpret_cast<const __bf16*>(src)[e_];
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < RI; ++i) {
       const int row = m0 + wm * (32 * RI) + i * 32 + li;

@@ -220,8 +220,12 @@ def test_linear_bf16(ops):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_qkv_layout(ops, dtype):
-    B, N, h = 2, 150, 3
+@pytest.mark.parametrize("B,N", [(2, 150), (3, 421), (2, 4197), (1, 517)])
+def test_qkv_layout(ops, dtype, B, N):
+    """q / k / V^T workspaces of as_qkv_fwd.  The bf16 V^T tiles are transposed through LDS with the staging columns shifted by
+    (first token's index in its image) % 8: images of 421 / 4197 tokens start at every residue, (2, 150) and (3, 421) have
+    tiles that straddle an image boundary (direct path), and the padded columns [N, Npad) must stay untouched."""
+    h = 3
     D = 64 * h
     g = torch.Generator().manual_seed(2)
     x = torch.randn(B, N, D, generator=g).to(dtype)
@@ -230,6 +234,14 @@ def test_qkv_layout(ops, dtype):
     ref = torch.nn.functional.linear(x.float(), w.float(), b).reshape(B, N, 3, h, 64).permute(2, 0, 3, 1, 4)
     q, k, vt = ops.qkv_fwd(dev(x), dev(w), dev(b), h)
     tol = 1e-4 if dtype == torch.float32 else 2e-2
+    if dtype == torch.bfloat16:                            # a second call into poisoned workspaces: only [.., :N] is written
+        from attentionshift_amd import _lib
+        lib = _lib.load()
+        q2, k2, vt2 = (torch.full_like(t_, 7.0) for t_ in (q, k, vt))
+        xd, wd, bd = dev(x), dev(w), dev(b)
+        assert lib.as_qkv_fwd(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), q2.data_ptr(), k2.data_ptr(), vt2.data_ptr(), B, N, D, h,
+                              1, torch.cuda.current_stream().cuda_stream) == 0
+        assert torch.equal(vt2[:, :, :, :N], vt[:, :, :, :N]) and (vt2[:, :, :, N:] == 7.0).all(), "V^T: stray or missing writes"
     # q is stored pre-scaled by log2(e) / 8 (one rounding, from the fp32 accumulator)
     assert_close(ref[0] * ops.QSCALE, ops.q_from_fragment_major(q)[:, :, :N].float(), tol, tol, "q (fragment-major, pre-scaled)")
     assert_close(ref[1], k[:, :, :N].float(), tol, tol, "k")
