@@ -435,8 +435,12 @@ __global__ void draw_distinct_kernel(const int32_t* __restrict__ counts /*[G,2] 
   const int n_pos = counts[g * 2 + 0], n = n_pos + counts[g * 2 + 1];
   int got = 0;
   int picked[32];
+  // the first 32 draws in one batch of independent loads (the scan below would otherwise pay one memory round trip per draw)
+  float ub[32];
+#pragma unroll
+  for (int j = 0; j < 32; ++j) ub[j] = u[g * M + min(j, M - 1)];
   for (int j = 0; j < M && got < K; ++j) {
-    int c = (int)(u[g * M + j] * (float)n);
+    int c = (int)((j < 32 ? ub[j] : u[g * M + j]) * (float)n);
     c = min(c, max(n - 1, 0));
     bool dup = false;
     for (int q = 0; q < got; ++q) dup = dup || picked[q] == c;

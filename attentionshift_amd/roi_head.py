@@ -794,6 +794,10 @@ class AttnShiftRoIHead(nn.Module):
         #                                           device generator, reference mode from torch's own engine (csrc/mt19937.hip)
         self.rng_stats = dict(device_calls=0, host_redos=0)   # reference mode: calls drawn on the device / repeated on the host
         self.part_slots = 8                       # merged-part slots per object carried by the one-readback merge stage
+        # sync-free path: the batched mean shift waits for the images' grid seeds only, so each image's mask-point / pseudo-mask
+        # kernels (queued behind the seeds on the image's stream) run under it.  False: wait for the whole image streams
+        # (bench.py times the affinity kernels alone that way)
+        self.overlap_mask_work = True
         self._dev_gens = {}
         self._pool, self._streams = None, []
         # parity tests set this to a list: every image's sampled refinement points and grid seeds are appended to it
@@ -1421,22 +1425,26 @@ class AttnShiftRoIHead(nn.Module):
                 draw_gen=None if mt_state is not None else self._device_gen(boxes.device), flags_out=flags,
                 last_level_only=True, mt_state=mt_state, flag_slot=None if flag_slots is None else flag_slots[i, 0:1],
                 box_patch=bp)
+            # what the batched mean shift (caller's stream) waits for comes FIRST -- the patch-grid foreground and the grid seeds
+            # -- and is marked with an event; the mask candidates, mask points and the pseudo-mask copy (B2', B6: ~130 us of
+            # launches nothing in the semantic chain reads) are queued behind it and run under the mean shift
+            fg_inter, _map_fg_patch, gs = self._semantic_pre(map_fg[-1], map_bg[-1], pos_mask_thr, float_map=False)
+            seeds, f2 = grid_seed_nosync(gs[0], gs[1], 20, flag=None if flag_slots is None else flag_slots[i, 1:2],
+                                         patch=None if seed_ids is None else (seed_ids[obj_off[i]:obj_off[i] + counts[i]],
+                                                                              i * _token_row_stride(feat_tok)))
+            seeds_ready = torch.cuda.current_stream().record_event() if boxes.is_cuda else None
             mp, mask_u8 = mask_points_and_pseudo_issue(map_fg[-1], map_bg[-1], pseudo_boxes[i], pos_mask_thr, neg_mask_thr,
                                                        corr_size, pos_mask_thr)
-            fg_inter, _map_fg_patch, gs = self._semantic_pre(map_fg[-1], map_bg[-1], pos_mask_thr, float_map=False)
             pm = _to_host_issue(mask_u8, side_stream=True)
             if mt_state is not None:
                 coord_point, labels_point, f1 = mask_points_mt(mp, num_mask_point_gt, mt_state)
             else:
                 coord_point, labels_point, f1 = mask_points_nosync(mp, num_mask_point_gt, self._device_gen(boxes.device),
                                                                    int_flag=flag_slots is not None)
-            seeds, f2 = grid_seed_nosync(gs[0], gs[1], 20, flag=None if flag_slots is None else flag_slots[i, 1:2],
-                                         patch=None if seed_ids is None else (seed_ids[obj_off[i]:obj_off[i] + counts[i]],
-                                                                              i * _token_row_stride(feat_tok)))
             if self.capture is not None:
                 self.capture.append(dict(image=i, seeds=seeds, fg_inter=fg_inter))
             flags += [f1, f2]
-            return coord_point, labels_point, map_fg, map_bg, feats_fg, feats_bg, (fg_inter, seeds), pm, flags, bp
+            return coord_point, labels_point, map_fg, map_bg, feats_fg, feats_bg, (fg_inter, seeds), pm, flags, bp, seeds_ready
 
         nosync = (self.rng_mode == "fast" and self.device_draws and not self.parallel_images and self.image_streams
                   and self.batch_mean_shift and torch.cuda.is_available() and not CLOCK.on and not self.visualize)
@@ -1482,8 +1490,12 @@ class AttnShiftRoIHead(nn.Module):
                 for st in self._streams[:num_imgs]:
                     st.wait_stream(main)
                 ra = [on_stream(i, phase_a_nosync, None, flag_slots) for i in range(num_imgs)]
-                for st in self._streams[:num_imgs]:
-                    main.wait_stream(st)
+                if self.overlap_mask_work:
+                    for r in ra:                                 # the seeds only: the mask-point work behind them keeps running
+                        main.wait_event(r[10])
+                else:                                            # (measurement switch: the mean shift alone on the device)
+                    for st in self._streams[:num_imgs]:
+                        main.wait_stream(st)
             shifted = self.mean_shift_batch([r[6][1] for r in ra], feats, pseudo_boxes, self.mean_shift_times_local,
                                             feat_tok=feat_tok, box_patch_list=[r[9] for r in ra], seed_ids=seed_ids,
                                             clamp=False)       # (the only consumer thresholds the maps at 0.8: no clamp(0))

@@ -489,6 +489,19 @@ def main():
             torch.cuda.synchronize()
         block_timing = ops.collect_timing()
         ops.disable_timing()
+        # the affinity call ALONE on the device: in the timed region it shares the chip with the per-image mask-point kernels
+        # (AttnShiftRoIHead.overlap_mask_work), which is faster for the step and slower for the call
+        if getattr(step, "head", None) is not None and hasattr(step.head, "overlap_mask_work"):
+            with torch.no_grad():
+                step.head.overlap_mask_work = False
+                step()
+                ops.enable_timing(["cosine_shift"])
+                for _ in range(5):
+                    step()
+                torch.cuda.synchronize()
+                step.head.overlap_mask_work = True
+            block_timing["cosine_shift_alone"] = ops.collect_timing().get("cosine_shift")
+            ops.disable_timing()
     B = CFG["batch"]
     rec = {
         "metric": "images/sec (1024^2, ViT-B) hot path: backbone attention fwd + attention-shift pseudo-labels",
@@ -542,7 +555,7 @@ def main():
                       "'launch' = the whole call",
             "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ach / PEAK_BF16_TFLOPS, 4),
-            "traffic": _static_traffic(("r04_sdpa_traffic.json", "r03_sdpa_traffic.json"), "per_as_sdpa_fwd_call_bytes") if headline else None,
+            "traffic": _static_traffic(("r05_sdpa_traffic.json", "r04_sdpa_traffic.json", "r03_sdpa_traffic.json"), "per_as_sdpa_fwd_call_bytes") if headline else None,
             "launches_timed": n_sdpa, "ms_per_launch": round(ms_sdpa, 4), "flops_per_launch": flops_sdpa}
         if all(k in block_timing for k in ("qkv_gemm", "sdpa_fwd", "proj_gemm")):
             D_ = CFG["embed_dim"]
@@ -579,9 +592,19 @@ def main():
             "kernel": "as_cosine_shift (per iteration: similarity / assign / aggregate launches; packed final similarity)",
             "bound": "hbm", "achieved": round(gbps, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
             "frac": round(gbps / PEAK_HBM_GBPS, 4),
-            "traffic": _static_traffic(("r04_shift_traffic.json", "r03_shift_traffic.json"), "per_call_bytes") if headline and imgs_per_call == 2 else None,
+            "traffic": _static_traffic(("r05_shift_traffic.json", "r04_shift_traffic.json", "r03_shift_traffic.json"), "per_call_bytes") if headline and imgs_per_call == 2 else None,
             "calls_timed": n_cs, "images_per_call": imgs_per_call, "ms_per_call": round(ms_cs, 4),
-            "algorithmic_bytes_per_call": bytes_cs}
+            "algorithmic_bytes_per_call": bytes_cs,
+            "timeline": "profiles/r05_shift_timeline.md (s_memrealtime stamps inside the three iteration kernels: where each "
+                        "launch's 8-12 us go)"}
+        alone = block_timing.get("cosine_shift_alone")
+        if alone:
+            # `ms_per_call` above is measured in the timed region, where the call overlaps the images' mask-point kernels;
+            # this is the same call with the device to itself (5 extra steps after the timed region)
+            rec["roofline_affinity"].update(
+                ms_per_call_alone=round(alone[1], 4), frac_alone=round(bytes_cs / (alone[1] * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4),
+                note="ms_per_call / frac: inside the timed region, sharing the device with the per-image mask-point kernels "
+                     "(a step-level overlap, round 5); ms_per_call_alone / frac_alone: the same call without that overlap")
         ra = rec["roofline_affinity"]
         if ra["traffic"] is not None:
             # the same call priced by the bytes the counters saw (the kernels skip out-of-box patches, which the SURVEY 8d
@@ -590,15 +613,16 @@ def main():
             ra["frac_counter_bytes"] = round(cb / (ms_cs * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4)
             ra["counter_over_algorithmic"] = round(cb / bytes_cs, 3)
         try:      # the dependent-chain floor of 16 launches of this grid size (tools/experiments/chain_floor.hip, this round)
-            with open(os.path.join(ROOT, "profiles", "r04_chain_floor.json")) as f:
+            cf_name = next(n for n in ("r05_chain_floor.json", "r04_chain_floor.json") if os.path.exists(os.path.join(ROOT, "profiles", n)))
+            with open(os.path.join(ROOT, "profiles", cf_name)) as f:
                 cf = json.load(f)
             ra["dependent_chain_floor"] = {
                 "us_16_launches_3_hops": cf["us_per_chain_by_hops"]["3"], "us_16_empty_launches": cf["us_per_chain_by_hops"]["0"],
-                "us_per_dependent_hop": cf["us_per_dependent_hop"], "source": "profiles/r04_chain_floor.json (micro-benchmark, chain queued behind a blocker so "
+                "us_per_dependent_hop": cf["us_per_dependent_hop"], "source": f"profiles/{cf_name} (micro-benchmark, chain queued behind a blocker so "
                 "the host's launch rate does not enter: 16 dependent launches of 126 workgroups, each thread walking 3 dependent "
                 "cache-resident loads) -- the launch boundaries explain ~1/6 of the call; the rest is the latency chains INSIDE "
                 "the 16 kernels (operands -> MFMA -> reductions, ~8-12 us each on a quarter-full chip)"}
-        except (OSError, KeyError, ValueError):
+        except (OSError, KeyError, ValueError, StopIteration):
             pass
         # the same step with the trainable MIL head choosing the roll-out depth from RoI-aligned features (stdroi:2308-2312)
         if os.environ.get("AS_BENCH_MIL", "1") == "1":
