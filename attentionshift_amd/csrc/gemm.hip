@@ -1025,6 +1025,7 @@ extern "C" int as_linear_splitk_fwd(const void* x, const void* W, void* out, int
 
 extern "C" int as_npad(int N) { return as_round_up(N, 64); }
 
+
 extern "C" int as_linear_fwd(const void* x, const void* W, const float* bias, void* out, int M, int Nout, int K,
                              int dtype, int act, as_stream_t stream) {
   AS_REQUIRE(x && W && out, AS_E_BADARG, "as_linear_fwd: null pointer");

@@ -25,7 +25,8 @@ NO_KERNEL = {"aten.view.default", "aten.reshape.default", "aten._unsafe_view.def
              "aten.empty_like.default", "aten.empty_strided.default", "aten.new_empty.default", "aten.unflatten.int",
              "aten.flatten.using_ints", "aten.narrow.default", "aten.view_as.default", "aten.chunk.default",
              "aten.lift_fresh.default", "aten.is_pinned.default", "aten.resize_.default", "aten.new_empty_strided.default",
-             "aten.sym_size.int", "aten.stride.int", "aten.numel.default", "aten.size.int"}
+             "aten.sym_size.int", "aten.stride.int", "aten.numel.default", "aten.size.int", "aten.view.dtype",
+             "aten.record_stream.default", "aten.as_strided.default"}
 
 
 class Sites(TorchDispatchMode):

@@ -26,5 +26,11 @@ PMC_TRAFFIC=1 PMC_TAG=${R}_sdpa bash tools/pmc_sdpa_impl.sh auto > gpurun_out/${
 cp gpurun_out/pmc_sdpa_${R}_sdpa.md gpurun_out/${R}_sdpa_pmc.md 2>/dev/null
 ( hipcc --offload-arch=gfx950 -O3 -o /tmp/chain_floor tools/experiments/chain_floor.hip > /dev/null 2>&1 && /tmp/chain_floor ) > gpurun_out/${R}_chain_floor.json 2>&1
 timeout 120 python tools/experiments/power_probe.py 2>&1 | grep kernel > gpurun_out/${R}_power_probe.jsonl
+# round 5: in-kernel timeline of the mean-shift kernels (instrumented build under tools/experiments/_build/), the glue census,
+# and -- when a round-4 tree has been unpacked into _r04/ (git archive b73500e | tar -x -C _r04; built there) -- the
+# same-box A/B of the headline leg against it
+timeout 200 python tools/experiments/shift_timeline.py run --md gpurun_out/${R}_shift_timeline.md > gpurun_out/${R}_shift_timeline.log 2>&1
+timeout 300 python tools/experiments/glue_sites.py --steps 3 --rows 200 > gpurun_out/${R}_glue_sites.log 2>&1
+[ -d _r04 ] && bash tools/experiments/r05_ab.sh > gpurun_out/${R}_ab_vs_r04.log 2>&1
 ls gpurun_out | grep ${R}_
 cat gpurun_out/${R}_bench_wall.txt
