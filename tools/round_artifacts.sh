@@ -9,7 +9,7 @@ mkdir -p gpurun_out
 t0=$(date +%s)
 timeout 600 python bench.py > gpurun_out/${R}_bench_final.json 2> gpurun_out/${R}_bench_final.log
 echo "default bench.py wall: $(( $(date +%s) - t0 )) s" | tee gpurun_out/${R}_bench_wall.txt
-AS_BENCH_OTHER_RNG=0 AS_BENCH_MIL=0 PROF_LINES=8 tools/prof_cmd.sh ${R}_bench_kernel_stats_final python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --train-steps 0 --other-configs "" > /dev/null 2>&1
+AS_BENCH_EVENTS=0 AS_BENCH_OTHER_RNG=0 AS_BENCH_MIL=0 PROF_LINES=8 tools/prof_cmd.sh ${R}_bench_kernel_stats_final python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --train-steps 0 --other-configs "" > /dev/null 2>&1
 timeout 300 python tools/kernel_bench.py --reps 20 > gpurun_out/${R}_kernel_bench.jsonl 2>&1
 bash tools/pmc_call_traffic.sh ${R}_shift_traffic > gpurun_out/${R}_shift_traffic.log 2>&1
 for k in shift_sim shift_assign shift_aggregate shift_final_sim; do
