@@ -95,7 +95,7 @@ class DeferredFPN:
     register file, so each small launch of the RoI head's chain waits for a GEMM workgroup to retire (7.43 -> 7.79 ms per
     step; with a fifth stream the four default hardware queues are over-subscribed and the two image chains serialise;
     with GPU_MAX_HW_QUEUES=8 the overlap is real and the step takes 8.4 ms -- also with 128 x 128 GEMM tiles that leave a
-    third of every register file free; a CU-masked stream is slower still).  It stays opt-in for callers whose head has
+    third of every register file free, and whatever the stream priorities; a CU-masked stream is slower still).  It stays opt-in for callers whose head has
     real work to hide it under."""
 
     def __init__(self, backbone, features, taps):
