@@ -275,6 +275,11 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const T* __restrict__ A, const
 #define AS_GEMM_ABLATE 0                     // timing ablations (tools/experiments/gemm_ablate.py); results are wrong when != 0
 #endif
 constexpr int GK = 32;                       // K step (elements)
+#ifndef AS_GEMM_EPI_PIPE
+#define AS_GEMM_EPI_PIPE 0                   // 1 = staged epilogue in RI slices: stage slice i, barrier, issue its stores, convert slice
+#endif                                       // i + 1 under them.  Measured round 5 (same box, us, 0 / 1): QKV-shaped 48.5-49.6 / 48.3-49.3,
+                                             // fc1 57.1-57.8 / 56.0-57.6, fc1 + GELU 67.5-68.5 / 67.6-67.7, fc2 50.2 / 48.7-50.0, as_qkv_fwd
+                                             // 53.6-56.9 / 54.2-58.7: no difference -- the stores were not what the epilogue waits for
 #ifndef AS_GEMM_VT_STAGED
 #define AS_GEMM_VT_STAGED 0                  // QKV epilogue: 1 = V^T tiles transposed through LDS and stored 16 bytes at a time.  Measured
                                              // round 5 (as_qkv_fwd, config 2, same box, bitwise equal): 56.0-60.8 us against 53.9-57.5 us
@@ -684,8 +689,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WN == 4 || KS == 4) ? 1 : (WM == 2 &
     for (int i = 0; i < RI; ++i) keep += acc[i][0][0] + acc[i][NJ - 1][15];
     if (keep == 12345.678f) smem[0] = 1;
   }
-#pragma unroll
-  for (int i = 0; i < (AS_GEMM_ABLATE == 8 ? 0 : RI); ++i) {
+  // stage(i): this wave's 32-row block i of the tile -> bias, scale / activation, bf16 -> its rows of the staging tile
+  auto stage_block = [&](const int i) {
     char* srow = smem + (wm * (32 * RI) + i * 32 + li) * G_EPI_PITCH;
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
@@ -711,19 +716,15 @@ __global__ __launch_bounds__(64 * WM * WN, (WN == 4 || KS == 4) ? 1 : (WM == 2 &
         bf16x4 pk = {(__bf16)v0, (__bf16)v1, (__bf16)v2, (__bf16)v3};
         *reinterpret_cast<bf16x4*>(srow + c0 * 2) = pk;
       }
-  }
-  __syncthreads();
-  if (AS_GEMM_ABLATE == 9) return;                   // timing experiment: staging only, no copy-out
-#pragma unroll
-  for (int t = 0; t < BM * (BN / 8) / NT; ++t) {
-    const int c = tid + t * NT;
-    const int rr = c / (BN / 8), ch = c % (BN / 8);   // BN / 8 chunks of 8 columns per row
+  };
+  // store_chunk(rr, ch): 16 bytes (8 columns) of staged row rr -> its place in the output layout
+  auto store_chunk = [&](const int rr, const int ch) {
     const int row = m0 + rr, col = n0 + ch * 8;
-    if (row >= M || col >= Nout) continue;
+    if (row >= M || col >= Nout) return;
     const uint4 v = *reinterpret_cast<const uint4*>(smem + rr * G_EPI_PITCH + ch * 16);
     if (AS_GEMM_ABLATE == 6) {                        // timing experiment: staged epilogue without its global stores
       if (v.x == 0x12345678u && v.w == 0x9abcdef0u) out[0] = (__bf16)1.0f;
-      continue;
+      return;
     }
     if (EM == 2) {
       // 2x2 / stride-2 transposed convolution: GEMM row = input pixel (b*h + i, j) of a grid epi.N wide, column =
@@ -753,6 +754,34 @@ __global__ __launch_bounds__(64 * WM * WN, (WN == 4 || KS == 4) ? 1 : (WM == 2 &
         *reinterpret_cast<uint4*>(reinterpret_cast<__bf16*>(epi.q) + qf_frag(bh, epi.Npad, n, d0 >> 4, (d0 >> 3) & 1)) = v;
       else
         *reinterpret_cast<uint4*>(reinterpret_cast<__bf16*>(epi.k) + (bh * epi.Npad + n) * 64 + d0) = v;
+    }
+  };
+  if constexpr (AS_GEMM_EPI_PIPE != 0 && AS_GEMM_ABLATE == 0) {
+    // Pipelined write-out: the tile leaves in RI slices of WM x 32 rows (the i-th 32-row block of every wave row).  Slice i is
+    // converted and staged, ONE barrier, then its 16-byte stores are issued -- and while they drain the waves are already in the
+    // bias / GELU / convert arithmetic of slice i + 1 (the slices use disjoint rows of the staging tile: no second barrier).
+    // Before, all RI slices were converted, then all stores issued: the memory pipe idled during the first half of the
+    // epilogue and the VALU during the second.
+#pragma unroll
+    for (int i = 0; i < RI; ++i) {
+      stage_block(i);
+      __syncthreads();
+#pragma unroll
+      for (int t = 0; t < WM * 32 * (BN / 8) / NT; ++t) {
+        const int c = tid + t * NT;
+        const int rl = c / (BN / 8), ch = c % (BN / 8);     // rl: row of the slice = (wave row, row of the 32-row block)
+        store_chunk((rl >> 5) * (32 * RI) + i * 32 + (rl & 31), ch);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < (AS_GEMM_ABLATE == 8 ? 0 : RI); ++i) stage_block(i);
+    __syncthreads();
+    if (AS_GEMM_ABLATE == 9) return;                 // timing experiment: staging only, no copy-out
+#pragma unroll
+    for (int t = 0; t < BM * (BN / 8) / NT; ++t) {
+      const int c = tid + t * NT;
+      store_chunk(c / (BN / 8), c % (BN / 8));        // BN / 8 chunks of 8 columns per row
     }
   }
   };   // run_tile
