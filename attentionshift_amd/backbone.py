@@ -410,14 +410,16 @@ class VisionTransformerDet(nn.Module):
         x[:, 1 + Np:] = self.point_token + self.point_pos_embed
         return x
 
-    def _block(self, blk, x, delta, keep_state, need_x, on_full=None):
+    def _block(self, blk, x, delta, keep_state, need_x, on_full=None, full_out=None, x_out=None):
         """models/vision_transformer.py:109-124 with the residual stream kept in fp32 and every residual add fused into
         the LayerNorm that follows it (ops.add_layernorm).  `delta` is the previous block's MLP output that has not
         been added to `x` yet (None for the first block): the first fused add+LayerNorm completes the PREVIOUS block's
         output, which `on_full` (a feature tap) may look at; returns (x, pending MLP output, attention state); with
-        `need_x` the block's own MLP output is added before returning (last block)."""
+        `need_x` the block's own MLP output is added before returning (last block).  `full_out` / `x_out`: the caller's
+        buffers for the completed previous output / this block's own full output (a tap's slot of the org_feats storage)."""
         cd = self.compute_dtype
-        x, y = ops.add_layernorm(x, delta, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps, cd)
+        x, y = ops.add_layernorm(x, delta, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps, cd,
+                                 x_out=full_out if delta is not None else None)
         if on_full is not None:
             on_full(x)
         a, st = ops.attention_fwd(y, self._w(blk.attn.qkv.weight),
@@ -428,7 +430,7 @@ class VisionTransformerDet(nn.Module):
         z = ops.linear(z, self._w(blk.mlp.fc1.weight), blk.mlp.fc1.bias.float(), act="gelu")
         z = ops.linear(z, self._w(blk.mlp.fc2.weight), blk.mlp.fc2.bias.float())
         if need_x:
-            x, _ = ops.add_layernorm(x, z, None, None, 0.0, cd, want_y=False)
+            x, _ = ops.add_layernorm(x, z, None, None, 0.0, cd, want_y=False, x_out=x_out)
             z = None
         return x, z, st
 
@@ -521,14 +523,18 @@ class VisionTransformerDet(nn.Module):
                 # GEMMs, RoIAlign -- read channels-last, and the gradient comes back in the same layout)
                 features.append(tap if os.environ.get("AS_TAP_VIEW", "1") != "0" else tap.contiguous())
                 return
-            # no-grad: org_feats [B, L, D, hp, wp] is a VIEW of token-major storage [L, B, hp, wp, D] (every tap a
-            # channels-last map): filling a slot is a straight copy of the tokens, not a transpose, and the
-            # channels-last consumers (FPN GEMMs, RoIAlign, the attention-shift kernels) read it without a copy
+            # no-grad: org_feats [B, L, D, hp, wp] is a VIEW of the token-major storage the tapped blocks' outputs were
+            # WRITTEN into (tap_slot: the fused residual add's output buffer is the tap's slot of [L, B, N, D]), every tap
+            # a channels-last map: no copy, no transpose, and the channels-last consumers (FPN GEMMs, RoIAlign, the
+            # attention-shift kernels) read it in place
+            if xf.data_ptr() != tap_slot(len(features)).data_ptr():
+                tap_slot(len(features)).copy_(xf)              # (a block output that could not be directed into its slot)
+            features.append(store[0][len(features)][:, 1:-T].unflatten(1, (hp, wp)).permute(0, 3, 1, 2))
+
+        def tap_slot(k):
             if not store:
-                store.append(torch.empty(len(self.out_indices), B, hp, wp, tap.shape[1], device=xf.device, dtype=xf.dtype))
-            org = store[0].permute(1, 0, 4, 2, 3)
-            org[:, len(features)].copy_(tap)
-            features.append(org[:, len(features)])
+                store.append(torch.empty(len(self.out_indices), *x.shape, device=x.device, dtype=torch.float32))
+            return store[0][k]
 
         tap_due = False                                    # the previous block is a tap whose MLP output is still pending
         nblk = len(self.blocks)
@@ -559,8 +565,12 @@ class VisionTransformerDet(nn.Module):
             else:
                 # a tapped block's full output appears inside the NEXT block's first fused add+LayerNorm: the tap is taken
                 # there (no add-only pass); only the last block adds its own MLP output before returning
+                last_tap = i in self.out_indices and i == nblk - 1
                 x, delta, st = self._block(blk, x, delta, self.return_attention, i == nblk - 1,
-                                           take_tap if tap_due else None)
+                                           take_tap if tap_due else None,
+                                           full_out=tap_slot(len(features)) if tap_due and x.dtype == torch.float32 else None,
+                                           x_out=tap_slot(len(features) + int(tap_due)) if last_tap and x.dtype == torch.float32
+                                           else None)
                 tap_due = i in self.out_indices and i != nblk - 1
                 if i in self.out_indices and i == nblk - 1:
                     take_tap(x)
@@ -569,7 +579,7 @@ class VisionTransformerDet(nn.Module):
             if self.last_feat and not self.recompute_last_feat and i == nblk - 1:
                 last_feat = x[:, :-T]
         self._train_shadow = {}                            # (the consumers' autograd nodes hold what backward needs)
-        org_features = store[0].permute(1, 0, 4, 2, 3) if store else None
+        org_features = store[0][:, :, 1:-T].unflatten(2, (hp, wp)).permute(1, 0, 4, 2, 3) if store else None
         if org_features is None:
             org_features = torch.stack(features, dim=1)
         if self.with_fpn and grad_path:

@@ -426,13 +426,13 @@ __global__ __launch_bounds__(RF_NT) void filter_parts_kernel(const float* __rest
 // The first K distinct values of M uniform draws floor(u * n) per object (= the head of a random permutation of the n
 // candidates, stdroi:447), split into positive / negative candidate ranks.  flag |= an object with n < 4K candidates
 // or fewer than K distinct draws (the caller then takes the host path for that image).
-__global__ void draw_distinct_kernel(const int32_t* __restrict__ counts /*[G,2] (n_pos, n_neg)*/,
-                                     const float* __restrict__ u /*[G,M]*/, int32_t* __restrict__ rank_pos,
+__global__ void draw_distinct_kernel(const int32_t* __restrict__ counts /*(n_pos, n_neg) of object g at g*csg + {0, csk}*/,
+                                     int csg, int csk, const float* __restrict__ u /*[G,M]*/, int32_t* __restrict__ rank_pos,
                                      int32_t* __restrict__ rank_neg, uint8_t* __restrict__ is_pos,
                                      int32_t* __restrict__ flag, int G, int M, int K) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= G) return;
-  const int n_pos = counts[g * 2 + 0], n = n_pos + counts[g * 2 + 1];
+  const int n_pos = counts[g * csg], n = n_pos + counts[g * csg + csk];
   int got = 0;
   int picked[32];
   // the first 32 draws in one batch of independent loads (the scan below would otherwise pay one memory round trip per draw)
@@ -467,14 +467,14 @@ extern "C" int as_filter_parts(const float* sim, const float* fg_inter, float si
   return AS_OK;
 }
 
-extern "C" int as_draw_distinct(const int32_t* counts, const float* u, int32_t* rank_pos, int32_t* rank_neg, uint8_t* is_pos,
-                                int32_t* flag, int G, int M, int K, as_stream_t stream) {
+extern "C" int as_draw_distinct(const int32_t* counts, int count_stride_g, int count_stride_k, const float* u, int32_t* rank_pos,
+                                int32_t* rank_neg, uint8_t* is_pos, int32_t* flag, int G, int M, int K, as_stream_t stream) {
   AS_REQUIRE(counts && u && rank_pos && rank_neg && is_pos && flag, AS_E_BADARG, "as_draw_distinct: null pointer");
+  AS_REQUIRE(count_stride_g > 0 && count_stride_k > 0, AS_E_BADARG, "as_draw_distinct: count strides %d, %d", count_stride_g,
+             count_stride_k);
   AS_REQUIRE(G > 0 && M > 0 && K > 0 && K <= 32 && M >= K, AS_E_UNSUPPORTED, "as_draw_distinct: K=%d of M=%d draws (K <= 32)", K, M);
-  hipStream_t s = (hipStream_t)stream;
-  (void)hipMemsetAsync(flag, 0, 4, s);
-  hipLaunchKernelGGL(draw_distinct_kernel, dim3(as_ceil_div(G, 64)), dim3(64), 0, s, counts, u, rank_pos, rank_neg, is_pos,
-                     flag, G, M, K);
+  hipLaunchKernelGGL(draw_distinct_kernel, dim3(as_ceil_div(G, 64)), dim3(64), 0, (hipStream_t)stream, counts, count_stride_g,
+                     count_stride_k, u, rank_pos, rank_neg, is_pos, flag, G, M, K);
   AS_CHECK_LAUNCH("draw_distinct");
   return AS_OK;
 }
@@ -639,6 +639,63 @@ extern "C" int as_merge_parts(const float* prot, const uint8_t* keep, float thr,
   hipLaunchKernelGGL(merge_parts_kernel, dim3(G), dim3(MG_NT), lds, (hipStream_t)stream, prot, keep, thr, merged, ngroups, flag,
                      P, C, slots);
   AS_CHECK_LAUNCH("merge_parts");
+  return AS_OK;
+}
+
+// =====================================================================================================
+// The layer choice of the stand-in selector and everything indexed by it, one thread per object (the MIL head's place in
+// stdroi:2953-2972 taken by the depth whose CAM box has the median area, roi_head.median_area_selector): stable ascending
+// rank of the Lc box areas, the chosen box, its row in the layer-major CAM stack and its patch box (`rois // stride`,
+// stdroi:1812).  Replaces ~20 tensor ops of index arithmetic per step.
+// =====================================================================================================
+namespace {
+__global__ void select_median_boxes_kernel(const float* __restrict__ boxes, const int32_t* __restrict__ meta, int Lc, float stride,
+                                           int64_t* __restrict__ pick, float* __restrict__ chosen,
+                                           int32_t* __restrict__ map_idx, int32_t* __restrict__ box_patch,
+                                           int32_t* __restrict__ box_int, const int32_t* __restrict__ status,
+                                           int32_t* __restrict__ bad, int n) {
+  const int o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= n) return;
+  const int off = meta[3 * o], cnt = meta[3 * o + 1], g = meta[3 * o + 2];
+  const float4* b = reinterpret_cast<const float4*>(boxes);
+  const int want = (Lc - 1) / 2;
+  int sel = 0;
+  for (int l = 0; l < Lc; ++l) {
+    const float4 bl = b[off + l * cnt + g];
+    const float al = fmaxf(bl.z - bl.x, 0.f) * fmaxf(bl.w - bl.y, 0.f);
+    int rank = 0;
+    for (int m = 0; m < Lc; ++m) {
+      const float4 bm = b[off + m * cnt + g];
+      const float am = fmaxf(bm.z - bm.x, 0.f) * fmaxf(bm.w - bm.y, 0.f);
+      rank += (am < al) || (am == al && m < l);
+    }
+    if (rank == want) sel = l;
+  }
+  const int row = off + sel * cnt + g;
+  const float4 c = b[row];
+  pick[o] = sel;
+  reinterpret_cast<float4*>(chosen)[o] = c;
+  map_idx[o] = row;
+  reinterpret_cast<int4*>(box_patch)[o] = make_int4((int)floorf(c.x / stride), (int)floorf(c.y / stride),
+                                                    (int)floorf(c.z / stride), (int)floorf(c.w / stride));
+  if (box_int) reinterpret_cast<int4*>(box_int)[o] = make_int4((int)c.x, (int)c.y, (int)c.z, (int)c.w);
+  if (status) {                                              // every row of `boxes` belongs to exactly one object
+    bool any_bad = false;
+    for (int l = 0; l < Lc; ++l) any_bad = any_bad || status[off + l * cnt + g] <= 0;
+    if (any_bad) atomicOr(bad, 1);
+  }
+}
+}  // namespace
+
+extern "C" int as_select_median_boxes(const float* boxes, const int32_t* meta, int Lc, int stride, int64_t* pick, float* chosen,
+                                      int32_t* map_idx, int32_t* box_patch, int32_t* box_int, const int32_t* status,
+                                      int32_t* bad, int n, as_stream_t stream) {
+  AS_REQUIRE(boxes && meta && pick && chosen && map_idx && box_patch, AS_E_BADARG, "as_select_median_boxes: null pointer");
+  AS_REQUIRE(n > 0 && Lc > 0 && Lc <= 64 && stride > 0, AS_E_UNSUPPORTED, "as_select_median_boxes: n=%d Lc=%d stride=%d", n, Lc, stride);
+  AS_REQUIRE(!status || bad, AS_E_BADARG, "as_select_median_boxes: status without a flag to raise");
+  hipLaunchKernelGGL(select_median_boxes_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, boxes, meta, Lc,
+                     (float)stride, pick, chosen, map_idx, box_patch, box_int, status, bad, n);
+  AS_CHECK_LAUNCH("select_median_boxes");
   return AS_OK;
 }
 

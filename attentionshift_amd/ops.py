@@ -250,9 +250,10 @@ def _scale_arg(delta_scale, x, delta):
     return delta_scale, x.shape[1]
 
 
-def add_layernorm(x, delta, gamma, beta, eps, out_dtype, want_x=True, want_y=True, delta_scale=None):
+def add_layernorm(x, delta, gamma, beta, eps, out_dtype, want_x=True, want_y=True, delta_scale=None, x_out=None):
     """x_new = x + delta (fp32; delta may be None), y = LayerNorm(x_new) in `out_dtype` -- one pass (csrc/layernorm.hip).
     delta_scale fp32 [B] | None: x_new = x + delta_scale[b] * delta (per-sample stochastic depth).
+    x_out: the caller's buffer for x_new (fp32, x's shape, contiguous; e.g. a feature tap's slot) instead of a new one.
     Returns (x_new | None, y | None)."""
     lib = _lib.load()
     D = x.shape[-1]
@@ -262,7 +263,13 @@ def add_layernorm(x, delta, gamma, beta, eps, out_dtype, want_x=True, want_y=Tru
     _chk(gamma, beta, dtype=torch.float32)       # (None is allowed when only the add is wanted)
     if delta is not None and delta.dtype != out_dtype:
         raise AttnShiftError("add_layernorm: delta must have the output dtype")
-    x_out = torch.empty_like(x2) if (want_x and delta is not None) else None
+    if x_out is not None:
+        if not (want_x and delta is not None) or x_out.shape != x.shape:
+            raise AttnShiftError("add_layernorm: x_out needs want_x, a delta and x's shape")
+        _chk(x_out, dtype=torch.float32)
+        x_out = x_out.view(-1, D)
+    else:
+        x_out = torch.empty_like(x2) if (want_x and delta is not None) else None
     y = torch.empty(x2.shape, device=x.device, dtype=out_dtype) if want_y else None
     dt = AS_BF16 if out_dtype == torch.bfloat16 else AS_F32
     sc, rps = _scale_arg(delta_scale, x, delta)
@@ -787,19 +794,30 @@ def filter_parts(sim, fg_inter, sim_thr=0.8, pos_thr=0.85):
     return keep.view(torch.bool)                      # 0/1 bytes: a view, not a conversion launch
 
 
-def draw_distinct(counts, u, k):
-    """counts [G,2] int32 (n_pos, n_neg), u [G,M] fp32 uniform -> (rank_pos, rank_neg int32 [G,k], is_pos bool [G,k],
-    flag int32 [1]): the first k distinct floor(u * n) per object, split by candidate kind."""
+def draw_distinct(counts, u, k, flag=None):
+    """counts [G,2] int32 (n_pos, n_neg) in any strided layout (e.g. the transposed rows of mask_candidates), u [G,M] fp32
+    uniform -> (rank_pos, rank_neg int32 [G,k], is_pos bool [G,k], flag int32 [1]): the first k distinct floor(u * n) per
+    object, split by candidate kind.  `flag`: a zeroed int32 [1] slot of the caller's (OR-ed); made here when absent."""
     lib = _lib.load()
-    counts = counts.to(torch.int32).contiguous()
+    if counts.dtype != torch.int32:
+        counts = counts.to(torch.int32)
+    if tuple(counts.shape) != (u.shape[0], 2):
+        raise AttnShiftError(f"draw_distinct: counts {tuple(counts.shape)} for {u.shape[0]} objects")
+    sg, sk = counts.stride()                               # any layout of the [G,2] table is read in place
+    if sg <= 0 or sk <= 0:
+        counts = counts.contiguous()
+        sg, sk = 2, 1
+    if not counts.is_cuda:
+        raise AttnShiftError("hot-path ops need device (HBM) tensors; there is no CPU fallback")
     u = u.contiguous()
     _chk(u, dtype=torch.float32)
     G, M = u.shape
     rp = torch.empty(G, k, device=u.device, dtype=torch.int32)
     rn = torch.empty(G, k, device=u.device, dtype=torch.int32)
     ip = torch.empty(G, k, device=u.device, dtype=torch.uint8)
-    flag = torch.empty(1, device=u.device, dtype=torch.int32)
-    _lib.check(lib.as_draw_distinct(_p(counts), _p(u), _p(rp), _p(rn), _p(ip), _p(flag), G, M, int(k), _stream()),
+    if flag is None:
+        flag = torch.zeros(1, device=u.device, dtype=torch.int32)
+    _lib.check(lib.as_draw_distinct(_p(counts), sg, sk, _p(u), _p(rp), _p(rn), _p(ip), _p(flag), G, M, int(k), _stream()),
                "as_draw_distinct")
     return rp, rn, ip.view(torch.bool), flag
 
@@ -887,6 +905,26 @@ def merge_parts(prot, keep, thr, slots, flag=None):
     _lib.check(lib.as_merge_parts(_p(prot), _p(k8), float(thr), _p(merged), _p(ngroups), _p(flag), G, P, C, int(slots),
                                   _stream()), "as_merge_parts")
     return merged, ngroups
+
+
+def select_median_boxes(boxes, meta, Lc, stride, status=None, bad=None):
+    """boxes [rows,4] fp32 (every image's CAM boxes layer-major), meta [n,3] int32 = (image's first row, objects in the image,
+    index in the image) -> (pick [n] int64, chosen [n,4] fp32, map_idx [n] int32, box_patch [n,4] int32, box_int [n,4]
+    int32): the median-area layer per object, its box, that box's row in `boxes`, floor(box / stride) and the box truncated
+    to integers (as_select_median_boxes).  With `status` ([rows] int32 of cam_boxes) the zeroed int32 slot `bad` is OR-ed
+    with 1 if any box of a listed object has status <= 0."""
+    lib = _lib.load()
+    _chk(boxes, dtype=torch.float32)
+    _chk(meta, status, bad, dtype=torch.int32)
+    n = meta.shape[0]
+    pick = torch.empty(n, device=boxes.device, dtype=torch.int64)
+    chosen = torch.empty(n, 4, device=boxes.device, dtype=torch.float32)
+    map_idx = torch.empty(n, device=boxes.device, dtype=torch.int32)
+    ints = torch.empty(2, n, 4, device=boxes.device, dtype=torch.int32)
+    _lib.check(lib.as_select_median_boxes(_p(boxes), _p(meta), int(Lc), int(stride), _p(pick), _p(chosen), _p(map_idx),
+                                          _p(ints[0]), _p(ints[1]), _p(status), _p(bad), n, _stream()),
+               "as_select_median_boxes")
+    return pick, chosen, map_idx, ints[0], ints[1]
 
 
 def mask_count(mask):

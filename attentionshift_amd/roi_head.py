@@ -333,22 +333,23 @@ def sample_points_from_cams(cams_lr, map_idx, minmax, gt_points, num_points, thr
 # raise a device FLAG; the caller reads it with a readback it needs anyway and redoes that image on the synchronous
 # path (same distributions, different draws).
 
-def sample_points_from_cams_nosync(cams_lr, map_idx, minmax, num_points, gen, thr_bg=0.1, thr_fg=0.2, flag=None):
+def sample_points_from_cams_nosync(cams_lr, map_idx, minmax, num_points, gen, thr_bg=0.1, thr_fg=0.2, flag=None, u=None):
     """sample_points_from_cams without the count readback.  Returns (pts_bg, pts_fg, pts_supp, flag) with flag a
     device flag: some candidate set is smaller than num_points (the reference's refill branches, stdroi:354-364).
     `flag` (a zeroed int32 [1] slot of the caller): the ranks are then derived inside the selection kernel from the
-    populations it counts anyway (ops.rank_draw_xy: one launch pair instead of the eight tensor ops below)."""
+    populations it counts anyway (ops.rank_draw_xy: one launch pair instead of the eight tensor ops below).
+    `u` [2G+1, num_points]: the uniform numbers, if the caller drew them already (one draw for the batch)."""
     G = map_idx.shape[0]
     masks, counts = ops.cam_sample_masks(cams_lr, map_idx, minmax, thr_bg, thr_fg, STRIDE)
     W = masks.shape[-1]
-    if flag is not None and (masks.shape[-1] * masks.shape[-2]) % 16 == 0:
+    if u is None:
         u = torch.rand(2 * G + 1, num_points, device=masks.device, generator=gen)
+    if flag is not None and (masks.shape[-1] * masks.shape[-2]) % 16 == 0:
         # also the token index of every drawn pixel, rows rotated to [fg objects, shared background, bg objects]: the
         # gather index of the seed features (seed_features' `// 16`, clamp and cat chain)
         pts, pidx = ops.rank_draw_xy(masks.flatten(1), num_points, W, u=u, flag=flag, patch=(None, STRIDE, W // STRIDE, 0, G))
         return pts[:G], pts[G:], pidx, flag.reshape(())
     n = counts.float()[:, None]
-    u = torch.rand(2 * G + 1, num_points, device=masks.device, generator=gen)
     ranks = torch.minimum((u * n).to(torch.int32), (counts[:, None] - 1).clamp(min=0))
     pts = rank_select_xy(masks.flatten(1), ranks, W)                           # (x, y) of every drawn candidate
     return pts[:G], pts[G:2 * G], pts[2 * G:], (counts < num_points).any()
@@ -384,15 +385,17 @@ def mask_points_mt(pend, num_gt, mt_state):
     return coords, is_pos, flag[0] != 0
 
 
-def mask_points_nosync(pend, num_gt, gen, int_flag=False):
+def mask_points_nosync(pend, num_gt, gen, int_flag=False, flag=None, u=None):
     """mask_points_finish without the count readback: num_gt DISTINCT uniform ranks among the n = n_pos + n_neg
     candidates of each object (the first num_gt entries of a random permutation, stdroi:447) = the first num_gt
     distinct values of 32 uniform draws.  flag: an object with fewer than 4*num_gt candidates (the host path's
     randperm / refill / empty branches) or, with probability < 1e-12, too few distinct draws."""
     pos, neg = pend["pos"], pend["neg"]
     G, H, W = pend["shape"]
-    u = torch.rand(G, 32, device=pos.device, generator=gen)
-    rank_pos, rank_neg, is_pos, flag = ops.draw_distinct(pend["counts"], u, num_gt)      # counts [G, 2] = (n_pos, n_neg)
+    if u is None:                                          # (else: the caller's share of one draw for the batch)
+        u = torch.rand(G, 32, device=pos.device, generator=gen)
+    # counts [G, 2] = (n_pos, n_neg), read in place; `flag`: a zeroed int32 [1] slot of the caller's flag vector
+    rank_pos, rank_neg, is_pos, flag = ops.draw_distinct(pend["counts"], u, num_gt, flag=flag)
     xy_pos = rank_select_xy(pos.flatten(1), rank_pos, W)
     xy_neg = rank_select_xy(neg.flatten(1), rank_neg, W)
     coords = torch.where(is_pos[..., None], xy_pos, xy_neg).float()
@@ -498,10 +501,11 @@ def mask_points_issue(map_fg, map_bg, rois, pos_thr, neg_thr, corr_size):
     return dict(pos=pos, neg=neg, cp=cp, crops=crops, counts=torch.stack((cp, cn), dim=1), shape=tuple(map_fg.shape))
 
 
-def mask_points_and_pseudo_issue(map_fg, map_bg, rois, pos_thr, neg_thr, corr_size, mask_thr):
+def mask_points_and_pseudo_issue(map_fg, map_bg, rois, pos_thr, neg_thr, corr_size, mask_thr, crops=None):
     """mask_points_issue plus the pseudo mask of stdroi:2357 from ONE fused call (ops.mask_candidates): the three
     thresholds share their maxima pass and their thresholding pass.  Returns (pending dict, pseudo mask uint8)."""
-    crops = rois.int().contiguous()                      # stdroi:1981: rois[i].int().tolist()
+    if crops is None:
+        crops = rois.int().contiguous()                  # stdroi:1981: rois[i].int().tolist()
     pos, neg, pseudo, counts = ops.mask_candidates(map_fg.contiguous(), map_bg.contiguous(), crops, pos_thr, neg_thr,
                                                    mask_thr, corr_size)
     return dict(pos=pos, neg=neg, cp=counts[0], crops=crops, counts=counts[:2].t(), shape=tuple(map_fg.shape)), pseudo
@@ -996,7 +1000,8 @@ class AttnShiftRoIHead(nn.Module):
         return ops.rollout_rows(states, num_proposals, rows=sel.to(states[0].q.device).long())
 
     def refine_maps(self, attn_sel, feat_chw, rois, gt_points, refine_times, obj_tau, minmax=None, cam_src=None,
-                    draw_gen=None, flags_out=None, last_level_only=False, mt_state=None, flag_slot=None, box_patch=None):
+                    draw_gen=None, flags_out=None, last_level_only=False, mt_state=None, flag_slot=None, box_patch=None,
+                    draw_u=None):
         """B2 (stdroi:1000-1019).  attn_sel [G,H,W], feat [C,hp,wp]; minmax [G,2] = per-map (min,max) if the
         caller already has them (as_cam_boxes does).  cam_src = (cams_lr [M,hp,wp], map_idx [G] int32, minmax [M,2])
         replaces attn_sel: the seed sampling then reads the low-resolution CAMs and the upsampled maps are never
@@ -1010,7 +1015,7 @@ class AttnShiftRoIHead(nn.Module):
         elif cam_src is not None and draw_gen is not None:        # fast-RNG mode: no readback, flag instead
             G = cam_src[1].shape[0]
             pts_bg, pts_fg, pts_supp, short = sample_points_from_cams_nosync(cam_src[0], cam_src[1], cam_src[2], 20, draw_gen,
-                                                                             flag=flag_slot)
+                                                                             flag=flag_slot, u=draw_u)
             flags_out.append(short)
             if flag_slot is not None and pts_supp.dim() == 2:      # (pts_fg already holds the shared group; pts_supp = token ids)
                 seed_idx, pts_supp = pts_supp, None
@@ -1164,7 +1169,7 @@ class AttnShiftRoIHead(nn.Module):
                                                                    merge_thr, num_semantic_points, extra), num_max_keep)
 
     def _semantic_post_issue(self, prot, sim, fg_inter, rois, vit_feat, gt_labels, merge_thr, num_semantic_points,
-                             extra=None, flag_slot=None):
+                             extra=None, flag_slot=None, flag_vec=None):
         """_semantic_post with ONE readback (fast-RNG path), first half: everything up to and including the START of
         that readback (a device -> pinned-host copy + event), so that a caller with several images can queue all of them
         before it waits for the first: the greedy merge plan (ops.merge_plan), the merged prototypes, their similarity
@@ -1192,8 +1197,8 @@ class AttnShiftRoIHead(nn.Module):
         feat_tok = vit_feat.flatten(1).t().contiguous()
         allp = merged.flatten(0, 1)
         P = slots                                                                      # from here on: slots per object
-        sims = torch.cat([ops.refine_similarity(feat_tok, allp[o:o + 32], None, 0, 0, 1.0, False, hp, wp)[0][0]
-                          for o in range(0, G * P, 32)]).reshape(G, P, hp, wp)
+        sims = [ops.refine_similarity(feat_tok, allp[o:o + 32], None, 0, 0, 1.0, False, hp, wp)[0][0] for o in range(0, G * P, 32)]
+        sims = (sims[0] if len(sims) == 1 else torch.cat(sims)).reshape(G, P, hp, wp)
         # per-slot statistics exactly as part_centers computes them per part (one launch), then the visiting order / cap
         # logic of stdroi:222-262 and the gathers behind it in as_part_select: nothing here waits for the host
         slot_owner = _const_tensor(("slot_owner", G, P), dev,
@@ -1202,7 +1207,13 @@ class AttnShiftRoIHead(nn.Module):
         coords, coords_org, labels, labels_org, corres, feats, split = ops.part_select(
             area, inside, ng32, c, yx, gt_labels.long().contiguous(), feat_tok, G, P, wp, num_semantic_points)
         pieces = [split, ng32]
-        if extra:
+        lo = 0 if flag_vec is None else flag_vec.data_ptr()
+        if extra and flag_vec is not None and all(e.dtype == torch.int32 and lo <= e.data_ptr() < lo + 4 * flag_vec.numel()
+                                                  for e in extra[1:]):
+            # every flag but the first (the caller's CAM check) is a slot of the caller's zero-filled vector: no stack
+            pieces += [extra[0].reshape(1), flag_vec]
+            extra[:] = [extra[0]] + [None] * flag_vec.numel()
+        elif extra:
             pieces.append(torch.stack([e.reshape(()) for e in extra]).int())
         return dict(pending=_to_host_issue(torch.cat(pieces)), extra=extra, G=G, P=P, sims=sims, rois=rois, dev=dev,
                     gt_labels=gt_labels, picked=(coords, coords_org, labels, labels_org, corres, feats))
@@ -1356,22 +1367,45 @@ class AttnShiftRoIHead(nn.Module):
         # the reference raises here when a CAM has no foreground component (torch.stack of an empty list, stdroi:80).
         # The flag stays on the device and is checked at the first host sync the chain needs anyway (the seed counts):
         # reading it here would stall the host for the whole roll-out + CAM-box phase with nothing queued behind it.
-        bad_cam = (status <= 0).any()                        # 0: no component; -1: run table overflow
-        if status.is_cuda:
-            bad_cam = bad_cam.to(torch.int32)                # the dtype of the other device flags it is read back with
+        # the default selector (median box area over the roll-out depths) with its index arithmetic as ONE launch for the batch:
+        # the chosen layer, its box, that box's row of the CAM stack, its patch box -- and the CAM check above
+        # (csrc/refine.hip select_median_boxes)
+        fused_sel = (self.layer_selector is median_area_selector and boxes.is_cuda and sum(counts) > 0
+                     and os.environ.get("AS_HEAD_TENSOR_GLUE") != "1")
+        flag_all = None
+        if fused_sel:
+            # one zero fill for every device flag of the call: 4 slots per image (raised by the selection kernels of the
+            # sync-free path) + the CAM check
+            flag_all = torch.zeros(4 * num_imgs + 1, dtype=torch.int32, device=boxes.device)
+            bad_cam = flag_all[4 * num_imgs]
+        else:
+            bad_cam = (status <= 0).any()                    # 0: no component; -1: run table overflow
+            if status.is_cuda:
+                bad_cam = bad_cam.to(torch.int32)            # the dtype of the other device flags it is read back with
         gt_scale_bboxes, attn_maps_dealed, cam_off, off = [], [], [], 0
         for i in range(num_imgs):
             n = Lc * counts[i]
-            gt_scale_bboxes.append(boxes[off:off + n].reshape(Lc, counts[i], 4).permute(1, 0, 2).contiguous())
+            if not fused_sel:
+                gt_scale_bboxes.append(boxes[off:off + n].reshape(Lc, counts[i], 4).permute(1, 0, 2).contiguous())
             if cams_up is not None:
                 attn_maps_dealed.append(cams_up[off:off + n].reshape(Lc, counts[i], H, W))
             cam_off.append(off)
             off += n
 
         CLOCK.mark("box_split")
-        gt_box_index = self.layer_selector(gt_scale_bboxes, gt_labels, roi_feature_map)
-        pseudo_boxes = [gt_scale_bboxes[i][_const_tensor(("arange", counts[i]), boxes.device, lambda n=counts[i]: torch.arange(n)),
-                                           gt_box_index[i]] for i in range(num_imgs)]
+        sel_rows = sel_patch = sel_int = None
+        if fused_sel:
+            meta = _const_tensor(("select_meta", tuple(counts), Lc), boxes.device, lambda: torch.tensor(
+                [[cam_off[i], counts[i], g] for i in range(num_imgs) for g in range(counts[i])], dtype=torch.int32))
+            pick, chosen, rows, patch, ints = ops.select_median_boxes(boxes, meta, Lc, STRIDE, status=status,
+                                                                      bad=flag_all[4 * num_imgs:])
+            gt_box_index, pseudo_boxes = list(pick.split(counts)), list(chosen.split(counts))
+            sel_rows, sel_patch, sel_int = rows.split(counts), patch.split(counts), ints.split(counts)
+        else:
+            gt_box_index = self.layer_selector(gt_scale_bboxes, gt_labels, roi_feature_map)
+            pseudo_boxes = [gt_scale_bboxes[i][_const_tensor(("arange", counts[i]), boxes.device,
+                                                             lambda n=counts[i]: torch.arange(n)), gt_box_index[i]]
+                            for i in range(num_imgs)]
         mil_losses = {}
         if self.mil_head is not None and roi_feature_map is not None and self._mil_selector.last_loss is not None:
             mil_losses["mil_loss"] = self._mil_selector.last_loss                # stdroi:2961
@@ -1386,13 +1420,18 @@ class AttnShiftRoIHead(nn.Module):
         feat_tok = feature_tokens(vit_feat)                                   # [B, Np, C], per-image contiguous
         feats = [feat_tok[i].t().unflatten(1, (patch_h, patch_w)) for i in range(num_imgs)]   # [C,hp,wp] views
 
+        def layer_rows(i):
+            if sel_rows is not None:
+                return sel_rows[i]
+            ar = _const_tensor(("arange", counts[i]), boxes.device, lambda: torch.arange(counts[i]))
+            return (cam_off[i] + gt_box_index[i] * counts[i] + ar).to(torch.int32)
+
         def phase_a(i):
             """Refinement (B2), then EVERYTHING that depends only on the refined maps is queued on the device -- the
             candidate masks of the mask points (B2'), the patch-grid foreground maps and seed counts (B3), the pseudo
             mask and its device->host copy (B6) -- before the first host sync of the chain, so that the device keeps
             working while the host waits for counts and draws.  (stdroi:1966-1993, 2011-2020, 2356-2358.)"""
-            ar = torch.arange(counts[i], device=boxes.device)
-            map_idx = (cam_off[i] + gt_box_index[i] * counts[i] + ar).to(torch.int32)      # rows of cams_lr (layer-major)
+            map_idx = layer_rows(i)                                                         # rows of cams_lr (layer-major)
             map_fg, map_bg, _pa, _pb, feats_fg, feats_bg = self.refine_maps(
                 None, feats[i], pseudo_boxes[i], gt_points[i], 2, obj_tau, cam_src=(cams_lr, map_idx, cam_minmax),
                 last_level_only=True)
@@ -1411,20 +1450,20 @@ class AttnShiftRoIHead(nn.Module):
                 self.capture.append(dict(image=i, seeds=seeds, fg_inter=fg_inter))
             return coord_point, labels_point, map_fg, map_bg, feats_fg, feats_bg, (fg_inter, seeds), pm
 
-        def phase_a_nosync(i, mt_state=None, flag_slots=None):
+        def phase_a_nosync(i, mt_state=None, flag_slots=None, draws=None):
             """phase_a + phase_a_finish with every draw made on the device: nothing is read back.  Fast RNG mode: uniform
             numbers from the device generator; reference mode (`mt_state`): torch's own engine advanced on the device, the
             images strictly in order on one stream.  The last element is the list of device flags that ask for the
             synchronous path (rare refill branches)."""
             flags = []
-            ar = _const_tensor(("arange", counts[i]), boxes.device, lambda: torch.arange(counts[i]))
-            map_idx = (cam_off[i] + gt_box_index[i] * counts[i] + ar).to(torch.int32)
-            bp = (pseudo_boxes[i] // STRIDE).to(torch.int32)         # stdroi:1812 patch box, shared by B2 and B4
+            map_idx = layer_rows(i)
+            # stdroi:1812 patch box, shared by B2 and B4
+            bp = sel_patch[i] if sel_patch is not None else (pseudo_boxes[i] // STRIDE).to(torch.int32)
             map_fg, map_bg, _pa, _pb, feats_fg, feats_bg = self.refine_maps(
                 None, feats[i], pseudo_boxes[i], gt_points[i], 2, obj_tau, cam_src=(cams_lr, map_idx, cam_minmax),
                 draw_gen=None if mt_state is not None else self._device_gen(boxes.device), flags_out=flags,
                 last_level_only=True, mt_state=mt_state, flag_slot=None if flag_slots is None else flag_slots[i, 0:1],
-                box_patch=bp)
+                box_patch=bp, draw_u=None if draws is None else draws[0])
             # what the batched mean shift (caller's stream) waits for comes FIRST -- the patch-grid foreground and the grid seeds
             # -- and is marked with an event; the mask candidates, mask points and the pseudo-mask copy (B2', B6: ~130 us of
             # launches nothing in the semantic chain reads) are queued behind it and run under the mean shift
@@ -1434,13 +1473,15 @@ class AttnShiftRoIHead(nn.Module):
                                                                               i * _token_row_stride(feat_tok)))
             seeds_ready = torch.cuda.current_stream().record_event() if boxes.is_cuda else None
             mp, mask_u8 = mask_points_and_pseudo_issue(map_fg[-1], map_bg[-1], pseudo_boxes[i], pos_mask_thr, neg_mask_thr,
-                                                       corr_size, pos_mask_thr)
+                                                       corr_size, pos_mask_thr, crops=None if sel_int is None else sel_int[i])
             pm = _to_host_issue(mask_u8, side_stream=True)
             if mt_state is not None:
                 coord_point, labels_point, f1 = mask_points_mt(mp, num_mask_point_gt, mt_state)
             else:
                 coord_point, labels_point, f1 = mask_points_nosync(mp, num_mask_point_gt, self._device_gen(boxes.device),
-                                                                   int_flag=flag_slots is not None)
+                                                                   int_flag=flag_slots is not None,
+                                                                   flag=None if flag_slots is None else flag_slots[i, 3:4],
+                                                                   u=None if draws is None else draws[1])
             if self.capture is not None:
                 self.capture.append(dict(image=i, seeds=seeds, fg_inter=fg_inter))
             flags += [f1, f2]
@@ -1479,17 +1520,23 @@ class AttnShiftRoIHead(nn.Module):
                 ra = [phase_a_nosync(i, mt_state) for i in range(num_imgs)]
                 mt_final = _to_host_issue(mt_state)
             else:
-                self._device_gen(boxes.device, reseed=True)
+                gen = self._device_gen(boxes.device, reseed=True)
+                # every uniform number of the call in ONE draw: per image [2G+1, 20] for the seed sampling (stdroi:346-369) and
+                # [G, 32] for the mask points (stdroi:447)
+                n_seed, n_mask = [(2 * c + 1) * 20 for c in counts], [c * 32 for c in counts]
+                u_all = torch.rand(sum(n_seed) + sum(n_mask), device=boxes.device, generator=gen).split(n_seed + n_mask)
+                draws = [(u_all[i].view(2 * counts[i] + 1, 20), u_all[num_imgs + i].view(counts[i], 32)) for i in range(num_imgs)]
                 # device flags raised by the selection kernels themselves (too few candidates): one zero fill for the batch
                 if os.environ.get("AS_HEAD_TENSOR_GLUE") != "1":     # (A/B switch: "1" = the tensor-op forms of the draws)
-                    flag_slots = torch.zeros(num_imgs, 3, dtype=torch.int32, device=boxes.device)
+                    flag_slots = (flag_all[:4 * num_imgs].view(num_imgs, 4) if flag_all is not None else
+                                  torch.zeros(num_imgs, 4, dtype=torch.int32, device=boxes.device))
                 if flag_slots is not None and _token_blocks_ok(feat_tok) and (patch_h * patch_w) % 16 == 0:
                     # token ids (image offset included) of every object's grid seeds, written by the selection kernels: the
                     # mean shift's initial prototypes are then ONE gather for the batch
                     seed_ids = torch.empty(sum(counts), 20, dtype=torch.int64, device=boxes.device)
                 for st in self._streams[:num_imgs]:
                     st.wait_stream(main)
-                ra = [on_stream(i, phase_a_nosync, None, flag_slots) for i in range(num_imgs)]
+                ra = [on_stream(i, phase_a_nosync, None, flag_slots, draws[i]) for i in range(num_imgs)]
                 if self.overlap_mask_work:
                     for r in ra:                                 # the seeds only: the mask-point work behind them keeps running
                         main.wait_event(r[10])
@@ -1505,7 +1552,8 @@ class AttnShiftRoIHead(nn.Module):
                 extra = [bad_cam] + ra[i][8]
                 return self._semantic_post_issue(prot, sim, ra[i][6][0], pseudo_boxes[i], feats[i], gt_labels[i], 0.85,
                                                  self.num_semantic_points, extra=extra,
-                                                 flag_slot=None if flag_slots is None else flag_slots[i, 2:3])
+                                                 flag_slot=None if flag_slots is None else flag_slots[i, 2:3],
+                                                 flag_vec=None if flag_slots is None else flag_slots[i])
 
             def chain_finish(i, st):
                 sc = self._semantic_post_finish(st)

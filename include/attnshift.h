@@ -313,10 +313,13 @@ int as_filter_parts(const float* sim /*[G,P,Np]*/, const float* fg_inter /*[G,Np
                     uint8_t* keep /*[G,P]*/, int G, int P, int Np, as_stream_t stream);
 
 /* Device-side draw of the mask points (fast-RNG mode; the head of a random permutation, stdroi:447): the first K
- * distinct values of floor(u[g,:] * n_g), n_g = counts[g,0] + counts[g,1], split into ranks among the positive /
- * negative candidates.  flag (int32, written) != 0: some object needs the host path (n_g < 4K or too few distinct). */
-int as_draw_distinct(const int32_t* counts /*[G,2]*/, const float* u /*[G,M]*/, int32_t* rank_pos /*[G,K]*/,
-                     int32_t* rank_neg, uint8_t* is_pos, int32_t* flag, int G, int M, int K, as_stream_t stream);
+ * distinct values of floor(u[g,:] * n_g), n_g = n_pos + n_neg of object g read at counts[g * count_stride_g] and
+ * counts[g * count_stride_g + count_stride_k] (so both a [G,2] table and the [3,G] table of as_mask_candidates are read in
+ * place), split into ranks among the positive / negative candidates.  *flag (int32, zeroed by the caller) is OR-ed with 1
+ * when some object needs the host path (n_g < 4K or too few distinct draws). */
+int as_draw_distinct(const int32_t* counts, int count_stride_g, int count_stride_k, const float* u /*[G,M]*/,
+                     int32_t* rank_pos /*[G,K]*/, int32_t* rank_neg, uint8_t* is_pos, int32_t* flag, int G, int M, int K,
+                     as_stream_t stream);
 
 /* The reference-RNG mode's draws made on the device (csrc/mt19937.hip): `state` = torch's CPU mt19937 engine as int32[626]
  * (624 state words, left, next: attentionshift_amd/mt19937.py), advanced in place exactly as the reference's host calls
@@ -418,6 +421,18 @@ int as_rank_select_xy(const uint8_t* mask /*[M,HW] 0/1*/, const int32_t* ranks /
  * is OR-ed with 1 when an object has more than `slots` groups.  prot [G,P,C] fp32, keep [G,P] 0/1, P <= 32. */
 int as_merge_parts(const float* prot, const uint8_t* keep, float thr, float* merged /*[G,slots,C]*/, int32_t* ngroups /*[G]*/,
                    int32_t* flag, int G, int P, int C, int slots, as_stream_t stream);
+
+/* The default layer selector and its index arithmetic in one launch (roi_head.median_area_selector standing in for the MIL
+ * head's choice, stdroi:2953-2972; the patch box of stdroi:1812): per object o with meta[o] = (first row of its image in
+ * `boxes`, objects in that image, index in the image) and the image's boxes layer-major ([Lc, cnt, 4] from as_cam_boxes),
+ *   pick[o]      the layer whose box area max(x1-x0,0)*max(y1-y0,0) has stable ascending rank (Lc-1)/2
+ *   chosen[o]    that box;  map_idx[o] its row in `boxes` (= the row of the CAM stack);  box_patch[o] = floor(box / stride);
+ *   box_int[o]   (may be NULL) the box truncated to integers, the crop of stdroi:1981
+ * `status` (may be NULL) [rows] int32, the per-box status of as_cam_boxes: *bad (zeroed by the caller) is OR-ed with 1 when any
+ * row of any listed object has status <= 0 (a CAM without a foreground component -- where stdroi:80 raises). */
+int as_select_median_boxes(const float* boxes /*[rows,4]*/, const int32_t* meta /*[n,3]*/, int Lc, int stride, int64_t* pick /*[n]*/,
+                           float* chosen /*[n,4]*/, int32_t* map_idx /*[n]*/, int32_t* box_patch /*[n,4]*/,
+                           int32_t* box_int /*[n,4]*/, const int32_t* status, int32_t* bad, int n, as_stream_t stream);
 
 /* Rank selection whose ranks are derived on the device from each row's population n (known from the same counting pass), so
  * that the sampling chains need no tensor-op glue and no readback (fast-RNG mode of the seed sampling, stdroi:346-369, and the

@@ -65,7 +65,7 @@ def test_bad_arguments_return_error_codes_without_launching():
     assert lib.as_chamfer_2d_fwd(None, None, None, None, None, None, 2, 9, 7, None) == -1
     assert lib.as_chamfer_2d_bwd(*([None] * 8), 2, 9, 7, None) == -1
     assert lib.as_filter_parts(None, None, 0.8, 0.85, None, 3, 20, 4096, None) == -1
-    assert lib.as_draw_distinct(None, None, None, None, None, None, 3, 32, 10, None) == -1
+    assert lib.as_draw_distinct(None, 2, 1, None, None, None, None, None, 3, 32, 10, None) == -1
     assert lib.as_part_stats(None, None, None, 16.0, None, None, None, None, 4, 64, 64, None) == -1
     assert lib.as_mask_candidates(None, None, None, 0.35, 0.8, 0.35, 21, None, None, None, None, None, 0, 3, 64, 64, None) == -1
     assert lib.as_semantic_prestage(None, 0.35, 11, 3, 64, 64, 16, None, None, None, None) == -1

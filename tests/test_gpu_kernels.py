@@ -1135,6 +1135,66 @@ def test_merge_parts_equals_the_tensor_op_chain(ops):
                     assert_close(ref_o[i], merged[i, :n], 1e-5, 1e-6, f"object {i}: merged prototypes vs oracle")
 
 
+def test_select_median_boxes_equals_the_selector_and_its_index_chain(ops):
+    """as_select_median_boxes against roi_head.median_area_selector (stable argsort of the clamped areas, the (Lc-1)//2-th
+    entry) and the tensor ops it replaces around it: the chosen box, its row in the layer-major stack, `box // 16` and
+    `box.int()` -- bit for bit, with ties in the areas and degenerate (negative-extent) boxes."""
+    from attentionshift_amd.roi_head import median_area_selector
+    g = torch.Generator().manual_seed(41)
+    for counts, Lc in (((3, 3), 7), ((1, 5, 2), 4), ((7,), 7), ((2, 0, 4), 3), ((64, 33), 12)):
+        per_img, rows, meta, off = [], [], [], 0
+        for i, c in enumerate(counts):
+            lo = torch.randint(0, 300, (Lc, c, 2), generator=g).float()
+            ext = torch.randint(-20, 400, (Lc, c, 2), generator=g).float()
+            b = torch.cat((lo, lo + ext), dim=-1)                               # [Lc, c, 4], some x1 < x0
+            if c:
+                b[Lc // 2, 0] = b[0, 0]                                        # an exact tie of two layers
+            if Lc > 2 and c > 1:
+                b[1, 1], b[2, 1] = torch.tensor([5., 5, 9, 3]), torch.tensor([8., 8, 2, 30])   # two zero areas (clamped)
+            rows.append(b.reshape(-1, 4))
+            per_img.append(b.permute(1, 0, 2).contiguous())
+            meta += [[off, c, k] for k in range(c)]
+            off += Lc * c
+        boxes = torch.cat(rows)
+        pick, chosen, map_idx, patch, ints = ops.select_median_boxes(dev(boxes), dev(torch.tensor(meta, dtype=torch.int32)), Lc, 16)
+        ref_pick = torch.cat(median_area_selector(per_img))
+        assert_equal(ref_pick, pick, f"median-area layer, counts {counts}")
+        ref_box = torch.cat([per_img[i][torch.arange(c), p] for i, (c, p) in enumerate(zip(counts, ref_pick.split(counts)))])
+        assert_equal(ref_box, chosen, "chosen boxes")
+        ref_rows = torch.cat([m0 + p * c + torch.arange(c) for (c, p, m0) in
+                              zip(counts, ref_pick.split(counts), [sum(Lc * x for x in counts[:i]) for i in range(len(counts))])])
+        assert_equal(ref_rows.int(), map_idx, "rows of the layer-major stack")
+        assert_equal((ref_box // 16).int(), patch, "patch boxes")
+        assert_equal(ref_box.int(), ints, "integer crops")
+        assert_equal(boxes[map_idx.long().cpu()], chosen, "map_idx addresses the chosen box")
+
+
+def test_draw_distinct_reads_a_strided_count_table_and_ors_into_the_callers_flag(ops):
+    """as_draw_distinct on the transposed view of mask_candidates' planar count rows == on its contiguous copy, and the flag
+    is OR-ed into the slot the caller zeroed (neighbouring slots untouched)."""
+    g = torch.Generator().manual_seed(43)
+    for G in (1, 3, 7):
+        planar = torch.randint(200, 5000, (3, G), generator=g).int()
+        u = torch.rand(G, 32, generator=g)
+        slots = torch.zeros(4, dtype=torch.int32).cuda()
+        a = ops.draw_distinct(dev(planar)[:2].t(), dev(u), 10, flag=slots[3:4])
+        b = ops.draw_distinct(dev(planar[:2].t()), dev(u), 10)
+        for x, y, what in zip(a[:3], b[:3], ("rank_pos", "rank_neg", "is_pos")):
+            assert_equal(y.cpu(), x, f"{what}, G={G}")
+        assert slots.tolist() == [0, 0, 0, 0] and int(b[3]) == 0
+        planar[1, 0] = 3; planar[0, 0] = 2                                   # fewer than 4 K candidates: flag
+        a = ops.draw_distinct(dev(planar)[:2].t(), dev(u), 10, flag=slots[3:4])
+        assert slots.tolist() == [0, 0, 0, 1]
+        n_pos, n = int(planar[0, -1]), int(planar[0, -1] + planar[1, -1])
+        want = []
+        for v in (u[-1] * float(n)).int().clamp(max=n - 1).tolist():
+            if v not in want:
+                want.append(v)
+        want = torch.tensor((want + [0] * 10)[:10])                           # (fewer distinct draws than asked: rank 0 fill)
+        assert_equal(torch.where(want < n_pos, want, torch.zeros_like(want)).int(), a[0][-1], "positive ranks of the last object")
+        assert_equal(torch.where(want < n_pos, torch.zeros_like(want), want - n_pos).int(), a[1][-1], "negative ranks")
+
+
 def test_rank_draw_xy_equals_the_tensor_op_chain(ops):
     """as_rank_draw_xy (ranks derived in the selection kernel from the populations it counts) against the chain of tensor
     ops it replaces in the fast-RNG sampling paths (roi_head.sample_points_from_cams_nosync / grid_seed_nosync), bit for
