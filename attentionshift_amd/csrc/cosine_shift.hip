@@ -908,7 +908,8 @@ extern "C" int as_refine_similarity(const float* feat, const float* seeds, const
   if (lds > 48 * 1024)
     (void)hipFuncSetAttribute((const void*)refine_aggregate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 
-  (void)hipMemsetAsync(peak, 0, (size_t)2 * PMAX * 4, s);
+  // (the per-map peaks feed the aggregation of the NEXT level only: without refinement levels nothing reads them)
+  if (refine_times > 0) (void)hipMemsetAsync(peak, 0, (size_t)2 * PMAX * 4, s);
   const float* cur = seeds;
   for (int lvl = 0; lvl <= refine_times; ++lvl) {
     if (lvl > 0) {
@@ -920,7 +921,7 @@ extern "C" int as_refine_similarity(const float* feat, const float* seeds, const
                        maps + (size_t)lvl * Gp * Np, peak + (lvl & 1) * PMAX, G, Gp, C, Hp, Wp, is_select,
                        lvl > 0 ? 1 : 0);
   }
-  if (refine_times == 0)
+  if (refine_times == 0 && seeds_out != seeds)
     (void)hipMemcpyAsync(seeds_out, seeds, (size_t)Gp * C * 4, hipMemcpyDeviceToDevice, s);
   AS_CHECK_LAUNCH("refine_similarity");
   return AS_OK;

@@ -972,9 +972,11 @@ namespace {
 template <bool VEC>
 __global__ __launch_bounds__(RF_NT) void cand_max_kernel(const float* __restrict__ map_fg, const float* __restrict__ map_bg,
                                                          const int32_t* __restrict__ crops, unsigned* __restrict__ mx,
-                                                         int G, int H, int W) {
+                                                         int32_t* __restrict__ counts_zero, int G, int H, int W) {
   __shared__ float sh[RF_NT];
   const int g = blockIdx.y;
+  // the candidate counts are accumulated by the kernels launched AFTER this one: cleared here instead of by a fill launch
+  if (blockIdx.x == 0 && threadIdx.x < 3) counts_zero[threadIdx.x * G + g] = 0;
   const Crop c = load_crop(crops, g, H, W);
   const size_t base = (size_t)g * H * W;
   float vf = -INFINITY, vb = -INFINITY, va = -INFINITY;
@@ -1093,18 +1095,17 @@ extern "C" int as_mask_candidates(const float* map_fg, const float* map_bg, cons
   uint8_t* t1 = t0 + plane;
   unsigned* mx = (unsigned*)(t1 + plane);
   const int bx = (int)(((size_t)H * W + RF_NT * 4 - 1) / (RF_NT * 4));
-  (void)hipMemsetAsync(mx, 0, (size_t)3 * G * 4, s);
-  (void)hipMemsetAsync(counts, 0, (size_t)3 * G * 4, s);
+  (void)hipMemsetAsync(mx, 0, (size_t)3 * G * 4, s);            // (counts [3,G]: cleared by cand_max_kernel)
   // atomics per workgroup on a few words per object: keep the workgroup count per object small
   // 16-byte accesses when rows are a multiple of 4 pixels and every plane (maps and byte masks, G*H*W apart) stays aligned
   const bool vec = W % 4 == 0 && (((size_t)map_fg | (size_t)map_bg) % 16 == 0) &&
                    (((size_t)(k == 1 ? pos : t0) | (size_t)neg | (size_t)pseudo) % 4 == 0);
   if (vec) {
-    hipLaunchKernelGGL(cand_max_kernel<true>, dim3(bx < 256 ? bx : 256, G), dim3(RF_NT), 0, s, map_fg, map_bg, crops, mx, G, H, W);
+    hipLaunchKernelGGL(cand_max_kernel<true>, dim3(bx < 256 ? bx : 256, G), dim3(RF_NT), 0, s, map_fg, map_bg, crops, mx, counts, G, H, W);
     hipLaunchKernelGGL(cand_threshold_kernel<true>, dim3(bx < 256 ? bx : 256, G), dim3(RF_NT), 0, s, map_fg, map_bg, crops, mx,
                        pos_thr, neg_thr, mask_thr, k == 1 ? pos : t0, neg, pseudo, counts, G, H, W);
   } else {
-    hipLaunchKernelGGL(cand_max_kernel<false>, dim3(bx < 256 ? bx : 256, G), dim3(RF_NT), 0, s, map_fg, map_bg, crops, mx, G, H, W);
+    hipLaunchKernelGGL(cand_max_kernel<false>, dim3(bx < 256 ? bx : 256, G), dim3(RF_NT), 0, s, map_fg, map_bg, crops, mx, counts, G, H, W);
     hipLaunchKernelGGL(cand_threshold_kernel<false>, dim3(bx < 96 ? bx : 96, G), dim3(RF_NT), 0, s, map_fg, map_bg, crops, mx,
                        pos_thr, neg_thr, mask_thr, k == 1 ? pos : t0, neg, pseudo, counts, G, H, W);
   }

@@ -676,7 +676,8 @@ def refine_similarity(feat, seeds, boxes_patch, num_obj, refine_times, tau, is_s
     Np_, C = feat.shape
     Gp = seeds.shape[0]
     maps = torch.empty(refine_times + 1, Gp, Np_, device=feat.device, dtype=torch.float32)
-    seeds_out = torch.empty(Gp, C, device=feat.device, dtype=torch.float32)
+    # (no refinement level: the seeds come back unchanged -- passed as their own output, which the library does not copy)
+    seeds_out = seeds if refine_times == 0 else torch.empty(Gp, C, device=feat.device, dtype=torch.float32)
     nbytes = lib.as_refine_similarity_workspace_bytes(C, Np_, Gp)
     ws = torch.empty(nbytes, device=feat.device, dtype=torch.uint8)
     n_select = (Gp if is_select else 0) if isinstance(is_select, bool) else int(is_select)

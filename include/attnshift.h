@@ -375,7 +375,8 @@ int as_cosine_shift_strided(const float* feat, long long feat_batch_stride, cons
  *   n_select  the first n_select maps form the selection group of `is_select=True` (box masking of its first G maps,
  *             keep-the-winner among the group, :676-683 / :697-703); 0 = none (`is_select=False`), Gp = all, a value in
  *             between refines the foreground and the background seed sets of an image in ONE call (group first)
- *   maps   [R+1,Gp,Np] ;  seeds_out [Gp,C] = refined seed features of the last round */
+ *   maps   [R+1,Gp,Np] ;  seeds_out [Gp,C] = refined seed features of the last round (with refine_times = 0 a copy of
+ *   `seeds`, skipped when seeds_out == seeds) */
 size_t as_refine_similarity_workspace_bytes(int C, int Np, int Gp);
 int as_refine_similarity(const float* feat, const float* seeds, const int32_t* boxes, int G, int Gp,
                          int refine_times, float tau, int n_select, float* maps, float* seeds_out, void* ws,
