@@ -43,6 +43,7 @@ SIGNATURES = {
     "as_linear_bwd_workspace_bytes": (ctypes.c_size_t, [_c_int] * 3),
     "as_linear_bwd": (_c_int, [_c_void_p] * 6 + [_c_int] * 5 + [_c_void_p, ctypes.c_size_t, _c_void_p]),
     "as_linear_bwd_dgelu": (_c_int, [_c_void_p] * 7 + [_c_int] * 5 + [_c_void_p, ctypes.c_size_t, _c_void_p]),
+    "as_assemble_tokens": (_c_int, [_c_void_p] * 3 + [_c_int] * 5 + [_c_void_p]),
     "as_maxpool_nhwc": (_c_int, [_c_void_p] * 2 + [_c_int] * 5 + [ctypes.c_longlong, _c_void_p]),
     "as_mask_count": (_c_int, [_c_void_p] * 2 + [_c_int] * 2 + [_c_void_p]),
     "as_window_attn_bwd_workspace_bytes": (_c_size_t, [_c_int] * 5),

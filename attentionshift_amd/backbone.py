@@ -170,6 +170,14 @@ class VisionTransformerDet(nn.Module):
         self.defer_fpn = bool(unused.pop("defer_fpn", False))
         self._fpn_stream = None
         self._point_pack = None
+        # no-grad forward: the point head's seven small launches (200 tokens) on a side stream, next to whatever the caller
+        # queues after the forward; opt-in for the same reason: outputs_class / outputs_coord of such a forward are valid on
+        # the caller's stream only after it waits for out["point_head_ready"] (seed_pseudo_gt(point_ready=...) does).
+        # MEASURED SLOWER (round 5, same box, three alternations): 6.50-6.59 ms per step in line, 6.81-6.95 ms on the side
+        # stream -- like DeferredFPN, a second queue next to the RoI head's latency-bound chain costs more than the ~90 us
+        # of device time it takes off the caller's stream.  bench.py keeps it off (AS_POINT_HEAD_STREAM=1 turns it on).
+        self.point_head_stream = bool(unused.pop("point_head_stream", False))
+        self._point_stream = None
 
         self.patch_embed = PatchEmbed(img_size, patch_size, in_chans, embed_dim)
         n_patches = self.patch_embed.num_patches
@@ -402,13 +410,22 @@ class VisionTransformerDet(nn.Module):
         patches.copy_(img.reshape(B, C, hp, ps, wp, ps).permute(0, 2, 4, 1, 3, 5))
         wmat = self._derived(self.patch_embed.proj.weight, "patch", lambda t: t.reshape(self.embed_dim, -1))
         emb = ops.linear(patches.view(B, hp * wp, C * ps * ps), wmat, self.patch_embed.proj.bias.float())
-        pos = self.interpolate_pos_encoding(hp * wp, w, h)
-        T, Np = self.point_token.shape[1], hp * wp
-        x = torch.empty(B, 1 + Np + T, self.embed_dim, device=img.device, dtype=torch.float32)
-        torch.add(emb.float() if emb.dtype != torch.bfloat16 else emb, pos[:, 1:], out=x[:, 1:1 + Np])
-        x[:, :1] = self.cls_token + pos[:, :1]
-        x[:, 1 + Np:] = self.point_token + self.point_pos_embed
-        return x
+        # cls / position / point tokens: one constant table, added to the projection in one pass over the token tensor
+        return ops.assemble_tokens(emb, self._token_table(hp * wp, w, h))
+
+    def _token_table(self, Np, w, h):
+        """[1 + Np + T, D] fp32: cls_token + pos_0, the (interpolated) position embedding of the patches, point_token +
+        point_pos_embed -- what prepare_tokens adds around / to the patch projection; cached until a parameter changes."""
+        srcs = (self.pos_embed, self.cls_token, self.point_token, self.point_pos_embed)
+        stamp = tuple(t._version for t in srcs) + (Np, w, h, self.pos_embed.device)
+        hit = self._wcache.get("token_table")
+        if hit is None or hit[0] != stamp:
+            with torch.no_grad():
+                pos = self.interpolate_pos_encoding(Np, w, h)
+                table = torch.cat((self.cls_token + pos[:, :1], pos[:, 1:], self.point_token + self.point_pos_embed), dim=1)
+            hit = (stamp, table[0].float().contiguous())
+            self._wcache["token_table"] = hit
+        return hit[1]
 
     def _block(self, blk, x, delta, keep_state, need_x, on_full=None, full_out=None, x_out=None):
         """models/vision_transformer.py:109-124 with the residual stream kept in fp32 and every residual add fused into
@@ -596,7 +613,19 @@ class VisionTransformerDet(nn.Module):
         out = dict(org_feats=org_features, feature=features if isinstance(features, DeferredFPN) else tuple(features),
                    point_tokens=point_tokens)
         if self.with_point_head and not grad_path and point_tokens.is_cuda and self._point_head_packable(point_tokens):
-            cls, reg = self._point_head_packed(point_tokens)
+            if self.point_head_stream:
+                if self._point_stream is None:
+                    self._point_stream = torch.cuda.Stream()
+                main = torch.cuda.current_stream()
+                self._point_stream.wait_stream(main)
+                with torch.cuda.stream(self._point_stream):
+                    cls, reg = self._point_head_packed(point_tokens)
+                    out["point_head_ready"] = self._point_stream.record_event()
+                for t in (point_tokens, cls, reg):               # (allocator: both streams use these blocks)
+                    t.record_stream(main)
+                    t.record_stream(self._point_stream)
+            else:
+                cls, reg = self._point_head_packed(point_tokens)
             out.update(outputs_class=cls, outputs_coord=reg)
         elif self.with_point_head:
             out.update(outputs_class=self.class_embed(point_tokens), outputs_coord=self.bbox_embed(point_tokens).sigmoid())

@@ -380,3 +380,52 @@ extern "C" int as_maxpool_nhwc(const float* x, float* out, int B, int H, int W, 
   AS_CHECK_LAUNCH("maxpool_nhwc");
   return AS_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// Token assembly of prepare_tokens (visual_transformer_det.py:192-214): out[b, n] = table[n] (+ emb[b, n - 1] for the Np patch
+// rows 1..Np), table = [cls + pos_0 ; pos_1..Np ; point tokens + their position embedding] kept by the caller.  One pass over
+// the fp32 token tensor instead of an add and four slice writes.
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+template <typename T>
+__global__ __launch_bounds__(256) void assemble_tokens_kernel(const T* __restrict__ emb, const float* __restrict__ table,
+                                                              float* __restrict__ out, int B, int Np, int N, int D) {
+  const int D4 = D >> 2;
+  const size_t total = (size_t)B * N * D4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % D4) * 4;
+    const size_t r = i / D4;
+    const int n = (int)(r % N), b = (int)(r / N);
+    float4 v = *reinterpret_cast<const float4*>(table + (size_t)n * D + c);
+    if (n >= 1 && n <= Np) {
+      const T* e = emb + ((size_t)b * Np + (n - 1)) * D + c;
+      if (sizeof(T) == 2) {
+        const bf16x4 e4 = *reinterpret_cast<const bf16x4*>(e);
+        v.x = (float)e4[0] + v.x; v.y = (float)e4[1] + v.y; v.z = (float)e4[2] + v.z; v.w = (float)e4[3] + v.w;
+      } else {
+        const float4 e4 = *reinterpret_cast<const float4*>(e);
+        v.x = e4.x + v.x; v.y = e4.y + v.y; v.z = e4.z + v.z; v.w = e4.w + v.w;
+      }
+    }
+    *reinterpret_cast<float4*>(out + i * 4) = v;
+  }
+}
+}  // namespace
+
+extern "C" int as_assemble_tokens(const void* emb, const float* table, float* out, int B, int Np, int N, int D, int dtype,
+                                  as_stream_t stream) {
+  AS_REQUIRE(emb && table && out, AS_E_BADARG, "as_assemble_tokens: null pointer");
+  AS_REQUIRE(B > 0 && Np > 0 && N > Np && D > 0 && D % 4 == 0, AS_E_BADARG, "as_assemble_tokens: B=%d Np=%d N=%d D=%d", B, Np, N, D);
+  const size_t total = (size_t)B * N * (D / 4);
+  const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  if (dtype == AS_BF16)
+    hipLaunchKernelGGL(assemble_tokens_kernel<__bf16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const __bf16*)emb, table, out,
+                       B, Np, N, D);
+  else if (dtype == AS_F32)
+    hipLaunchKernelGGL(assemble_tokens_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)emb, table, out,
+                       B, Np, N, D);
+  else
+    AS_REQUIRE(false, AS_E_UNSUPPORTED, "as_assemble_tokens: dtype %d", dtype);
+  AS_CHECK_LAUNCH("assemble_tokens");
+  return AS_OK;
+}

@@ -279,6 +279,20 @@ def add_layernorm(x, delta, gamma, beta, eps, out_dtype, want_x=True, want_y=Tru
     return (xo if want_x else None), (None if y is None else y.reshape(x.shape))
 
 
+def assemble_tokens(emb, table):
+    """emb [B,Np,D] (fp32 / bf16), table [N,D] fp32 with N > Np -> x [B,N,D] fp32: x[:, 1:1+Np] = emb + table[1:1+Np], every
+    other row = table's (class token in front, point tokens behind; csrc/layernorm.hip as_assemble_tokens)."""
+    lib = _lib.load()
+    emb = emb.contiguous()
+    _chk(emb)
+    _chk(table, dtype=torch.float32)
+    B, Np, D = emb.shape
+    N = table.shape[0]
+    x = torch.empty(B, N, D, device=emb.device, dtype=torch.float32)
+    _lib.check(lib.as_assemble_tokens(_p(emb), _p(table), _p(x), B, Np, N, D, _dt(emb), _stream()), "as_assemble_tokens")
+    return x
+
+
 def maxpool_nhwc(x_nhwc, k):
     """nn.MaxPool2d(k, k) of a token-major fp32 map [B,H,W,C] -> [B,H/k,W/k,C] (csrc/layernorm.hip as_maxpool_nhwc).
     Every image must be dense ([H,W,C] contiguous); the images may be strided (the patch-token slice of [B,N,C])."""

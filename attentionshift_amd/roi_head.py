@@ -1317,12 +1317,16 @@ class AttnShiftRoIHead(nn.Module):
                         vit_feat=None, img=None, point_init=None, point_cls=None, point_reg=None, imgs_whwh=None,
                         attns=None, gt_points=None, gt_points_labels=None, roi_feature_map=None, return_mask=False,
                         pos_mask_thr=0.6, neg_mask_thr=0.1, num_mask_point_gt=10, corr_size=21, point_adjuster=None,
-                        edges=None, obj_tau=0.85, pos_inds=None, matched_gt=None, _mt_ok=True):
+                        edges=None, obj_tau=0.85, pos_inds=None, matched_gt=None, point_ready=None, _mt_ok=True):
         """stdroi:2209-2415.  Extra optional inputs `pos_inds` / `matched_gt` (per-image lists) bypass the
-        Hungarian matching when the caller already has it (fixtures, benchmarks)."""
+        Hungarian matching when the caller already has it (fixtures, benchmarks).  `point_ready`: the event behind which
+        point_cls / point_reg are valid when the backbone computed them on its side stream (point_head_stream); only their
+        shapes are read before it."""
         num_imgs = point_reg.size(0)
         num_proposals = point_cls.size(1)
         if pos_inds is None:
+            if point_ready is not None:
+                torch.cuda.current_stream().wait_event(point_ready)
             pa = getattr(self.train_cfg, "point_assigner", None) or {}
             pos_inds, matched_gt = [], []
             for i in range(num_imgs):

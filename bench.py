@@ -131,7 +131,8 @@ def build(device, rng_mode="fast", train=False, ranks=None, mil=False):
                                qkv_bias=True, drop_path_rate=0.05, out_indices=(3, 5, 7, 11) if CFG["depth"] == 12 else (5, 11, 17, 23),
                                learnable_pos_embed=True, use_checkpoint=True, last_feat=True,
                                point_tokens_num=CFG["point_tokens"], num_classes=CFG["num_classes"], return_attention=True,
-                               compute_dtype=torch.bfloat16, defer_fpn=not train and os.environ.get("AS_DEFER_FPN", "0") == "1"))
+                               compute_dtype=torch.bfloat16, defer_fpn=not train and os.environ.get("AS_DEFER_FPN", "0") == "1",
+                               point_head_stream=not train and os.environ.get("AS_POINT_HEAD_STREAM", "0") == "1"))
     bb = bb.to(device)
     bb = bb.train() if train else bb.eval()
 
@@ -185,7 +186,7 @@ def build(device, rng_mode="fast", train=False, ranks=None, mil=False):
     def pseudo_labels(out):
         return head.seed_pseudo_gt(out["feature"], metas, None, None, None, vit_feat=vit_feat, img=img,
                                    point_cls=out["outputs_class"], point_reg=out["outputs_coord"], attns=out["attns"],
-                                   gt_points=gt_points, gt_points_labels=gt_labels,
+                                   gt_points=gt_points, gt_points_labels=gt_labels, point_ready=out.get("point_head_ready"),
                                    roi_feature_map=out["feature"][2].float() if mil else None, **seed_kw)
 
     if not train:
@@ -194,6 +195,8 @@ def build(device, rng_mode="fast", train=False, ranks=None, mil=False):
             res = pseudo_labels(out)
             if hasattr(out["feature"], "result"):
                 out["feature"].result()                # the step ends with the FPN maps valid on the caller's stream
+            if "point_head_ready" in out:              # ... and the point head's outputs (queued on its own stream)
+                torch.cuda.current_stream().wait_event(out["point_head_ready"])
             return res
 
         step.head = head

@@ -195,6 +195,14 @@ int as_linear_bwd_dgelu(const void* x, const void* W, const void* dy, const void
 int as_maxpool_nhwc(const float* x, float* out, int B, int H, int W, int C, int k, long long x_batch_stride,
                     as_stream_t stream);
 
+/* Token assembly of prepare_tokens (mmdet/models/backbones/visual_transformer_det.py:192-214: patch embedding + position
+ * embedding, class token in front, point tokens + their position embedding behind): out [B,N,D] fp32,
+ *   out[b,n] = table[n] + emb[b,n-1]  for 1 <= n <= Np,   out[b,n] = table[n]  otherwise,
+ * emb [B,Np,D] (`dtype`), table [N,D] fp32 = [cls + pos_0 ; pos_1..Np ; point_token + point_pos_embed] (the caller's
+ * constant).  D % 4 == 0. */
+int as_assemble_tokens(const void* emb, const float* table, float* out, int B, int Np, int N, int D, int dtype,
+                       as_stream_t stream);
+
 /* Backward of as_add_layernorm for the trainable path.  x [M,D] fp32 = the x_out the forward wrote (x_in + delta); dy
  * [M,D] in `dtype` = gradient of y_out (NULL: the call was add-only); dx_res [M,D] fp32 = gradient of x_out from the
  * residual stream (NULL: none); gamma fp32 [D].  Writes dx_out [M,D] fp32 (gradient of x_in) and / or ddelta_out [M,D]

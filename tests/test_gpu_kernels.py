@@ -1135,6 +1135,22 @@ def test_merge_parts_equals_the_tensor_op_chain(ops):
                     assert_close(ref_o[i], merged[i, :n], 1e-5, 1e-6, f"object {i}: merged prototypes vs oracle")
 
 
+def test_assemble_tokens_equals_the_add_and_slice_writes(ops):
+    """as_assemble_tokens against prepare_tokens' tensor ops (visual_transformer_det.py:192-214): bit for bit, bf16 and fp32
+    projections, several token counts."""
+    g = torch.Generator().manual_seed(47)
+    for B, Np, T, D, dt in ((2, 4096, 100, 768, torch.bfloat16), (1, 196, 5, 64, torch.float32), (3, 49, 1, 192, torch.bfloat16)):
+        emb = torch.randn(B, Np, D, generator=g).to(dt)
+        pos = torch.randn(1, 1 + Np, D, generator=g)
+        cls, pt, ptpos = torch.randn(1, 1, D, generator=g), torch.randn(1, T, D, generator=g), torch.randn(1, T, D, generator=g)
+        ref = torch.empty(B, 1 + Np + T, D)
+        torch.add(emb.float(), pos[:, 1:], out=ref[:, 1:1 + Np])
+        ref[:, :1] = cls + pos[:, :1]
+        ref[:, 1 + Np:] = pt + ptpos
+        table = torch.cat((cls + pos[:, :1], pos[:, 1:], pt + ptpos), dim=1)[0].contiguous()
+        assert_equal(ref, ops.assemble_tokens(dev(emb), dev(table)), f"token tensor B={B} Np={Np} T={T} D={D} {dt}")
+
+
 def test_select_median_boxes_equals_the_selector_and_its_index_chain(ops):
     """as_select_median_boxes against roi_head.median_area_selector (stable argsort of the clamped areas, the (Lc-1)//2-th
     entry) and the tensor ops it replaces around it: the chosen box, its row in the layer-major stack, `box // 16` and

@@ -96,6 +96,27 @@ def test_deferred_fpn_is_the_same_maps(golden):
     assert isinstance(bb(img)["feature"], tuple)
 
 
+def test_point_head_on_its_side_stream_is_the_same_outputs(golden):
+    """VisionTransformerDet.point_head_stream: class / coordinate outputs queued on the backbone's side stream are
+    bit-identical to the in-line ones once the caller has waited for out["point_head_ready"], with the caller's stream busy
+    and the forward repeated (the token tensor's block is reused) in between."""
+    g = golden("backbone_tiny224")
+    bb, img, cfg = build_backbone(g, torch.bfloat16)
+    ref = bb(img)
+    assert "point_head_ready" not in ref
+    ref_cls, ref_reg = ref["outputs_class"].clone(), ref["outputs_coord"].clone()
+    bb.point_head_stream = True
+    busy = torch.randn(2048, 2048, device="cuda")
+    for _ in range(3):
+        out = bb(img)
+        for _ in range(4):
+            busy = busy @ busy * 1e-3
+        torch.cuda.current_stream().wait_event(out["point_head_ready"])
+        assert torch.equal(out["outputs_class"], ref_cls) and torch.equal(out["outputs_coord"], ref_reg)
+    bb.point_head_stream = False
+    assert "point_head_ready" not in bb(img)
+
+
 @pytest.mark.parametrize("tag", ["tiny224", "mid320"])
 def test_seed_pseudo_gt_chain_matches_reference(golden, tag, monkeypatch):
     import attentionshift_amd as A
