@@ -1084,7 +1084,7 @@ class AttnShiftRoIHead(nn.Module):
         return pout.flatten(0, 1), sim.reshape(-1, hp, wp).clamp(0)
 
     def mean_shift_batch(self, coords_list, feats_list, rois_list, n_shift, tau=0.1, temp=0.1, feat_tok=None,
-                         box_patch_list=None, seed_ids=None, clamp=True):
+                         box_patch_list=None, seed_ids=None, clamp=True, box_patch_all=None):
         """mean_shift_grid_prototype for every image of the batch in ONE as_cosine_shift call (coords_list[i] =
         grid_seed_coords of image i; the objects carry their
         image index; the kernels are batched over objects, and a call's latency does not depend on how many objects it
@@ -1101,9 +1101,12 @@ class AttnShiftRoIHead(nn.Module):
         else:
             prot = torch.cat([feat.permute(1, 2, 0)[coords[..., 0], coords[..., 1]]
                               for coords, feat in zip(coords_list, feats_list)]).contiguous()
-        if box_patch_list is None:
-            box_patch_list = [(rois // STRIDE).to(torch.int32) for rois in rois_list]
-        boxes = torch.cat(box_patch_list).contiguous() if len(box_patch_list) > 1 else box_patch_list[0].contiguous()
+        if box_patch_all is not None:                        # the batch's patch boxes in one tensor already (image order)
+            boxes = box_patch_all
+        else:
+            if box_patch_list is None:
+                box_patch_list = [(rois // STRIDE).to(torch.int32) for rois in rois_list]
+            boxes = torch.cat(box_patch_list).contiguous() if len(box_patch_list) > 1 else box_patch_list[0].contiguous()
         owners = _const_tensor(("owners", sizes), dev,
                                lambda: torch.cat([torch.full((n,), i, dtype=torch.int32) for i, n in enumerate(sizes)]))
         pout, sim = ops.cosine_shift(feat_tok, boxes, owners, prot, n_shift, hp, wp, tau, temp)
@@ -1397,7 +1400,7 @@ class AttnShiftRoIHead(nn.Module):
             off += n
 
         CLOCK.mark("box_split")
-        sel_rows = sel_patch = sel_int = None
+        sel_rows = sel_patch = sel_int = sel_patch_all = None
         if fused_sel:
             meta = _const_tensor(("select_meta", tuple(counts), Lc), boxes.device, lambda: torch.tensor(
                 [[cam_off[i], counts[i], g] for i in range(num_imgs) for g in range(counts[i])], dtype=torch.int32))
@@ -1405,6 +1408,7 @@ class AttnShiftRoIHead(nn.Module):
                                                                       bad=flag_all[4 * num_imgs:])
             gt_box_index, pseudo_boxes = list(pick.split(counts)), list(chosen.split(counts))
             sel_rows, sel_patch, sel_int = rows.split(counts), patch.split(counts), ints.split(counts)
+            sel_patch_all = patch
         else:
             gt_box_index = self.layer_selector(gt_scale_bboxes, gt_labels, roi_feature_map)
             pseudo_boxes = [gt_scale_bboxes[i][_const_tensor(("arange", counts[i]), boxes.device,
@@ -1549,7 +1553,7 @@ class AttnShiftRoIHead(nn.Module):
                         main.wait_stream(st)
             shifted = self.mean_shift_batch([r[6][1] for r in ra], feats, pseudo_boxes, self.mean_shift_times_local,
                                             feat_tok=feat_tok, box_patch_list=[r[9] for r in ra], seed_ids=seed_ids,
-                                            clamp=False)       # (the only consumer thresholds the maps at 0.8: no clamp(0))
+                                            clamp=False, box_patch_all=sel_patch_all)       # (the only consumer thresholds the maps at 0.8: no clamp(0))
 
             def chain_issue(i):
                 prot, sim = shifted[i]

@@ -36,7 +36,7 @@ def main():
             setattr(RH, name, scoped(getattr(RH, name), name))
     head = step.head
     for name in ("rollout_cams", "refine_maps", "_semantic_pre", "mean_shift_batch", "_semantic_post_issue",
-                 "_semantic_post_finish", "layer_selector"):
+                 "_semantic_post_finish"):         # (not layer_selector: the head fuses the default selector by identity)
         if hasattr(head, name):
             setattr(head, name, scoped(getattr(head, name), name))
     from attentionshift_amd import ops as OPS
