@@ -32,5 +32,6 @@ timeout 120 python tools/experiments/power_probe.py 2>&1 | grep kernel > gpurun_
 timeout 200 python tools/experiments/shift_timeline.py run --md gpurun_out/${R}_shift_timeline.md > gpurun_out/${R}_shift_timeline.log 2>&1
 timeout 300 python tools/experiments/glue_sites.py --steps 3 --rows 200 > gpurun_out/${R}_glue_sites.log 2>&1
 [ -d _r04 ] && bash tools/experiments/r05_ab.sh > gpurun_out/${R}_ab_vs_r04.log 2>&1
+timeout 300 python tools/experiments/step_trace.py > gpurun_out/${R}_step_trace.log 2>&1 && cp gpurun_out/step_timeline.txt gpurun_out/${R}_step_timeline.txt
 ls gpurun_out | grep ${R}_
 cat gpurun_out/${R}_bench_wall.txt
