@@ -94,7 +94,7 @@ SIGNATURES = {
     "as_rank_select": (_c_int, [_c_void_p] * 4 + [_c_size_t] + [_c_int] * 3 + [_c_void_p]),
     "as_rank_select_xy": (_c_int, [_c_void_p] * 4 + [_c_size_t] + [_c_int] * 5 + [_c_void_p]),
     "as_merge_parts": (_c_int, [_c_void_p] * 2 + [_c_float] + [_c_void_p] * 3 + [_c_int] * 4 + [_c_void_p]),
-    "as_select_median_boxes": (_c_int, [_c_void_p] * 2 + [_c_int] * 2 + [_c_void_p] * 7 + [_c_int, _c_void_p]),
+    "as_select_median_boxes": (_c_int, [_c_void_p] * 2 + [_c_int] * 2 + [_c_void_p] * 8 + [_c_int, _c_void_p]),
     "as_rank_draw_xy": (_c_int, [_c_void_p, _c_int] + [_c_void_p] * 4 + [_c_int, _c_int, ctypes.c_int64, _c_int, _c_void_p, _c_size_t]
                         + [_c_int] * 5 + [_c_void_p]),
     "as_instance_maps": (_c_int, [_c_void_p] * 2 + [_c_int] * 6 + [_c_void_p] * 3 + [_c_size_t, _c_void_p]),

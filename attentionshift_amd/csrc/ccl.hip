@@ -550,7 +550,7 @@ __global__ __launch_bounds__(CC_NT) void cam_sample_masks_kernel(const float* __
   if (c_supp) atomicAdd(&cnt_s[2 * G], c_supp);
   __syncthreads();
   for (int k = tid; k < 2 * G + 1; k += CC_NT)
-    if (cnt_s[k]) atomicAdd(&counts[k], cnt_s[k]);
+    if (counts && cnt_s[k]) atomicAdd(&counts[k], cnt_s[k]);
 }
 
 inline int blocks_for(size_t total) { return (int)((total + CC_NT - 1) / CC_NT); }
@@ -637,14 +637,14 @@ extern "C" size_t as_cam_sample_masks_workspace_bytes(int G, int Hp, int Wp, int
 extern "C" int as_cam_sample_masks(const float* cams, const int32_t* map_idx, const float* minmax, int G, int Hp, int Wp,
                                    int up, float thr_bg, float thr_fg, uint8_t* masks, int32_t* counts, void* ws,
                                    size_t ws_bytes, as_stream_t stream) {
-  AS_REQUIRE(cams && map_idx && minmax && masks && counts, AS_E_BADARG, "as_cam_sample_masks: null pointer");
+  AS_REQUIRE(cams && map_idx && minmax && masks, AS_E_BADARG, "as_cam_sample_masks: null pointer");
   AS_REQUIRE(G > 0 && G <= 32 && Hp > 0 && Wp > 0 && up > 0 && up % 4 == 0, AS_E_UNSUPPORTED,
              "as_cam_sample_masks: G=%d maps (max 32), scale %d must be a multiple of 4", G, up);
   const size_t need = as_cam_sample_masks_workspace_bytes(G, Hp, Wp, up);
   AS_REQUIRE(ws_bytes >= need && (ws || !need), AS_E_WORKSPACE, "as_cam_sample_masks: workspace %zu < %zu bytes",
              ws_bytes, need);
   hipStream_t s = (hipStream_t)stream;
-  (void)hipMemsetAsync(counts, 0, (size_t)(2 * G + 1) * 4, s);
+  if (counts) (void)hipMemsetAsync(counts, 0, (size_t)(2 * G + 1) * 4, s);   // (NULL: a caller that counts the rows itself)
   // one atomic per counter per workgroup (256 workgroups at 1024 rows)
   hipLaunchKernelGGL(cam_sample_masks_kernel, dim3(as_ceil_div(Hp * up, CSM_RB)), dim3(CC_NT), 0, s, cams, map_idx,
                      minmax, G, Hp, Wp, up, thr_bg, thr_fg, masks, counts, (float*)ws);

@@ -650,7 +650,8 @@ extern "C" int as_merge_parts(const float* prot, const uint8_t* keep, float thr,
 // =====================================================================================================
 namespace {
 __global__ void select_median_boxes_kernel(const float* __restrict__ boxes, const int32_t* __restrict__ meta, int Lc, float stride,
-                                           int64_t* __restrict__ pick, float* __restrict__ chosen,
+                                           const int64_t* __restrict__ pick_in, int64_t* __restrict__ pick,
+                                           float* __restrict__ chosen,
                                            int32_t* __restrict__ map_idx, int32_t* __restrict__ box_patch,
                                            int32_t* __restrict__ box_int, const int32_t* __restrict__ status,
                                            int32_t* __restrict__ bad, int n) {
@@ -659,8 +660,8 @@ __global__ void select_median_boxes_kernel(const float* __restrict__ boxes, cons
   const int off = meta[3 * o], cnt = meta[3 * o + 1], g = meta[3 * o + 2];
   const float4* b = reinterpret_cast<const float4*>(boxes);
   const int want = (Lc - 1) / 2;
-  int sel = 0;
-  for (int l = 0; l < Lc; ++l) {
+  int sel = pick_in ? min(max((int)pick_in[o], 0), Lc - 1) : 0;      // (a selector's own choice: only the indexing is done here)
+  for (int l = 0; l < Lc && !pick_in; ++l) {
     const float4 bl = b[off + l * cnt + g];
     const float al = fmaxf(bl.z - bl.x, 0.f) * fmaxf(bl.w - bl.y, 0.f);
     int rank = 0;
@@ -687,14 +688,15 @@ __global__ void select_median_boxes_kernel(const float* __restrict__ boxes, cons
 }
 }  // namespace
 
-extern "C" int as_select_median_boxes(const float* boxes, const int32_t* meta, int Lc, int stride, int64_t* pick, float* chosen,
+extern "C" int as_select_median_boxes(const float* boxes, const int32_t* meta, int Lc, int stride, const int64_t* pick_in,
+                                      int64_t* pick, float* chosen,
                                       int32_t* map_idx, int32_t* box_patch, int32_t* box_int, const int32_t* status,
                                       int32_t* bad, int n, as_stream_t stream) {
   AS_REQUIRE(boxes && meta && pick && chosen && map_idx && box_patch, AS_E_BADARG, "as_select_median_boxes: null pointer");
   AS_REQUIRE(n > 0 && Lc > 0 && Lc <= 64 && stride > 0, AS_E_UNSUPPORTED, "as_select_median_boxes: n=%d Lc=%d stride=%d", n, Lc, stride);
   AS_REQUIRE(!status || bad, AS_E_BADARG, "as_select_median_boxes: status without a flag to raise");
   hipLaunchKernelGGL(select_median_boxes_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, boxes, meta, Lc,
-                     (float)stride, pick, chosen, map_idx, box_patch, box_int, status, bad, n);
+                     (float)stride, pick_in, pick, chosen, map_idx, box_patch, box_int, status, bad, n);
   AS_CHECK_LAUNCH("select_median_boxes");
   return AS_OK;
 }
@@ -753,8 +755,8 @@ __global__ __launch_bounds__(RF_NT) void semantic_prestage_kernel(const float* _
     const int lane = threadIdx.x & 63;
     const int g_first = __shfl(g, 0), g_last = __shfl(g, 48);
     if (g_first == g_last) {
-      if (lane == 0) atomicAdd(&counts[g_first], __popcll(b));
-    } else if (live && r == 0 && m) {
+      if (lane == 0 && counts) atomicAdd(&counts[g_first], __popcll(b));
+    } else if (live && r == 0 && m && counts) {
       atomicAdd(&counts[g], 1);
     }
   }
@@ -764,11 +766,11 @@ __global__ __launch_bounds__(RF_NT) void semantic_prestage_kernel(const float* _
 
 extern "C" int as_semantic_prestage(const float* map_fg, float thr, int k, int G, int Hp, int Wp, int up, float* fg_inter,
                                     uint8_t* mask, int32_t* counts, as_stream_t stream) {
-  AS_REQUIRE(map_fg && fg_inter && mask && counts, AS_E_BADARG, "as_semantic_prestage: null pointer");
+  AS_REQUIRE(map_fg && fg_inter && mask, AS_E_BADARG, "as_semantic_prestage: null pointer");
   AS_REQUIRE(G > 0 && Hp > 0 && Wp > 0 && up >= 2 && up % 2 == 0 && k >= 1 && (k & 1) == 1 && k <= 15, AS_E_UNSUPPORTED,
              "as_semantic_prestage: even scale >= 2 and odd erosion size <= 15 (got %d, %d)", up, k);
   hipStream_t s = (hipStream_t)stream;
-  (void)hipMemsetAsync(counts, 0, (size_t)G * 4, s);
+  if (counts) (void)hipMemsetAsync(counts, 0, (size_t)G * 4, s);     // (NULL: a caller that does not read the counts)
   const size_t threads = (size_t)G * Hp * Wp * 16;
   hipLaunchKernelGGL(semantic_prestage_kernel, dim3((unsigned)((threads + RF_NT - 1) / RF_NT)), dim3(RF_NT), 0, s, map_fg,
                      thr, G, Hp, Wp, up, k, fg_inter, mask, counts);

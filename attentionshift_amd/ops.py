@@ -603,16 +603,17 @@ def cam_boxes(cams, points, cam_thr, area_ratio, up=16, return_upsampled=False, 
     return (boxes, status, minmax) if return_minmax else (boxes, status)
 
 
-def cam_sample_masks(cams, map_idx, minmax, thr_bg, thr_fg, up=16):
+def cam_sample_masks(cams, map_idx, minmax, thr_bg, thr_fg, up=16, want_counts=True):
     """cams [M,Hp,Wp] fp32, map_idx [G] int32, minmax [M,2] -> (masks [2G+1, H, W] uint8, counts [2G+1] int32):
-    the background / foreground / shared-background candidate masks of the seed sampling (stdroi:1003-1007)."""
+    the background / foreground / shared-background candidate masks of the seed sampling (stdroi:1003-1007).
+    want_counts=False: counts is None (the selection kernel behind it counts the rows anyway: no fill, no atomics)."""
     lib = _lib.load()
     _chk(cams, minmax, dtype=torch.float32)
     _chk(map_idx, dtype=torch.int32)
     M, Hp, Wp = cams.shape
     G = map_idx.shape[0]
     masks = torch.empty(2 * G + 1, Hp * up, Wp * up, device=cams.device, dtype=torch.uint8)
-    counts = torch.empty(2 * G + 1, device=cams.device, dtype=torch.int32)
+    counts = torch.empty(2 * G + 1, device=cams.device, dtype=torch.int32) if want_counts else None
     nbytes = lib.as_cam_sample_masks_workspace_bytes(G, Hp, Wp, up)
     ws = torch.empty(nbytes, device=cams.device, dtype=torch.uint8) if nbytes else None
     _lib.check(lib.as_cam_sample_masks(_p(cams), _p(map_idx), _p(minmax), G, Hp, Wp, up, float(thr_bg), float(thr_fg),
@@ -620,8 +621,8 @@ def cam_sample_masks(cams, map_idx, minmax, thr_bg, thr_fg, up=16):
     return masks, counts
 
 
-def semantic_prestage(map_fg, thr, k=11, up=16):
-    """map_fg [G,H,W] fp32 -> (fg_inter [G,H/up,W/up] fp32, mask uint8 same shape, counts [G] int32):
+def semantic_prestage(map_fg, thr, k=11, up=16, want_counts=True):
+    """map_fg [G,H,W] fp32 -> (fg_inter [G,H/up,W/up] fp32, mask uint8 same shape, counts [G] int32 | None):
     bilinear down-sampling of erode_k(map_fg > thr), its > thr binarisation and the per-object counts."""
     lib = _lib.load()
     _chk(map_fg, dtype=torch.float32)
@@ -629,7 +630,7 @@ def semantic_prestage(map_fg, thr, k=11, up=16):
     hp, wp = H // up, W // up
     fg_inter = torch.empty(G, hp, wp, device=map_fg.device, dtype=torch.float32)
     mask = torch.empty(G, hp, wp, device=map_fg.device, dtype=torch.uint8)
-    counts = torch.empty(G, device=map_fg.device, dtype=torch.int32)
+    counts = torch.empty(G, device=map_fg.device, dtype=torch.int32) if want_counts else None
     _lib.check(lib.as_semantic_prestage(_p(map_fg), float(thr), int(k), G, hp, wp, up, _p(fg_inter), _p(mask), _p(counts),
                                         _stream()), "as_semantic_prestage")
     return fg_inter, mask, counts
@@ -922,21 +923,25 @@ def merge_parts(prot, keep, thr, slots, flag=None):
     return merged, ngroups
 
 
-def select_median_boxes(boxes, meta, Lc, stride, status=None, bad=None):
+def select_median_boxes(boxes, meta, Lc, stride, status=None, bad=None, pick_in=None):
     """boxes [rows,4] fp32 (every image's CAM boxes layer-major), meta [n,3] int32 = (image's first row, objects in the image,
     index in the image) -> (pick [n] int64, chosen [n,4] fp32, map_idx [n] int32, box_patch [n,4] int32, box_int [n,4]
     int32): the median-area layer per object, its box, that box's row in `boxes`, floor(box / stride) and the box truncated
     to integers (as_select_median_boxes).  With `status` ([rows] int32 of cam_boxes) the zeroed int32 slot `bad` is OR-ed
-    with 1 if any box of a listed object has status <= 0."""
+    with 1 if any box of a listed object has status <= 0.  `pick_in` [n] int64: another selector's layer choice (the median
+    rule is then skipped; `pick` returns it clamped to [0, Lc))."""
     lib = _lib.load()
     _chk(boxes, dtype=torch.float32)
     _chk(meta, status, bad, dtype=torch.int32)
+    _chk(pick_in, dtype=torch.int64)
     n = meta.shape[0]
     pick = torch.empty(n, device=boxes.device, dtype=torch.int64)
     chosen = torch.empty(n, 4, device=boxes.device, dtype=torch.float32)
     map_idx = torch.empty(n, device=boxes.device, dtype=torch.int32)
     ints = torch.empty(2, n, 4, device=boxes.device, dtype=torch.int32)
-    _lib.check(lib.as_select_median_boxes(_p(boxes), _p(meta), int(Lc), int(stride), _p(pick), _p(chosen), _p(map_idx),
+    if pick_in is not None and pick_in.numel() != n:
+        raise AttnShiftError(f"select_median_boxes: {pick_in.numel()} choices for {n} objects")
+    _lib.check(lib.as_select_median_boxes(_p(boxes), _p(meta), int(Lc), int(stride), _p(pick_in), _p(pick), _p(chosen), _p(map_idx),
                                           _p(ints[0]), _p(ints[1]), _p(status), _p(bad), n, _stream()),
                "as_select_median_boxes")
     return pick, chosen, map_idx, ints[0], ints[1]

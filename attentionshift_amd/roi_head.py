@@ -340,11 +340,12 @@ def sample_points_from_cams_nosync(cams_lr, map_idx, minmax, num_points, gen, th
     populations it counts anyway (ops.rank_draw_xy: one launch pair instead of the eight tensor ops below).
     `u` [2G+1, num_points]: the uniform numbers, if the caller drew them already (one draw for the batch)."""
     G = map_idx.shape[0]
-    masks, counts = ops.cam_sample_masks(cams_lr, map_idx, minmax, thr_bg, thr_fg, STRIDE)
+    in_kernel = flag is not None and (cams_lr.shape[-1] * cams_lr.shape[-2] * STRIDE * STRIDE) % 16 == 0
+    masks, counts = ops.cam_sample_masks(cams_lr, map_idx, minmax, thr_bg, thr_fg, STRIDE, want_counts=not in_kernel)
     W = masks.shape[-1]
     if u is None:
         u = torch.rand(2 * G + 1, num_points, device=masks.device, generator=gen)
-    if flag is not None and (masks.shape[-1] * masks.shape[-2]) % 16 == 0:
+    if in_kernel:
         # also the token index of every drawn pixel, rows rotated to [fg objects, shared background, bg objects]: the
         # gather index of the seed features (seed_features' `// 16`, clamp and cat chain)
         pts, pidx = ops.rank_draw_xy(masks.flatten(1), num_points, W, u=u, flag=flag, patch=(None, STRIDE, W // STRIDE, 0, G))
@@ -1140,12 +1141,13 @@ class AttnShiftRoIHead(nn.Module):
             self._dev_gens[key].manual_seed(int(torch.randint(2 ** 62, (1,)).item()))
         return self._dev_gens[key]
 
-    def _semantic_pre(self, map_cos_fg, map_cos_bg, pos_thr, float_map=True):
+    def _semantic_pre(self, map_cos_fg, map_cos_bg, pos_thr, float_map=True, want_counts=True):
         """First part of get_semantic_centers (stdroi:2011-2020): the patch-grid foreground maps, one fused launch
         (ops.semantic_prestage).  The reference also down-samples max_g(map_cos_bg) here (bg_inter, :2013), but its
         only consumer is commented out (filter_maps :267), so it is not computed.  Returns fg_inter, the binary
         patch map (float, as the reference), and (mask uint8, counts) of its positives for the grid seeds."""
-        fg_inter, mask, counts = ops.semantic_prestage(map_cos_fg.contiguous(), pos_thr, 11, STRIDE)
+        kw = {} if want_counts else dict(want_counts=False)   # (only the sync-free path asks the kernel to skip the counting)
+        fg_inter, mask, counts = ops.semantic_prestage(map_cos_fg.contiguous(), pos_thr, 11, STRIDE, **kw)
         CLOCK.mark("  sc:prestage")
         return fg_inter, (mask.to(fg_inter.dtype) if float_map else None), (mask, counts)
 
@@ -1377,10 +1379,12 @@ class AttnShiftRoIHead(nn.Module):
         # the default selector (median box area over the roll-out depths) with its index arithmetic as ONE launch for the batch:
         # the chosen layer, its box, that box's row of the CAM stack, its patch box -- and the CAM check above
         # (csrc/refine.hip select_median_boxes)
-        fused_sel = (self.layer_selector is median_area_selector and boxes.is_cuda and sum(counts) > 0
-                     and os.environ.get("AS_HEAD_TENSOR_GLUE") != "1")
+        # Any other selector (the trained MIL head) still makes its choice itself -- from the per-image box lists -- and only
+        # the indexing behind it runs in the kernel (`pick_in`).
+        fused_idx = boxes.is_cuda and sum(counts) > 0 and os.environ.get("AS_HEAD_TENSOR_GLUE") != "1"
+        fused_sel = fused_idx and self.layer_selector is median_area_selector
         flag_all = None
-        if fused_sel:
+        if fused_idx:
             # one zero fill for every device flag of the call: 4 slots per image (raised by the selection kernels of the
             # sync-free path) + the CAM check
             flag_all = torch.zeros(4 * num_imgs + 1, dtype=torch.int32, device=boxes.device)
@@ -1401,12 +1405,19 @@ class AttnShiftRoIHead(nn.Module):
 
         CLOCK.mark("box_split")
         sel_rows = sel_patch = sel_int = sel_patch_all = None
-        if fused_sel:
+        if fused_idx:
             meta = _const_tensor(("select_meta", tuple(counts), Lc), boxes.device, lambda: torch.tensor(
                 [[cam_off[i], counts[i], g] for i in range(num_imgs) for g in range(counts[i])], dtype=torch.int32))
+            pick_in = None
+            if not fused_sel:
+                gt_box_index = self.layer_selector(gt_scale_bboxes, gt_labels, roi_feature_map)
+                pick_in = (torch.cat([g.long() for g in gt_box_index]) if num_imgs > 1 else gt_box_index[0].long())
+                pick_in = pick_in.to(boxes.device).contiguous()
             pick, chosen, rows, patch, ints = ops.select_median_boxes(boxes, meta, Lc, STRIDE, status=status,
-                                                                      bad=flag_all[4 * num_imgs:])
-            gt_box_index, pseudo_boxes = list(pick.split(counts)), list(chosen.split(counts))
+                                                                      bad=flag_all[4 * num_imgs:], pick_in=pick_in)
+            if fused_sel:
+                gt_box_index = list(pick.split(counts))
+            pseudo_boxes = list(chosen.split(counts))
             sel_rows, sel_patch, sel_int = rows.split(counts), patch.split(counts), ints.split(counts)
             sel_patch_all = patch
         else:
@@ -1475,7 +1486,10 @@ class AttnShiftRoIHead(nn.Module):
             # what the batched mean shift (caller's stream) waits for comes FIRST -- the patch-grid foreground and the grid seeds
             # -- and is marked with an event; the mask candidates, mask points and the pseudo-mask copy (B2', B6: ~130 us of
             # launches nothing in the semantic chain reads) are queued behind it and run under the mean shift
-            fg_inter, _map_fg_patch, gs = self._semantic_pre(map_fg[-1], map_bg[-1], pos_mask_thr, float_map=False)
+            # (with a flag slot and a 16-divisible patch grid the selection kernel counts the seeds' candidates itself)
+            fg_inter, _map_fg_patch, gs = self._semantic_pre(
+                map_fg[-1], map_bg[-1], pos_mask_thr, float_map=False,
+                want_counts=flag_slots is None or (patch_h * patch_w) % 16 != 0)
             seeds, f2 = grid_seed_nosync(gs[0], gs[1], 20, flag=None if flag_slots is None else flag_slots[i, 1:2],
                                          patch=None if seed_ids is None else (seed_ids[obj_off[i]:obj_off[i] + counts[i]],
                                                                               i * _token_row_stride(feat_tok)))

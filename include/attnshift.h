@@ -282,7 +282,7 @@ int as_cam_boxes(const float* cams /*[M,Hp,Wp]*/, const float* points /*[M,2] (x
  *   nm_g = (up(cams[map_idx[g]]) - min) / (max - min)   with (min, max) = minmax[map_idx[g]] of as_cam_boxes
  *   masks [2G+1, H*W] uint8: rows 0..G-1  nm_g < thr_bg,  rows G..2G-1  nm_g >= thr_fg,
  *                            row 2G       mean_g(nm_g) < thr_bg
- *   counts [2G+1] int32: set pixels per row (written by the call).
+ *   counts [2G+1] int32: set pixels per row (written by the call); may be NULL (no counting, no fill launch).
  * The upsampled maps are never materialised (same bilinear arithmetic as as_cam_boxes). */
 size_t as_cam_sample_masks_workspace_bytes(int G, int Hp, int Wp, int up);     /* 0 for G <= 8 */
 int as_cam_sample_masks(const float* cams /*[M,Hp,Wp]*/, const int32_t* map_idx /*[G]*/,
@@ -348,7 +348,8 @@ int as_merge_plan(const uint8_t* keep, const uint8_t* link, int32_t* groups, int
 
 /* Patch-grid foreground of get_semantic_centers (stdroi:2011-2012, 2020), one launch:
  *   fg_inter [G,Hp*Wp] = bilinear x(1/up) of erode_k(map_fg > thr)   (map_fg [G, Hp*up, Wp*up])
- *   mask     [G,Hp*Wp] uint8 = fg_inter > thr,  counts [G] = set entries per object (the grid-seed candidates, :1784) */
+ *   mask     [G,Hp*Wp] uint8 = fg_inter > thr,  counts [G] = set entries per object (the grid-seed candidates, :1784);
+ *   counts may be NULL (no counting, no fill launch) */
 int as_semantic_prestage(const float* map_fg, float thr, int k, int G, int Hp, int Wp, int up, float* fg_inter,
                          uint8_t* mask, int32_t* counts, as_stream_t stream);
 
@@ -434,13 +435,14 @@ int as_merge_parts(const float* prot, const uint8_t* keep, float thr, float* mer
 /* The default layer selector and its index arithmetic in one launch (roi_head.median_area_selector standing in for the MIL
  * head's choice, stdroi:2953-2972; the patch box of stdroi:1812): per object o with meta[o] = (first row of its image in
  * `boxes`, objects in that image, index in the image) and the image's boxes layer-major ([Lc, cnt, 4] from as_cam_boxes),
- *   pick[o]      the layer whose box area max(x1-x0,0)*max(y1-y0,0) has stable ascending rank (Lc-1)/2
+ *   pick[o]      the layer whose box area max(x1-x0,0)*max(y1-y0,0) has stable ascending rank (Lc-1)/2 -- or, with
+ *                `pick_in` [n] (may be NULL), the layer another selector chose (the trained MIL head), clamped to [0, Lc)
  *   chosen[o]    that box;  map_idx[o] its row in `boxes` (= the row of the CAM stack);  box_patch[o] = floor(box / stride);
  *   box_int[o]   (may be NULL) the box truncated to integers, the crop of stdroi:1981
  * `status` (may be NULL) [rows] int32, the per-box status of as_cam_boxes: *bad (zeroed by the caller) is OR-ed with 1 when any
  * row of any listed object has status <= 0 (a CAM without a foreground component -- where stdroi:80 raises). */
-int as_select_median_boxes(const float* boxes /*[rows,4]*/, const int32_t* meta /*[n,3]*/, int Lc, int stride, int64_t* pick /*[n]*/,
-                           float* chosen /*[n,4]*/, int32_t* map_idx /*[n]*/, int32_t* box_patch /*[n,4]*/,
+int as_select_median_boxes(const float* boxes /*[rows,4]*/, const int32_t* meta /*[n,3]*/, int Lc, int stride,
+                           const int64_t* pick_in, int64_t* pick /*[n]*/, float* chosen /*[n,4]*/, int32_t* map_idx /*[n]*/, int32_t* box_patch /*[n,4]*/,
                            int32_t* box_int /*[n,4]*/, const int32_t* status, int32_t* bad, int n, as_stream_t stream);
 
 /* Rank selection whose ranks are derived on the device from each row's population n (known from the same counting pass), so

@@ -1183,6 +1183,20 @@ def test_select_median_boxes_equals_the_selector_and_its_index_chain(ops):
         assert_equal((ref_box // 16).int(), patch, "patch boxes")
         assert_equal(ref_box.int(), ints, "integer crops")
         assert_equal(boxes[map_idx.long().cpu()], chosen, "map_idx addresses the chosen box")
+        # another selector's choice (`pick_in`): the same indexing behind a given layer per object, out-of-range values clamped
+        given = torch.randint(0, Lc, (len(meta),), generator=g)
+        if len(meta) > 2:
+            given[0], given[1] = Lc + 3, -2
+        pick2, chosen2, rows2, patch2, ints2 = ops.select_median_boxes(dev(boxes), dev(torch.tensor(meta, dtype=torch.int32)), Lc, 16,
+                                                                       pick_in=dev(given))
+        want = given.clamp(0, Lc - 1)
+        assert_equal(want, pick2, "given layers (clamped)")
+        m = torch.tensor(meta)
+        want_rows = m[:, 0] + want * m[:, 1] + m[:, 2]
+        assert_equal(want_rows.int(), rows2, "rows behind the given layers")
+        assert_equal(boxes[want_rows], chosen2, "boxes behind the given layers")
+        assert_equal((boxes[want_rows] // 16).int(), patch2, "patch boxes behind the given layers")
+        assert_equal(boxes[want_rows].int(), ints2, "integer crops behind the given layers")
 
 
 def test_draw_distinct_reads_a_strided_count_table_and_ors_into_the_callers_flag(ops):
