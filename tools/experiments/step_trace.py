@@ -45,14 +45,28 @@ def main():
         for _ in range(5):
             step()
         torch.cuda.synchronize()
-        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
-            step()
-            torch.cuda.synchronize()
-    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    path = os.path.join(ROOT, "gpurun_out", "step_trace.json")
-    prof.export_chrome_trace(path)
-    ev = json.load(open(path))["traceEvents"]
-    dev_ev = sorted((e for e in ev if e.get("cat") in ("kernel", "gpu_memcpy", "gpu_memset") and "dur" in e), key=lambda e: e["ts"])
+        # the tracer occasionally stalls the host for tens of ms inside the traced step (seen once as a 72 ms hole between the
+        # two images' chains): trace up to four single steps and keep the one with the shortest device span
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        path = os.path.join(ROOT, "gpurun_out", "step_trace.json")
+        best = None
+        for attempt in range(4):
+            with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+                step()
+                torch.cuda.synchronize()
+            tmp = path + ".tmp"
+            prof.export_chrome_trace(tmp)
+            ev_a = json.load(open(tmp))["traceEvents"]
+            dev_a = sorted((e for e in ev_a if e.get("cat") in ("kernel", "gpu_memcpy", "gpu_memset") and "dur" in e),
+                           key=lambda e: e["ts"])
+            span = dev_a[-1]["ts"] + dev_a[-1]["dur"] - dev_a[0]["ts"]
+            print(f"traced step {attempt}: device span {span:.0f} us")
+            if best is None or span < best[0]:
+                best = (span, ev_a, dev_a)
+                os.replace(tmp, path)
+            if span < 9000:
+                break
+    ev, dev_ev = best[1], best[2]
     t0 = dev_ev[0]["ts"]
     lines = []
     for e in dev_ev:
