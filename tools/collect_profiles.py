@@ -34,7 +34,7 @@ if os.path.exists(kb):
         if line.startswith("{"):
             rows.append(json.loads(line))
     with open(os.path.join(dst, f"{R}_kernel_bench.md"), "w") as f:
-        f.write(f"# {R} kernel_bench (tools/kernel_bench.py --reps 20, one MI355X box; HIP events, back-to-back calls)\n\n")
+        f.write(f"# {R} kernel_bench (tools/kernel_bench.py --reps 20, one MI355X box; HIP events, back-to-back calls, fastest of three batches)\n\n")
         f.write("| kernel | ms | TFLOP/s or GB/s | fraction of peak | note |\n|---|---|---|---|---|\n")
         for r in rows:
             rate = r.get("tflops", r.get("gbps", ""))

@@ -2,7 +2,7 @@
 
     python tools/kernel_bench.py [--reps 20]
 Prints one JSON line per kernel: ms, achieved TFLOP/s or GB/s, fraction of the gfx950 roof.
-Timing = HIP events on the current stream around `reps` back-to-back launches (after warm-up).
+Timing = HIP events on the current stream around `reps` back-to-back launches (after warm-up), fastest of three such batches.
 """
 import argparse
 import json
@@ -30,13 +30,18 @@ def timeit(fn, reps, warm=3, sync_each=False):
             torch.cuda.synchronize()
             tot += time.perf_counter() - t0
         return tot / reps * 1e3
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        fn()
-    e1.record()
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / reps
+    # three timed batches of `reps` back-to-back launches, the fastest batch reported: one batch in a few hundred is hit by
+    # a stall that has nothing to do with the kernel (a 0.45 ms "QKV GEMM" on a box whose other figures were normal)
+    best = float("inf")
+    for _ in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1) / reps)
+    return best
 
 
 def main():
