@@ -676,9 +676,13 @@ __global__ __launch_bounds__(S1_NT) void refine_sim_kernel(const float* __restri
   __shared__ float red[8][32][33];
   __shared__ float nrm[2][16][32];
   __shared__ float val[32][33];
+  __shared__ Box sbox[32];
   const int Np = Hp * Wp;
   const int tile = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // the boxes of the selection group, read once (the epilogue below used to load them per map inside its loops: two
+  // dependent L2 round trips per map in the launch's critical path)
+  if (tid < 32) sbox[tid] = (tid < is_select && tid < G) ? load_box(boxes, tid, Hp, Wp) : Box{0, 0, -1, -1};
   const int li = lane & 31, half = lane >> 5;
   const int n_mine = min(tile * CS_TILE1 + li, Np - 1);
   const float* frow = feat + (size_t)n_mine * C;
@@ -741,37 +745,43 @@ __global__ __launch_bounds__(S1_NT) void refine_sim_kernel(const float* __restri
   }
   __syncthreads();
 
-  if (tid < 32) {                                // one lane per patch: masking, winner, outputs, row maxima
-    const int n = tile * CS_TILE1 + tid;
+  // epilogue: one thread per (map, patch) -- masking, the selection group's winner, both outputs, and the row maximum of
+  // the map over the tile's 32 patches (a half-wave reduction, one atomic per map and workgroup).  The first `is_select`
+  // maps form the selection group (0 = none, the refinement of the background seeds; Gp = all, the foreground seeds; in
+  // between = both seed sets refined by one call, the group first).  (Round 5: this ran as a loop over the maps on 32
+  // lanes -- 24 serial iterations of stores + shuffles + an atomic for the part-similarity call.)
+  const int nsel = is_select;
+  for (int idx = tid; idx < 32 * Gp; idx += S1_NT) {
+    const int g = idx >> 5, pl = idx & 31;
+    const int n = tile * CS_TILE1 + pl;
     const bool nvalid = n < Np;
     const int nc = min(n, Np - 1);
-    // the first `is_select` maps form the selection group (0 = none, the refinement of the background seeds; Gp = all,
-    // the foreground seeds; in between = both seed sets refined by one call, the group first)
-    const int nsel = is_select;
-    auto masked = [&](int g) {
-      float v = val[g][tid];
-      if (g < nsel && g < G) v = v * (in_box(load_box(boxes, g, Hp, Wp), nc, Wp) ? 1.0f : 0.0f);
+    auto masked = [&](int gg) {
+      float v = val[gg][pl];
+      if (gg < nsel && gg < G) v = v * (in_box(sbox[gg], nc, Wp) ? 1.0f : 0.0f);
       return v;
     };
-    int best = 0;
-    float bv = -INFINITY;
-    for (int g = 0; g < nsel; ++g) {
-      const float v = masked(g);
-      if (v > bv) { bv = v; best = g; }          // strict: ties keep the lowest map index
-    }
-    for (int g = 0; g < Gp; ++g) {
-      const float raw = val[g][tid], mv = masked(g);
-      const float o = g < nsel ? (g == best ? mv : 0.0f) : raw;
-      const float wv = (g < nsel && mask_work) ? mv : raw;
-      if (nvalid) {
-        out[(size_t)g * Np + n] = o;
-        work[(size_t)g * Np + n] = wv;
+    const float raw = val[g][pl];
+    float o = raw, wv = raw;
+    if (g < nsel) {
+      int best = 0;
+      float bv = -INFINITY;
+      for (int gg = 0; gg < nsel; ++gg) {
+        const float v = masked(gg);
+        if (v > bv) { bv = v; best = gg; }       // strict: ties keep the lowest map index
       }
-      float m = nvalid ? wv : -INFINITY;
-#pragma unroll
-      for (int off = 16; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
-      if (tid == 0) atomicMax(&peak[g], f2ord(m));
+      const float mv = masked(g);
+      o = g == best ? mv : 0.0f;
+      wv = mask_work ? mv : raw;
     }
+    if (nvalid) {
+      out[(size_t)g * Np + n] = o;
+      work[(size_t)g * Np + n] = wv;
+    }
+    float m = nvalid ? wv : -INFINITY;
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if (pl == 0) atomicMax(&peak[g], f2ord(m));
   }
 }
 

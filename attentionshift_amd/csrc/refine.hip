@@ -661,16 +661,34 @@ __global__ void select_median_boxes_kernel(const float* __restrict__ boxes, cons
   const float4* b = reinterpret_cast<const float4*>(boxes);
   const int want = (Lc - 1) / 2;
   int sel = pick_in ? min(max((int)pick_in[o], 0), Lc - 1) : 0;      // (a selector's own choice: only the indexing is done here)
-  for (int l = 0; l < Lc && !pick_in; ++l) {
-    const float4 bl = b[off + l * cnt + g];
-    const float al = fmaxf(bl.z - bl.x, 0.f) * fmaxf(bl.w - bl.y, 0.f);
-    int rank = 0;
-    for (int m = 0; m < Lc; ++m) {
-      const float4 bm = b[off + m * cnt + g];
-      const float am = fmaxf(bm.z - bm.x, 0.f) * fmaxf(bm.w - bm.y, 0.f);
-      rank += (am < al) || (am == al && m < l);
+  if (!pick_in && Lc <= 16) {
+    // all box loads in flight at once, the Lc^2 compares on registers (a load inside the rank loops was one L2 round trip per
+    // compare: 11 us for 7 layers)
+    float area[16];
+#pragma unroll
+    for (int l = 0; l < 16; ++l) {
+      const float4 bl = b[off + min(l, Lc - 1) * cnt + g];
+      area[l] = fmaxf(bl.z - bl.x, 0.f) * fmaxf(bl.w - bl.y, 0.f);
     }
-    if (rank == want) sel = l;
+#pragma unroll
+    for (int l = 0; l < 16; ++l) {
+      int rank = 0;
+#pragma unroll
+      for (int m = 0; m < 16; ++m) rank += (m < Lc) && ((area[m] < area[l]) || (area[m] == area[l] && m < l));
+      if (l < Lc && rank == want) sel = l;
+    }
+  } else {
+    for (int l = 0; l < Lc && !pick_in; ++l) {
+      const float4 bl = b[off + l * cnt + g];
+      const float al = fmaxf(bl.z - bl.x, 0.f) * fmaxf(bl.w - bl.y, 0.f);
+      int rank = 0;
+      for (int m = 0; m < Lc; ++m) {
+        const float4 bm = b[off + m * cnt + g];
+        const float am = fmaxf(bm.z - bm.x, 0.f) * fmaxf(bm.w - bm.y, 0.f);
+        rank += (am < al) || (am == al && m < l);
+      }
+      if (rank == want) sel = l;
+    }
   }
   const int row = off + sel * cnt + g;
   const float4 c = b[row];
@@ -681,9 +699,9 @@ __global__ void select_median_boxes_kernel(const float* __restrict__ boxes, cons
                                                     (int)floorf(c.z / stride), (int)floorf(c.w / stride));
   if (box_int) reinterpret_cast<int4*>(box_int)[o] = make_int4((int)c.x, (int)c.y, (int)c.z, (int)c.w);
   if (status) {                                              // every row of `boxes` belongs to exactly one object
-    bool any_bad = false;
-    for (int l = 0; l < Lc; ++l) any_bad = any_bad || status[off + l * cnt + g] <= 0;
-    if (any_bad) atomicOr(bad, 1);
+    int worst = 1;                                            // (no short-circuit: the loads are independent)
+    for (int l = 0; l < Lc; ++l) worst = min(worst, status[off + l * cnt + g]);
+    if (worst <= 0) atomicOr(bad, 1);
   }
 }
 }  // namespace
