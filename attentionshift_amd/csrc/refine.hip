@@ -649,7 +649,7 @@ extern "C" int as_merge_parts(const float* prot, const uint8_t* keep, float thr,
 // stdroi:1812).  Replaces ~20 tensor ops of index arithmetic per step.
 // =====================================================================================================
 namespace {
-__global__ void select_median_boxes_kernel(const float* __restrict__ boxes, const int32_t* __restrict__ meta, int Lc, float stride,
+__global__ __launch_bounds__(64) void select_median_boxes_kernel(const float* __restrict__ boxes, const int32_t* __restrict__ meta, int Lc, float stride,
                                            const int64_t* __restrict__ pick_in, int64_t* __restrict__ pick,
                                            float* __restrict__ chosen,
                                            int32_t* __restrict__ map_idx, int32_t* __restrict__ box_patch,
@@ -662,20 +662,24 @@ __global__ void select_median_boxes_kernel(const float* __restrict__ boxes, cons
   const int want = (Lc - 1) / 2;
   int sel = pick_in ? min(max((int)pick_in[o], 0), Lc - 1) : 0;      // (a selector's own choice: only the indexing is done here)
   if (!pick_in && Lc <= 16) {
-    // all box loads in flight at once, the Lc^2 compares on registers (a load inside the rank loops was one L2 round trip per
-    // compare: 11 us for 7 layers)
-    float area[16];
+    // all box loads in flight at once, then the Lc^2 compares on this thread's column of an LDS table (a load inside the
+    // rank loops was one L2 round trip per compare: 11 us for 7 layers; 256 unrolled compares on registers: 4000
+    // instructions for one wave)
+    __shared__ float sa[16][64];
+    const int t = threadIdx.x;
+    float4 bb[16];
 #pragma unroll
-    for (int l = 0; l < 16; ++l) {
-      const float4 bl = b[off + min(l, Lc - 1) * cnt + g];
-      area[l] = fmaxf(bl.z - bl.x, 0.f) * fmaxf(bl.w - bl.y, 0.f);
-    }
+    for (int l = 0; l < 16; ++l) bb[l] = b[off + min(l, Lc - 1) * cnt + g];
 #pragma unroll
-    for (int l = 0; l < 16; ++l) {
+    for (int l = 0; l < 16; ++l) sa[l][t] = fmaxf(bb[l].z - bb[l].x, 0.f) * fmaxf(bb[l].w - bb[l].y, 0.f);
+    for (int l = 0; l < Lc; ++l) {
+      const float al = sa[l][t];
       int rank = 0;
-#pragma unroll
-      for (int m = 0; m < 16; ++m) rank += (m < Lc) && ((area[m] < area[l]) || (area[m] == area[l] && m < l));
-      if (l < Lc && rank == want) sel = l;
+      for (int m = 0; m < Lc; ++m) {
+        const float am = sa[m][t];
+        rank += (am < al) || (am == al && m < l);
+      }
+      if (rank == want) sel = l;
     }
   } else {
     for (int l = 0; l < Lc && !pick_in; ++l) {
