@@ -1016,6 +1016,24 @@ int splitk_chunk(int M, int Nout, int K, int* splits, bool* tall = nullptr) {
 
 }  // namespace
 
+// ---- csrc/gemm_pp.hip: the persistent ping-pong kernel (round 6).  cfg 0 = 256 x 256 tiles, 1 = 256 x 128 ----
+bool as_pp_applies(int M, int Nout, int K, int cfg);
+int as_pp_linear(const void* x, const void* W, const float* bias, void* out, int M, int Nout, int K, int act, int cfg, hipStream_t s);
+int as_pp_qkv(const void* x, const void* Wqkv, const float* bqkv, void* q, void* k, void* vt, int B, int N, int Npad, int D, int h,
+              hipStream_t s);
+// which tile shape of the persistent kernel a plain linear takes (-1: the one-tile-per-workgroup kernels above).
+// AS_GEMM_PP = 0 off | a | b force cfg 0 / 1 where it applies | unset: auto.  Re-read per call when AS_GEMM_PP_DYN is set
+// (tools/experiments A/B in one process).
+static int pp_pick(int M, int Nout, int K, bool qkv) {
+  static const bool dyn = getenv("AS_GEMM_PP_DYN") != nullptr;
+  static const char* e0 = getenv("AS_GEMM_PP");
+  const char* e = dyn ? getenv("AS_GEMM_PP") : e0;
+  if (e != nullptr && e[0] == '0') return -1;
+  if (e != nullptr && e[0] == 'a') return !qkv && as_pp_applies(M, Nout, K, 0) ? 0 : -1;
+  if (e != nullptr && e[0] == 'b') return as_pp_applies(M, Nout, K, 1) ? 1 : -1;
+  return -1;                                                    // (auto: set after the first measurement)
+}
+
 extern "C" size_t as_linear_splitk_workspace_bytes(int M, int Nout, int K) {
   if (M <= 0 || Nout <= 0 || K <= 0) return 0;
   int S = 1;
@@ -1062,6 +1080,10 @@ extern "C" int as_linear_fwd(const void* x, const void* W, const float* bias, vo
   AS_REQUIRE(act == 0 || act == 1 || act == 4, AS_E_BADARG, "as_linear_fwd: act must be 0 (none), 1 (GELU) or 4 (ReLU)");
   QkvEpi epi{};
   hipStream_t s = (hipStream_t)stream;
+  if (dtype == AS_BF16) {
+    const int cfg = pp_pick(M, Nout, K, false);
+    if (cfg >= 0) return as_pp_linear(x, W, bias, out, M, Nout, K, act, cfg, s);
+  }
   if (dtype == AS_BF16 && K % GK == 0) return launch_gemm_glds<0>(x, W, bias, out, M, Nout, K, act, epi, s);
   if (dtype == AS_BF16) return launch_gemm<__bf16, 0>(x, W, bias, out, M, Nout, K, act, epi, s);
   if (dtype == AS_F32) return launch_gemm<float, 0>(x, W, bias, out, M, Nout, K, act, epi, s);
@@ -1123,6 +1145,8 @@ extern "C" int as_qkv_fwd(const void* x, const void* Wqkv, const float* bqkv, vo
              "as_qkv_fwd: head dim must be 64 (D=%d h=%d)", D, h);
   QkvEpi epi{q, k, vt, N, as_npad(N), D, h};
   hipStream_t s = (hipStream_t)stream;
+  if (dtype == AS_BF16 && D % 128 == 0 && pp_pick(B * N, 3 * D, D, true) == 1)
+    return as_pp_qkv(x, Wqkv, bqkv, q, k, vt, B, N, as_npad(N), D, h, s);
   if (dtype == AS_BF16 && D % GK == 0) return launch_gemm_glds<1>(x, Wqkv, bqkv, nullptr, B * N, 3 * D, D, 0, epi, s);
   if (dtype == AS_BF16) return launch_gemm<__bf16, 1>(x, Wqkv, bqkv, nullptr, B * N, 3 * D, D, 0, epi, s);
   if (dtype == AS_F32) return launch_gemm<float, 1>(x, Wqkv, bqkv, nullptr, B * N, 3 * D, D, 0, epi, s);

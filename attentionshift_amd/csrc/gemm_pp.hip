@@ -1,0 +1,444 @@
+// Persistent ping-pong GEMM for gfx950 (round 6):  C[M,Nout] = act(A[M,K] . W[Nout,K]^T + bias), bf16 operands.
+//
+// Replaces nn.Linear / the QKV projection of Attention and Mlp (reference models/vision_transformer.py:47-59, 75-77, 84)
+// on the shapes of the backbone (M = B * N tokens, K and Nout multiples of 64 / 128).  What is different from the
+// one-tile-per-workgroup kernel of gemm.hip, and why (profiles/r04_gemm_analysis.md: 39 % of an fc1 launch was prologue +
+// epilogue, the main loop 71 % busy):
+//   * ONE workgroup per CU that walks a list of output tiles, and ONE operand stream over all of its (tile, K step) pairs:
+//     the LDS-DMA prefetch of the next tile's first K steps is issued under the previous tile's last K steps, so a tile has
+//     no prologue, and its global stores drain under the next tile's main loop (they are fire-and-forget);
+//   * the epilogue goes from the accumulators straight to memory: the W rows of a tile are PERMUTED when they are staged
+//     (the LDS-DMA source address is per lane, so this is free) such that the two 16 x 16 MFMA fragments of a 32-column block
+//     leave every lane with 8 CONSECUTIVE output columns = one 16-byte store; no LDS staging tile, no barrier;
+//   * the main loop is the two-group ("ping-pong") schedule on v_mfma_f32_16x16x32_bf16: waves 0-3 and 4-7 (one of each
+//     per SIMD) run half a phase apart, so that one group's fragment reads + LDS-DMA issue sit under the other group's
+//     MFMAs; every phase is {ds_read the phase's fragments, issue one half-tile of LDS-DMA, s_barrier, lgkmcnt(0), 16 MFMAs,
+//     s_barrier}; the DMA is waited for with a counted vmcnt ONCE per K step, never 0 (cdna_hip_programming.md section 5,
+//     "8-phase" schedule; the phase tables below are this kernel's own and are derived in DESIGN.md section 4.2).
+// Two tile shapes:
+//   cfg 0  256 x 256 x 64, waves 2 (M) x 4 (N), wave tile (64 + 64) x (32 + 32), 4 phases per K step, 2 LDS buffers x 64 KiB
+//   cfg 1  256 x 128 x 64, waves 4 (M) x 2 (N), wave tile 64 x (32 + 32),        2 phases per K step, 3 LDS buffers x 48 KiB
+// LDS image of a half-tile (16 KiB = 128 rows x 64 k): row r at r * 128, 16-byte chunk c of the row at slot c ^ ((r >> 1) & 7):
+// the 16-lane groups of a ds_read_b128 fragment read (rows i = lane & 15, chunk lane >> 4) then cover the 16 slots of a 256-byte
+// bank row exactly once.  The image is lane-linear for the LDS-DMA, so the XOR sits on the SOURCE chunk.
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) unsigned pp_u32x4;
+typedef __attribute__((ext_vector_type(2))) float pp_f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 pp_bf16x2;
+
+struct PPEpi {
+  void* q; void* k; void* vt;       // QKV mode outputs
+  int N, Npad, D, h;                // tokens per image, padded, model width, heads
+};
+
+template <int OFF> __device__ __forceinline__ void pp_read(pp_u32x4& d, unsigned addr) {
+  static_assert(OFF >= 0 && OFF < 65536, "ds_read offset field is 16 bits");
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
+}
+__device__ __forceinline__ void pp_wait12(pp_u32x4 (&x)[4][2], pp_u32x4 (&w)[2][2]) {
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(x[0][0]), "+v"(x[0][1]), "+v"(x[1][0]), "+v"(x[1][1]), "+v"(x[2][0]), "+v"(x[2][1]), "+v"(x[3][0]),
+                 "+v"(x[3][1]), "+v"(w[0][0]), "+v"(w[0][1]), "+v"(w[1][0]), "+v"(w[1][1]));
+  __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ void pp_wait8(pp_u32x4 (&x)[4][2]) {
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(x[0][0]), "+v"(x[0][1]), "+v"(x[1][0]), "+v"(x[1][1]), "+v"(x[2][0]), "+v"(x[2][1]), "+v"(x[3][0]),
+                 "+v"(x[3][1]));
+  __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ void pp_wait4(pp_u32x4 (&w)[2][2]) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w[0][0]), "+v"(w[0][1]), "+v"(w[1][0]), "+v"(w[1][1]));
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// erf-GELU for a bf16 result (A&S 7.1.26, |erf error| <= 1.5e-7), two values per call on the packed fp32 VALU ops
+// (the same function as gemm.hip's gelu_bf16_x2, kept bit-identical: the two kernels must agree on every shape)
+__device__ __forceinline__ pp_f32x2 pp_gelu_x2(pp_f32x2 x) {
+  const pp_f32x2 hx = x * 0.5f;
+  pp_f32x2 ahx;
+  ahx.x = fabsf(hx.x); ahx.y = fabsf(hx.y);
+  const pp_f32x2 z = ahx * 1.41421356237309504880f;
+  const pp_f32x2 den = z * 0.3275911f + 1.0f;
+  pp_f32x2 t;
+  t.x = __builtin_amdgcn_rcpf(den.x); t.y = __builtin_amdgcn_rcpf(den.y);
+  pp_f32x2 p = t * 1.061405429f + (-1.453152027f);
+  p = p * t + 1.421413741f;
+  p = p * t + (-0.284496736f);
+  p = p * t + 0.254829592f;
+  const pp_f32x2 a = (z * z) * (-1.44269504088896340736f);
+  pp_f32x2 g;
+  g.x = __builtin_amdgcn_exp2f(a.x); g.y = __builtin_amdgcn_exp2f(a.y);
+  const pp_f32x2 e = 1.0f - (p * t) * g;
+  return hx + ahx * e;
+}
+
+// column of a 32-column block held by MFMA row j of the block's two 16-row fragments (j = 16 f + i, lane group g = i >> 2,
+// register r = i & 3): 8 g + 4 f + r -- fragment pair (f = 0, 1) gives lane group g the columns 8 g .. 8 g + 7
+__device__ __forceinline__ int pp_pi32(int j) { return 8 * ((j & 15) >> 2) + 4 * (j >> 4) + (j & 3); }
+
+template <int CFG> struct PPCfg;
+template <> struct PPCfg<0> {
+  static constexpr int BM = 256, BN = 256, NBUF = 2, BUF = 65536, MA = 8, NWH = 2;
+  static constexpr int X0 = 0, X1 = 16384, W0 = 32768, W1 = 49152;
+};
+template <> struct PPCfg<1> {
+  static constexpr int BM = 256, BN = 128, NBUF = 3, BUF = 49152, MA = 4, NWH = 1;
+  static constexpr int X0 = 0, X1 = 16384, W0 = 32768, W1 = 32768;
+};
+
+// EM: 0 = row-major out (+ bias, ACT 0 none / 1 GELU / 4 ReLU), 1 = QKV scatter (q fragment-major pre-scaled, k, V^T)
+template <int CFG, int EM, int ACT>
+__global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const __bf16* __restrict__ A, const __bf16* __restrict__ W,
+                                                         const float* __restrict__ bias, __bf16* __restrict__ out, int M,
+                                                         int Nout, int K, PPEpi epi) {
+  using C = PPCfg<CFG>;
+  constexpr int BM = C::BM, BN = C::BN, NBUF = C::NBUF, MA = C::MA;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2;                                 // ping-pong group: waves w and w + 4 share a SIMD
+  const int wr = CFG == 0 ? (wave >> 2) : (wave >> 1);       // wave row    (cfg 0: 2, cfg 1: 4)
+  const int wc = CFG == 0 ? (wave & 3) : (wave & 1);         // wave column (cfg 0: 4, cfg 1: 2)
+  const int li = lane & 15, lg = lane >> 4;
+
+  // ---- this workgroup's tiles: rank r of G (ranks of one XCD contiguous), tiles r, r + G, ... in (panel, column) order ----
+  const int nt_n = Nout / BN, tiles = ((M + BM - 1) / BM) * nt_n;
+  const int G = gridDim.x;
+  const int rank = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+  if (rank >= tiles) return;
+  const int my_tiles = (tiles - rank + G - 1) / G;
+  const int nk = K >> 6;
+  const int total = my_tiles * nk;                           // K steps of this workgroup's operand stream
+
+  // ---- LDS-DMA source pointers: [half-tile type][piece]; wave w moves pieces 2w, 2w+1 (8 LDS rows x 128 B each) ----
+  // piece p, lane l -> LDS row 8 p + (l >> 3), physical chunk l & 7 -> source chunk (l & 7) ^ ((row >> 1) & 7)
+  const char* sx[2][2];                                      // X0 / X1
+  const char* sw[C::NWH][2];                                 // W0 (/ W1)
+  int ld_row[2], ld_chunk[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    ld_row[j] = (2 * wave + j) * 8 + (lane >> 3);
+    ld_chunk[j] = ((lane & 7) ^ ((ld_row[j] >> 1) & 7)) << 4;
+  }
+  auto x_src = [&](int h, int j, int tile) {
+    const int m0 = (tile / nt_n) * BM, l = ld_row[j];
+    const int trow = CFG == 0 ? ((l >> 6) * 128 + h * 64 + (l & 63)) : (h * 128 + l);
+    return reinterpret_cast<const char*>(A) + (size_t)min(m0 + trow, M - 1) * K * 2 + ld_chunk[j];
+  };
+  auto w_src = [&](int h, int j, int tile) {
+    const int n0 = (tile % nt_n) * BN, l = ld_row[j];
+    const int tcol = CFG == 0 ? ((l >> 5) * 64 + h * 32 + pp_pi32(l & 31)) : ((l >> 5) * 32 + pp_pi32(l & 31));
+    return reinterpret_cast<const char*>(W) + (size_t)(n0 + tcol) * K * 2 + ld_chunk[j];
+  };
+  // stream position of every half-tile type: (tile index in my list, K step, LDS buffer)
+  int st_ti[2 + C::NWH], st_kt[2 + C::NWH], st_buf[2 + C::NWH];
+#pragma unroll
+  for (int t = 0; t < 2 + C::NWH; ++t) { st_ti[t] = 0; st_kt[t] = 0; st_buf[t] = 0; }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    sx[0][j] = x_src(0, j, rank); sx[1][j] = x_src(1, j, rank);
+#pragma unroll
+    for (int h = 0; h < C::NWH; ++h) sw[h][j] = w_src(h, j, rank);
+  }
+  // stage<T>(): the next K step of half-tile type T (0 X0, 1 X1, 2 W0, 3 W1) -> its slot of buffer st_buf[T]; a no-op once the
+  // stream is exhausted (the waits below switch to vmcnt(0) there)
+  auto stage = [&](auto t_c) {
+    constexpr int T = decltype(t_c)::value;
+    constexpr int SLOT = T == 0 ? C::X0 : T == 1 ? C::X1 : T == 2 ? C::W0 : C::W1;
+    if (st_ti[T] >= my_tiles) return;
+    char* dst = smem + st_buf[T] * C::BUF + SLOT + (2 * wave) * 1024;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const char* src;
+      if constexpr (T < 2) src = sx[T][j];
+      else src = sw[T - 2][j];
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(dst + j * 1024), 16, 0, 0);
+    }
+    st_buf[T] = st_buf[T] + 1 == NBUF ? 0 : st_buf[T] + 1;
+    if (++st_kt[T] == nk) {
+      st_kt[T] = 0;
+      ++st_ti[T];
+      if (st_ti[T] < my_tiles) {
+        const int tile = rank + st_ti[T] * G;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          if constexpr (T < 2) sx[T][j] = x_src(T, j, tile);
+          else sw[T - 2][j] = w_src(T - 2, j, tile);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if constexpr (T < 2) sx[T][j] += 128;
+        else sw[T - 2][j] += 128;
+      }
+    }
+  };
+  using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+
+  // ---- fragment read addresses (per lane): row i = lane & 15 of a 16-row fragment, chunk (lane >> 4) + 4 ks ----
+  const unsigned smem_base = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)smem;
+  const unsigned frag_lane = (unsigned)(li * 128 + ((lg ^ ((li >> 1) & 7)) << 4));
+  const unsigned ks1 = (frag_lane & 64u) ? (unsigned)-64 : 64u;   // k32 step 1 = chunk ^ 4 = +- 64 bytes (no alignment assumed)
+  const unsigned x_lane = smem_base + frag_lane + (CFG == 0 ? wr * 64 * 128 : (wr & 1) * 64 * 128 + (wr >> 1) * C::X1);
+  const unsigned w_lane = smem_base + frag_lane + (CFG == 0 ? wc * 32 * 128 : wc * 64 * 128);
+
+  f32x4 acc[MA][2][2];                                       // [m fragment][32-column block][fragment of the block]
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int a = 0; a < MA; ++a)
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int f = 0; f < 2; ++f) acc[a][p][f] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  };
+  zero_acc();
+
+  pp_u32x4 xf[4][2], wf[2][2];                               // [fragment][ks]
+  // 16 MFMAs: m fragments A0 .. A0+3 x the two fragments of column block P, two k32 steps; D[n][m] = W . X^T
+  auto mfma16 = [&](auto a0_c, auto p_c) {
+    constexpr int A0 = decltype(a0_c)::value, P = decltype(p_c)::value;
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+          acc[A0 + a][P][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[f][ks]),
+                                                                      __builtin_bit_cast(bf16x8, xf[a][ks]), acc[A0 + a][P][f], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  auto read_x = [&](auto slot_c, unsigned base) {             // 4 fragments x 2 k32 steps of one X half-tile
+    constexpr int SLOT = decltype(slot_c)::value;
+    const unsigned b1 = base + ks1;
+    pp_read<SLOT + 0 * 2048>(xf[0][0], base); pp_read<SLOT + 0 * 2048>(xf[0][1], b1);
+    pp_read<SLOT + 1 * 2048>(xf[1][0], base); pp_read<SLOT + 1 * 2048>(xf[1][1], b1);
+    pp_read<SLOT + 2 * 2048>(xf[2][0], base); pp_read<SLOT + 2 * 2048>(xf[2][1], b1);
+    pp_read<SLOT + 3 * 2048>(xf[3][0], base); pp_read<SLOT + 3 * 2048>(xf[3][1], b1);
+  };
+  auto read_w = [&](auto slot_c, unsigned base) {             // 2 fragments x 2 k32 steps of one 32-column block
+    constexpr int SLOT = decltype(slot_c)::value;
+    const unsigned b1 = base + ks1;
+    pp_read<SLOT + 0 * 2048>(wf[0][0], base); pp_read<SLOT + 0 * 2048>(wf[0][1], b1);
+    pp_read<SLOT + 1 * 2048>(wf[1][0], base); pp_read<SLOT + 1 * 2048>(wf[1][1], b1);
+  };
+  auto bar = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  // ---- epilogue: accumulators -> memory, 16 bytes (8 consecutive columns) per lane and (m fragment, column block) ----
+  auto epilogue = [&](int tile) {
+    const int m0 = (tile / nt_n) * BM, n0 = (tile % nt_n) * BN;
+    const int colw = n0 + wc * 64 + 8 * lg;                  // + 32 p
+    float4 bv[2][2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      if (bias != nullptr) {
+        bv[p][0] = *reinterpret_cast<const float4*>(bias + colw + 32 * p);
+        bv[p][1] = *reinterpret_cast<const float4*>(bias + colw + 32 * p + 4);
+      } else {
+        bv[p][0] = bv[p][1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      }
+    }
+    int which = 0, head0 = 0;
+    if constexpr (EM == 1) { which = n0 / epi.D; head0 = (n0 % epi.D) >> 6; }
+#pragma unroll
+    for (int a = 0; a < MA; ++a) {
+      const int row = m0 + (CFG == 0 ? wr * 128 : wr * 64) + 16 * a + li;
+      int b_img = 0, n_img = row;
+      if constexpr (EM == 1) { b_img = row / epi.N; n_img = row - b_img * epi.N; }
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        float v[8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { v[r] = acc[a][p][0][r]; v[4 + r] = acc[a][p][1][r]; }
+        v[0] += bv[p][0].x; v[1] += bv[p][0].y; v[2] += bv[p][0].z; v[3] += bv[p][0].w;
+        v[4] += bv[p][1].x; v[5] += bv[p][1].y; v[6] += bv[p][1].z; v[7] += bv[p][1].w;
+        if constexpr (EM == 0) {
+          if constexpr (ACT == 1) {
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+              const pp_f32x2 gq = pp_gelu_x2(pp_f32x2{v[e], v[e + 1]});
+              v[e] = gq.x; v[e + 1] = gq.y;
+            }
+          } else if constexpr (ACT == 4) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.0f);
+          }
+        } else if (which == 0) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] *= AS_QSCALE;     // q is stored pre-scaled by log2(e) / 8 (common.h)
+        }
+        uint4 pk;
+        pk.x = __builtin_bit_cast(unsigned, pp_bf16x2{(__bf16)v[0], (__bf16)v[1]});
+        pk.y = __builtin_bit_cast(unsigned, pp_bf16x2{(__bf16)v[2], (__bf16)v[3]});
+        pk.z = __builtin_bit_cast(unsigned, pp_bf16x2{(__bf16)v[4], (__bf16)v[5]});
+        pk.w = __builtin_bit_cast(unsigned, pp_bf16x2{(__bf16)v[6], (__bf16)v[7]});
+        if (row >= M) continue;
+        const int col = colw + 32 * p;
+        if constexpr (EM == 0) {
+          *reinterpret_cast<uint4*>(out + (size_t)row * Nout + col) = pk;
+        } else {
+          const int cl = col - n0;                            // column inside the 128-wide tile: head cl >> 6, d0 = cl & 63
+          const size_t bh = (size_t)(b_img * epi.h + head0 + (cl >> 6));
+          const int d0 = cl & 63;
+          if (which == 0) {
+            *reinterpret_cast<uint4*>(reinterpret_cast<__bf16*>(epi.q) + qf_frag(bh, epi.Npad, n_img, d0 >> 4, (d0 >> 3) & 1)) = pk;
+          } else if (which == 1) {
+            *reinterpret_cast<uint4*>(reinterpret_cast<__bf16*>(epi.k) + (bh * epi.Npad + n_img) * 64 + d0) = pk;
+          } else {
+            // V^T [B,h,64,Npad]: the lane's 8 values are 8 features of ONE token: 2-byte stores, 16 consecutive tokens
+            // (32 bytes) per lane group and instruction
+            __bf16* dst = reinterpret_cast<__bf16*>(epi.vt) + (bh * 64 + d0) * epi.Npad + n_img;
+            const unsigned wds[4] = {pk.x, pk.y, pk.z, pk.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const unsigned short bits = (unsigned short)(e & 1 ? wds[e >> 1] >> 16 : wds[e >> 1] & 0xffffu);
+              *reinterpret_cast<unsigned short*>(dst + (size_t)e * epi.Npad) = bits;
+            }
+          }
+        }
+      }
+    }
+  };
+
+  // ---- prologue: fill the pipeline (see the schedule tables in DESIGN.md section 4.2) ----
+  if constexpr (CFG == 0) {
+    stage(I0{}); stage(I2{}); stage(I3{}); stage(I1{});       // K step 0: X0 W0 W1 X1
+    stage(I0{}); stage(I3{});                                 // K step 1: X0 W1   (X1, W0 of step 1 follow in phases 0, 1)
+    if (total >= 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else {
+    stage(I0{}); stage(I1{}); stage(I2{});                    // K step 0: X0 X1 W
+    stage(I0{}); stage(I1{}); stage(I2{});                    // K step 1
+    stage(I0{});                                              // K step 2: X0
+    if (total >= 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  bar();
+  if (grp == 1) bar();                                        // group 1 runs one barrier behind group 0
+
+  int cbuf = 0, ckt = 0, cti = 0;
+  for (int g = 0; g < total; ++g) {
+    const unsigned boff = (unsigned)(cbuf * C::BUF);
+    const unsigned xb = x_lane + boff, wb = w_lane + boff;
+    if constexpr (CFG == 0) {
+      // phase 0: quadrant (M0, N0); stage X1 of step g + 1
+      read_x(std::integral_constant<int, C::X0>{}, xb);
+      read_w(std::integral_constant<int, C::W0>{}, wb);
+      stage(I1{});
+      bar();
+      pp_wait12(xf, wf);
+      mfma16(I0{}, I0{});
+      bar();
+      // phase 1: (M0, N1); stage W0 of step g + 1
+      read_w(std::integral_constant<int, C::W1>{}, wb);
+      stage(I2{});
+      bar();
+      pp_wait4(wf);
+      mfma16(I0{}, I1{});
+      bar();
+      // phase 2: (M1, N1); stage X0 of step g + 2
+      read_x(std::integral_constant<int, C::X1>{}, xb);
+      stage(I0{});
+      bar();
+      pp_wait8(xf);
+      mfma16(std::integral_constant<int, 4>{}, I1{});
+      bar();
+      // phase 3: (M1, N0); stage W1 of step g + 2; everything of step g + 1 has landed when <= 4 LDS-DMAs are in flight
+      read_w(std::integral_constant<int, C::W0>{}, wb);
+      stage(I3{});
+      if (g + 2 < total) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      bar();
+      pp_wait4(wf);
+      mfma16(std::integral_constant<int, 4>{}, I0{});
+      bar();
+    } else {
+      // phase 0: (M, N0); stage X1 of step g + 2
+      read_x(std::integral_constant<int, 0>{}, xb);
+      read_w(std::integral_constant<int, C::W0>{}, wb);
+      stage(I1{});
+      bar();
+      pp_wait12(xf, wf);
+      mfma16(I0{}, I0{});
+      bar();
+      // phase 1: (M, N1); stage W of step g + 2 and X0 of step g + 3; step g + 1 has landed when <= 8 LDS-DMAs are in flight
+      read_w(std::integral_constant<int, C::W0 + 32 * 128>{}, wb);
+      stage(I2{});
+      stage(I0{});
+      if (g + 3 < total) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      bar();
+      pp_wait4(wf);
+      mfma16(I0{}, I1{});
+      bar();
+    }
+    cbuf = cbuf + 1 == NBUF ? 0 : cbuf + 1;
+    if (++ckt == nk) {
+      ckt = 0;
+      epilogue(rank + cti * G);
+      ++cti;
+      zero_acc();
+    }
+  }
+  if (grp == 0) bar();                                        // pairs with group 1's last barrier
+}
+
+template <int CFG, int EM, int ACT>
+int launch_pp(const void* A, const void* W, const float* bias, void* out, int M, int Nout, int K, PPEpi epi, hipStream_t s) {
+  using C = PPCfg<CFG>;
+  static const int cus = [] {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return n >= 8 ? n - n % 8 : 8;
+  }();
+  const int tiles = as_ceil_div(M, C::BM) * (Nout / C::BN);
+  const int grid = tiles >= cus ? cus : as_round_up(tiles, 8);
+  const size_t lds = (size_t)C::NBUF * C::BUF;
+  static std::atomic<bool> attr_set{false};
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)gemm_pp_kernel<CFG, EM, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_pp_kernel<CFG, EM, ACT>), dim3(grid), dim3(512), lds, s, (const __bf16*)A, (const __bf16*)W, bias,
+                     (__bf16*)out, M, Nout, K, epi);
+  AS_CHECK_LAUNCH("gemm_pp");
+  return AS_OK;
+}
+
+}  // namespace
+
+// ---- internal entry points (gemm.hip dispatches here; not part of the C ABI) ----
+// cfg: 0 = 256 x 256 tiles, 1 = 256 x 128.  Preconditions (checked by the callers through as_pp_applies): bf16,
+// K % 64 == 0, Nout % BN == 0, 16-byte aligned rows.
+bool as_pp_applies(int M, int Nout, int K, int cfg) {
+  const int bn = cfg == 0 ? 256 : 128;
+  return M >= 256 && K >= 128 && K % 64 == 0 && Nout % bn == 0 && (long long)M * K < (1LL << 31) && (long long)Nout * K < (1LL << 31);
+}
+int as_pp_linear(const void* x, const void* W, const float* bias, void* out, int M, int Nout, int K, int act, int cfg,
+                 hipStream_t s) {
+  PPEpi epi{};
+  if (cfg == 0) {
+    if (act == 1) return launch_pp<0, 0, 1>(x, W, bias, out, M, Nout, K, epi, s);
+    if (act == 4) return launch_pp<0, 0, 4>(x, W, bias, out, M, Nout, K, epi, s);
+    return launch_pp<0, 0, 0>(x, W, bias, out, M, Nout, K, epi, s);
+  }
+  if (act == 1) return launch_pp<1, 0, 1>(x, W, bias, out, M, Nout, K, epi, s);
+  if (act == 4) return launch_pp<1, 0, 4>(x, W, bias, out, M, Nout, K, epi, s);
+  return launch_pp<1, 0, 0>(x, W, bias, out, M, Nout, K, epi, s);
+}
+int as_pp_qkv(const void* x, const void* Wqkv, const float* bqkv, void* q, void* k, void* vt, int B, int N, int Npad, int D, int h,
+              hipStream_t s) {
+  PPEpi epi{q, k, vt, N, Npad, D, h};
+  return launch_pp<1, 1, 0>(x, Wqkv, bqkv, nullptr, B * N, 3 * D, D, epi, s);
+}

@@ -426,6 +426,33 @@ def timed(step, ranks, steps, per_rank=None):
     return total
 
 
+def launch_plan(gpus, env, argv, n_devices, script=None):
+    """What `--gpus N` means for this process (the flag used to be decorative).  Returns
+        ("run", None)        this process is a rank (or the single process of N = 1): go on
+        ("spawn", cmd)       N > 1 and no launcher in the environment: re-execute under torch.distributed.run, one rank
+                             per GPU on 127.0.0.1 (what the driver does itself for N > 1)
+        ("error", message)   the request cannot be honoured: fail loudly instead of measuring one rank
+    Pure function of its arguments (tests/test_host_logic.py covers it without a GPU)."""
+    world = int(env.get("WORLD_SIZE", "0") or 0)
+    if gpus < 1:
+        return "error", f"--gpus {gpus}: need at least one GPU"
+    if world == 0:                                          # no launcher
+        if gpus == 1:
+            return "run", None
+        if n_devices < gpus and not env.get("AS_BENCH_SHARE_GPUS"):
+            return "error", (f"--gpus {gpus} but this node exposes {n_devices} GPU(s); one rank per GPU is the contract "
+                             f"(AS_BENCH_SHARE_GPUS=1 lets ranks share devices for a plumbing check)")
+        port = env.get("MASTER_PORT") or str(29500 + os.getpid() % 2000)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr",
+               "127.0.0.1", "--master-port", port, script or os.path.abspath(__file__)] + list(argv)
+        return "spawn", cmd
+    if world != gpus:
+        return "error", f"--gpus {gpus} but the launcher started WORLD_SIZE={world} ranks: the record would misreport n_gpus"
+    if n_devices < min(gpus, int(env.get("LOCAL_WORLD_SIZE", gpus) or gpus)) and not env.get("AS_BENCH_SHARE_GPUS"):
+        return "error", f"{world} ranks on a node with {n_devices} GPU(s) (set AS_BENCH_SHARE_GPUS=1 for a plumbing check)"
+    return "run", None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -442,6 +469,14 @@ def main():
     if a.cpu_sample > 0:
         cpu_baseline(only_threads=a.cpu_sample)
         return
+    what, arg = launch_plan(a.gpus, os.environ, sys.argv[1:], torch.cuda.device_count())
+    if what == "error":
+        print(f"bench.py: {arg}", file=sys.stderr, flush=True)
+        sys.exit(2)
+    if what == "spawn":                                     # python bench.py --gpus N without a launcher: become the launcher
+        import subprocess
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        sys.exit(subprocess.call(arg, env=env))
     CFG.clear()
     CFG.update(CONFIGS[a.config])
 
@@ -460,6 +495,9 @@ def main():
     from attentionshift_amd.dist import Ranks
     ranks = Ranks(device=device)       # gloo for host scalars + "nccl" (= RCCL on ROCm) for device tensors (dist.Ranks)
     world, rank = ranks.world, ranks.rank
+    if world != a.gpus:                                     # (launch_plan checked the environment; this checks the group itself)
+        print(f"bench.py: process group has {world} ranks but --gpus {a.gpus}", file=sys.stderr, flush=True)
+        sys.exit(2)
 
     from attentionshift_amd import ops
     # the host side of this path is a single Python thread; a 256-thread intra-op pool only adds spin-wait noise
