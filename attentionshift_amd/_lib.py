@@ -19,6 +19,7 @@ SIGNATURES = {
     "as_last_error": (ctypes.c_char_p, []),
     "as_npad": (_c_int, [_c_int]),
     "as_linear_fwd": (_c_int, [_c_void_p] * 4 + [_c_int] * 5 + [_c_void_p]),
+    "as_linear_small_fwd": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p] + [_c_int] * 5 + [_c_void_p]),
     "as_linear_sk_workspace_bytes": (_c_size_t, [_c_int] * 3),
     "as_linear_sk_fwd": (_c_int, [_c_void_p] * 4 + [_c_int] * 5 + [_c_void_p, _c_size_t, _c_void_p]),
     "as_linear_gelu_fwd": (_c_int, [_c_void_p] * 5 + [_c_int] * 4 + [_c_void_p]),

@@ -15,7 +15,7 @@ PKG = os.path.dirname(HERE)
 OBJ = os.path.join(HERE, "_obj")
 LIB = os.path.join(PKG, "libattnshift_hip.so")
 
-SOURCES = ["capi.cpp", "gemm.hip", "gemm_pp.hip", "sdpa.hip", "sdpa_bwd.hip", "attn_bwd.hip", "window_attn.hip", "layernorm.hip", "rollout.hip", "cosine_shift.hip", "shift_final.hip", "ccl.hip", "refine.hip", "chamfer.hip", "small_attn.hip", "roi_align.hip", "mt19937.hip", "gemm_tn.hip"]
+SOURCES = ["capi.cpp", "gemm.hip", "gemm_pp.hip", "linear_small.hip", "sdpa.hip", "sdpa_bwd.hip", "attn_bwd.hip", "window_attn.hip", "layernorm.hip", "rollout.hip", "cosine_shift.hip", "shift_final.hip", "ccl.hip", "refine.hip", "chamfer.hip", "small_attn.hip", "roi_align.hip", "mt19937.hip", "gemm_tn.hip"]
 # files whose floating-point steps must round exactly like ATen's (no implicit fma contraction)
 NO_CONTRACT = {"ccl.hip", "refine.hip"}
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]

@@ -9,6 +9,7 @@
 // the transposed store stays coalesced.
 #include <utility>
 #include "common.h"
+#include "gemm_epi.h"
 
 namespace {
 
@@ -28,84 +29,6 @@ struct QkvEpi {
   int N, Npad, D, h;
   int stagger;     // two-workgroups-per-CU tiles: the second wave of workgroups starts this many s_sleep(127) late (0 = off)
 };
-
-__device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
-// erf-GELU for a bf16 result: erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far below bf16's 2^-9), ~15
-// instructions instead of the ~50 of erff -- at 64 outputs per lane erff alone cost twice the MFMA time of a K=768 tile.
-__device__ __forceinline__ float gelu_bf16(float x) {
-  const float z = fabsf(x) * 0.70710678118654752440f;
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-  float p = fmaf(1.061405429f, t, -1.453152027f);
-  p = fmaf(p, t, 1.421413741f);
-  p = fmaf(p, t, -0.284496736f);
-  p = fmaf(p, t, 0.254829592f);
-  const float e = 1.0f - p * t * __builtin_amdgcn_exp2f(-z * z * 1.44269504088896340736f);   // erf(|x| / sqrt 2)
-  return 0.5f * x + 0.5f * fabsf(x) * e;
-}
-
-// The same function on two values at once: the polynomial, the scalings and the final blend go through the packed fp32 VALU
-// ops (v_pk_mul / v_pk_fma_f32: two IEEE results per instruction), the reciprocal and the exponential stay scalar (no packed
-// transcendental) -- 17 instructions per PAIR instead of ~16 per value.  Used by the inference epilogue (act == 1), where a
-// 256 x 256 tile spends 64 k of these per workgroup with the matrix pipe idle.
-typedef __attribute__((ext_vector_type(2))) float g_f32x2;
-__device__ __forceinline__ g_f32x2 gelu_bf16_x2(g_f32x2 x) {
-  const g_f32x2 hx = x * 0.5f;
-  g_f32x2 ahx;
-  ahx.x = fabsf(hx.x); ahx.y = fabsf(hx.y);                             // |x| / 2
-  const g_f32x2 z = ahx * 1.41421356237309504880f;                      // |x| / sqrt 2
-  const g_f32x2 den = z * 0.3275911f + 1.0f;
-  g_f32x2 t;
-  t.x = __builtin_amdgcn_rcpf(den.x); t.y = __builtin_amdgcn_rcpf(den.y);
-  g_f32x2 p = t * 1.061405429f + (-1.453152027f);
-  p = p * t + 1.421413741f;
-  p = p * t + (-0.284496736f);
-  p = p * t + 0.254829592f;
-  const g_f32x2 a = (z * z) * (-1.44269504088896340736f);
-  g_f32x2 g;
-  g.x = __builtin_amdgcn_exp2f(a.x); g.y = __builtin_amdgcn_exp2f(a.y);
-  const g_f32x2 e = 1.0f - (p * t) * g;                                 // erf(|x| / sqrt 2)
-  return hx + ahx * e;
-}
-
-// d/dx of the erf-GELU with the same erf: 0.5 (1 + erf(x / sqrt 2)) + x exp(-x^2 / 2) / sqrt(2 pi)
-__device__ __forceinline__ float gelu_grad_bf16(float x) {
-  const float z = fabsf(x) * 0.70710678118654752440f;
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-  float p = fmaf(1.061405429f, t, -1.453152027f);
-  p = fmaf(p, t, 1.421413741f);
-  p = fmaf(p, t, -0.284496736f);
-  p = fmaf(p, t, 0.254829592f);
-  const float g = __builtin_amdgcn_exp2f(-z * z * 1.44269504088896340736f);                   // exp(-x^2 / 2)
-  const float e = 1.0f - p * t * g;                                                            // erf(|x| / sqrt 2)
-  return 0.5f + copysignf(0.5f * e, x) + x * g * 0.39894228040143267794f;
-}
-// the two training-path epilogues of the bf16 LDS-DMA kernel, applied to a staged 16-byte chunk (8 bf16) at copy-out:
-//   act 2: the chunk is the PRE-activation h: write it to `pre` and gelu(h) to out     (fc1 under autograd)
-//   act 3: the chunk is dA; out = dA * gelu'(h) with h read from `pre`                 (fc2's input gradient)
-typedef __attribute__((ext_vector_type(2))) __bf16 g_bf16x2;
-__device__ __forceinline__ uint4 gelu_chunk(uint4 hv) {
-  const uint32_t w[4] = {hv.x, hv.y, hv.z, hv.w};
-  uint32_t r[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const float a = gelu_bf16(__uint_as_float(w[j] << 16)), b = gelu_bf16(__uint_as_float(w[j] & 0xffff0000u));
-    const g_bf16x2 pk = {(__bf16)a, (__bf16)b};
-    r[j] = __builtin_bit_cast(uint32_t, pk);
-  }
-  return make_uint4(r[0], r[1], r[2], r[3]);
-}
-__device__ __forceinline__ uint4 dgelu_chunk(uint4 dv, uint4 hv) {
-  const uint32_t d[4] = {dv.x, dv.y, dv.z, dv.w}, w[4] = {hv.x, hv.y, hv.z, hv.w};
-  uint32_t r[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const float a = __uint_as_float(d[j] << 16) * gelu_grad_bf16(__uint_as_float(w[j] << 16));
-    const float b = __uint_as_float(d[j] & 0xffff0000u) * gelu_grad_bf16(__uint_as_float(w[j] & 0xffff0000u));
-    const g_bf16x2 pk = {(__bf16)a, (__bf16)b};
-    r[j] = __builtin_bit_cast(uint32_t, pk);
-  }
-  return make_uint4(r[0], r[1], r[2], r[3]);
-}
 
 // accumulators -> memory.  MODE 0: row-major out (+bias, +GELU).  MODE 1: q,k [B,h,Npad,64] and V^T [B,h,64,Npad].
 template <typename T, int MODE>
@@ -1018,20 +941,40 @@ int splitk_chunk(int M, int Nout, int K, int* splits, bool* tall = nullptr) {
 
 // ---- csrc/gemm_pp.hip: the persistent ping-pong kernel (round 6).  cfg 0 = 256 x 256 tiles, 1 = 256 x 128 ----
 bool as_pp_applies(int M, int Nout, int K, int cfg);
-int as_pp_linear(const void* x, const void* W, const float* bias, void* out, int M, int Nout, int K, int act, int cfg, hipStream_t s);
+int as_pp_linear(const void* x, const void* W, const float* bias, void* out, void* pre, int M, int Nout, int K, int act, int cfg,
+                 hipStream_t s);
+int as_pp_deconv(const void* x, const void* W4, const float* bias4, void* out, int M, int w, int cin, int cout, int act, int cfg,
+                 hipStream_t s);
 int as_pp_qkv(const void* x, const void* Wqkv, const float* bqkv, void* q, void* k, void* vt, int B, int N, int Npad, int D, int h,
               hipStream_t s);
-// which tile shape of the persistent kernel a plain linear takes (-1: the one-tile-per-workgroup kernels above).
-// AS_GEMM_PP = 0 off | a | b force cfg 0 / 1 where it applies | unset: auto.  Re-read per call when AS_GEMM_PP_DYN is set
-// (tools/experiments A/B in one process).
-static int pp_pick(int M, int Nout, int K, bool qkv) {
+// which tile shape of the persistent kernel a linear takes (-1: the one-tile-per-workgroup kernels above).
+// AS_GEMM_PP = 0 off | a | b force cfg 0 / 1 where it applies | unset: the round model below.  Re-read per call when
+// AS_GEMM_PP_DYN is set (tools/experiments A/B in one process).
+// Round model, calibrated on one MI355X (profiles/r06_gemm_pp.md): a workgroup per CU walks ceil(tiles / CUs) tiles; a K step of
+// 64 costs 1.55 us on a 256 x 256 tile and 0.85 us on a 256 x 128 tile (both are bound by the L2 -> LDS stream, ~17 TB/s over
+// the chip), a tile's epilogue 3 / 2 us (+ 5 / 2.5 us with the GELU).  Small problems (< 64 tiles of 256 x 128) stay with
+// the one-tile-per-workgroup kernels: their launch has no pipeline to fill.
+static int pp_pick(int M, int Nout, int K, bool qkv, int act) {
   static const bool dyn = getenv("AS_GEMM_PP_DYN") != nullptr;
   static const char* e0 = getenv("AS_GEMM_PP");
   const char* e = dyn ? getenv("AS_GEMM_PP") : e0;
   if (e != nullptr && e[0] == '0') return -1;
   if (e != nullptr && e[0] == 'a') return !qkv && as_pp_applies(M, Nout, K, 0) ? 0 : -1;
   if (e != nullptr && e[0] == 'b') return as_pp_applies(M, Nout, K, 1) ? 1 : -1;
-  return -1;                                                    // (auto: set after the first measurement)
+  if (!as_pp_applies(M, Nout, K, 1)) return -1;
+  static const int cus = [] {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return n >= 8 ? n - n % 8 : 8;
+  }();
+  const int panels = as_ceil_div(M, 256), nk = K / 64;
+  const int tiles_b = panels * (Nout / 128);
+  if (tiles_b < 64) return -1;
+  const float gelu = act == 1 ? 1.0f : 0.0f;
+  const float cost_b = (float)as_ceil_div(tiles_b, cus) * (nk * 0.85f + 2.0f + 2.5f * gelu);
+  if (qkv || !as_pp_applies(M, Nout, K, 0)) return 1;
+  const float cost_a = (float)as_ceil_div(panels * (Nout / 256), cus) * (nk * 1.55f + 3.0f + 5.0f * gelu);
+  return cost_a < cost_b ? 0 : 1;
 }
 
 extern "C" size_t as_linear_splitk_workspace_bytes(int M, int Nout, int K) {
@@ -1081,8 +1024,8 @@ extern "C" int as_linear_fwd(const void* x, const void* W, const float* bias, vo
   QkvEpi epi{};
   hipStream_t s = (hipStream_t)stream;
   if (dtype == AS_BF16) {
-    const int cfg = pp_pick(M, Nout, K, false);
-    if (cfg >= 0) return as_pp_linear(x, W, bias, out, M, Nout, K, act, cfg, s);
+    const int cfg = pp_pick(M, Nout, K, false, act);
+    if (cfg >= 0) return as_pp_linear(x, W, bias, out, nullptr, M, Nout, K, act, cfg, s);
   }
   if (dtype == AS_BF16 && K % GK == 0) return launch_gemm_glds<0>(x, W, bias, out, M, Nout, K, act, epi, s);
   if (dtype == AS_BF16) return launch_gemm<__bf16, 0>(x, W, bias, out, M, Nout, K, act, epi, s);
@@ -1113,6 +1056,10 @@ extern "C" int as_linear_gelu_fwd(const void* x, const void* W, const float* bia
   AS_REQUIRE(M > 0 && Nout > 0 && K > 0 && K % GK == 0 && Nout % 8 == 0, AS_E_BADARG,
              "as_linear_gelu_fwd: need M > 0, K %% 32 == 0, Nout %% 8 == 0 (Nout=%d K=%d)", Nout, K);
   AS_REQUIRE(dtype == AS_BF16, AS_E_UNSUPPORTED, "as_linear_gelu_fwd: bf16 only (dtype %d)", dtype);
+  {
+    const int cfg = pp_pick(M, Nout, K, false, 1);
+    if (cfg >= 0) return as_pp_linear(x, W, bias, out, pre, M, Nout, K, 2, cfg, (hipStream_t)stream);
+  }
   QkvEpi epi{pre, nullptr, nullptr, 0, 0, 0, 0};
   return launch_gemm_glds<0>(x, W, bias, out, M, Nout, K, 2, epi, (hipStream_t)stream);
 }
@@ -1123,6 +1070,10 @@ extern "C" int as_linear_dgelu_fwd(const void* x, const void* W, const void* pre
   AS_REQUIRE(M > 0 && Nout > 0 && K > 0 && K % GK == 0 && Nout % 8 == 0, AS_E_BADARG,
              "as_linear_dgelu_fwd: need M > 0, K %% 32 == 0, Nout %% 8 == 0 (Nout=%d K=%d)", Nout, K);
   AS_REQUIRE(dtype == AS_BF16, AS_E_UNSUPPORTED, "as_linear_dgelu_fwd: bf16 only (dtype %d)", dtype);
+  {
+    const int cfg = pp_pick(M, Nout, K, false, 1);
+    if (cfg >= 0) return as_pp_linear(x, W, nullptr, out, const_cast<void*>(pre), M, Nout, K, 3, cfg, (hipStream_t)stream);
+  }
   QkvEpi epi{const_cast<void*>(pre), nullptr, nullptr, 0, 0, 0, 0};
   return launch_gemm_glds<0>(x, W, nullptr, out, M, Nout, K, 3, epi, (hipStream_t)stream);
 }
@@ -1134,6 +1085,11 @@ extern "C" int as_deconv2x2_fwd(const void* x, const void* W4, const float* bias
   AS_REQUIRE(dtype == AS_BF16 && cin % GK == 0 && cout % 8 == 0, AS_E_UNSUPPORTED,
              "as_deconv2x2_fwd: bf16 with cin %% 32 == 0 and cout %% 8 == 0 only (cin=%d cout=%d dtype=%d)", cin, cout, dtype);
   AS_REQUIRE(act == 0 || act == 1, AS_E_BADARG, "as_deconv2x2_fwd: act must be 0 or 1");
+  {
+    const int cfg = pp_pick(M, 4 * cout, cin, false, act);
+    if (cfg >= 0 && (4 * cout) % (cfg == 0 ? 256 : 128) == 0 && cout % 8 == 0)
+      return as_pp_deconv(x, W4, bias4, out, M, w, cin, cout, act, cfg, (hipStream_t)stream);
+  }
   QkvEpi epi{nullptr, nullptr, nullptr, w, 0, cout, 0};
   return launch_gemm_glds<2>(x, W4, bias4, out, M, 4 * cout, cin, act, epi, (hipStream_t)stream);
 }
@@ -1145,7 +1101,7 @@ extern "C" int as_qkv_fwd(const void* x, const void* Wqkv, const float* bqkv, vo
              "as_qkv_fwd: head dim must be 64 (D=%d h=%d)", D, h);
   QkvEpi epi{q, k, vt, N, as_npad(N), D, h};
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == AS_BF16 && D % 128 == 0 && pp_pick(B * N, 3 * D, D, true) == 1)
+  if (dtype == AS_BF16 && D % 128 == 0 && pp_pick(B * N, 3 * D, D, true, 0) == 1)
     return as_pp_qkv(x, Wqkv, bqkv, q, k, vt, B, N, as_npad(N), D, h, s);
   if (dtype == AS_BF16 && D % GK == 0) return launch_gemm_glds<1>(x, Wqkv, bqkv, nullptr, B * N, 3 * D, D, 0, epi, s);
   if (dtype == AS_BF16) return launch_gemm<__bf16, 1>(x, Wqkv, bqkv, nullptr, B * N, 3 * D, D, 0, epi, s);

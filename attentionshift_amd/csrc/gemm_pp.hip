@@ -21,12 +21,31 @@
 // LDS image of a half-tile (16 KiB = 128 rows x 64 k): row r at r * 128, 16-byte chunk c of the row at slot c ^ ((r >> 1) & 7):
 // the 16-lane groups of a ds_read_b128 fragment read (rows i = lane & 15, chunk lane >> 4) then cover the 16 slots of a 256-byte
 // bank row exactly once.  The image is lane-linear for the LDS-DMA, so the XOR sits on the SOURCE chunk.
+#include <utility>
 #include "common.h"
+#include "gemm_epi.h"
+
+#ifndef AS_PP_PRIO
+#define AS_PP_PRIO 1     // s_setprio: 0 none, 1 raised around the MFMA cluster, 2 raised in the load segment
+#endif
+#ifndef AS_PP_BUF
+#define AS_PP_BUF 0      // LDS-DMA instruction: 0 global_load_lds (a 64-bit address per lane), 1 buffer_load ... lds (one descriptor per
+#endif                   // operand, a 32-bit offset per lane that is fixed per tile, the K step in the scalar offset).  Measured equal
+                         // (the stream runs at ~17 TB/s over the chip either way, profiles/r06_gemm_pp.md); 0 is 0-5 % ahead on 256 x 256
+// (the buffer-descriptor type exists in the device pass only: the host pass, which needs the kernel for its launch stub only,
+//  compiles the pointer form)
+#if AS_PP_BUF && defined(__HIP_DEVICE_COMPILE__)
+#define PP_BUF 1
+#else
+#define PP_BUF 0
+#endif
+#ifndef AS_PP_ABLATE
+#define AS_PP_ABLATE 0   // timing experiments (tools/experiments/gemm_pp_ablate.py); results are WRONG when != 0.  Bit mask:
+#endif                   // 1 no LDS-DMA in the loop, 2 no fragment reads, 4 no MFMAs, 8 no bank swizzle on the DMA source
 
 namespace {
 
 typedef __attribute__((ext_vector_type(4))) unsigned pp_u32x4;
-typedef __attribute__((ext_vector_type(2))) float pp_f32x2;
 typedef __attribute__((ext_vector_type(2))) __bf16 pp_bf16x2;
 
 struct PPEpi {
@@ -36,7 +55,11 @@ struct PPEpi {
 
 template <int OFF> __device__ __forceinline__ void pp_read(pp_u32x4& d, unsigned addr) {
   static_assert(OFF >= 0 && OFF < 65536, "ds_read offset field is 16 bits");
+#if AS_PP_ABLATE & 2
+  asm volatile("" : "=v"(d) : "v"(addr));
+#else
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
+#endif
 }
 __device__ __forceinline__ void pp_wait12(pp_u32x4 (&x)[4][2], pp_u32x4 (&w)[2][2]) {
   asm volatile("s_waitcnt lgkmcnt(0)"
@@ -55,30 +78,16 @@ __device__ __forceinline__ void pp_wait4(pp_u32x4 (&w)[2][2]) {
   __builtin_amdgcn_sched_barrier(0);
 }
 
-// erf-GELU for a bf16 result (A&S 7.1.26, |erf error| <= 1.5e-7), two values per call on the packed fp32 VALU ops
-// (the same function as gemm.hip's gelu_bf16_x2, kept bit-identical: the two kernels must agree on every shape)
-__device__ __forceinline__ pp_f32x2 pp_gelu_x2(pp_f32x2 x) {
-  const pp_f32x2 hx = x * 0.5f;
-  pp_f32x2 ahx;
-  ahx.x = fabsf(hx.x); ahx.y = fabsf(hx.y);
-  const pp_f32x2 z = ahx * 1.41421356237309504880f;
-  const pp_f32x2 den = z * 0.3275911f + 1.0f;
-  pp_f32x2 t;
-  t.x = __builtin_amdgcn_rcpf(den.x); t.y = __builtin_amdgcn_rcpf(den.y);
-  pp_f32x2 p = t * 1.061405429f + (-1.453152027f);
-  p = p * t + 1.421413741f;
-  p = p * t + (-0.284496736f);
-  p = p * t + 0.254829592f;
-  const pp_f32x2 a = (z * z) * (-1.44269504088896340736f);
-  pp_f32x2 g;
-  g.x = __builtin_amdgcn_exp2f(a.x); g.y = __builtin_amdgcn_exp2f(a.y);
-  const pp_f32x2 e = 1.0f - (p * t) * g;
-  return hx + ahx * e;
-}
-
 // column of a 32-column block held by MFMA row j of the block's two 16-row fragments (j = 16 f + i, lane group g = i >> 2,
 // register r = i & 3): 8 g + 4 f + r -- fragment pair (f = 0, 1) gives lane group g the columns 8 g .. 8 g + 7
 __device__ __forceinline__ int pp_pi32(int j) { return 8 * ((j & 15) >> 2) + 4 * (j >> 4) + (j & 3); }
+
+template <int... I, typename F> __device__ __forceinline__ void pp_static_for_impl(std::integer_sequence<int, I...>, F&& f) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <typename F> __device__ __forceinline__ void g_static_for16(F&& f) {
+  pp_static_for_impl(std::make_integer_sequence<int, 16>{}, f);
+}
 
 template <int CFG> struct PPCfg;
 template <> struct PPCfg<0> {
@@ -90,7 +99,14 @@ template <> struct PPCfg<1> {
   static constexpr int X0 = 0, X1 = 16384, W0 = 32768, W1 = 32768;
 };
 
-// EM: 0 = row-major out (+ bias, ACT 0 none / 1 GELU / 4 ReLU), 1 = QKV scatter (q fragment-major pre-scaled, k, V^T)
+// EM: 0 = row-major out + bias, ACT 0 none / 1 GELU / 4 ReLU / 2 training fc1 (the bf16 pre-activation goes to epi.q, its GELU to
+//         out) / 3 fc2's input gradient (out = acc * GELU'(pre), pre read from epi.q);
+//     1 = QKV scatter (q fragment-major pre-scaled, k, V^T);
+//     2 = 2 x 2 / stride-2 transposed convolution: GEMM row = input pixel of a grid epi.N wide, column = (tap, co < epi.D) ->
+//         NHWC output pixel (as_deconv2x2_fwd), ACT 0 / 1
+// (Where the LDS-DMA instructions are issued was measured three ways, profiles/r06_gemm_pp.md: in the phase's load segment
+//  beside the fragment reads -- kept --, between the MFMAs of the phase's cluster, and behind the cluster; the last two are
+//  12-17 % slower on every shape: the issuing wave's MFMAs stall behind each DMA instruction.)
 template <int CFG, int EM, int ACT>
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const __bf16* __restrict__ A, const __bf16* __restrict__ W,
                                                          const float* __restrict__ bias, __bf16* __restrict__ out, int M,
@@ -116,23 +132,37 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const __bf16* __restric
 
   // ---- LDS-DMA source pointers: [half-tile type][piece]; wave w moves pieces 2w, 2w+1 (8 LDS rows x 128 B each) ----
   // piece p, lane l -> LDS row 8 p + (l >> 3), physical chunk l & 7 -> source chunk (l & 7) ^ ((row >> 1) & 7)
+#if PP_BUF
+  unsigned sx[2][2], sw[C::NWH][2];                          // per-lane byte offsets into A / W (fixed per tile)
+  const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(A), (short)0, (int)((size_t)M * K * 2), 0x00027000);
+  const __amdgpu_buffer_rsrc_t rsrcW = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(W), (short)0, (int)((size_t)Nout * K * 2), 0x00027000);
+#else
   const char* sx[2][2];                                      // X0 / X1
   const char* sw[C::NWH][2];                                 // W0 (/ W1)
+#endif
   int ld_row[2], ld_chunk[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     ld_row[j] = (2 * wave + j) * 8 + (lane >> 3);
-    ld_chunk[j] = ((lane & 7) ^ ((ld_row[j] >> 1) & 7)) << 4;
+    ld_chunk[j] = ((lane & 7) ^ ((AS_PP_ABLATE & 8) ? 0 : ((ld_row[j] >> 1) & 7))) << 4;
   }
   auto x_src = [&](int h, int j, int tile) {
     const int m0 = (tile / nt_n) * BM, l = ld_row[j];
     const int trow = CFG == 0 ? ((l >> 6) * 128 + h * 64 + (l & 63)) : (h * 128 + l);
+#if PP_BUF
+    return (unsigned)(min(m0 + trow, M - 1) * (K * 2) + ld_chunk[j]);
+#else
     return reinterpret_cast<const char*>(A) + (size_t)min(m0 + trow, M - 1) * K * 2 + ld_chunk[j];
+#endif
   };
   auto w_src = [&](int h, int j, int tile) {
     const int n0 = (tile % nt_n) * BN, l = ld_row[j];
     const int tcol = CFG == 0 ? ((l >> 5) * 64 + h * 32 + pp_pi32(l & 31)) : ((l >> 5) * 32 + pp_pi32(l & 31));
+#if PP_BUF
+    return (unsigned)((n0 + tcol) * (K * 2) + ld_chunk[j]);
+#else
     return reinterpret_cast<const char*>(W) + (size_t)(n0 + tcol) * K * 2 + ld_chunk[j];
+#endif
   };
   // stream position of every half-tile type: (tile index in my list, K step, LDS buffer)
   int st_ti[2 + C::NWH], st_kt[2 + C::NWH], st_buf[2 + C::NWH];
@@ -144,38 +174,44 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const __bf16* __restric
 #pragma unroll
     for (int h = 0; h < C::NWH; ++h) sw[h][j] = w_src(h, j, rank);
   }
-  // stage<T>(): the next K step of half-tile type T (0 X0, 1 X1, 2 W0, 3 W1) -> its slot of buffer st_buf[T]; a no-op once the
-  // stream is exhausted (the waits below switch to vmcnt(0) there)
+  bool in_loop = false;                                      // (AS_PP_ABLATE & 1 only)
+  // stage<T>(): the next K step of half-tile type T (0 X0, 1 X1, 2 W0, 3 W1) -> its slot of buffer st_buf[T], two LDS-DMA
+  // instructions per wave.  The stream never runs dry: behind the last K step of the last tile it wraps to that tile's first
+  // K step again (two or three K steps of loads nobody reads, into slots that are free by then) -- so every counted vmcnt below
+  // holds for every iteration and the load segment carries no "stream exhausted" branches (each s_cbranch in it is on the
+  // critical path of the ping-pong: the load segment, not the 16 MFMAs, bounds a phase).
   auto stage = [&](auto t_c) {
     constexpr int T = decltype(t_c)::value;
     constexpr int SLOT = T == 0 ? C::X0 : T == 1 ? C::X1 : T == 2 ? C::W0 : C::W1;
-    if (st_ti[T] >= my_tiles) return;
+    if ((AS_PP_ABLATE & 1) && in_loop) return;
     char* dst = smem + st_buf[T] * C::BUF + SLOT + (2 * wave) * 1024;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
+#if PP_BUF
+      unsigned off;
+      if constexpr (T < 2) off = sx[T][j];
+      else off = sw[T - 2][j];
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(T < 2 ? rsrcA : rsrcW, (__attribute__((address_space(3))) void*)(dst + j * 1024), 16,
+                                               (int)off, st_kt[T] * 128, 0, 0);
+#else
       const char* src;
       if constexpr (T < 2) src = sx[T][j];
       else src = sw[T - 2][j];
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(dst + j * 1024), 16, 0, 0);
+      if constexpr (T < 2) sx[T][j] = src + 128;
+      else sw[T - 2][j] = src + 128;
+#endif
     }
     st_buf[T] = st_buf[T] + 1 == NBUF ? 0 : st_buf[T] + 1;
-    if (++st_kt[T] == nk) {
+    if (__builtin_expect(++st_kt[T] == nk, 0)) {             // (once per tile and type)
       st_kt[T] = 0;
-      ++st_ti[T];
-      if (st_ti[T] < my_tiles) {
-        const int tile = rank + st_ti[T] * G;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          if constexpr (T < 2) sx[T][j] = x_src(T, j, tile);
-          else sw[T - 2][j] = w_src(T - 2, j, tile);
-        }
-      }
-    } else {
+      st_ti[T] = st_ti[T] + 1 < my_tiles ? st_ti[T] + 1 : st_ti[T];
+      const int tile = rank + st_ti[T] * G;
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        if constexpr (T < 2) sx[T][j] += 128;
-        else sw[T - 2][j] += 128;
+        if constexpr (T < 2) sx[T][j] = x_src(T, j, tile);
+        else sw[T - 2][j] = w_src(T - 2, j, tile);
       }
     }
   };
@@ -204,16 +240,21 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const __bf16* __restric
   // 16 MFMAs: m fragments A0 .. A0+3 x the two fragments of column block P, two k32 steps; D[n][m] = W . X^T
   auto mfma16 = [&](auto a0_c, auto p_c) {
     constexpr int A0 = decltype(a0_c)::value, P = decltype(p_c)::value;
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int f = 0; f < 2; ++f)
-          acc[A0 + a][P][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[f][ks]),
-                                                                      __builtin_bit_cast(bf16x8, xf[a][ks]), acc[A0 + a][P][f], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
+    if (AS_PP_PRIO == 1) __builtin_amdgcn_s_setprio(1);
+    if (AS_PP_PRIO == 2) __builtin_amdgcn_s_setprio(0);
+    g_static_for16([&](auto n_c) {
+      constexpr int n = decltype(n_c)::value, ks = n >> 3, a = (n >> 1) & 3, f = n & 1;
+#if AS_PP_ABLATE & 4
+      auto& a_ = acc[A0 + a][P][f];
+      auto& w_ = wf[f][ks];
+      auto& x_ = xf[a][ks];
+      asm volatile("" : "+v"(a_) : "v"(w_), "v"(x_));
+#else
+      acc[A0 + a][P][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[f][ks]),
+                                                                  __builtin_bit_cast(bf16x8, xf[a][ks]), acc[A0 + a][P][f], 0, 0, 0);
+#endif
+    });
+    if (AS_PP_PRIO == 1) __builtin_amdgcn_s_setprio(0);
   };
   auto read_x = [&](auto slot_c, unsigned base) {             // 4 fragments x 2 k32 steps of one X half-tile
     constexpr int SLOT = decltype(slot_c)::value;
@@ -234,76 +275,112 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const __bf16* __restric
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
   };
+  // barrier that ends an MFMA segment = opens a load segment (AS_PP_PRIO 2: the loader, not the MFMA wave, gets the issue slots)
+  auto bar_load = [&]() {
+    bar();
+    if (AS_PP_PRIO == 2) __builtin_amdgcn_s_setprio(1);
+  };
 
   // ---- epilogue: accumulators -> memory, 16 bytes (8 consecutive columns) per lane and (m fragment, column block) ----
   auto epilogue = [&](int tile) {
     const int m0 = (tile / nt_n) * BM, n0 = (tile % nt_n) * BN;
     const int colw = n0 + wc * 64 + 8 * lg;                  // + 32 p
-    float4 bv[2][2];
+    f32x4 bv[2][2];
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
       if (bias != nullptr) {
-        bv[p][0] = *reinterpret_cast<const float4*>(bias + colw + 32 * p);
-        bv[p][1] = *reinterpret_cast<const float4*>(bias + colw + 32 * p + 4);
+        bv[p][0] = *reinterpret_cast<const f32x4*>(bias + colw + 32 * p);
+        bv[p][1] = *reinterpret_cast<const f32x4*>(bias + colw + 32 * p + 4);
       } else {
-        bv[p][0] = bv[p][1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        bv[p][0] = bv[p][1] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
       }
     }
+    // the bias is waited for HERE, on every path: left to the first use, the wait lands inside the row < M branches -- hipcc then
+    // repeats a vmcnt(0) in every branch (each store waits for the one before it) and, through the loop's back edge, puts one in
+    // front of the main loop's fragment reads (the LDS-DMA queue drained every K step)
+#pragma unroll
+    for (int p = 0; p < 2; ++p) asm volatile("" : "+v"(bv[p][0]), "+v"(bv[p][1]));
     int which = 0, head0 = 0;
     if constexpr (EM == 1) { which = n0 / epi.D; head0 = (n0 % epi.D) >> 6; }
+    const int row0 = m0 + (CFG == 0 ? wr * 128 : wr * 64) + li;
 #pragma unroll
-    for (int a = 0; a < MA; ++a) {
-      const int row = m0 + (CFG == 0 ? wr * 128 : wr * 64) + 16 * a + li;
-      int b_img = 0, n_img = row;
-      if constexpr (EM == 1) { b_img = row / epi.N; n_img = row - b_img * epi.N; }
+    for (int a0 = 0; a0 < MA; a0 += 4) {
+      // ACT 3: the pre-activations of these four row fragments, loaded (rows clamped: no branch) and waited for up front
+      pp_u32x4 pre[4][2];
+      if constexpr (EM == 0 && ACT == 3) {
 #pragma unroll
-      for (int p = 0; p < 2; ++p) {
-        float v[8];
+        for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { v[r] = acc[a][p][0][r]; v[4 + r] = acc[a][p][1][r]; }
-        v[0] += bv[p][0].x; v[1] += bv[p][0].y; v[2] += bv[p][0].z; v[3] += bv[p][0].w;
-        v[4] += bv[p][1].x; v[5] += bv[p][1].y; v[6] += bv[p][1].z; v[7] += bv[p][1].w;
-        if constexpr (EM == 0) {
-          if constexpr (ACT == 1) {
+          for (int p = 0; p < 2; ++p)
+            pre[a][p] = *reinterpret_cast<const pp_u32x4*>(reinterpret_cast<const __bf16*>(epi.q) +
+                                                           (size_t)min(row0 + 16 * (a0 + a), M - 1) * Nout + colw + 32 * p);
 #pragma unroll
-            for (int e = 0; e < 8; e += 2) {
-              const pp_f32x2 gq = pp_gelu_x2(pp_f32x2{v[e], v[e + 1]});
-              v[e] = gq.x; v[e + 1] = gq.y;
+        for (int a = 0; a < 4; ++a) asm volatile("" : "+v"(pre[a][0]), "+v"(pre[a][1]));
+      }
+#pragma unroll
+      for (int a = a0; a < a0 + 4; ++a) {
+        const int row = row0 + 16 * a;
+        int b_img = 0, n_img = row;
+        if constexpr (EM == 1) { b_img = row / epi.N; n_img = row - b_img * epi.N; }
+        if constexpr (EM == 2) { b_img = row / epi.N; n_img = row - b_img * epi.N; }   // (pixel row of the grid, column)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          float v[8];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { v[r] = acc[a][p][0][r] + bv[p][0][r]; v[4 + r] = acc[a][p][1][r] + bv[p][1][r]; }
+          if constexpr (EM != 1) {
+            if constexpr (ACT == 1) {
+#pragma unroll
+              for (int e = 0; e < 8; e += 2) {
+                const g_f32x2 gq = gelu_bf16_x2(g_f32x2{v[e], v[e + 1]});
+                v[e] = gq.x; v[e + 1] = gq.y;
+              }
+            } else if constexpr (ACT == 4) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.0f);
             }
-          } else if constexpr (ACT == 4) {
+          } else if (which == 0) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.0f);
+            for (int e = 0; e < 8; ++e) v[e] *= AS_QSCALE;   // q is stored pre-scaled by log2(e) / 8 (common.h)
           }
-        } else if (which == 0) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] *= AS_QSCALE;     // q is stored pre-scaled by log2(e) / 8 (common.h)
-        }
-        uint4 pk;
-        pk.x = __builtin_bit_cast(unsigned, pp_bf16x2{(__bf16)v[0], (__bf16)v[1]});
-        pk.y = __builtin_bit_cast(unsigned, pp_bf16x2{(__bf16)v[2], (__bf16)v[3]});
-        pk.z = __builtin_bit_cast(unsigned, pp_bf16x2{(__bf16)v[4], (__bf16)v[5]});
-        pk.w = __builtin_bit_cast(unsigned, pp_bf16x2{(__bf16)v[6], (__bf16)v[7]});
-        if (row >= M) continue;
-        const int col = colw + 32 * p;
-        if constexpr (EM == 0) {
-          *reinterpret_cast<uint4*>(out + (size_t)row * Nout + col) = pk;
-        } else {
-          const int cl = col - n0;                            // column inside the 128-wide tile: head cl >> 6, d0 = cl & 63
-          const size_t bh = (size_t)(b_img * epi.h + head0 + (cl >> 6));
-          const int d0 = cl & 63;
-          if (which == 0) {
-            *reinterpret_cast<uint4*>(reinterpret_cast<__bf16*>(epi.q) + qf_frag(bh, epi.Npad, n_img, d0 >> 4, (d0 >> 3) & 1)) = pk;
-          } else if (which == 1) {
-            *reinterpret_cast<uint4*>(reinterpret_cast<__bf16*>(epi.k) + (bh * epi.Npad + n_img) * 64 + d0) = pk;
+          uint4 pk;
+          pk.x = __builtin_bit_cast(unsigned, pp_bf16x2{(__bf16)v[0], (__bf16)v[1]});
+          pk.y = __builtin_bit_cast(unsigned, pp_bf16x2{(__bf16)v[2], (__bf16)v[3]});
+          pk.z = __builtin_bit_cast(unsigned, pp_bf16x2{(__bf16)v[4], (__bf16)v[5]});
+          pk.w = __builtin_bit_cast(unsigned, pp_bf16x2{(__bf16)v[6], (__bf16)v[7]});
+          if (row >= M) continue;
+          const int col = colw + 32 * p;
+          if constexpr (EM == 0) {
+            if constexpr (ACT == 2) {                          // (gelu_chunk: the GELU of the ROUNDED pre-activation, as gemm.hip)
+              *reinterpret_cast<uint4*>(reinterpret_cast<__bf16*>(epi.q) + (size_t)row * Nout + col) = pk;
+              *reinterpret_cast<uint4*>(out + (size_t)row * Nout + col) = gelu_chunk(pk);
+            } else if constexpr (ACT == 3) {
+              const pp_u32x4 h = pre[a - a0][p];
+              *reinterpret_cast<uint4*>(out + (size_t)row * Nout + col) = dgelu_chunk(pk, make_uint4(h.x, h.y, h.z, h.w));
+            } else {
+              *reinterpret_cast<uint4*>(out + (size_t)row * Nout + col) = pk;
+            }
+          } else if constexpr (EM == 2) {
+            const int tap = col / epi.D, co = col - tap * epi.D;   // (a 16-byte chunk never straddles a tap: epi.D % 8 == 0)
+            *reinterpret_cast<uint4*>(out + ((size_t)(2 * b_img + (tap >> 1)) * (2 * epi.N) + 2 * n_img + (tap & 1)) * epi.D + co) = pk;
           } else {
-            // V^T [B,h,64,Npad]: the lane's 8 values are 8 features of ONE token: 2-byte stores, 16 consecutive tokens
-            // (32 bytes) per lane group and instruction
-            __bf16* dst = reinterpret_cast<__bf16*>(epi.vt) + (bh * 64 + d0) * epi.Npad + n_img;
-            const unsigned wds[4] = {pk.x, pk.y, pk.z, pk.w};
+            const int cl = col - n0;                          // column inside the 128-wide tile: head cl >> 6, d0 = cl & 63
+            const size_t bh = (size_t)(b_img * epi.h + head0 + (cl >> 6));
+            const int d0 = cl & 63;
+            if (which == 0) {
+              *reinterpret_cast<uint4*>(reinterpret_cast<__bf16*>(epi.q) + qf_frag(bh, epi.Npad, n_img, d0 >> 4, (d0 >> 3) & 1)) = pk;
+            } else if (which == 1) {
+              *reinterpret_cast<uint4*>(reinterpret_cast<__bf16*>(epi.k) + (bh * epi.Npad + n_img) * 64 + d0) = pk;
+            } else {
+              // V^T [B,h,64,Npad]: the lane's 8 values are 8 features of ONE token: 2-byte stores, 16 consecutive tokens
+              // (32 bytes) per lane group and instruction
+              __bf16* dst = reinterpret_cast<__bf16*>(epi.vt) + (bh * 64 + d0) * epi.Npad + n_img;
+              const unsigned wds[4] = {pk.x, pk.y, pk.z, pk.w};
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-              const unsigned short bits = (unsigned short)(e & 1 ? wds[e >> 1] >> 16 : wds[e >> 1] & 0xffffu);
-              *reinterpret_cast<unsigned short*>(dst + (size_t)e * epi.Npad) = bits;
+              for (int e = 0; e < 8; ++e) {
+                const unsigned short bits = (unsigned short)(e & 1 ? wds[e >> 1] >> 16 : wds[e >> 1] & 0xffffu);
+                *reinterpret_cast<unsigned short*>(dst + (size_t)e * epi.Npad) = bits;
+              }
             }
           }
         }
@@ -315,82 +392,85 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const __bf16* __restric
   if constexpr (CFG == 0) {
     stage(I0{}); stage(I2{}); stage(I3{}); stage(I1{});       // K step 0: X0 W0 W1 X1
     stage(I0{}); stage(I3{});                                 // K step 1: X0 W1   (X1, W0 of step 1 follow in phases 0, 1)
-    if (total >= 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   } else {
     stage(I0{}); stage(I1{}); stage(I2{});                    // K step 0: X0 X1 W
     stage(I0{}); stage(I1{}); stage(I2{});                    // K step 1
     stage(I0{});                                              // K step 2: X0
-    if (total >= 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   }
   bar();
   if (grp == 1) bar();                                        // group 1 runs one barrier behind group 0
+  if (AS_PP_PRIO == 2) __builtin_amdgcn_s_setprio(1);
 
   int cbuf = 0, ckt = 0, cti = 0;
+  in_loop = true;
   for (int g = 0; g < total; ++g) {
     const unsigned boff = (unsigned)(cbuf * C::BUF);
     const unsigned xb = x_lane + boff, wb = w_lane + boff;
     if constexpr (CFG == 0) {
-      // phase 0: quadrant (M0, N0); stage X1 of step g + 1
+      // phase 0: quadrant (M0, N0); X1 of step g + 1
       read_x(std::integral_constant<int, C::X0>{}, xb);
       read_w(std::integral_constant<int, C::W0>{}, wb);
       stage(I1{});
       bar();
       pp_wait12(xf, wf);
       mfma16(I0{}, I0{});
-      bar();
-      // phase 1: (M0, N1); stage W0 of step g + 1
+      bar_load();
+      // phase 1: (M0, N1); W0 of step g + 1
       read_w(std::integral_constant<int, C::W1>{}, wb);
       stage(I2{});
       bar();
       pp_wait4(wf);
       mfma16(I0{}, I1{});
-      bar();
-      // phase 2: (M1, N1); stage X0 of step g + 2
+      bar_load();
+      // phase 2: (M1, N1); X0 of step g + 2
       read_x(std::integral_constant<int, C::X1>{}, xb);
       stage(I0{});
       bar();
       pp_wait8(xf);
       mfma16(std::integral_constant<int, 4>{}, I1{});
-      bar();
-      // phase 3: (M1, N0); stage W1 of step g + 2; everything of step g + 1 has landed when <= 4 LDS-DMAs are in flight
+      bar_load();
+      // phase 3: (M1, N0); W1 of step g + 2.  Everything of step g + 1 has landed when at most the LDS-DMAs issued after its
+      // last half-tile (W0, phase 1) are in flight: X0, W1 of step g + 2 = 4
       read_w(std::integral_constant<int, C::W0>{}, wb);
       stage(I3{});
-      if (g + 2 < total) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       bar();
       pp_wait4(wf);
       mfma16(std::integral_constant<int, 4>{}, I0{});
-      bar();
+      bar_load();
     } else {
-      // phase 0: (M, N0); stage X1 of step g + 2
+      // phase 0: (M, N0); X1 of step g + 2
       read_x(std::integral_constant<int, 0>{}, xb);
       read_w(std::integral_constant<int, C::W0>{}, wb);
       stage(I1{});
       bar();
       pp_wait12(xf, wf);
       mfma16(I0{}, I0{});
-      bar();
-      // phase 1: (M, N1); stage W of step g + 2 and X0 of step g + 3; step g + 1 has landed when <= 8 LDS-DMAs are in flight
+      bar_load();
+      // phase 1: (M, N1); W of step g + 2, X0 of step g + 3.  Step g + 1 has landed when at most the LDS-DMAs issued after ITS
+      // W are in flight: X0(g+2), X1(g+2), W(g+2), X0(g+3) = 8
       read_w(std::integral_constant<int, C::W0 + 32 * 128>{}, wb);
       stage(I2{});
       stage(I0{});
-      if (g + 3 < total) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       bar();
       pp_wait4(wf);
       mfma16(I0{}, I1{});
-      bar();
+      bar_load();
     }
     cbuf = cbuf + 1 == NBUF ? 0 : cbuf + 1;
     if (++ckt == nk) {
       ckt = 0;
+      if (AS_PP_PRIO == 2) __builtin_amdgcn_s_setprio(0);
       epilogue(rank + cti * G);
       ++cti;
       zero_acc();
+      if (AS_PP_PRIO == 2) __builtin_amdgcn_s_setprio(1);
     }
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the wrapped tail of the operand stream lands before the LDS is freed
   if (grp == 0) bar();                                        // pairs with group 1's last barrier
 }
 
@@ -423,19 +503,31 @@ int launch_pp(const void* A, const void* W, const float* bias, void* out, int M,
 // K % 64 == 0, Nout % BN == 0, 16-byte aligned rows.
 bool as_pp_applies(int M, int Nout, int K, int cfg) {
   const int bn = cfg == 0 ? 256 : 128;
-  return M >= 256 && K >= 128 && K % 64 == 0 && Nout % bn == 0 && (long long)M * K < (1LL << 31) && (long long)Nout * K < (1LL << 31);
+  return M >= 256 && K >= 128 && K % 64 == 0 && Nout % bn == 0 && (long long)M * K < (1LL << 30) && (long long)Nout * K < (1LL << 30);
 }
-int as_pp_linear(const void* x, const void* W, const float* bias, void* out, int M, int Nout, int K, int act, int cfg,
+// act: 0 none, 1 GELU, 4 ReLU; 2 = training fc1 (pre-activation -> `pre`, its GELU -> out); 3 = out = acc * GELU'(pre)
+int as_pp_linear(const void* x, const void* W, const float* bias, void* out, void* pre, int M, int Nout, int K, int act, int cfg,
                  hipStream_t s) {
-  PPEpi epi{};
-  if (cfg == 0) {
-    if (act == 1) return launch_pp<0, 0, 1>(x, W, bias, out, M, Nout, K, epi, s);
-    if (act == 4) return launch_pp<0, 0, 4>(x, W, bias, out, M, Nout, K, epi, s);
-    return launch_pp<0, 0, 0>(x, W, bias, out, M, Nout, K, epi, s);
+  PPEpi epi{pre, nullptr, nullptr, 0, 0, 0, 0};
+#define PP_GO(C_)                                                                           \
+  switch (act) {                                                                            \
+    case 1: return launch_pp<C_, 0, 1>(x, W, bias, out, M, Nout, K, epi, s);                \
+    case 2: return launch_pp<C_, 0, 2>(x, W, bias, out, M, Nout, K, epi, s);                \
+    case 3: return launch_pp<C_, 0, 3>(x, W, bias, out, M, Nout, K, epi, s);                \
+    case 4: return launch_pp<C_, 0, 4>(x, W, bias, out, M, Nout, K, epi, s);                \
+    default: return launch_pp<C_, 0, 0>(x, W, bias, out, M, Nout, K, epi, s);               \
   }
-  if (act == 1) return launch_pp<1, 0, 1>(x, W, bias, out, M, Nout, K, epi, s);
-  if (act == 4) return launch_pp<1, 0, 4>(x, W, bias, out, M, Nout, K, epi, s);
-  return launch_pp<1, 0, 0>(x, W, bias, out, M, Nout, K, epi, s);
+  if (cfg == 0) { PP_GO(0) }
+  PP_GO(1)
+#undef PP_GO
+}
+int as_pp_deconv(const void* x, const void* W4, const float* bias4, void* out, int M, int w, int cin, int cout, int act, int cfg,
+                 hipStream_t s) {
+  PPEpi epi{nullptr, nullptr, nullptr, w, 0, cout, 0};
+  if (cfg == 0) return act == 1 ? launch_pp<0, 2, 1>(x, W4, bias4, out, M, 4 * cout, cin, epi, s)
+                                : launch_pp<0, 2, 0>(x, W4, bias4, out, M, 4 * cout, cin, epi, s);
+  return act == 1 ? launch_pp<1, 2, 1>(x, W4, bias4, out, M, 4 * cout, cin, epi, s)
+                  : launch_pp<1, 2, 0>(x, W4, bias4, out, M, 4 * cout, cin, epi, s);
 }
 int as_pp_qkv(const void* x, const void* Wqkv, const float* bqkv, void* q, void* k, void* vt, int B, int N, int Npad, int D, int h,
               hipStream_t s) {

@@ -634,8 +634,14 @@ extern "C" int as_merge_parts(const float* prot, const uint8_t* keep, float thr,
              "as_merge_parts: P=%d prototypes per object (max %d), %d slots", P, MG_PMAX, slots);
   const size_t lds = (size_t)P * (C + 1) * sizeof(float);
   AS_REQUIRE(lds <= 140 * 1024, AS_E_UNSUPPORTED, "as_merge_parts: %d x %d prototypes exceed the LDS image", P, C);
-  if (lds > 48 * 1024)
+  // (a driver call in the latency-critical per-image chain: made only when this launch needs more than any before it; a race
+  //  between two host threads only repeats the idempotent call -- ADVICE r05)
+  static std::atomic<size_t> lds_set{48 * 1024};
+  if (lds > lds_set.load(std::memory_order_relaxed)) {
     (void)hipFuncSetAttribute((const void*)merge_parts_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    size_t seen = lds_set.load(std::memory_order_relaxed);
+    while (seen < lds && !lds_set.compare_exchange_weak(seen, lds, std::memory_order_relaxed)) {}
+  }
   hipLaunchKernelGGL(merge_parts_kernel, dim3(G), dim3(MG_NT), lds, (hipStream_t)stream, prot, keep, thr, merged, ngroups, flag,
                      P, C, slots);
   AS_CHECK_LAUNCH("merge_parts");

@@ -4,6 +4,7 @@ PyTorch is plumbing here: device memory, the current HIP stream, autograd bookke
 function validates device/dtype/contiguity, passes raw pointers and raises on any non-zero return.
 """
 import ctypes
+import os
 
 import threading
 
@@ -110,7 +111,8 @@ _SK_WS = {}
 
 
 def _sk_bytes(lib, M, Nout, K):
-    key = (M, Nout, K)
+    # (the library re-reads AS_GEMM_SK on every call -- tests switch it -- so the switch is part of the key: ADVICE r05)
+    key = (M, Nout, K, os.environ.get("AS_GEMM_SK"))
     v = _SK_BYTES.get(key)
     if v is None:
         v = _SK_BYTES[key] = int(lib.as_linear_sk_workspace_bytes(M, Nout, K))
@@ -147,6 +149,35 @@ def linear(x, weight, bias=None, act="none"):
     else:
         _lib.check(lib.as_linear_fwd(_p(x2), _p(weight), _p(bias), _p(out), M, Nout, K, _dt(x), code, _stream()), "as_linear_fwd")
     return out.reshape(*x.shape[:-1], Nout)
+
+
+def linear_small(x, weight, bias=None, act="none", out=None):
+    """fp32 nn.Linear for a few hundred rows (the point head, as_linear_small_fwd): x [M, K] fp32 whose rows may be a column
+    slice of a wider tensor (stride(0) >= K, stride(1) == 1), weight [Nout, K] fp32 contiguous, bias fp32 | None;
+    act none | gelu | relu | sigmoid.  `out` [M, Nout] (row stride >= Nout) is written in place when given."""
+    lib = _lib.load()
+    if x.dim() != 2 or x.dtype != torch.float32 or weight.dtype != torch.float32 or x.stride(1) != 1 or not weight.is_contiguous():
+        raise AttnShiftError("linear_small: x [M, K] fp32 with unit column stride, weight [Nout, K] fp32 contiguous")
+    M, K = x.shape
+    Nout = weight.shape[0]
+    if weight.shape[1] != K:
+        raise AttnShiftError("linear_small: weight must be [Nout, K]")
+    if bias is not None:
+        _chk(bias, dtype=torch.float32)
+    if out is None:
+        out = torch.empty(M, Nout, device=x.device, dtype=torch.float32)
+    elif out.shape != (M, Nout) or out.dtype != torch.float32 or out.stride(1) != 1:
+        raise AttnShiftError("linear_small: out must be [M, Nout] fp32 with unit column stride")
+    code = {"none": 0, "gelu": 1, "relu": 4, "sigmoid": 5}[act]
+    _lib.check(lib.as_linear_small_fwd(_p(x), x.stride(0), _p(weight), _p(bias), _p(out), out.stride(0), M, Nout, K, code, _stream()),
+               "as_linear_small_fwd")
+    return out
+
+
+def linear_small_applies(x, weight):
+    return (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == 2 and 0 < x.shape[0] <= 1024
+            and x.shape[1] >= 64 and x.shape[1] % 16 == 0 and x.stride(1) == 1 and x.stride(0) % 4 == 0 and weight.is_contiguous()
+            and x.data_ptr() % 16 == 0 and weight.data_ptr() % 16 == 0)
 
 
 def linear_gelu(x, weight, bias=None):

@@ -576,19 +576,50 @@ def grid_seed_finish(mask, count_dev, rois, n_points=20):
 
 
 _CONSTS = {}
+_CONSTS_LRU = None          # count-dependent entries (one per distinct tuple of per-image object counts), bounded
+_CONSTS_LRU_MAX = 64
 
 
-def _const_tensor(key, device, make):
-    """Small index tensors that depend only on sizes (arange, owners of padded slots): built once on the host, copied, and
-    reused by every later call and stream (the creating stream is drained once so that no other stream can read early)."""
+def _const_tensor(key, device, make, make_device=None):
+    """Small index tensors (arange, owners of padded slots, per-object metadata), reused by later calls and streams.
+
+    Keys that depend only on fixed sizes (make_device None): built once on the host, copied, the creating stream drained once
+    so that no other stream can read early; kept for the life of the process.
+    Keys that depend on the BATCH's per-image object counts (make_device given): on real data almost every step brings a new
+    tuple, so a miss must cost neither a host sync nor a pageable copy, and the cache must not grow with the dataset
+    (ADVICE r05).  make_device() builds the tensor with device-side fills on the CURRENT stream (scalars travel as kernel
+    arguments); the entry carries an event that later users on other streams wait for ON THE DEVICE until it has completed
+    once; at most _CONSTS_LRU_MAX such entries are kept (least recently used dropped)."""
+    global _CONSTS_LRU
     k = (key, str(device))
-    t = _CONSTS.get(k)
-    if t is None:
-        t = make().to(device)
-        if t.is_cuda:
-            torch.cuda.current_stream(t.device).synchronize()
-        _CONSTS[k] = t
-    return t
+    if make_device is None or torch.device(device).type != "cuda":
+        t = _CONSTS.get(k)
+        if t is None:
+            t = make().to(device)
+            if t.is_cuda:
+                torch.cuda.current_stream(t.device).synchronize()
+            _CONSTS[k] = t
+        return t
+    if _CONSTS_LRU is None:
+        import collections
+        _CONSTS_LRU = collections.OrderedDict()
+    ent = _CONSTS_LRU.get(k)
+    if ent is None:
+        t = make_device()
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(t.device))
+        ent = [t, ev]
+        _CONSTS_LRU[k] = ent
+        while len(_CONSTS_LRU) > _CONSTS_LRU_MAX:
+            _CONSTS_LRU.popitem(last=False)
+        return t
+    _CONSTS_LRU.move_to_end(k)
+    if ent[1] is not None:
+        if ent[1].query():
+            ent[1] = None                                    # landed: visible to every stream from now on
+        else:
+            torch.cuda.current_stream(ent[0].device).wait_event(ent[1])
+    return ent[0]
 
 
 def _token_blocks_ok(t):
@@ -1109,7 +1140,8 @@ class AttnShiftRoIHead(nn.Module):
                 box_patch_list = [(rois // STRIDE).to(torch.int32) for rois in rois_list]
             boxes = torch.cat(box_patch_list).contiguous() if len(box_patch_list) > 1 else box_patch_list[0].contiguous()
         owners = _const_tensor(("owners", sizes), dev,
-                               lambda: torch.cat([torch.full((n,), i, dtype=torch.int32) for i, n in enumerate(sizes)]))
+                               lambda: torch.cat([torch.full((n,), i, dtype=torch.int32) for i, n in enumerate(sizes)]),
+                               lambda: torch.cat([torch.full((n,), i, dtype=torch.int32, device=dev) for i, n in enumerate(sizes)]))
         pout, sim = ops.cosine_shift(feat_tok, boxes, owners, prot, n_shift, hp, wp, tau, temp)
         out, off = [], 0
         for g in sizes:
@@ -1406,8 +1438,18 @@ class AttnShiftRoIHead(nn.Module):
         CLOCK.mark("box_split")
         sel_rows = sel_patch = sel_int = sel_patch_all = None
         if fused_idx:
+            def meta_on_device():                                               # rows [cam_off[i], counts[i], g]
+                rows = []
+                for i in range(num_imgs):
+                    m = torch.empty(counts[i], 3, dtype=torch.int32, device=boxes.device)
+                    m[:, 0] = cam_off[i]
+                    m[:, 1] = counts[i]
+                    m[:, 2] = torch.arange(counts[i], dtype=torch.int32, device=boxes.device)
+                    rows.append(m)
+                return torch.cat(rows) if len(rows) > 1 else rows[0]
             meta = _const_tensor(("select_meta", tuple(counts), Lc), boxes.device, lambda: torch.tensor(
-                [[cam_off[i], counts[i], g] for i in range(num_imgs) for g in range(counts[i])], dtype=torch.int32))
+                [[cam_off[i], counts[i], g] for i in range(num_imgs) for g in range(counts[i])], dtype=torch.int32),
+                meta_on_device)
             pick_in = None
             if not fused_sel:
                 gt_box_index = self.layer_selector(gt_scale_bboxes, gt_labels, roi_feature_map)

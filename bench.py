@@ -107,7 +107,7 @@ def synthetic_proposals(shift, device, n=1000):
     return out
 
 
-def build(device, rng_mode="fast", train=False, ranks=None, mil=False):
+def build(device, rng_mode="fast", train=False, ranks=None, mil=False, compute_dtype=torch.bfloat16):
     import attentionshift_amd as A
     from attentionshift_amd import synthetic
 
@@ -131,7 +131,7 @@ def build(device, rng_mode="fast", train=False, ranks=None, mil=False):
                                qkv_bias=True, drop_path_rate=0.05, out_indices=(3, 5, 7, 11) if CFG["depth"] == 12 else (5, 11, 17, 23),
                                learnable_pos_embed=True, use_checkpoint=True, last_feat=True,
                                point_tokens_num=CFG["point_tokens"], num_classes=CFG["num_classes"], return_attention=True,
-                               compute_dtype=torch.bfloat16, defer_fpn=not train and os.environ.get("AS_DEFER_FPN", "0") == "1",
+                               compute_dtype=compute_dtype, defer_fpn=not train and os.environ.get("AS_DEFER_FPN", "0") == "1",
                                point_head_stream=not train and os.environ.get("AS_POINT_HEAD_STREAM", "0") == "1"))
     bb = bb.to(device)
     bb = bb.train() if train else bb.eval()
@@ -665,6 +665,19 @@ def main():
                 "the 16 kernels (operands -> MFMA -> reductions, ~8-12 us each on a quarter-full chip)"}
         except (OSError, KeyError, ValueError, StopIteration):
             pass
+        # the same step on the path that meets north_star's 1e-3 (compute_dtype=float32: exact-fp32 MFMA kernels,
+        # tests/test_gpu_backbone_fullsize.py); the headline is the bf16 path BASELINE config 2 names
+        if os.environ.get("AS_BENCH_FP32", "1") == "1":
+            try:
+                fstep = build(device, rng_mode, compute_dtype=torch.float32)
+                with torch.no_grad():
+                    for _ in range(2):
+                        fstep()
+                    rec["images_per_sec_fp32_parity_path"] = round(world * B * 5 / timed(fstep, ranks, 5), 3)
+                del fstep
+            except Exception as e:                          # noqa: BLE001
+                rec["images_per_sec_fp32_parity_path"] = None
+                rec["fp32_parity_path_error"] = f"{type(e).__name__}: {e}"[:200]
         # the same step with the trainable MIL head choosing the roll-out depth from RoI-aligned features (stdroi:2308-2312)
         if os.environ.get("AS_BENCH_MIL", "1") == "1":
             del step

@@ -61,6 +61,15 @@ int as_npad(int N);
 int as_linear_fwd(const void* x, const void* W, const float* bias, void* out, int M, int Nout, int K,
                   int dtype, int act, as_stream_t stream);
 
+/* out[M,Nout] = act(x[M,K] . W[Nout,K]^T + bias) in fp32 for SMALL M (a few hundred rows): the point head of
+ * VisionTransformerDet -- class_embed / bbox_embed, two 3-layer FFNs over the B * T = 200 point tokens
+ * (mmdet/models/backbones/visual_transformer_det.py:26-38, 145-146, 262-267).  32 x 64 output tiles whose four waves split
+ * K, so 200 rows still fill the chip; exact fp32 arithmetic (f32 MFMA chains), deterministic summation order.  Row strides
+ * ldx / ldo (elements) let a column slice of a packed activation be read / written in place.  act: 0 none, 1 exact GELU,
+ * 4 ReLU, 5 sigmoid (the coordinate head, :267).  K % 16 == 0, K >= 64, ldx % 4 == 0, 16-byte aligned x / W; bias or NULL. */
+int as_linear_small_fwd(const float* x, int ldx, const float* W, const float* bias, float* out, int ldo, int M, int Nout, int K,
+                        int act, as_stream_t stream);
+
 /* as_linear_fwd with a stream-K schedule for shapes whose tile count leaves the last round of the plain grid mostly empty
  * (ViT-B at 2 x 4197 tokens: fc1 = 396 tiles of 256 x 256 on 256 CUs, fc2 = 198 of 256 x 128): every workgroup contracts
  * the same number of K steps of the flattened (tile, K step) space; a tile cut into pieces is finished by its last-arriving

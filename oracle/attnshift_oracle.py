@@ -197,19 +197,25 @@ def prepare_tokens(img, sd, patch_size):
 
 
 def backbone_forward(img, sd, *, patch_size, depth, num_heads, out_indices, point_tokens_num,
-                     with_fpn=True, bn_eps=1e-5):
+                     with_fpn=True, bn_eps=1e-5, trace=None):
     """visual_transformer_det.py:221-275 VisionTransformerDet.forward in eval mode
-    (return_attention=True, last_feat=True, with_point_head=True, patch_size 16 FPN)."""
+    (return_attention=True, last_feat=True, with_point_head=True, patch_size 16 FPN).
+    trace (a list): receives the token tensor in front of every block and behind the last one (depth + 1 entries), for
+    per-block ("teacher-forced") comparisons."""
     B, _, H, W = img.shape
     Hp, Wp = H // patch_size, W // patch_size
     T = point_tokens_num
     x = prepare_tokens(img, sd, patch_size)
     feats, attns = [], []
     for i in range(depth):
+        if trace is not None:
+            trace.append(x.clone())
         x, p = block(x, sd, f"blocks.{i}.", num_heads)
         attns.append(p.mean(1))
         if i in out_indices:
             feats.append(x[:, 1:, :][:, :-T].permute(0, 2, 1).reshape(B, -1, Hp, Wp).contiguous())
+    if trace is not None:
+        trace.append(x.clone())
     last_feat = x[:, :-T]
     org = torch.stack(feats, dim=1)
     if with_fpn:

@@ -5,6 +5,10 @@ import numpy as np
 import pytest
 import torch
 
+# the GEMM tests force one kernel family per call (AS_GEMM_PP=0|a|b): the library re-reads the switch on every call only when
+# this is set before its first use
+os.environ.setdefault("AS_GEMM_PP_DYN", "1")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "oracle")):
     if p not in sys.path:

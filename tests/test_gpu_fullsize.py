@@ -10,6 +10,8 @@ that iteration, except patches whose two candidates are tied to within the fp32 
 weights both underflow (helpers.check_shift_decisions).  Everything else (boxes, sampled points, mask points, masks,
 part counts) is compared bit for bit.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -64,6 +66,7 @@ def test_cosine_shift_every_iteration_is_the_reference_argmax(ops, cfg2):
     pout, sim, assign, tau = run(S, True)
     states = [prot0] + [run(k)[0].cpu() for k in range(1, S)] + [pout.cpu()]
     flips_total = 0
+    record = []                                              # per-iteration counts -> gpurun_out/r06_shift_flips.json
     for k in range(S):
         tau_k = 0.1 if k == 0 else tau[k - 1].cpu()[..., None]        # python float at iteration 0, as the reference
         step = O.cosine_shift_step(states[k], feats, tau_k, faithful=True)
@@ -78,10 +81,21 @@ def test_cosine_shift_every_iteration_is_the_reference_argmax(ops, cfg2):
         _rows_close(step["prot"][same], states[k + 1][same], f"prototypes after iteration {k}")
         assert_close(step["tau"][..., 0][same], tau[k].cpu()[same], 1e-3, 2e-6, f"tau after iteration {k}")
         print(f"[cfg2] iteration {k}: {n} coin-flip patches (near ties {near}, underflow {under}) of {assign[k].numel()}")
+        record.append(dict(iteration=k, coin_flip_patches=int(n), near_ties=int(near), underflow=int(under),
+                           assignments=int(assign[k].numel())))
     # against the reference's own trajectory (fixture): identical unless a coin flip moved a patch
     ref_assign = t(g["ref_assign"]).long()
     diff = [(assign[k].long().cpu() != ref_assign[k]).sum().item() for k in range(S)]
     print(f"[cfg2] patches assigned differently from the reference run, per iteration: {diff}; coin flips {flips_total}")
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out_dir):                               # (the relaxed argmax bar stays visible)
+        import json
+        with open(os.path.join(out_dir, "r06_shift_flips.json"), "w") as f:
+            json.dump({"case": "tests/golden/shift_cfg2.npz (64 x 64 patches, C = 768, G = 3, 20 seeds, 5 iterations)",
+                       "bar": "argmax equal on every DETERMINED decision; a patch may differ only where the fp64 margin between its two "
+                              "best clusters is inside the fp32 noise of the cosine (tests/helpers.py check_shift_decisions)",
+                       "per_iteration": record, "differs_from_reference_run_per_iteration": [int(d) for d in diff],
+                       "bound_per_iteration": 16}, f, indent=1)
     if flips_total == 0:
         assert sum(diff) == 0, "no coin flips, so the whole trajectory must equal the reference's"
         _rows_close(t(g["ref_prot"]), pout.reshape(-1, pout.shape[-1]).cpu(), "prototypes vs reference")

@@ -239,3 +239,34 @@ def test_median_area_selector_batched_equals_per_image():
     mixed = median_area_selector([boxes[0], boxes[1][:, :5]])           # different depth counts: per-image path
     assert torch.equal(mixed[0], single[0]) and mixed[1].shape == (5,)
 
+
+
+def test_bench_gpus_flag_launches_or_fails_loudly():
+    """bench.py --gpus N: without a launcher N > 1 re-executes under torch.distributed.run with one
+    rank per GPU on 127.0.0.1; under a launcher the world size must equal --gpus; a node with fewer GPUs than ranks is an
+    error unless AS_BENCH_SHARE_GPUS asks for the plumbing check.  (The re-exec itself runs in test_distributed_cpu.)"""
+    import bench
+    assert bench.launch_plan(1, {}, [], 0) == ("run", None)
+    what, cmd = bench.launch_plan(4, {}, ["--gpus", "4", "--steps", "3"], 8, script="/x/bench.py")
+    assert what == "spawn"
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-5:] == ["/x/bench.py", "--gpus", "4", "--steps", "3"]
+    assert bench.launch_plan(2, {}, [], 1)[0] == "error"                                   # 2 ranks, 1 GPU: fail loudly
+    assert bench.launch_plan(2, {"AS_BENCH_SHARE_GPUS": "1"}, [], 1)[0] == "spawn"         # ... unless sharing is asked for
+    assert bench.launch_plan(2, {"WORLD_SIZE": "2", "LOCAL_WORLD_SIZE": "2"}, [], 2) == ("run", None)
+    assert bench.launch_plan(1, {"WORLD_SIZE": "2"}, [], 2)[0] == "error"                  # launcher and flag disagree
+    assert bench.launch_plan(8, {"WORLD_SIZE": "8", "LOCAL_WORLD_SIZE": "8"}, [], 1)[0] == "error"
+    assert bench.launch_plan(0, {}, [], 1)[0] == "error"
+
+
+def test_bench_gpus_2_on_a_box_without_two_gpus_exits_2_instead_of_measuring_one_rank():
+    import subprocess
+    import sys as _sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        pytest.skip("needs a box with fewer than two GPUs")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "AS_BENCH_SHARE_GPUS")}
+    p = subprocess.run([_sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode == 2, (p.returncode, p.stderr[-500:])
+    assert "--gpus 2" in p.stderr and p.stdout.strip() == ""

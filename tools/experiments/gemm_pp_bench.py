@@ -31,7 +31,7 @@ def main():
     ap.add_argument("--lib", action="store_true", help="also time torch.nn.functional.linear (hipBLASLt)")
     ap.add_argument("--qkv", action="store_true", help="as_qkv_fwd: parity of q / k / V^T against gemm.hip + timing")
     ap.add_argument("--only", default="")
-    ap.add_argument("--variants", default="0,a,b")
+    ap.add_argument("--variants", default="0,a0,a1,b0,b1", help="0 = gemm.hip; a / b = tile shape, then the VAR digit")
     a = ap.parse_args()
     import torch
     from attentionshift_amd import _lib
@@ -66,7 +66,8 @@ def main():
             out = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
 
             def call(v=v, out=out):
-                os.environ["AS_GEMM_PP"] = v
+                os.environ["AS_GEMM_PP"] = v[0]
+                os.environ["AS_GEMM_PP_VAR"] = v[1:] or "1"
                 rc = lib.as_linear_fwd(x.data_ptr(), w.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, K, 1, act, st)
                 assert rc == 0, (rc, lib.as_last_error())
             for _ in range(3):
@@ -107,13 +108,14 @@ def main():
             w = ((torch.rand(3 * D, D, device="cuda", generator=g) * 2 - 1) * 0.05).bfloat16()
             b = torch.rand(3 * D, device="cuda", generator=g) * 2 - 1
             res, calls = {}, {}
-            for v in ("0", "b"):
+            for v in ("0", "b0", "b1"):
                 q = torch.zeros(B, h, Npad, 64, device="cuda", dtype=torch.bfloat16)
                 k = torch.zeros_like(q)
                 vt = torch.zeros(B, h, 64, Npad, device="cuda", dtype=torch.bfloat16)
 
                 def call(v=v, q=q, k=k, vt=vt):
-                    os.environ["AS_GEMM_PP"] = v
+                    os.environ["AS_GEMM_PP"] = v[0]
+                    os.environ["AS_GEMM_PP_VAR"] = v[1:] or "1"
                     rc = lib.as_qkv_fwd(x.data_ptr(), w.data_ptr(), b.data_ptr(), q.data_ptr(), k.data_ptr(), vt.data_ptr(), B, N, D, h, 1, st)
                     assert rc == 0, (rc, lib.as_last_error())
                 for _ in range(3):
@@ -128,12 +130,14 @@ def main():
             y = torch.nn.functional.linear(x.float(), w.float(), b).reshape(B, N, 3, h, 64)
             kref = y[:, :, 1].permute(0, 2, 1, 3)
             vref = y[:, :, 2].permute(0, 2, 3, 1)
-            rec = dict(shape=f"qkv B{B} N{N} D{D}", us_old=round(min(times["0"]), 1), us_pp=round(min(times["b"]), 1))
-            for v in ("0", "b"):
+            rec = dict(shape=f"qkv B{B} N{N} D{D}", us_old=round(min(times["0"]), 1), us_pp0=round(min(times["b0"]), 1),
+                       us_pp1=round(min(times["b1"]), 1))
+            for v in ("0", "b0", "b1"):
                 q, k, vt = res[v]
                 rec[f"k_err_{v}"] = round(float((k[:, :, :N].float() - kref).abs().max() / kref.abs().max()), 5)
                 rec[f"vt_err_{v}"] = round(float((vt[:, :, :, :N].float() - vref).abs().max() / vref.abs().max()), 5)
-            dq = (res["0"][0].float() - res["b"][0].float()).abs()
+            rec["b0_eq_b1"] = all(bool(torch.equal(x0, x1)) for x0, x1 in zip(res["b0"], res["b1"]))
+            dq = (res["0"][0].float() - res["b1"][0].float()).abs()
             rec["q_max_diff_vs_old"] = round(float(dq.max() / res["0"][0].float().abs().max()), 5)
             rec["q_frac_diff"] = round(float((dq > 0).float().mean()), 5)
             print(json.dumps(rec), flush=True)
