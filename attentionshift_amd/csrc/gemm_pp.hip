@@ -21,6 +21,8 @@
 // LDS image of a half-tile (16 KiB = 128 rows x 64 k): row r at r * 128, 16-byte chunk c of the row at slot c ^ ((r >> 1) & 7):
 // the 16-lane groups of a ds_read_b128 fragment read (rows i = lane & 15, chunk lane >> 4) then cover the 16 slots of a 256-byte
 // bank row exactly once.  The image is lane-linear for the LDS-DMA, so the XOR sits on the SOURCE chunk.
+#include <map>
+#include <mutex>
 #include <utility>
 #include "common.h"
 #include "gemm_epi.h"
@@ -51,6 +53,15 @@ typedef __attribute__((ext_vector_type(2))) __bf16 pp_bf16x2;
 struct PPEpi {
   void* q; void* k; void* vt;       // QKV mode outputs
   int N, Npad, D, h;                // tokens per image, padded, model width, heads
+};
+
+// Stream-K plan of a launch (SK kernels only; csrc/gemm_pp.hip launch_pp): the first D * G tiles are whole tiles (workgroup r:
+// r, r + G, ...), the other `sk_tiles` (G <= sk_tiles < 2 G) are cut into G contiguous ranges of the (tile, K step) sequence.
+struct PPPlan {
+  int D, sk_tiles;
+  unsigned epoch;                   // this launch's flag value (never 0; flags are never reset)
+  void* slabs;                      // [G][NV4][512] 16-byte vectors: the fp32 accumulators of a workgroup's open tile
+  unsigned* flags;                  // [G][8]: wave w of workgroup g has published its part of slab g when flags[g][w] == epoch
 };
 
 template <int OFF> __device__ __forceinline__ void pp_read(pp_u32x4& d, unsigned addr) {
@@ -107,10 +118,21 @@ template <> struct PPCfg<1> {
 // (Where the LDS-DMA instructions are issued was measured three ways, profiles/r06_gemm_pp.md: in the phase's load segment
 //  beside the fragment reads -- kept --, between the MFMAs of the phase's cluster, and behind the cluster; the last two are
 //  12-17 % slower on every shape: the issuing wave's MFMAs stall behind each DMA instruction.)
-template <int CFG, int EM, int ACT>
+// SK (stream-K tail, round 6): the tiles that do not fill a whole round of the G workgroups are shared out by K steps, so that
+// every workgroup streams the same number of K steps (+- 1).  A workgroup's range [u0, u1) of the tail's (tile, K step)
+// sequence is 1 .. 2 tiles long (G <= sk_tiles < 2 G), so it touches 2 or 3 tiles and a tile has at most TWO contributors:
+//   * the workgroup that holds a tile's FIRST K steps but not its last runs that piece FIRST, stores the accumulators to its
+//     slab (write-through 16-byte stores) and publishes per-wave flags two K steps later -- loads and stores retire in order
+//     on the vm counter, so the K loop's own counted wait covers the slab stores by then: no drain, no fence;
+//   * then its whole tiles; and LAST the tile whose remaining K steps it holds: it starts from the neighbour's slab instead of
+//     zero (flag poll + sc1 loads; the slab was written ~a whole launch earlier) and finishes the tile.
+// Every output is still ONE k-ordered fp32 MFMA chain -- handed over once through memory -- so the result is bit-identical to the
+// non-split kernel's and to gemm.hip's.  No workgroup ever waits for a workgroup that waits: producers publish before anything else.
+template <int CFG, int EM, int ACT, bool SK>
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const __bf16* __restrict__ A, const __bf16* __restrict__ W,
                                                          const float* __restrict__ bias, __bf16* __restrict__ out, int M,
-                                                         int Nout, int K, PPEpi epi) {
+                                                         int Nout, int K, PPEpi epi, PPPlan plan) {
+#if defined(__HIP_DEVICE_COMPILE__)                            // (buffer descriptors are a device-pass type; the host pass needs the stub only)
   using C = PPCfg<CFG>;
   constexpr int BM = C::BM, BN = C::BN, NBUF = C::NBUF, MA = C::MA;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -126,9 +148,49 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const __bf16* __restric
   const int G = gridDim.x;
   const int rank = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
   if (rank >= tiles) return;
-  const int my_tiles = (tiles - rank + G - 1) / G;
   const int nk = K >> 6;
-  const int total = my_tiles * nk;                           // K steps of this workgroup's operand stream
+  // this workgroup's SEGMENTS in execution order: (tile, first K step, end K step).  Not SK: its whole tiles.  SK: [the open
+  // head of a tail tile] [D whole tiles] [up to three pieces of the tail, the one that continues a neighbour's tile last]
+  int nA = 0, nB = 0, nD = (tiles - rank + G - 1) / G;
+  int a_t = 0, a_k1 = 0, b0_t = 0, b0_k0 = 0, b1_t = 0, b1_k0 = 0, b2_t = 0, b2_k0 = 0;   // (scalars, no indexed array: SGPRs)
+  int total = nD * nk;                                       // K steps of this workgroup's operand stream
+  if constexpr (SK) {
+    nD = plan.D;
+    const int base = plan.D * G;
+    const unsigned U = (unsigned)(plan.sk_tiles * nk);        // (U * G < 2^31: checked by the launcher; 32-bit scalar divisions)
+    const int u0 = __builtin_amdgcn_readfirstlane((int)(U * (unsigned)rank / (unsigned)G));
+    const int u1 = __builtin_amdgcn_readfirstlane((int)(U * (unsigned)(rank + 1) / (unsigned)G));
+    const int tf = u0 / nk, kf = u0 - tf * nk, tl = (u1 - 1) / nk, kl = u1 - tl * nk;
+    if (tf == tl) {                                          // (one whole tile: u1 - u0 >= nk)
+      b0_t = base + tf; b0_k0 = 0; nB = 1;
+    } else {
+      const bool tail_full = kl == nk, mid = tl - tf == 2;
+      if (!tail_full) { a_t = base + tl; a_k1 = kl; nA = 1; }
+      nB = 1 + (tail_full ? 1 : 0) + (mid ? 1 : 0);           // [whole tail] [middle] head
+      b0_t = base + (tail_full ? tl : mid ? tf + 1 : tf);
+      b0_k0 = tail_full || mid ? 0 : kf;
+      b1_t = base + (tail_full && mid ? tf + 1 : tf);
+      b1_k0 = tail_full && mid ? 0 : kf;
+      b2_t = base + tf;
+      b2_k0 = kf;
+    }
+    total = nD * nk + (u1 - u0);
+  }
+  const int nseg = nA + nD + nB;
+  // segment i -> tile, k0, k1 (all uniform)
+  struct Seg { int tile, k0, k1; };
+  auto seg_at = [&](int i) __attribute__((always_inline)) -> Seg {
+    if (SK && i < nA) return Seg{a_t, 0, a_k1};
+    if (!SK || i < nA + nD) return Seg{rank + (i - nA) * G, 0, nk};
+    const int j = i - nA - nD;
+    // (arithmetic selects on VALUES: `c ? x : y` on captured variables is a select of their addresses -- hipcc then keeps every
+    //  captured scalar in scratch memory and loads it back through a flat pointer inside the K loop)
+    const int t0 = b0_t + 0, t1 = b1_t + 0, t2 = b2_t + 0, q0 = b0_k0 + 0, q1 = b1_k0 + 0, q2 = b2_k0 + 0;
+    const int m0 = -(int)(j == 0), m1 = -(int)(j == 1), m2 = -(int)(j >= 2);
+    return Seg{(t0 & m0) | (t1 & m1) | (t2 & m2), (q0 & m0) | (q1 & m1) | (q2 & m2), nk};
+  };
+  const Seg seg0 = seg_at(0);
+  const int seg0_t = seg0.tile, seg0_k0 = seg0.k0, seg0_k1 = seg0.k1;
 
   // ---- LDS-DMA source pointers: [half-tile type][piece]; wave w moves pieces 2w, 2w+1 (8 LDS rows x 128 B each) ----
   // piece p, lane l -> LDS row 8 p + (l >> 3), physical chunk l & 7 -> source chunk (l & 7) ^ ((row >> 1) & 7)
@@ -146,7 +208,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const __bf16* __restric
     ld_row[j] = (2 * wave + j) * 8 + (lane >> 3);
     ld_chunk[j] = ((lane & 7) ^ ((AS_PP_ABLATE & 8) ? 0 : ((ld_row[j] >> 1) & 7))) << 4;
   }
-  auto x_src = [&](int h, int j, int tile) {
+  auto x_src = [&](int h, int j, int tile) __attribute__((always_inline)) {
     const int m0 = (tile / nt_n) * BM, l = ld_row[j];
     const int trow = CFG == 0 ? ((l >> 6) * 128 + h * 64 + (l & 63)) : (h * 128 + l);
 #if PP_BUF
@@ -155,7 +217,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const __bf16* __restric
     return reinterpret_cast<const char*>(A) + (size_t)min(m0 + trow, M - 1) * K * 2 + ld_chunk[j];
 #endif
   };
-  auto w_src = [&](int h, int j, int tile) {
+  auto w_src = [&](int h, int j, int tile) __attribute__((always_inline)) {
     const int n0 = (tile % nt_n) * BN, l = ld_row[j];
     const int tcol = CFG == 0 ? ((l >> 5) * 64 + h * 32 + pp_pi32(l & 31)) : ((l >> 5) * 32 + pp_pi32(l & 31));
 #if PP_BUF
@@ -165,22 +227,23 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const __bf16* __restric
 #endif
   };
   // stream position of every half-tile type: (tile index in my list, K step, LDS buffer)
-  int st_ti[2 + C::NWH], st_kt[2 + C::NWH], st_buf[2 + C::NWH];
+  int st_ti[2 + C::NWH], st_kt[2 + C::NWH], st_ke[2 + C::NWH], st_buf[2 + C::NWH];   // (segment index, K step, the segment's end K step)
 #pragma unroll
-  for (int t = 0; t < 2 + C::NWH; ++t) { st_ti[t] = 0; st_kt[t] = 0; st_buf[t] = 0; }
+  for (int t = 0; t < 2 + C::NWH; ++t) { st_ti[t] = 0; st_kt[t] = seg0_k0; st_ke[t] = seg0_k1; st_buf[t] = 0; }
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
-    sx[0][j] = x_src(0, j, rank); sx[1][j] = x_src(1, j, rank);
+    sx[0][j] = x_src(0, j, seg0_t); sx[1][j] = x_src(1, j, seg0_t);
 #pragma unroll
-    for (int h = 0; h < C::NWH; ++h) sw[h][j] = w_src(h, j, rank);
+    for (int h = 0; h < C::NWH; ++h) sw[h][j] = w_src(h, j, seg0_t);
   }
+  static_assert(!(SK && PP_BUF), "the stream-K kernels use the pointer form of the LDS-DMA");
   bool in_loop = false;                                      // (AS_PP_ABLATE & 1 only)
   // stage<T>(): the next K step of half-tile type T (0 X0, 1 X1, 2 W0, 3 W1) -> its slot of buffer st_buf[T], two LDS-DMA
   // instructions per wave.  The stream never runs dry: behind the last K step of the last tile it wraps to that tile's first
   // K step again (two or three K steps of loads nobody reads, into slots that are free by then) -- so every counted vmcnt below
   // holds for every iteration and the load segment carries no "stream exhausted" branches (each s_cbranch in it is on the
   // critical path of the ping-pong: the load segment, not the 16 MFMAs, bounds a phase).
-  auto stage = [&](auto t_c) {
+  auto stage = [&](auto t_c) __attribute__((always_inline)) {
     constexpr int T = decltype(t_c)::value;
     constexpr int SLOT = T == 0 ? C::X0 : T == 1 ? C::X1 : T == 2 ? C::W0 : C::W1;
     if ((AS_PP_ABLATE & 1) && in_loop) return;
@@ -204,14 +267,21 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const __bf16* __restric
 #endif
     }
     st_buf[T] = st_buf[T] + 1 == NBUF ? 0 : st_buf[T] + 1;
-    if (__builtin_expect(++st_kt[T] == nk, 0)) {             // (once per tile and type)
-      st_kt[T] = 0;
-      st_ti[T] = st_ti[T] + 1 < my_tiles ? st_ti[T] + 1 : st_ti[T];
-      const int tile = rank + st_ti[T] * G;
+    if (__builtin_expect(++st_kt[T] == st_ke[T], 0)) {       // (once per segment and type)
+      st_ti[T] = st_ti[T] + 1 < nseg ? st_ti[T] + 1 : st_ti[T];
+      const Seg sg = seg_at(st_ti[T]);
+      const int tile = sg.tile, k0 = sg.k0;
+      st_kt[T] = k0;
+      st_ke[T] = sg.k1;
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
+#if PP_BUF
         if constexpr (T < 2) sx[T][j] = x_src(T, j, tile);
         else sw[T - 2][j] = w_src(T - 2, j, tile);
+#else
+        if constexpr (T < 2) sx[T][j] = x_src(T, j, tile) + k0 * 128;
+        else sw[T - 2][j] = w_src(T - 2, j, tile) + k0 * 128;
+#endif
       }
     }
   };
@@ -282,7 +352,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const __bf16* __restric
   };
 
   // ---- epilogue: accumulators -> memory, 16 bytes (8 consecutive columns) per lane and (m fragment, column block) ----
-  auto epilogue = [&](int tile) {
+  auto epilogue = [&](int tile) __attribute__((always_inline)) {
     const int m0 = (tile / nt_n) * BM, n0 = (tile % nt_n) * BN;
     const int colw = n0 + wc * 64 + 8 * lg;                  // + 32 p
     f32x4 bv[2][2];
@@ -403,7 +473,48 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const __bf16* __restric
   if (grp == 1) bar();                                        // group 1 runs one barrier behind group 0
   if (AS_PP_PRIO == 2) __builtin_amdgcn_s_setprio(1);
 
-  int cbuf = 0, ckt = 0, cti = 0;
+  // ---- stream-K hand-over of an open tile (SK): the accumulators as 16-byte vectors, vector j of thread t at [slab][j][t] ----
+  constexpr int NV4 = MA * 4;
+  const __amdgpu_buffer_rsrc_t rs_slab =
+      __builtin_amdgcn_make_buffer_rsrc(plan.slabs, (short)0, SK ? (int)((size_t)G * NV4 * 512 * 16) : 0, 0x00027000);
+  int pub = 0;                                               // > 0: K steps until this wave may publish its slab's flag
+  auto slab_store = [&]() __attribute__((always_inline)) {
+    const unsigned base = (unsigned)((rank * NV4) * 512 + tid) * 16u;
+#pragma unroll
+    for (int a = 0; a < MA; ++a)
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pp_u32x4, acc[a][p][f]), rs_slab,
+                                                 (int)(base + (unsigned)((a * 2 + p) * 2 + f) * 8192u), 0, 16 /* sc1: write-through */);
+  };
+  auto slab_publish = [&]() __attribute__((always_inline)) {                                // (every lane stores the same word: no divergent branch in the loop)
+    __hip_atomic_store(plan.flags + rank * 8 + wave, plan.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  auto slab_load = [&]() __attribute__((always_inline)) {                                   // the neighbour's open tile -> the accumulators
+    const unsigned* flag = plan.flags + (rank - 1) * 8 + wave;
+    // (readfirstlane: a UNIFORM exit -- hipcc otherwise treats everything the K loop carries past this loop as divergent and
+    //  moves the stream's counters to VGPRs)
+    while ((unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != plan.epoch)
+      __builtin_amdgcn_s_sleep(4);
+    const unsigned base = (unsigned)(((rank - 1) * NV4) * 512 + tid) * 16u;
+#pragma unroll
+    for (int a = 0; a < MA; ++a)
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+          acc[a][p][f] = __builtin_bit_cast(
+              f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_slab, (int)(base + (unsigned)((a * 2 + p) * 2 + f) * 8192u), 0, 16 /* sc1 */));
+    // waited for HERE (as the bias in the epilogue): hipcc must not carry a vmcnt(0) for these loads into the K loop
+#pragma unroll
+    for (int a = 0; a < MA; ++a)
+#pragma unroll
+      for (int p = 0; p < 2; ++p) asm volatile("" : "+v"(acc[a][p][0]), "+v"(acc[a][p][1]));
+  };
+
+  int cbuf = 0, ckt = seg0_k0, cke = seg0_k1, ctile = seg0_t, cti = 0;
   in_loop = true;
   for (int g = 0; g < total; ++g) {
     const unsigned boff = (unsigned)(cbuf * C::BUF);
@@ -461,17 +572,90 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const __bf16* __restric
       bar_load();
     }
     cbuf = cbuf + 1 == NBUF ? 0 : cbuf + 1;
-    if (++ckt == nk) {
-      ckt = 0;
+    if constexpr (SK) {
+      // this K step's counted wait is behind us: two K steps after the slab stores they are older than every operation the wait
+      // may leave in flight (cfg 0: 8 LDS-DMAs per K step, vmcnt(4); cfg 1: 6 per K step, vmcnt(8)), i.e. retired = written through
+      if (__builtin_expect(pub == 1, 0)) slab_publish();
+      pub = pub > 0 ? pub - 1 : 0;
+    }
+    if (++ckt == cke) {
       if (AS_PP_PRIO == 2) __builtin_amdgcn_s_setprio(0);
-      epilogue(rank + cti * G);
+      if (SK && cke < nk) {                                   // an open tile: hand the accumulators to the next workgroup
+        slab_store();
+        pub = 2;
+      } else {
+        epilogue(ctile);
+      }
       ++cti;
-      zero_acc();
+      ckt = 0;
+      if (cti < nseg) {
+        const Seg sg = seg_at(cti);
+        ctile = sg.tile; ckt = sg.k0; cke = sg.k1;
+      }
+      if (SK && ckt > 0) slab_load();
+      else zero_acc();
       if (AS_PP_PRIO == 2) __builtin_amdgcn_s_setprio(1);
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the wrapped tail of the operand stream lands before the LDS is freed
+  if constexpr (SK) {
+    if (pub > 0) slab_publish();                              // (a last segment shorter than two K steps)
+  }
   if (grp == 0) bar();                                        // pairs with group 1's last barrier
+#endif
+}
+
+// ---- stream-K workspace: one per (device, stream), made on first use, never freed (64 MiB of slabs + 8 KiB of flags) ----
+// Launches on one stream are ordered, so a stream's slabs are reused launch after launch; the flags are never reset: each
+// launch compares them with its own epoch.
+struct PPWorkspace {
+  void* slabs = nullptr;
+  unsigned* flags = nullptr;
+  unsigned epoch = 0;
+};
+constexpr size_t PP_SLAB_BYTES = (size_t)256 * 32 * 512 * 16;   // G <= 256 workgroups x the 256 x 256 tile's 32 vectors per thread
+constexpr size_t PP_FLAG_BYTES = (size_t)256 * 8 * sizeof(unsigned);
+
+PPWorkspace* pp_workspace(hipStream_t s) {
+  static std::mutex mu;
+  static std::map<std::pair<int, hipStream_t>, PPWorkspace> all;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = all.find({dev, s});
+  if (it != all.end()) return it->second.slabs ? &it->second : nullptr;
+  PPWorkspace ws;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return nullptr; }
+  void* mem = nullptr;
+  if (hipMalloc(&mem, PP_SLAB_BYTES + PP_FLAG_BYTES) != hipSuccess) {
+    (void)hipGetLastError();
+    all[{dev, s}] = ws;                                       // (remembered: this stream stays with whole tiles)
+    return nullptr;
+  }
+  ws.slabs = mem;
+  ws.flags = reinterpret_cast<unsigned*>(static_cast<char*>(mem) + PP_SLAB_BYTES);
+  (void)hipMemsetAsync(ws.flags, 0, PP_FLAG_BYTES, s);
+  return &(all[{dev, s}] = ws);
+}
+
+// AS_GEMM_PP_SK = 0: whole tiles only | 1: the stream-K tail wherever it applies | unset: where the round model below predicts a gain
+// (re-read per call under AS_GEMM_PP_DYN).  Measured on one MI355X (profiles/r06_gemm_pp_sk.md): the hand-over costs ~9 us per launch
+// with 128 KiB slabs (256 x 128 tiles) and ~20 us with 256 KiB slabs -- the write-through slab stores retire in order with the LDS-DMAs,
+// so the K loop's counted waits stand behind them -- which eats the saved fraction of a round on the ViT-B shapes (fc1 792 tiles: 50.5
+// vs 50.8 us) and pays where the last round is mostly empty (ViT-L fc2, 328 tiles of 64 K steps: 103.8 -> 89.2 us).
+int pp_sk_mode() {
+  static const bool dyn = getenv("AS_GEMM_PP_DYN") != nullptr;
+  static const char* e0 = getenv("AS_GEMM_PP_SK");
+  const char* e = dyn ? getenv("AS_GEMM_PP_SK") : e0;
+  return e == nullptr ? -1 : e[0] == '0' ? 0 : 1;
+}
+bool pp_sk_pays(int cfg, int tiles, int grid, int nk, bool gelu) {
+  const float tk = cfg == 0 ? 1.55f : 0.85f, epi = (cfg == 0 ? 3.0f : 2.0f) + (gelu ? (cfg == 0 ? 5.0f : 2.5f) : 0.0f);
+  const float rounds = (float)as_ceil_div(tiles, grid);
+  const float whole = rounds * (nk * tk + epi);
+  const float shared = (float)tiles * nk / grid * tk + rounds * epi + (cfg == 0 ? 20.0f : 9.0f);
+  return shared < 0.92f * whole;
 }
 
 template <int CFG, int EM, int ACT>
@@ -485,13 +669,34 @@ int launch_pp(const void* A, const void* W, const float* bias, void* out, int M,
   const int tiles = as_ceil_div(M, C::BM) * (Nout / C::BN);
   const int grid = tiles >= cus ? cus : as_round_up(tiles, 8);
   const size_t lds = (size_t)C::NBUF * C::BUF;
-  static std::atomic<bool> attr_set{false};
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_pp_kernel<CFG, EM, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
+  // stream-K tail: more than one round and a ragged last one (GELU' form excluded: its epilogue loads beside the slab loads were
+  // not worth a second variant).  All `grid` workgroups must be co-resident for the hand-over to be prompt (one per CU: they are)
+  PPPlan plan{0, 0, 0u, nullptr, nullptr};
+  bool sk = false;
+  if (tiles > grid && tiles % grid != 0 && grid <= 256 && !(EM == 0 && ACT == 3) && (long long)2 * grid * (K / 64) * grid < (1LL << 31) &&
+      (pp_sk_mode() == 1 || (pp_sk_mode() < 0 && pp_sk_pays(CFG, tiles, grid, K / 64, EM != 1 && (ACT == 1 || ACT == 2))))) {
+    if (PPWorkspace* ws = pp_workspace(s)) {
+      plan.D = tiles / grid - 1;
+      plan.sk_tiles = tiles - plan.D * grid;
+      if (++ws->epoch == 0u) ws->epoch = 1u;
+      plan.epoch = ws->epoch;
+      plan.slabs = ws->slabs;
+      plan.flags = ws->flags;
+      sk = true;
+    }
   }
-  hipLaunchKernelGGL((gemm_pp_kernel<CFG, EM, ACT>), dim3(grid), dim3(512), lds, s, (const __bf16*)A, (const __bf16*)W, bias,
-                     (__bf16*)out, M, Nout, K, epi);
+  static std::atomic<bool> attr_set[2] = {{false}, {false}};
+  if (!attr_set[sk]) {
+    if (sk) (void)hipFuncSetAttribute((const void*)gemm_pp_kernel<CFG, EM, ACT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    else (void)hipFuncSetAttribute((const void*)gemm_pp_kernel<CFG, EM, ACT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set[sk] = true;
+  }
+  if (sk)
+    hipLaunchKernelGGL((gemm_pp_kernel<CFG, EM, ACT, true>), dim3(grid), dim3(512), lds, s, (const __bf16*)A, (const __bf16*)W, bias,
+                       (__bf16*)out, M, Nout, K, epi, plan);
+  else
+    hipLaunchKernelGGL((gemm_pp_kernel<CFG, EM, ACT, false>), dim3(grid), dim3(512), lds, s, (const __bf16*)A, (const __bf16*)W, bias,
+                       (__bf16*)out, M, Nout, K, epi, plan);
   AS_CHECK_LAUNCH("gemm_pp");
   return AS_OK;
 }

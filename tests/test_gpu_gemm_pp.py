@@ -189,3 +189,67 @@ def test_linear_small_reads_and_writes_column_slices_in_place():
     ops.linear_small(h1[:, :hc], w, None, out=wide[:, hc:2 * hc])
     assert torch.equal(wide[:, hc:2 * hc], ops.linear_small(h1[:, :hc], w, None))
     assert (wide[:, :hc] == -7.0).all() and (wide[:, 2 * hc:] == -7.0).all()
+
+
+# ---- stream-K tail (round 6): launches with more than one round of tiles and a ragged last one share the tail out by K steps; an
+# open tile is handed to the next workgroup through a slab of fp32 accumulators (one k-ordered chain per output still: bit-identical)
+SK_SHAPES = [  # M, N, K, act, cfg -- tiles / 256 workgroups
+    (8394, 3072, 768, "gelu", "a"),     # 396 tiles: D = 0, 396 tail tiles (every workgroup: open head, whole tile or not, open tail)
+    (8394, 3072, 768, "none", "b"),     # 792: two whole rounds + 280 tail tiles
+    (8394, 2304, 768, "none", "b"),     # 594 (the QKV shape as a plain linear): one whole round + 338
+    (8394, 2304, 128, "relu", "b"),     # the shortest stream: 2 K steps per tile, open pieces of ONE K step
+    (10402, 4096, 1024, "gelu", "a"),   # ViT-L fc1: 41 x 16 = 656 tiles: D = 1, 400 tail tiles
+    (6501, 3072, 192, "none", "b"),     # 26 x 24 = 624: ragged last panel inside the tail
+    (16500, 2048, 256, "none", "a"),    # 65 x 8 = 520: D = 1, 264 tail tiles (a tail barely longer than one round)
+    (16500, 2048, 256, "none", "b"),    # 65 x 16 = 1040: D = 3, 272
+]
+
+
+@pytest.mark.parametrize("M,N,K,act,cfg", SK_SHAPES)
+def test_stream_k_tail_is_bitwise_the_whole_tile_kernel(M, N, K, act, cfg):
+    from attentionshift_amd import ops
+    x, w = rnd(M, K, seed=M + K + 3), rnd(N, K, seed=N + K + 5)
+    b = rnd(N, seed=11, dtype=torch.float32)
+    ref = torch.nn.functional.linear(x.float(), w.float(), b)
+    ref = torch.nn.functional.gelu(ref) if act == "gelu" else torch.relu(ref) if act == "relu" else ref
+    os.environ["AS_GEMM_PP_SK"] = "0"
+    try:
+        with force(cfg):
+            whole = ops.linear(x, w, b, act=act)
+        os.environ["AS_GEMM_PP_SK"] = "1"
+        with force(cfg):
+            outs = [ops.linear(x, w, b, act=act) for _ in range(4)]       # the slabs / flags of one stream, launch after launch
+    finally:
+        os.environ.pop("AS_GEMM_PP_SK", None)
+    err = float((outs[0].float() - ref).abs().max() / ref.abs().max())
+    assert err < 6e-3, err
+    for o in outs:
+        assert torch.equal(o, whole), float((o.float() - whole.float()).abs().max())
+
+
+def test_stream_k_many_launches_two_streams():
+    """200 launches alternating two shapes on each of two streams that run concurrently: every launch reuses its stream's slabs and
+    flags (the flags are never reset, only compared with the launch's epoch) -- every result bit-identical to the first."""
+    from attentionshift_amd import ops
+    shapes = [(8394, 3072, 768, "gelu"), (8394, 2304, 768, "none")]
+    data = []
+    for (M, N, K, act) in shapes:
+        x, w = rnd(M, K, seed=M + N), rnd(N, K, seed=N + K)
+        b = rnd(N, seed=2, dtype=torch.float32)
+        os.environ["AS_GEMM_PP_SK"] = "0"
+        want = ops.linear(x, w, b, act=act)
+        os.environ.pop("AS_GEMM_PP_SK", None)
+        data.append((x, w, b, act, want))
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    bad = 0
+    for it in range(50):
+        outs = []
+        for si, st in enumerate(streams):
+            with torch.cuda.stream(st):
+                for j in range(2):
+                    x, w, b, act, want = data[(it + si + j) % 2]
+                    outs.append((ops.linear(x, w, b, act=act), want))
+        torch.cuda.synchronize()
+        bad += sum(0 if torch.equal(o, want) else 1 for o, want in outs)
+    assert bad == 0, bad

@@ -3,7 +3,8 @@ and the vendor library, in ONE process with interleaved rounds (cdna_hip_program
 
     python tools/experiments/gemm_pp_bench.py [--rounds 5] [--reps 30] [--lib] [--qkv]            (GPU box)
 
-AS_GEMM_PP is switched per call (AS_GEMM_PP_DYN=1): "0" = gemm.hip, "a" = 256 x 256 tiles, "b" = 256 x 128 tiles.
+AS_GEMM_PP is switched per call (AS_GEMM_PP_DYN=1): "0" = gemm.hip, "a" = 256 x 256 tiles, "b" = 256 x 128 tiles; the digit behind
+the letter is AS_GEMM_PP_SK (0 = whole tiles only, 1 = stream-K tail where the launch has a ragged last round).
 Every variant is checked against an fp32 reference of the same product (max error relative to the output range) on
 uniform [-1, 1) operands; the timing is on the same operands.  One JSON line per (shape, act, variant).
 """
@@ -67,7 +68,7 @@ def main():
 
             def call(v=v, out=out):
                 os.environ["AS_GEMM_PP"] = v[0]
-                os.environ["AS_GEMM_PP_VAR"] = v[1:] or "1"
+                os.environ["AS_GEMM_PP_SK"] = v[1:] or "1"
                 rc = lib.as_linear_fwd(x.data_ptr(), w.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, K, 1, act, st)
                 assert rc == 0, (rc, lib.as_last_error())
             for _ in range(3):
@@ -115,7 +116,7 @@ def main():
 
                 def call(v=v, q=q, k=k, vt=vt):
                     os.environ["AS_GEMM_PP"] = v[0]
-                    os.environ["AS_GEMM_PP_VAR"] = v[1:] or "1"
+                    os.environ["AS_GEMM_PP_SK"] = v[1:] or "1"
                     rc = lib.as_qkv_fwd(x.data_ptr(), w.data_ptr(), b.data_ptr(), q.data_ptr(), k.data_ptr(), vt.data_ptr(), B, N, D, h, 1, st)
                     assert rc == 0, (rc, lib.as_last_error())
                 for _ in range(3):
