@@ -270,6 +270,14 @@ class GradAllReducer:
         missing = [i for i, p in enumerate(self.params) if p.grad is None]
         if self.ranks.world == 1:
             unused = {id(self.params[i]) for i in missing}
+        elif missing and not self.find_unused_parameters and not getattr(self, "_warned_unused", False):
+            # one GPU leaves such gradients None (AdamW skips the parameter); N > 1 without find_unused_parameters writes the
+            # rank-averaged zeros (weight decay and momentum keep running): say so once instead of training differently in silence
+            import warnings
+            self._warned_unused = True
+            warnings.warn(f"GradAllReducer: {len(missing)} parameter(s) received no gradient on rank {self.ranks.rank}; with "
+                          f"world={self.ranks.world} and find_unused_parameters=False they get zero gradients (a one-rank run "
+                          "leaves them None).  Pass find_unused_parameters=True to keep None on every world size.", RuntimeWarning)
         elif self.find_unused_parameters:
             used = torch.ones(len(self.params), dtype=torch.float32)
             used[missing] = 0.0

@@ -9,15 +9,15 @@ mkdir -p gpurun_out
 t0=$(date +%s)
 timeout 600 python bench.py > gpurun_out/${R}_bench_final.json 2> gpurun_out/${R}_bench_final.log
 echo "default bench.py wall: $(( $(date +%s) - t0 )) s" | tee gpurun_out/${R}_bench_wall.txt
-AS_BENCH_EVENTS=0 AS_BENCH_OTHER_RNG=0 AS_BENCH_MIL=0 PROF_LINES=8 tools/prof_cmd.sh ${R}_bench_kernel_stats_final python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --train-steps 0 --other-configs "" > /dev/null 2>&1
+AS_BENCH_EVENTS=0 AS_BENCH_OTHER_RNG=0 AS_BENCH_MIL=0 AS_BENCH_FP32=0 PROF_LINES=8 tools/prof_cmd.sh ${R}_bench_kernel_stats_final python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --train-steps 0 --other-configs "" > /dev/null 2>&1
 timeout 300 python tools/kernel_bench.py --reps 20 > gpurun_out/${R}_kernel_bench.jsonl 2>&1
 bash tools/pmc_call_traffic.sh ${R}_shift_traffic > gpurun_out/${R}_shift_traffic.log 2>&1
 for k in shift_sim shift_assign shift_aggregate shift_final_sim; do
   PMC_TAG=${R}_$k PMC_FILTER=${k}_kernel PMC_CMD="python $GRAFT_REPO_ROOT/tools/kernel_bench.py --reps 6 --only shift" bash tools/pmc_sdpa_impl.sh auto > /dev/null 2>&1
 done
 PMC_TAG=${R}_rollout_step4 PMC_FILTER=rollout_step4 PMC_CMD="python $GRAFT_REPO_ROOT/tools/kernel_bench.py --reps 8 --only rollout" bash tools/pmc_sdpa_impl.sh auto > /dev/null 2>&1
-PMC_TRAFFIC=1 PMC_TAG=${R}_gemm_fc1 PMC_FILTER=gemm_glds PMC_CMD="python $GRAFT_REPO_ROOT/tools/experiments/gemm_variant_bench.py _one --variants base --shapes 8394x3072x768" bash tools/pmc_sdpa_impl.sh auto > /dev/null 2>&1
-PMC_TRAFFIC=1 PMC_TAG=${R}_gemm_fc2 PMC_FILTER=gemm_glds PMC_CMD="python $GRAFT_REPO_ROOT/tools/experiments/gemm_variant_bench.py _one --variants base --shapes 8394x768x3072" bash tools/pmc_sdpa_impl.sh auto > /dev/null 2>&1
+PMC_TRAFFIC=1 PMC_TAG=${R}_gemm_fc1 PMC_FILTER=gemm_pp PMC_CMD="python $GRAFT_REPO_ROOT/tools/experiments/gemm_variant_bench.py _one --variants base --shapes 8394x3072x768" bash tools/pmc_sdpa_impl.sh auto > /dev/null 2>&1
+PMC_TRAFFIC=1 PMC_TAG=${R}_gemm_fc2 PMC_FILTER=gemm_pp PMC_CMD="python $GRAFT_REPO_ROOT/tools/experiments/gemm_variant_bench.py _one --variants base --shapes 8394x768x3072" bash tools/pmc_sdpa_impl.sh auto > /dev/null 2>&1
 PROF_LINES=8 tools/prof_cmd.sh ${R}_train_step_kernel_stats python $GRAFT_REPO_ROOT/tools/experiments/train_steps.py 6 > /dev/null 2>&1
 timeout 300 python tools/experiments/train_phases.py 8 2>&1 | tail -9 > gpurun_out/${R}_train_phases.txt
 timeout 300 python tools/experiments/train_syncs.py 2>&1 | tail -8 > gpurun_out/${R}_train_syncs.txt
