@@ -596,7 +596,7 @@ def main():
                       "'launch' = the whole call",
             "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ach / PEAK_BF16_TFLOPS, 4),
-            "traffic": _static_traffic(("r05_sdpa_traffic.json", "r04_sdpa_traffic.json", "r03_sdpa_traffic.json"), "per_as_sdpa_fwd_call_bytes") if headline else None,
+            "traffic": _static_traffic(("r06_sdpa_traffic.json", "r05_sdpa_traffic.json", "r04_sdpa_traffic.json", "r03_sdpa_traffic.json"), "per_as_sdpa_fwd_call_bytes") if headline else None,
             "launches_timed": n_sdpa, "ms_per_launch": round(ms_sdpa, 4), "flops_per_launch": flops_sdpa}
         if all(k in block_timing for k in ("qkv_gemm", "sdpa_fwd", "proj_gemm")):
             D_ = CFG["embed_dim"]
@@ -633,7 +633,7 @@ def main():
             "kernel": "as_cosine_shift (per iteration: similarity / assign / aggregate launches; packed final similarity)",
             "bound": "hbm", "achieved": round(gbps, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
             "frac": round(gbps / PEAK_HBM_GBPS, 4),
-            "traffic": _static_traffic(("r05_shift_traffic.json", "r04_shift_traffic.json", "r03_shift_traffic.json"), "per_call_bytes") if headline and imgs_per_call == 2 else None,
+            "traffic": _static_traffic(("r06_shift_traffic.json", "r05_shift_traffic.json", "r04_shift_traffic.json", "r03_shift_traffic.json"), "per_call_bytes") if headline and imgs_per_call == 2 else None,
             "calls_timed": n_cs, "images_per_call": imgs_per_call, "ms_per_call": round(ms_cs, 4),
             "algorithmic_bytes_per_call": bytes_cs,
             "timeline": "profiles/r05_shift_timeline.md (s_memrealtime stamps inside the three iteration kernels: where each "
@@ -654,7 +654,7 @@ def main():
             ra["frac_counter_bytes"] = round(cb / (ms_cs * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4)
             ra["counter_over_algorithmic"] = round(cb / bytes_cs, 3)
         try:      # the dependent-chain floor of 16 launches of this grid size (tools/experiments/chain_floor.hip, this round)
-            cf_name = next(n for n in ("r05_chain_floor.json", "r04_chain_floor.json") if os.path.exists(os.path.join(ROOT, "profiles", n)))
+            cf_name = next(n for n in ("r06_chain_floor.json", "r05_chain_floor.json", "r04_chain_floor.json") if os.path.exists(os.path.join(ROOT, "profiles", n)))
             with open(os.path.join(ROOT, "profiles", cf_name)) as f:
                 cf = json.load(f)
             ra["dependent_chain_floor"] = {

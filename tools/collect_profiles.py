@@ -41,3 +41,22 @@ if os.path.exists(kb):
             f.write(f"| `{r['kernel']}` | {r['ms']} | {rate} | {r.get('frac', '')} | {r.get('note', '')} |\n")
     copied.append(f"{R}_kernel_bench.md")
 print("\n".join(copied))
+
+# the SDPA launch's HBM bytes as bench.py reads them (roofline.traffic): from the round's PMC summary of the shipped kernel
+pmc = os.path.join(dst, f"{R}_sdpa_pmc.md")
+if os.path.exists(pmc):
+    import re
+    txt = open(pmc).read()
+    rd = re.search(r"hbm_read_bytes_corrected = .*? = ([\d.e+]+) B", txt)
+    fs = re.search(r"\| FETCH_SIZE \| ([\d.e+]+) \|", txt)
+    ws = re.search(r"\| WRITE_SIZE \| ([\d.e+]+) \|", txt)
+    if fs and ws:
+        read_b, write_b = float(fs.group(1)) * 1024 * 2, float(ws.group(1)) * 1024
+        with open(os.path.join(dst, f"{R}_sdpa_traffic.json"), "w") as f:
+            json.dump({"source": f"profiles/{R}_sdpa_pmc.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, kernel-trace only; "
+                                 "FETCH_SIZE doubled per MI355X_MICROARCH.md, WRITE_SIZE uncalibrated)",
+                       "note": f"round {R[1:].lstrip('0')}, shipped kernel sdpa_fwd_pipe_kernel<2,0,1,8> (512-row workgroups of eight waves), unchanged since round 4",
+                       "shape": "B=2 h=12 N=4197 bf16, one launch per as_sdpa_fwd call",
+                       "hbm_read_bytes": read_b, "hbm_write_bytes": write_b, "per_as_sdpa_fwd_call_bytes": read_b + write_b,
+                       "algorithmic_bytes": 53700000.0}, f, indent=1)
+        print(f"{R}_sdpa_traffic.json")
