@@ -14,16 +14,19 @@ for line in open(os.path.join(P, f"{R}_kernel_bench.md")):
     m = re.match(r"\| `(.*?)` \| ([\d.]+) \| ([\d.]*) \| ([\d.]*) \|", line)
     if m:
         kb[m.group(1)] = (float(m.group(2)), m.group(3), m.group(4))
-ab = [l.split() for l in open(os.path.join(P, f"{R}_ab_vs_r04.txt")) if l.startswith(("r04 ", "r05 "))]
+ab_path = os.path.join(P, f"{R}_ab_vs_r04.txt")                   # (the same-box A/B against an older tree: round 5 only)
+ab = [l.split() for l in open(ab_path) if l.startswith(("r04 ", "r05 "))] if os.path.exists(ab_path) else []
 old = [float(x[1]) for x in ab if x[0] == "r04"]
 new = [float(x[1]) for x in ab if x[0] == "r05"]
+ab_text = (f"same box, alternating runs against the round-4 tree: {min(old):.1f}–{max(old):.1f} → **{min(new):.1f}–{max(new):.1f}** "
+           f"(`profiles/{R}_ab_vs_r04.txt`); ") if old and new else ""
 ro, blk, aff, tr = rec["roofline"], rec.get("roofline_attention_block", {}), rec["roofline_affinity"], rec.get("train", {})
 oc = rec.get("other_configs", {})
 cpu = rec.get("cpu_baseline", {})
 rows = [
     ("hot path, BASELINE config 2 (ViT-B, 1024², 2 images/GPU, 3 objects), `python bench.py`",
-     f"**{rec['value']:.1f} images/s** ({rec['ms_per_step']:.3f} ms/step); same box, alternating runs against the round-4 tree: "
-     f"{min(old):.1f}–{max(old):.1f} → **{min(new):.1f}–{max(new):.1f}** (`profiles/{R}_ab_vs_r04.txt`); "
+     f"**{rec['value']:.1f} images/s** ({rec['ms_per_step']:.3f} ms/step); " + ab_text +
+     f"{rec.get('images_per_sec_fp32_parity_path', float('nan'))} with `compute_dtype=float32` (the 1e-3 parity path); "
      f"{rec.get('images_per_sec_reference_rng', float('nan')):.1f} with the reference's literal RNG stream, "
      f"{rec.get('images_per_sec_mil_selector', float('nan')):.1f} with the MIL head choosing the roll-out depth"),
     ("config 4 (ViT-L, 1280², 1 image, 7 objects) / config 5 (Swin-B backbone, 1024², 2 images): legs of the default run",
