@@ -273,6 +273,9 @@ __device__ __forceinline__ void lds_wait8(u32x2 (&v)[8]) {
 #define AS_SDPA_PRIO 0            // experiments with static s_setprio (tools/experiments/sdpa_impl_bench.py)
 #endif
 #ifndef AS_SDPA_SGB
+#ifndef AS_SDPA_WIDE_STORE
+#define AS_SDPA_WIDE_STORE 1     // 16-byte O stores through v_permlane32_swap pairs (0: 8-byte stores per half-wave)
+#endif
 #define AS_SDPA_SGB 1             // sched_group_barrier interleave of sdpa_fwd_pipe_kernel's reference-free step
 #endif
 #ifndef AS_SDPA_NO_DEAD_SKIP
@@ -1064,6 +1067,35 @@ __global__ __launch_bounds__(64 * NW, NQ == 1 ? 3 : 2) void sdpa_fwd_pipe_kernel
     for (int qb = 0; qb < NQ; ++qb) {
       const float l = l_row[qb];
       const float inv = 1.0f / l;
+#if AS_SDPA_WIDE_STORE
+      // A query's row is split across the half-waves (lane i: columns 8k .. 8k+3, lane i + 32: 8k+4 .. 8k+7 of column group k):
+      // one v_permlane32_swap per dword and PAIR of groups leaves lanes 0-31 with the 16 contiguous bytes of group k and lanes
+      // 32-63 with those of group k + 1 -- 8 16-byte stores per row instead of 16 8-byte ones, same bytes, same addresses
+      // (cdna_hip_programming.md T21: the tail is store-ISSUE-bound).  Every lane takes part in the swaps; rows >= N skip the store.
+      uint2 o2[8];
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const bf16x4 v = {(__bf16)(oacc[qb][db][4 * g] * inv), (__bf16)(oacc[qb][db][4 * g + 1] * inv),
+                            (__bf16)(oacc[qb][db][4 * g + 2] * inv), (__bf16)(oacc[qb][db][4 * g + 3] * inv)};
+          o2[db * 4 + g] = __builtin_bit_cast(uint2, v);
+        }
+#pragma unroll
+      for (int k = 0; k < 8; k += 2) {
+        auto rx = __builtin_amdgcn_permlane32_swap(o2[k].x, o2[k + 1].x, false, false);
+        auto ry = __builtin_amdgcn_permlane32_swap(o2[k].y, o2[k + 1].y, false, false);
+        o2[k].x = rx[0]; o2[k + 1].x = rx[1];
+        o2[k].y = ry[0]; o2[k + 1].y = ry[1];
+      }
+      if (query[qb] < N) {
+        __bf16* orow = o + ((size_t)b * N + query[qb]) * ((size_t)h * HD) + head * HD + 8 * half;
+#pragma unroll
+        for (int k = 0; k < 8; k += 2)
+          *reinterpret_cast<uint4*>(orow + 8 * k) = make_uint4(o2[k].x, o2[k].y, o2[k + 1].x, o2[k + 1].y);
+        if (half == 0) lse[(size_t)bh * N + query[qb]] = m_run[qb] * AS_LN2 + logf(l);
+      }
+#else
       if (query[qb] < N) {
         __bf16* orow = o + ((size_t)b * N + query[qb]) * ((size_t)h * HD) + head * HD;
 #pragma unroll
@@ -1076,6 +1108,7 @@ __global__ __launch_bounds__(64 * NW, NQ == 1 ? 3 : 2) void sdpa_fwd_pipe_kernel
           }
         if (half == 0) lse[(size_t)bh * N + query[qb]] = m_run[qb] * AS_LN2 + logf(l);
       }
+#endif
     }
   };
 
