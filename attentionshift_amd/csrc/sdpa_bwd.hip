@@ -42,6 +42,33 @@ __device__ __forceinline__ void st4(__bf16* p, float a, float b, float c, float 
   bf16x4 v = {(__bf16)a, (__bf16)b, (__bf16)c, (__bf16)d};
   *reinterpret_cast<bf16x4*>(p) = v;
 }
+// (cdna_hip_programming.md T21) A 64-column bf16 row held as acc[2][16] (lane: columns db * 32 + 8 g + 4 * half + r of ITS row,
+// both half-waves on the same row): one v_permlane32_swap per dword and pair of column groups leaves lanes 0-31 with the 16
+// contiguous bytes of group k and lanes 32-63 with those of group k + 1 -- eight 16-byte stores instead of sixteen 8-byte ones,
+// same bytes, same addresses.  Every lane of the wave must call it; `valid` gates the stores only.
+__device__ __forceinline__ void store_row64_wide(__bf16* row, const f32x16 (&acc)[2], float scale, int half, bool valid) {
+  uint2 o2[8];
+#pragma unroll
+  for (int db = 0; db < 2; ++db)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const bf16x4 v = {(__bf16)(acc[db][4 * g] * scale), (__bf16)(acc[db][4 * g + 1] * scale), (__bf16)(acc[db][4 * g + 2] * scale),
+                        (__bf16)(acc[db][4 * g + 3] * scale)};
+      o2[db * 4 + g] = __builtin_bit_cast(uint2, v);
+    }
+#pragma unroll
+  for (int k = 0; k < 8; k += 2) {
+    auto rx = __builtin_amdgcn_permlane32_swap(o2[k].x, o2[k + 1].x, false, false);
+    auto ry = __builtin_amdgcn_permlane32_swap(o2[k].y, o2[k + 1].y, false, false);
+    o2[k].x = rx[0]; o2[k + 1].x = rx[1];
+    o2[k].y = ry[0]; o2[k + 1].y = ry[1];
+  }
+  if (valid) {
+#pragma unroll
+    for (int k = 0; k < 8; k += 2)
+      *reinterpret_cast<uint4*>(row + 8 * k + 8 * half) = make_uint4(o2[k].x, o2[k].y, o2[k + 1].x, o2[k + 1].y);
+  }
+}
 __device__ __forceinline__ void st4(float* p, float a, float b, float c, float d) {
   *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
 }
@@ -1203,19 +1230,13 @@ __global__ __launch_bounds__(BW_NT, 2) void sdpa_bwd_dkv_tr_kernel(const __bf16*
     });
   }
 
-  if (key < N) {
+  {
     const int D = h * BW_HD;
-    T* row = dqkv + ((size_t)b * N + key) * (size_t)(3 * D) + head * BW_HD;
-#pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int d = db * 32 + 8 * g + 4 * half;
-        // dK = dS^T q / 8 with the STORED q' = q log2(e) / 8: dS^T q' ln 2
-        st4(row + D + d, dkacc[db][4 * g] * AS_LN2, dkacc[db][4 * g + 1] * AS_LN2, dkacc[db][4 * g + 2] * AS_LN2,
-            dkacc[db][4 * g + 3] * AS_LN2);
-        st4(row + 2 * D + d, dvacc[db][4 * g], dvacc[db][4 * g + 1], dvacc[db][4 * g + 2], dvacc[db][4 * g + 3]);
-      }
+    const int keyc = min(key, N - 1);
+    T* row = dqkv + ((size_t)b * N + keyc) * (size_t)(3 * D) + head * BW_HD;
+    // dK = dS^T q / 8 with the STORED q' = q log2(e) / 8: dS^T q' ln 2
+    store_row64_wide(row + D, dkacc, AS_LN2, half, key < N);
+    store_row64_wide(row + 2 * D, dvacc, 1.0f, half, key < N);
   }
 }
 
@@ -1345,14 +1366,9 @@ __global__ __launch_bounds__(BW_NT, 2) void sdpa_bwd_dq_tr_kernel(const __bf16* 
     });
   }
 
-  if (query < N) {
-    T* row = dqkv + ((size_t)b * N + query) * (size_t)(3 * h * BW_HD) + head * BW_HD;       // q slot of [3,h,64]
-#pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-      for (int g = 0; g < 4; ++g)
-        st4(row + db * 32 + 8 * g + 4 * half, dqacc[db][4 * g] * 0.125f, dqacc[db][4 * g + 1] * 0.125f,
-            dqacc[db][4 * g + 2] * 0.125f, dqacc[db][4 * g + 3] * 0.125f);
+  {
+    T* row = dqkv + ((size_t)b * N + min(query, N - 1)) * (size_t)(3 * h * BW_HD) + head * BW_HD;       // q slot of [3,h,64]
+    store_row64_wide(row, dqacc, 0.125f, half, query < N);
   }
 }
 
