@@ -273,6 +273,9 @@ __device__ __forceinline__ void lds_wait8(u32x2 (&v)[8]) {
 #define AS_SDPA_PRIO 0            // experiments with static s_setprio (tools/experiments/sdpa_impl_bench.py)
 #endif
 #ifndef AS_SDPA_SGB
+#ifndef AS_SDPA_LATE_QPIN
+#define AS_SDPA_LATE_QPIN 1       // wait for the Q fragments behind the first K / V^T tiles' DMA, not in front of it
+#endif
 #ifndef AS_SDPA_WIDE_STORE
 #define AS_SDPA_WIDE_STORE 1     // 16-byte O stores through v_permlane32_swap pairs (0: 8-byte stores per half-wave)
 #endif
@@ -680,7 +683,9 @@ __global__ __launch_bounds__(64 * NW, NQ == 1 ? 3 : 2) void sdpa_fwd_pipe_kernel
 #pragma unroll
     for (int qb = 0; qb < NQ; ++qb) asm volatile("; Q fragments landed" : "+v"(fq[qb][0]), "+v"(fq[qb][1]), "+v"(fq[qb][2]), "+v"(fq[qb][3]));
   };
+#if !AS_SDPA_LATE_QPIN
   if (!SK) pin_q();
+#endif
 
   auto ring_barrier = [&]() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -758,6 +763,13 @@ __global__ __launch_bounds__(64 * NW, NQ == 1 ? 3 : 2) void sdpa_fwd_pipe_kernel
     stage(0);
     if (nkt > 1) stage(1);
     if (NBUF == 4 && nkt > 2) stage(2);
+#if AS_SDPA_LATE_QPIN
+    // the Q fragments (ordinary loads, issued at the top of the kernel) are waited for HERE, behind the first tiles' LDS-DMA:
+    // the two round trips overlap instead of following each other (the wait belongs in front of the first consumer, T20
+    // follow-on).  hipcc counts only its own loads, so its wait is vmcnt(0): it covers the tiles just staged as well -- they
+    // were issued back to back and land together
+    if (!SK) pin_q();
+#endif
     // the slot "before tile 0" feeds the first step's (all-zero) P.V product: its V^T half must hold finite numbers
     {
       const uint4 z = make_uint4(0, 0, 0, 0);
