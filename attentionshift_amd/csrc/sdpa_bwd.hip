@@ -1116,9 +1116,7 @@ __global__ __launch_bounds__(BW_NT, 2) void sdpa_bwd_dkv_tr_kernel(const __bf16*
     fk[ks].load16B(k + ((size_t)bh * Npad + kc) * BW_HD + ks * 16 + half * 8);
     fv[ks].load16B(vrow + ((size_t)bh * Npad + kc) * BW_HD + ks * 16 + half * 8);
   }
-  // the ordinary loads are complete before the first LDS-DMA is issued (hipcc does not count the asm DMAs in vmcnt)
-  asm volatile("s_waitcnt vmcnt(0)" : "+v"(fk[0].v), "+v"(fk[1].v), "+v"(fk[2].v), "+v"(fk[3].v), "+v"(fv[0].v), "+v"(fv[1].v),
-               "+v"(fv[2].v), "+v"(fv[3].v));
+  // (these ordinary loads are waited for BEHIND the first tiles' LDS-DMA below: one round trip instead of two)
 
   const unsigned smem_u = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)smem;
   const char* q_b = reinterpret_cast<const char*>(qr + (size_t)bh * Npad * BW_HD);
@@ -1146,6 +1144,11 @@ __global__ __launch_bounds__(BW_NT, 2) void sdpa_bwd_dkv_tr_kernel(const __bf16*
 #pragma unroll
   for (int p_ = 0; p_ < NST - 1; ++p_)
     if (p_ < nqt) stage(p_, p_);
+  // the K / V fragments (ordinary loads issued at the top) and the tiles just staged land together; hipcc does not count the asm
+  // DMAs, so its wait for the fragments must be complete HERE, before the loop's counted waits (the loads are older than every
+  // DMA and retire first, but a compiler-placed vmcnt(0) at their first use inside the loop would drain the ring every tile)
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(fk[0].v), "+v"(fk[1].v), "+v"(fk[2].v), "+v"(fk[3].v), "+v"(fv[0].v), "+v"(fv[1].v),
+               "+v"(fv[2].v), "+v"(fv[3].v));
   // the ring slot is a compile-time constant inside the body (NST tiles per trip): every LDS address is a loop-invariant
   // lane offset + an immediate
   for (int t0 = 0; t0 < nqt; t0 += NST) {
@@ -1263,12 +1266,7 @@ __global__ __launch_bounds__(BW_NT, 2) void sdpa_bwd_dq_tr_kernel(const __bf16* 
   }
   float nl2 = -lse[(size_t)bh * N + qc] * AS_LOG2E;
   float ndl = ndelta[(size_t)bh * Npad + qc];
-  asm volatile("s_waitcnt vmcnt(0)" : "+v"(fq[0].v), "+v"(fq[1].v), "+v"(fq[2].v), "+v"(fq[3].v), "+v"(fdo[0].v), "+v"(fdo[1].v),
-               "+v"(fdo[2].v), "+v"(fdo[3].v), "+v"(nl2), "+v"(ndl));
-  // my query's statistics as C operands of the first score MFMAs (every accumulator register belongs to my query)
-  f32x16 c_l, c_d;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) { c_l[r] = nl2; c_d[r] = ndl; }
+  // (waited for behind the first tiles' LDS-DMA below: one round trip instead of two)
 
   const unsigned smem_u = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)smem;
   const char* k_b = reinterpret_cast<const char*>(kr + (size_t)bh * Npad * BW_HD);
@@ -1292,6 +1290,12 @@ __global__ __launch_bounds__(BW_NT, 2) void sdpa_bwd_dq_tr_kernel(const __bf16* 
 #pragma unroll
   for (int p_ = 0; p_ < NST - 1; ++p_)
     if (p_ < nkt) stage(p_, p_);
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(fq[0].v), "+v"(fq[1].v), "+v"(fq[2].v), "+v"(fq[3].v), "+v"(fdo[0].v), "+v"(fdo[1].v),
+               "+v"(fdo[2].v), "+v"(fdo[3].v), "+v"(nl2), "+v"(ndl));
+  // my query's statistics as C operands of the first score MFMAs (every accumulator register belongs to my query)
+  f32x16 c_l, c_d;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { c_l[r] = nl2; c_d[r] = ndl; }
   for (int t0 = 0; t0 < nkt; t0 += NST) {
     t3_static_for<NST>([&](auto slot_c) {
     constexpr int SLOT = decltype(slot_c)::value;
